@@ -1,0 +1,139 @@
+"""Pins the CPU oracle (oracle/grb_oracle.c) against every known-answer literal the reference's own
+tests/docs hold for mxm / mxv / vxm (tests/golden/reference_literals.json), and cross-checks it
+against the independent dense brute-force evaluator (oracle/dense_eval.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import dense_eval as D
+from oracle import grb_oracle as O
+from tests.helpers import o_obj, oracle_case, same
+
+_G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_literals.json")))
+
+
+@pytest.mark.parametrize("case", _G["cases"], ids=[c["name"] for c in _G["cases"]])
+def test_reference_literal(case):
+    got = oracle_case(case, _G["inputs"])
+    if "expect_shape" in case:
+        assert [got.nrows, got.ncols] == case["expect_shape"]
+    else:
+        same(got, case["expect"])
+
+
+def test_primer_sssp():
+    s = _G["sssp"]
+    G = o_obj(_G["inputs"][s["G"]])
+    v = o_obj(s["start"])
+    for _ in range(10):
+        w = O.vxm(v, G, "min_plus", w=v, accum="min")
+        if w.idx.tolist() == v.idx.tolist() and w.vals.tolist() == v.vals.tolist():
+            break
+        v = w
+    same(v, s["expect"])
+
+
+def _rand_dense(rng, shape, density, tname):
+    has = rng.random(shape) < density
+    np_t = O.NP_OF[tname]
+    if tname == "BOOL":
+        val = rng.random(shape) < 0.6
+    elif tname.startswith("FP"):
+        val = rng.integers(-8, 9, shape).astype(np_t)  # exact in fp => order independent
+    elif tname.startswith("U"):
+        val = rng.integers(0, np.iinfo(np_t).max, shape, dtype=np.uint64).astype(np_t)
+    else:
+        info = np.iinfo(np_t)
+        val = rng.integers(info.min, info.max, shape, dtype=np.int64).astype(np_t)
+    val = np.where(has, val, 0).astype(np_t)
+    return val, has
+
+
+def _omat(val, has, tname):
+    r, c = np.nonzero(has)
+    return O.OMat.from_coo(r, c, val[r, c], has.shape[0], has.shape[1], tname)
+
+
+def _ovec(val, has, tname):
+    (i,) = np.nonzero(has)
+    return O.OVec(len(has), i, val[i], tname)
+
+
+SEMIRINGS = ["plus_times", "min_plus", "lor_land", "any_pair", "max_plus", "plus_plus", "min_second",
+             "max_first", "plus_pair", "min_max", "lxor_land", "land_lor"]
+
+
+@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("semiring", SEMIRINGS)
+def test_oracle_vs_dense_bruteforce(semiring, seed):
+    rng = np.random.default_rng(1000 * seed + hash(semiring) % 997)
+    monoid, mult = semiring.split("_", 1)
+    boolish = monoid in ("lor", "land", "lxor", "lxnor")
+    tname = "BOOL" if boolish else ["INT64", "INT8", "FP64", "UINT16", "FP32", "INT32"][seed]
+    if semiring == "any_pair":
+        tname = ["BOOL", "INT64", "FP32", "UINT8", "INT16", "FP64"][seed]
+    np_t = O.NP_OF[tname]
+    m, k, n = rng.integers(1, 9, 3)
+    Av, Ah = _rand_dense(rng, (m, k), 0.5, tname)
+    Bv, Bh = _rand_dense(rng, (k, n), 0.5, tname)
+    Cv, Ch = _rand_dense(rng, (m, n), 0.4, tname)
+    Mv, Mh = _rand_dense(rng, (m, n), 0.6, "INT8")
+    comp, struct, replace = (bool(x) for x in rng.integers(0, 2, 3))
+    use_mask = bool(rng.integers(0, 3))
+    accum = [None, "plus", "min", "second", "first", "max"][rng.integers(0, 6)]
+    # --- mxm
+    Tv, Th = D.matmul(Av, Ah, Bv, Bh, monoid, mult, np_t)
+    Nv, Nh = D.write(Cv, Ch, Tv, Th, Mv if use_mask else None, Mh if use_mask else None, comp=comp,
+                     struct=struct, accum=accum, replace=replace and use_mask, np_t=np_t)
+    got = O.mxm(_omat(Av, Ah, tname), _omat(Bv, Bh, tname), semiring, C=_omat(Cv, Ch, tname),
+                mask=_omat(Mv, Mh, "INT8") if use_mask else None, mask_comp=comp and use_mask,
+                mask_struct=struct, accum=accum, replace=replace and use_mask)
+    exp = _omat(Nv, Nh, tname)
+    assert got.indptr.tolist() == exp.indptr.tolist() and got.indices.tolist() == exp.indices.tolist()
+    assert got.values.tolist() == exp.values.tolist()
+    # --- mxv / vxm on column 0 / row 0
+    uv, uh = Bv[:, 0], Bh[:, 0]
+    Tv1, Th1 = D.matmul(Av, Ah, uv[:, None], uh[:, None], monoid, mult, np_t)
+    wv, wh = Cv[:, 0], Ch[:, 0]
+    mv, mh = Mv[:, 0], Mh[:, 0]
+    Nv1, Nh1 = D.write(wv, wh, Tv1[:, 0], Th1[:, 0], mv if use_mask else None, mh if use_mask else None,
+                       comp=comp, struct=struct, accum=accum, replace=replace and use_mask, np_t=np_t)
+    got = O.mxv(_omat(Av, Ah, tname), _ovec(uv, uh, tname), semiring, w=_ovec(wv, wh, tname),
+                mask=_ovec(mv, mh, "INT8") if use_mask else None, mask_comp=comp and use_mask,
+                mask_struct=struct, accum=accum, replace=replace and use_mask)
+    exp = _ovec(Nv1, Nh1, tname)
+    assert got.idx.tolist() == exp.idx.tolist() and got.vals.tolist() == exp.vals.tolist()
+    # vxm(u, A') must equal mxv(A, u) when mult is commutative; with first/second swapped otherwise
+    if mult not in ("first", "second"):
+        got2 = O.vxm(_ovec(uv, uh, tname), _omat(Av, Ah, tname), semiring, transpose_b=True,
+                     w=_ovec(wv, wh, tname), mask=_ovec(mv, mh, "INT8") if use_mask else None,
+                     mask_comp=comp and use_mask, mask_struct=struct, accum=accum, replace=replace and use_mask)
+        assert got2.idx.tolist() == exp.idx.tolist() and got2.vals.tolist() == exp.vals.tolist()
+    # row vector times matrix: u' B
+    rv, rh = Av[0, :], Ah[0, :]
+    Tv2, Th2 = D.matmul(rv[None, :], rh[None, :], Bv, Bh, monoid, mult, np_t)
+    got3 = O.vxm(_ovec(rv, rh, tname), _omat(Bv, Bh, tname), semiring)
+    exp3 = _ovec(Tv2[0], Th2[0], tname)
+    assert got3.idx.tolist() == exp3.idx.tolist() and got3.vals.tolist() == exp3.vals.tolist()
+
+
+def test_scipy_crosscheck_plus_times():
+    sp = pytest.importorskip("scipy.sparse")
+    rng = np.random.default_rng(7)
+    A = sp.random(200, 150, 0.05, format="csr", random_state=rng, data_rvs=lambda n: rng.integers(1, 9, n).astype(float))
+    B = sp.random(150, 120, 0.05, format="csr", random_state=rng, data_rvs=lambda n: rng.integers(1, 9, n).astype(float))
+    A.sort_indices(); B.sort_indices()
+    oa = O.OMat(200, 150, A.indptr, A.indices, A.data, "FP64")
+    ob = O.OMat(150, 120, B.indptr, B.indices, B.data, "FP64")
+    C = (A @ B).tocsr(); C.sort_indices()
+    got = O.mxm(oa, ob, "plus_times")
+    assert got.indptr.tolist() == C.indptr.tolist() and got.indices.tolist() == C.indices.tolist()
+    np.testing.assert_allclose(got.values, C.data, rtol=1e-12)
+    x = rng.integers(1, 5, 150).astype(float)
+    y = O.mxv(oa, O.OVec(150, np.arange(150), x, "FP64"), "plus_times")
+    ref = A @ x
+    nz = np.diff(A.indptr) > 0
+    assert y.idx.tolist() == np.flatnonzero(nz).tolist()
+    np.testing.assert_allclose(y.vals, ref[nz], rtol=1e-12)
