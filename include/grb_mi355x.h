@@ -1,0 +1,234 @@
+/* grb_mi355x.h -- C-ABI of libgrb_mi355x.so: the GraphBLAS C API 2.0 entry points that
+ * python-graphblas dispatches to on its mxm / mxv / vxm hot path, implemented with hand-written
+ * gfx950 (MI355X / CDNA4) HIP kernels.  Plain C: opaque handles, plain pointers and sizes.
+ *
+ * What each group replaces in the reference (paths relative to /root/reference):
+ *   - every function below is reached through graphblas/core/base.py:23-54 `call(cfunc_name, args)`
+ *     (symbol lookup graphblas/core/utils.py:11-23) on the cffi `lib` bound at
+ *     graphblas/__init__.py:143-199; return codes are mapped by graphblas/exceptions.py:123-189.
+ *   - GrB_mxv  <- graphblas/core/matrix.py:2252-2259  ("GrB_mxv", args marshalled base.py:496-501)
+ *   - GrB_mxm  <- graphblas/core/matrix.py:2318-2328  ("GrB_mxm")
+ *   - GrB_vxm  <- graphblas/core/vector.py:1367-1375  ("GrB_vxm")
+ *   - GrB_Matrix_new/free/nvals/... <- graphblas/core/matrix.py:190-225, 493; Vector twins core/vector.py:159-191
+ *   - GrB_Matrix_build_T <- core/matrix.py:627-681; GrB_Matrix_import_T/export_T <- :992-1068, :1601-1645
+ *   - GrB_Matrix_extractTuples_T <- core/matrix.py:525-594
+ *   - GrB_DESC_* globals <- core/descriptor.py:51-84; GrB_<TYPE> globals <- core/dtypes.py:329-420
+ *   - semiring / monoid / binaryop globals are discovered by regex over dir(lib):
+ *     core/operator/base.py:803-893, core/operator/semiring.py:185-219
+ *   - GrB_*_error <- exceptions.py:171-189
+ *
+ * GrX_* functions are this library's own extensions (device-resident import/export, stream and
+ * timing hooks); the reference has no counterpart (its GxB zero-copy import is core/ss/matrix.py:1279-1349).
+ */
+#ifndef GRB_MI355X_H
+#define GRB_MI355X_H
+
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GRB_VERSION 2
+#define GRB_SUBVERSION 0
+
+typedef uint64_t GrB_Index;
+#define GrB_INDEX_MAX ((GrB_Index)(1ULL << 60) - 1)
+
+/* GraphBLAS C API 2.0 return codes (spec values) */
+typedef enum {
+    GrB_SUCCESS = 0,
+    GrB_NO_VALUE = 1,
+    GrB_UNINITIALIZED_OBJECT = -1,
+    GrB_NULL_POINTER = -2,
+    GrB_INVALID_VALUE = -3,
+    GrB_INVALID_INDEX = -4,
+    GrB_DOMAIN_MISMATCH = -5,
+    GrB_DIMENSION_MISMATCH = -6,
+    GrB_OUTPUT_NOT_EMPTY = -7,
+    GrB_NOT_IMPLEMENTED = -8,
+    GrB_PANIC = -101,
+    GrB_OUT_OF_MEMORY = -102,
+    GrB_INSUFFICIENT_SPACE = -103,
+    GrB_INVALID_OBJECT = -104,
+    GrB_INDEX_OUT_OF_BOUNDS = -105,
+    GrB_EMPTY_OBJECT = -106
+} GrB_Info;
+
+typedef enum { GrB_NONBLOCKING = 0, GrB_BLOCKING = 1 } GrB_Mode;
+typedef enum { GrB_COMPLETE = 0, GrB_MATERIALIZE = 1 } GrB_WaitMode;
+typedef enum { GrB_OUTP = 0, GrB_MASK = 1, GrB_INP0 = 2, GrB_INP1 = 3 } GrB_Desc_Field;
+typedef enum { GrB_DEFAULT = 0, GrB_REPLACE = 1, GrB_COMP = 2, GrB_TRAN = 3, GrB_STRUCTURE = 4 } GrB_Desc_Value;
+typedef enum { GrB_CSR_FORMAT = 0, GrB_CSC_FORMAT = 1, GrB_COO_FORMAT = 2 } GrB_Format;
+
+typedef struct GB_Type_opaque *GrB_Type;
+typedef struct GB_BinaryOp_opaque *GrB_BinaryOp;
+typedef struct GB_Monoid_opaque *GrB_Monoid;
+typedef struct GB_Semiring_opaque *GrB_Semiring;
+typedef struct GB_Descriptor_opaque *GrB_Descriptor;
+typedef struct GB_Vector_opaque *GrB_Vector;
+typedef struct GB_Matrix_opaque *GrB_Matrix;
+
+/* GrB_ALL: the reference only compares this pointer (core/expr.py:14) */
+extern const uint64_t *GrB_ALL;
+
+/* ---- context ------------------------------------------------------------------------------ */
+GrB_Info GrB_init(GrB_Mode mode);      /* requires a gfx950 device: GrB_PANIC otherwise (no CPU fallback) */
+GrB_Info GrB_finalize(void);
+GrB_Info GrB_getVersion(unsigned int *version, unsigned int *subversion);
+
+/* ---- the hot path ------------------------------------------------------------------------- */
+GrB_Info GrB_mxm(GrB_Matrix C, const GrB_Matrix Mask, const GrB_BinaryOp accum, const GrB_Semiring semiring,
+                 const GrB_Matrix A, const GrB_Matrix B, const GrB_Descriptor desc);
+GrB_Info GrB_mxv(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_Semiring semiring,
+                 const GrB_Matrix A, const GrB_Vector u, const GrB_Descriptor desc);
+GrB_Info GrB_vxm(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_Semiring semiring,
+                 const GrB_Vector u, const GrB_Matrix A, const GrB_Descriptor desc);
+
+/* ---- Matrix ------------------------------------------------------------------------------- */
+GrB_Info GrB_Matrix_new(GrB_Matrix *A, GrB_Type type, GrB_Index nrows, GrB_Index ncols);
+GrB_Info GrB_Matrix_dup(GrB_Matrix *C, const GrB_Matrix A);
+GrB_Info GrB_Matrix_free(GrB_Matrix *A);
+GrB_Info GrB_Matrix_clear(GrB_Matrix A);
+GrB_Info GrB_Matrix_nrows(GrB_Index *nrows, const GrB_Matrix A);
+GrB_Info GrB_Matrix_ncols(GrB_Index *ncols, const GrB_Matrix A);
+GrB_Info GrB_Matrix_nvals(GrB_Index *nvals, const GrB_Matrix A);
+GrB_Info GrB_Matrix_wait(GrB_Matrix A, GrB_WaitMode mode);
+GrB_Info GrB_Matrix_error(const char **error, const GrB_Matrix A);
+GrB_Info GrB_Matrix_exportSize(GrB_Index *Ap_len, GrB_Index *Ai_len, GrB_Index *Ax_len, GrB_Format format,
+                               const GrB_Matrix A);
+GrB_Info GrB_Matrix_exportHint(GrB_Format *format, const GrB_Matrix A);
+GrB_Info GrB_transpose(GrB_Matrix C, const GrB_Matrix Mask, const GrB_BinaryOp accum, const GrB_Matrix A,
+                       const GrB_Descriptor desc); /* Mask/accum must be NULL (only the plain transpose is on the path) */
+
+/* ---- Vector ------------------------------------------------------------------------------- */
+GrB_Info GrB_Vector_new(GrB_Vector *v, GrB_Type type, GrB_Index n);
+GrB_Info GrB_Vector_dup(GrB_Vector *w, const GrB_Vector u);
+GrB_Info GrB_Vector_free(GrB_Vector *v);
+GrB_Info GrB_Vector_clear(GrB_Vector v);
+GrB_Info GrB_Vector_size(GrB_Index *n, const GrB_Vector v);
+GrB_Info GrB_Vector_nvals(GrB_Index *nvals, const GrB_Vector v);
+GrB_Info GrB_Vector_wait(GrB_Vector v, GrB_WaitMode mode);
+GrB_Info GrB_Vector_error(const char **error, const GrB_Vector v);
+
+/* ---- typed ingress / egress (C type per GraphBLAS type; GrB_BOOL is `bool`, 1 byte) --------- */
+#define GRB_FOR_EACH_TYPE(X) \
+    X(BOOL, bool)            \
+    X(INT8, int8_t)          \
+    X(INT16, int16_t)        \
+    X(INT32, int32_t)        \
+    X(INT64, int64_t)        \
+    X(UINT8, uint8_t)        \
+    X(UINT16, uint16_t)      \
+    X(UINT32, uint32_t)      \
+    X(UINT64, uint64_t)      \
+    X(FP32, float)           \
+    X(FP64, double)
+
+#define GRB_DECL_TYPED(NAME, ctype)                                                                                    \
+    extern GrB_Type GrB_##NAME;                                                                                        \
+    GrB_Info GrB_Matrix_build_##NAME(GrB_Matrix C, const GrB_Index *I, const GrB_Index *J, const ctype *X,            \
+                                     GrB_Index nvals, const GrB_BinaryOp dup);                                         \
+    GrB_Info GrB_Matrix_extractTuples_##NAME(GrB_Index *I, GrB_Index *J, ctype *X, GrB_Index *nvals,                   \
+                                             const GrB_Matrix A);                                                      \
+    GrB_Info GrB_Matrix_import_##NAME(GrB_Matrix *A, GrB_Type type, GrB_Index nrows, GrB_Index ncols,                  \
+                                      const GrB_Index *Ap, const GrB_Index *Ai, const ctype *Ax, GrB_Index Ap_len,     \
+                                      GrB_Index Ai_len, GrB_Index Ax_len, GrB_Format format);                          \
+    GrB_Info GrB_Matrix_export_##NAME(GrB_Index *Ap, GrB_Index *Ai, ctype *Ax, GrB_Index *Ap_len, GrB_Index *Ai_len,   \
+                                      GrB_Index *Ax_len, GrB_Format format, const GrB_Matrix A);                       \
+    GrB_Info GrB_Vector_build_##NAME(GrB_Vector w, const GrB_Index *I, const ctype *X, GrB_Index nvals,                \
+                                     const GrB_BinaryOp dup);                                                          \
+    GrB_Info GrB_Vector_extractTuples_##NAME(GrB_Index *I, ctype *X, GrB_Index *nvals, const GrB_Vector v);
+GRB_FOR_EACH_TYPE(GRB_DECL_TYPED)
+#undef GRB_DECL_TYPED
+
+/* ---- descriptors (core/descriptor.py:51-84) ------------------------------------------------- */
+GrB_Info GrB_Descriptor_new(GrB_Descriptor *desc);
+GrB_Info GrB_Descriptor_set(GrB_Descriptor desc, GrB_Desc_Field field, GrB_Desc_Value value);
+GrB_Info GrB_Descriptor_free(GrB_Descriptor *desc);
+extern GrB_Descriptor
+    GrB_DESC_T1, GrB_DESC_T0, GrB_DESC_T0T1, GrB_DESC_C, GrB_DESC_CT1, GrB_DESC_CT0, GrB_DESC_CT0T1,
+    GrB_DESC_S, GrB_DESC_ST1, GrB_DESC_ST0, GrB_DESC_ST0T1, GrB_DESC_SC, GrB_DESC_SCT1, GrB_DESC_SCT0,
+    GrB_DESC_SCT0T1, GrB_DESC_R, GrB_DESC_RT1, GrB_DESC_RT0, GrB_DESC_RT0T1, GrB_DESC_RC, GrB_DESC_RCT1,
+    GrB_DESC_RCT0, GrB_DESC_RCT0T1, GrB_DESC_RS, GrB_DESC_RST1, GrB_DESC_RST0, GrB_DESC_RST0T1, GrB_DESC_RSC,
+    GrB_DESC_RSCT1, GrB_DESC_RSCT0, GrB_DESC_RSCT0T1;
+
+/* ---- builtin operators ------------------------------------------------------------------------
+ * Names follow the GraphBLAS C API / SuiteSparse GxB conventions matched by the reference's regexes
+ * (core/operator/semiring.py:185-219, binary.py, monoid.py). */
+#define GRB_FOR_EACH_NUMERIC(X) X(INT8) X(INT16) X(INT32) X(INT64) X(UINT8) X(UINT16) X(UINT32) X(UINT64) X(FP32) X(FP64)
+#define GRB_FOR_EACH_TNAME(X) X(BOOL) GRB_FOR_EACH_NUMERIC(X)
+
+#define GRB_DECL_BINOPS(T)                                                                                             \
+    extern GrB_BinaryOp GrB_FIRST_##T, GrB_SECOND_##T, GrB_ONEB_##T, GxB_PAIR_##T, GrB_PLUS_##T, GrB_MINUS_##T,        \
+        GrB_TIMES_##T, GrB_MIN_##T, GrB_MAX_##T, GxB_ANY_##T, GxB_LOR_##T, GxB_LAND_##T, GxB_LXOR_##T;                 \
+    extern GrB_Monoid GxB_ANY_##T##_MONOID;                                                                            \
+    extern GrB_Semiring GxB_ANY_PAIR_##T, GxB_ANY_FIRST_##T, GxB_ANY_SECOND_##T;
+GRB_FOR_EACH_TNAME(GRB_DECL_BINOPS)
+#undef GRB_DECL_BINOPS
+extern GrB_BinaryOp GrB_LOR, GrB_LAND, GrB_LXOR, GrB_LXNOR;
+extern GrB_Monoid GrB_LOR_MONOID_BOOL, GrB_LAND_MONOID_BOOL, GrB_LXOR_MONOID_BOOL, GrB_LXNOR_MONOID_BOOL;
+
+#define GRB_DECL_NUMERIC_OPS(T)                                                                                        \
+    extern GrB_Monoid GrB_PLUS_MONOID_##T, GrB_TIMES_MONOID_##T, GrB_MIN_MONOID_##T, GrB_MAX_MONOID_##T;               \
+    extern GrB_Semiring GrB_PLUS_TIMES_SEMIRING_##T, GrB_PLUS_MIN_SEMIRING_##T, GrB_MIN_PLUS_SEMIRING_##T,             \
+        GrB_MIN_TIMES_SEMIRING_##T, GrB_MIN_FIRST_SEMIRING_##T, GrB_MIN_SECOND_SEMIRING_##T,                           \
+        GrB_MIN_MAX_SEMIRING_##T, GrB_MAX_PLUS_SEMIRING_##T, GrB_MAX_TIMES_SEMIRING_##T,                               \
+        GrB_MAX_FIRST_SEMIRING_##T, GrB_MAX_SECOND_SEMIRING_##T, GrB_MAX_MIN_SEMIRING_##T;                             \
+    extern GrB_Semiring GxB_PLUS_PLUS_##T, GxB_PLUS_PAIR_##T, GxB_PLUS_FIRST_##T, GxB_PLUS_SECOND_##T,                 \
+        GxB_PLUS_MAX_##T, GxB_MIN_MIN_##T, GxB_MAX_MAX_##T, GxB_MIN_PAIR_##T, GxB_MAX_PAIR_##T, GxB_TIMES_TIMES_##T,   \
+        GxB_TIMES_PLUS_##T;
+GRB_FOR_EACH_NUMERIC(GRB_DECL_NUMERIC_OPS)
+#undef GRB_DECL_NUMERIC_OPS
+
+extern GrB_Semiring GrB_LOR_LAND_SEMIRING_BOOL, GrB_LAND_LOR_SEMIRING_BOOL, GrB_LXOR_LAND_SEMIRING_BOOL,
+    GrB_LXNOR_LOR_SEMIRING_BOOL;
+extern GrB_Semiring GxB_LOR_LOR_BOOL, GxB_LAND_LAND_BOOL, GxB_LOR_FIRST_BOOL, GxB_LOR_SECOND_BOOL, GxB_LOR_PAIR_BOOL,
+    GxB_LAND_FIRST_BOOL, GxB_LAND_SECOND_BOOL, GxB_LOR_LXOR_BOOL, GxB_LAND_LXOR_BOOL, GxB_LXOR_LOR_BOOL,
+    GxB_LXOR_LXOR_BOOL, GxB_LXOR_FIRST_BOOL, GxB_LXOR_SECOND_BOOL, GxB_LXOR_PAIR_BOOL;
+
+/* =================================================================================================
+ * GrX_* : extensions of this library (no reference counterpart).
+ * ================================================================================================= */
+
+/* Adopt (copy=0: take a reference; the caller keeps the allocation alive and unmodified until the
+ * matrix is freed) or copy (copy=1) a CSR that already lives in HBM.  d_Ap: int64[nrows+1],
+ * d_Aj: int32[nvals] sorted within each row, d_Ax: nvals values of `type` (or ONE value when iso!=0). */
+GrB_Info GrX_Matrix_import_CSR_device(GrB_Matrix *A, GrB_Type type, GrB_Index nrows, GrB_Index ncols,
+                                      const int64_t *d_Ap, const int32_t *d_Aj, const void *d_Ax, GrB_Index nvals,
+                                      int iso, int copy);
+/* Borrow the device CSR of A (valid until A is modified or freed). */
+GrB_Info GrX_Matrix_export_CSR_device(const int64_t **d_Ap, const int32_t **d_Aj, const void **d_Ax, GrB_Index *nvals,
+                                      int *iso, const GrB_Matrix A);
+/* Dense-with-presence vector image in HBM: d_val = n values, d_present = bit-packed presence
+ * (bit i of 32-bit word i>>5), NULL meaning "all n entries present".  Always copies. */
+GrB_Info GrX_Vector_import_dense_device(GrB_Vector *v, GrB_Type type, GrB_Index n, const void *d_val,
+                                        const uint32_t *d_present);
+/* Borrow the device image of v (valid until v is modified or freed). *d_present has ceil(n/64)*2 words. */
+GrB_Info GrX_Vector_export_dense_device(const void **d_val, const uint32_t **d_present, const GrB_Vector v);
+/* Build and cache the transpose now (otherwise built lazily on the first T0/vxm use). */
+GrB_Info GrX_Matrix_cache_transpose(GrB_Matrix A);
+/* Launch on this hipStream_t (default: the null stream, which orders with torch's default stream). */
+GrB_Info GrX_set_stream(void *hip_stream);
+GrB_Info GrX_synchronize(void);
+/* HIP-event stopwatch on the library's stream. */
+GrB_Info GrX_timer_start(void);
+GrB_Info GrX_timer_stop(float *elapsed_ms);
+/* Statistics of the most recent mxv/vxm/mxm call (for bench/roofline bookkeeping). */
+typedef struct {
+    int64_t kernel_launches;  /* HIP kernels launched by the call */
+    int64_t tiles;            /* merge-path tiles (mxv/vxm) or row bins (mxm) */
+    int64_t flops;            /* mxm: sum_k nnz(A(:,k)) nnz(B(k,:)) from the symbolic pass; mxv: nnz(A) */
+    int64_t out_nvals;        /* mxm: nnz(T); mxv: -1 (not counted) */
+    int32_t method;           /* 1 pull (merge-path SpMV), 2 push (SpMSpV), 3 hash SpGEMM */
+    int32_t fused_epilogue;   /* 1 if mask/accum/replace were applied inside the product kernel */
+} GrX_Stats;
+GrB_Info GrX_last_stats(GrX_Stats *stats);
+const char *GrX_version_string(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRB_MI355X_H */

@@ -1,0 +1,156 @@
+// grb_context.hip -- library context: device selection, stream, stream-ordered memory, timing hooks.
+// Counterpart of the reference's `initialize(blocking=..., memory_manager="numpy")` call at
+// graphblas/__init__.py:170-173 (there: SuiteSparse GrB_init on the host; here: a gfx950 device is
+// mandatory -- there is no CPU fallback).
+#include "grb_internal.hpp"
+
+namespace grb {
+
+Context &ctx()
+{
+    static Context c;
+    return c;
+}
+
+void require_init()
+{
+    if (!ctx().initialized) fail(GrB_PANIC, "GrB_init has not been called (or no HIP device is available)");
+}
+
+void *dev_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (bytes == 0) bytes = 16;
+    hipError_t e = hipMallocAsync(&p, bytes, ctx().stream);
+    if (e != hipSuccess || !p) {
+        (void)hipGetLastError();
+        fail(GrB_OUT_OF_MEMORY, "device allocation of " + std::to_string(bytes) + " bytes failed: " + hipGetErrorString(e));
+    }
+    return p;
+}
+
+void *dev_alloc_zero(size_t bytes)
+{
+    void *p = dev_alloc(bytes);
+    GRB_HIP(hipMemsetAsync(p, 0, bytes ? bytes : 16, ctx().stream));
+    return p;
+}
+
+void dev_free(void *p)
+{
+    if (p) (void)hipFreeAsync(p, ctx().stream);
+}
+
+void h2d(void *dst, const void *src, size_t bytes)
+{
+    if (bytes) {
+        GRB_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx().stream));
+        GRB_HIP(hipStreamSynchronize(ctx().stream));  // the caller's host buffer is only borrowed for the call
+    }
+}
+void d2h(void *dst, const void *src, size_t bytes)
+{
+    if (bytes) GRB_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx().stream));
+    GRB_HIP(hipStreamSynchronize(ctx().stream));
+}
+void d2d(void *dst, const void *src, size_t bytes)
+{
+    if (bytes) GRB_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx().stream));
+}
+void sync_stream() { GRB_HIP(hipStreamSynchronize(ctx().stream)); }
+
+}  // namespace grb
+
+using namespace grb;
+
+extern "C" GrB_Info GrB_init(GrB_Mode mode)
+{
+    Context &c = ctx();
+    if (c.initialized) return GrB_INVALID_VALUE;
+    if (mode != GrB_BLOCKING && mode != GrB_NONBLOCKING) return GrB_INVALID_VALUE;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        (void)hipGetLastError();
+        return GrB_PANIC;  // fail loudly: the product has no CPU path
+    }
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return GrB_PANIC;
+    c.device = dev;
+    c.blocking = (mode == GrB_BLOCKING);
+    c.stream = nullptr;
+    // keep freed blocks in the pool: BFS/SSSP loops allocate and free the same temporaries every call
+    hipMemPool_t pool;
+    if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
+        uint64_t thresh = UINT64_MAX;
+        (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thresh);
+    }
+    (void)hipGetLastError();
+    if (hipEventCreate(&c.ev0) != hipSuccess || hipEventCreate(&c.ev1) != hipSuccess) return GrB_PANIC;
+    c.initialized = true;
+    return GrB_SUCCESS;
+}
+
+extern "C" GrB_Info GrB_finalize(void)
+{
+    Context &c = ctx();
+    if (!c.initialized) return GrB_SUCCESS;
+    (void)hipStreamSynchronize(c.stream);
+    if (c.ev0) (void)hipEventDestroy(c.ev0);
+    if (c.ev1) (void)hipEventDestroy(c.ev1);
+    c.ev0 = c.ev1 = nullptr;
+    c.initialized = false;
+    return GrB_SUCCESS;
+}
+
+extern "C" GrB_Info GrB_getVersion(unsigned int *version, unsigned int *subversion)
+{
+    if (!version || !subversion) return GrB_NULL_POINTER;
+    *version = GRB_VERSION;
+    *subversion = GRB_SUBVERSION;
+    return GrB_SUCCESS;
+}
+
+extern "C" GrB_Info GrX_set_stream(void *hip_stream)
+{
+    GRB_TRY
+    require_init();
+    sync_stream();
+    ctx().stream = static_cast<hipStream_t>(hip_stream);
+    GRB_CATCH(nullptr)
+}
+
+extern "C" GrB_Info GrX_synchronize(void)
+{
+    GRB_TRY
+    require_init();
+    sync_stream();
+    GRB_CATCH(nullptr)
+}
+
+extern "C" GrB_Info GrX_timer_start(void)
+{
+    GRB_TRY
+    require_init();
+    GRB_HIP(hipEventRecord(ctx().ev0, ctx().stream));
+    GRB_CATCH(nullptr)
+}
+
+extern "C" GrB_Info GrX_timer_stop(float *elapsed_ms)
+{
+    GRB_TRY
+    require_init();
+    if (!elapsed_ms) fail(GrB_NULL_POINTER, "elapsed_ms is NULL");
+    GRB_HIP(hipEventRecord(ctx().ev1, ctx().stream));
+    GRB_HIP(hipEventSynchronize(ctx().ev1));
+    GRB_HIP(hipEventElapsedTime(elapsed_ms, ctx().ev0, ctx().ev1));
+    GRB_CATCH(nullptr)
+}
+
+extern "C" GrB_Info GrX_last_stats(GrX_Stats *stats)
+{
+    if (!stats) return GrB_NULL_POINTER;
+    *stats = ctx().stats;
+    return GrB_SUCCESS;
+}
+
+extern "C" const char *GrX_version_string(void) { return "grb-mi355x 0.1 (gfx950, GraphBLAS C API 2.0 subset)"; }

@@ -1,0 +1,218 @@
+// grb_internal.hpp -- object model, error plumbing and device-memory helpers of libgrb_mi355x.so.
+//
+// Data layout in HBM (DESIGN.md "Data layout"):
+//   Matrix  : CSR, int64 row pointers, int32 column indices sorted within a row, values of the
+//             matrix type (ONE value when iso); an optional cached transpose (same layout) and a
+//             cached merge-path tile table for the pull SpMV.
+//   Vector  : dense-with-presence ("bitmap"): n values + bit-packed presence (64-bit words; bit i of
+//             word i>>6, which is also bit i&31 of 32-bit word i>>5).  nvals is cached, -1 = unknown.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <type_traits>
+
+#include "grb_mi355x.h"
+
+namespace grb {
+
+enum TypeCode : int {
+    TC_BOOL = 0, TC_INT8, TC_INT16, TC_INT32, TC_INT64, TC_UINT8, TC_UINT16, TC_UINT32, TC_UINT64, TC_FP32, TC_FP64,
+    TC_COUNT
+};
+
+// binary operators and monoids share one code space
+enum OpCode : int {
+    OP_NONE = -1,
+    OP_FIRST = 0, OP_SECOND, OP_PAIR, OP_PLUS, OP_MINUS, OP_RMINUS, OP_TIMES, OP_MIN, OP_MAX,
+    OP_LOR, OP_LAND, OP_LXOR, OP_LXNOR, OP_ANY, OP_COUNT
+};
+
+constexpr uint64_t MAGIC_VECTOR = 0x4752425645435452ULL;  // "GRBVECTR"
+constexpr uint64_t MAGIC_MATRIX = 0x4752424d41545258ULL;  // "GRBMATRX"
+constexpr uint64_t MAGIC_FREED = 0xdeadbeefdeadbeefULL;
+
+struct Error {
+    GrB_Info info;
+    std::string msg;
+};
+
+[[noreturn]] inline void fail(GrB_Info info, const std::string &msg) { throw Error{info, msg}; }
+
+#define GRB_HIP(expr)                                                                                       \
+    do {                                                                                                    \
+        hipError_t _e = (expr);                                                                             \
+        if (_e != hipSuccess) {                                                                             \
+            ::grb::fail(_e == hipErrorOutOfMemory ? GrB_OUT_OF_MEMORY : GrB_PANIC,                          \
+                        std::string("HIP error '") + hipGetErrorString(_e) + "' at " __FILE__ ":" +        \
+                            std::to_string(__LINE__) + " in " #expr);                                       \
+        }                                                                                                   \
+    } while (0)
+
+struct Context {
+    bool initialized = false;
+    bool blocking = false;
+    int device = 0;
+    hipStream_t stream = nullptr;  // null stream: ordered with torch's default stream
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    GrX_Stats stats{};
+};
+Context &ctx();
+void require_init();
+
+// stream-ordered device memory
+void *dev_alloc(size_t bytes);
+void *dev_alloc_zero(size_t bytes);
+void dev_free(void *p);
+void h2d(void *dst, const void *src, size_t bytes);
+void d2h(void *dst, const void *src, size_t bytes);  // synchronous w.r.t. the host on return
+void d2d(void *dst, const void *src, size_t bytes);
+void sync_stream();
+
+template <typename T>
+struct DevBuf {  // RAII temporary
+    T *p = nullptr;
+    explicit DevBuf(size_t n, bool zero = false)
+    {
+        p = static_cast<T *>(zero ? dev_alloc_zero(sizeof(T) * (n ? n : 1)) : dev_alloc(sizeof(T) * (n ? n : 1)));
+    }
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { dev_free(p); }
+    T *release()
+    {
+        T *q = p;
+        p = nullptr;
+        return q;
+    }
+};
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+inline size_t bits_words64(uint64_t n) { return (size_t)((n + 63) / 64); }
+
+}  // namespace grb
+
+// ---- opaque object definitions (global namespace: they are the C-ABI's incomplete types) ----------
+struct GB_Type_opaque {
+    int code;
+    size_t size;
+    const char *name;
+};
+struct GB_BinaryOp_opaque {
+    int op;
+    int type;
+    const char *name;
+};
+struct GB_Monoid_opaque {
+    int op;
+    int type;
+    const char *name;
+};
+struct GB_Semiring_opaque {
+    int monoid;
+    int mult;
+    int type;
+    const char *name;
+};
+struct GB_Descriptor_opaque {
+    bool replace, comp, structure, t0, t1;
+    bool builtin;
+};
+
+struct GB_Vector_opaque {
+    uint64_t magic;
+    GrB_Type type;
+    uint64_t n;
+    void *d_val;       // n values (allocated lazily), nullptr while the vector has never been written
+    uint64_t *d_bits;  // presence, ceil(n/64) words, bits >= n are always 0
+    int64_t nvals;     // -1 = unknown (counted on demand)
+    std::string err;
+};
+
+struct GB_Matrix_opaque {
+    uint64_t magic;
+    GrB_Type type;
+    uint64_t nrows, ncols;
+    int64_t nvals;
+    int64_t *d_ptr;  // nrows+1 (nullptr while empty)
+    int32_t *d_col;
+    void *d_val;  // nvals values, or 1 value when iso
+    bool iso;
+    bool owns;             // false for adopted (GrX import, copy=0) buffers
+    GB_Matrix_opaque *tr;  // cached transpose (owned), or nullptr
+    // merge-path tile table for the pull SpMV (grb_mxv.hip), built on first use
+    int64_t *d_tile_row;
+    int64_t n_tiles;
+    int tile_items;
+    std::string err;
+};
+
+namespace grb {
+
+GrB_Type type_of_code(int code);
+
+inline void check_vector(const GB_Vector_opaque *v, const char *what)
+{
+    if (!v) fail(GrB_NULL_POINTER, std::string(what) + " is NULL");
+    if (v->magic != MAGIC_VECTOR)
+        fail(v->magic == MAGIC_FREED ? GrB_UNINITIALIZED_OBJECT : GrB_INVALID_OBJECT, std::string(what) + " is not a valid GrB_Vector");
+}
+inline void check_matrix(const GB_Matrix_opaque *A, const char *what)
+{
+    if (!A) fail(GrB_NULL_POINTER, std::string(what) + " is NULL");
+    if (A->magic != MAGIC_MATRIX)
+        fail(A->magic == MAGIC_FREED ? GrB_UNINITIALIZED_OBJECT : GrB_INVALID_OBJECT, std::string(what) + " is not a valid GrB_Matrix");
+}
+
+inline std::string *errp(GB_Vector_opaque *v) { return (v && v->magic == MAGIC_VECTOR) ? &v->err : nullptr; }
+inline std::string *errp(GB_Matrix_opaque *A) { return (A && A->magic == MAGIC_MATRIX) ? &A->err : nullptr; }
+
+// ---- object services implemented in grb_object.hip --------------------------------------------------
+void vector_ensure_storage(GB_Vector_opaque *v);               // allocate zeroed values+bits if absent
+void vector_release_storage(GB_Vector_opaque *v);              // free buffers, nvals = 0
+int64_t vector_nvals(GB_Vector_opaque *v);                     // counts if unknown
+GB_Vector_opaque *vector_new(GrB_Type type, uint64_t n);
+void vector_free(GB_Vector_opaque *v);
+void matrix_release_storage(GB_Matrix_opaque *A);              // frees CSR + caches, nvals = 0
+GB_Matrix_opaque *matrix_new(GrB_Type type, uint64_t nrows, uint64_t ncols);
+void matrix_free(GB_Matrix_opaque *A);
+void matrix_invalidate_caches(GB_Matrix_opaque *A);
+const int64_t *matrix_rowptr(GB_Matrix_opaque *A);             // allocates a zero row-pointer array for empty matrices
+GB_Matrix_opaque *matrix_transpose_cached(GB_Matrix_opaque *A);  // builds A->tr on first use
+// values cast: dst[i] = (dst_type) src[i]   (GraphBLAS typecast rules)
+void cast_array(int dst_type, void *dst, int src_type, const void *src, int64_t n);
+// returns a matrix of `type` sharing structure (fresh values); caller frees with matrix_free.  nullptr if A already has that type.
+GB_Matrix_opaque *matrix_cast_copy(GB_Matrix_opaque *A, int type);
+GB_Vector_opaque *vector_cast_copy(GB_Vector_opaque *v, int type);
+// out_bits = present(v) & (structure ? 1 : value != 0)
+void vector_mask_bits(GB_Vector_opaque *m, bool structure, uint64_t *out_bits);
+
+// ---- primitives implemented in grb_prim.hip (rocPRIM-backed) ---------------------------------------
+void prim_sort_pairs_u64_u32(const uint64_t *keys_in, uint64_t *keys_out, const uint32_t *vals_in, uint32_t *vals_out,
+                             int64_t n, int end_bit);
+void prim_exclusive_sum_i64(const int64_t *in, int64_t *out, int64_t n);  // in == out allowed
+
+}  // namespace grb
+
+// ---- C boundary helpers ----------------------------------------------------------------------------
+#define GRB_TRY try {
+#define GRB_CATCH(errstr_ptr)                                    \
+    }                                                            \
+    catch (const ::grb::Error &e)                                \
+    {                                                            \
+        std::string *_s = (errstr_ptr);                          \
+        if (_s) *_s = e.msg;                                     \
+        return e.info;                                           \
+    }                                                            \
+    catch (const std::bad_alloc &)                               \
+    {                                                            \
+        return GrB_OUT_OF_MEMORY;                                \
+    }                                                            \
+    catch (...)                                                  \
+    {                                                            \
+        return GrB_PANIC;                                        \
+    }                                                            \
+    return GrB_SUCCESS;

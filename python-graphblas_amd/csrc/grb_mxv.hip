@@ -1,0 +1,667 @@
+// grb_mxv.hip -- GrB_mxv / GrB_vxm: merge-path pull SpMV over a semiring with the GraphBLAS write
+// rule (mask, accumulator, replace) fused into the kernel epilogue.
+//
+// Reference call sites (paths relative to /root/reference):
+//   GrB_mxv  graphblas/core/matrix.py:2203-2262 (expression :2252-2259), dispatched core/base.py:496-503
+//   GrB_vxm  graphblas/core/vector.py:1309-1378 (expression :1367-1375)
+// The arithmetic replaced is SuiteSparse:GraphBLAS's GrB_mxv/GrB_vxm (not in /root/reference).
+//
+// Kernel design (DESIGN.md "Kernels"):
+//   * Work = the merge of the row-end list (m items) with the nnz list (nnz items); every 256-thread
+//     workgroup owns TILE = 256*IPT consecutive merge items, so tiles are balanced no matter how
+//     skewed the degree distribution is (R-MAT hubs, empty rows).  Tile start rows are cached with
+//     the matrix (they only depend on the row pointers).
+//   * Column indices / values of the tile are staged through LDS with coalesced loads; each thread
+//     then walks IPT merge items: first pass issues all its x gathers (presence word, then value)
+//     back to back so IPT random accesses per lane are in flight, second pass folds the products.
+//   * Rows completed inside a thread are stored straight into an LDS row accumulator; rows shared by
+//     several threads combine with LDS atomics; rows shared by several tiles leave per-tile carries
+//     that a second small kernel (one wavefront per seam, __shfl_down reduction) folds.
+//   * Epilogue: each wavefront takes 64 consecutive output rows, applies mask / accum / replace
+//     against the old w, writes values coalesced and the presence word with one __ballot.
+#include <algorithm>
+
+#include "grb_internal.hpp"
+#include "grb_ops.hpp"
+
+namespace grb {
+
+constexpr int PULL_BLOCK = 256;
+
+struct PullArgs {
+    int64_t m, nnz;
+    const int64_t *rowptr;
+    const int32_t *col;
+    const void *aval;
+    int a_iso;
+    const void *u_val;
+    const uint32_t *u_bits;
+    int u_full;
+    int monoid, mult;
+    int need_aval, need_uval;
+    const int64_t *tile_row;
+    int64_t n_tiles;
+    // write rule
+    const uint64_t *m_bits;
+    int has_mask, m_comp;
+    int accum, replace;
+    const void *w_old_val;
+    const uint64_t *w_old_bits;
+    void *w_new_val;
+    uint64_t *w_new_bits;
+    int fresh;  // w_new_* are different buffers from w_old_*: every kept entry must be copied
+    // seams between tiles
+    void *carry_val;
+    uint8_t *carry_has;
+    void *first_val;
+    uint8_t *first_has;  // bit0: has a partial, bit1: the tile's first row started in an earlier tile
+};
+
+template <typename T, typename W>
+__device__ __forceinline__ T from_acc(W v)
+{
+    if constexpr (std::is_same<T, bool>::value) return v != (W)0;
+    else return (T)v;
+}
+
+// slot = monoid(slot, v) on an LDS (or global) word, compare-and-swap loop
+template <typename W>
+__device__ __forceinline__ void atomic_combine(W *slot, W v, int monoid)
+{
+    if constexpr (sizeof(W) == 4) {
+        unsigned int *p = (unsigned int *)slot;
+        unsigned int old = *p, assumed;
+        do {
+            assumed = old;
+            const W nw = apply_binop<W>(monoid, __builtin_bit_cast(W, assumed), v);
+            old = atomicCAS(p, assumed, __builtin_bit_cast(unsigned int, nw));
+        } while (old != assumed);
+    } else {
+        unsigned long long *p = (unsigned long long *)slot;
+        unsigned long long old = *p, assumed;
+        do {
+            assumed = old;
+            const W nw = apply_binop<W>(monoid, __builtin_bit_cast(W, assumed), v);
+            old = atomicCAS(p, assumed, __builtin_bit_cast(unsigned long long, nw));
+        } while (old != assumed);
+    }
+}
+
+// rows consumed by the merge path at diagonal `diag` (row-end list vs nnz list)
+__global__ void k_tile_table(const int64_t *rowptr, int64_t m, int64_t nnz, int tile, int64_t n_tiles, int64_t *tile_row)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > n_tiles) return;
+    const int64_t total = m + nnz;
+    int64_t diag = t * (int64_t)tile;
+    if (diag > total) diag = total;
+    int64_t lo = diag - nnz > 0 ? diag - nnz : 0, hi = diag < m ? diag : m;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (rowptr[mid + 1] <= diag - mid - 1) lo = mid + 1;
+        else hi = mid;
+    }
+    tile_row[t] = lo;
+}
+
+// The write rule for one output row.  Returns the new presence; stores the value when present.
+template <typename T>
+__device__ __forceinline__ bool write_rule_row(const PullArgs &a, int64_t row, bool mact, bool old_has, bool t_has, T t_val)
+{
+    const T *w_old = (const T *)a.w_old_val;
+    T *w_new = (T *)a.w_new_val;
+    if (!mact) {
+        const bool keep = a.replace ? false : old_has;
+        if (keep && a.fresh) w_new[row] = w_old[row];
+        return keep;
+    }
+    if (a.accum >= 0) {
+        if (old_has && t_has) { w_new[row] = apply_binop<T>(a.accum, w_old[row], t_val); return true; }
+        if (old_has) { if (a.fresh) w_new[row] = w_old[row]; return true; }
+        if (t_has) { w_new[row] = t_val; return true; }
+        return false;
+    }
+    if (t_has) w_new[row] = t_val;
+    return t_has;
+}
+
+template <typename T, int MONOID_CT, int MULT_CT, int IPT>
+__global__ __launch_bounds__(PULL_BLOCK) void k_mxv_pull(const PullArgs a)
+{
+    using W = typename Widen<T>::type;
+    constexpr int TILE = PULL_BLOCK * IPT;
+    __shared__ int s_rowend[TILE + 2];
+    __shared__ int s_col[TILE];
+    __shared__ T s_aval[TILE];
+    __shared__ W s_tval[TILE + 1];
+    __shared__ unsigned char s_thas[TILE + 1];
+    __shared__ unsigned int s_act[TILE / 32 + 3];
+    __shared__ int s_any;
+
+    const int monoid = MONOID_CT >= 0 ? MONOID_CT : a.monoid;
+    const int mult = MULT_CT >= 0 ? MULT_CT : a.mult;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int64_t tile = blockIdx.x;
+    const int64_t i0 = a.tile_row[tile], i1 = a.tile_row[tile + 1];
+    const int64_t total = a.m + a.nnz;
+    const int64_t d0 = tile * (int64_t)TILE;
+    const int64_t d1 = d0 + TILE < total ? d0 + TILE : total;
+    const int64_t j0 = d0 - i0, j1 = d1 - i1;
+    const int nrows_t = (int)(i1 - i0);  // rows whose end falls inside this tile
+    const int nnz_t = (int)(j1 - j0);
+    const int items = (int)(d1 - d0);
+    const T *aval = (const T *)a.aval;
+    const T *uval = (const T *)a.u_val;
+    const bool need_aval = a.need_aval != 0, need_uval = a.need_uval != 0;
+    const bool has_mask = a.has_mask != 0;
+
+    // ---- stage row ends (relative to j0), reset row accumulators ------------------------------------
+    for (int k = tid; k <= nrows_t; k += PULL_BLOCK) {
+        const int64_t row = i0 + k;
+        int rel = TILE + 1;
+        if (row < a.m) {
+            const int64_t e = a.rowptr[row + 1] - j0;
+            rel = e > TILE ? TILE + 1 : (int)e;
+        }
+        s_rowend[k] = rel;
+        s_tval[k] = monoid_identity<T, W>(monoid);
+        s_thas[k] = 0;
+    }
+    if (tid == 0) s_any = has_mask ? 0 : 1;
+    __syncthreads();
+
+    // ---- active-row bits for rows i0 .. min(i1, m-1) -------------------------------------------------
+    const int64_t wbase = i0 >> 5;
+    const int64_t last_row = i1 < a.m ? i1 : a.m - 1;
+    if (has_mask) {
+        const int nw = (int)((last_row >> 5) - wbase) + 1;
+        const uint32_t *mb = (const uint32_t *)a.m_bits;
+        for (int k = tid; k < nw; k += PULL_BLOCK) {
+            uint32_t w = mb[wbase + k];
+            if (a.m_comp) w = ~w;
+            s_act[k] = w;
+            // restrict to [i0, last_row] for the "anything to do" test
+            const int64_t base_row = (wbase + k) << 5;
+            uint32_t in = 0xffffffffu;
+            if (base_row < i0) in &= 0xffffffffu << (int)(i0 - base_row);
+            if (base_row + 31 > last_row) in &= 0xffffffffu >> (int)(base_row + 31 - last_row);
+            if (w & in) s_any = 1;
+        }
+    }
+    __syncthreads();
+    const bool any_active = s_any != 0;
+
+#define ROW_ACTIVE(r) (!has_mask || ((s_act[(int)(((i0 + (r)) >> 5) - wbase)] >> ((i0 + (r)) & 31)) & 1u))
+
+    if (any_active) {
+        // ---- stage this tile's column indices and values, coalesced ------------------------------------
+        for (int k = tid; k < nnz_t; k += PULL_BLOCK) {
+            s_col[k] = a.col[j0 + k];
+            if (need_aval && !a.a_iso) s_aval[k] = aval[j0 + k];
+        }
+        __syncthreads();
+
+        // ---- per-thread merge-path start -----------------------------------------------------------------
+        const int diag = tid * IPT < items ? tid * IPT : items;
+        int lo = diag - nnz_t > 0 ? diag - nnz_t : 0, hi = diag < nrows_t ? diag : nrows_t;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (s_rowend[mid] <= diag - mid - 1) lo = mid + 1;
+            else hi = mid;
+        }
+        const int r_start = lo, j_start = diag - lo;
+        const int my_items = items - diag < IPT ? items - diag : IPT;
+
+        // ---- pass 1a: classify my items (column to gather, skipped nnz = -1, row end = -2) --------------
+        int cc[IPT];
+        {
+            int r = r_start, j = j_start, rend = s_rowend[r];
+            bool act = ROW_ACTIVE(r);
+#pragma unroll
+            for (int s = 0; s < IPT; s++) {
+                cc[s] = -3;
+                if (s < my_items) {
+                    if (j < rend) {
+                        cc[s] = act ? s_col[j] : -1;
+                        j++;
+                    } else {
+                        cc[s] = -2;
+                        r++;
+                        rend = s_rowend[r];
+                        act = ROW_ACTIVE(r);
+                    }
+                }
+            }
+        }
+        // ---- pass 1b/1c: gather presence words, then values: IPT independent loads in flight per lane ---
+        bool xp[IPT];
+        T xv[IPT];
+        if (a.u_full) {
+#pragma unroll
+            for (int s = 0; s < IPT; s++) xp[s] = cc[s] >= 0;
+        } else {
+            uint32_t bw[IPT];
+#pragma unroll
+            for (int s = 0; s < IPT; s++) bw[s] = cc[s] >= 0 ? a.u_bits[cc[s] >> 5] : 0u;
+#pragma unroll
+            for (int s = 0; s < IPT; s++) xp[s] = cc[s] >= 0 && ((bw[s] >> (cc[s] & 31)) & 1u);
+        }
+#pragma unroll
+        for (int s = 0; s < IPT; s++) xv[s] = (xp[s] && need_uval) ? uval[cc[s]] : (T)0;
+
+        // ---- pass 2: fold products along the merge path -----------------------------------------------------
+        const T iso_v = (a.a_iso && need_aval) ? aval[0] : (T)0;
+        int r = r_start, j = j_start;
+        int row_start_rel;
+        if (r_start > 0) row_start_rel = s_rowend[r_start - 1];
+        else {
+            const int64_t rs = (i0 < a.m ? a.rowptr[i0] : a.nnz) - j0;
+            row_start_rel = rs < -1 ? -1 : (int)rs;
+        }
+        bool first_partial = (j_start != row_start_rel);
+        T acc = (T)0;
+        bool has = false;
+#pragma unroll
+        for (int s = 0; s < IPT; s++) {
+            if (cc[s] == -2) {  // row r ends here
+                if (has) {
+                    const W v = (W)acc;
+                    if (monoid == OP_ANY || !first_partial) s_tval[r] = v;
+                    else atomic_combine<W>(&s_tval[r], v, monoid);
+                    s_thas[r] = 1;
+                }
+                r++;
+                has = false;
+                first_partial = false;
+            } else if (cc[s] != -3) {  // an nnz of row r
+                if (xp[s]) {
+                    const T av = need_aval ? (a.a_iso ? iso_v : s_aval[j]) : (T)0;
+                    const T prod = apply_binop<T>(mult, av, xv[s]);
+                    acc = has ? apply_binop<T>(monoid, acc, prod) : prod;
+                    has = true;
+                }
+                j++;
+            }
+        }
+        if (has) {  // carry-out into the row still open at the end of my range
+            const W v = (W)acc;
+            if (monoid == OP_ANY) s_tval[r] = v;
+            else atomic_combine<W>(&s_tval[r], v, monoid);
+            s_thas[r] = 1;
+        }
+    }
+    __syncthreads();
+
+    // ---- epilogue: rows this tile owns, 64 consecutive rows per wavefront -----------------------------
+    const bool started_earlier = (i0 < a.m) && (a.rowptr[i0] < j0);
+    const int own_lo = (started_earlier && nrows_t > 0) ? 1 : 0;
+    const int64_t row_lo = i0 + own_lo, row_hi = i1;  // [row_lo, row_hi)
+    if (row_lo < row_hi) {
+        const int64_t g_first = row_lo >> 6, g_last = (row_hi - 1) >> 6;
+        for (int64_t g = g_first + (tid >> 6); g <= g_last; g += PULL_BLOCK / 64) {
+            const int64_t row = (g << 6) + lane;
+            const bool owned = row >= row_lo && row < row_hi;
+            const uint64_t oldw = a.w_old_bits[g];
+            const bool old_has = (oldw >> lane) & 1ull;
+            bool new_has = false;
+            if (owned) {
+                const int k = (int)(row - i0);
+                const bool mact = ROW_ACTIVE(k);
+                new_has = write_rule_row<T>(a, row, mact, old_has, s_thas[k] != 0, from_acc<T, W>(s_tval[k]));
+            }
+            const unsigned long long nb = __ballot(owned && new_has);
+            const unsigned long long om = __ballot(owned);
+            if (lane == 0) {
+                if (om == ~0ull) a.w_new_bits[g] = nb;
+                else {
+                    atomicAnd((unsigned long long *)&a.w_new_bits[g], ~om);
+                    if (nb) atomicOr((unsigned long long *)&a.w_new_bits[g], nb);
+                }
+            }
+        }
+    }
+#undef ROW_ACTIVE
+
+    // ---- seams: the row still open at the tile end, and a first row that began in an earlier tile ----
+    if (tid == 0) {
+        a.carry_has[tile] = s_thas[nrows_t];
+        ((W *)a.carry_val)[tile] = s_tval[nrows_t];
+        const bool se = started_earlier && nrows_t > 0;
+        a.first_has[tile] = se ? (unsigned char)(2 | (s_thas[0] ? 1 : 0)) : (unsigned char)0;
+        ((W *)a.first_val)[tile] = s_tval[0];
+    }
+}
+
+// One wavefront per tile whose first row began in earlier tiles: fold the carries of tiles
+// [t_s, tile) with the tile's own first partial and apply the write rule for that row.
+template <typename T, int TILE>
+__global__ __launch_bounds__(PULL_BLOCK) void k_mxv_seams(const PullArgs a)
+{
+    using W = typename Widen<T>::type;
+    const int lane = threadIdx.x & 63;
+    const int64_t tile = (int64_t)blockIdx.x * (PULL_BLOCK / 64) + (threadIdx.x >> 6);
+    if (tile >= a.n_tiles) return;  // wave-uniform
+    const unsigned char flag = a.first_has[tile];
+    if (!(flag & 2)) return;  // wave-uniform
+    const int monoid = a.monoid;
+    const int64_t row = a.tile_row[tile];
+    const int64_t t_s = (row + a.rowptr[row]) / TILE;
+    const W *cv = (const W *)a.carry_val;
+    W acc = monoid_identity<T, W>(monoid);
+    int has = 0;
+    for (int64_t t = t_s + lane; t < tile; t += 64) {
+        if (a.carry_has[t]) {
+            acc = has ? apply_binop<W>(monoid, acc, cv[t]) : cv[t];
+            has = 1;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const W o = __shfl_down(acc, off);
+        const int oh = __shfl_down(has, off);
+        if (oh) {
+            acc = has ? apply_binop<W>(monoid, acc, o) : o;
+            has = 1;
+        }
+    }
+    if (lane == 0) {
+        if (flag & 1) {
+            const W f = ((const W *)a.first_val)[tile];
+            acc = has ? apply_binop<W>(monoid, acc, f) : f;
+            has = 1;
+        }
+        bool mact = true;
+        if (a.has_mask) {
+            mact = (((const uint32_t *)a.m_bits)[row >> 5] >> (row & 31)) & 1u;
+            if (a.m_comp) mact = !mact;
+        }
+        const bool old_has = (a.w_old_bits[row >> 6] >> (row & 63)) & 1ull;
+        const bool new_has = write_rule_row<T>(a, row, mact, old_has, has != 0, from_acc<T, W>(acc));
+        const unsigned long long bit = 1ull << (row & 63);
+        if (new_has) atomicOr((unsigned long long *)&a.w_new_bits[row >> 6], bit);
+        else atomicAnd((unsigned long long *)&a.w_new_bits[row >> 6], ~bit);
+    }
+}
+
+// General (unfused) write rule: w<mask,replace> = accum(w, (TW) t), t of another type.
+template <typename TW>
+__global__ void k_vec_write(int64_t n, const TW *w_old_val, const uint64_t *w_old_bits, TW *w_new_val,
+                            uint64_t *w_new_bits, const TW *t_val, const uint64_t *t_bits, const uint64_t *m_bits,
+                            int has_mask, int m_comp, int accum, int replace, int fresh)
+{
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one wavefront = one presence word
+    const int lane = threadIdx.x & 63;
+    const int64_t g = row >> 6;
+    const int64_t nwords = (n + 63) >> 6;
+    bool new_has = false;
+    if (row < n) {
+        bool mact = true;
+        if (has_mask) {
+            mact = (m_bits[g] >> lane) & 1ull;
+            if (m_comp) mact = !mact;
+        }
+        const bool old_has = (w_old_bits[g] >> lane) & 1ull;
+        const bool t_has = (t_bits[g] >> lane) & 1ull;
+        if (!mact) {
+            new_has = replace ? false : old_has;
+            if (new_has && fresh) w_new_val[row] = w_old_val[row];
+        } else if (accum >= 0) {
+            if (old_has && t_has) { w_new_val[row] = apply_binop<TW>(accum, w_old_val[row], t_val[row]); new_has = true; }
+            else if (old_has) { if (fresh) w_new_val[row] = w_old_val[row]; new_has = true; }
+            else if (t_has) { w_new_val[row] = t_val[row]; new_has = true; }
+        } else if (t_has) { w_new_val[row] = t_val[row]; new_has = true; }
+    }
+    const unsigned long long nb = __ballot(new_has);
+    if (lane == 0 && g < nwords) w_new_bits[g] = nb;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------
+template <typename T> struct PullIPT { static constexpr int value = sizeof(T) >= 8 ? 4 : 8; };
+
+static void ensure_tile_table(GB_Matrix_opaque *A, int tile_items)
+{
+    if (A->d_tile_row && A->tile_items == tile_items) return;
+    dev_free(A->d_tile_row);
+    A->d_tile_row = nullptr;
+    const int64_t total = (int64_t)A->nrows + A->nvals;
+    const int64_t n_tiles = ceil_div(total, tile_items);
+    int64_t *tab = (int64_t *)dev_alloc(sizeof(int64_t) * (size_t)(n_tiles + 1));
+    const int64_t nt1 = n_tiles + 1;
+    hipLaunchKernelGGL(k_tile_table, dim3((unsigned)ceil_div(nt1, 256)), dim3(256), 0, ctx().stream, matrix_rowptr(A),
+                       (int64_t)A->nrows, A->nvals, tile_items, n_tiles, tab);
+    A->d_tile_row = tab;
+    A->n_tiles = n_tiles;
+    A->tile_items = tile_items;
+}
+
+template <typename T, int MON, int MUL>
+static void launch_pull(GB_Matrix_opaque *A, PullArgs &a)
+{
+    using W = typename Widen<T>::type;
+    constexpr int IPT = PullIPT<T>::value;
+    constexpr int TILE = PULL_BLOCK * IPT;
+    ensure_tile_table(A, TILE);
+    a.tile_row = A->d_tile_row;
+    a.n_tiles = A->n_tiles;
+    if (a.n_tiles > 0x7fffffff) fail(GrB_NOT_IMPLEMENTED, "too many tiles for one launch");
+    DevBuf<W> carry_val(a.n_tiles), first_val(a.n_tiles);
+    DevBuf<uint8_t> carry_has(a.n_tiles), first_has(a.n_tiles);
+    a.carry_val = carry_val.p;
+    a.first_val = first_val.p;
+    a.carry_has = carry_has.p;
+    a.first_has = first_has.p;
+    hipLaunchKernelGGL((k_mxv_pull<T, MON, MUL, IPT>), dim3((unsigned)a.n_tiles), dim3(PULL_BLOCK), 0, ctx().stream, a);
+    hipLaunchKernelGGL((k_mxv_seams<T, TILE>), dim3((unsigned)ceil_div(a.n_tiles, PULL_BLOCK / 64)), dim3(PULL_BLOCK), 0,
+                       ctx().stream, a);
+    GRB_HIP(hipGetLastError());
+    ctx().stats.kernel_launches += 2;
+    ctx().stats.tiles = a.n_tiles;
+}
+
+static void pull_dispatch(GB_Matrix_opaque *A, int type, PullArgs &a)
+{
+    const int mon = a.monoid, mul = a.mult;
+    // hot semirings get fully specialised kernels; everything else runs the runtime-operator kernel
+#define SPECIAL(TC, CT, MON, MUL)                                \
+    if (type == TC && mon == MON && mul == MUL) {                \
+        launch_pull<CT, MON, MUL>(A, a);                         \
+        return;                                                  \
+    }
+    SPECIAL(TC_FP32, float, OP_MIN, OP_PLUS)
+    SPECIAL(TC_FP64, double, OP_MIN, OP_PLUS)
+    SPECIAL(TC_INT64, int64_t, OP_MIN, OP_PLUS)
+    SPECIAL(TC_FP32, float, OP_PLUS, OP_TIMES)
+    SPECIAL(TC_FP64, double, OP_PLUS, OP_TIMES)
+    SPECIAL(TC_INT64, int64_t, OP_PLUS, OP_TIMES)
+    SPECIAL(TC_BOOL, bool, OP_LOR, OP_LAND)
+    SPECIAL(TC_BOOL, bool, OP_ANY, OP_PAIR)
+    SPECIAL(TC_INT64, int64_t, OP_ANY, OP_PAIR)
+    SPECIAL(TC_FP32, float, OP_ANY, OP_PAIR)
+#undef SPECIAL
+    GRB_DISPATCH_TYPE(type, T, { launch_pull<T, -1, -1>(A, a); })
+}
+
+struct DescFlags {
+    bool replace = false, comp = false, structure = false, t0 = false, t1 = false;
+};
+static DescFlags flags_of(const GB_Descriptor_opaque *d)
+{
+    DescFlags f;
+    if (d) { f.replace = d->replace; f.comp = d->comp; f.structure = d->structure; f.t0 = d->t0; f.t1 = d->t1; }
+    return f;
+}
+
+// w<mask> = accum(w, S (+.x) u) where S is the CSR to pull over (A or its cached transpose);
+// `flip` evaluates mult(u_k, S_ik) instead of mult(S_ik, u_k)  (vxm).
+static void mxv_core(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_BinaryOp_opaque *accum,
+                     const GB_Semiring_opaque *sr, GB_Matrix_opaque *S, GB_Vector_opaque *u, bool flip, DescFlags f)
+{
+    if (S->ncols != u->n) fail(GrB_DIMENSION_MISMATCH, "mxv/vxm: matrix inner dimension " + std::to_string(S->ncols) + " does not match vector size " + std::to_string(u->n));
+    if (w->n != S->nrows) fail(GrB_DIMENSION_MISMATCH, "mxv/vxm: output size " + std::to_string(w->n) + " does not match matrix dimension " + std::to_string(S->nrows));
+    if (mask && mask->n != w->n) fail(GrB_DIMENSION_MISMATCH, "mxv/vxm: mask size does not match output size");
+    if (accum && accum->type != w->type->code) fail(GrB_DOMAIN_MISMATCH, "mxv/vxm: accum operator type must equal the output type");
+    ctx().stats = GrX_Stats{};
+    ctx().stats.method = 1;
+    ctx().stats.flops = S->nvals;
+    ctx().stats.out_nvals = -1;
+    const int64_t m = (int64_t)w->n;
+    if (m == 0) return;
+    if (!mask && f.comp) {  // complement of "no mask": nothing may be written
+        if (f.replace) vector_release_storage(w);
+        return;
+    }
+    const int st = sr->type;
+    const int monoid = canonical_op(st, sr->monoid);
+    int mult = canonical_op(st, sr->mult);
+    if (flip) mult = flip_op(mult);
+
+    // ---- operands in the semiring's type --------------------------------------------------------------
+    DevBuf<char> a_cast(0), u_cast(0);
+    const void *aval = S->d_val;
+    if (S->nvals && S->type->code != st) {
+        const int64_t nv = S->iso ? 1 : S->nvals;
+        dev_free(a_cast.p);
+        a_cast.p = (char *)dev_alloc(type_size(st) * (size_t)nv);
+        cast_array(st, a_cast.p, S->type->code, S->d_val, nv);
+        aval = a_cast.p;
+    }
+    vector_ensure_storage(u);
+    const void *uval = u->d_val;
+    if (u->type->code != st) {
+        dev_free(u_cast.p);
+        u_cast.p = (char *)dev_alloc(type_size(st) * (size_t)u->n);
+        cast_array(st, u_cast.p, u->type->code, u->d_val, (int64_t)u->n);
+        uval = u_cast.p;
+    }
+
+    // ---- mask bits ------------------------------------------------------------------------------------------
+    DevBuf<uint64_t> mbits_tmp(0);
+    const uint64_t *m_bits = nullptr;
+    if (mask) {
+        // (a mask that aliases w is snapshotted: tiles update w's presence words while others still read them)
+        if (f.structure && mask->d_val && mask != w) m_bits = mask->d_bits;
+        else {
+            dev_free(mbits_tmp.p);
+            mbits_tmp.p = (uint64_t *)dev_alloc(bits_words64(mask->n) * 8);
+            vector_mask_bits(mask, f.structure, mbits_tmp.p);
+            m_bits = mbits_tmp.p;
+        }
+    }
+
+    PullArgs a{};
+    a.m = m;
+    a.nnz = S->nvals;
+    a.rowptr = matrix_rowptr(S);
+    a.col = S->d_col;
+    a.aval = aval;
+    a.a_iso = S->iso ? 1 : 0;
+    a.u_val = uval;
+    a.u_bits = (const uint32_t *)u->d_bits;
+    a.u_full = (u->nvals == (int64_t)u->n) ? 1 : 0;
+    a.monoid = monoid;
+    a.mult = mult;
+    a.need_aval = !(mult == OP_PAIR || mult == OP_SECOND) && S->nvals > 0;
+    a.need_uval = !(mult == OP_PAIR || mult == OP_FIRST || mult == OP_ANY);
+    if (mult == OP_ANY) a.need_aval = S->nvals > 0;
+    a.m_bits = m_bits;
+    a.has_mask = mask ? 1 : 0;
+    a.m_comp = f.comp ? 1 : 0;
+    a.replace = f.replace ? 1 : 0;
+
+    const bool fused = (w->type->code == st);
+    vector_ensure_storage(w);
+    if (fused) {
+        a.accum = accum ? canonical_op(st, accum->op) : -1;
+        const bool fresh = (w == u);
+        void *new_val = w->d_val;
+        uint64_t *new_bits = w->d_bits;
+        if (fresh) {
+            new_val = dev_alloc((size_t)w->n * w->type->size);
+            new_bits = (uint64_t *)dev_alloc_zero(bits_words64(w->n) * 8);
+        }
+        a.w_old_val = w->d_val;
+        a.w_old_bits = w->d_bits;
+        a.w_new_val = new_val;
+        a.w_new_bits = new_bits;
+        a.fresh = fresh ? 1 : 0;
+        pull_dispatch(S, st, a);
+        if (fresh) {
+            dev_free(w->d_val);
+            dev_free(w->d_bits);
+            w->d_val = new_val;
+            w->d_bits = new_bits;
+        }
+        ctx().stats.fused_epilogue = 1;
+    } else {
+        // product into a temporary of the semiring type, then the general write rule with a typecast
+        GB_Vector_opaque *t = vector_new(type_of_code(st), w->n);
+        try {
+            vector_ensure_storage(t);
+            a.accum = -1;
+            a.has_mask = 0;
+            a.replace = 0;
+            a.w_old_val = t->d_val;
+            a.w_old_bits = t->d_bits;
+            a.w_new_val = t->d_val;
+            a.w_new_bits = t->d_bits;
+            a.fresh = 0;
+            pull_dispatch(S, st, a);
+            DevBuf<char> tc((size_t)w->n * w->type->size);
+            cast_array(w->type->code, tc.p, st, t->d_val, (int64_t)w->n);
+            const int acc_op = accum ? canonical_op(w->type->code, accum->op) : -1;
+            GRB_DISPATCH_TYPE(w->type->code, TW, {
+                const int64_t nthreads = (int64_t)bits_words64(w->n) * 64;
+                hipLaunchKernelGGL((k_vec_write<TW>), dim3((unsigned)ceil_div(nthreads, 256)), dim3(256), 0, ctx().stream,
+                                   (int64_t)w->n, (const TW *)w->d_val, (const uint64_t *)w->d_bits, (TW *)w->d_val,
+                                   w->d_bits, (const TW *)tc.p, (const uint64_t *)t->d_bits, m_bits, mask ? 1 : 0,
+                                   f.comp ? 1 : 0, acc_op, f.replace ? 1 : 0, 0);
+            })
+            ctx().stats.kernel_launches += 1;
+        } catch (...) {
+            vector_free(t);
+            throw;
+        }
+        vector_free(t);
+    }
+    w->nvals = -1;
+    if (ctx().blocking) sync_stream();
+}
+
+}  // namespace grb
+
+using namespace grb;
+
+extern "C" GrB_Info GrB_mxv(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_Semiring semiring,
+                            const GrB_Matrix A, const GrB_Vector u, const GrB_Descriptor desc)
+{
+    GRB_TRY
+    require_init();
+    check_vector(w, "w");
+    if (mask) check_vector(mask, "mask");
+    check_matrix(A, "A");
+    check_vector(u, "u");
+    if (!semiring) fail(GrB_NULL_POINTER, "semiring is NULL");
+    DescFlags f = flags_of(desc);
+    GB_Matrix_opaque *S = f.t0 ? matrix_transpose_cached(A) : A;
+    mxv_core(w, mask, accum, semiring, S, u, /*flip=*/false, f);
+    GRB_CATCH(errp(w))
+}
+
+extern "C" GrB_Info GrB_vxm(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_Semiring semiring,
+                            const GrB_Vector u, const GrB_Matrix A, const GrB_Descriptor desc)
+{
+    GRB_TRY
+    require_init();
+    check_vector(w, "w");
+    if (mask) check_vector(mask, "mask");
+    check_matrix(A, "A");
+    check_vector(u, "u");
+    if (!semiring) fail(GrB_NULL_POINTER, "semiring is NULL");
+    DescFlags f = flags_of(desc);
+    // w' = u' A  <=>  w = A' u with the multiply operands swapped; desc T1 transposes A
+    GB_Matrix_opaque *S = f.t1 ? A : matrix_transpose_cached(A);
+    mxv_core(w, mask, accum, semiring, S, u, /*flip=*/true, f);
+    GRB_CATCH(errp(w))
+}

@@ -1,0 +1,175 @@
+// grb_ops.hpp -- builtin operator arithmetic shared by all kernels (device + host callable).
+//
+// One switch-based evaluator: kernels specialised on a compile-time operator pass a constant and the
+// switch folds away; generic kernels pass the runtime code (a wave-uniform scalar branch).
+#pragma once
+#include "grb_internal.hpp"
+
+namespace grb {
+
+#define GRB_HD __host__ __device__ __forceinline__
+
+template <typename T> struct Widen { using type = T; };
+template <> struct Widen<bool> { using type = int32_t; };
+template <> struct Widen<int8_t> { using type = int32_t; };
+template <> struct Widen<int16_t> { using type = int32_t; };
+template <> struct Widen<uint8_t> { using type = uint32_t; };
+template <> struct Widen<uint16_t> { using type = uint32_t; };
+
+template <typename T> struct WrapOf { using type = T; };
+template <> struct WrapOf<int8_t> { using type = uint8_t; };
+template <> struct WrapOf<int16_t> { using type = uint16_t; };
+template <> struct WrapOf<int32_t> { using type = uint32_t; };
+template <> struct WrapOf<int64_t> { using type = uint64_t; };
+
+// z = op(a, b).  For T = bool the host canonicalises PLUS/MAX->LOR, TIMES/MIN->LAND, MINUS->LXOR first.
+template <typename T>
+GRB_HD T apply_binop(int op, T a, T b)
+{
+    if constexpr (std::is_same<T, bool>::value) {
+        switch (op) {
+        case OP_FIRST: case OP_ANY: return a;
+        case OP_SECOND: return b;
+        case OP_PAIR: return true;
+        case OP_PLUS: case OP_MAX: case OP_LOR: return a || b;
+        case OP_TIMES: case OP_MIN: case OP_LAND: return a && b;
+        case OP_MINUS: case OP_RMINUS: case OP_LXOR: return a != b;
+        case OP_LXNOR: return a == b;
+        default: return false;
+        }
+    } else {
+        using U = typename WrapOf<T>::type;
+        switch (op) {
+        case OP_FIRST: case OP_ANY: return a;
+        case OP_SECOND: return b;
+        case OP_PAIR: return (T)1;
+        case OP_PLUS: return (T)((U)a + (U)b);
+        case OP_MINUS: return (T)((U)a - (U)b);
+        case OP_RMINUS: return (T)((U)b - (U)a);
+        case OP_TIMES: return (T)((U)a * (U)b);
+        case OP_MIN:
+            if constexpr (std::is_floating_point<T>::value) return (a != a) ? b : ((b != b) ? a : (a < b ? a : b));
+            else return a < b ? a : b;
+        case OP_MAX:
+            if constexpr (std::is_floating_point<T>::value) return (a != a) ? b : ((b != b) ? a : (a > b ? a : b));
+            else return a > b ? a : b;
+        case OP_LOR: return (T)((a != (T)0) || (b != (T)0));
+        case OP_LAND: return (T)((a != (T)0) && (b != (T)0));
+        case OP_LXOR: return (T)((a != (T)0) != (b != (T)0));
+        case OP_LXNOR: return (T)((a != (T)0) == (b != (T)0));
+        default: return (T)0;
+        }
+    }
+}
+
+template <typename T>
+GRB_HD T type_max()
+{
+    if constexpr (std::is_same<T, float>::value) return __builtin_huge_valf();
+    else if constexpr (std::is_same<T, double>::value) return __builtin_huge_val();
+    else if constexpr (std::is_signed<T>::value) return (T)((((unsigned long long)1) << (sizeof(T) * 8 - 1)) - 1);
+    else return (T)~(T)0;
+}
+template <typename T>
+GRB_HD T type_lowest()
+{
+    if constexpr (std::is_same<T, float>::value) return -__builtin_huge_valf();
+    else if constexpr (std::is_same<T, double>::value) return -__builtin_huge_val();
+    else if constexpr (std::is_signed<T>::value) return (T)(-(long long)((((unsigned long long)1) << (sizeof(T) * 8 - 1)) - 1) - 1);
+    else return (T)0;
+}
+
+// identity of monoid `op` over the VALUE type T, returned in accumulator type W (W = T or Widen<T>)
+template <typename T, typename W>
+GRB_HD W monoid_identity(int op)
+{
+    if constexpr (std::is_same<T, bool>::value) {
+        switch (op) {
+        case OP_LAND: case OP_TIMES: case OP_MIN: case OP_LXNOR: return (W)1;
+        default: return (W)0;
+        }
+    } else {
+        switch (op) {
+        case OP_TIMES: case OP_LAND: case OP_LXNOR: return (W)1;
+        case OP_MIN: return (W)type_max<T>();
+        case OP_MAX: return (W)type_lowest<T>();
+        default: return (W)0;
+        }
+    }
+}
+
+// monoid terminal ("annihilator") test used for early exit: lor->true, land->false, any->anything
+template <typename T>
+GRB_HD bool monoid_is_terminal(int op, T v)
+{
+    switch (op) {
+    case OP_ANY: return true;
+    case OP_LOR: return v != (T)0;
+    case OP_LAND: return v == (T)0;
+    default: return false;
+    }
+}
+
+inline int canonical_op(int type, int op)
+{
+    if (type != TC_BOOL) return op;
+    switch (op) {
+    case OP_PLUS: case OP_MAX: return OP_LOR;
+    case OP_TIMES: case OP_MIN: return OP_LAND;
+    case OP_MINUS: case OP_RMINUS: return OP_LXOR;
+    default: return op;
+    }
+}
+
+inline int flip_op(int op)  // op'(a,b) = op(b,a)
+{
+    switch (op) {
+    case OP_FIRST: return OP_SECOND;
+    case OP_SECOND: return OP_FIRST;
+    case OP_MINUS: return OP_RMINUS;
+    case OP_RMINUS: return OP_MINUS;
+    default: return op;
+    }
+}
+
+inline size_t type_size(int code)
+{
+    static const size_t s[TC_COUNT] = {1, 1, 2, 4, 8, 1, 2, 4, 8, 4, 8};
+    return s[code];
+}
+
+// ---- GraphBLAS typecast (SuiteSparse rules: ->bool is x!=0, float->int saturates with NaN->0) -------
+template <typename D, typename S>
+GRB_HD D cast_value(S s)
+{
+    if constexpr (std::is_same<D, S>::value) return s;
+    else if constexpr (std::is_same<D, bool>::value) return s != (S)0;
+    else if constexpr (std::is_floating_point<S>::value && std::is_integral<D>::value) {
+        if (s != s) return (D)0;
+        const double x = (double)s;
+        if (x <= (double)type_lowest<D>()) return type_lowest<D>();
+        if (x >= (double)type_max<D>()) return type_max<D>();
+        return (D)x;
+    } else return (D)s;
+}
+
+#define GRB_DISPATCH_TYPE(code, T, ...)                                               \
+    switch (code) {                                                                   \
+    case ::grb::TC_BOOL: { using T = bool; __VA_ARGS__; } break;                      \
+    case ::grb::TC_INT8: { using T = int8_t; __VA_ARGS__; } break;                    \
+    case ::grb::TC_INT16: { using T = int16_t; __VA_ARGS__; } break;                  \
+    case ::grb::TC_INT32: { using T = int32_t; __VA_ARGS__; } break;                  \
+    case ::grb::TC_INT64: { using T = int64_t; __VA_ARGS__; } break;                  \
+    case ::grb::TC_UINT8: { using T = uint8_t; __VA_ARGS__; } break;                  \
+    case ::grb::TC_UINT16: { using T = uint16_t; __VA_ARGS__; } break;                \
+    case ::grb::TC_UINT32: { using T = uint32_t; __VA_ARGS__; } break;                \
+    case ::grb::TC_UINT64: { using T = uint64_t; __VA_ARGS__; } break;                \
+    case ::grb::TC_FP32: { using T = float; __VA_ARGS__; } break;                     \
+    case ::grb::TC_FP64: { using T = double; __VA_ARGS__; } break;                    \
+    default: ::grb::fail(GrB_INVALID_OBJECT, "unknown type code");                    \
+    }
+
+// ---- presence-bit helpers -------------------------------------------------------------------------
+GRB_HD bool bit_test(const uint32_t *bits, int64_t i) { return (bits[i >> 5] >> (i & 31)) & 1u; }
+
+}  // namespace grb

@@ -1,0 +1,35 @@
+// grb_prim.hip -- device-wide primitives used by ingress (COO->CSR build, transpose) and by the
+// SpGEMM row-pointer scan.  These are plumbing around the hot path, so they lean on rocPRIM
+// (ROCm's own primitive library); the hot kernels themselves are hand-written (grb_mxv.hip, grb_mxm.hip).
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "grb_internal.hpp"
+
+namespace grb {
+
+void prim_sort_pairs_u64_u32(const uint64_t *keys_in, uint64_t *keys_out, const uint32_t *vals_in, uint32_t *vals_out,
+                             int64_t n, int end_bit)
+{
+    if (n <= 0) return;
+    size_t tmp_bytes = 0;
+    GRB_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u,
+                                      (unsigned)end_bit, ctx().stream));
+    DevBuf<char> tmp(tmp_bytes);
+    GRB_HIP(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u,
+                                      (unsigned)end_bit, ctx().stream));
+}
+
+void prim_exclusive_sum_i64(const int64_t *in, int64_t *out, int64_t n)
+{
+    if (n <= 0) return;
+    size_t tmp_bytes = 0;
+    GRB_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, in, out, (int64_t)0, (size_t)n, rocprim::plus<int64_t>(),
+                                    ctx().stream));
+    DevBuf<char> tmp(tmp_bytes);
+    GRB_HIP(rocprim::exclusive_scan(tmp.p, tmp_bytes, in, out, (int64_t)0, (size_t)n, rocprim::plus<int64_t>(),
+                                    ctx().stream));
+}
+
+}  // namespace grb

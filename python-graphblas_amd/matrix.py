@@ -1,0 +1,275 @@
+"""Matrix / TransposedMatrix: the host-side mirror of graphblas/core/matrix.py for the path --
+constructor :190-203, ``__del__`` :218-225, ``build`` :627-681, ``from_coo`` :818-894, ``_from_csx``
+:992-1068, ``to_coo`` :525-594, ``_to_csx`` :1601-1645, ``isequal`` :373-415, ``mxv`` :2203-2262,
+``mxm`` :2264-2331, ``TransposedMatrix`` :3900-3960."""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from .base import BaseType, Expression, InfixMatMul, call, call_on
+from .dtypes import lookup_dtype
+from .operator import get_typed_op, semiring as _semiring
+from .vector import Vector, _name_counter, _ptr
+
+GrB_CSR_FORMAT, GrB_CSC_FORMAT = 0, 1
+
+
+class Matrix(BaseType):
+    _grb_kind = "Matrix"
+    ndim = 2
+    _is_transposed = False
+
+    def __init__(self, dtype=float, nrows=0, ncols=0, *, name=None):
+        self.dtype = lookup_dtype(dtype)
+        self._nrows, self._ncols = int(nrows), int(ncols)
+        self.name = name or f"M_{next(_name_counter)}"
+        self._handle = ctypes.c_void_p()
+        _lib.load()
+        call_on(None, "GrB_Matrix_new", [ctypes.byref(self._handle), self.dtype._carg, self._nrows, self._ncols])
+
+    @property
+    def _carg(self):
+        return self._handle
+
+    @property
+    def _matrix(self):
+        return self
+
+    def __del__(self):
+        h = getattr(self, "_handle", None)
+        if h is not None and h.value and _lib is not None and _lib.lib is not None:
+            try:
+                _lib.lib.GrB_Matrix_free(ctypes.byref(h))
+            except Exception:  # interpreter shutdown
+                pass
+
+    nrows = property(lambda self: self._nrows)
+    ncols = property(lambda self: self._ncols)
+    shape = property(lambda self: (self._nrows, self._ncols))
+
+    @property
+    def nvals(self):
+        n = ctypes.c_uint64()
+        call_on(self, "GrB_Matrix_nvals", [ctypes.byref(n), self._handle])
+        return int(n.value)
+
+    @property
+    def T(self):
+        return TransposedMatrix(self)
+
+    def __repr__(self):
+        return f"Matrix<{self.dtype}, {self._nrows}x{self._ncols}, name={self.name}>"
+
+    # ---- ingress / egress ---------------------------------------------------------------------------------
+    def build(self, rows, columns, values, *, dup_op=None, clear=False):
+        """reference core/matrix.py:627-681: uint64 indices (:637-638), default dup_op=plus with
+        duplicate detection by nvals < n (:657-681)."""
+        rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        columns = np.ascontiguousarray(columns, dtype=np.uint64)
+        values = np.asarray(values)
+        if values.ndim == 0:
+            values = np.broadcast_to(values, rows.shape)
+        values = np.ascontiguousarray(values.astype(self.dtype.np_type, copy=False))
+        n = values.size
+        if rows.size != n or columns.size != n:
+            raise ValueError(f"`rows` and `columns` and `values` lengths must match: {rows.size}, {columns.size}, {n}")
+        if clear:
+            self.clear()
+        if n == 0:
+            return
+        dup_orig = dup_op
+        if dup_op is None:
+            dup_op = "plus"
+        dup_t = get_typed_op(dup_op, self.dtype, kind="binary")
+        if dup_t.opclass == "Monoid":
+            dup_t = dup_t.binaryop
+        call(f"GrB_Matrix_build_{self.dtype.name}", [self, _ptr(rows), _ptr(columns), _ptr(values), n, dup_t])
+        if dup_orig is None and self.nvals < n:
+            self.clear()
+            raise ValueError("Duplicate indices found, must provide `dup_op` BinaryOp")
+
+    @classmethod
+    def from_coo(cls, rows, columns, values=1.0, dtype=None, *, nrows=None, ncols=None, dup_op=None, name=None):
+        """reference core/matrix.py:818-894: shape inferred as max index + 1 when not given."""
+        rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        columns = np.ascontiguousarray(columns, dtype=np.uint64)
+        values = np.asarray(values)
+        if dtype is None:
+            dtype = lookup_dtype(values.dtype) if values.dtype.kind in "biuf" else lookup_dtype(float)
+        if nrows is None:
+            if rows.size == 0:
+                raise ValueError("No row indices provided. Unable to infer nrows.")
+            nrows = int(rows.max()) + 1
+        if ncols is None:
+            if columns.size == 0:
+                raise ValueError("No column indices provided. Unable to infer ncols.")
+            ncols = int(columns.max()) + 1
+        C = cls(dtype, nrows, ncols, name=name)
+        C.build(rows, columns, values, dup_op=dup_op)
+        return C
+
+    @classmethod
+    def _from_csx(cls, fmt, indptr, indices, values, dtype, num, name):
+        indptr = np.ascontiguousarray(indptr, dtype=np.uint64)
+        indices = np.ascontiguousarray(indices, dtype=np.uint64)
+        values = np.asarray(values)
+        if dtype is None:
+            dtype = lookup_dtype(values.dtype)
+        dtype = lookup_dtype(dtype)
+        if values.ndim == 0:
+            values = np.broadcast_to(values, indices.shape)
+        values = np.ascontiguousarray(values.astype(dtype.np_type, copy=False))
+        if num is None:
+            num = int(indices.max()) + 1 if indices.size else 0
+        nrows, ncols = (indptr.size - 1, num) if fmt == GrB_CSR_FORMAT else (num, indptr.size - 1)
+        A = cls.__new__(cls)
+        A.dtype, A._nrows, A._ncols, A.name = dtype, nrows, ncols, name or f"M_{next(_name_counter)}"
+        A._handle = ctypes.c_void_p()
+        _lib.load()
+        call_on(None, f"GrB_Matrix_import_{dtype.name}",
+                [ctypes.byref(A._handle), dtype._carg, nrows, ncols, _ptr(indptr), _ptr(indices), _ptr(values),
+                 indptr.size, indices.size, values.size, fmt])
+        return A
+
+    @classmethod
+    def from_csr(cls, indptr, col_indices, values=1.0, dtype=None, *, ncols=None, name=None):
+        return cls._from_csx(GrB_CSR_FORMAT, indptr, col_indices, values, dtype, ncols, name)
+
+    @classmethod
+    def from_csc(cls, indptr, row_indices, values=1.0, dtype=None, *, nrows=None, name=None):
+        return cls._from_csx(GrB_CSC_FORMAT, indptr, row_indices, values, dtype, nrows, name)
+
+    def to_coo(self, dtype=None, *, rows=True, columns=True, values=True, sort=True):
+        """reference core/matrix.py:525-594 (row-major sorted)."""
+        n = self.nvals
+        I = np.empty(n, np.uint64) if rows else None
+        J = np.empty(n, np.uint64) if columns else None
+        X = np.empty(n, self.dtype.np_type) if values else None
+        cnt = ctypes.c_uint64(n)
+        call_on(self, f"GrB_Matrix_extractTuples_{self.dtype.name}",
+                [_ptr(I) if n else None, _ptr(J) if n else None, _ptr(X) if n else None, ctypes.byref(cnt), self._handle])
+        if X is not None and dtype is not None:
+            X = X.astype(lookup_dtype(dtype).np_type)
+        return I, J, X
+
+    def _to_csx(self, fmt):
+        ap, ai, ax = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+        call_on(self, "GrB_Matrix_exportSize", [ctypes.byref(ap), ctypes.byref(ai), ctypes.byref(ax), fmt, self._handle])
+        Ap = np.empty(ap.value, np.uint64)
+        Ai = np.empty(ai.value, np.uint64)
+        Ax = np.empty(ax.value, self.dtype.np_type)
+        call_on(self, f"GrB_Matrix_export_{self.dtype.name}",
+                [_ptr(Ap), Ai.ctypes.data_as(ctypes.c_void_p), Ax.ctypes.data_as(ctypes.c_void_p), ctypes.byref(ap),
+                 ctypes.byref(ai), ctypes.byref(ax), fmt, self._handle])
+        return Ap[: ap.value], Ai[: ai.value], Ax[: ax.value]
+
+    def to_csr(self):
+        return self._to_csx(GrB_CSR_FORMAT)
+
+    def to_csc(self):
+        return self._to_csx(GrB_CSC_FORMAT)
+
+    def dup(self, dtype=None, *, name=None):
+        C = Matrix.__new__(Matrix)
+        C.dtype, C._nrows, C._ncols, C.name = self.dtype, self._nrows, self._ncols, name or f"M_{next(_name_counter)}"
+        C._handle = ctypes.c_void_p()
+        call_on(self, "GrB_Matrix_dup", [ctypes.byref(C._handle), self._handle])
+        if dtype is not None and lookup_dtype(dtype) is not self.dtype:
+            I, J, X = C.to_coo()
+            return Matrix.from_coo(I, J, X.astype(lookup_dtype(dtype).np_type), nrows=self._nrows, ncols=self._ncols, name=name)
+        return C
+
+    def clear(self):
+        call("GrB_Matrix_clear", [self])
+
+    def isequal(self, other, *, check_dtype=False):
+        """Same shape, structure and values (reference core/matrix.py:373-415)."""
+        if not isinstance(other, Matrix):
+            raise TypeError(f"Expected type: Matrix; got {type(other).__name__}")
+        if check_dtype and self.dtype is not other.dtype:
+            return False
+        if self.shape != other.shape or self.nvals != other.nvals:
+            return False
+        a, b = self.to_coo(), other.to_coo()
+        return bool(all(np.array_equal(x, y) for x, y in zip(a, b)))
+
+    def isclose(self, other, *, rel_tol=1e-7, abs_tol=0.0, check_dtype=False):
+        if check_dtype and self.dtype is not other.dtype:
+            return False
+        if self.shape != other.shape or self.nvals != other.nvals:
+            return False
+        a, b = self.to_coo(), other.to_coo()
+        return bool(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+                    and np.allclose(a[2].astype(float), b[2].astype(float), rtol=rel_tol, atol=abs_tol))
+
+    # ---- the hot path ---------------------------------------------------------------------------------------
+    def mxv(self, other, op=_semiring.plus_times):
+        """``w << A.mxv(v, semiring)``  (reference core/matrix.py:2203-2262 -> C ``GrB_mxv``)."""
+        return _mxv(self, other, op)
+
+    def mxm(self, other, op=_semiring.plus_times):
+        """``C << A.mxm(B, semiring)``  (reference core/matrix.py:2264-2331 -> C ``GrB_mxm``)."""
+        return _mxm(self, other, op)
+
+    def __matmul__(self, other):
+        return InfixMatMul(self, other)
+
+
+class TransposedMatrix:
+    """``A.T``: a view that only flips the descriptor's T0/T1 (reference core/matrix.py:3900-3960)."""
+
+    _is_transposed = True
+    ndim = 2
+
+    def __init__(self, matrix):
+        self._matrix = matrix
+        self._nrows, self._ncols = matrix._ncols, matrix._nrows
+
+    dtype = property(lambda self: self._matrix.dtype)
+    nrows = property(lambda self: self._nrows)
+    ncols = property(lambda self: self._ncols)
+    shape = property(lambda self: (self._nrows, self._ncols))
+    name = property(lambda self: f"{self._matrix.name}.T")
+
+    @property
+    def T(self):
+        return self._matrix
+
+    def mxv(self, other, op=_semiring.plus_times):
+        return _mxv(self, other, op)
+
+    def mxm(self, other, op=_semiring.plus_times):
+        return _mxm(self, other, op)
+
+    def __matmul__(self, other):
+        return InfixMatMul(self, other)
+
+    def new(self, dtype=None, *, name=None):
+        C = Matrix(dtype or self.dtype, self._nrows, self._ncols, name=name)
+        call("GrB_transpose", [C, None, None, self._matrix, None])
+        return C
+
+
+def _mxv(A, v, op):
+    if not isinstance(v, Vector):
+        raise TypeError(f"Expected type: Vector; got {type(v).__name__}")
+    op = get_typed_op(op, A.dtype, v.dtype, kind="semiring")
+    expr = Expression("mxv", "GrB_mxv", [A._matrix, v], op=op, output_type=Vector, shape=(A._nrows,),
+                      at=A._is_transposed)
+    if A._ncols != v._size:
+        expr._force_library_error()
+    return expr
+
+
+def _mxm(A, B, op):
+    if not isinstance(B, (Matrix, TransposedMatrix)):
+        raise TypeError(f"Expected type: Matrix; got {type(B).__name__}")
+    op = get_typed_op(op, A.dtype, B.dtype, kind="semiring")
+    expr = Expression("mxm", "GrB_mxm", [A._matrix, B._matrix], op=op, output_type=Matrix,
+                      shape=(A._nrows, B._ncols), at=A._is_transposed, bt=B._is_transposed)
+    if A._ncols != B._nrows:
+        expr._force_library_error()
+    return expr

@@ -1,0 +1,185 @@
+"""Vector: the host-side mirror of graphblas/core/vector.py for the path -- constructor :159-170,
+``__del__`` :179-191, ``build`` :522-568, ``from_coo`` (:~700), ``from_dense`` :849-901,
+``to_dense`` :903-955, ``to_coo`` (:~470), ``isequal`` :340-379 and ``vxm`` :1309-1378."""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from .base import BaseType, Expression, InfixMatMul, call, call_on
+from .dtypes import lookup_dtype
+from .operator import get_typed_op, semiring as _semiring
+
+_name_counter = iter(range(1 << 62))
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p) if a is not None and a.size else None
+
+
+class Vector(BaseType):
+    _grb_kind = "Vector"
+    ndim = 1
+
+    def __init__(self, dtype=float, size=0, *, name=None):
+        self.dtype = lookup_dtype(dtype)
+        self._size = int(size)
+        self.name = name or f"v_{next(_name_counter)}"
+        self._handle = ctypes.c_void_p()
+        _lib.load()
+        call_on(None, "GrB_Vector_new", [ctypes.byref(self._handle), self.dtype._carg, self._size])
+
+    @property
+    def _carg(self):
+        return self._handle
+
+    def __del__(self):
+        h = getattr(self, "_handle", None)
+        if h is not None and h.value and _lib is not None and _lib.lib is not None:
+            try:
+                _lib.lib.GrB_Vector_free(ctypes.byref(h))
+            except Exception:  # interpreter shutdown
+                pass
+
+    # ---- properties ---------------------------------------------------------------------------------
+    @property
+    def size(self):
+        return self._size
+
+    @property
+    def shape(self):
+        return (self._size,)
+
+    @property
+    def nvals(self):
+        n = ctypes.c_uint64()
+        call_on(self, "GrB_Vector_nvals", [ctypes.byref(n), self._handle])
+        return int(n.value)
+
+    def __repr__(self):
+        return f"Vector<{self.dtype}, size={self._size}, name={self.name}>"
+
+    # ---- ingress / egress ---------------------------------------------------------------------------------
+    def build(self, indices, values, *, dup_op=None, clear=False, size=None):
+        """reference core/vector.py:522-568: indices as uint64; duplicates need ``dup_op``."""
+        indices = np.ascontiguousarray(indices, dtype=np.uint64)
+        values = np.asarray(values)
+        if values.ndim == 0:
+            values = np.broadcast_to(values, indices.shape)
+        values = np.ascontiguousarray(values.astype(self.dtype.np_type, copy=False))
+        n = indices.size
+        if values.size != n:
+            raise ValueError(f"`indices` and `values` lengths must match: {n} != {values.size}")
+        if clear:
+            self.clear()
+        if n == 0:
+            return
+        dup_orig = dup_op
+        if dup_op is None:
+            dup_op = "plus"  # duplicates are detected below, exactly like the reference (:548-566)
+        dup_t = get_typed_op(dup_op, self.dtype, kind="binary")
+        if dup_t.opclass == "Monoid":
+            dup_t = dup_t.binaryop
+        call(f"GrB_Vector_build_{self.dtype.name}", [self, _ptr(indices), _ptr(values), n, dup_t])
+        if dup_orig is None and self.nvals < n:
+            self.clear()
+            raise ValueError("Duplicate indices found, must provide `dup_op` BinaryOp")
+
+    @classmethod
+    def from_coo(cls, indices, values=1.0, dtype=None, *, size=None, dup_op=None, name=None):
+        indices = np.ascontiguousarray(indices, dtype=np.uint64)
+        values = np.asarray(values)
+        if dtype is None:
+            dtype = lookup_dtype(values.dtype) if values.dtype.kind in "biuf" else lookup_dtype(float)
+        if size is None:
+            if indices.size == 0:
+                raise ValueError("No indices provided. Unable to infer size.")
+            size = int(indices.max()) + 1
+        w = cls(dtype, size, name=name)
+        w.build(indices, values, dup_op=dup_op)
+        return w
+
+    @classmethod
+    def from_dense(cls, values, missing_value=None, *, dtype=None, name=None):
+        """reference core/vector.py:849-901 (vanilla path: from_coo(arange(n), values))."""
+        values = np.asarray(values)
+        if dtype is None:
+            dtype = lookup_dtype(values.dtype)
+        idx = np.arange(values.size, dtype=np.uint64)
+        if missing_value is not None:
+            keep = values != missing_value
+            idx, values = idx[keep], values[keep]
+        w = cls(dtype, np.asarray(values).size if missing_value is None else int(keep.size), name=name)
+        w.build(idx, values)
+        return w
+
+    def to_coo(self, dtype=None, *, indices=True, values=True, sort=True):
+        n = self.nvals
+        I = np.empty(n, np.uint64) if indices else None
+        X = np.empty(n, self.dtype.np_type) if values else None
+        cnt = ctypes.c_uint64(n)
+        call_on(self, f"GrB_Vector_extractTuples_{self.dtype.name}", [_ptr(I) if n else None, _ptr(X) if n else None,
+                                                                      ctypes.byref(cnt), self._handle])
+        if X is not None and dtype is not None:
+            X = X.astype(lookup_dtype(dtype).np_type)
+        return I, X
+
+    def to_dense(self, fill_value=None, dtype=None):
+        I, X = self.to_coo()
+        if fill_value is None and I.size < self._size:
+            raise TypeError("fill_value must be given for vectors with missing elements")
+        out = np.full(self._size, fill_value if fill_value is not None else 0,
+                      (lookup_dtype(dtype) if dtype is not None else self.dtype).np_type)
+        out[I.astype(np.int64)] = X
+        return out
+
+    def dup(self, dtype=None, *, name=None):
+        w = Vector.__new__(Vector)
+        w.dtype, w._size, w.name = self.dtype, self._size, name or f"v_{next(_name_counter)}"
+        w._handle = ctypes.c_void_p()
+        call_on(self, "GrB_Vector_dup", [ctypes.byref(w._handle), self._handle])
+        if dtype is not None and lookup_dtype(dtype) is not self.dtype:
+            I, X = w.to_coo()
+            return Vector.from_coo(I, X.astype(lookup_dtype(dtype).np_type), size=self._size, name=name)
+        return w
+
+    def clear(self):
+        call("GrB_Vector_clear", [self])
+
+    def isequal(self, other, *, check_dtype=False):
+        """Same size, structure and values (reference core/vector.py:340-379)."""
+        if not isinstance(other, Vector):
+            raise TypeError(f"Expected type: Vector; got {type(other).__name__}")
+        if check_dtype and self.dtype is not other.dtype:
+            return False
+        if self._size != other._size or self.nvals != other.nvals:
+            return False
+        (i1, x1), (i2, x2) = self.to_coo(), other.to_coo()
+        return bool(np.array_equal(i1, i2) and np.array_equal(x1, x2))
+
+    def isclose(self, other, *, rel_tol=1e-7, abs_tol=0.0, check_dtype=False):
+        if check_dtype and self.dtype is not other.dtype:
+            return False
+        if self._size != other._size or self.nvals != other.nvals:
+            return False
+        (i1, x1), (i2, x2) = self.to_coo(), other.to_coo()
+        return bool(np.array_equal(i1, i2) and np.allclose(x1.astype(float), x2.astype(float), rtol=rel_tol, atol=abs_tol))
+
+    # ---- the hot path ---------------------------------------------------------------------------------------
+    def vxm(self, other, op=_semiring.plus_times):
+        """``w << u.vxm(A, semiring)``  (reference core/vector.py:1309-1378 -> C ``GrB_vxm``)."""
+        from .matrix import Matrix, TransposedMatrix
+
+        if not isinstance(other, (Matrix, TransposedMatrix)):
+            raise TypeError(f"Expected type: Matrix; got {type(other).__name__}")
+        op = get_typed_op(op, self.dtype, other.dtype, kind="semiring")
+        expr = Expression("vxm", "GrB_vxm", [self, other._matrix], op=op, output_type=Vector, shape=(other._ncols,),
+                          bt=other._is_transposed)
+        if self._size != other._nrows:
+            expr._force_library_error()
+        return expr
+
+    def __matmul__(self, other):
+        return InfixMatMul(self, other)

@@ -1,0 +1,20 @@
+#!/bin/bash
+# TEST INFRASTRUCTURE ONLY: compile the unmodified kernel sources for the CPU SIMT emulator.
+set -e
+HERE="$(cd "$(dirname "$0")" && pwd)"
+ROOT="$(cd "$HERE/../.." && pwd)"
+SRC="$ROOT/python-graphblas_amd/csrc"
+OUT="$HERE/libgrb_emu.so"
+mkdir -p "$HERE/obj"
+pids=()
+for f in "$SRC"/*.hip; do
+  o="$HERE/obj/$(basename "${f%.hip}").o"
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ -n "$(find "$SRC" "$HERE/hip" "$HERE/rocprim" "$ROOT/include" -newer "$o" \( -name '*.hpp' -o -name '*.h' \) | head -1)" ]; then
+    g++ -O1 -g -std=c++17 -fPIC -x c++ -I"$HERE" -I"$ROOT/include" -I"$SRC" -Wno-attributes -c "$f" -o "$o" &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]}"; do wait "$p"; done
+g++ -O1 -g -std=c++17 -fPIC -I"$HERE" -c "$HERE/emu_runtime.cpp" -o "$HERE/obj/emu_runtime.o"
+g++ -shared -o "$OUT" "$HERE"/obj/*.o
+echo "built $OUT"

@@ -1,0 +1,192 @@
+"""Seeded random parity: the HIP path (GPU tier) / the same kernels under the SIMT emulator (CPU tier)
+against the CPU oracle, bit-exact for integer, boolean and min/max semirings; floating-point values are
+small integers, so plus_times is exact as well and the comparison stays bit-exact.
+
+Covers: empty and hub rows (longer than a merge tile, so the tile seams are exercised), ragged sizes,
+all mask/complement/structure/replace combinations, accumulators, w aliased with u, a mask aliased with w,
+vxm (transpose cache), desc T0/T1, operands whose type differs from the semiring type."""
+import numpy as np
+import pytest
+
+from oracle import grb_oracle as O
+from tests.backend import DEVICES, bind
+
+TYPES = ["INT64", "FP32", "BOOL", "FP64", "INT8", "UINT16", "INT32"]
+
+
+@pytest.fixture(params=DEVICES)
+def gb(request):
+    return bind(request.param)
+
+
+def rand_coo(rng, m, n, tname, long_rows=0):
+    np_t = O.NP_OF[tname]
+    deg = rng.integers(0, 6, m)
+    deg[rng.random(m) < 0.3] = 0
+    deg = np.minimum(deg, n)
+    for _ in range(long_rows):
+        deg[rng.integers(0, m)] = rng.integers(n // 2, n + 1)
+    rows = np.repeat(np.arange(m), deg)
+    cols = np.concatenate([rng.choice(n, d, replace=False) for d in deg]) if deg.sum() else np.zeros(0, np.int64)
+    return rows, cols, rand_vals(rng, len(rows), tname)
+
+
+def rand_vals(rng, k, tname):
+    np_t = O.NP_OF[tname]
+    if tname == "BOOL":
+        return rng.random(k) < 0.8
+    if tname.startswith("FP"):
+        return rng.integers(1, 9, k).astype(np_t)
+    return rng.integers(0, 100, k).astype(np_t)
+
+
+def rand_vec(rng, n, dens, tname):
+    idx = np.flatnonzero(rng.random(n) < dens)
+    return idx, rand_vals(rng, len(idx), tname)
+
+
+def semirings_for(tname):
+    if tname == "BOOL":
+        return ["lor_land", "any_pair", "land_lor", "lxor_land"]
+    return ["plus_times", "min_plus", "any_pair", "max_plus", "plus_plus", "min_second", "max_first", "plus_pair"]
+
+
+def same_vec(got, exp):
+    gi, gv = got.to_coo()
+    assert gi.tolist() == exp.idx.tolist()
+    assert gv.tolist() == exp.vals.tolist()
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_mxv_random(gb, seed):
+    rng = np.random.default_rng(seed)
+    tname = TYPES[seed % 7]
+    srs = semirings_for(tname)
+    sr = srs[rng.integers(len(srs))]
+    m, n = int(rng.integers(1, 3000)), int(rng.integers(1, 3000))
+    if seed % 5 == 0:
+        m, n = int(rng.integers(1, 70)), int(rng.integers(1, 70))
+    r, c, v = rand_coo(rng, m, n, tname, long_rows=int(rng.integers(0, 3)))
+    ui, uv = rand_vec(rng, n, [1.0, 0.5, 0.05][seed % 3], tname)
+    wi, wv = rand_vec(rng, m, 0.4, tname)
+    mi, mv = rand_vec(rng, m, 0.5, "INT8")
+    use_mask = seed % 4 != 0
+    comp, struct, repl = (bool(x) for x in rng.integers(0, 2, 3))
+    accum = [None, "plus", "min", "second", "max"][rng.integers(5)]
+    exp = O.mxv(O.OMat.from_coo(r, c, v, m, n, tname), O.OVec(n, ui, uv, tname), sr, w=O.OVec(m, wi, wv, tname),
+                mask=O.OVec(m, mi, mv, "INT8") if use_mask else None, mask_comp=comp and use_mask,
+                mask_struct=struct, accum=accum, replace=repl and use_mask)
+    A = gb.Matrix.from_coo(r, c, v, dtype=tname, nrows=m, ncols=n)
+    u = gb.Vector.from_coo(ui, uv, dtype=tname, size=n)
+    w = gb.Vector.from_coo(wi, wv, dtype=tname, size=m)
+    kw = {}
+    if use_mask:
+        mk = gb.Vector.from_coo(mi, mv, dtype="INT8", size=m)
+        mm = mk.S if struct else mk.V
+        kw = dict(mask=~mm if comp else mm, replace=repl)
+    if accum:
+        kw["accum"] = accum
+    w(**kw) << A.mxv(u, getattr(gb.semiring, sr))
+    same_vec(w, exp)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_vxm_and_transposes_random(gb, seed):
+    rng = np.random.default_rng(100 + seed)
+    tname = TYPES[seed % 7]
+    sr = semirings_for(tname)[seed % 4]
+    m, n = int(rng.integers(1, 1500)), int(rng.integers(1, 1500))
+    r, c, v = rand_coo(rng, m, n, tname, long_rows=1)
+    oa = O.OMat.from_coo(r, c, v, m, n, tname)
+    A = gb.Matrix.from_coo(r, c, v, dtype=tname, nrows=m, ncols=n)
+    ui, uv = rand_vec(rng, m, 0.3, tname)
+    xi, xv = rand_vec(rng, n, 0.3, tname)
+    u, ou = gb.Vector.from_coo(ui, uv, dtype=tname, size=m), O.OVec(m, ui, uv, tname)
+    x, ox = gb.Vector.from_coo(xi, xv, dtype=tname, size=n), O.OVec(n, xi, xv, tname)
+    S = getattr(gb.semiring, sr)
+    same_vec(u.vxm(A, S).new(), O.vxm(ou, oa, sr))                        # u' A
+    same_vec(x.vxm(A.T, S).new(), O.vxm(ox, oa, sr, transpose_b=True))    # x' A'  (desc T1)
+    same_vec(A.T.mxv(u, S).new(), O.mxv(oa, ou, sr, transpose_a=True))    # A' u   (desc T0)
+    same_vec(A.mxv(x, S).new(), O.mxv(oa, ox, sr))
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_aliasing(gb, seed):
+    """w is also u (BFS style  q(~v.S, replace) << A.mxv(q)); mask is also w."""
+    rng = np.random.default_rng(200 + seed)
+    tname = ["BOOL", "INT64", "FP32", "FP64"][seed % 4]
+    sr = "lor_land" if tname == "BOOL" else ["min_plus", "plus_times"][seed % 2]
+    n = int(rng.integers(2, 2500))
+    r, c, v = rand_coo(rng, n, n, tname, long_rows=1)
+    oa = O.OMat.from_coo(r, c, v, n, n, tname)
+    A = gb.Matrix.from_coo(r, c, v, dtype=tname, nrows=n, ncols=n)
+    qi, qv = rand_vec(rng, n, 0.2, tname)
+    vi, vv = rand_vec(rng, n, 0.5, "BOOL")
+    q, oq = gb.Vector.from_coo(qi, qv, dtype=tname, size=n), O.OVec(n, qi, qv, tname)
+    vis, ovis = gb.Vector.from_coo(vi, vv, dtype="BOOL", size=n), O.OVec(n, vi, vv, "BOOL")
+    S = getattr(gb.semiring, sr)
+    q(~vis.S, replace=True) << A.mxv(q, S)
+    same_vec(q, O.mxv(oa, oq, sr, w=oq, mask=ovis, mask_comp=True, mask_struct=True, replace=True))
+    # mask aliased with the output
+    wi, wv = rand_vec(rng, n, 0.5, tname)
+    w, ow = gb.Vector.from_coo(wi, wv, dtype=tname, size=n), O.OVec(n, wi, wv, tname)
+    xi, xv = rand_vec(rng, n, 0.7, tname)
+    x, ox = gb.Vector.from_coo(xi, xv, dtype=tname, size=n), O.OVec(n, xi, xv, tname)
+    w(w.S, replace=bool(seed & 1)) << A.mxv(x, S)
+    same_vec(w, O.mxv(oa, ox, sr, w=ow, mask=ow, mask_struct=True, replace=bool(seed & 1)))
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_mixed_types(gb, seed):
+    """Operand / output types that differ from the semiring type (typecasts, unfused write rule)."""
+    rng = np.random.default_rng(300 + seed)
+    ta, tu, tw = [("INT8", "UINT16", "INT64"), ("FP32", "INT32", "FP64"), ("INT64", "INT64", "FP32"),
+                  ("BOOL", "INT32", "INT32"), ("INT32", "FP64", "INT16"), ("UINT8", "UINT8", "FP64"),
+                  ("INT64", "FP32", "INT64"), ("INT16", "INT16", "BOOL")][seed]
+    m, n = int(rng.integers(1, 800)), int(rng.integers(1, 800))
+    r, c, v = rand_coo(rng, m, n, ta, long_rows=1)
+    ui, uv = rand_vec(rng, n, 0.6, tu)
+    wi, wv = rand_vec(rng, m, 0.4, tw)
+    mi, mv = rand_vec(rng, m, 0.5, "BOOL")
+    sr = ["plus_times", "min_plus", "max_plus", "plus_plus"][seed % 4]
+    accum = [None, "plus"][seed % 2]
+    exp = O.mxv(O.OMat.from_coo(r, c, v, m, n, ta), O.OVec(n, ui, uv, tu), sr, w=O.OVec(m, wi, wv, tw),
+                mask=O.OVec(m, mi, mv, "BOOL"), accum=accum)
+    A = gb.Matrix.from_coo(r, c, v, dtype=ta, nrows=m, ncols=n)
+    u = gb.Vector.from_coo(ui, uv, dtype=tu, size=n)
+    w = gb.Vector.from_coo(wi, wv, dtype=tw, size=m)
+    mk = gb.Vector.from_coo(mi, mv, dtype="BOOL", size=m)
+    w(mk.V, accum=accum) << A.mxv(u, getattr(gb.semiring, sr))
+    same_vec(w, exp)
+
+
+def test_edge_shapes(gb):
+    S = gb.semiring
+    # completely empty matrix: result is empty, and replaces the old content of w when unmasked
+    A = gb.Matrix(int, 5, 4)
+    u = gb.Vector.from_coo([0, 1], [1, 2], size=4)
+    w = gb.Vector.from_coo([1, 2], [7, 8], size=5)
+    w << A.mxv(u, S.plus_times)
+    assert w.nvals == 0
+    # empty u
+    A = gb.Matrix.from_coo([0, 1], [1, 0], [3, 4], nrows=2, ncols=2)
+    w = A.mxv(gb.Vector(int, 2), S.min_plus).new()
+    assert w.nvals == 0
+    # 1x1
+    A = gb.Matrix.from_coo([0], [0], [5])
+    w = A.mxv(gb.Vector.from_coo([0], [6]), S.plus_times).new()
+    assert w.to_coo()[1].tolist() == [30]
+    # a single row longer than several tiles, everything else empty
+    n = 9000
+    A = gb.Matrix.from_coo(np.full(n, 3), np.arange(n), np.ones(n, np.int64), nrows=7, ncols=n)
+    w = A.mxv(gb.Vector.from_dense(np.arange(n)), S.plus_times).new()
+    assert w.to_coo()[0].tolist() == [3] and w.to_coo()[1].tolist() == [n * (n - 1) // 2]
+    w = A.mxv(gb.Vector.from_dense(np.arange(n) + 5), S.min_plus).new()
+    assert w.to_coo()[1].tolist() == [6]
+    # many empty rows around few entries (tiles made only of row ends)
+    m = 20000
+    A = gb.Matrix.from_coo([5, m - 1], [0, 1], [2.0, 3.0], nrows=m, ncols=2)
+    w = gb.Vector.from_dense(np.ones(m))
+    w(accum=gb.binary.plus) << A.mxv(gb.Vector.from_dense(np.array([10.0, 20.0])), S.plus_times)
+    d = w.to_dense()
+    assert d[5] == 21.0 and d[m - 1] == 61.0 and d.sum() == m + 20 + 60
