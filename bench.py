@@ -1,0 +1,278 @@
+#!/usr/bin/env python3
+"""bench.py -- the hot-path benchmark (BASELINE.json metric: GTEPS of mxv on R-MAT scale-24).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--scale S] [--workload NAME]
+
+One "step" = one pass of the hot path over the resident graph: the masked SSSP relaxation
+    w<~visited.S> = min(w, A min.+ u)          (GrB_mxv, GrB_MIN_PLUS_SEMIRING_FP32, accum GrB_MIN_FP32)
+on the R-MAT scale-24 graph (north-star target line), inputs already resident in HBM.  With N > 1 ranks
+(one process per GPU, launched by torch.distributed.run) the matrix is 1-D row-sharded, u is replicated
+and every step ends with an RCCL all-gather of the w slices into the next u (strong scaling).
+
+Prints ONE JSON line on rank 0 (see the driver contract); `roofline` is computed from the algorithmic
+bytes of DESIGN.md / SURVEY.md section 8d and the HIP-event duration of the timed region; `cpu_baseline`
+times the C oracle (OpenMP, all host cores) on the same workload -- it is the checker doubling as the
+reported CPU baseline, never the product.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); 6290 GB/s measured copy
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--scale", type=int, default=24)
+    p.add_argument("--visited", type=float, default=0.5, help="fraction of rows masked out (visited)")
+    p.add_argument("--workload", default="mxv_min_plus_masked",
+                   choices=["mxv_min_plus_masked", "mxv_lor_land_masked", "mxv_min_plus", "mxm_plus_times"])
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--extra", action="store_true", help="also run the secondary workloads (reported under 'extra')")
+    return p.parse_args()
+
+
+def algorithmic_bytes_mxv(nnz_active, m, n, v_a, v_u, v_w, accum, mask):
+    """pull mxv bytes = nnz*(I+V_A) + (m+1)*P + n*V_u + m*V_w*(1+[accum]) + m*Mb*[mask],
+    I = 4 B column index, P = 8 B row pointer, Mb = 1/8 B (bit-packed mask), x counted once."""
+    return nnz_active * (4 + v_a) + (m + 1) * 8 + n * v_u + m * v_w * (1 + int(accum)) + (m / 8.0) * int(mask)
+
+
+class MxvWorkload:
+    """Holds the HBM-resident operands of one masked mxv and launches it through the C ABI directly
+    (ctypes call with pre-resolved handles: no per-step Python marshalling beyond one FFI call)."""
+
+    def __init__(self, gb, torch, scale, rank, world, semiring, visited_frac, seed=0):
+        from graphblas_amd import _lib, device, synthetic
+
+        self.gb, self.torch, self.rank, self.world = gb, torch, rank, world
+        n = 1 << scale
+        assert n % (64 * world) == 0
+        rows = n // world
+        lo, hi = rank * rows, (rank + 1) * rows
+        self.n, self.m, self.lo, self.hi = n, rows, lo, hi
+        indptr, col = synthetic.rmat_csr(scale, device="cuda", row_range=(lo, hi) if world > 1 else None)
+        self.nnz_local = int(col.numel())
+        gen = torch.Generator(device="cuda")
+        gen.manual_seed(4242 + seed)
+        visited = torch.rand(n, generator=gen, device="cuda") < visited_frac
+        self.visited_local = visited[lo:hi].contiguous()
+        rowlen = indptr[1:] - indptr[:-1]
+        self.nnz_active_local = int(rowlen[~self.visited_local].sum().item())
+        self.semiring = semiring
+        if semiring == "min_plus":
+            vals = synthetic.edge_weights(col, scale)
+            self.A = device.matrix_from_device_csr(indptr, col, vals, rows, n, "FP32")
+            dist = torch.randint(0, 1000, (n,), generator=gen, device="cuda").to(torch.float32)
+            self.u = device.vector_from_device(dist)
+            self.w = device.vector_from_device(dist[lo:hi].contiguous())
+            self.sr = gb.semiring.min_plus["FP32"]
+            self.accum = gb.binary.min["FP32"]
+            self.dtype_name, self.v_a, self.v_u, self.v_w = "f32", 4, 4, 4
+        else:  # lor_land on an iso-True BOOL matrix: one BFS level step  q<~visited.S, replace> = A lor.land q
+            one = torch.ones(1, dtype=torch.bool, device="cuda")
+            self.A = device.matrix_from_device_csr(indptr, col, one, rows, n, "BOOL", iso=True)
+            frontier = torch.rand(n, generator=gen, device="cuda") < 0.3
+            self.u = device.vector_from_device(torch.ones(n, dtype=torch.bool, device="cuda"), present=frontier)
+            self.w = device.vector_from_device(torch.ones(rows, dtype=torch.bool, device="cuda"),
+                                               present=frontier[lo:hi].contiguous())
+            self.sr = gb.semiring.lor_land["BOOL"]
+            self.accum = None
+            self.dtype_name, self.v_a, self.v_u, self.v_w = "bool", 0, 1, 1
+        self.mask = device.vector_from_device(torch.ones(rows, dtype=torch.bool, device="cuda"), present=self.visited_local)
+        self._keep = (indptr, col)
+        desc_name = "GrB_DESC_SC" if semiring == "min_plus" else "GrB_DESC_RSC"
+        L = _lib.lib
+        self._call = L.GrB_mxv
+        self._args = (self.w._carg, self.mask._carg, self.accum._carg if self.accum else None, self.sr._carg,
+                      self.A._carg, self.u._carg, ctypes.c_void_p(_lib.handle(desc_name)))
+        if world > 1:
+            self.u_vals, _ = device.vector_device_views(self.u)
+            self.w_vals, _ = device.vector_device_views(self.w)
+
+    def step(self):
+        rc = self._call(*self._args)
+        if rc != 0:
+            raise RuntimeError(f"GrB_mxv failed with GrB_Info {rc}")
+        if self.world > 1 and self.semiring == "min_plus":
+            # next u = all ranks' w slices (u and w stay full, so only values travel; 4 B * n/N per rank)
+            self.torch.distributed.all_gather_into_tensor(self.u_vals, self.w_vals)
+
+    def bytes_per_step(self):
+        return algorithmic_bytes_mxv(self.nnz_active_local, self.m, self.n, self.v_a, self.v_u, self.v_w,
+                                     accum=self.accum is not None, mask=True)
+
+
+def cpu_baseline_mxv(wl, torch, reps_budget_s=20.0):
+    """Time the C oracle (OpenMP) on the same single-GPU workload: full graph, a few repetitions."""
+    import numpy as np
+
+    from graphblas_amd import device
+    from oracle import grb_oracle as O
+
+    ip, cj = wl._keep
+    ip = ip.cpu().numpy()
+    cj64 = cj.cpu().numpy().astype(np.int64)
+    m, n = wl.m, wl.n
+    row_active = (~wl.visited_local).cpu().numpy().astype(np.uint8)
+    L = O.lib()
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+    if wl.semiring == "min_plus":
+        from graphblas_amd import synthetic
+
+        vals = synthetic.edge_weights(cj, int(round(np.log2(n)))).cpu().numpy()
+        uvals, _ = device.vector_device_views(wl.u)
+        u_val = uvals.cpu().numpy()
+        u_has = np.ones(n, np.uint8)
+        tcode, mon, mul, acc = O.TYPE_CODES["FP32"], O.OP_CODES["min"], O.OP_CODES["plus"], O.OP_CODES["min"]
+        w_val = u_val[:m].copy()
+        a_iso, replace = 0, 0
+    else:
+        vals = np.ones(1, np.uint8)
+        uvals, uwords = device.vector_device_views(wl.u)
+        u_val = uvals.cpu().numpy().astype(np.uint8)
+        u_has = np.unpackbits(uwords.cpu().numpy().view(np.uint8), bitorder="little")[:n].astype(np.uint8)
+        tcode, mon, mul, acc = O.TYPE_CODES["BOOL"], O.OP_CODES["lor"], O.OP_CODES["land"], -1
+        w_val = np.zeros(m, np.uint8)
+        a_iso, replace = 1, 1
+    w_has = np.ones(m, np.uint8)
+    t_has = np.zeros(m, np.uint8)
+    t_val = np.zeros(m, w_val.dtype)
+    mask_true = wl.visited_local.cpu().numpy().astype(np.uint8)
+    times = []
+    t_begin = time.perf_counter()
+    while len(times) < 3 or (len(times) < 10 and time.perf_counter() - t_begin < reps_budget_s):
+        t0 = time.perf_counter()
+        L.grbo_mxv(tcode, mon, mul, ctypes.c_int64(m), p(ip), p(cj64), p(vals), a_iso, p(u_has), p(u_val), p(row_active),
+                   p(t_has), p(t_val))
+        L.grbo_vec_write(tcode, ctypes.c_int64(m), p(w_has), p(w_val), p(t_has), p(t_val), p(mask_true), 1, acc, replace)
+        times.append(time.perf_counter() - t0)
+    best = float(np.median(times))
+    return {"value": wl.nnz_active_local / best / 1e9, "unit": "GTEPS", "cores": O.num_threads(), "kind": "port",
+            "sample": f"same graph and operands, full pass, median of {len(times)} reps ({best * 1e3:.1f} ms each); "
+                      "C oracle (oracle/grb_oracle.c, OpenMP) -- a CPU restatement, not SuiteSparse"}
+
+
+def main():
+    args = parse()
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    import graphblas_amd as gb
+    from graphblas_amd import device
+
+    gb.init()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def run(workload):
+        sr = {"mxv_min_plus_masked": "min_plus", "mxv_lor_land_masked": "lor_land", "mxv_min_plus": "min_plus"}[workload]
+        visited = 0.0 if workload == "mxv_min_plus" else args.visited
+        wl = MxvWorkload(gb, torch, args.scale, rank, world, sr, visited)
+        for _ in range(args.warmup):
+            wl.step()
+        barrier()
+        t0 = time.perf_counter()
+        device.timer_start()
+        for _ in range(args.steps):
+            wl.step()
+        ev_ms = device.timer_stop()
+        barrier()
+        dt = time.perf_counter() - t0
+        t = torch.tensor([dt, float(wl.nnz_active_local), ev_ms], dtype=torch.float64, device="cuda")
+        if dist is not None:
+            tmax = t.clone()
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            tsum = t.clone()
+            dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+            dt, edges, ev_ms = tmax[0].item(), tsum[1].item(), tmax[2].item()
+        else:
+            edges = float(wl.nnz_active_local)
+        ms_per_step = dt / args.steps * 1e3
+        kernel_ms = ev_ms / args.steps
+        achieved = wl.bytes_per_step() / (kernel_ms * 1e-3) / 1e9
+        res = {
+            "value": edges / (ms_per_step * 1e-3) / 1e9,
+            "ms_per_step": ms_per_step,
+            "dtype": wl.dtype_name,
+            "edges_per_step": edges,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy_peak_6290": achieved / 6290.0,
+                         "traffic": None, "kernel": "k_mxv_pull (+ k_mxv_seams)",
+                         "kernel_ms_hip_events": kernel_ms, "algorithmic_bytes_per_launch": wl.bytes_per_step()},
+            "stats": device.last_stats(),
+        }
+        return wl, res
+
+    if args.workload == "mxm_plus_times":
+        raise SystemExit("mxm bench: see --workload mxm_plus_times once GrB_mxm lands")
+    wl, res = run(args.workload)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            cpu = cpu_baseline_mxv(wl, torch)
+        except Exception as e:  # the baseline must never take the bench line down
+            cpu = {"value": None, "unit": "GTEPS", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
+    extra = []
+    if args.extra and world == 1:
+        del wl
+        for name in ("mxv_lor_land_masked", "mxv_min_plus"):
+            if name == args.workload:
+                continue
+            _, r = run(name)
+            extra.append({"workload": name, **{k: r[k] for k in ("value", "ms_per_step", "dtype", "roofline")}})
+    if rank == 0:
+        out = {
+            "metric": "GTEPS (mxv) on R-MAT scale-%d" % args.scale,
+            "value": res["value"],
+            "unit": "GTEPS",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": res["ms_per_step"],
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": res["dtype"],
+            "data": "synthetic",
+            "config": {"workload": f"rmat{args.scale} {args.workload}: w<~visited.S> = min(w, A min.+ u), "
+                                   f"edge factor 16, visited density {args.visited}, dense u"
+                       if args.workload == "mxv_min_plus_masked" else f"rmat{args.scale} {args.workload}",
+                       "edges_counted_per_step": res["edges_per_step"],
+                       "parallelism": f"row-shard x{world}" + (" + RCCL all-gather of w" if world > 1 else "")},
+            "roofline": res["roofline"] if world == 1 else {**res["roofline"], "note": "per-rank max over ranks"},
+            "cpu_baseline": cpu,
+            "stats": res["stats"],
+        }
+        if extra:
+            out["extra"] = extra
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

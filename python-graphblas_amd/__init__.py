@@ -14,7 +14,7 @@ syntax ``C(mask, accum, replace) << A.mxm(B, semiring)`` documented at
 from . import _lib, descriptor, dtypes, exceptions
 from .base import _replace_singleton as replace
 from .base import record_calls
-from .operator import binary, monoid, op, semiring
+from .operators import binary, monoid, op, semiring
 
 _initialized = False
 backend = "mi355x"

@@ -14,7 +14,7 @@ from . import _lib
 from .descriptor import lookup as descriptor_lookup
 from .dtypes import BOOL, lookup_dtype
 from .exceptions import check_status
-from .operator import Monoid, TypedOp, get_typed_op, semiring
+from .operators import Monoid, TypedOp, get_typed_op, semiring
 
 _recorder = None  # optional list collecting C-call strings (reference core/recorder.py)
 

@@ -1,0 +1,108 @@
+"""Zero-copy bridges between torch device tensors and the library's HBM-resident objects (GrX_*
+extensions of include/grb_mi355x.h).  torch is used for allocation / RNG / collectives only; every
+GraphBLAS operation runs in the library's own HIP kernels."""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from .base import call_on
+from .dtypes import lookup_dtype
+from .matrix import Matrix
+from .vector import Vector, _name_counter
+
+
+def _dptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def matrix_from_device_csr(indptr, col_indices, values, nrows, ncols, dtype=None, *, iso=False, copy=False, name=None):
+    """Adopt a CSR held in torch CUDA tensors: int64 indptr[nrows+1], int32 sorted col_indices[nnz],
+    values[nnz] (or one value when ``iso``).  With copy=False the tensors are kept alive by the Matrix."""
+    import torch
+
+    assert indptr.dtype == torch.int64 and col_indices.dtype == torch.int32
+    dtype = lookup_dtype(dtype if dtype is not None else str(values.dtype).replace("torch.", "").replace("float32", "FP32").replace("float64", "FP64"))
+    A = Matrix.__new__(Matrix)
+    A.dtype, A._nrows, A._ncols, A.name = dtype, int(nrows), int(ncols), name or f"M_{next(_name_counter)}"
+    A._handle = ctypes.c_void_p()
+    _lib.load()
+    nnz = int(col_indices.numel())
+    call_on(None, "GrX_Matrix_import_CSR_device",
+            [ctypes.byref(A._handle), dtype._carg, A._nrows, A._ncols, _dptr(indptr), _dptr(col_indices), _dptr(values),
+             nnz, 1 if iso else 0, 1 if copy else 0])
+    if not copy:
+        A._keepalive = (indptr, col_indices, values)
+    return A
+
+
+def pack_bits(present):
+    """bool tensor [n] -> int32 presence words (bit i of word i>>5), padded to whole 64-bit words."""
+    import torch
+
+    n = present.numel()
+    pad = (-n) % 64
+    p = torch.nn.functional.pad(present.to(torch.int64), (0, pad)).view(-1, 64)
+    w = (p << torch.arange(64, device=present.device, dtype=torch.int64)).sum(1)  # wraps into the sign bit as intended
+    return w.view(torch.int32)
+
+
+def vector_from_device(values, present=None, dtype=None, *, name=None):
+    """Dense-with-presence vector from a torch CUDA tensor of values (+ optional bool presence)."""
+    import torch
+
+    dtype = lookup_dtype(dtype if dtype is not None else {torch.float32: "FP32", torch.float64: "FP64", torch.int64: "INT64",
+                                                          torch.int32: "INT32", torch.bool: "BOOL", torch.uint8: "UINT8",
+                                                          torch.int8: "INT8", torch.int16: "INT16"}[values.dtype])
+    v = Vector.__new__(Vector)
+    v.dtype, v._size, v.name = dtype, int(values.numel()), name or f"v_{next(_name_counter)}"
+    v._handle = ctypes.c_void_p()
+    _lib.load()
+    bits = pack_bits(present) if present is not None else None
+    call_on(None, "GrX_Vector_import_dense_device",
+            [ctypes.byref(v._handle), dtype._carg, v._size, _dptr(values.contiguous()), _dptr(bits)])
+    return v
+
+
+class _CudaView:
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (ptr, False), "version": 2}
+
+
+def vector_device_views(v):
+    """(values, presence_words) torch tensors ALIASING the vector's HBM image (valid until the vector
+    is modified by a call that reallocates it, or freed)."""
+    import torch
+
+    dv, db = ctypes.c_void_p(), ctypes.c_void_p()
+    call_on(v, "GrX_Vector_export_dense_device", [ctypes.byref(dv), ctypes.byref(db), v._handle])
+    n = v._size
+    vals = torch.as_tensor(_CudaView(dv.value, (n,), np.dtype(v.dtype.np_type).str), device="cuda")
+    words = torch.as_tensor(_CudaView(db.value, (((n + 63) // 64) * 2,), "<i4"), device="cuda")
+    return vals, words
+
+
+def synchronize():
+    call_on(None, "GrX_synchronize", [])
+
+
+def timer_start():
+    call_on(None, "GrX_timer_start", [])
+
+
+def timer_stop():
+    ms = ctypes.c_float()
+    call_on(None, "GrX_timer_stop", [ctypes.byref(ms)])
+    return float(ms.value)
+
+
+def last_stats():
+    s = _lib.GrX_Stats()
+    _lib.lib.GrX_last_stats(ctypes.byref(s))
+    return {k: getattr(s, k) for k, _ in s._fields_}
+
+
+def cache_transpose(A):
+    call_on(A, "GrX_Matrix_cache_transpose", [A._handle])

@@ -11,7 +11,7 @@ import numpy as np
 from . import _lib
 from .base import BaseType, Expression, InfixMatMul, call, call_on
 from .dtypes import lookup_dtype
-from .operator import get_typed_op, semiring as _semiring
+from .operators import get_typed_op, semiring as _semiring
 from .vector import Vector, _name_counter, _ptr
 
 GrB_CSR_FORMAT, GrB_CSC_FORMAT = 0, 1

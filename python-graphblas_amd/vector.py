@@ -10,7 +10,7 @@ import numpy as np
 from . import _lib
 from .base import BaseType, Expression, InfixMatMul, call, call_on
 from .dtypes import lookup_dtype
-from .operator import get_typed_op, semiring as _semiring
+from .operators import get_typed_op, semiring as _semiring
 
 _name_counter = iter(range(1 << 62))
 

@@ -1,0 +1,177 @@
+"""GPU tier, BASELINE.json sizes: the HIP path on R-MAT graphs against (a) the CPU oracle at sizes the
+oracle finishes in seconds and (b) size-independent properties at full scale:
+  * linearity in the mask: the masked result equals the unmasked result restricted to the mask;
+  * mxv(A, u) == vxm(u, A') (transpose cache) ;
+  * idempotence of a min.+ relaxation with accum=min once converged (SSSP fixed point = Dijkstra via scipy);
+  * BFS by lor_land level steps reaches exactly the vertices scipy's BFS reaches, level by level.
+All through the C ABI (the Python host is a thin ctypes layer)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gb():
+    from tests.backend import bind
+
+    return bind("gpu")
+
+
+def _graph(gb, scale, kind):
+    import torch
+
+    from graphblas_amd import device, synthetic
+
+    indptr, col = synthetic.rmat_csr(scale, device="cuda")
+    n = 1 << scale
+    if kind == "FP32":
+        vals = synthetic.edge_weights(col, scale)
+        A = device.matrix_from_device_csr(indptr, col, vals, n, n, "FP32")
+    elif kind == "INT64":
+        vals = synthetic.edge_weights(col, scale, dtype=torch.int64)
+        A = device.matrix_from_device_csr(indptr, col, vals, n, n, "INT64")
+    else:
+        vals = torch.ones(1, dtype=torch.bool, device="cuda")
+        A = device.matrix_from_device_csr(indptr, col, vals, n, n, "BOOL", iso=True)
+    return A, indptr, col, vals
+
+
+@pytest.mark.parametrize("scale,kind,sr", [(16, "FP32", "min_plus"), (17, "BOOL", "lor_land"), (16, "INT64", "plus_times"),
+                                           (18, "FP32", "plus_times"), (16, "BOOL", "any_pair")])
+def test_rmat_vs_oracle(gb, scale, kind, sr):
+    """configs[1]-style graphs at oracle-friendly sizes: bit-exact against the CPU oracle."""
+    import torch
+
+    from graphblas_amd import device
+    from oracle import grb_oracle as O
+
+    A, indptr, col, vals = _graph(gb, scale, kind)
+    n = 1 << scale
+    ip, cj = indptr.cpu().numpy(), col.cpu().numpy().astype(np.int64)
+    nnz = cj.size
+    hv = np.ones(nnz, bool) if kind == "BOOL" else vals.cpu().numpy()
+    oa = O.OMat(n, n, ip, cj, hv, kind)
+    rng = np.random.default_rng(scale)
+    for dens, vis_d, accum, repl in ((1.0, 0.5, "min" if sr == "min_plus" else None, False), (0.01, 0.9, None, True),
+                                     (0.3, 0.0, None, False)):
+        ui = np.flatnonzero(rng.random(n) < dens)
+        uv = (rng.random(ui.size) < 0.9) if kind == "BOOL" else rng.integers(1, 50, ui.size).astype(O.NP_OF[kind])
+        vi = np.flatnonzero(rng.random(n) < vis_d)
+        u, ou = gb.Vector.from_coo(ui, uv, dtype=kind, size=n), O.OVec(n, ui, uv, kind)
+        vis, ovis = gb.Vector.from_coo(vi, np.ones(vi.size, bool), dtype="BOOL", size=n), O.OVec(n, vi, np.ones(vi.size, bool), "BOOL")
+        w = u.dup()
+        w(~vis.S, accum=accum, replace=repl) << A.mxv(u, getattr(gb.semiring, sr))
+        exp = O.mxv(oa, ou, sr, w=ou, mask=ovis, mask_comp=True, mask_struct=True, accum=accum, replace=repl)
+        gi, gv = w.to_coo()
+        assert np.array_equal(gi.astype(np.int64), exp.idx)
+        if kind == "FP32" and sr == "plus_times":
+            np.testing.assert_allclose(gv, exp.vals, rtol=1e-6)  # fp plus: order of summation differs (north-star tolerance)
+        else:
+            assert np.array_equal(gv, exp.vals)
+        # vxm over the cached transpose must agree with mxv
+        w2 = u.dup()
+        w2(~vis.S, accum=accum, replace=repl) << u.vxm(A.T, getattr(gb.semiring, sr))
+        assert w2.isclose(w, rel_tol=1e-6) if (kind == "FP32" and sr == "plus_times") else w2.isequal(w)
+
+
+def test_sssp_fixed_point_matches_dijkstra(gb):
+    """primer.rst:221-251 loop at R-MAT scale 15: v(min) << min_plus(v @ G) until fixed point == scipy Dijkstra."""
+    sp = pytest.importorskip("scipy.sparse")
+    from scipy.sparse.csgraph import dijkstra
+
+    scale = 15
+    A, indptr, col, vals = _graph(gb, scale, "FP32")
+    n = 1 << scale
+    G = sp.csr_matrix((vals.cpu().numpy().astype(np.float64), col.cpu().numpy(), indptr.cpu().numpy()), shape=(n, n))
+    src = int(np.argmax(np.diff(indptr.cpu().numpy())))
+    ref = dijkstra(G, directed=True, indices=src)
+    v = gb.Vector.from_coo([src], [0.0], dtype="FP32", size=n)
+    for it in range(200):
+        before = v.nvals, None
+        prev = v.dup()
+        v(gb.op.min) << gb.semiring.min_plus(v @ A)
+        if v.isequal(prev):
+            break
+    assert it < 199
+    idx, val = v.to_coo()
+    reach = np.flatnonzero(np.isfinite(ref))
+    assert np.array_equal(idx.astype(np.int64), reach)
+    assert np.array_equal(val.astype(np.float64), ref[reach])  # integer weights: exact in fp32
+    # idempotence once converged
+    again = v.dup()
+    again(gb.op.min) << gb.semiring.min_plus(again @ A)
+    assert again.isequal(v)
+
+
+def test_bfs_levels_match_scipy(gb):
+    """Level BFS with  q(~visited.S, replace) << q.vxm(A, lor_land)  (notebooks/Example B.1) at scale 16."""
+    sp = pytest.importorskip("scipy.sparse")
+    from scipy.sparse.csgraph import breadth_first_order
+
+    scale = 16
+    A, indptr, col, _ = _graph(gb, scale, "BOOL")
+    n = 1 << scale
+    ip, cj = indptr.cpu().numpy(), col.cpu().numpy()
+    G = sp.csr_matrix((np.ones(cj.size, np.int8), cj, ip), shape=(n, n))
+    src = int(np.argmax(np.diff(ip)))
+    order, pred = breadth_first_order(G, src, directed=True, return_predecessors=True)
+    level = np.full(n, -1)
+    level[src] = 0
+    for x in order[1:]:
+        level[x] = level[pred[x]] + 1
+    q = gb.Vector.from_coo([src], [True], dtype="BOOL", size=n)
+    visited_idx = [np.array([src], np.uint64)]
+    visited = gb.Vector.from_coo([src], [True], dtype="BOOL", size=n)
+    depth = 0
+    while True:
+        depth += 1
+        q(~visited.S, replace=True) << q.vxm(A, gb.semiring.lor_land)
+        qi, qv = q.to_coo()
+        if qi.size == 0:
+            break
+        assert qv.all()
+        assert np.array_equal(qi.astype(np.int64), np.flatnonzero(level == depth))
+        visited_idx.append(qi)
+        allv = np.concatenate(visited_idx)
+        visited = gb.Vector.from_coo(allv, np.ones(allv.size, bool), dtype="BOOL", size=n)
+    assert depth - 1 == level.max()
+
+
+def test_full_scale_properties(gb):
+    """R-MAT scale-22 (configs-sized rows; scale-24 runs in bench.py): mask restriction + transpose agreement."""
+    import torch
+
+    from graphblas_amd import device
+
+    scale = 22
+    A, indptr, col, vals = _graph(gb, scale, "FP32")
+    n = 1 << scale
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(5)
+    dist = torch.randint(0, 1000, (n,), generator=gen, device="cuda").to(torch.float32)
+    present = torch.rand(n, generator=gen, device="cuda") < 0.5
+    visited = torch.rand(n, generator=gen, device="cuda") < 0.5
+    u = device.vector_from_device(dist, present=present)
+    vis = device.vector_from_device(torch.ones(n, dtype=torch.bool, device="cuda"), present=visited)
+    full = A.mxv(u, gb.semiring.min_plus).new()
+    masked = A.mxv(u, gb.semiring.min_plus).new(mask=~vis.S)
+    fv, fb = device.vector_device_views(full)
+    mv, mb = device.vector_device_views(masked)
+    fbits = torch.from_numpy(np.unpackbits(fb.cpu().numpy().view(np.uint8), bitorder="little")[:n].astype(bool)).cuda()
+    mbits = torch.from_numpy(np.unpackbits(mb.cpu().numpy().view(np.uint8), bitorder="little")[:n].astype(bool)).cuda()
+    assert torch.equal(mbits, fbits & ~visited)
+    assert torch.equal(mv[mbits], fv[mbits])
+    # independent check of the unmasked product with torch segment reductions (same fp32 adds, min is exact)
+    rows = torch.repeat_interleave(torch.arange(n, device="cuda"), indptr[1:] - indptr[:-1])
+    cl = col.long()
+    ok = present[cl]
+    cand = torch.where(ok, vals + dist[cl], torch.full_like(vals, float("inf")))
+    ref = torch.full((n,), float("inf"), device="cuda").scatter_reduce(0, rows, cand, "amin")
+    ref_has = torch.zeros(n, dtype=torch.bool, device="cuda").index_put_((rows[ok],), torch.tensor(True, device="cuda"))
+    assert torch.equal(fbits, ref_has)
+    assert torch.equal(fv[fbits], ref[fbits])
+    # transpose agreement: (A')' u via vxm
+    t = u.vxm(A.T, gb.semiring.min_plus).new()
+    tv, tb = device.vector_device_views(t)
+    assert torch.equal(tb, fb) and torch.equal(tv[fbits], fv[fbits])
