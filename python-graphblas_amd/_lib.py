@@ -45,9 +45,34 @@ def load(path: str | None = None):
             f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(there is no pure-Python or CPU fallback)"
         )
+    if os.path.basename(path) == os.path.basename(DEFAULT_LIB):  # (the CPU emulator build has no HIP runtime)
+        _share_hip_runtime_with_torch()
     lib = ctypes.CDLL(path)
     _declare(lib)
     return lib
+
+
+def _share_hip_runtime_with_torch():
+    """torch wheels bundle their own libamdhip64.so.7; a process must not end up with the system copy
+    loaded first and torch's second (torch then reports "no ROCm-capable device").  When torch is
+    installed, load ITS runtime before our library so both resolve the SONAME to the same copy."""
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
 
 
 def _declare(L):

@@ -1,10 +1,589 @@
-// placeholder until the SpGEMM lands
+// grb_mxm.hip -- GrB_mxm: two-pass (symbolic + numeric) row-wise Gustavson SpGEMM with LDS hash
+// accumulators sized for gfx950 (160 KiB LDS per CU) and a dense-accumulator path for hub rows,
+// followed by the GraphBLAS write rule C<M,replace> = accum(C, T).
+//
+// Reference call site: graphblas/core/matrix.py:2264-2331 (expression :2318-2328) -> C ``GrB_mxm``,
+// arguments marshalled at core/base.py:496-503.  The arithmetic replaced is SuiteSparse:GraphBLAS's
+// GrB_mxm (Gustavson / hash / dot methods named at core/ss/descriptor.py:77-83); it is not in /root/reference.
+//
+// Pipeline (DESIGN.md "SpGEMM"):
+//   1. flops: f[p] = nnz(B(col[p], :)) per stored entry of A, exclusive scan -> per-row upper bound ub_i.
+//   2. rows are binned by ub_i (symbolic) / by nnz(T_i) (numeric) with one stable radix sort of (bin,row).
+//   3. symbolic: a 256-thread workgroup per row inserts column keys into an LDS hash table (256 / 2048 /
+//      32768 keys); rows above that use a per-workgroup global bitmap.  Output: nnz(T_i).
+//   4. exclusive scan -> row pointers of T; allocate T.
+//   5. numeric: same hash insertion with LDS value accumulators (256 / 2048 / 8192 entries: the table is now
+//      sized by the exact nnz(T_i)); keys are compacted, bitonic-sorted in LDS and written with their values,
+//      so rows of T come out sorted.  Heavier rows accumulate into a dense per-workgroup accumulator in HBM
+//      (values + presence bitmap) and are emitted by an ordered bitmap sweep.
+//   6. write rule: no mask and no accum -> T becomes C; otherwise a row-merge of (C_old, T, Mask).
+#include <algorithm>
+
 #include "grb_internal.hpp"
+#include "grb_ops.hpp"
+
+namespace grb {
+
+constexpr int MM_BLOCK = 256;
+constexpr int MM_GROUP = 16;  // lanes cooperating on one A(i,k): they stride B(k,:)
+
+struct MxmArgs {
+    int64_t m, n;  // T is m x n
+    const int64_t *Ap;
+    const int32_t *Aj;
+    const void *Ax;
+    int a_iso;
+    const int64_t *Bp;
+    const int32_t *Bj;
+    const void *Bx;
+    int b_iso;
+    int monoid, mult;
+    int need_a, need_b;
+    // outputs
+    int64_t *row_nnz;  // symbolic result (counts), later turned into Tp by a scan
+    const int64_t *Tp;
+    int32_t *Tj;
+    void *Tx;
+    // dense accumulators for hub rows (one slice per workgroup)
+    uint64_t *spa_bits;
+    void *spa_vals;
+    int64_t spa_words;  // 64-bit words per slice
+};
+
+__device__ __forceinline__ unsigned hash_col(int c, int table_mask) { return ((unsigned)c * 2654435761u) & (unsigned)table_mask; }
+
+// ---- step 1 helpers ---------------------------------------------------------------------------------------
+__global__ void k_nnz_flops(const int32_t *Aj, int64_t nnzA, const int64_t *Bp, int64_t *f)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < nnzA) {
+        const int c = Aj[p];
+        f[p] = Bp[c + 1] - Bp[c];
+    } else if (p == nnzA) f[p] = 0;
+}
+
+__device__ __forceinline__ int bin_of(int64_t x, int64_t b1, int64_t b2, int64_t b3)
+{
+    return x == 0 ? 0 : (x <= b1 ? 1 : (x <= b2 ? 2 : (x <= b3 ? 3 : 4)));
+}
+
+// size[i] = F[Ap[i+1]] - F[Ap[i]]  (F == nullptr: size[i] is already in `size`);  key = bin, payload = row
+__global__ void k_row_bins(const int64_t *Ap, const int64_t *F, int64_t m, int64_t *size, int64_t b1, int64_t b2,
+                           int64_t b3, uint64_t *binkey, uint32_t *rowid)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    int64_t s = F ? F[Ap[i + 1]] - F[Ap[i]] : size[i];
+    if (F) size[i] = s;
+    binkey[i] = (uint64_t)bin_of(s, b1, b2, b3);
+    rowid[i] = (uint32_t)i;
+}
+
+// bin_start[b] = first position in sorted keys with key >= b, b = 0..5
+__global__ void k_bin_starts(const uint64_t *keys, int64_t m, int64_t *bin_start)
+{
+    const int b = threadIdx.x;
+    if (b > 5) return;
+    int64_t lo = 0, hi = m;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (keys[mid] < (uint64_t)b) lo = mid + 1;
+        else hi = mid;
+    }
+    bin_start[b] = lo;
+}
+
+// ---- LDS hash kernels -------------------------------------------------------------------------------------------
+// One workgroup per row.  NUMERIC=false: count distinct columns.  NUMERIC=true: accumulate, sort, emit.
+template <typename T, int TABLE, bool NUMERIC>
+__global__ __launch_bounds__(MM_BLOCK) void k_spgemm_hash(const MxmArgs a, const uint32_t *rows)
+{
+    using W = typename Widen<T>::type;
+    constexpr int NV = NUMERIC ? TABLE : 1;
+    constexpr int NS = NUMERIC ? TABLE / 2 : 1;
+    __shared__ int s_key[TABLE];
+    __shared__ W s_val[NV];
+    __shared__ int s_sorted[NS];
+    __shared__ int s_cnt;
+    const int tid = threadIdx.x;
+    const int64_t row = rows[blockIdx.x];
+    const int monoid = a.monoid, mult = a.mult;
+    const T *Ax = (const T *)a.Ax, *Bx = (const T *)a.Bx;
+    for (int k = tid; k < TABLE; k += MM_BLOCK) {
+        s_key[k] = -1;
+        if (NUMERIC) s_val[k] = monoid_identity<T, W>(monoid);
+    }
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+
+    const int g = tid / MM_GROUP, gl = tid % MM_GROUP;
+    int my_new = 0;
+    for (int64_t p = a.Ap[row] + g; p < a.Ap[row + 1]; p += MM_BLOCK / MM_GROUP) {
+        const int k = a.Aj[p];
+        const T av = a.need_a ? Ax[a.a_iso ? 0 : p] : (T)0;
+        for (int64_t q = a.Bp[k] + gl; q < a.Bp[k + 1]; q += MM_GROUP) {
+            const int j = a.Bj[q];
+            unsigned h = hash_col(j, TABLE - 1);
+            while (true) {
+                const int old = atomicCAS(&s_key[h], -1, j);
+                if (old == -1) { my_new++; break; }
+                if (old == j) break;
+                h = (h + 1) & (TABLE - 1);
+            }
+            if (NUMERIC) {
+                const T bv = a.need_b ? Bx[a.b_iso ? 0 : q] : (T)0;
+                const W prod = (W)apply_binop<T>(mult, av, bv);
+                if (monoid == OP_ANY) s_val[h] = prod;
+                else atomic_combine<W>(&s_val[h], prod, monoid);
+            }
+        }
+    }
+    if (!NUMERIC) {
+        if (my_new) atomicAdd(&s_cnt, my_new);
+        __syncthreads();
+        if (tid == 0) a.row_nnz[row] = s_cnt;
+        return;
+    }
+    __syncthreads();
+    // ---- compact the occupied keys, sort them, emit (col, value) in column order ------------------------
+    for (int k = tid; k < TABLE; k += MM_BLOCK) {
+        const int key = s_key[k];
+        if (key >= 0) s_sorted[atomicAdd(&s_cnt, 1)] = key;
+    }
+    __syncthreads();
+    const int cnt = s_cnt;
+    int np2 = 1;
+    while (np2 < cnt) np2 <<= 1;
+    for (int k = cnt + tid; k < np2; k += MM_BLOCK) s_sorted[k] = 0x7fffffff;
+    __syncthreads();
+    for (int size = 2; size <= np2; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = tid; t < (np2 >> 1); t += MM_BLOCK) {
+                const int lo = 2 * t - (t & (stride - 1));
+                const int hi = lo + stride;
+                const bool up = ((lo & size) == 0);
+                const int x = s_sorted[lo], y = s_sorted[hi];
+                if ((x > y) == up) { s_sorted[lo] = y; s_sorted[hi] = x; }
+            }
+            __syncthreads();
+        }
+    }
+    const int64_t base = a.Tp[row];
+    T *Tx = (T *)a.Tx;
+    for (int k = tid; k < cnt; k += MM_BLOCK) {
+        const int key = s_sorted[k];
+        unsigned h = hash_col(key, TABLE - 1);
+        while (s_key[h] != key) h = (h + 1) & (TABLE - 1);
+        a.Tj[base + k] = key;
+        Tx[base + k] = from_acc<T, W>(s_val[h]);
+    }
+}
+
+// ---- dense-accumulator (SPA) kernels for hub rows ------------------------------------------------------------------
+// Persistent workgroups: workgroup b owns slice b of spa_bits / spa_vals and walks rows b, b+G, ...
+template <typename T, bool NUMERIC>
+__global__ __launch_bounds__(MM_BLOCK) void k_spgemm_spa(const MxmArgs a, const uint32_t *rows, int64_t nrows_bin)
+{
+    using W = typename Widen<T>::type;
+    __shared__ int s_cnt;
+    __shared__ int s_wave[MM_BLOCK / 64];
+    __shared__ long long s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int monoid = a.monoid, mult = a.mult;
+    const T *Ax = (const T *)a.Ax, *Bx = (const T *)a.Bx;
+    unsigned long long *bits = (unsigned long long *)(a.spa_bits + (int64_t)blockIdx.x * a.spa_words);
+    W *vals = NUMERIC ? ((W *)a.spa_vals + (int64_t)blockIdx.x * a.spa_words * 64) : nullptr;
+    const int g = tid / MM_GROUP, gl = tid % MM_GROUP;
+    for (int64_t r = blockIdx.x; r < nrows_bin; r += gridDim.x) {
+        const int64_t row = rows[r];
+        if (tid == 0) { s_cnt = 0; s_base = 0; }
+        __syncthreads();
+        int my_new = 0;
+        for (int64_t p = a.Ap[row] + g; p < a.Ap[row + 1]; p += MM_BLOCK / MM_GROUP) {
+            const int k = a.Aj[p];
+            const T av = a.need_a ? Ax[a.a_iso ? 0 : p] : (T)0;
+            for (int64_t q = a.Bp[k] + gl; q < a.Bp[k + 1]; q += MM_GROUP) {
+                const int j = a.Bj[q];
+                const unsigned long long bit = 1ull << (j & 63);
+                const unsigned long long old = atomicOr(&bits[j >> 6], bit);
+                if (!(old & bit)) my_new++;
+                if (NUMERIC) {
+                    const T bv = a.need_b ? Bx[a.b_iso ? 0 : q] : (T)0;
+                    const W prod = (W)apply_binop<T>(mult, av, bv);
+                    if (monoid == OP_ANY) vals[j] = prod;
+                    else atomic_combine<W>(&vals[j], prod, monoid);
+                }
+            }
+        }
+        if (!NUMERIC) {
+            if (my_new) atomicAdd(&s_cnt, my_new);
+            __syncthreads();
+            if (tid == 0) a.row_nnz[row] = s_cnt;
+            // clear the touched words again (second walk over the same products)
+            for (int64_t p = a.Ap[row] + g; p < a.Ap[row + 1]; p += MM_BLOCK / MM_GROUP) {
+                const int k = a.Aj[p];
+                for (int64_t q = a.Bp[k] + gl; q < a.Bp[k + 1]; q += MM_GROUP) bits[a.Bj[q] >> 6] = 0ull;
+            }
+            __syncthreads();
+            continue;
+        }
+        __syncthreads();
+        // ordered sweep of the presence words: emit sorted (col, value), restore identity / zero
+        const int64_t out0 = a.Tp[row];
+        T *Tx = (T *)a.Tx;
+        const W ident = monoid_identity<T, W>(monoid);
+        for (int64_t w0 = 0; w0 < a.spa_words; w0 += MM_BLOCK) {
+            const int64_t w = w0 + tid;
+            unsigned long long b = (w < a.spa_words) ? bits[w] : 0ull;
+            const int c = __popcll(b);
+            // workgroup exclusive scan of c: wave scan by shuffles, then the 4 wave totals through LDS
+            int incl = c;
+            for (int off = 1; off < 64; off <<= 1) {
+                const int t = __shfl_up(incl, off);
+                if (lane >= off) incl += t;
+            }
+            if (lane == 63) s_wave[wv] = incl;
+            __syncthreads();
+            int wave_off = 0;
+            for (int x = 0; x < wv; x++) wave_off += s_wave[x];
+            int total = 0;
+            for (int x = 0; x < MM_BLOCK / 64; x++) total += s_wave[x];
+            int64_t o = out0 + s_base + wave_off + (incl - c);
+            if (b) {
+                bits[w] = 0ull;
+                while (b) {
+                    const int t = __ffsll(b) - 1;
+                    b &= b - 1;
+                    const int64_t j = w * 64 + t;
+                    a.Tj[o] = (int32_t)j;
+                    Tx[o] = from_acc<T, W>(vals[j]);
+                    vals[j] = ident;
+                    o++;
+                }
+            }
+            __syncthreads();
+            if (tid == 0) s_base += total;
+            __syncthreads();
+        }
+    }
+}
+
+template <typename W>
+__global__ void k_fill_ident(W *p, int64_t n, W v)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// ---- write rule on sorted CSR rows: one thread per row, two passes (count / fill) -------------------------------------
+template <typename TM>
+__device__ __forceinline__ bool mask_true_at(const TM *Mx, int m_iso, int64_t p) { return Mx[m_iso ? 0 : p] != (TM)0; }
+
+template <typename T, bool FILL>
+__global__ void k_mat_write(int64_t m, const int64_t *Cp, const int32_t *Cj, const T *Cx, int c_iso, const int64_t *Tp,
+                            const int32_t *Tj, const T *Tx, const int64_t *Mp, const int32_t *Mj, const void *Mx, int m_type,
+                            int m_iso, int has_mask, int m_struct, int m_comp, int accum, int replace, int64_t *Ncount,
+                            const int64_t *Np, int32_t *Nj, T *Nx)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    int64_t pc = Cp ? Cp[i] : 0, ec = Cp ? Cp[i + 1] : 0, pt = Tp[i], et = Tp[i + 1];
+    int64_t pm = has_mask ? Mp[i] : 0, em = has_mask ? Mp[i + 1] : 0;
+    int64_t o = FILL ? Np[i] : 0, cnt = 0;
+    while (pc < ec || pt < et) {
+        const int jc = pc < ec ? Cj[pc] : 0x7fffffff, jt = pt < et ? Tj[pt] : 0x7fffffff;
+        const int j = jc < jt ? jc : jt;
+        const bool hc = (jc == j), ht = (jt == j);
+        bool mk = true;
+        if (has_mask) {
+            while (pm < em && Mj[pm] < j) pm++;
+            mk = (pm < em && Mj[pm] == j);
+            if (mk && !m_struct) {
+                switch (m_type) {
+                case TC_BOOL: case TC_INT8: case TC_UINT8: mk = mask_true_at<uint8_t>((const uint8_t *)Mx, m_iso, pm); break;
+                case TC_INT16: case TC_UINT16: mk = mask_true_at<uint16_t>((const uint16_t *)Mx, m_iso, pm); break;
+                case TC_INT32: case TC_UINT32: mk = mask_true_at<uint32_t>((const uint32_t *)Mx, m_iso, pm); break;
+                case TC_INT64: case TC_UINT64: mk = mask_true_at<uint64_t>((const uint64_t *)Mx, m_iso, pm); break;
+                case TC_FP32: mk = mask_true_at<float>((const float *)Mx, m_iso, pm); break;
+                default: mk = mask_true_at<double>((const double *)Mx, m_iso, pm); break;
+                }
+            }
+            if (m_comp) mk = !mk;
+        }
+        bool zh = false;
+        T zv = (T)0;
+        if (mk) {
+            if (accum >= 0) {
+                const T cv = hc ? Cx[c_iso ? 0 : pc] : (T)0;
+                if (hc && ht) { zh = true; zv = apply_binop<T>(accum, cv, Tx[pt]); }
+                else if (hc) { zh = true; zv = cv; }
+                else { zh = true; zv = Tx[pt]; }
+            } else if (ht) { zh = true; zv = Tx[pt]; }
+        } else if (!replace && hc) { zh = true; zv = Cx[c_iso ? 0 : pc]; }
+        if (zh) {
+            if (FILL) { Nj[o + cnt] = j; Nx[o + cnt] = zv; }
+            cnt++;
+        }
+        if (hc) pc++;
+        if (ht) pt++;
+    }
+    if (!FILL) Ncount[i] = cnt;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------
+struct RowBins {
+    DevBuf<uint32_t> rows;
+    int64_t start[6];
+    explicit RowBins(int64_t m) : rows(m) {}
+    int64_t count(int b) const { return start[b + 1] - start[b]; }
+    const uint32_t *ptr(int b) const { return rows.p + start[b]; }
+};
+
+// stable sort of rows by bin(size): rows inside a bin stay in increasing order
+static void make_bins(RowBins &rb, const int64_t *Ap, const int64_t *F, int64_t m, int64_t *size, int64_t b1, int64_t b2,
+                      int64_t b3)
+{
+    DevBuf<uint64_t> key(m), key2(m);
+    DevBuf<uint32_t> rid(m);
+    hipLaunchKernelGGL(k_row_bins, dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, ctx().stream, Ap, F, m, size, b1, b2, b3,
+                       key.p, rid.p);
+    prim_sort_pairs_u64_u32(key.p, key2.p, rid.p, rb.rows.p, m, 3);
+    DevBuf<int64_t> bs(6);
+    hipLaunchKernelGGL(k_bin_starts, dim3(1), dim3(64), 0, ctx().stream, key2.p, m, bs.p);
+    d2h(rb.start, bs.p, sizeof(int64_t) * 6);
+    ctx().stats.kernel_launches += 2;
+}
+
+template <typename T, bool NUMERIC>
+static void run_bins(MxmArgs &a, const RowBins &rb)
+{
+    using W = typename Widen<T>::type;
+    constexpr int T1 = 256, T2 = 2048, T3 = NUMERIC ? 8192 : 32768;
+    if (rb.count(1)) hipLaunchKernelGGL((k_spgemm_hash<T, T1, NUMERIC>), dim3((unsigned)rb.count(1)), dim3(MM_BLOCK), 0, ctx().stream, a, rb.ptr(1));
+    if (rb.count(2)) hipLaunchKernelGGL((k_spgemm_hash<T, T2, NUMERIC>), dim3((unsigned)rb.count(2)), dim3(MM_BLOCK), 0, ctx().stream, a, rb.ptr(2));
+    if (rb.count(3)) hipLaunchKernelGGL((k_spgemm_hash<T, T3, NUMERIC>), dim3((unsigned)rb.count(3)), dim3(MM_BLOCK), 0, ctx().stream, a, rb.ptr(3));
+    ctx().stats.kernel_launches += 3;
+    if (rb.count(4)) {
+        // dense accumulators: as many workgroup slices as fit in ~12 GiB, at most 512
+        const int64_t words = (int64_t)bits_words64((uint64_t)a.n);
+        const int64_t slice_bytes = words * 8 + (NUMERIC ? words * 64 * (int64_t)sizeof(W) : 0);
+        int64_t G = std::min<int64_t>(std::min<int64_t>(512, rb.count(4)), std::max<int64_t>(1, (12ll << 30) / slice_bytes));
+        DevBuf<uint64_t> bits((size_t)(G * words), true);
+        DevBuf<W> vals(NUMERIC ? (size_t)(G * words * 64) : 1);
+        if (NUMERIC) {
+            const int64_t nv = G * words * 64;
+            hipLaunchKernelGGL((k_fill_ident<W>), dim3((unsigned)ceil_div(nv, 256)), dim3(256), 0, ctx().stream, vals.p, nv,
+                               monoid_identity<T, W>(a.monoid));
+        }
+        a.spa_bits = bits.p;
+        a.spa_vals = vals.p;
+        a.spa_words = words;
+        hipLaunchKernelGGL((k_spgemm_spa<T, NUMERIC>), dim3((unsigned)G), dim3(MM_BLOCK), 0, ctx().stream, a, rb.ptr(4), rb.count(4));
+        ctx().stats.kernel_launches += 2;
+        sync_stream();  // slices are freed when this scope ends
+    }
+    GRB_HIP(hipGetLastError());
+}
+
+// T = A (+.x) B in the semiring's type; returns a fresh matrix (sorted rows)
+template <typename T>
+static GB_Matrix_opaque *spgemm(GB_Matrix_opaque *A, const void *Ax, GB_Matrix_opaque *B, const void *Bx, int st, int monoid,
+                                int mult)
+{
+    GB_Matrix_opaque *Tm = matrix_new(type_of_code(st), A->nrows, B->ncols);
+    if (A->nvals == 0 || B->nvals == 0) return Tm;
+    try {
+        const int64_t m = (int64_t)A->nrows, nnzA = A->nvals;
+        MxmArgs a{};
+        a.m = m;
+        a.n = (int64_t)B->ncols;
+        a.Ap = A->d_ptr; a.Aj = A->d_col; a.Ax = Ax; a.a_iso = A->iso ? 1 : 0;
+        a.Bp = B->d_ptr; a.Bj = B->d_col; a.Bx = Bx; a.b_iso = B->iso ? 1 : 0;
+        a.monoid = monoid;
+        a.mult = mult;
+        a.need_a = !(mult == OP_PAIR || mult == OP_SECOND);
+        a.need_b = !(mult == OP_PAIR || mult == OP_FIRST || mult == OP_ANY);
+        // 1. flops per stored entry of A, scanned
+        DevBuf<int64_t> F(nnzA + 1);
+        hipLaunchKernelGGL(k_nnz_flops, dim3((unsigned)ceil_div(nnzA + 1, 256)), dim3(256), 0, ctx().stream, A->d_col, nnzA,
+                           B->d_ptr, F.p);
+        prim_exclusive_sum_i64(F.p, F.p, nnzA + 1);
+        int64_t flops = 0;
+        d2h(&flops, F.p + nnzA, sizeof(int64_t));
+        ctx().stats.flops = flops;
+        // 2./3. symbolic
+        DevBuf<int64_t> rownnz(m + 1, true);
+        a.row_nnz = rownnz.p;
+        {
+            RowBins rb(m);
+            make_bins(rb, A->d_ptr, F.p, m, rownnz.p, 128, 1024, 16384);
+            GRB_HIP(hipMemsetAsync(rownnz.p, 0, sizeof(int64_t) * (m + 1), ctx().stream));
+            run_bins<T, false>(a, rb);
+        }
+        // 4. row pointers of T (counts stay in rownnz for the numeric binning)
+        int64_t *Tp = (int64_t *)dev_alloc(sizeof(int64_t) * (m + 1));
+        prim_exclusive_sum_i64(rownnz.p, Tp, m + 1);
+        int64_t nnzT = 0;
+        d2h(&nnzT, Tp + m, sizeof(int64_t));
+        Tm->d_ptr = Tp;
+        ctx().stats.out_nvals = nnzT;
+        if (nnzT == 0) {
+            dev_free(Tm->d_ptr);
+            Tm->d_ptr = nullptr;
+            return Tm;
+        }
+        Tm->d_col = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)nnzT);
+        Tm->d_val = dev_alloc(sizeof(T) * (size_t)nnzT);
+        Tm->nvals = nnzT;
+        a.Tp = Tp;
+        a.Tj = Tm->d_col;
+        a.Tx = Tm->d_val;
+        // 5. numeric, binned by the exact row sizes
+        {
+            RowBins rb(m);
+            make_bins(rb, A->d_ptr, nullptr, m, rownnz.p, 128, 1024, 4096);
+            run_bins<T, true>(a, rb);
+        }
+    } catch (...) {
+        matrix_free(Tm);
+        throw;
+    }
+    return Tm;
+}
+
+struct MDesc {
+    bool replace = false, comp = false, structure = false, t0 = false, t1 = false;
+};
+
+static void take_storage(GB_Matrix_opaque *C, GB_Matrix_opaque *src)
+{
+    matrix_release_storage(C);
+    C->d_ptr = src->d_ptr; C->d_col = src->d_col; C->d_val = src->d_val;
+    C->nvals = src->nvals; C->iso = src->iso; C->owns = true;
+    src->d_ptr = nullptr; src->d_col = nullptr; src->d_val = nullptr; src->nvals = 0;
+}
+
+static void mxm_core(GB_Matrix_opaque *C, GB_Matrix_opaque *Mask, const GB_BinaryOp_opaque *accum,
+                     const GB_Semiring_opaque *sr, GB_Matrix_opaque *A, GB_Matrix_opaque *B, MDesc f)
+{
+    GB_Matrix_opaque *Ae = f.t0 ? matrix_transpose_cached(A) : A;
+    GB_Matrix_opaque *Be = f.t1 ? matrix_transpose_cached(B) : B;
+    if (Ae->ncols != Be->nrows) fail(GrB_DIMENSION_MISMATCH, "mxm: inner dimensions " + std::to_string(Ae->ncols) + " and " + std::to_string(Be->nrows) + " differ");
+    if (C->nrows != Ae->nrows || C->ncols != Be->ncols) fail(GrB_DIMENSION_MISMATCH, "mxm: output is " + std::to_string(C->nrows) + "x" + std::to_string(C->ncols) + ", product is " + std::to_string(Ae->nrows) + "x" + std::to_string(Be->ncols));
+    if (Mask && (Mask->nrows != C->nrows || Mask->ncols != C->ncols)) fail(GrB_DIMENSION_MISMATCH, "mxm: mask shape does not match the output");
+    if (accum && accum->type != C->type->code) fail(GrB_DOMAIN_MISMATCH, "mxm: accum operator type must equal the output type");
+    ctx().stats = GrX_Stats{};
+    ctx().stats.method = 3;
+    if (!Mask && f.comp) {
+        if (f.replace) matrix_release_storage(C);
+        return;
+    }
+    const int st = sr->type;
+    const int monoid = canonical_op(st, sr->monoid), mult = canonical_op(st, sr->mult);
+    // operands in the semiring's type
+    DevBuf<char> a_cast(0), b_cast(0);
+    const void *Ax = Ae->d_val, *Bx = Be->d_val;
+    if (Ae->nvals && Ae->type->code != st) {
+        const int64_t nv = Ae->iso ? 1 : Ae->nvals;
+        dev_free(a_cast.p);
+        a_cast.p = (char *)dev_alloc(type_size(st) * (size_t)nv);
+        cast_array(st, a_cast.p, Ae->type->code, Ae->d_val, nv);
+        Ax = a_cast.p;
+    }
+    if (Be->nvals && Be->type->code != st) {
+        const int64_t nv = Be->iso ? 1 : Be->nvals;
+        dev_free(b_cast.p);
+        b_cast.p = (char *)dev_alloc(type_size(st) * (size_t)nv);
+        cast_array(st, b_cast.p, Be->type->code, Be->d_val, nv);
+        Bx = b_cast.p;
+    }
+    GB_Matrix_opaque *Tm = nullptr;
+    GRB_DISPATCH_TYPE(st, T, { Tm = spgemm<T>(Ae, Ax, Be, Bx, st, monoid, mult); })
+    try {
+        // T in the output type
+        if (Tm->nvals && Tm->type->code != C->type->code) {
+            void *cv = dev_alloc(C->type->size * (size_t)Tm->nvals);
+            cast_array(C->type->code, cv, st, Tm->d_val, Tm->nvals);
+            dev_free(Tm->d_val);
+            Tm->d_val = cv;
+        }
+        Tm->type = C->type;
+        if (!Mask && !accum) {
+            take_storage(C, Tm);  // C = T (aliasing with A/B is safe: T is a fresh object)
+        } else {
+            const int64_t m = (int64_t)C->nrows;
+            const int64_t *Tp = matrix_rowptr(Tm);
+            const int acc_op = accum ? canonical_op(C->type->code, accum->op) : -1;
+            const int64_t *Mp = Mask ? matrix_rowptr(Mask) : nullptr;
+            GB_Matrix_opaque *N = matrix_new(C->type, C->nrows, C->ncols);
+            try {
+                DevBuf<int64_t> cnt(m + 1, true);
+                int64_t *Np = (int64_t *)dev_alloc(sizeof(int64_t) * (m + 1));
+                N->d_ptr = Np;
+                int64_t nnzN = 0;
+                GRB_DISPATCH_TYPE(C->type->code, TW, {
+                    const dim3 grid((unsigned)ceil_div(m, 256)), block(256);
+                    hipLaunchKernelGGL((k_mat_write<TW, false>), grid, block, 0, ctx().stream, m, (const int64_t *)C->d_ptr,
+                                       (const int32_t *)C->d_col, (const TW *)C->d_val, C->iso ? 1 : 0, Tp,
+                                       (const int32_t *)Tm->d_col, (const TW *)Tm->d_val, Mp,
+                                       Mask ? (const int32_t *)Mask->d_col : nullptr, Mask ? (const void *)Mask->d_val : nullptr,
+                                       Mask ? Mask->type->code : 0, Mask && Mask->iso ? 1 : 0, Mask ? 1 : 0,
+                                       f.structure ? 1 : 0, f.comp ? 1 : 0, acc_op, f.replace ? 1 : 0, cnt.p,
+                                       (const int64_t *)nullptr, (int32_t *)nullptr, (TW *)nullptr);
+                    prim_exclusive_sum_i64(cnt.p, Np, m + 1);
+                    d2h(&nnzN, Np + m, sizeof(int64_t));
+                    if (nnzN) {
+                        N->d_col = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)nnzN);
+                        N->d_val = dev_alloc(sizeof(TW) * (size_t)nnzN);
+                        hipLaunchKernelGGL((k_mat_write<TW, true>), grid, block, 0, ctx().stream, m, (const int64_t *)C->d_ptr,
+                                           (const int32_t *)C->d_col, (const TW *)C->d_val, C->iso ? 1 : 0, Tp,
+                                           (const int32_t *)Tm->d_col, (const TW *)Tm->d_val, Mp,
+                                           Mask ? (const int32_t *)Mask->d_col : nullptr,
+                                           Mask ? (const void *)Mask->d_val : nullptr, Mask ? Mask->type->code : 0,
+                                           Mask && Mask->iso ? 1 : 0, Mask ? 1 : 0, f.structure ? 1 : 0, f.comp ? 1 : 0, acc_op,
+                                           f.replace ? 1 : 0, (int64_t *)nullptr, (const int64_t *)Np, N->d_col, (TW *)N->d_val);
+                    }
+                })
+                N->nvals = nnzN;
+                ctx().stats.kernel_launches += 2;
+                if (nnzN == 0) {
+                    dev_free(N->d_ptr);
+                    N->d_ptr = nullptr;
+                }
+                sync_stream();
+                take_storage(C, N);
+            } catch (...) {
+                matrix_free(N);
+                throw;
+            }
+            matrix_free(N);
+        }
+    } catch (...) {
+        matrix_free(Tm);
+        throw;
+    }
+    matrix_free(Tm);
+    if (ctx().blocking) sync_stream();
+}
+
+}  // namespace grb
+
 using namespace grb;
-extern "C" GrB_Info GrB_mxm(GrB_Matrix C, const GrB_Matrix, const GrB_BinaryOp, const GrB_Semiring, const GrB_Matrix,
-                            const GrB_Matrix, const GrB_Descriptor)
+
+extern "C" GrB_Info GrB_mxm(GrB_Matrix C, const GrB_Matrix Mask, const GrB_BinaryOp accum, const GrB_Semiring semiring,
+                            const GrB_Matrix A, const GrB_Matrix B, const GrB_Descriptor desc)
 {
     GRB_TRY
-    fail(GrB_NOT_IMPLEMENTED, "GrB_mxm: not built yet");
+    require_init();
+    check_matrix(C, "C");
+    if (Mask) check_matrix(Mask, "Mask");
+    check_matrix(A, "A");
+    check_matrix(B, "B");
+    if (!semiring) fail(GrB_NULL_POINTER, "semiring is NULL");
+    MDesc f;
+    if (desc) { f.replace = desc->replace; f.comp = desc->comp; f.structure = desc->structure; f.t0 = desc->t0; f.t1 = desc->t1; }
+    mxm_core(C, Mask, accum, semiring, A, B, f);
     GRB_CATCH(errp(C))
 }

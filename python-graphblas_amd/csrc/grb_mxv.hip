@@ -57,36 +57,6 @@ struct PullArgs {
     uint8_t *first_has;  // bit0: has a partial, bit1: the tile's first row started in an earlier tile
 };
 
-template <typename T, typename W>
-__device__ __forceinline__ T from_acc(W v)
-{
-    if constexpr (std::is_same<T, bool>::value) return v != (W)0;
-    else return (T)v;
-}
-
-// slot = monoid(slot, v) on an LDS (or global) word, compare-and-swap loop
-template <typename W>
-__device__ __forceinline__ void atomic_combine(W *slot, W v, int monoid)
-{
-    if constexpr (sizeof(W) == 4) {
-        unsigned int *p = (unsigned int *)slot;
-        unsigned int old = *p, assumed;
-        do {
-            assumed = old;
-            const W nw = apply_binop<W>(monoid, __builtin_bit_cast(W, assumed), v);
-            old = atomicCAS(p, assumed, __builtin_bit_cast(unsigned int, nw));
-        } while (old != assumed);
-    } else {
-        unsigned long long *p = (unsigned long long *)slot;
-        unsigned long long old = *p, assumed;
-        do {
-            assumed = old;
-            const W nw = apply_binop<W>(monoid, __builtin_bit_cast(W, assumed), v);
-            old = atomicCAS(p, assumed, __builtin_bit_cast(unsigned long long, nw));
-        } while (old != assumed);
-    }
-}
-
 // rows consumed by the merge path at diagonal `diag` (row-end list vs nnz list)
 __global__ void k_tile_table(const int64_t *rowptr, int64_t m, int64_t nnz, int tile, int64_t n_tiles, int64_t *tile_row)
 {

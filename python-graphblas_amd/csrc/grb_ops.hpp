@@ -169,6 +169,37 @@ GRB_HD D cast_value(S s)
     default: ::grb::fail(GrB_INVALID_OBJECT, "unknown type code");                    \
     }
 
+// ---- accumulator helpers (device only) ----------------------------------------------------------------
+template <typename T, typename W>
+__device__ __forceinline__ T from_acc(W v)
+{
+    if constexpr (std::is_same<T, bool>::value) return v != (W)0;
+    else return (T)v;
+}
+
+// slot = monoid(slot, v) on an LDS (or global) word, compare-and-swap loop
+template <typename W>
+__device__ __forceinline__ void atomic_combine(W *slot, W v, int monoid)
+{
+    if constexpr (sizeof(W) == 4) {
+        unsigned int *p = (unsigned int *)slot;
+        unsigned int old = *p, assumed;
+        do {
+            assumed = old;
+            const W nw = apply_binop<W>(monoid, __builtin_bit_cast(W, assumed), v);
+            old = atomicCAS(p, assumed, __builtin_bit_cast(unsigned int, nw));
+        } while (old != assumed);
+    } else {
+        unsigned long long *p = (unsigned long long *)slot;
+        unsigned long long old = *p, assumed;
+        do {
+            assumed = old;
+            const W nw = apply_binop<W>(monoid, __builtin_bit_cast(W, assumed), v);
+            old = atomicCAS(p, assumed, __builtin_bit_cast(unsigned long long, nw));
+        } while (old != assumed);
+    }
+}
+
 // ---- presence-bit helpers -------------------------------------------------------------------------
 GRB_HD bool bit_test(const uint32_t *bits, int64_t i) { return (bits[i >> 5] >> (i & 31)) & 1u; }
 

@@ -190,3 +190,76 @@ def test_edge_shapes(gb):
     w(accum=gb.binary.plus) << A.mxv(gb.Vector.from_dense(np.array([10.0, 20.0])), S.plus_times)
     d = w.to_dense()
     assert d[5] == 21.0 and d[m - 1] == 61.0 and d.sum() == m + 20 + 60
+
+
+def same_mat(got, exp):
+    I, J, X = got.to_coo()
+    er, ec, ev = exp.to_coo()
+    assert got.shape == (exp.nrows, exp.ncols)
+    assert I.tolist() == er.tolist() and J.tolist() == ec.tolist()
+    assert X.tolist() == ev.tolist()
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_mxm_random(gb, seed):
+    """Hash SpGEMM (all LDS table sizes + the dense-accumulator path for hub rows) and the matrix write rule."""
+    rng = np.random.default_rng(500 + seed)
+    tname = TYPES[seed % 7]
+    srs = semirings_for(tname)
+    sr = srs[rng.integers(len(srs))]
+    m, k, n = (int(x) for x in rng.integers(1, 400, 3))
+    if seed % 6 == 0:
+        m, k, n = (int(x) for x in rng.integers(1, 12, 3))
+    big = seed % 4 == 1  # rows whose product exceeds the LDS tables (ub > 16384, nnz(T_i) > 4096)
+    if big:
+        m, k, n = 40, 700, 9000
+    ar, ac, av = rand_coo(rng, m, k, tname, long_rows=2 if big else int(rng.integers(0, 2)))
+    br, bc, bv = rand_coo(rng, k, n, tname, long_rows=int(rng.integers(0, 3)))
+    if big:  # dense-ish B rows so that one A row yields thousands of distinct columns
+        deg = rng.integers(20, 60, k)
+        br = np.repeat(np.arange(k), deg)
+        bc = np.concatenate([rng.choice(n, d, replace=False) for d in deg])
+        bv = rand_vals(rng, br.size, tname)
+    cr, cc, cv = rand_coo(rng, m, n, tname)
+    mr, mc, mv = rand_coo(rng, m, n, "INT8", long_rows=1)
+    use_mask = seed % 3 != 0
+    comp, struct, repl = (bool(x) for x in rng.integers(0, 2, 3))
+    accum = [None, "plus", "min", "second"][rng.integers(4)]
+    use_c = bool(rng.integers(2)) or accum is not None
+    oa, ob = O.OMat.from_coo(ar, ac, av, m, k, tname), O.OMat.from_coo(br, bc, bv, k, n, tname)
+    oc = O.OMat.from_coo(cr, cc, cv, m, n, tname) if use_c else None
+    om = O.OMat.from_coo(mr, mc, mv, m, n, "INT8")
+    exp = O.mxm(oa, ob, sr, C=oc, mask=om if use_mask else None, mask_comp=comp and use_mask, mask_struct=struct,
+                accum=accum, replace=repl and use_mask)
+    A = gb.Matrix.from_coo(ar, ac, av, dtype=tname, nrows=m, ncols=k)
+    B = gb.Matrix.from_coo(br, bc, bv, dtype=tname, nrows=k, ncols=n)
+    C = gb.Matrix.from_coo(cr, cc, cv, dtype=tname, nrows=m, ncols=n) if use_c else gb.Matrix(tname, m, n)
+    kw = {}
+    if use_mask:
+        M = gb.Matrix.from_coo(mr, mc, mv, dtype="INT8", nrows=m, ncols=n)
+        mm = M.S if struct else M.V
+        kw = dict(mask=~mm if comp else mm, replace=repl)
+    if accum:
+        kw["accum"] = accum
+    C(**kw) << A.mxm(B, getattr(gb.semiring, sr))
+    same_mat(C, exp)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_mxm_transposes_and_types(gb, seed):
+    rng = np.random.default_rng(600 + seed)
+    ta, tb, tc = [("INT64", "INT64", "INT64"), ("INT8", "UINT16", "INT64"), ("FP32", "INT32", "FP64"),
+                  ("BOOL", "BOOL", "INT32"), ("INT32", "INT32", "FP32"), ("FP64", "FP64", "FP64")][seed]
+    sr = ["plus_times", "min_plus", "max_plus", "lor_land", "plus_pair", "min_second"][seed]
+    m, k, n = (int(x) for x in rng.integers(1, 200, 3))
+    ta_, tb_ = bool(seed & 1), bool(seed & 2)
+    ar, ac, av = rand_coo(rng, *((k, m) if ta_ else (m, k)), ta, long_rows=1)
+    br, bc, bv = rand_coo(rng, *((n, k) if tb_ else (k, n)), tb, long_rows=1)
+    oa = O.OMat.from_coo(ar, ac, av, *((k, m) if ta_ else (m, k)), ta)
+    ob = O.OMat.from_coo(br, bc, bv, *((n, k) if tb_ else (k, n)), tb)
+    exp = O.mxm(oa, ob, sr, out_type=tc, transpose_a=ta_, transpose_b=tb_)
+    A = gb.Matrix.from_coo(ar, ac, av, dtype=ta, nrows=oa.nrows, ncols=oa.ncols)
+    B = gb.Matrix.from_coo(br, bc, bv, dtype=tb, nrows=ob.nrows, ncols=ob.ncols)
+    C = (A.T if ta_ else A).mxm(B.T if tb_ else B, getattr(gb.semiring, sr)).new(dtype=tc)
+    assert C.dtype == tc
+    same_mat(C, exp)

@@ -222,3 +222,109 @@ def test_roundtrips(gb):
     vd = gb.Vector.from_dense(d)
     assert vd.nvals == 50 and np.array_equal(vd.to_dense(), d)
     assert gb.Vector(float, 5).nvals == 0
+
+
+# ---- mxm ------------------------------------------------------------------------------------------------
+def test_mxm(gb, A):
+    # graphblas/tests/test_matrix.py:307-314
+    C = A.mxm(A, gb.semiring.plus_times).new()
+    result = gb.Matrix.from_coo(
+        [0, 0, 0, 0, 1, 1, 1, 1, 2, 3, 3, 3, 4, 5, 6, 6, 6],
+        [0, 2, 4, 6, 2, 3, 4, 5, 2, 1, 3, 5, 2, 5, 0, 2, 5],
+        [9, 9, 16, 8, 20, 28, 12, 56, 1, 6, 9, 3, 7, 1, 21, 21, 26],
+    )
+    assert C.isequal(result)
+
+
+def test_mxm_transpose(gb, A):
+    # graphblas/tests/test_matrix.py:317-332
+    C = A.dup()
+    C << A.mxm(A.T, gb.semiring.plus_times)
+    result = gb.Matrix.from_coo(
+        [0, 0, 1, 1, 2, 2, 3, 3, 3, 4, 4, 5, 5, 5, 6, 6, 6, 6, 6],
+        [0, 6, 1, 6, 2, 4, 3, 5, 6, 2, 4, 3, 5, 6, 0, 1, 3, 5, 6],
+        [13, 21, 80, 24, 1, 7, 18, 3, 15, 7, 49, 3, 1, 5, 21, 24, 15, 5, 83],
+    )
+    assert C.isequal(result)
+    C << A.T.mxm(A, gb.semiring.plus_times)
+    result2 = gb.Matrix.from_coo(
+        [0, 0, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 6, 6],
+        [0, 2, 1, 3, 0, 2, 3, 4, 1, 2, 3, 4, 2, 3, 4, 6, 5, 4, 6],
+        [9, 9, 4, 6, 9, 35, 35, 15, 6, 35, 58, 21, 15, 21, 73, 32, 50, 32, 16],
+    )
+    assert C.isequal(result2)
+
+
+def test_mxm_nonsquare(gb):
+    # graphblas/tests/test_matrix.py:335-345
+    A = gb.Matrix.from_coo([0, 0, 0], [0, 2, 4], [1, 2, 3], nrows=1, ncols=5)
+    B = gb.Matrix.from_coo([0, 2, 4], [0, 0, 0], [10, 20, 30], nrows=5, ncols=1)
+    C = gb.Matrix(A.dtype, nrows=1, ncols=1)
+    C << A.mxm(B, gb.semiring.max_plus)
+    assert C.to_coo()[2].tolist() == [33]
+    C1 = A.mxm(B, gb.semiring.max_plus).new()
+    assert C1.isequal(C)
+    C2 = A.T.mxm(B.T, gb.semiring.max_plus).new()
+    assert C2.nrows == 5
+    assert C2.ncols == 5
+
+
+def test_mxm_mask(gb, A):
+    # graphblas/tests/test_matrix.py:348-374
+    Matrix, semiring = gb.Matrix, gb.semiring
+    val_mask = Matrix.from_coo([0, 3, 4], [2, 3, 2], [True, True, True], nrows=7, ncols=7)
+    struct_mask = Matrix.from_coo([0, 3, 4], [2, 3, 2], [1, 0, 0], nrows=7, ncols=7)
+    C = A.dup()
+    C(val_mask.V) << A.mxm(A, semiring.plus_times)
+    result = Matrix.from_coo(
+        [0, 0, 0, 1, 1, 2, 3, 3, 3, 4, 4, 5, 6, 6, 6],
+        [1, 2, 3, 4, 6, 5, 0, 2, 3, 2, 5, 2, 2, 3, 4],
+        [2, 9, 3, 8, 4, 1, 3, 3, 9, 7, 7, 1, 5, 7, 3],
+    )
+    assert C.isequal(result)
+    C = A.dup()
+    C(~val_mask.V) << A.mxm(A, semiring.plus_times)
+    result2 = Matrix.from_coo(
+        [0, 0, 0, 1, 1, 1, 1, 2, 3, 3, 5, 6, 6, 6],
+        [0, 4, 6, 2, 3, 4, 5, 2, 1, 5, 5, 0, 2, 5],
+        [9, 16, 8, 20, 28, 12, 56, 1, 6, 3, 1, 21, 21, 26],
+    )
+    assert C.isequal(result2)
+    C = A.dup()
+    C(struct_mask.S, replace=True).update(A.mxm(A, semiring.plus_times))
+    result3 = Matrix.from_coo([0, 3, 4], [2, 3, 2], [9, 9, 7], nrows=7, ncols=7)
+    assert C.isequal(result3)
+    C2 = A.mxm(A, semiring.plus_times).new(mask=struct_mask.S)
+    assert C2.isequal(result3)
+    with pytest.raises(TypeError, match="Mask must be"):
+        A.mxm(A).new(mask=struct_mask)  # would be okay if bool mask, but it's not
+
+
+def test_mxm_accum(gb, A):
+    # graphblas/tests/test_matrix.py:377-386 -- C aliased with A
+    A(gb.binary.plus) << A.mxm(A, gb.semiring.plus_times)
+    # fmt: off
+    result = gb.Matrix.from_coo(
+        [0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 3, 3, 3, 3, 3, 4, 4, 5, 5, 6, 6, 6, 6, 6],
+        [0, 1, 2, 3, 4, 6, 2, 3, 4, 5, 6, 2, 5, 0, 1, 2, 3, 5, 2, 5, 2, 5, 0, 2, 3, 4, 5],
+        [9, 2, 9, 3, 16, 8, 20, 28, 20, 56, 4, 1, 1, 3, 6, 3, 9, 3, 7, 7, 1, 1, 21, 26, 7, 3, 26],
+    )
+    # fmt: on
+    assert A.isequal(result)
+
+
+def test_docs_mxm_and_plus_plus(gb):
+    # docs/user_guide/operations.rst:26-75 (cell [2,1] is 5.5 by arithmetic; the doc table prints 5.0 -- see
+    # tests/golden/make_reference_literals.py) and graphblas/tests/test_op.py:462-464
+    A = gb.Matrix.from_coo([0, 0, 1, 1, 2], [1, 2, 2, 3, 3], [2.0, 5.0, 1.5, 4.25, 0.5], nrows=4, ncols=4)
+    B = gb.Matrix.from_coo([0, 0, 1, 1, 2, 2, 3, 3], [1, 2, 0, 1, 1, 2, 0, 1], [3.0, 2.0, 9.0, 6.0, 3.0, 1.0, 0.0, 5.0])
+    C = gb.Matrix(float, A.nrows, B.ncols)
+    C << A.mxm(B, op="min_plus")
+    exp = gb.Matrix.from_coo([0, 0, 0, 1, 1, 1, 2, 2], [0, 1, 2, 0, 1, 2, 0, 1], [11.0, 8.0, 6.0, 4.25, 4.5, 2.5, 0.5, 5.5],
+                             nrows=4, ncols=3)
+    assert C.isequal(exp)
+    C2 = gb.Matrix(float, A.nrows, B.ncols)
+    C2 << gb.semiring.min_plus(A @ B)
+    assert C2.isequal(exp)
+    A2 = gb.Matrix.from_coo([0, 0, 1, 1], [0, 1, 0, 1], [1, 2, 3, 4])
+    assert A2.mxm(A2, gb.semiring.plus_plus).new().isequal(gb.Matrix.from_coo([0, 0, 1, 1], [0, 1, 0, 1], [7, 9, 11, 13]))
