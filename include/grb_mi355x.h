@@ -226,6 +226,10 @@ typedef struct {
     int32_t fused_epilogue;   /* 1 if mask/accum/replace were applied inside the product kernel */
 } GrX_Stats;
 GrB_Info GrX_last_stats(GrX_Stats *stats);
+/* Benchmark diagnostics: kernel ablation switches (0 = product behaviour; non-zero values make results
+ * WRONG on purpose: 1 skips the x gathers, 2 the A staging loads, 4 the epilogue) and the pull SpMV's
+ * merge items per thread (0 = default).  Also read from GRB_DEBUG / GRB_PULL_IPT at GrB_init. */
+GrB_Info GrX_tuning_set(int debug_flags, int pull_items_per_thread);
 const char *GrX_version_string(void);
 
 #ifdef __cplusplus

@@ -2,6 +2,8 @@
 // Counterpart of the reference's `initialize(blocking=..., memory_manager="numpy")` call at
 // graphblas/__init__.py:170-173 (there: SuiteSparse GrB_init on the host; here: a gfx950 device is
 // mandatory -- there is no CPU fallback).
+#include <cstdlib>
+
 #include "grb_internal.hpp"
 
 namespace grb {
@@ -86,6 +88,8 @@ extern "C" GrB_Info GrB_init(GrB_Mode mode)
     }
     (void)hipGetLastError();
     if (hipEventCreate(&c.ev0) != hipSuccess || hipEventCreate(&c.ev1) != hipSuccess) return GrB_PANIC;
+    if (const char *e = getenv("GRB_DEBUG")) c.debug_flags = atoi(e);
+    if (const char *e = getenv("GRB_PULL_IPT")) c.tune_pull_ipt = atoi(e);
     c.initialized = true;
     return GrB_SUCCESS;
 }
@@ -150,6 +154,13 @@ extern "C" GrB_Info GrX_last_stats(GrX_Stats *stats)
 {
     if (!stats) return GrB_NULL_POINTER;
     *stats = ctx().stats;
+    return GrB_SUCCESS;
+}
+
+extern "C" GrB_Info GrX_tuning_set(int debug_flags, int pull_items_per_thread)
+{
+    ctx().debug_flags = debug_flags;
+    ctx().tune_pull_ipt = pull_items_per_thread;
     return GrB_SUCCESS;
 }
 

@@ -59,6 +59,8 @@ struct Context {
     hipStream_t stream = nullptr;  // null stream: ordered with torch's default stream
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     GrX_Stats stats{};
+    int debug_flags = 0;    // GRB_DEBUG: kernel ablation switches (benchmark diagnostics only)
+    int tune_pull_ipt = 0;  // GRB_PULL_IPT: merge items per thread of the pull SpMV (0 = default)
 };
 Context &ctx();
 void require_init();

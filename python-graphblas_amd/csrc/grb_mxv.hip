@@ -55,6 +55,7 @@ struct PullArgs {
     uint8_t *carry_has;
     void *first_val;
     uint8_t *first_has;  // bit0: has a partial, bit1: the tile's first row started in an earlier tile
+    int dbg;             // ablation switches (GRB_DEBUG): 1 = no x gathers, 2 = no A staging loads, 4 = no epilogue
 };
 
 // rows consumed by the merge path at diagonal `diag` (row-end list vs nnz list)
@@ -167,8 +168,8 @@ __global__ __launch_bounds__(PULL_BLOCK) void k_mxv_pull(const PullArgs a)
     if (any_active) {
         // ---- stage this tile's column indices and values, coalesced ------------------------------------
         for (int k = tid; k < nnz_t; k += PULL_BLOCK) {
-            s_col[k] = a.col[j0 + k];
-            if (need_aval && !a.a_iso) s_aval[k] = aval[j0 + k];
+            s_col[k] = (a.dbg & 2) ? (int)((j0 + k) & 1023) : a.col[j0 + k];
+            if (need_aval && !a.a_iso) s_aval[k] = (a.dbg & 2) ? (T)1 : aval[j0 + k];
         }
         __syncthreads();
 
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(PULL_BLOCK) void k_mxv_pull(const PullArgs a)
         // ---- pass 1b/1c: gather presence words, then values: IPT independent loads in flight per lane ---
         bool xp[IPT];
         T xv[IPT];
-        if (a.u_full) {
+        if (a.u_full || (a.dbg & 1)) {
 #pragma unroll
             for (int s = 0; s < IPT; s++) xp[s] = cc[s] >= 0;
         } else {
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(PULL_BLOCK) void k_mxv_pull(const PullArgs a)
             for (int s = 0; s < IPT; s++) xp[s] = cc[s] >= 0 && ((bw[s] >> (cc[s] & 31)) & 1u);
         }
 #pragma unroll
-        for (int s = 0; s < IPT; s++) xv[s] = (xp[s] && need_uval) ? uval[cc[s]] : (T)0;
+        for (int s = 0; s < IPT; s++) xv[s] = (xp[s] && need_uval) ? ((a.dbg & 1) ? (T)(cc[s] & 7) : uval[cc[s]]) : (T)0;
 
         // ---- pass 2: fold products along the merge path -----------------------------------------------------
         const T iso_v = (a.a_iso && need_aval) ? aval[0] : (T)0;
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(PULL_BLOCK) void k_mxv_pull(const PullArgs a)
     const bool started_earlier = (i0 < a.m) && (a.rowptr[i0] < j0);
     const int own_lo = (started_earlier && nrows_t > 0) ? 1 : 0;
     const int64_t row_lo = i0 + own_lo, row_hi = i1;  // [row_lo, row_hi)
-    if (row_lo < row_hi) {
+    if (row_lo < row_hi && !(a.dbg & 4)) {
         const int64_t g_first = row_lo >> 6, g_last = (row_hi - 1) >> 6;
         for (int64_t g = g_first + (tid >> 6); g <= g_last; g += PULL_BLOCK / 64) {
             const int64_t row = (g << 6) + lane;
@@ -406,12 +407,12 @@ static void ensure_tile_table(GB_Matrix_opaque *A, int tile_items)
     A->tile_items = tile_items;
 }
 
-template <typename T, int MON, int MUL>
-static void launch_pull(GB_Matrix_opaque *A, PullArgs &a)
+template <typename T, int MON, int MUL, int IPT>
+static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
 {
     using W = typename Widen<T>::type;
-    constexpr int IPT = PullIPT<T>::value;
     constexpr int TILE = PULL_BLOCK * IPT;
+    a.dbg = ctx().debug_flags;
     ensure_tile_table(A, TILE);
     a.tile_row = A->d_tile_row;
     a.n_tiles = A->n_tiles;
@@ -428,6 +429,18 @@ static void launch_pull(GB_Matrix_opaque *A, PullArgs &a)
     GRB_HIP(hipGetLastError());
     ctx().stats.kernel_launches += 2;
     ctx().stats.tiles = a.n_tiles;
+}
+
+template <typename T, int MON, int MUL>
+static void launch_pull(GB_Matrix_opaque *A, PullArgs &a)
+{
+    // GRB_PULL_IPT (tuning knob) is honoured by the fully specialised kernels only
+    if constexpr (MON >= 0) {
+        const int want = ctx().tune_pull_ipt;
+        if (want == 4 && sizeof(T) <= 4) return launch_pull_ipt<T, MON, MUL, 4>(A, a);
+        if (want == 16 && sizeof(T) <= 4) return launch_pull_ipt<T, MON, MUL, 16>(A, a);
+    }
+    launch_pull_ipt<T, MON, MUL, PullIPT<T>::value>(A, a);
 }
 
 static void pull_dispatch(GB_Matrix_opaque *A, int type, PullArgs &a)
