@@ -208,6 +208,9 @@ GrB_Info GrX_Vector_import_dense_device(GrB_Vector *v, GrB_Type type, GrB_Index 
                                         const uint32_t *d_present);
 /* Borrow the device image of v (valid until v is modified or freed). *d_present has ceil(n/64)*2 words. */
 GrB_Info GrX_Vector_export_dense_device(const void **d_val, const uint32_t **d_present, const GrB_Vector v);
+/* Tell the library that the caller wrote into the image returned by GrX_Vector_export_dense_device
+ * (e.g. an RCCL all-gather landed there): the cached entry count is dropped. */
+GrB_Info GrX_Vector_modified(GrB_Vector v);
 /* Build and cache the transpose now (otherwise built lazily on the first T0/vxm use). */
 GrB_Info GrX_Matrix_cache_transpose(GrB_Matrix A);
 /* Launch on this hipStream_t (default: the null stream, which orders with torch's default stream). */

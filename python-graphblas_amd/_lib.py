@@ -112,6 +112,8 @@ def _declare(L):
     L.GrX_Matrix_cache_transpose.argtypes = [c_void_p]
     L.GrX_Vector_import_dense_device.argtypes = [P(c_void_p), c_void_p, c_u64, c_void_p, c_void_p]
     L.GrX_Vector_export_dense_device.argtypes = [P(c_void_p), P(c_void_p), c_void_p]
+    L.GrX_Vector_modified.argtypes = [c_void_p]
+    L.GrX_tuning_set.argtypes = [c_int, c_int]
     L.GrX_set_stream.argtypes = [c_void_p]
     L.GrX_synchronize.argtypes = []
     L.GrX_timer_start.argtypes = []

@@ -76,19 +76,20 @@ __global__ void k_tile_table(const int64_t *rowptr, int64_t m, int64_t nnz, int 
 }
 
 // The write rule for one output row.  Returns the new presence; stores the value when present.
+// `old_val` is w_old[row] (only read by the caller when old_has and (accum or fresh)).
 template <typename T>
-__device__ __forceinline__ bool write_rule_row(const PullArgs &a, int64_t row, bool mact, bool old_has, bool t_has, T t_val)
+__device__ __forceinline__ bool write_rule_row(const PullArgs &a, int64_t row, bool mact, bool old_has, T old_val, bool t_has,
+                                               T t_val)
 {
-    const T *w_old = (const T *)a.w_old_val;
     T *w_new = (T *)a.w_new_val;
     if (!mact) {
         const bool keep = a.replace ? false : old_has;
-        if (keep && a.fresh) w_new[row] = w_old[row];
+        if (keep && a.fresh) w_new[row] = old_val;
         return keep;
     }
     if (a.accum >= 0) {
-        if (old_has && t_has) { w_new[row] = apply_binop<T>(a.accum, w_old[row], t_val); return true; }
-        if (old_has) { if (a.fresh) w_new[row] = w_old[row]; return true; }
+        if (old_has && t_has) { w_new[row] = apply_binop<T>(a.accum, old_val, t_val); return true; }
+        if (old_has) { if (a.fresh) w_new[row] = old_val; return true; }
         if (t_has) { w_new[row] = t_val; return true; }
         return false;
     }
@@ -127,52 +128,77 @@ __global__ __launch_bounds__(PULL_BLOCK) void k_mxv_pull(const PullArgs a)
     const bool need_aval = a.need_aval != 0, need_uval = a.need_uval != 0;
     const bool has_mask = a.has_mask != 0;
 
-    // ---- stage row ends (relative to j0), reset row accumulators ------------------------------------
+    // ---- issue every global load of the staging phase before the first LDS write (they all overlap):
+    //      this tile's column indices and values, its row ends, its mask words ------------------------------
+    const int32_t *colp = a.col + j0;
+    const T *avp = aval + (a.a_iso ? 0 : j0);
+    const bool stage_vals = need_aval && !a.a_iso;
+    int creg[IPT];
+    T vreg[IPT];
+#pragma unroll
+    for (int s = 0; s < IPT; s++) {
+        const int k = tid + s * PULL_BLOCK;
+        creg[s] = (k < nnz_t) ? ((a.dbg & 2) ? (k & 1023) : colp[k]) : 0;
+        vreg[s] = (stage_vals && k < nnz_t) ? ((a.dbg & 2) ? (T)1 : avp[k]) : (T)0;
+    }
+    int64_t re0 = 0;
+    if (tid <= nrows_t && i0 + tid < a.m) re0 = a.rowptr[i0 + tid + 1];
+    const int abase = (int)(i0 & 31);  // bit of row i0 inside s_act[0]
+    const int64_t last_row = i1 < a.m ? i1 : a.m - 1;
+    const int nw = has_mask ? (int)((last_row >> 5) - (i0 >> 5)) + 1 : 0;
+    uint32_t mword = 0;
+    if (tid < nw) mword = ((const uint32_t *)a.m_bits)[(i0 >> 5) + tid];
+    // the epilogue's reads of the old w for this wavefront's first 64-row group, issued now as well
+    const bool need_old = (a.accum >= 0) || a.fresh;
+    const int64_t pre_g = (i0 >> 6) + (tid >> 6);
+    const int64_t pre_row = (pre_g << 6) + lane;
+    uint64_t pre_word = 0;
+    T pre_val = (T)0;
+    if ((pre_g << 6) < a.m) {
+        pre_word = a.w_old_bits[pre_g];
+        if (need_old && pre_row < a.m) pre_val = ((const T *)a.w_old_val)[pre_row];
+    }
+
+    // ---- LDS: row ends (relative to j0), row accumulators, staged tile -----------------------------------
     for (int k = tid; k <= nrows_t; k += PULL_BLOCK) {
         const int64_t row = i0 + k;
         int rel = TILE + 1;
         if (row < a.m) {
-            const int64_t e = a.rowptr[row + 1] - j0;
+            const int64_t e = (k == tid ? re0 : a.rowptr[row + 1]) - j0;
             rel = e > TILE ? TILE + 1 : (int)e;
         }
         s_rowend[k] = rel;
         s_tval[k] = monoid_identity<T, W>(monoid);
         s_thas[k] = 0;
     }
+#pragma unroll
+    for (int s = 0; s < IPT; s++) {
+        const int k = tid + s * PULL_BLOCK;
+        if (k < nnz_t) {
+            s_col[k] = creg[s];
+            if (stage_vals) s_aval[k] = vreg[s];
+        }
+    }
     if (tid == 0) s_any = has_mask ? 0 : 1;
     __syncthreads();
-
     // ---- active-row bits for rows i0 .. min(i1, m-1) -------------------------------------------------
-    const int64_t wbase = i0 >> 5;
-    const int64_t last_row = i1 < a.m ? i1 : a.m - 1;
-    if (has_mask) {
-        const int nw = (int)((last_row >> 5) - wbase) + 1;
-        const uint32_t *mb = (const uint32_t *)a.m_bits;
-        for (int k = tid; k < nw; k += PULL_BLOCK) {
-            uint32_t w = mb[wbase + k];
-            if (a.m_comp) w = ~w;
-            s_act[k] = w;
-            // restrict to [i0, last_row] for the "anything to do" test
-            const int64_t base_row = (wbase + k) << 5;
-            uint32_t in = 0xffffffffu;
-            if (base_row < i0) in &= 0xffffffffu << (int)(i0 - base_row);
-            if (base_row + 31 > last_row) in &= 0xffffffffu >> (int)(base_row + 31 - last_row);
-            if (w & in) s_any = 1;
-        }
+    for (int k = tid; k < nw; k += PULL_BLOCK) {
+        uint32_t w = (k == tid) ? mword : ((const uint32_t *)a.m_bits)[(i0 >> 5) + k];
+        if (a.m_comp) w = ~w;
+        s_act[k] = w;
+        // restrict to [i0, last_row] for the "anything to do" test
+        const int64_t base_row = ((i0 >> 5) + k) << 5;
+        uint32_t in = 0xffffffffu;
+        if (base_row < i0) in &= 0xffffffffu << (int)(i0 - base_row);
+        if (base_row + 31 > last_row) in &= 0xffffffffu >> (int)(base_row + 31 - last_row);
+        if (w & in) s_any = 1;
     }
     __syncthreads();
     const bool any_active = s_any != 0;
 
-#define ROW_ACTIVE(r) (!has_mask || ((s_act[(int)(((i0 + (r)) >> 5) - wbase)] >> ((i0 + (r)) & 31)) & 1u))
+#define ROW_ACTIVE(r) (!has_mask || ((s_act[(abase + (r)) >> 5] >> ((abase + (r)) & 31)) & 1u))
 
     if (any_active) {
-        // ---- stage this tile's column indices and values, coalesced ------------------------------------
-        for (int k = tid; k < nnz_t; k += PULL_BLOCK) {
-            s_col[k] = (a.dbg & 2) ? (int)((j0 + k) & 1023) : a.col[j0 + k];
-            if (need_aval && !a.a_iso) s_aval[k] = (a.dbg & 2) ? (T)1 : aval[j0 + k];
-        }
-        __syncthreads();
-
         // ---- per-thread merge-path start -----------------------------------------------------------------
         const int diag = tid * IPT < items ? tid * IPT : items;
         int lo = diag - nnz_t > 0 ? diag - nnz_t : 0, hi = diag < nrows_t ? diag : nrows_t;
@@ -273,13 +299,15 @@ __global__ __launch_bounds__(PULL_BLOCK) void k_mxv_pull(const PullArgs a)
         for (int64_t g = g_first + (tid >> 6); g <= g_last; g += PULL_BLOCK / 64) {
             const int64_t row = (g << 6) + lane;
             const bool owned = row >= row_lo && row < row_hi;
-            const uint64_t oldw = a.w_old_bits[g];
+            const uint64_t oldw = (g == pre_g) ? pre_word : a.w_old_bits[g];
             const bool old_has = (oldw >> lane) & 1ull;
             bool new_has = false;
             if (owned) {
                 const int k = (int)(row - i0);
                 const bool mact = ROW_ACTIVE(k);
-                new_has = write_rule_row<T>(a, row, mact, old_has, s_thas[k] != 0, from_acc<T, W>(s_tval[k]));
+                T old_val = pre_val;
+                if (g != pre_g && need_old && old_has) old_val = ((const T *)a.w_old_val)[row];
+                new_has = write_rule_row<T>(a, row, mact, old_has, old_val, s_thas[k] != 0, from_acc<T, W>(s_tval[k]));
             }
             const unsigned long long nb = __ballot(owned && new_has);
             const unsigned long long om = __ballot(owned);
@@ -347,7 +375,8 @@ __global__ __launch_bounds__(PULL_BLOCK) void k_mxv_seams(const PullArgs a)
             if (a.m_comp) mact = !mact;
         }
         const bool old_has = (a.w_old_bits[row >> 6] >> (row & 63)) & 1ull;
-        const bool new_has = write_rule_row<T>(a, row, mact, old_has, has != 0, from_acc<T, W>(acc));
+        const T old_val = old_has ? ((const T *)a.w_old_val)[row] : (T)0;
+        const bool new_has = write_rule_row<T>(a, row, mact, old_has, old_val, has != 0, from_acc<T, W>(acc));
         const unsigned long long bit = 1ull << (row & 63);
         if (new_has) atomicOr((unsigned long long *)&a.w_new_bits[row >> 6], bit);
         else atomicAnd((unsigned long long *)&a.w_new_bits[row >> 6], ~bit);

@@ -1099,3 +1099,11 @@ extern "C" GrB_Info GrX_Vector_export_dense_device(const void **d_val, const uin
     if (d_present) *d_present = (const uint32_t *)v->d_bits;
     GRB_CATCH(errp(v))
 }
+
+extern "C" GrB_Info GrX_Vector_modified(GrB_Vector v)
+{
+    GRB_TRY
+    check_vector(v, "v");
+    v->nvals = -1;  // the caller wrote the HBM image obtained from GrX_Vector_export_dense_device
+    GRB_CATCH(errp(v))
+}

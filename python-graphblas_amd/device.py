@@ -71,14 +71,23 @@ class _CudaView:
         self.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (ptr, False), "version": 2}
 
 
-def vector_device_views(v):
+def vector_device_views(v, device="cuda"):
     """(values, presence_words) torch tensors ALIASING the vector's HBM image (valid until the vector
-    is modified by a call that reallocates it, or freed)."""
+    is modified by a call that reallocates it, or freed).  ``device="cpu"`` is for the CPU test tier,
+    where the emulator build keeps the image in host memory."""
     import torch
 
     dv, db = ctypes.c_void_p(), ctypes.c_void_p()
     call_on(v, "GrX_Vector_export_dense_device", [ctypes.byref(dv), ctypes.byref(db), v._handle])
     n = v._size
+    if device == "cpu":
+        nb = n * np.dtype(v.dtype.np_type).itemsize
+        vals = np.ctypeslib.as_array((ctypes.c_uint8 * max(nb, 1)).from_address(dv.value))[:nb].view(v.dtype.np_type)
+        nw = ((n + 63) // 64) * 2
+        words = np.ctypeslib.as_array((ctypes.c_uint8 * max(nw * 4, 1)).from_address(db.value))[: nw * 4].view(np.int32)
+        if v.dtype.np_type == np.dtype(bool):
+            return torch.from_numpy(vals.view(np.uint8)).view(torch.bool), torch.from_numpy(words)
+        return torch.from_numpy(vals), torch.from_numpy(words)
     vals = torch.as_tensor(_CudaView(dv.value, (n,), np.dtype(v.dtype.np_type).str), device="cuda")
     words = torch.as_tensor(_CudaView(db.value, (((n + 63) // 64) * 2,), "<i4"), device="cuda")
     return vals, words
@@ -106,3 +115,8 @@ def last_stats():
 
 def cache_transpose(A):
     call_on(A, "GrX_Matrix_cache_transpose", [A._handle])
+
+
+def vector_modified(v):
+    """Call after writing into the tensors returned by :func:`vector_device_views`."""
+    call_on(v, "GrX_Vector_modified", [v._handle])

@@ -13,13 +13,15 @@ import graphblas_amd as gb  # noqa: E402
 from graphblas_amd import _lib, device  # noqa: E402
 
 scale = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+IPTS = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else '0,4,16').split(',')]
+DBGS = [int(x) for x in (sys.argv[3] if len(sys.argv) > 3 else '0,1,2,3,4,7').split(',')]
 gb.init()
 out = []
 for wl_name, sr, vis in (("min_plus_masked", "min_plus", 0.5), ("min_plus_unmasked", "min_plus", 0.0),
                          ("lor_land_masked", "lor_land", 0.5)):
     wl = bench.MxvWorkload(gb, torch, scale, 0, 1, sr, vis)
-    for ipt in (0, 4, 16):
-        for dbg in (0, 1, 2, 3, 4, 7):
+    for ipt in IPTS:
+        for dbg in DBGS:
             _lib.lib.GrX_tuning_set(dbg, ipt)
             for _ in range(2):
                 wl.step()

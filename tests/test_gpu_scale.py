@@ -38,7 +38,7 @@ def _graph(gb, scale, kind):
 
 
 @pytest.mark.parametrize("scale,kind,sr", [(16, "FP32", "min_plus"), (17, "BOOL", "lor_land"), (16, "INT64", "plus_times"),
-                                           (18, "FP32", "plus_times"), (16, "BOOL", "any_pair")])
+                                           (16, "FP32", "plus_times"), (16, "BOOL", "any_pair")])
 def test_rmat_vs_oracle(gb, scale, kind, sr):
     """configs[1]-style graphs at oracle-friendly sizes: bit-exact against the CPU oracle."""
     import torch
@@ -56,7 +56,8 @@ def test_rmat_vs_oracle(gb, scale, kind, sr):
     for dens, vis_d, accum, repl in ((1.0, 0.5, "min" if sr == "min_plus" else None, False), (0.01, 0.9, None, True),
                                      (0.3, 0.0, None, False)):
         ui = np.flatnonzero(rng.random(n) < dens)
-        uv = (rng.random(ui.size) < 0.9) if kind == "BOOL" else rng.integers(1, 50, ui.size).astype(O.NP_OF[kind])
+        # small integer values: every partial sum stays below 2^24, so even fp32 plus_times is exact in any order
+        uv = (rng.random(ui.size) < 0.9) if kind == "BOOL" else rng.integers(1, 3 if kind == "FP32" else 50, ui.size).astype(O.NP_OF[kind])
         vi = np.flatnonzero(rng.random(n) < vis_d)
         u, ou = gb.Vector.from_coo(ui, uv, dtype=kind, size=n), O.OVec(n, ui, uv, kind)
         vis, ovis = gb.Vector.from_coo(vi, np.ones(vi.size, bool), dtype="BOOL", size=n), O.OVec(n, vi, np.ones(vi.size, bool), "BOOL")
