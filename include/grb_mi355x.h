@@ -227,12 +227,16 @@ typedef struct {
     int64_t out_nvals;        /* mxm: nnz(T); mxv: -1 (not counted) */
     int32_t method;           /* 1 pull (merge-path SpMV), 2 push (SpMSpV), 3 hash SpGEMM */
     int32_t fused_epilogue;   /* 1 if mask/accum/replace were applied inside the product kernel */
+    int64_t hot_k;            /* mxv/vxm: entries of the hot-column table used by the call (0 = none) */
 } GrX_Stats;
 GrB_Info GrX_last_stats(GrX_Stats *stats);
-/* Benchmark diagnostics: kernel ablation switches (0 = product behaviour; non-zero values make results
- * WRONG on purpose: 1 skips the x gathers, 2 the A staging loads, 4 the epilogue) and the pull SpMV's
- * merge items per thread (0 = default).  Also read from GRB_DEBUG / GRB_PULL_IPT at GrB_init. */
-GrB_Info GrX_tuning_set(int debug_flags, int pull_items_per_thread);
+/* Tuning / diagnostics knobs (also read from the environment at GrB_init as GRB_<NAME upper-case>):
+ *   "debug_flags"   kernel ablation switches for benchmarking; non-zero values make results WRONG on purpose
+ *                   (1 skips the x gathers, 2 the A staging loads, 4 the epilogue)
+ *   "pull_ipt"      merge items per thread of the pull SpMV (0 = default)
+ *   "hot_min_cols"  matrices with at least this many columns get a hot-column table for the pull SpMV
+ *   "hot_k"         entries of that table (0 = sized to ~2 MiB of x values) */
+GrB_Info GrX_option_set(const char *name, int64_t value);
 const char *GrX_version_string(void);
 
 #ifdef __cplusplus

@@ -30,7 +30,8 @@ GrB_NO_VALUE = 1
 
 class GrX_Stats(ctypes.Structure):
     _fields_ = [("kernel_launches", ctypes.c_int64), ("tiles", ctypes.c_int64), ("flops", ctypes.c_int64),
-                ("out_nvals", ctypes.c_int64), ("method", ctypes.c_int32), ("fused_epilogue", ctypes.c_int32)]
+                ("out_nvals", ctypes.c_int64), ("method", ctypes.c_int32), ("fused_epilogue", ctypes.c_int32),
+                ("hot_k", ctypes.c_int64)]
 
 
 def load(path: str | None = None):
@@ -113,7 +114,7 @@ def _declare(L):
     L.GrX_Vector_import_dense_device.argtypes = [P(c_void_p), c_void_p, c_u64, c_void_p, c_void_p]
     L.GrX_Vector_export_dense_device.argtypes = [P(c_void_p), P(c_void_p), c_void_p]
     L.GrX_Vector_modified.argtypes = [c_void_p]
-    L.GrX_tuning_set.argtypes = [c_int, c_int]
+    L.GrX_option_set.argtypes = [ctypes.c_char_p, ctypes.c_int64]
     L.GrX_set_stream.argtypes = [c_void_p]
     L.GrX_synchronize.argtypes = []
     L.GrX_timer_start.argtypes = []

@@ -88,8 +88,10 @@ extern "C" GrB_Info GrB_init(GrB_Mode mode)
     }
     (void)hipGetLastError();
     if (hipEventCreate(&c.ev0) != hipSuccess || hipEventCreate(&c.ev1) != hipSuccess) return GrB_PANIC;
-    if (const char *e = getenv("GRB_DEBUG")) c.debug_flags = atoi(e);
+    if (const char *e = getenv("GRB_DEBUG_FLAGS")) c.debug_flags = atoi(e);
     if (const char *e = getenv("GRB_PULL_IPT")) c.tune_pull_ipt = atoi(e);
+    if (const char *e = getenv("GRB_HOT_MIN_COLS")) c.hot_min_cols = atoll(e);
+    if (const char *e = getenv("GRB_HOT_K")) c.hot_k = atoll(e);
     c.initialized = true;
     return GrB_SUCCESS;
 }
@@ -157,10 +159,16 @@ extern "C" GrB_Info GrX_last_stats(GrX_Stats *stats)
     return GrB_SUCCESS;
 }
 
-extern "C" GrB_Info GrX_tuning_set(int debug_flags, int pull_items_per_thread)
+extern "C" GrB_Info GrX_option_set(const char *name, int64_t value)
 {
-    ctx().debug_flags = debug_flags;
-    ctx().tune_pull_ipt = pull_items_per_thread;
+    if (!name) return GrB_NULL_POINTER;
+    Context &c = ctx();
+    const std::string n(name);
+    if (n == "debug_flags") c.debug_flags = (int)value;
+    else if (n == "pull_ipt") c.tune_pull_ipt = (int)value;
+    else if (n == "hot_min_cols") c.hot_min_cols = value;
+    else if (n == "hot_k") c.hot_k = value;
+    else return GrB_INVALID_VALUE;
     return GrB_SUCCESS;
 }
 

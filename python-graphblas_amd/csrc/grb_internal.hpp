@@ -61,6 +61,8 @@ struct Context {
     GrX_Stats stats{};
     int debug_flags = 0;    // GRB_DEBUG: kernel ablation switches (benchmark diagnostics only)
     int tune_pull_ipt = 0;  // GRB_PULL_IPT: merge items per thread of the pull SpMV (0 = default)
+    int64_t hot_min_cols = 1 << 20;  // matrices at least this wide get a hot-column table (pull SpMV)
+    int64_t hot_k = 0;               // table entries (0 = ~2 MiB of x values)
 };
 Context &ctx();
 void require_init();
@@ -149,6 +151,12 @@ struct GB_Matrix_opaque {
     int64_t *d_tile_row;
     int64_t n_tiles;
     int tile_items;
+    // hot-column table for the pull SpMV (grb_mxv.hip): the K most referenced columns are renumbered
+    // 0..K-1 (their x entries are gathered into a small L2-resident table per call), all others K+col
+    int32_t *d_col_hot;   // nvals re-coded column indices, or nullptr
+    int32_t *d_hot_cols;  // K original column indices, hottest first
+    int64_t hot_k;
+    int hot_state;        // 0 = not analysed, 1 = enabled, -1 = not worth it
     std::string err;
 };
 

@@ -55,6 +55,9 @@ struct PullArgs {
     uint8_t *carry_has;
     void *first_val;
     uint8_t *first_has;  // bit0: has a partial, bit1: the tile's first row started in an earlier tile
+    int hot_k;           // columns re-coded < hot_k live in the hot table (0 = no table)
+    const void *hot_val;
+    const uint32_t *hot_bits;
     int dbg;             // ablation switches (GRB_DEBUG): 1 = no x gathers, 2 = no A staging loads, 4 = no epilogue
 };
 
@@ -125,6 +128,8 @@ __global__ __launch_bounds__(PULL_BLOCK) void k_mxv_pull(const PullArgs a)
     const int items = (int)(d1 - d0);
     const T *aval = (const T *)a.aval;
     const T *uval = (const T *)a.u_val;
+    const T *hotv = (const T *)a.hot_val;
+    const int hot_k = a.hot_k;
     const bool need_aval = a.need_aval != 0, need_uval = a.need_uval != 0;
     const bool has_mask = a.has_mask != 0;
 
@@ -240,12 +245,21 @@ __global__ __launch_bounds__(PULL_BLOCK) void k_mxv_pull(const PullArgs a)
         } else {
             uint32_t bw[IPT];
 #pragma unroll
-            for (int s = 0; s < IPT; s++) bw[s] = cc[s] >= 0 ? a.u_bits[cc[s] >> 5] : 0u;
+            for (int s = 0; s < IPT; s++) {
+                const int c = cc[s];
+                bw[s] = c >= 0 ? (c < hot_k ? a.hot_bits[c >> 5] : a.u_bits[(c - hot_k) >> 5]) : 0u;
+            }
 #pragma unroll
-            for (int s = 0; s < IPT; s++) xp[s] = cc[s] >= 0 && ((bw[s] >> (cc[s] & 31)) & 1u);
+            for (int s = 0; s < IPT; s++) {
+                const int c = cc[s] < hot_k ? cc[s] : cc[s] - hot_k;
+                xp[s] = cc[s] >= 0 && ((bw[s] >> (c & 31)) & 1u);
+            }
         }
 #pragma unroll
-        for (int s = 0; s < IPT; s++) xv[s] = (xp[s] && need_uval) ? ((a.dbg & 1) ? (T)(cc[s] & 7) : uval[cc[s]]) : (T)0;
+        for (int s = 0; s < IPT; s++) {
+            const int c = cc[s];
+            xv[s] = (xp[s] && need_uval) ? ((a.dbg & 1) ? (T)(c & 7) : (c < hot_k ? hotv[c] : uval[c - hot_k])) : (T)0;
+        }
 
         // ---- pass 2: fold products along the merge path -----------------------------------------------------
         const T iso_v = (a.a_iso && need_aval) ? aval[0] : (T)0;
@@ -418,6 +432,99 @@ __global__ void k_vec_write(int64_t n, const TW *w_old_val, const uint64_t *w_ol
 // ---------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------
+// ---- hot-column table ------------------------------------------------------------------------------------
+// Power-law graphs send most gathers to a few columns (R-MAT scale 24: ~3 % of the columns receive ~80 % of
+// the references) but vertex labels are scrambled, so every 128-byte line of x holds about one hot entry
+// and nothing stays cached.  The K most referenced columns are therefore re-coded 0..K-1 in a cached copy
+// of the column indices; per call their x entries are gathered into a K-entry table (~2 MiB: resident in
+// every XCD's 4 MiB L2) and the kernel reads hot columns from the table, all others (coded K+col) from x.
+__global__ void k_hot_hist(const int32_t *col, int64_t nnz, unsigned int *cnt)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < nnz) atomicAdd(&cnt[col[p]], 1u);
+}
+__global__ void k_hot_keys(const unsigned int *cnt, int64_t n, uint64_t *keys, uint32_t *ids)
+{
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < n) {
+        keys[c] = (uint64_t)(0xffffffffu - cnt[c]);  // ascending sort = most referenced first
+        ids[c] = (uint32_t)c;
+    }
+}
+__global__ void k_hot_rank(const uint32_t *sorted_ids, const uint64_t *sorted_keys, int64_t k, int32_t *rank, int32_t *hot_cols,
+                           unsigned long long *covered)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long c = 0;
+    if (r < k) {
+        rank[sorted_ids[r]] = (int32_t)r;
+        hot_cols[r] = (int32_t)sorted_ids[r];
+        c = 0xffffffffull - sorted_keys[r];
+    }
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(covered, c);
+}
+__global__ void k_hot_recode(const int32_t *col, int64_t nnz, const int32_t *rank, int k, int32_t *col_hot)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < nnz) {
+        const int c = col[p];
+        const int r = rank[c];
+        col_hot[p] = r >= 0 ? r : k + c;
+    }
+}
+// per call: table[r] = x[hot_cols[r]], presence word by ballot
+template <typename T>
+__global__ void k_hot_gather(const int32_t *hot_cols, int k, const T *u_val, const uint32_t *u_bits, int u_full, T *hot_val,
+                             uint64_t *hot_bits)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    bool p = false;
+    if (r < k) {
+        const int c = hot_cols[r];
+        p = u_full ? true : ((u_bits[c >> 5] >> (c & 31)) & 1u);
+        if (p) hot_val[r] = u_val[c];
+    }
+    const unsigned long long b = __ballot(p);
+    if ((threadIdx.x & 63) == 0 && r < ((k + 63) / 64) * 64) hot_bits[r >> 6] = b;
+}
+
+static void ensure_hot(GB_Matrix_opaque *A, size_t value_bytes)
+{
+    if (A->hot_state != 0) return;
+    A->hot_state = -1;
+    const int64_t n = (int64_t)A->ncols, nnz = A->nvals;
+    if (n < ctx().hot_min_cols || nnz == 0 || n + (int64_t)(1 << 22) > 0x7fffffff) return;
+    int64_t k = ctx().hot_k > 0 ? ctx().hot_k : (int64_t)((2u << 20) / (value_bytes ? value_bytes : 1));
+    k = std::min<int64_t>(k, n / 4);
+    k &= ~(int64_t)63;
+    if (k < 64) return;
+    DevBuf<unsigned int> cnt(n, true);
+    hipLaunchKernelGGL(k_hot_hist, dim3((unsigned)ceil_div(nnz, 256)), dim3(256), 0, ctx().stream, A->d_col, nnz, cnt.p);
+    DevBuf<uint64_t> keys(n), keys2(n);
+    DevBuf<uint32_t> ids(n), ids2(n);
+    hipLaunchKernelGGL(k_hot_keys, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx().stream, cnt.p, n, keys.p, ids.p);
+    prim_sort_pairs_u64_u32(keys.p, keys2.p, ids.p, ids2.p, n, 32);
+    DevBuf<int32_t> rank(n);
+    GRB_HIP(hipMemsetAsync(rank.p, 0xff, sizeof(int32_t) * (size_t)n, ctx().stream));
+    int32_t *hot_cols = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)k);
+    DevBuf<unsigned long long> covered(1, true);
+    hipLaunchKernelGGL(k_hot_rank, dim3((unsigned)ceil_div(k, 256)), dim3(256), 0, ctx().stream, ids2.p, keys2.p, k, rank.p,
+                       hot_cols, covered.p);
+    unsigned long long cov = 0;
+    d2h(&cov, covered.p, sizeof(cov));
+    if ((double)cov < 0.25 * (double)nnz) {  // flat degree distribution: the table would not pay for itself
+        dev_free(hot_cols);
+        return;
+    }
+    A->d_col_hot = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)nnz);
+    hipLaunchKernelGGL(k_hot_recode, dim3((unsigned)ceil_div(nnz, 256)), dim3(256), 0, ctx().stream, A->d_col, nnz, rank.p,
+                       (int)k, A->d_col_hot);
+    A->d_hot_cols = hot_cols;
+    A->hot_k = k;
+    A->hot_state = 1;
+}
+
 template <typename T> struct PullIPT { static constexpr int value = sizeof(T) >= 8 ? 4 : 8; };
 
 static void ensure_tile_table(GB_Matrix_opaque *A, int tile_items)
@@ -577,6 +684,30 @@ static void mxv_core(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_Binar
     a.need_aval = !(mult == OP_PAIR || mult == OP_SECOND) && S->nvals > 0;
     a.need_uval = !(mult == OP_PAIR || mult == OP_FIRST || mult == OP_ANY);
     if (mult == OP_ANY) a.need_aval = S->nvals > 0;
+    // hot-column table (wide matrices with a skewed column-degree distribution)
+    DevBuf<char> hot_val(0);
+    DevBuf<uint64_t> hot_bits(0);
+    if (a.need_uval || !a.u_full) {
+        ensure_hot(S, type_size(st));
+        if (S->hot_state == 1) {
+            const int k = (int)S->hot_k;
+            dev_free(hot_val.p);
+            hot_val.p = (char *)dev_alloc(type_size(st) * (size_t)k);
+            dev_free(hot_bits.p);
+            hot_bits.p = (uint64_t *)dev_alloc((size_t)(k / 64) * 8);
+            GRB_DISPATCH_TYPE(st, T, {
+                hipLaunchKernelGGL((k_hot_gather<T>), dim3((unsigned)ceil_div(k, 256)), dim3(256), 0, ctx().stream,
+                                   (const int32_t *)S->d_hot_cols, k, (const T *)uval, (const uint32_t *)u->d_bits, a.u_full,
+                                   (T *)hot_val.p, hot_bits.p);
+            })
+            ctx().stats.kernel_launches += 1;
+            a.col = S->d_col_hot;
+            a.hot_k = k;
+            ctx().stats.hot_k = k;
+            a.hot_val = hot_val.p;
+            a.hot_bits = (const uint32_t *)hot_bits.p;
+        }
+    }
     a.m_bits = m_bits;
     a.has_mask = mask ? 1 : 0;
     a.m_comp = f.comp ? 1 : 0;

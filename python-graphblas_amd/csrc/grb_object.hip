@@ -435,6 +435,10 @@ GB_Matrix_opaque *matrix_new(GrB_Type type, uint64_t nrows, uint64_t ncols)
     A->d_tile_row = nullptr;
     A->n_tiles = 0;
     A->tile_items = 0;
+    A->d_col_hot = nullptr;
+    A->d_hot_cols = nullptr;
+    A->hot_k = 0;
+    A->hot_state = 0;
     return A;
 }
 
@@ -448,6 +452,12 @@ void matrix_invalidate_caches(GB_Matrix_opaque *A)
     A->d_tile_row = nullptr;
     A->n_tiles = 0;
     A->tile_items = 0;
+    dev_free(A->d_col_hot);
+    dev_free(A->d_hot_cols);
+    A->d_col_hot = nullptr;
+    A->d_hot_cols = nullptr;
+    A->hot_k = 0;
+    A->hot_state = 0;
 }
 
 void matrix_release_storage(GB_Matrix_opaque *A)

@@ -22,7 +22,7 @@ for wl_name, sr, vis in (("min_plus_masked", "min_plus", 0.5), ("min_plus_unmask
     wl = bench.MxvWorkload(gb, torch, scale, 0, 1, sr, vis)
     for ipt in IPTS:
         for dbg in DBGS:
-            _lib.lib.GrX_tuning_set(dbg, ipt)
+            _lib.lib.GrX_option_set(b'debug_flags', dbg); _lib.lib.GrX_option_set(b'pull_ipt', ipt)
             for _ in range(2):
                 wl.step()
             torch.cuda.synchronize()
@@ -34,5 +34,5 @@ for wl_name, sr, vis in (("min_plus_masked", "min_plus", 0.5), ("min_plus_unmask
                    "GTEPS": round(wl.nnz_active_local / ms / 1e6, 1), "GBs_alg": round(wl.bytes_per_step() / ms / 1e6, 1)}
             print(json.dumps(rec), flush=True)
             out.append(rec)
-    _lib.lib.GrX_tuning_set(0, 0)
+    _lib.lib.GrX_option_set(b'debug_flags', 0); _lib.lib.GrX_option_set(b'pull_ipt', 0)
     del wl
