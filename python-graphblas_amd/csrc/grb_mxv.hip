@@ -100,32 +100,38 @@ __device__ __forceinline__ bool write_rule_row(const PullArgs &a, int64_t row, b
     return t_has;
 }
 
+// LDS index with one pad word per 32: a lane reading IPT consecutive entries (stride IPT across lanes)
+// and a lane reading entry tid + s*256 (stride 1) are both bank-conflict free.
+#define PADI(x) ((x) + ((x) >> 5))
+
 template <typename T, int MONOID_CT, int MULT_CT, int IPT>
 __global__ __launch_bounds__(PULL_BLOCK) void k_mxv_pull(const PullArgs a)
 {
     using W = typename Widen<T>::type;
     constexpr int TILE = PULL_BLOCK * IPT;
+    constexpr int TILEP = TILE + TILE / 32 + 1;
     __shared__ int s_rowend[TILE + 2];
-    __shared__ int s_col[TILE];
-    __shared__ T s_aval[TILE];
+    __shared__ int s_col[TILEP];
+    __shared__ T s_aval[TILEP];
+    __shared__ __attribute__((aligned(16))) unsigned short s_head[TILE + 8];
     __shared__ W s_tval[TILE + 1];
     __shared__ unsigned char s_thas[TILE + 1];
     __shared__ unsigned int s_act[TILE / 32 + 3];
     __shared__ int s_any;
+    __shared__ int s_wave_last[PULL_BLOCK / 64];
 
     const int monoid = MONOID_CT >= 0 ? MONOID_CT : a.monoid;
     const int mult = MULT_CT >= 0 ? MULT_CT : a.mult;
     const int tid = threadIdx.x;
-    const int lane = tid & 63;
+    const int lane = tid & 63, wave = tid >> 6;
     const int64_t tile = blockIdx.x;
     const int64_t i0 = a.tile_row[tile], i1 = a.tile_row[tile + 1];
     const int64_t total = a.m + a.nnz;
     const int64_t d0 = tile * (int64_t)TILE;
     const int64_t d1 = d0 + TILE < total ? d0 + TILE : total;
     const int64_t j0 = d0 - i0, j1 = d1 - i1;
-    const int nrows_t = (int)(i1 - i0);  // rows whose end falls inside this tile
+    const int nrows_t = (int)(i1 - i0);  // rows whose end falls inside this tile (slot nrows_t = the row still open)
     const int nnz_t = (int)(j1 - j0);
-    const int items = (int)(d1 - d0);
     const T *aval = (const T *)a.aval;
     const T *uval = (const T *)a.u_val;
     const T *hotv = (const T *)a.hot_val;
@@ -134,7 +140,7 @@ __global__ __launch_bounds__(PULL_BLOCK) void k_mxv_pull(const PullArgs a)
     const bool has_mask = a.has_mask != 0;
 
     // ---- issue every global load of the staging phase before the first LDS write (they all overlap):
-    //      this tile's column indices and values, its row ends, its mask words ------------------------------
+    //      this tile's column indices and values, its row ends, its mask words, the old w of its first rows ----
     const int32_t *colp = a.col + j0;
     const T *avp = aval + (a.a_iso ? 0 : j0);
     const bool stage_vals = need_aval && !a.a_iso;
@@ -148,14 +154,14 @@ __global__ __launch_bounds__(PULL_BLOCK) void k_mxv_pull(const PullArgs a)
     }
     int64_t re0 = 0;
     if (tid <= nrows_t && i0 + tid < a.m) re0 = a.rowptr[i0 + tid + 1];
+    const int64_t rs0_64 = (i0 < a.m ? a.rowptr[i0] : a.nnz) - j0;  // start of row i0 relative to the tile (< 0: began earlier)
     const int abase = (int)(i0 & 31);  // bit of row i0 inside s_act[0]
     const int64_t last_row = i1 < a.m ? i1 : a.m - 1;
     const int nw = has_mask ? (int)((last_row >> 5) - (i0 >> 5)) + 1 : 0;
     uint32_t mword = 0;
     if (tid < nw) mword = ((const uint32_t *)a.m_bits)[(i0 >> 5) + tid];
-    // the epilogue's reads of the old w for this wavefront's first 64-row group, issued now as well
     const bool need_old = (a.accum >= 0) || a.fresh;
-    const int64_t pre_g = (i0 >> 6) + (tid >> 6);
+    const int64_t pre_g = (i0 >> 6) + wave;
     const int64_t pre_row = (pre_g << 6) + lane;
     uint64_t pre_word = 0;
     T pre_val = (T)0;
@@ -164,7 +170,7 @@ __global__ __launch_bounds__(PULL_BLOCK) void k_mxv_pull(const PullArgs a)
         if (need_old && pre_row < a.m) pre_val = ((const T *)a.w_old_val)[pre_row];
     }
 
-    // ---- LDS: row ends (relative to j0), row accumulators, staged tile -----------------------------------
+    // ---- LDS: row ends (relative to j0), row accumulators, cleared row-head marks, the staged tile ---------
     for (int k = tid; k <= nrows_t; k += PULL_BLOCK) {
         const int64_t row = i0 + k;
         int rel = TILE + 1;
@@ -176,27 +182,33 @@ __global__ __launch_bounds__(PULL_BLOCK) void k_mxv_pull(const PullArgs a)
         s_tval[k] = monoid_identity<T, W>(monoid);
         s_thas[k] = 0;
     }
+    for (int k = tid * 8; k < TILE + 8; k += PULL_BLOCK * 8) *(uint4 *)&s_head[k] = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
     for (int s = 0; s < IPT; s++) {
         const int k = tid + s * PULL_BLOCK;
         if (k < nnz_t) {
-            s_col[k] = creg[s];
-            if (stage_vals) s_aval[k] = vreg[s];
+            s_col[PADI(k)] = creg[s];
+            if (stage_vals) s_aval[PADI(k)] = vreg[s];
         }
     }
     if (tid == 0) s_any = has_mask ? 0 : 1;
     __syncthreads();
-    // ---- active-row bits for rows i0 .. min(i1, m-1) -------------------------------------------------
+
+    // ---- active-row bits for rows i0 .. min(i1, m-1); mark the nnz at which each non-empty row starts ----
     for (int k = tid; k < nw; k += PULL_BLOCK) {
         uint32_t w = (k == tid) ? mword : ((const uint32_t *)a.m_bits)[(i0 >> 5) + k];
         if (a.m_comp) w = ~w;
         s_act[k] = w;
-        // restrict to [i0, last_row] for the "anything to do" test
         const int64_t base_row = ((i0 >> 5) + k) << 5;
-        uint32_t in = 0xffffffffu;
+        uint32_t in = 0xffffffffu;  // restrict to [i0, last_row] for the "anything to do" test
         if (base_row < i0) in &= 0xffffffffu << (int)(i0 - base_row);
         if (base_row + 31 > last_row) in &= 0xffffffffu >> (int)(base_row + 31 - last_row);
         if (w & in) s_any = 1;
+    }
+    const int rs0 = rs0_64 < -1 ? -1 : (int)rs0_64;
+    for (int k = tid; k <= nrows_t; k += PULL_BLOCK) {
+        const int start = (k == 0) ? rs0 : s_rowend[k - 1];
+        if (start >= 0 && start < nnz_t && start < s_rowend[k]) s_head[start] = (unsigned short)(k + 1);
     }
     __syncthreads();
     const bool any_active = s_any != 0;
@@ -204,113 +216,112 @@ __global__ __launch_bounds__(PULL_BLOCK) void k_mxv_pull(const PullArgs a)
 #define ROW_ACTIVE(r) (!has_mask || ((s_act[(abase + (r)) >> 5] >> ((abase + (r)) & 31)) & 1u))
 
     if (any_active) {
-        // ---- per-thread merge-path start -----------------------------------------------------------------
-        const int diag = tid * IPT < items ? tid * IPT : items;
-        int lo = diag - nnz_t > 0 ? diag - nnz_t : 0, hi = diag < nrows_t ? diag : nrows_t;
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (s_rowend[mid] <= diag - mid - 1) lo = mid + 1;
-            else hi = mid;
-        }
-        const int r_start = lo, j_start = diag - lo;
-        const int my_items = items - diag < IPT ? items - diag : IPT;
-
-        // ---- pass 1a: classify my items (column to gather, skipped nnz = -1, row end = -2) --------------
-        int cc[IPT];
-        {
-            int r = r_start, j = j_start, rend = s_rowend[r];
-            bool act = ROW_ACTIVE(r);
+        // ---- local row (encoded k+1) of each of my IPT consecutive nnz: heads inside my chunk, else the
+        //      last head seen by earlier lanes (wavefront max-scan by shuffles) / earlier waves (LDS) -----------
+        const int base = tid * IPT;
+        int h[IPT];
+        if constexpr (IPT == 8) {
+            const uint4 v = *(const uint4 *)&s_head[base];
+            h[0] = v.x & 0xffff; h[1] = v.x >> 16; h[2] = v.y & 0xffff; h[3] = v.y >> 16;
+            h[4] = v.z & 0xffff; h[5] = v.z >> 16; h[6] = v.w & 0xffff; h[7] = v.w >> 16;
+        } else {
 #pragma unroll
-            for (int s = 0; s < IPT; s++) {
-                cc[s] = -3;
-                if (s < my_items) {
-                    if (j < rend) {
-                        cc[s] = act ? s_col[j] : -1;
-                        j++;
-                    } else {
-                        cc[s] = -2;
-                        r++;
-                        rend = s_rowend[r];
-                        act = ROW_ACTIVE(r);
-                    }
-                }
-            }
+            for (int i = 0; i < IPT; i++) h[i] = s_head[base + i];
         }
-        // ---- pass 1b/1c: gather presence words, then values: IPT independent loads in flight per lane ---
+        int lastk = 0;
+#pragma unroll
+        for (int i = 0; i < IPT; i++) lastk = h[i] ? h[i] : lastk;  // heads increase along the tile: last = max
+        int incl = lastk;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off);
+            if (lane >= off) incl = incl > t ? incl : t;
+        }
+        int excl = __shfl_up(incl, 1);
+        if (lane == 0) excl = 0;
+        if (lane == 63) s_wave_last[wave] = incl;
+        __syncthreads();
+        int e = 1;  // the tile's first nnz belong to row i0
+        for (int x = 0; x < wave; x++) e = e > s_wave_last[x] ? e : s_wave_last[x];
+        e = e > excl ? e : excl;
+
+        // ---- classify: column to gather (or -1: past the tile end / masked-out row) ----------------------------
+        int ek[IPT], cc[IPT];
+#pragma unroll
+        for (int i = 0; i < IPT; i++) {
+            e = h[i] ? h[i] : e;
+            ek[i] = e;
+            const bool valid = base + i < nnz_t;
+            cc[i] = (valid && ROW_ACTIVE(e - 1)) ? s_col[PADI(base + i)] : -1;
+        }
+        // ---- gathers: presence words, then values -- IPT independent random accesses in flight per lane -------
         bool xp[IPT];
         T xv[IPT];
         if (a.u_full || (a.dbg & 1)) {
 #pragma unroll
-            for (int s = 0; s < IPT; s++) xp[s] = cc[s] >= 0;
+            for (int i = 0; i < IPT; i++) xp[i] = cc[i] >= 0;
         } else {
             uint32_t bw[IPT];
 #pragma unroll
-            for (int s = 0; s < IPT; s++) {
-                const int c = cc[s];
-                bw[s] = c >= 0 ? (c < hot_k ? a.hot_bits[c >> 5] : a.u_bits[(c - hot_k) >> 5]) : 0u;
+            for (int i = 0; i < IPT; i++) {
+                const int c = cc[i];
+                bw[i] = c >= 0 ? (c < hot_k ? a.hot_bits[c >> 5] : a.u_bits[(c - hot_k) >> 5]) : 0u;
             }
 #pragma unroll
-            for (int s = 0; s < IPT; s++) {
-                const int c = cc[s] < hot_k ? cc[s] : cc[s] - hot_k;
-                xp[s] = cc[s] >= 0 && ((bw[s] >> (c & 31)) & 1u);
+            for (int i = 0; i < IPT; i++) {
+                const int c = cc[i] < hot_k ? cc[i] : cc[i] - hot_k;
+                xp[i] = cc[i] >= 0 && ((bw[i] >> (c & 31)) & 1u);
             }
         }
 #pragma unroll
-        for (int s = 0; s < IPT; s++) {
-            const int c = cc[s];
-            xv[s] = (xp[s] && need_uval) ? ((a.dbg & 1) ? (T)(c & 7) : (c < hot_k ? hotv[c] : uval[c - hot_k])) : (T)0;
+        for (int i = 0; i < IPT; i++) {
+            const int c = cc[i];
+            xv[i] = (xp[i] && need_uval) ? ((a.dbg & 1) ? (T)(c & 7) : (c < hot_k ? hotv[c] : uval[c - hot_k])) : (T)0;
         }
 
-        // ---- pass 2: fold products along the merge path -----------------------------------------------------
+        // ---- segmented fold of my chunk; a segment shared with other threads combines by LDS atomic ---------
         const T iso_v = (a.a_iso && need_aval) ? aval[0] : (T)0;
-        int r = r_start, j = j_start;
-        int row_start_rel;
-        if (r_start > 0) row_start_rel = s_rowend[r_start - 1];
-        else {
-            const int64_t rs = (i0 < a.m ? a.rowptr[i0] : a.nnz) - j0;
-            row_start_rel = rs < -1 ? -1 : (int)rs;
-        }
-        bool first_partial = (j_start != row_start_rel);
         T acc = (T)0;
         bool has = false;
+        bool partial = (h[0] == 0);  // my first segment began in an earlier thread (or an earlier tile)
+        int cur = ek[0];
 #pragma unroll
-        for (int s = 0; s < IPT; s++) {
-            if (cc[s] == -2) {  // row r ends here
+        for (int i = 0; i < IPT; i++) {
+            if (i > 0 && h[i]) {  // a new row starts here: the previous segment is complete
                 if (has) {
                     const W v = (W)acc;
-                    if (monoid == OP_ANY || !first_partial) s_tval[r] = v;
-                    else atomic_combine<W>(&s_tval[r], v, monoid);
-                    s_thas[r] = 1;
+                    if (monoid == OP_ANY || !partial) s_tval[cur - 1] = v;
+                    else atomic_combine<W>(&s_tval[cur - 1], v, monoid);
+                    s_thas[cur - 1] = 1;
                 }
-                r++;
                 has = false;
-                first_partial = false;
-            } else if (cc[s] != -3) {  // an nnz of row r
-                if (xp[s]) {
-                    const T av = need_aval ? (a.a_iso ? iso_v : s_aval[j]) : (T)0;
-                    const T prod = apply_binop<T>(mult, av, xv[s]);
-                    acc = has ? apply_binop<T>(monoid, acc, prod) : prod;
-                    has = true;
-                }
-                j++;
+                partial = false;
+                cur = ek[i];
+            }
+            if (xp[i]) {
+                const T av = need_aval ? (a.a_iso ? iso_v : s_aval[PADI(base + i)]) : (T)0;
+                const T prod = apply_binop<T>(mult, av, xv[i]);
+                acc = has ? apply_binop<T>(monoid, acc, prod) : prod;
+                has = true;
             }
         }
-        if (has) {  // carry-out into the row still open at the end of my range
+        if (has) {  // last segment: shared if the row continues into the next thread's chunk
+            if (base + IPT < nnz_t && s_rowend[cur - 1] > base + IPT) partial = true;
             const W v = (W)acc;
-            if (monoid == OP_ANY) s_tval[r] = v;
-            else atomic_combine<W>(&s_tval[r], v, monoid);
-            s_thas[r] = 1;
+            if (monoid == OP_ANY || !partial) s_tval[cur - 1] = v;
+            else atomic_combine<W>(&s_tval[cur - 1], v, monoid);
+            s_thas[cur - 1] = 1;
         }
     }
     __syncthreads();
 
     // ---- epilogue: rows this tile owns, 64 consecutive rows per wavefront -----------------------------
-    const bool started_earlier = (i0 < a.m) && (a.rowptr[i0] < j0);
+    const bool started_earlier = (i0 < a.m) && (rs0_64 < 0);
     const int own_lo = (started_earlier && nrows_t > 0) ? 1 : 0;
     const int64_t row_lo = i0 + own_lo, row_hi = i1;  // [row_lo, row_hi)
     if (row_lo < row_hi && !(a.dbg & 4)) {
         const int64_t g_first = row_lo >> 6, g_last = (row_hi - 1) >> 6;
-        for (int64_t g = g_first + (tid >> 6); g <= g_last; g += PULL_BLOCK / 64) {
+        for (int64_t g = g_first + wave; g <= g_last; g += PULL_BLOCK / 64) {
             const int64_t row = (g << 6) + lane;
             const bool owned = row >= row_lo && row < row_hi;
             const uint64_t oldw = (g == pre_g) ? pre_word : a.w_old_bits[g];

@@ -28,6 +28,8 @@ struct dim3 {
     constexpr dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
 struct uint3 { unsigned x, y, z; };
+struct uint4 { unsigned x, y, z, w; };
+inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
 
 extern uint3 threadIdx, blockIdx;
 extern dim3 blockDim, gridDim;
