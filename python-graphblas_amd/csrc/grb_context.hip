@@ -78,6 +78,10 @@ extern "C" GrB_Info GrB_init(GrB_Mode mode)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return GrB_PANIC;
     c.device = dev;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) c.num_cus = cus;
+    }
     c.blocking = (mode == GrB_BLOCKING);
     c.stream = nullptr;
     // keep freed blocks in the pool: BFS/SSSP loops allocate and free the same temporaries every call

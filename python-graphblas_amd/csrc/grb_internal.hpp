@@ -56,6 +56,7 @@ struct Context {
     bool initialized = false;
     bool blocking = false;
     int device = 0;
+    int num_cus = 256;
     hipStream_t stream = nullptr;  // null stream: ordered with torch's default stream
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     GrX_Stats stats{};

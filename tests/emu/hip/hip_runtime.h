@@ -48,6 +48,8 @@ inline const char *hipGetErrorString(hipError_t) { return "emu error"; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
 hipError_t hipGetDeviceCount(int *n);
 inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount };
+inline hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t, int) { *v = 3; return hipSuccess; }  // few CUs: persistent loops iterate
 inline hipError_t hipMallocAsync(void **p, size_t bytes, hipStream_t) { *p = malloc(bytes ? bytes : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 inline hipError_t hipFreeAsync(void *p, hipStream_t) { free(p); return hipSuccess; }
 inline hipError_t hipMemsetAsync(void *p, int v, size_t bytes, hipStream_t) { memset(p, v, bytes); return hipSuccess; }
@@ -104,6 +106,8 @@ inline unsigned long long __ballot(int pred)
 }
 inline int __any(int pred) { return __ballot(pred) != 0; }
 
+inline long long clock64() { return 0; }
+inline void __builtin_amdgcn_s_waitcnt(int) {}
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline int __popc(unsigned x) { return __builtin_popcount(x); }
 inline int __ffsll(unsigned long long x) { return __builtin_ffsll((long long)x); }
