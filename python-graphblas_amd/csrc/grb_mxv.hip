@@ -162,7 +162,7 @@ __device__ __forceinline__ void load_tile(const PullArgs &a, int64_t tile, int64
     }
 }
 
-template <typename T, int MONOID_CT, int MULT_CT, int IPT>
+template <typename T, int MONOID_CT, int MULT_CT, int IPT, bool PERSIST>
 __global__ __launch_bounds__(PULL_BLOCK) void k_mxv_pull(const PullArgs a)
 {
     using W = typename Widen<T>::type;
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(PULL_BLOCK) void k_mxv_pull(const PullArgs a)
         const int64_t last_row = i1 < a.m ? i1 : a.m - 1;
         const int nw = has_mask ? (int)((last_row >> 5) - (i0 >> 5)) + 1 : 0;
         // coordinates of the next tile of this workgroup (its staging loads are issued below)
-        const int64_t next = tile + gridDim.x;
+        const int64_t next = PERSIST ? tile + gridDim.x : a.n_tiles;  // (!PERSIST: one tile per workgroup)
         int64_t i0n = 0, i1n = 0;
         if (next < a.n_tiles) {
             i0n = a.tile_row[next];
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(PULL_BLOCK) void k_mxv_pull(const PullArgs a)
                 if (i > 0 && h[i]) {  // a new row starts here: the previous segment is complete
                     if (has) {
                         const W v = (W)acc;
-                        if (monoid == OP_ANY || !partial) s_tval[cur - 1] = v;
+                        if (monoid == OP_ANY || !partial || (a.dbg & 16)) s_tval[cur - 1] = v;
                         else atomic_combine<W>(&s_tval[cur - 1], v, monoid);
                         s_thas[cur - 1] = 1;
                     }
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(PULL_BLOCK) void k_mxv_pull(const PullArgs a)
             if (has) {  // last segment: shared if the row continues into the next thread's chunk
                 if (base + IPT < nnz_t && h_next == 0) partial = true;
                 const W v = (W)acc;
-                if (monoid == OP_ANY || !partial) s_tval[cur - 1] = v;
+                if (monoid == OP_ANY || !partial || (a.dbg & 16)) s_tval[cur - 1] = v;
                 else atomic_combine<W>(&s_tval[cur - 1], v, monoid);
                 s_thas[cur - 1] = 1;
             }
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(PULL_BLOCK) void k_mxv_pull(const PullArgs a)
             ((W *)a.first_val)[tile] = s_tval[0];
         }
         PHASE_STAMP(7);
-        if (next >= a.n_tiles) break;
+        if (!PERSIST || next >= a.n_tiles) break;
         tile = next;
         __syncthreads();  // LDS is recycled by the next tile
     }
@@ -658,8 +658,9 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
     a.dbg_times = (ctx().debug_flags & 8) ? dbg_times.p : nullptr;
     // persistent workgroups: as many as stay resident (LDS-bound), each walks tiles b, b+G, b+2G, ...
     const int64_t resident = (int64_t)ctx().num_cus * pull_blocks_per_cu<T, IPT>();
-    const int64_t G = std::min<int64_t>(a.n_tiles, std::max<int64_t>(resident, 1));
-    hipLaunchKernelGGL((k_mxv_pull<T, MON, MUL, IPT>), dim3((unsigned)G), dim3(PULL_BLOCK), 0, ctx().stream, a);
+    (void)resident;  // (a persistent variant, G = resident workgroups each prefetching its next tile, measured slower:
+                     //  the loop-carried tile registers cost 3x the VGPRs -- DESIGN.md "what did not work")
+    hipLaunchKernelGGL((k_mxv_pull<T, MON, MUL, IPT, false>), dim3((unsigned)a.n_tiles), dim3(PULL_BLOCK), 0, ctx().stream, a);
     if (a.dbg_times) report_phase_times(dbg_times.p, a.n_tiles);
     hipLaunchKernelGGL((k_mxv_seams<T, TILE>), dim3((unsigned)ceil_div(a.n_tiles, PULL_BLOCK / 64)), dim3(PULL_BLOCK), 0,
                        ctx().stream, a);
