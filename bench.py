@@ -163,6 +163,69 @@ def cpu_baseline_mxv(wl, torch, reps_budget_s=20.0):
                       "C oracle (oracle/grb_oracle.c, OpenMP) -- a CPU restatement, not SuiteSparse"}
 
 
+def main_mxm(args, gb, torch, device, rank, world, dist, barrier):
+    """configs[3]: C = A (+.x) A, plus_times INT64 on R-MAT (ones), rows of A sharded over the ranks, B = A
+    replicated; no collective in the timed loop (the product stays row-sharded).  value = nnz(C) / s."""
+    from graphblas_amd import _lib, sharded, synthetic
+
+    n = 1 << args.scale
+    lo, hi = sharded.row_block(n, rank, world)
+    ip_b, col_b = synthetic.rmat_csr(args.scale, device="cuda")
+    one = torch.ones(1, dtype=torch.int64, device="cuda")
+    B = device.matrix_from_device_csr(ip_b, col_b, one, n, n, "INT64", iso=True)
+    if world > 1:
+        ip_a = (ip_b[lo: hi + 1] - ip_b[lo]).contiguous()
+        col_a = col_b[ip_b[lo]: ip_b[hi]].contiguous()
+        A = device.matrix_from_device_csr(ip_a, col_a, one, hi - lo, n, "INT64", iso=True)
+    else:
+        A = B
+    sr = gb.semiring.plus_times["INT64"]
+    L = _lib.lib
+
+    def step():
+        C = gb.Matrix("INT64", hi - lo, n)
+        rc = L.GrB_mxm(C._carg, None, None, sr._carg, A._carg, B._carg, None)
+        if rc != 0:
+            raise RuntimeError(f"GrB_mxm failed with GrB_Info {rc}")
+        st = device.last_stats()
+        return st
+
+    for _ in range(args.warmup):
+        st = step()
+    barrier()
+    t0 = time.perf_counter()
+    device.timer_start()
+    for _ in range(args.steps):
+        st = step()
+    ev_ms = device.timer_stop()
+    barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt, float(st["out_nvals"]), float(st["flops"]), ev_ms], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt, nnz_c, flops, ev_ms = tmax[0].item(), tsum[1].item(), tsum[2].item(), tmax[3].item()
+    else:
+        nnz_c, flops = float(st["out_nvals"]), float(st["flops"])
+    ms = dt / args.steps * 1e3
+    nnz_a = float(col_b.numel())
+    alg_bytes = nnz_a * 12 + flops * 12 + nnz_c * 12 + 3 * (n + 1) * 8  # SURVEY.md section 8d, I = 4, V = 8
+    achieved = alg_bytes / world / (ev_ms / args.steps * 1e-3) / 1e9
+    if rank == 0:
+        print(json.dumps({
+            "metric": "SpGEMM nnz-out/s on R-MAT scale-%d" % args.scale, "value": nnz_c / (ms * 1e-3), "unit": "nnz(C)/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+            "config": {"workload": f"rmat{args.scale} mxm_plus_times: C = A (+.x) A, INT64 ones", "nnz_A": nnz_a,
+                       "flops": flops, "nnz_C": nnz_c, "parallelism": f"row-shard x{world}, B replicated"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_spgemm_hash / k_spgemm_spa",
+                         "kernel_ms_hip_events": ev_ms / args.steps, "algorithmic_bytes_per_launch": alg_bytes / world},
+            "cpu_baseline": None, "stats": st}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     import torch
@@ -228,7 +291,7 @@ def main():
         return wl, res
 
     if args.workload == "mxm_plus_times":
-        raise SystemExit("mxm bench: see --workload mxm_plus_times once GrB_mxm lands")
+        return main_mxm(args, gb, torch, device, rank, world, dist, barrier)
     wl, res = run(args.workload)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

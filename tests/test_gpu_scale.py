@@ -176,3 +176,35 @@ def test_full_scale_properties(gb):
     t = u.vxm(A.T, gb.semiring.min_plus).new()
     tv, tb = device.vector_device_views(t)
     assert torch.equal(tb, fb) and torch.equal(tv[fbits], fv[fbits])
+
+
+@pytest.mark.parametrize("scale", [10, 13])
+def test_mxm_rmat_vs_scipy(gb, scale):
+    """configs[3]-style A@A (plus_times INT64, ones) against scipy's csr @ csr -- integer, bit-exact -- plus the
+    masked (triangle-count style) C<A.S> = A@A against the oracle's write rule."""
+    sp = pytest.importorskip("scipy.sparse")
+    import torch
+
+    from graphblas_amd import device, synthetic
+    from oracle import grb_oracle as O
+
+    n = 1 << scale
+    indptr, col = synthetic.rmat_csr(scale, device="cuda")
+    one = torch.ones(1, dtype=torch.int64, device="cuda")
+    A = device.matrix_from_device_csr(indptr, col, one, n, n, "INT64", iso=True)
+    ip, cj = indptr.cpu().numpy(), col.cpu().numpy()
+    S = sp.csr_matrix((np.ones(cj.size, np.int64), cj, ip), shape=(n, n))
+    ref = (S @ S).tocsr()
+    ref.sort_indices()
+    C = A.mxm(A, gb.semiring.plus_times).new()
+    st = device.last_stats()
+    assert st["out_nvals"] == ref.nnz
+    Cp, Cj, Cx = C.to_csr()
+    assert np.array_equal(Cp.astype(np.int64), ref.indptr) and np.array_equal(Cj.astype(np.int64), ref.indices)
+    assert np.array_equal(Cx, ref.data)
+    M = A.mxm(A, gb.semiring.plus_times).new(mask=A.S)
+    oa = O.OMat(n, n, ip, cj.astype(np.int64), np.ones(cj.size, np.int64), "INT64")
+    exp = O.mxm(oa, oa, "plus_times", mask=oa, mask_struct=True)
+    Mp, Mj, Mx = M.to_csr()
+    assert np.array_equal(Mp.astype(np.int64), exp.indptr) and np.array_equal(Mj.astype(np.int64), exp.indices)
+    assert np.array_equal(Mx, exp.values)
