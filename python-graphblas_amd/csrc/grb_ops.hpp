@@ -177,9 +177,11 @@ __device__ __forceinline__ T from_acc(W v)
     else return (T)v;
 }
 
-// slot = monoid(slot, v) on an LDS (or global) word, compare-and-swap loop
+// slot = monoid(slot, v) on an LDS or global word.  plus / min / max / lor / land / lxor map to ONE hardware
+// atomic (ds_* / global_atomic_*, no return value, so a lane can keep issuing); times, lxnor and any other
+// operator fall back to a compare-and-swap loop.
 template <typename W>
-__device__ __forceinline__ void atomic_combine(W *slot, W v, int monoid)
+__device__ __forceinline__ void atomic_combine_cas(W *slot, W v, int monoid)
 {
     if constexpr (sizeof(W) == 4) {
         unsigned int *p = (unsigned int *)slot;
@@ -197,6 +199,52 @@ __device__ __forceinline__ void atomic_combine(W *slot, W v, int monoid)
             const W nw = apply_binop<W>(monoid, __builtin_bit_cast(W, assumed), v);
             old = atomicCAS(p, assumed, __builtin_bit_cast(unsigned long long, nw));
         } while (old != assumed);
+    }
+}
+
+template <typename W>
+__device__ __forceinline__ void atomic_combine(W *slot, W v, int monoid)
+{
+    if constexpr (std::is_same<W, float>::value || std::is_same<W, double>::value) {
+        switch (monoid) {
+        case OP_PLUS: atomicAdd(slot, v); return;
+        case OP_MIN: if (v == v) atomicMin(slot, v); return;  // fmin semantics: a NaN operand is ignored
+        case OP_MAX: if (v == v) atomicMax(slot, v); return;
+        default: atomic_combine_cas<W>(slot, v, monoid); return;
+        }
+    } else if constexpr (std::is_same<W, int32_t>::value) {
+        switch (monoid) {
+        case OP_PLUS: atomicAdd((int *)slot, (int)v); return;
+        case OP_MIN: atomicMin((int *)slot, (int)v); return;
+        case OP_MAX: atomicMax((int *)slot, (int)v); return;
+        case OP_LOR: if (v != 0) atomicOr((unsigned int *)slot, 1u); return;   // accumulators of lor/land/lxor hold 0/1
+        case OP_LAND: if (v == 0) atomicAnd((unsigned int *)slot, 0u); return;
+        case OP_LXOR: if (v != 0) atomicXor((unsigned int *)slot, 1u); return;
+        default: atomic_combine_cas<W>(slot, v, monoid); return;
+        }
+    } else if constexpr (std::is_same<W, uint32_t>::value) {
+        switch (monoid) {
+        case OP_PLUS: atomicAdd((unsigned int *)slot, (unsigned int)v); return;
+        case OP_MIN: atomicMin((unsigned int *)slot, (unsigned int)v); return;
+        case OP_MAX: atomicMax((unsigned int *)slot, (unsigned int)v); return;
+        default: atomic_combine_cas<W>(slot, v, monoid); return;
+        }
+    } else if constexpr (std::is_same<W, int64_t>::value) {
+        switch (monoid) {
+        case OP_PLUS: atomicAdd((unsigned long long *)slot, (unsigned long long)v); return;  // two's complement: same bits
+        case OP_MIN: atomicMin((long long *)slot, (long long)v); return;
+        case OP_MAX: atomicMax((long long *)slot, (long long)v); return;
+        default: atomic_combine_cas<W>(slot, v, monoid); return;
+        }
+    } else if constexpr (std::is_same<W, uint64_t>::value) {
+        switch (monoid) {
+        case OP_PLUS: atomicAdd((unsigned long long *)slot, (unsigned long long)v); return;
+        case OP_MIN: atomicMin((unsigned long long *)slot, (unsigned long long)v); return;
+        case OP_MAX: atomicMax((unsigned long long *)slot, (unsigned long long)v); return;
+        default: atomic_combine_cas<W>(slot, v, monoid); return;
+        }
+    } else {
+        atomic_combine_cas<W>(slot, v, monoid);
     }
 }
 

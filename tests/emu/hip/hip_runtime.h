@@ -132,3 +132,13 @@ inline unsigned int atomicExch(unsigned int *p, unsigned int v) { auto o = *p; *
 inline int atomicMax(int *p, int v) { auto o = *p; if (v > o) *p = v; return o; }
 inline unsigned int atomicMax(unsigned int *p, unsigned int v) { auto o = *p; if (v > o) *p = v; return o; }
 inline int atomicMin(int *p, int v) { auto o = *p; if (v < o) *p = v; return o; }
+inline unsigned int atomicMin(unsigned int *p, unsigned int v) { auto o = *p; if (v < o) *p = v; return o; }
+inline long long atomicMin(long long *p, long long v) { auto o = *p; if (v < o) *p = v; return o; }
+inline long long atomicMax(long long *p, long long v) { auto o = *p; if (v > o) *p = v; return o; }
+inline unsigned long long atomicMin(unsigned long long *p, unsigned long long v) { auto o = *p; if (v < o) *p = v; return o; }
+inline unsigned long long atomicMax(unsigned long long *p, unsigned long long v) { auto o = *p; if (v > o) *p = v; return o; }
+inline float atomicMin(float *p, float v) { auto o = *p; if (v < o || o != o) *p = v; return o; }
+inline float atomicMax(float *p, float v) { auto o = *p; if (v > o || o != o) *p = v; return o; }
+inline double atomicMin(double *p, double v) { auto o = *p; if (v < o || o != o) *p = v; return o; }
+inline double atomicMax(double *p, double v) { auto o = *p; if (v > o || o != o) *p = v; return o; }
+inline unsigned int atomicXor(unsigned int *p, unsigned int v) { auto o = *p; *p = o ^ v; return o; }
