@@ -93,6 +93,41 @@ __global__ void k_bin_starts(const uint64_t *keys, int64_t m, int64_t *bin_start
     bin_start[b] = lo;
 }
 
+// Visit every product A(row,k) * B(k,j): 16-lane groups take one A entry each and stride B(k,:).  The pointer
+// chase Aj -> Bp -> Bj is a chain of dependent HBM round trips, so each group keeps MM_UNROLL entries of the
+// row in flight (their k, their B row bounds and their first B entry are fetched before any is consumed).
+constexpr int MM_UNROLL = 4;
+template <typename F>
+__device__ __forceinline__ void foreach_product(const MxmArgs &a, int64_t row, int g, int gl, F &&f)
+{
+    constexpr int NG = MM_BLOCK / MM_GROUP;
+    const int64_t pend = a.Ap[row + 1];
+    for (int64_t p0 = a.Ap[row] + g; p0 < pend; p0 += NG * MM_UNROLL) {
+        int k[MM_UNROLL], jf[MM_UNROLL];
+        int64_t qb[MM_UNROLL], qe[MM_UNROLL];
+#pragma unroll
+        for (int u = 0; u < MM_UNROLL; u++) {
+            const int64_t p = p0 + u * NG;
+            k[u] = p < pend ? a.Aj[p] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < MM_UNROLL; u++) {
+            qb[u] = k[u] >= 0 ? a.Bp[k[u]] + gl : 0;
+            qe[u] = k[u] >= 0 ? a.Bp[k[u] + 1] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < MM_UNROLL; u++) jf[u] = qb[u] < qe[u] ? a.Bj[qb[u]] : -1;
+#pragma unroll
+        for (int u = 0; u < MM_UNROLL; u++) {
+            if (jf[u] >= 0) {
+                const int64_t p = p0 + u * NG;
+                f(jf[u], p, qb[u]);
+                for (int64_t q = qb[u] + MM_GROUP; q < qe[u]; q += MM_GROUP) f(a.Bj[q], p, q);
+            }
+        }
+    }
+}
+
 // ---- LDS hash kernels -------------------------------------------------------------------------------------------
 // One workgroup per row.  NUMERIC=false: count distinct columns.  NUMERIC=true: accumulate, sort, emit.
 template <typename T, int TABLE, bool NUMERIC>
@@ -118,26 +153,22 @@ __global__ __launch_bounds__(MM_BLOCK) void k_spgemm_hash(const MxmArgs a, const
 
     const int g = tid / MM_GROUP, gl = tid % MM_GROUP;
     int my_new = 0;
-    for (int64_t p = a.Ap[row] + g; p < a.Ap[row + 1]; p += MM_BLOCK / MM_GROUP) {
-        const int k = a.Aj[p];
-        const T av = a.need_a ? Ax[a.a_iso ? 0 : p] : (T)0;
-        for (int64_t q = a.Bp[k] + gl; q < a.Bp[k + 1]; q += MM_GROUP) {
-            const int j = a.Bj[q];
-            unsigned h = hash_col(j, TABLE - 1);
-            while (true) {
-                const int old = atomicCAS(&s_key[h], -1, j);
-                if (old == -1) { my_new++; break; }
-                if (old == j) break;
-                h = (h + 1) & (TABLE - 1);
-            }
-            if (NUMERIC) {
-                const T bv = a.need_b ? Bx[a.b_iso ? 0 : q] : (T)0;
-                const W prod = (W)apply_binop<T>(mult, av, bv);
-                if (monoid == OP_ANY) s_val[h] = prod;
-                else atomic_combine<W>(&s_val[h], prod, monoid);
-            }
+    foreach_product(a, row, g, gl, [&](int j, int64_t p, int64_t q) {
+        unsigned h = hash_col(j, TABLE - 1);
+        while (true) {
+            const int old = atomicCAS(&s_key[h], -1, j);
+            if (old == -1) { my_new++; break; }
+            if (old == j) break;
+            h = (h + 1) & (TABLE - 1);
         }
-    }
+        if (NUMERIC) {
+            const T av = a.need_a ? Ax[a.a_iso ? 0 : p] : (T)0;
+            const T bv = a.need_b ? Bx[a.b_iso ? 0 : q] : (T)0;
+            const W prod = (W)apply_binop<T>(mult, av, bv);
+            if (monoid == OP_ANY) s_val[h] = prod;
+            else atomic_combine<W>(&s_val[h], prod, monoid);
+        }
+    });
     if (!NUMERIC) {
         if (my_new) atomicAdd(&s_cnt, my_new);
         __syncthreads();
@@ -199,31 +230,26 @@ __global__ __launch_bounds__(MM_BLOCK) void k_spgemm_spa(const MxmArgs a, const 
         if (tid == 0) { s_cnt = 0; s_base = 0; }
         __syncthreads();
         int my_new = 0;
-        for (int64_t p = a.Ap[row] + g; p < a.Ap[row + 1]; p += MM_BLOCK / MM_GROUP) {
-            const int k = a.Aj[p];
-            const T av = a.need_a ? Ax[a.a_iso ? 0 : p] : (T)0;
-            for (int64_t q = a.Bp[k] + gl; q < a.Bp[k + 1]; q += MM_GROUP) {
-                const int j = a.Bj[q];
-                const unsigned long long bit = 1ull << (j & 63);
+        foreach_product(a, row, g, gl, [&](int j, int64_t p, int64_t q) {
+            const unsigned long long bit = 1ull << (j & 63);
+            if (NUMERIC) {
+                atomicOr(&bits[j >> 6], bit);
+                const T av = a.need_a ? Ax[a.a_iso ? 0 : p] : (T)0;
+                const T bv = a.need_b ? Bx[a.b_iso ? 0 : q] : (T)0;
+                const W prod = (W)apply_binop<T>(mult, av, bv);
+                if (monoid == OP_ANY) vals[j] = prod;
+                else atomic_combine<W>(&vals[j], prod, monoid);
+            } else {
                 const unsigned long long old = atomicOr(&bits[j >> 6], bit);
                 if (!(old & bit)) my_new++;
-                if (NUMERIC) {
-                    const T bv = a.need_b ? Bx[a.b_iso ? 0 : q] : (T)0;
-                    const W prod = (W)apply_binop<T>(mult, av, bv);
-                    if (monoid == OP_ANY) vals[j] = prod;
-                    else atomic_combine<W>(&vals[j], prod, monoid);
-                }
             }
-        }
+        });
         if (!NUMERIC) {
             if (my_new) atomicAdd(&s_cnt, my_new);
             __syncthreads();
             if (tid == 0) a.row_nnz[row] = s_cnt;
             // clear the touched words again (second walk over the same products)
-            for (int64_t p = a.Ap[row] + g; p < a.Ap[row + 1]; p += MM_BLOCK / MM_GROUP) {
-                const int k = a.Aj[p];
-                for (int64_t q = a.Bp[k] + gl; q < a.Bp[k + 1]; q += MM_GROUP) bits[a.Bj[q] >> 6] = 0ull;
-            }
+            foreach_product(a, row, g, gl, [&](int j, int64_t, int64_t) { bits[j >> 6] = 0ull; });
             __syncthreads();
             continue;
         }
@@ -366,10 +392,10 @@ static void run_bins(MxmArgs &a, const RowBins &rb)
     if (rb.count(3)) hipLaunchKernelGGL((k_spgemm_hash<T, T3, NUMERIC>), dim3((unsigned)rb.count(3)), dim3(MM_BLOCK), 0, ctx().stream, a, rb.ptr(3));
     ctx().stats.kernel_launches += 3;
     if (rb.count(4)) {
-        // dense accumulators: as many workgroup slices as fit in ~12 GiB, at most 512
+        // dense accumulators: one slice per resident workgroup (8 per CU), as many as fit in ~32 GiB
         const int64_t words = (int64_t)bits_words64((uint64_t)a.n);
         const int64_t slice_bytes = words * 8 + (NUMERIC ? words * 64 * (int64_t)sizeof(W) : 0);
-        int64_t G = std::min<int64_t>(std::min<int64_t>(512, rb.count(4)), std::max<int64_t>(1, (12ll << 30) / slice_bytes));
+        int64_t G = std::min<int64_t>(std::min<int64_t>((int64_t)ctx().num_cus * 8, rb.count(4)), std::max<int64_t>(1, (32ll << 30) / slice_bytes));
         DevBuf<uint64_t> bits((size_t)(G * words), true);
         DevBuf<W> vals(NUMERIC ? (size_t)(G * words * 64) : 1);
         if (NUMERIC) {
