@@ -56,9 +56,7 @@ struct PullArgs {
     uint8_t *carry_has;
     void *first_val;
     uint8_t *first_has;  // bit0: has a partial, bit1: the tile's first row started in an earlier tile
-    int hot_k;           // columns re-coded < hot_k live in the hot table (0 = no table)
-    const void *hot_val;
-    const uint32_t *hot_bits;
+    int64_t x_len;       // entries of the u image the column codes index ([hot table | u] when a hot table is in use)
     long long *dbg_times;  // GRB_DEBUG_FLAGS & 8: 10 phase timestamps per tile (thread 0)
     int dbg;             // ablation switches (GRB_DEBUG): 1 = no x gathers, 2 = no A staging loads, 4 = no epilogue
 };
@@ -107,8 +105,28 @@ __device__ __forceinline__ bool write_rule_row(const PullArgs &a, int64_t row, b
 #define PADI(x) ((x) + ((x) >> 5))
 #define PHASE_STAMP(i) do { if (a.dbg_times && threadIdx.x == 0) a.dbg_times[tile * 10 + (i)] = clock64(); } while (0)
 
-// Everything one thread fetches from HBM to stage one tile; loaded one tile AHEAD of its use so that
-// the fetch latency hides behind the previous tile's gathers and fold (persistent workgroups).
+// ---- buffer-descriptor loads: the hardware range check returns 0 for out-of-range offsets, so gathers of
+//      "no column" (index -1) and tile tails need neither a branch nor an exec-mask dance -------------------
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, int64_t bytes)
+{
+    const int64_t lim = bytes < 0 ? 0 : (bytes > 0xfffffff0ll ? 0xfffffff0ll : bytes);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)(unsigned)lim, 0x00020000);
+}
+template <typename T>
+__device__ __forceinline__ T buf_load(__amdgpu_buffer_rsrc_t r, unsigned byte_off)
+{
+    if constexpr (sizeof(T) == 1) return __builtin_bit_cast(T, (unsigned char)__builtin_amdgcn_raw_buffer_load_b8(r, byte_off, 0, 0));
+    else if constexpr (sizeof(T) == 2) return __builtin_bit_cast(T, (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, byte_off, 0, 0));
+    else if constexpr (sizeof(T) == 4) return __builtin_bit_cast(T, (unsigned int)__builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+    else {
+        const auto v = __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, 0);
+        const unsigned long long u = (unsigned long long)v[0] | ((unsigned long long)v[1] << 32);
+        return __builtin_bit_cast(T, u);
+    }
+}
+
+// Everything one thread fetches from HBM to stage one tile.  creg[4q+i] / vreg[4q+i] hold tile position
+// (tid + q*256)*4 + i: column indices (and 4-byte values) travel as 16-byte loads.
 template <typename T, int IPT>
 struct TileRegs {
     int64_t i0, i1, j0;
@@ -127,6 +145,7 @@ __device__ __forceinline__ void load_tile(const PullArgs &a, int64_t tile, int64
                                           bool need_old, TileRegs<T, IPT> &r)
 {
     constexpr int TILE = PULL_BLOCK * IPT;
+    static_assert(IPT % 4 == 0, "IPT must be a multiple of 4 (16-byte staging loads)");
     const int64_t total = a.m + a.nnz;
     const int64_t d0 = tile * (int64_t)TILE;
     const int64_t d1 = d0 + TILE < total ? d0 + TILE : total;
@@ -135,13 +154,32 @@ __device__ __forceinline__ void load_tile(const PullArgs &a, int64_t tile, int64
     r.j0 = d0 - i0;
     r.nrows_t = (int)(i1 - i0);
     r.nnz_t = (int)((d1 - i1) - r.j0);
-    const int32_t *colp = a.col + r.j0;
-    const T *avp = (const T *)a.aval + (a.a_iso ? 0 : r.j0);
+    const int64_t left = a.nnz - r.j0;  // entries from the tile start to the end of the arrays
+    const __amdgpu_buffer_rsrc_t crs = make_rsrc(a.col + r.j0, left * 4);
+    const __amdgpu_buffer_rsrc_t vrs = make_rsrc((const T *)a.aval + (a.a_iso ? 0 : r.j0), stage_vals ? left * (int64_t)sizeof(T) : 0);
+    const bool whole = left >= TILE + 4;  // 16-byte loads never straddle the end of the arrays
 #pragma unroll
-    for (int s = 0; s < IPT; s++) {
-        const int k = tid + s * PULL_BLOCK;
-        r.creg[s] = (k < r.nnz_t) ? ((a.dbg & 2) ? (k & 1023) : colp[k]) : 0;
-        r.vreg[s] = (stage_vals && k < r.nnz_t) ? ((a.dbg & 2) ? (T)1 : avp[k]) : (T)0;
+    for (int q = 0; q < IPT / 4; q++) {
+        const unsigned k = (unsigned)(tid + q * PULL_BLOCK) * 4u;
+        if (whole && !(a.dbg & 2)) {
+            const auto c4 = __builtin_amdgcn_raw_buffer_load_b128(crs, k * 4u, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; i++) r.creg[q * 4 + i] = (int)c4[i];
+            if constexpr (sizeof(T) == 4) {
+                const auto v4 = __builtin_amdgcn_raw_buffer_load_b128(vrs, k * 4u, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; i++) r.vreg[q * 4 + i] = __builtin_bit_cast(T, (unsigned int)v4[i]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; i++) r.vreg[q * 4 + i] = buf_load<T>(vrs, (k + i) * (unsigned)sizeof(T));
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                r.creg[q * 4 + i] = (a.dbg & 2) ? (int)((k + i) & 1023) : buf_load<int>(crs, (k + i) * 4u);
+                r.vreg[q * 4 + i] = (a.dbg & 2) ? (T)1 : buf_load<T>(vrs, (k + i) * (unsigned)sizeof(T));
+            }
+        }
     }
     r.rs = r.re = 0;
     if (tid <= r.nrows_t && i0 + tid < a.m) {
@@ -183,13 +221,13 @@ __global__ __launch_bounds__(PULL_BLOCK) void k_mxv_pull(const PullArgs a)
     const int lane = tid & 63, wave = tid >> 6;
     const T *aval = (const T *)a.aval;
     const T *uval = (const T *)a.u_val;
-    const T *hotv = (const T *)a.hot_val;
-    const int hot_k = a.hot_k;
     const bool need_aval = a.need_aval != 0, need_uval = a.need_uval != 0;
     const bool has_mask = a.has_mask != 0;
     const bool stage_vals = need_aval && !a.a_iso;
     const bool need_old = (a.accum >= 0) || a.fresh;
     const T iso_v = (a.a_iso && need_aval) ? aval[0] : (T)0;
+    const __amdgpu_buffer_rsrc_t xval_rs = make_rsrc(a.u_val, a.x_len * (int64_t)sizeof(T));
+    const __amdgpu_buffer_rsrc_t xbits_rs = make_rsrc(a.u_bits, a.u_full ? 0 : ((a.x_len + 63) >> 6) * 8);
 
     int64_t tile = blockIdx.x;
     if (tile >= a.n_tiles) return;
@@ -224,11 +262,12 @@ __global__ __launch_bounds__(PULL_BLOCK) void k_mxv_pull(const PullArgs a)
         }
         for (int k = tid * 8; k < TILE + 8; k += PULL_BLOCK * 8) *(uint4 *)&s_head[k] = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
-        for (int s = 0; s < IPT; s++) {
-            const int k = tid + s * PULL_BLOCK;
-            if (k < nnz_t) {
-                s_col[PADI(k)] = R.creg[s];
-                if (stage_vals) s_aval[PADI(k)] = R.vreg[s];
+        for (int q = 0; q < IPT / 4; q++) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int k = (tid + q * PULL_BLOCK) * 4 + i;  // (< TILE: always inside the LDS arrays)
+                s_col[PADI(k)] = R.creg[q * 4 + i];
+                if (stage_vals) s_aval[PADI(k)] = R.vreg[q * 4 + i];
             }
         }
         if (tid == 0) s_any = has_mask ? 0 : 1;
@@ -272,7 +311,6 @@ __global__ __launch_bounds__(PULL_BLOCK) void k_mxv_pull(const PullArgs a)
 #pragma unroll
                 for (int i = 0; i < IPT; i++) h[i] = s_head[base + i];
             }
-            const int h_next = s_head[base + IPT];  // does the next thread's chunk start a new row?
             int lastk = 0;
 #pragma unroll
             for (int i = 0; i < IPT; i++) lastk = h[i] ? h[i] : lastk;  // heads increase along the tile: last = max
@@ -300,7 +338,8 @@ __global__ __launch_bounds__(PULL_BLOCK) void k_mxv_pull(const PullArgs a)
                 const bool valid = base + i < nnz_t;
                 cc[i] = (valid && ROW_ACTIVE(e - 1)) ? s_col[PADI(base + i)] : -1;
             }
-            // ---- gathers: presence words, then values -- IPT independent random accesses in flight per lane ---
+            // ---- gathers: presence words, then values -- IPT independent random accesses in flight per lane.
+            //      Buffer loads: "no column" (-1) is out of range, returns 0 and costs no memory traffic ----------
             bool xp[IPT];
             T xv[IPT];
             if (a.u_full || (a.dbg & 1)) {
@@ -309,54 +348,40 @@ __global__ __launch_bounds__(PULL_BLOCK) void k_mxv_pull(const PullArgs a)
             } else {
                 uint32_t bw[IPT];
 #pragma unroll
-                for (int i = 0; i < IPT; i++) {
-                    const int c = cc[i];
-                    bw[i] = c >= 0 ? (c < hot_k ? a.hot_bits[c >> 5] : a.u_bits[(c - hot_k) >> 5]) : 0u;
-                }
+                for (int i = 0; i < IPT; i++) bw[i] = buf_load<uint32_t>(xbits_rs, (unsigned)(cc[i] >> 5) * 4u);
 #pragma unroll
-                for (int i = 0; i < IPT; i++) {
-                    const int c = cc[i] < hot_k ? cc[i] : cc[i] - hot_k;
-                    xp[i] = cc[i] >= 0 && ((bw[i] >> (c & 31)) & 1u);
-                }
+                for (int i = 0; i < IPT; i++) xp[i] = (bw[i] >> (cc[i] & 31)) & 1u;
             }
+            if (need_uval && !(a.dbg & 1)) {
 #pragma unroll
-            for (int i = 0; i < IPT; i++) {
-                const int c = cc[i];
-                xv[i] = (xp[i] && need_uval) ? ((a.dbg & 1) ? (T)(c & 7) : (c < hot_k ? hotv[c] : uval[c - hot_k])) : (T)0;
+                for (int i = 0; i < IPT; i++) xv[i] = buf_load<T>(xval_rs, xp[i] ? (unsigned)cc[i] * (unsigned)sizeof(T) : 0xfffffff8u);
+            } else {
+#pragma unroll
+                for (int i = 0; i < IPT; i++) xv[i] = (T)(cc[i] & 7);
             }
             PHASE_STAMP(4);
 
-            // ---- segmented fold of my chunk; a segment shared with other threads combines by LDS atomic -------
+            // ---- segmented fold of my chunk, straight-line: a segment ends where the next item starts a row (or
+            //      at the end of the chunk) and is emitted with ONE LDS atomic into its row's accumulator ------------
             T acc = (T)0;
             bool has = false;
-            bool partial = (h[0] == 0);  // my first segment began in an earlier thread (or an earlier tile)
-            int cur = ek[0];
 #pragma unroll
             for (int i = 0; i < IPT; i++) {
-                if (i > 0 && h[i]) {  // a new row starts here: the previous segment is complete
-                    if (has) {
-                        const W v = (W)acc;
-                        if (monoid == OP_ANY || !partial || (a.dbg & 16)) s_tval[cur - 1] = v;
-                        else atomic_combine<W>(&s_tval[cur - 1], v, monoid);
-                        s_thas[cur - 1] = 1;
-                    }
-                    has = false;
-                    partial = false;
-                    cur = ek[i];
+                const T av = need_aval ? (a.a_iso ? iso_v : s_aval[PADI(base + i)]) : (T)0;
+                const T prod = apply_binop<T>(mult, av, xv[i]);
+                const bool fresh_seg = (i == 0) || (h[i] != 0);
+                const bool keep = has && !fresh_seg;
+                acc = xp[i] ? (keep ? apply_binop<T>(monoid, acc, prod) : prod) : (keep ? acc : (T)0);
+                has = xp[i] || keep;
+                const bool seg_end = (i == IPT - 1) ? true : (h[i + 1] != 0);
+                if (seg_end && has) {
+                    const int k = ek[i] - 1;
+                    // (row accumulators start at the monoid identity, so one atomic is right whether or not other
+                    //  threads share the row; "any" just stores)
+                    if (monoid == OP_ANY || (a.dbg & 16)) s_tval[k] = (W)acc;
+                    else atomic_combine<W>(&s_tval[k], (W)acc, monoid);
+                    s_thas[k] = 1;
                 }
-                if (xp[i]) {
-                    const T av = need_aval ? (a.a_iso ? iso_v : s_aval[PADI(base + i)]) : (T)0;
-                    const T prod = apply_binop<T>(mult, av, xv[i]);
-                    acc = has ? apply_binop<T>(monoid, acc, prod) : prod;
-                    has = true;
-                }
-            }
-            if (has) {  // last segment: shared if the row continues into the next thread's chunk
-                if (base + IPT < nnz_t && h_next == 0) partial = true;
-                const W v = (W)acc;
-                if (monoid == OP_ANY || !partial || (a.dbg & 16)) s_tval[cur - 1] = v;
-                else atomic_combine<W>(&s_tval[cur - 1], v, monoid);
-                s_thas[cur - 1] = 1;
             }
         }
         __syncthreads();
@@ -786,28 +811,35 @@ static void mxv_core(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_Binar
     a.need_aval = !(mult == OP_PAIR || mult == OP_SECOND) && S->nvals > 0;
     a.need_uval = !(mult == OP_PAIR || mult == OP_FIRST || mult == OP_ANY);
     if (mult == OP_ANY) a.need_aval = S->nvals > 0;
-    // hot-column table (wide matrices with a skewed column-degree distribution)
-    DevBuf<char> hot_val(0);
-    DevBuf<uint64_t> hot_bits(0);
+    a.x_len = (int64_t)u->n;
+    if ((uint64_t)u->n * type_size(st) >= 0xfffffff0ull)
+        fail(GrB_NOT_IMPLEMENTED, "mxv/vxm: input vectors of 4 GiB or more are not supported by the pull kernel yet");
+    // hot-column table (wide matrices with a skewed column-degree distribution): the kernel indexes ONE image
+    // [ K hot entries | the n entries of u ] with the re-coded column indices (hot rank, or K + col)
+    DevBuf<char> xcat_val(0);
+    DevBuf<uint64_t> xcat_bits(0);
     if (a.need_uval || !a.u_full) {
         ensure_hot(S, type_size(st));
-        if (S->hot_state == 1) {
-            const int k = (int)S->hot_k;
-            dev_free(hot_val.p);
-            hot_val.p = (char *)dev_alloc(type_size(st) * (size_t)k);
-            dev_free(hot_bits.p);
-            hot_bits.p = (uint64_t *)dev_alloc((size_t)(k / 64) * 8);
+        if (S->hot_state == 1 && (uint64_t)(u->n + S->hot_k) * type_size(st) < 0xfffffff0ull) {
+            const int k = (int)S->hot_k;  // multiple of 64
+            const size_t vb = type_size(st);
+            dev_free(xcat_val.p);
+            xcat_val.p = (char *)dev_alloc(vb * (size_t)(k + u->n));
+            dev_free(xcat_bits.p);
+            xcat_bits.p = (uint64_t *)dev_alloc((size_t)(k / 64 + bits_words64(u->n)) * 8);
             GRB_DISPATCH_TYPE(st, T, {
                 hipLaunchKernelGGL((k_hot_gather<T>), dim3((unsigned)ceil_div(k, 256)), dim3(256), 0, ctx().stream,
                                    (const int32_t *)S->d_hot_cols, k, (const T *)uval, (const uint32_t *)u->d_bits, a.u_full,
-                                   (T *)hot_val.p, hot_bits.p);
+                                   (T *)xcat_val.p, xcat_bits.p);
             })
+            d2d(xcat_val.p + vb * (size_t)k, uval, vb * (size_t)u->n);
+            if (!a.u_full) d2d(xcat_bits.p + k / 64, u->d_bits, bits_words64(u->n) * 8);
             ctx().stats.kernel_launches += 1;
-            a.col = S->d_col_hot;
-            a.hot_k = k;
             ctx().stats.hot_k = k;
-            a.hot_val = hot_val.p;
-            a.hot_bits = (const uint32_t *)hot_bits.p;
+            a.col = S->d_col_hot;
+            a.u_val = xcat_val.p;
+            a.u_bits = (const uint32_t *)xcat_bits.p;
+            a.x_len = (int64_t)u->n + k;
         }
     }
     a.m_bits = m_bits;

@@ -108,6 +108,30 @@ inline int __any(int pred) { return __ballot(pred) != 0; }
 
 inline long long clock64() { return 0; }
 inline void __builtin_amdgcn_s_waitcnt(int) {}
+// raw buffer loads: out-of-range offsets return 0 (per dword), like the hardware range check with stride 0
+struct __amdgpu_buffer_rsrc_t { const char *base; unsigned n; };
+inline __amdgpu_buffer_rsrc_t __builtin_amdgcn_make_buffer_rsrc(void *p, short, int n, int) { return {(const char *)p, (unsigned)n}; }
+template <typename T> inline T emu_buf_load(__amdgpu_buffer_rsrc_t r, unsigned off)
+{
+    T v{};
+    if ((unsigned long long)off + sizeof(T) <= r.n) memcpy(&v, r.base + off, sizeof(T));
+    return v;
+}
+typedef unsigned emu_u32x4 __attribute__((vector_size(16)));
+typedef unsigned emu_u32x2 __attribute__((vector_size(8)));
+inline unsigned char __builtin_amdgcn_raw_buffer_load_b8(__amdgpu_buffer_rsrc_t r, unsigned off, int, int) { return emu_buf_load<unsigned char>(r, off); }
+inline unsigned short __builtin_amdgcn_raw_buffer_load_b16(__amdgpu_buffer_rsrc_t r, unsigned off, int, int) { return emu_buf_load<unsigned short>(r, off); }
+inline unsigned __builtin_amdgcn_raw_buffer_load_b32(__amdgpu_buffer_rsrc_t r, unsigned off, int, int) { return emu_buf_load<unsigned>(r, off); }
+inline emu_u32x2 __builtin_amdgcn_raw_buffer_load_b64(__amdgpu_buffer_rsrc_t r, unsigned off, int, int)
+{
+    emu_u32x2 v = {emu_buf_load<unsigned>(r, off), emu_buf_load<unsigned>(r, off + 4)};
+    return v;
+}
+inline emu_u32x4 __builtin_amdgcn_raw_buffer_load_b128(__amdgpu_buffer_rsrc_t r, unsigned off, int, int)
+{
+    emu_u32x4 v = {emu_buf_load<unsigned>(r, off), emu_buf_load<unsigned>(r, off + 4), emu_buf_load<unsigned>(r, off + 8), emu_buf_load<unsigned>(r, off + 12)};
+    return v;
+}
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline int __popc(unsigned x) { return __builtin_popcount(x); }
 inline int __ffsll(unsigned long long x) { return __builtin_ffsll((long long)x); }
