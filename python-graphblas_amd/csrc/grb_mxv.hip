@@ -100,10 +100,7 @@ __device__ __forceinline__ bool write_rule_row(const PullArgs &a, int64_t row, b
     return t_has;
 }
 
-// LDS index with one pad word per 32: a lane reading IPT consecutive entries (stride IPT across lanes)
-// and a lane reading entry tid + s*256 (stride 1) are both bank-conflict free.
-#define PADI(x) ((x) + ((x) >> 5))
-#define PHASE_STAMP(i) do { if (a.dbg_times && threadIdx.x == 0) a.dbg_times[tile * 10 + (i)] = clock64(); } while (0)
+#define PHASE_STAMP(i) do { if (a.dbg_times && threadIdx.x == 0) a.dbg_times[blockIdx.x * 10 + (i)] = clock64(); } while (0)
 
 // ---- buffer-descriptor loads: the hardware range check returns 0 for out-of-range offsets, so gathers of
 //      "no column" (index -1) and tile tails need neither a branch nor an exec-mask dance -------------------
@@ -125,89 +122,14 @@ __device__ __forceinline__ T buf_load(__amdgpu_buffer_rsrc_t r, unsigned byte_of
     }
 }
 
-// Everything one thread fetches from HBM to stage one tile.  creg[4q+i] / vreg[4q+i] hold tile position
-// (tid + q*256)*4 + i: column indices (and 4-byte values) travel as 16-byte loads.
-template <typename T, int IPT>
-struct TileRegs {
-    int64_t i0, i1, j0;
-    int nnz_t, nrows_t;
-    int creg[IPT];
-    T vreg[IPT];
-    int64_t rs, re;  // row start / end (absolute) of row i0 + tid
-    int64_t rs0;     // start of row i0 relative to the tile (< 0: it began in an earlier tile)
-    uint32_t mword;
-    uint64_t pre_word;
-    T pre_val;
-};
-
-template <typename T, int IPT>
-__device__ __forceinline__ void load_tile(const PullArgs &a, int64_t tile, int64_t i0, int64_t i1, int tid, bool stage_vals,
-                                          bool need_old, TileRegs<T, IPT> &r)
-{
-    constexpr int TILE = PULL_BLOCK * IPT;
-    static_assert(IPT % 4 == 0, "IPT must be a multiple of 4 (16-byte staging loads)");
-    const int64_t total = a.m + a.nnz;
-    const int64_t d0 = tile * (int64_t)TILE;
-    const int64_t d1 = d0 + TILE < total ? d0 + TILE : total;
-    r.i0 = i0;
-    r.i1 = i1;
-    r.j0 = d0 - i0;
-    r.nrows_t = (int)(i1 - i0);
-    r.nnz_t = (int)((d1 - i1) - r.j0);
-    const int64_t left = a.nnz - r.j0;  // entries from the tile start to the end of the arrays
-    const __amdgpu_buffer_rsrc_t crs = make_rsrc(a.col + r.j0, left * 4);
-    const __amdgpu_buffer_rsrc_t vrs = make_rsrc((const T *)a.aval + (a.a_iso ? 0 : r.j0), stage_vals ? left * (int64_t)sizeof(T) : 0);
-    const bool whole = left >= TILE + 4;  // 16-byte loads never straddle the end of the arrays
-#pragma unroll
-    for (int q = 0; q < IPT / 4; q++) {
-        const unsigned k = (unsigned)(tid + q * PULL_BLOCK) * 4u;
-        if (whole && !(a.dbg & 2)) {
-            const auto c4 = __builtin_amdgcn_raw_buffer_load_b128(crs, k * 4u, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 4; i++) r.creg[q * 4 + i] = (int)c4[i];
-            if constexpr (sizeof(T) == 4) {
-                const auto v4 = __builtin_amdgcn_raw_buffer_load_b128(vrs, k * 4u, 0, 0);
-#pragma unroll
-                for (int i = 0; i < 4; i++) r.vreg[q * 4 + i] = __builtin_bit_cast(T, (unsigned int)v4[i]);
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; i++) r.vreg[q * 4 + i] = buf_load<T>(vrs, (k + i) * (unsigned)sizeof(T));
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                r.creg[q * 4 + i] = (a.dbg & 2) ? (int)((k + i) & 1023) : buf_load<int>(crs, (k + i) * 4u);
-                r.vreg[q * 4 + i] = (a.dbg & 2) ? (T)1 : buf_load<T>(vrs, (k + i) * (unsigned)sizeof(T));
-            }
-        }
-    }
-    r.rs = r.re = 0;
-    if (tid <= r.nrows_t && i0 + tid < a.m) {
-        r.rs = a.rowptr[i0 + tid];
-        r.re = a.rowptr[i0 + tid + 1];
-    }
-    r.rs0 = (i0 < a.m ? a.rowptr[i0] : a.nnz) - r.j0;
-    const int64_t last_row = i1 < a.m ? i1 : a.m - 1;
-    const int nw = a.has_mask ? (int)((last_row >> 5) - (i0 >> 5)) + 1 : 0;
-    r.mword = (tid < nw) ? ((const uint32_t *)a.m_bits)[(i0 >> 5) + tid] : 0u;
-    const int64_t pre_g = (i0 >> 6) + (tid >> 6);
-    const int64_t pre_row = (pre_g << 6) + (tid & 63);
-    r.pre_word = 0;
-    r.pre_val = (T)0;
-    if ((pre_g << 6) < a.m) {
-        r.pre_word = a.w_old_bits[pre_g];
-        if (need_old && pre_row < a.m) r.pre_val = ((const T *)a.w_old_val)[pre_row];
-    }
-}
-
-template <typename T, int MONOID_CT, int MULT_CT, int IPT, bool PERSIST>
+template <typename T, int MONOID_CT, int MULT_CT, int IPT>
 __global__ __launch_bounds__(PULL_BLOCK) void k_mxv_pull(const PullArgs a)
 {
     using W = typename Widen<T>::type;
     constexpr int TILE = PULL_BLOCK * IPT;
-    constexpr int TILEP = TILE + TILE / 32 + 1;
-    __shared__ int s_col[TILEP];
-    __shared__ T s_aval[TILEP];
+    static_assert(IPT % 4 == 0, "IPT must be a multiple of 4 (16-byte loads)");
+    // LDS holds only per-ROW state (row-start marks, row accumulators): the tile's column indices and values
+    // go straight from HBM into the registers of the thread that consumes them (IPT consecutive entries).
     __shared__ __attribute__((aligned(16))) unsigned short s_head[TILE + 8];
     __shared__ W s_tval[TILE + 1];
     __shared__ unsigned char s_thas[TILE + 1];
@@ -219,220 +141,236 @@ __global__ __launch_bounds__(PULL_BLOCK) void k_mxv_pull(const PullArgs a)
     const int mult = MULT_CT >= 0 ? MULT_CT : a.mult;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
+    const int64_t tile = blockIdx.x;
     const T *aval = (const T *)a.aval;
-    const T *uval = (const T *)a.u_val;
     const bool need_aval = a.need_aval != 0, need_uval = a.need_uval != 0;
     const bool has_mask = a.has_mask != 0;
     const bool stage_vals = need_aval && !a.a_iso;
     const bool need_old = (a.accum >= 0) || a.fresh;
+    PHASE_STAMP(0);
+
+    // ---- tile coordinates -------------------------------------------------------------------------------------
+    const int64_t i0 = a.tile_row[tile], i1 = a.tile_row[tile + 1];
+    const int64_t total = a.m + a.nnz;
+    const int64_t d0 = tile * (int64_t)TILE;
+    const int64_t d1 = d0 + TILE < total ? d0 + TILE : total;
+    const int64_t j0 = d0 - i0;
+    const int nrows_t = (int)(i1 - i0);  // rows whose end falls inside this tile (slot nrows_t = the row still open)
+    const int nnz_t = (int)((d1 - i1) - j0);
+    const int base = tid * IPT;  // my IPT consecutive entries of the tile
+
+    // ---- issue every HBM load of the tile now: my entries (16-byte buffer loads; the descriptor ends at the
+    //      end of the arrays, out-of-range parts read 0), my row's bounds, mask word, old w of my first rows ----
+    const int64_t left = a.nnz - j0;
+    const __amdgpu_buffer_rsrc_t crs = make_rsrc(a.col + j0, left * 4);
+    const __amdgpu_buffer_rsrc_t vrs = make_rsrc(aval + (a.a_iso ? 0 : j0), stage_vals ? left * (int64_t)sizeof(T) : 0);
+    const bool whole = left >= TILE + 4;  // 16-byte loads never straddle the end of the arrays
+    int creg[IPT];
+    T vreg[IPT];
+#pragma unroll
+    for (int q = 0; q < IPT / 4; q++) {
+        const unsigned k = (unsigned)(base + q * 4);
+        if (whole && !(a.dbg & 2)) {
+            const auto c4 = __builtin_amdgcn_raw_buffer_load_b128(crs, k * 4u, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; i++) creg[q * 4 + i] = (int)c4[i];
+            if constexpr (sizeof(T) == 4) {
+                const auto v4 = __builtin_amdgcn_raw_buffer_load_b128(vrs, k * 4u, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; i++) vreg[q * 4 + i] = __builtin_bit_cast(T, (unsigned int)v4[i]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; i++) vreg[q * 4 + i] = buf_load<T>(vrs, (k + i) * (unsigned)sizeof(T));
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                creg[q * 4 + i] = (a.dbg & 2) ? (int)((k + i) & 1023) : buf_load<int>(crs, (k + i) * 4u);
+                vreg[q * 4 + i] = (a.dbg & 2) ? (T)1 : buf_load<T>(vrs, (k + i) * (unsigned)sizeof(T));
+            }
+        }
+    }
+    int64_t my_rs = 0, my_re = 0;
+    if (tid <= nrows_t && i0 + tid < a.m) {
+        my_rs = a.rowptr[i0 + tid];
+        my_re = a.rowptr[i0 + tid + 1];
+    }
+    const int64_t rs0_64 = (i0 < a.m ? a.rowptr[i0] : a.nnz) - j0;  // start of row i0 relative to the tile
+    const int abase = (int)(i0 & 31);  // bit of row i0 inside s_act[0]
+    const int64_t last_row = i1 < a.m ? i1 : a.m - 1;
+    const int nw = has_mask ? (int)((last_row >> 5) - (i0 >> 5)) + 1 : 0;
+    const uint32_t mword = (tid < nw) ? ((const uint32_t *)a.m_bits)[(i0 >> 5) + tid] : 0u;
+    const int64_t pre_g = (i0 >> 6) + wave;
+    const int64_t pre_row = (pre_g << 6) + lane;
+    uint64_t pre_word = 0;
+    T pre_val = (T)0;
+    if ((pre_g << 6) < a.m) {
+        pre_word = a.w_old_bits[pre_g];
+        if (need_old && pre_row < a.m) pre_val = ((const T *)a.w_old_val)[pre_row];
+    }
     const T iso_v = (a.a_iso && need_aval) ? aval[0] : (T)0;
     const __amdgpu_buffer_rsrc_t xval_rs = make_rsrc(a.u_val, a.x_len * (int64_t)sizeof(T));
     const __amdgpu_buffer_rsrc_t xbits_rs = make_rsrc(a.u_bits, a.u_full ? 0 : ((a.x_len + 63) >> 6) * 8);
+    PHASE_STAMP(1);
 
-    int64_t tile = blockIdx.x;
-    if (tile >= a.n_tiles) return;
-    TileRegs<T, IPT> R;
-    load_tile<T, IPT>(a, tile, a.tile_row[tile], a.tile_row[tile + 1], tid, stage_vals, need_old, R);
-
-    for (;;) {
-        PHASE_STAMP(0);
-        // ---- the tile whose data sits in R -------------------------------------------------------------------
-        const int64_t i0 = R.i0, i1 = R.i1, j0 = R.j0;
-        const int nrows_t = R.nrows_t;  // rows whose end falls inside this tile (slot nrows_t = the row still open)
-        const int nnz_t = R.nnz_t;
-        const int64_t rs0_64 = R.rs0;
-        const uint64_t pre_word = R.pre_word;
-        const T pre_val = R.pre_val;
-        const int64_t pre_g = (i0 >> 6) + wave;
-        const int abase = (int)(i0 & 31);  // bit of row i0 inside s_act[0]
-        const int64_t last_row = i1 < a.m ? i1 : a.m - 1;
-        const int nw = has_mask ? (int)((last_row >> 5) - (i0 >> 5)) + 1 : 0;
-        // coordinates of the next tile of this workgroup (its staging loads are issued below)
-        const int64_t next = PERSIST ? tile + gridDim.x : a.n_tiles;  // (!PERSIST: one tile per workgroup)
-        int64_t i0n = 0, i1n = 0;
-        if (next < a.n_tiles) {
-            i0n = a.tile_row[next];
-            i1n = a.tile_row[next + 1];
-        }
-
-        // ---- LDS: row accumulators, cleared row-head marks, the staged tile, active-row words ---------------
-        for (int k = tid; k <= nrows_t; k += PULL_BLOCK) {
-            s_tval[k] = monoid_identity<T, W>(monoid);
-            s_thas[k] = 0;
-        }
-        for (int k = tid * 8; k < TILE + 8; k += PULL_BLOCK * 8) *(uint4 *)&s_head[k] = make_uint4(0u, 0u, 0u, 0u);
-#pragma unroll
-        for (int q = 0; q < IPT / 4; q++) {
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int k = (tid + q * PULL_BLOCK) * 4 + i;  // (< TILE: always inside the LDS arrays)
-                s_col[PADI(k)] = R.creg[q * 4 + i];
-                if (stage_vals) s_aval[PADI(k)] = R.vreg[q * 4 + i];
-            }
-        }
-        if (tid == 0) s_any = has_mask ? 0 : 1;
-        __syncthreads();
-        PHASE_STAMP(1);
-        for (int k = tid; k < nw; k += PULL_BLOCK) {
-            uint32_t w = (k == tid) ? R.mword : ((const uint32_t *)a.m_bits)[(i0 >> 5) + k];
-            if (a.m_comp) w = ~w;
-            s_act[k] = w;
-            const int64_t base_row = ((i0 >> 5) + k) << 5;
-            uint32_t in = 0xffffffffu;  // restrict to [i0, last_row] for the "anything to do" test
-            if (base_row < i0) in &= 0xffffffffu << (int)(i0 - base_row);
-            if (base_row + 31 > last_row) in &= 0xffffffffu >> (int)(base_row + 31 - last_row);
-            if (w & in) s_any = 1;
-        }
-        // mark the nnz at which each non-empty row of the tile starts (encoded local row index + 1)
-        for (int k = tid; k <= nrows_t && i0 + k < a.m; k += PULL_BLOCK) {
-            const int64_t rs = (k == tid) ? R.rs : a.rowptr[i0 + k];
-            const int64_t re = (k == tid) ? R.re : a.rowptr[i0 + k + 1];
-            const int64_t start = rs - j0;
-            if (start >= 0 && start < nnz_t && rs < re) s_head[start] = (unsigned short)(k + 1);
-        }
-        // ---- now that R is consumed, issue the NEXT tile's loads: they fly during the rest of this tile ------
-        if (next < a.n_tiles) load_tile<T, IPT>(a, next, i0n, i1n, tid, stage_vals, need_old, R);
-        __syncthreads();
-        PHASE_STAMP(2);
-        const bool any_active = s_any != 0;
+    // ---- LDS: row accumulators at the monoid identity, row-start marks cleared -----------------------------------
+    for (int k = tid; k <= nrows_t; k += PULL_BLOCK) {
+        s_tval[k] = monoid_identity<T, W>(monoid);
+        s_thas[k] = 0;
+    }
+    for (int k = tid * 8; k < TILE + 8; k += PULL_BLOCK * 8) *(uint4 *)&s_head[k] = make_uint4(0u, 0u, 0u, 0u);
+    if (tid == 0) s_any = has_mask ? 0 : 1;
+    __syncthreads();
+    // ---- active-row words for rows i0 .. min(i1, m-1); mark the entry at which each non-empty row starts ----------
+    for (int k = tid; k < nw; k += PULL_BLOCK) {
+        uint32_t w = (k == tid) ? mword : ((const uint32_t *)a.m_bits)[(i0 >> 5) + k];
+        if (a.m_comp) w = ~w;
+        s_act[k] = w;
+        const int64_t base_row = ((i0 >> 5) + k) << 5;
+        uint32_t in = 0xffffffffu;  // restrict to [i0, last_row] for the "anything to do" test
+        if (base_row < i0) in &= 0xffffffffu << (int)(i0 - base_row);
+        if (base_row + 31 > last_row) in &= 0xffffffffu >> (int)(base_row + 31 - last_row);
+        if (w & in) s_any = 1;
+    }
+    for (int k = tid; k <= nrows_t && i0 + k < a.m; k += PULL_BLOCK) {
+        const int64_t rs = (k == tid) ? my_rs : a.rowptr[i0 + k];
+        const int64_t re = (k == tid) ? my_re : a.rowptr[i0 + k + 1];
+        const int64_t start = rs - j0;
+        if (start >= 0 && start < nnz_t && rs < re) s_head[start] = (unsigned short)(k + 1);  // local row + 1
+    }
+    __syncthreads();
+    PHASE_STAMP(2);
+    const bool any_active = s_any != 0;
 
 #define ROW_ACTIVE(r) (!has_mask || ((s_act[(abase + (r)) >> 5] >> ((abase + (r)) & 31)) & 1u))
 
-        if (any_active) {
-            // ---- local row (encoded k+1) of each of my IPT consecutive nnz: heads inside my chunk, else the
-            //      last head seen by earlier lanes (wavefront max-scan by shuffles) / earlier waves (LDS) -------
-            const int base = tid * IPT;
-            int h[IPT];
-            if constexpr (IPT == 8) {
-                const uint4 v = *(const uint4 *)&s_head[base];
-                h[0] = v.x & 0xffff; h[1] = v.x >> 16; h[2] = v.y & 0xffff; h[3] = v.y >> 16;
-                h[4] = v.z & 0xffff; h[5] = v.z >> 16; h[6] = v.w & 0xffff; h[7] = v.w >> 16;
-            } else {
+    if (any_active) {
+        // ---- local row (encoded k+1) of each of my entries: row starts inside my chunk, else the last start
+        //      seen by earlier lanes (wavefront max-scan by shuffles) / earlier wavefronts (LDS) -------------------
+        int h[IPT];
+        if constexpr (IPT == 8) {
+            const uint4 v = *(const uint4 *)&s_head[base];
+            h[0] = v.x & 0xffff; h[1] = v.x >> 16; h[2] = v.y & 0xffff; h[3] = v.y >> 16;
+            h[4] = v.z & 0xffff; h[5] = v.z >> 16; h[6] = v.w & 0xffff; h[7] = v.w >> 16;
+        } else {
 #pragma unroll
-                for (int i = 0; i < IPT; i++) h[i] = s_head[base + i];
-            }
-            int lastk = 0;
-#pragma unroll
-            for (int i = 0; i < IPT; i++) lastk = h[i] ? h[i] : lastk;  // heads increase along the tile: last = max
-            int incl = lastk;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const int t = __shfl_up(incl, off);
-                if (lane >= off) incl = incl > t ? incl : t;
-            }
-            int excl = __shfl_up(incl, 1);
-            if (lane == 0) excl = 0;
-            if (lane == 63) s_wave_last[wave] = incl;
-            __syncthreads();
-            PHASE_STAMP(3);
-            int e = 1;  // the tile's first nnz belong to row i0
-            for (int x = 0; x < wave; x++) e = e > s_wave_last[x] ? e : s_wave_last[x];
-            e = e > excl ? e : excl;
-
-            // ---- classify: column to gather (or -1: past the tile end / masked-out row) ------------------------
-            int ek[IPT], cc[IPT];
-#pragma unroll
-            for (int i = 0; i < IPT; i++) {
-                e = h[i] ? h[i] : e;
-                ek[i] = e;
-                const bool valid = base + i < nnz_t;
-                cc[i] = (valid && ROW_ACTIVE(e - 1)) ? s_col[PADI(base + i)] : -1;
-            }
-            // ---- gathers: presence words, then values -- IPT independent random accesses in flight per lane.
-            //      Buffer loads: "no column" (-1) is out of range, returns 0 and costs no memory traffic ----------
-            bool xp[IPT];
-            T xv[IPT];
-            if (a.u_full || (a.dbg & 1)) {
-#pragma unroll
-                for (int i = 0; i < IPT; i++) xp[i] = cc[i] >= 0;
-            } else {
-                uint32_t bw[IPT];
-#pragma unroll
-                for (int i = 0; i < IPT; i++) bw[i] = buf_load<uint32_t>(xbits_rs, (unsigned)(cc[i] >> 5) * 4u);
-#pragma unroll
-                for (int i = 0; i < IPT; i++) xp[i] = (bw[i] >> (cc[i] & 31)) & 1u;
-            }
-            if (need_uval && !(a.dbg & 1)) {
-#pragma unroll
-                for (int i = 0; i < IPT; i++) xv[i] = buf_load<T>(xval_rs, xp[i] ? (unsigned)cc[i] * (unsigned)sizeof(T) : 0xfffffff8u);
-            } else {
-#pragma unroll
-                for (int i = 0; i < IPT; i++) xv[i] = (T)(cc[i] & 7);
-            }
-            PHASE_STAMP(4);
-
-            // ---- segmented fold of my chunk, straight-line: a segment ends where the next item starts a row (or
-            //      at the end of the chunk) and is emitted with ONE LDS atomic into its row's accumulator ------------
-            T acc = (T)0;
-            bool has = false;
-#pragma unroll
-            for (int i = 0; i < IPT; i++) {
-                const T av = need_aval ? (a.a_iso ? iso_v : s_aval[PADI(base + i)]) : (T)0;
-                const T prod = apply_binop<T>(mult, av, xv[i]);
-                const bool fresh_seg = (i == 0) || (h[i] != 0);
-                const bool keep = has && !fresh_seg;
-                acc = xp[i] ? (keep ? apply_binop<T>(monoid, acc, prod) : prod) : (keep ? acc : (T)0);
-                has = xp[i] || keep;
-                const bool seg_end = (i == IPT - 1) ? true : (h[i + 1] != 0);
-                if (seg_end && has) {
-                    const int k = ek[i] - 1;
-                    // (row accumulators start at the monoid identity, so one atomic is right whether or not other
-                    //  threads share the row; "any" just stores)
-                    if (monoid == OP_ANY || (a.dbg & 16)) s_tval[k] = (W)acc;
-                    else atomic_combine<W>(&s_tval[k], (W)acc, monoid);
-                    s_thas[k] = 1;
-                }
-            }
+            for (int i = 0; i < IPT; i++) h[i] = s_head[base + i];
         }
+        int lastk = 0;
+#pragma unroll
+        for (int i = 0; i < IPT; i++) lastk = h[i] ? h[i] : lastk;  // marks increase along the tile: last = max
+        int incl = lastk;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off);
+            if (lane >= off) incl = incl > t ? incl : t;
+        }
+        int excl = __shfl_up(incl, 1);
+        if (lane == 0) excl = 0;
+        if (lane == 63) s_wave_last[wave] = incl;
         __syncthreads();
-        PHASE_STAMP(5);
+        PHASE_STAMP(3);
+        int e = 1;  // the tile's first entries belong to row i0
+        for (int x = 0; x < wave; x++) e = e > s_wave_last[x] ? e : s_wave_last[x];
+        e = e > excl ? e : excl;
 
-        // ---- epilogue: rows this tile owns, 64 consecutive rows per wavefront -----------------------------
-        const bool started_earlier = (i0 < a.m) && (rs0_64 < 0);
-        const int own_lo = (started_earlier && nrows_t > 0) ? 1 : 0;
-        const int64_t row_lo = i0 + own_lo, row_hi = i1;  // [row_lo, row_hi)
-        if (row_lo < row_hi && !(a.dbg & 4)) {
-            const int64_t g_first = row_lo >> 6, g_last = (row_hi - 1) >> 6;
-            for (int64_t g = g_first + wave; g <= g_last; g += PULL_BLOCK / 64) {
-                const int64_t row = (g << 6) + lane;
-                const bool owned = row >= row_lo && row < row_hi;
-                const uint64_t oldw = (g == pre_g) ? pre_word : a.w_old_bits[g];
-                const bool old_has = (oldw >> lane) & 1ull;
-                bool new_has = false;
-                if (owned) {
-                    const int k = (int)(row - i0);
-                    const bool mact = ROW_ACTIVE(k);
-                    T old_val = pre_val;
-                    if (g != pre_g && need_old && old_has) old_val = ((const T *)a.w_old_val)[row];
-                    new_has = write_rule_row<T>(a, row, mact, old_has, old_val, s_thas[k] != 0, from_acc<T, W>(s_tval[k]));
-                }
-                const unsigned long long nb = __ballot(owned && new_has);
-                const unsigned long long om = __ballot(owned);
-                if (lane == 0) {
-                    if (om == ~0ull) a.w_new_bits[g] = nb;
-                    else {
-                        atomicAnd((unsigned long long *)&a.w_new_bits[g], ~om);
-                        if (nb) atomicOr((unsigned long long *)&a.w_new_bits[g], nb);
-                    }
+        // ---- classify: column to gather, or -1 (past the tile end / masked-out row: the gather reads nothing) --------
+        int ek[IPT], cc[IPT];
+#pragma unroll
+        for (int i = 0; i < IPT; i++) {
+            e = h[i] ? h[i] : e;
+            ek[i] = e;
+            cc[i] = (base + i < nnz_t && ROW_ACTIVE(e - 1)) ? creg[i] : -1;
+        }
+        // ---- gathers: presence words, then values -- IPT independent random accesses in flight per lane --------------
+        bool xp[IPT];
+        T xv[IPT];
+        if (a.u_full || (a.dbg & 1)) {
+#pragma unroll
+            for (int i = 0; i < IPT; i++) xp[i] = cc[i] >= 0;
+        } else {
+            uint32_t bw[IPT];
+#pragma unroll
+            for (int i = 0; i < IPT; i++) bw[i] = buf_load<uint32_t>(xbits_rs, (unsigned)(cc[i] >> 5) * 4u);
+#pragma unroll
+            for (int i = 0; i < IPT; i++) xp[i] = (bw[i] >> (cc[i] & 31)) & 1u;
+        }
+        if (need_uval && !(a.dbg & 1)) {
+#pragma unroll
+            for (int i = 0; i < IPT; i++) xv[i] = buf_load<T>(xval_rs, xp[i] ? (unsigned)cc[i] * (unsigned)sizeof(T) : 0xfffffff8u);
+        } else {
+#pragma unroll
+            for (int i = 0; i < IPT; i++) xv[i] = (T)(cc[i] & 7);
+        }
+        PHASE_STAMP(4);
+
+        // ---- segmented fold of my chunk, straight-line: a segment ends where the next entry starts a row (or at the
+        //      end of the chunk) and is emitted with ONE LDS atomic into its row's accumulator ------------------------
+        T acc = (T)0;
+        bool has = false;
+#pragma unroll
+        for (int i = 0; i < IPT; i++) {
+            const T av = need_aval ? (a.a_iso ? iso_v : vreg[i]) : (T)0;
+            const T prod = apply_binop<T>(mult, av, xv[i]);
+            const bool keep = has && (i > 0) && (h[i] == 0);
+            acc = xp[i] ? (keep ? apply_binop<T>(monoid, acc, prod) : prod) : (keep ? acc : (T)0);
+            has = xp[i] || keep;
+            const bool seg_end = (i == IPT - 1) ? true : (h[i + 1] != 0);
+            if (seg_end && has) {
+                const int k = ek[i] - 1;
+                // (accumulators start at the monoid identity, so one atomic is right whether or not other threads
+                //  share the row; "any" just stores)
+                if (monoid == OP_ANY || (a.dbg & 16)) s_tval[k] = (W)acc;
+                else atomic_combine<W>(&s_tval[k], (W)acc, monoid);
+                s_thas[k] = 1;
+            }
+        }
+    }
+    __syncthreads();
+    PHASE_STAMP(5);
+
+    // ---- epilogue: rows this tile owns, 64 consecutive rows per wavefront -----------------------------------------
+    const bool started_earlier = (i0 < a.m) && (rs0_64 < 0);
+    const int own_lo = (started_earlier && nrows_t > 0) ? 1 : 0;
+    const int64_t row_lo = i0 + own_lo, row_hi = i1;  // [row_lo, row_hi)
+    if (row_lo < row_hi && !(a.dbg & 4)) {
+        const int64_t g_first = row_lo >> 6, g_last = (row_hi - 1) >> 6;
+        for (int64_t g = g_first + wave; g <= g_last; g += PULL_BLOCK / 64) {
+            const int64_t row = (g << 6) + lane;
+            const bool owned = row >= row_lo && row < row_hi;
+            const uint64_t oldw = (g == pre_g) ? pre_word : a.w_old_bits[g];
+            const bool old_has = (oldw >> lane) & 1ull;
+            bool new_has = false;
+            if (owned) {
+                const int k = (int)(row - i0);
+                const bool mact = ROW_ACTIVE(k);
+                T old_val = pre_val;
+                if (g != pre_g && need_old && old_has) old_val = ((const T *)a.w_old_val)[row];
+                new_has = write_rule_row<T>(a, row, mact, old_has, old_val, s_thas[k] != 0, from_acc<T, W>(s_tval[k]));
+            }
+            const unsigned long long nb = __ballot(owned && new_has);
+            const unsigned long long om = __ballot(owned);
+            if (lane == 0) {
+                if (om == ~0ull) a.w_new_bits[g] = nb;
+                else {
+                    atomicAnd((unsigned long long *)&a.w_new_bits[g], ~om);
+                    if (nb) atomicOr((unsigned long long *)&a.w_new_bits[g], nb);
                 }
             }
         }
-#undef ROW_ACTIVE
-        PHASE_STAMP(6);
-
-        // ---- seams: the row still open at the tile end, and a first row that began in an earlier tile ----
-        if (tid == 0) {
-            a.carry_has[tile] = s_thas[nrows_t];
-            ((W *)a.carry_val)[tile] = s_tval[nrows_t];
-            const bool se = started_earlier && nrows_t > 0;
-            a.first_has[tile] = se ? (unsigned char)(2 | (s_thas[0] ? 1 : 0)) : (unsigned char)0;
-            ((W *)a.first_val)[tile] = s_tval[0];
-        }
-        PHASE_STAMP(7);
-        if (!PERSIST || next >= a.n_tiles) break;
-        tile = next;
-        __syncthreads();  // LDS is recycled by the next tile
     }
+#undef ROW_ACTIVE
+    PHASE_STAMP(6);
+
+    // ---- seams: the row still open at the tile end, and a first row that began in an earlier tile ------------------
+    if (tid == 0) {
+        a.carry_has[tile] = s_thas[nrows_t];
+        ((W *)a.carry_val)[tile] = s_tval[nrows_t];
+        const bool se = started_earlier && nrows_t > 0;
+        a.first_has[tile] = se ? (unsigned char)(2 | (s_thas[0] ? 1 : 0)) : (unsigned char)0;
+        ((W *)a.first_val)[tile] = s_tval[0];
+    }
+    PHASE_STAMP(7);
 }
 
 // One wavefront per tile whose first row began in earlier tiles: fold the carries of tiles
@@ -632,18 +570,6 @@ static void ensure_tile_table(GB_Matrix_opaque *A, int tile_items)
     A->tile_items = tile_items;
 }
 
-// workgroups of k_mxv_pull that fit one CU: LDS-bound (160 KiB per CU), at most 8 (32 waves)
-template <typename T, int IPT>
-static constexpr int pull_blocks_per_cu()
-{
-    using W = typename Widen<T>::type;
-    constexpr int TILE = PULL_BLOCK * IPT;
-    constexpr int TILEP = TILE + TILE / 32 + 1;
-    constexpr size_t lds = TILEP * 4 + TILEP * sizeof(T) + (TILE + 8) * 2 + (TILE + 1) * sizeof(W) + (TILE + 1) + (TILE / 32 + 3) * 4 + 64;
-    constexpr int b = (int)((160 * 1024) / lds);
-    return b > 8 ? 8 : (b < 1 ? 1 : b);
-}
-
 // diagnostics (GRB_DEBUG_FLAGS & 8): mean cycles between the phase stamps of k_mxv_pull
 static void report_phase_times(const long long *d_times, int64_t n_tiles)
 {
@@ -681,11 +607,7 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
     a.first_has = first_has.p;
     DevBuf<long long> dbg_times((ctx().debug_flags & 8) ? (size_t)a.n_tiles * 10 : 1, true);
     a.dbg_times = (ctx().debug_flags & 8) ? dbg_times.p : nullptr;
-    // persistent workgroups: as many as stay resident (LDS-bound), each walks tiles b, b+G, b+2G, ...
-    const int64_t resident = (int64_t)ctx().num_cus * pull_blocks_per_cu<T, IPT>();
-    (void)resident;  // (a persistent variant, G = resident workgroups each prefetching its next tile, measured slower:
-                     //  the loop-carried tile registers cost 3x the VGPRs -- DESIGN.md "what did not work")
-    hipLaunchKernelGGL((k_mxv_pull<T, MON, MUL, IPT, false>), dim3((unsigned)a.n_tiles), dim3(PULL_BLOCK), 0, ctx().stream, a);
+    hipLaunchKernelGGL((k_mxv_pull<T, MON, MUL, IPT>), dim3((unsigned)a.n_tiles), dim3(PULL_BLOCK), 0, ctx().stream, a);
     if (a.dbg_times) report_phase_times(dbg_times.p, a.n_tiles);
     hipLaunchKernelGGL((k_mxv_seams<T, TILE>), dim3((unsigned)ceil_div(a.n_tiles, PULL_BLOCK / 64)), dim3(PULL_BLOCK), 0,
                        ctx().stream, a);
