@@ -131,8 +131,9 @@ __global__ __launch_bounds__(PULL_BLOCK) void k_mxv_pull(const PullArgs a)
     // LDS holds only per-ROW state (row-start marks, row accumulators): the tile's column indices and values
     // go straight from HBM into the registers of the thread that consumes them (IPT consecutive entries).
     __shared__ __attribute__((aligned(16))) unsigned short s_head[TILE + 8];
-    __shared__ W s_tval[TILE + 1];
-    __shared__ unsigned char s_thas[TILE + 1];
+    // (+64: per-lane scratch slots that absorb the "nothing to emit" case of the branch-free fold)
+    __shared__ W s_tval[TILE + 1 + 64];
+    __shared__ unsigned char s_thas[TILE + 1 + 64];
     __shared__ unsigned int s_act[TILE / 32 + 3];
     __shared__ int s_any;
     __shared__ int s_wave_last[PULL_BLOCK / 64];
@@ -171,11 +172,14 @@ __global__ __launch_bounds__(PULL_BLOCK) void k_mxv_pull(const PullArgs a)
     for (int q = 0; q < IPT / 4; q++) {
         const unsigned k = (unsigned)(base + q * 4);
         if (whole && !(a.dbg & 2)) {
-            const auto c4 = __builtin_amdgcn_raw_buffer_load_b128(crs, k * 4u, 0, 0);
+            // (non-temporal streaming, aux 2, measured 2-3 % slower than default-policy loads: debug flag 64 selects it)
+            const auto c4 = (a.dbg & 64) ? __builtin_amdgcn_raw_buffer_load_b128(crs, k * 4u, 0, 2)
+                                         : __builtin_amdgcn_raw_buffer_load_b128(crs, k * 4u, 0, 0);
 #pragma unroll
             for (int i = 0; i < 4; i++) creg[q * 4 + i] = (int)c4[i];
             if constexpr (sizeof(T) == 4) {
-                const auto v4 = __builtin_amdgcn_raw_buffer_load_b128(vrs, k * 4u, 0, 0);
+                const auto v4 = (a.dbg & 64) ? __builtin_amdgcn_raw_buffer_load_b128(vrs, k * 4u, 0, 2)
+                                             : __builtin_amdgcn_raw_buffer_load_b128(vrs, k * 4u, 0, 0);
 #pragma unroll
                 for (int i = 0; i < 4; i++) vreg[q * 4 + i] = __builtin_bit_cast(T, (unsigned int)v4[i]);
             } else {
@@ -316,14 +320,13 @@ __global__ __launch_bounds__(PULL_BLOCK) void k_mxv_pull(const PullArgs a)
             acc = xp[i] ? (keep ? apply_binop<T>(monoid, acc, prod) : prod) : (keep ? acc : (T)0);
             has = xp[i] || keep;
             const bool seg_end = (i == IPT - 1) ? true : (h[i + 1] != 0);
-            if (seg_end && has) {
-                const int k = ek[i] - 1;
-                // (accumulators start at the monoid identity, so one atomic is right whether or not other threads
-                //  share the row; "any" just stores)
-                if (monoid == OP_ANY || (a.dbg & 16)) s_tval[k] = (W)acc;
-                else atomic_combine<W>(&s_tval[k], (W)acc, monoid);
-                s_thas[k] = 1;
-            }
+            // emit without a branch: a finished segment goes to its row's accumulator, anything else to this
+            // lane's scratch slot (accumulators start at the monoid identity, so one atomic is right whether or
+            // not other threads share the row; "any" just stores)
+            const int k = (seg_end && has) ? ek[i] - 1 : TILE + 1 + lane;
+            if (monoid == OP_ANY || (a.dbg & 16)) s_tval[k] = (W)acc;
+            else atomic_combine<W>(&s_tval[k], (W)acc, monoid);
+            s_thas[k] = 1;
         }
     }
     __syncthreads();
