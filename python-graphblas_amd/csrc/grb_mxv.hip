@@ -100,6 +100,7 @@ __device__ __forceinline__ bool write_rule_row(const PullArgs &a, int64_t row, b
     return t_has;
 }
 
+#define EARLY_EXIT(level) do { if (((a.dbg >> 8) & 15) == (level)) return; } while (0)
 #define PHASE_STAMP(i) do { if (a.dbg_times && threadIdx.x == 0) a.dbg_times[blockIdx.x * 10 + (i)] = clock64(); } while (0)
 
 // ---- buffer-descriptor loads: the hardware range check returns 0 for out-of-range offsets, so gathers of
@@ -159,6 +160,7 @@ __global__ __launch_bounds__(PULL_BLOCK) void k_mxv_pull(const PullArgs a)
     const int nrows_t = (int)(i1 - i0);  // rows whose end falls inside this tile (slot nrows_t = the row still open)
     const int nnz_t = (int)((d1 - i1) - j0);
     const int base = tid * IPT;  // my IPT consecutive entries of the tile
+    EARLY_EXIT(1);
 
     // ---- issue every HBM load of the tile now: my entries (16-byte buffer loads; the descriptor ends at the
     //      end of the arrays, out-of-range parts read 0), my row's bounds, mask word, old w of my first rows ----
@@ -216,6 +218,7 @@ __global__ __launch_bounds__(PULL_BLOCK) void k_mxv_pull(const PullArgs a)
     const __amdgpu_buffer_rsrc_t xval_rs = make_rsrc(a.u_val, a.x_len * (int64_t)sizeof(T));
     const __amdgpu_buffer_rsrc_t xbits_rs = make_rsrc(a.u_bits, a.u_full ? 0 : ((a.x_len + 63) >> 6) * 8);
     PHASE_STAMP(1);
+    EARLY_EXIT(2);
 
     // ---- LDS: row accumulators at the monoid identity, row-start marks cleared -----------------------------------
     for (int k = tid; k <= nrows_t; k += PULL_BLOCK) {
@@ -225,6 +228,7 @@ __global__ __launch_bounds__(PULL_BLOCK) void k_mxv_pull(const PullArgs a)
     for (int k = tid * 8; k < TILE + 8; k += PULL_BLOCK * 8) *(uint4 *)&s_head[k] = make_uint4(0u, 0u, 0u, 0u);
     if (tid == 0) s_any = has_mask ? 0 : 1;
     __syncthreads();
+    EARLY_EXIT(3);
     // ---- active-row words for rows i0 .. min(i1, m-1); mark the entry at which each non-empty row starts ----------
     for (int k = tid; k < nw; k += PULL_BLOCK) {
         uint32_t w = (k == tid) ? mword : ((const uint32_t *)a.m_bits)[(i0 >> 5) + k];
@@ -244,6 +248,7 @@ __global__ __launch_bounds__(PULL_BLOCK) void k_mxv_pull(const PullArgs a)
     }
     __syncthreads();
     PHASE_STAMP(2);
+    EARLY_EXIT(4);
     const bool any_active = s_any != 0;
 
 #define ROW_ACTIVE(r) (!has_mask || ((s_act[(abase + (r)) >> 5] >> ((abase + (r)) & 31)) & 1u))
@@ -274,6 +279,7 @@ __global__ __launch_bounds__(PULL_BLOCK) void k_mxv_pull(const PullArgs a)
         if (lane == 63) s_wave_last[wave] = incl;
         __syncthreads();
         PHASE_STAMP(3);
+        EARLY_EXIT(5);
         int e = 1;  // the tile's first entries belong to row i0
         for (int x = 0; x < wave; x++) e = e > s_wave_last[x] ? e : s_wave_last[x];
         e = e > excl ? e : excl;
@@ -331,6 +337,7 @@ __global__ __launch_bounds__(PULL_BLOCK) void k_mxv_pull(const PullArgs a)
     }
     __syncthreads();
     PHASE_STAMP(5);
+    EARLY_EXIT(6);
 
     // ---- epilogue: rows this tile owns, 64 consecutive rows per wavefront -----------------------------------------
     const bool started_earlier = (i0 < a.m) && (rs0_64 < 0);
