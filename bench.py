@@ -28,6 +28,22 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); 6290 GB/s measured copy
 
 
+def measured_traffic(workload, scale):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/rNN/pmc_traffic.json,
+    collected by scripts/gpu_final.sh with rocprofv3 --pmc in separate runs); None when no profile matches."""
+    import glob
+
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_traffic.json"))):
+        try:
+            rec = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if rec.get("workload") == workload and rec.get("scale") == scale:
+            best = rec
+    return best["traffic_bytes_per_launch"] if best else None
+
+
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
@@ -284,7 +300,8 @@ def main():
             "edges_per_step": edges,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy_peak_6290": achieved / 6290.0,
-                         "traffic": None, "kernel": "k_mxv_pull (+ k_mxv_seams)",
+                         "traffic": measured_traffic(workload, args.scale) if world == 1 else None,
+                         "kernel": "k_mxv_pull (+ k_mxv_seams)",
                          "kernel_ms_hip_events": kernel_ms, "algorithmic_bytes_per_launch": wl.bytes_per_step()},
             "stats": device.last_stats(),
         }
