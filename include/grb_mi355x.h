@@ -235,7 +235,9 @@ GrB_Info GrX_last_stats(GrX_Stats *stats);
  *                   (1 skips the x gathers, 2 the A staging loads, 4 the epilogue)
  *   "pull_ipt"      merge items per thread of the pull SpMV (0 = default)
  *   "hot_min_cols"  matrices with at least this many columns get a hot-column table for the pull SpMV
- *   "hot_k"         entries of that table (0 = sized to ~2 MiB of x values) */
+ *   "hot_k"         entries of that table (0 = sized to ~2 MiB of x values)
+ *   "push_mode"     mxv/vxm direction: 0 always pull, 1 (default) push when u has fewer than n/64 entries and the
+ *                   matrix indexed like u is at hand, 2 always push when possible */
 GrB_Info GrX_option_set(const char *name, int64_t value);
 const char *GrX_version_string(void);
 

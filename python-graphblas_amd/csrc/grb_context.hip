@@ -96,6 +96,7 @@ extern "C" GrB_Info GrB_init(GrB_Mode mode)
     if (const char *e = getenv("GRB_PULL_IPT")) c.tune_pull_ipt = atoi(e);
     if (const char *e = getenv("GRB_HOT_MIN_COLS")) c.hot_min_cols = atoll(e);
     if (const char *e = getenv("GRB_HOT_K")) c.hot_k = atoll(e);
+    if (const char *e = getenv("GRB_PUSH_MODE")) c.push_mode = atoi(e);
     c.initialized = true;
     return GrB_SUCCESS;
 }
@@ -172,6 +173,7 @@ extern "C" GrB_Info GrX_option_set(const char *name, int64_t value)
     else if (n == "pull_ipt") c.tune_pull_ipt = (int)value;
     else if (n == "hot_min_cols") c.hot_min_cols = value;
     else if (n == "hot_k") c.hot_k = value;
+    else if (n == "push_mode") c.push_mode = (int)value;
     else return GrB_INVALID_VALUE;
     return GrB_SUCCESS;
 }

@@ -64,6 +64,7 @@ struct Context {
     int tune_pull_ipt = 0;  // GRB_PULL_IPT: merge items per thread of the pull SpMV (0 = default)
     int64_t hot_min_cols = 1 << 20;  // matrices at least this wide get a hot-column table (pull SpMV)
     int64_t hot_k = 0;               // table entries (0 = ~2 MiB of x values)
+    int push_mode = 1;               // 0 never push, 1 push when u has < n/64 entries, 2 always push (tests)
 };
 Context &ctx();
 void require_init();
@@ -185,6 +186,7 @@ inline std::string *errp(GB_Matrix_opaque *A) { return (A && A->magic == MAGIC_M
 void vector_ensure_storage(GB_Vector_opaque *v);               // allocate zeroed values+bits if absent
 void vector_release_storage(GB_Vector_opaque *v);              // free buffers, nvals = 0
 int64_t vector_nvals(GB_Vector_opaque *v);                     // counts if unknown
+int64_t vector_index_list(GB_Vector_opaque *v, uint64_t **d_idx);  // ascending indices of the entries (fresh device array)
 GB_Vector_opaque *vector_new(GrB_Type type, uint64_t n);
 void vector_free(GB_Vector_opaque *v);
 void matrix_release_storage(GB_Matrix_opaque *A);              // frees CSR + caches, nvals = 0

@@ -467,6 +467,78 @@ __global__ void k_vec_write(int64_t n, const TW *w_old_val, const uint64_t *w_ol
 }
 
 // ---------------------------------------------------------------------------------------------------
+// push direction (SpMSpV): few entries in u.  T(j) = (+)_{k in u} mult(u_k, P(k,j)) where P's ROWS are indexed
+// like u (P = A for vxm, A' for mxv).  The work -- all entries of the rows selected by u -- is cut into equal
+// chunks over the prefix sum of those rows' lengths (hub rows in the frontier are shared by many threads);
+// products land in a dense accumulator by native global atomics, restricted to positions the mask admits.
+// ---------------------------------------------------------------------------------------------------
+constexpr int PUSH_CHUNK = 8;  // consecutive work items per thread
+
+__global__ void k_push_degrees(const uint64_t *idx, int64_t f, const int64_t *rowptr, int64_t *deg)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < f) {
+        const int64_t k = (int64_t)idx[i];
+        deg[i] = rowptr[k + 1] - rowptr[k];
+    } else if (i == f) deg[i] = 0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_push(const uint64_t *idx, int64_t f, const int64_t *pre /* f+1 */, int64_t work,
+                                              const int64_t *rowptr, const int32_t *col, const T *aval, int a_iso,
+                                              const T *u_val, int monoid, int mult, int need_a, int need_u,
+                                              const uint64_t *m_bits, int has_mask, int m_comp,
+                                              typename Widen<T>::type *t_val, unsigned long long *t_bits)
+{
+    using W = typename Widen<T>::type;
+    const int64_t x0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * PUSH_CHUNK;
+    if (x0 >= work) return;
+    // the frontier entry owning work item x0: last i with pre[i] <= x0
+    int64_t lo = 0, hi = f;
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (pre[mid] <= x0) lo = mid;
+        else hi = mid;
+    }
+    int64_t i = lo;
+    int64_t k = (int64_t)idx[i];
+    int64_t next = pre[i + 1];
+    int64_t p = rowptr[k] + (x0 - pre[i]);
+    T uk = need_u ? u_val[k] : (T)0;
+    const int64_t x1 = x0 + PUSH_CHUNK < work ? x0 + PUSH_CHUNK : work;
+    for (int64_t x = x0; x < x1; x++) {
+        while (x >= next) {  // move to the next frontier entry (rows of length 0 are skipped)
+            i++;
+            k = (int64_t)idx[i];
+            next = pre[i + 1];
+            p = rowptr[k];
+            uk = need_u ? u_val[k] : (T)0;
+        }
+        const int j = col[p];
+        bool ok = true;
+        if (has_mask) {
+            ok = (m_bits[j >> 6] >> (j & 63)) & 1ull;
+            if (m_comp) ok = !ok;
+        }
+        if (ok) {
+            const T av = need_a ? aval[a_iso ? 0 : p] : (T)0;
+            const W prod = (W)apply_binop<T>(mult, uk, av);
+            if (monoid == OP_ANY) t_val[j] = prod;
+            else atomic_combine<W>(&t_val[j], prod, monoid);
+            atomicOr(&t_bits[j >> 6], 1ull << (j & 63));
+        }
+        p++;
+    }
+}
+
+template <typename W>
+__global__ void k_fill_w(W *p, int64_t n, W v)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------
 // ---- hot-column table ------------------------------------------------------------------------------------
@@ -838,6 +910,116 @@ static void mxv_core(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_Binar
     if (ctx().blocking) sync_stream();
 }
 
+static int widened_type_code(int st)
+{
+    switch (st) {
+    case TC_BOOL: case TC_INT8: case TC_INT16: return TC_INT32;
+    case TC_UINT8: case TC_UINT16: return TC_UINT32;
+    default: return st;
+    }
+}
+
+// w<mask> = accum(w, u (+.x) P) with P's rows indexed like u.  `flip`: multiply evaluates mult(P_kj, u_k).
+static void push_core(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_BinaryOp_opaque *accum,
+                      const GB_Semiring_opaque *sr, GB_Matrix_opaque *P, GB_Vector_opaque *u, bool flip, DescFlags f)
+{
+    ctx().stats = GrX_Stats{};
+    ctx().stats.method = 2;
+    ctx().stats.out_nvals = -1;
+    const int64_t n_out = (int64_t)w->n;
+    const int st = sr->type;
+    const int monoid = canonical_op(st, sr->monoid);
+    int mult = canonical_op(st, sr->mult);
+    if (flip) mult = flip_op(mult);  // the kernel evaluates mult(u_k, P_kj)
+    // operands in the semiring's type
+    DevBuf<char> a_cast(0), u_cast(0);
+    const void *aval = P->d_val;
+    if (P->nvals && P->type->code != st) {
+        const int64_t nv = P->iso ? 1 : P->nvals;
+        dev_free(a_cast.p);
+        a_cast.p = (char *)dev_alloc(type_size(st) * (size_t)nv);
+        cast_array(st, a_cast.p, P->type->code, P->d_val, nv);
+        aval = a_cast.p;
+    }
+    const void *uval = u->d_val;
+    if (u->type->code != st) {
+        dev_free(u_cast.p);
+        u_cast.p = (char *)dev_alloc(type_size(st) * (size_t)u->n);
+        cast_array(st, u_cast.p, u->type->code, u->d_val, (int64_t)u->n);
+        uval = u_cast.p;
+    }
+    DevBuf<uint64_t> mbits_tmp(0);
+    const uint64_t *m_bits = nullptr;
+    if (mask) {
+        if (f.structure && mask->d_val && mask != w) m_bits = mask->d_bits;
+        else {
+            dev_free(mbits_tmp.p);
+            mbits_tmp.p = (uint64_t *)dev_alloc(bits_words64(mask->n) * 8);
+            vector_mask_bits(mask, f.structure, mbits_tmp.p);
+            m_bits = mbits_tmp.p;
+        }
+    }
+    // frontier list, its rows' lengths, prefix sums
+    uint64_t *d_idx = nullptr;
+    const int64_t fcount = vector_index_list(u, &d_idx);
+    DevBuf<uint64_t> idx_hold(0);
+    dev_free(idx_hold.p);
+    idx_hold.p = d_idx;
+    const int wt = widened_type_code(st);
+    const size_t wbytes = type_size(wt);
+    // dense accumulator of the product (semiring type, widened) + presence
+    DevBuf<char> t_val((size_t)n_out * wbytes);
+    DevBuf<uint64_t> t_bits(bits_words64((uint64_t)n_out), true);
+    int64_t work = 0;
+    GRB_DISPATCH_TYPE(st, T, {
+        using W = typename Widen<T>::type;
+        hipLaunchKernelGGL((k_fill_w<W>), dim3((unsigned)ceil_div(n_out, 256)), dim3(256), 0, ctx().stream, (W *)t_val.p, n_out,
+                           monoid_identity<T, W>(monoid));
+        if (fcount > 0 && P->nvals > 0) {
+            DevBuf<int64_t> pre(fcount + 1);
+            hipLaunchKernelGGL(k_push_degrees, dim3((unsigned)ceil_div(fcount + 1, 256)), dim3(256), 0, ctx().stream, d_idx, fcount,
+                               matrix_rowptr(P), pre.p);
+            prim_exclusive_sum_i64(pre.p, pre.p, fcount + 1);
+            d2h(&work, pre.p + fcount, sizeof(int64_t));
+            if (work > 0) {
+                const int64_t nthreads = ceil_div(work, PUSH_CHUNK);
+                const int need_a = !(mult == OP_PAIR || mult == OP_FIRST || mult == OP_ANY);
+                const int need_u = !(mult == OP_PAIR || mult == OP_SECOND);
+                hipLaunchKernelGGL((k_push<T>), dim3((unsigned)ceil_div(nthreads, 256)), dim3(256), 0, ctx().stream, d_idx, fcount,
+                                   pre.p, work, matrix_rowptr(P), P->d_col, (const T *)aval, P->iso ? 1 : 0, (const T *)uval,
+                                   monoid, mult, need_a, need_u, m_bits, mask ? 1 : 0, f.comp ? 1 : 0, (W *)t_val.p,
+                                   (unsigned long long *)t_bits.p);
+                sync_stream();  // `pre` is released at the end of this scope
+            }
+        }
+    })
+    ctx().stats.flops = work;
+    ctx().stats.kernel_launches += 4;
+    // write rule, in place on w (w never aliases the dense accumulator); u == w is safe: u was read above
+    vector_ensure_storage(w);
+    DevBuf<char> tc((size_t)n_out * w->type->size);
+    cast_array(w->type->code, tc.p, wt, t_val.p, n_out);
+    const int acc_op = accum ? canonical_op(w->type->code, accum->op) : -1;
+    GRB_DISPATCH_TYPE(w->type->code, TW, {
+        const int64_t nthreads = (int64_t)bits_words64(w->n) * 64;
+        hipLaunchKernelGGL((k_vec_write<TW>), dim3((unsigned)ceil_div(nthreads, 256)), dim3(256), 0, ctx().stream, (int64_t)w->n,
+                           (const TW *)w->d_val, (const uint64_t *)w->d_bits, (TW *)w->d_val, w->d_bits, (const TW *)tc.p,
+                           (const uint64_t *)t_bits.p, m_bits, mask ? 1 : 0, f.comp ? 1 : 0, acc_op, f.replace ? 1 : 0, 0);
+    })
+    w->nvals = -1;
+    if (ctx().blocking) sync_stream();
+}
+
+// choose the direction: push when u has few entries and the matrix whose rows are indexed like u is at hand
+static bool want_push(GB_Vector_opaque *u, GB_Matrix_opaque *P_or_null)
+{
+    if (!P_or_null) return false;
+    if (ctx().push_mode == 0) return false;
+    if (ctx().push_mode == 2) return true;
+    const int64_t nv = vector_nvals(u);
+    return nv * 64 < (int64_t)u->n;  // fewer than n/64 entries
+}
+
 }  // namespace grb
 
 using namespace grb;
@@ -853,8 +1035,15 @@ extern "C" GrB_Info GrB_mxv(GrB_Vector w, const GrB_Vector mask, const GrB_Binar
     check_vector(u, "u");
     if (!semiring) fail(GrB_NULL_POINTER, "semiring is NULL");
     DescFlags f = flags_of(desc);
-    GB_Matrix_opaque *S = f.t0 ? matrix_transpose_cached(A) : A;
-    mxv_core(w, mask, accum, semiring, S, u, /*flip=*/false, f);
+    // pull over S = A (or A' with T0); push needs the matrix whose ROWS are indexed like u: S' -- only when cached
+    GB_Matrix_opaque *P = f.t0 ? A : A->tr;
+    const bool dims_ok = (f.t0 ? A->nrows : A->ncols) == u->n && (f.t0 ? A->ncols : A->nrows) == w->n && (!mask || mask->n == w->n);
+    if (dims_ok && (!accum || accum->type == w->type->code) && !(!mask && f.comp) && w->n > 0 && want_push(u, P)) {
+        push_core(w, mask, accum, semiring, P, u, /*flip=*/true, f);
+    } else {
+        GB_Matrix_opaque *S = f.t0 ? matrix_transpose_cached(A) : A;
+        mxv_core(w, mask, accum, semiring, S, u, /*flip=*/false, f);
+    }
     GRB_CATCH(errp(w))
 }
 
@@ -870,7 +1059,14 @@ extern "C" GrB_Info GrB_vxm(GrB_Vector w, const GrB_Vector mask, const GrB_Binar
     if (!semiring) fail(GrB_NULL_POINTER, "semiring is NULL");
     DescFlags f = flags_of(desc);
     // w' = u' A  <=>  w = A' u with the multiply operands swapped; desc T1 transposes A
-    GB_Matrix_opaque *S = f.t1 ? A : matrix_transpose_cached(A);
-    mxv_core(w, mask, accum, semiring, S, u, /*flip=*/true, f);
+    // push walks the rows of P = A (or A' with T1, when cached) selected by u; pull gathers over S = P'
+    GB_Matrix_opaque *P = f.t1 ? A->tr : A;
+    const bool dims_ok = (f.t1 ? A->ncols : A->nrows) == u->n && (f.t1 ? A->nrows : A->ncols) == w->n && (!mask || mask->n == w->n);
+    if (dims_ok && (!accum || accum->type == w->type->code) && !(!mask && f.comp) && w->n > 0 && want_push(u, P)) {
+        push_core(w, mask, accum, semiring, P, u, /*flip=*/false, f);
+    } else {
+        GB_Matrix_opaque *S = f.t1 ? A : matrix_transpose_cached(A);
+        mxv_core(w, mask, accum, semiring, S, u, /*flip=*/true, f);
+    }
     GRB_CATCH(errp(w))
 }

@@ -415,6 +415,22 @@ static void vector_extract_typed(GB_Vector_opaque *v, uint64_t *I, void *X, int 
     }
 }
 
+// indices of the present entries, ascending, as a fresh device array (caller frees); returns the count
+int64_t vector_index_list(GB_Vector_opaque *v, uint64_t **d_idx)
+{
+    *d_idx = nullptr;
+    const int64_t nv = vector_nvals(v);
+    if (nv == 0) return 0;
+    const int64_t nwords = (int64_t)bits_words64(v->n);
+    DevBuf<int64_t> offs(nwords + 1);
+    LAUNCH(k_word_popcounts, nwords, v->d_bits, nwords, offs.p);
+    prim_exclusive_sum_i64(offs.p, offs.p, nwords);
+    uint64_t *idx = (uint64_t *)dev_alloc(sizeof(uint64_t) * (size_t)nv);
+    LAUNCH((k_vec_extract<uint8_t>), nwords, v->d_bits, (const uint8_t *)nullptr, nwords, offs.p, idx, (uint8_t *)nullptr);
+    *d_idx = idx;
+    return nv;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Matrix
 // ---------------------------------------------------------------------------------------------------

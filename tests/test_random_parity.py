@@ -313,3 +313,63 @@ def test_hot_column_table(gb, seed):
     finally:
         _lib.lib.GrX_option_set(b"hot_min_cols", 1 << 20)
         _lib.lib.GrX_option_set(b"hot_k", 0)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_push_direction(gb, seed):
+    """Push-direction SpMSpV (forced on): vxm over A's own rows, mxv over the cached transpose; sparse and dense u,
+    masks, accumulators, w aliased with u (BFS style), typecasts."""
+    from graphblas_amd import _lib, device
+
+    rng = np.random.default_rng(900 + seed)
+    tname = TYPES[seed % 7]
+    sr = semirings_for(tname)[seed % 4]
+    m, n = int(rng.integers(1, 1200)), int(rng.integers(1, 1200))
+    r, c, v = rand_coo(rng, m, n, tname, long_rows=2)
+    oa = O.OMat.from_coo(r, c, v, m, n, tname)
+    ui, uv = rand_vec(rng, m, [0.02, 0.3, 1.0][seed % 3], tname)
+    wi, wv = rand_vec(rng, n, 0.4, tname)
+    mi, mv = rand_vec(rng, n, 0.5, "INT8")
+    use_mask = seed % 4 != 0
+    comp, struct, repl = (bool(x) for x in rng.integers(0, 2, 3))
+    accum = [None, "plus", "min", "second"][rng.integers(4)]
+    exp = O.vxm(O.OVec(m, ui, uv, tname), oa, sr, w=O.OVec(n, wi, wv, tname), mask=O.OVec(n, mi, mv, "INT8") if use_mask else None,
+                mask_comp=comp and use_mask, mask_struct=struct, accum=accum, replace=repl and use_mask)
+    xi, xv = rand_vec(rng, n, 0.05, tname)
+    exp_mxv = O.mxv(oa, O.OVec(n, xi, xv, tname), sr)
+    try:
+        _lib.lib.GrX_option_set(b"push_mode", 2)
+        A = gb.Matrix.from_coo(r, c, v, dtype=tname, nrows=m, ncols=n)
+        u = gb.Vector.from_coo(ui, uv, dtype=tname, size=m)
+        w = gb.Vector.from_coo(wi, wv, dtype=tname, size=n)
+        kw = {}
+        if use_mask:
+            mk = gb.Vector.from_coo(mi, mv, dtype="INT8", size=n)
+            mm = mk.S if struct else mk.V
+            kw = dict(mask=~mm if comp else mm, replace=repl)
+        if accum:
+            kw["accum"] = accum
+        w(**kw) << u.vxm(A, getattr(gb.semiring, sr))
+        assert device.last_stats()["method"] == 2
+        same_vec(w, exp)
+        # mxv pushes over the transpose once it is cached
+        x = gb.Vector.from_coo(xi, xv, dtype=tname, size=n)
+        device.cache_transpose(A)
+        y = A.mxv(x, getattr(gb.semiring, sr)).new()
+        assert device.last_stats()["method"] == 2
+        same_vec(y, exp_mxv)
+        if m == n:
+            pass
+        # BFS-style aliasing on a square matrix
+        k = min(m, n)
+        r2, c2, v2 = rand_coo(rng, k, k, tname, long_rows=1)
+        B = gb.Matrix.from_coo(r2, c2, v2, dtype=tname, nrows=k, ncols=k)
+        ob = O.OMat.from_coo(r2, c2, v2, k, k, tname)
+        qi, qv = rand_vec(rng, k, 0.1, tname)
+        vi, vv = rand_vec(rng, k, 0.5, "BOOL")
+        q, oq = gb.Vector.from_coo(qi, qv, dtype=tname, size=k), O.OVec(k, qi, qv, tname)
+        vis, ovis = gb.Vector.from_coo(vi, vv, dtype="BOOL", size=k), O.OVec(k, vi, vv, "BOOL")
+        q(~vis.S, replace=True) << q.vxm(B, getattr(gb.semiring, sr))
+        same_vec(q, O.vxm(oq, ob, sr, w=oq, mask=ovis, mask_comp=True, mask_struct=True, replace=True))
+    finally:
+        _lib.lib.GrX_option_set(b"push_mode", 1)
