@@ -20,7 +20,8 @@ def bind(dev):
 
     if _bound is None:
         if dev == "emu":
-            subprocess.check_call([os.path.join(ROOT, "tests", "emu", "build_emu.sh")], stdout=subprocess.DEVNULL)
+            if not os.environ.get("GRB_EMU_PREBUILT"):  # (worker processes of a multi-rank test reuse the parent's build)
+                subprocess.check_call([os.path.join(ROOT, "tests", "emu", "build_emu.sh")], stdout=subprocess.DEVNULL)
             gb.init(lib_path=EMU_SO)
         else:
             gb.init()

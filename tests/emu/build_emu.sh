@@ -15,6 +15,11 @@ for f in "$SRC"/*.hip; do
   fi
 done
 for p in "${pids[@]}"; do wait "$p"; done
-g++ -O1 -g -std=c++17 -fPIC -I"$HERE" -c "$HERE/emu_runtime.cpp" -o "$HERE/obj/emu_runtime.o"
-g++ -shared -o "$OUT" "$HERE"/obj/*.o
+if [ ! -f "$HERE/obj/emu_runtime.o" ] || [ "$HERE/emu_runtime.cpp" -nt "$HERE/obj/emu_runtime.o" ] || [ "$HERE/hip/hip_runtime.h" -nt "$HERE/obj/emu_runtime.o" ]; then
+  g++ -O1 -g -std=c++17 -fPIC -I"$HERE" -c "$HERE/emu_runtime.cpp" -o "$HERE/obj/emu_runtime.o"
+fi
+# relink only when an object changed (several test processes may call this script at the same time)
+if [ ! -f "$OUT" ] || [ -n "$(find "$HERE/obj" -name '*.o' -newer "$OUT" | head -1)" ]; then
+  g++ -shared -o "$OUT.tmp.$$" "$HERE"/obj/*.o && mv -f "$OUT.tmp.$$" "$OUT"
+fi
 echo "built $OUT"

@@ -12,7 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _worker(rank, world, port, scale, iters, q):
     sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      GRB_EMU_PREBUILT="1")
     import torch
     import torch.distributed as dist
 
@@ -51,9 +52,13 @@ def _worker(rank, world, port, scale, iters, q):
 
 
 def test_row_sharded_mxv_two_ranks():
+    import subprocess
+
     import torch.multiprocessing as mp
 
     from oracle import grb_oracle as O
+
+    subprocess.check_call([os.path.join(ROOT, "tests", "emu", "build_emu.sh")], stdout=subprocess.DEVNULL)
 
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
