@@ -202,6 +202,7 @@ GB_Matrix_opaque *matrix_cast_copy(GB_Matrix_opaque *A, int type);
 GB_Vector_opaque *vector_cast_copy(GB_Vector_opaque *v, int type);
 // out_bits = present(v) & (structure ? 1 : value != 0)
 void vector_mask_bits(GB_Vector_opaque *m, bool structure, uint64_t *out_bits);
+void pack_bool_values(const uint64_t *present, const bool *val, int64_t n, uint64_t *out);
 
 // ---- primitives implemented in grb_prim.hip (rocPRIM-backed) ---------------------------------------
 void prim_sort_pairs_u64_u32(const uint64_t *keys_in, uint64_t *keys_out, const uint32_t *vals_in, uint32_t *vals_out,

@@ -56,6 +56,7 @@ struct PullArgs {
     uint8_t *carry_has;
     void *first_val;
     uint8_t *first_has;  // bit0: has a partial, bit1: the tile's first row started in an earlier tile
+    const uint32_t *u_valbits;  // BOOL semirings: values of the u image, bit-packed (bit = present and true)
     int64_t x_len;       // entries of the u image the column codes index ([hot table | u] when a hot table is in use)
     long long *dbg_times;  // GRB_DEBUG_FLAGS & 8: 10 phase timestamps per tile (thread 0)
     int dbg;             // ablation switches (GRB_DEBUG): 1 = no x gathers, 2 = no A staging loads, 4 = no epilogue
@@ -217,6 +218,7 @@ __global__ __launch_bounds__(PULL_BLOCK) void k_mxv_pull(const PullArgs a)
     const T iso_v = (a.a_iso && need_aval) ? aval[0] : (T)0;
     const __amdgpu_buffer_rsrc_t xval_rs = make_rsrc(a.u_val, a.x_len * (int64_t)sizeof(T));
     const __amdgpu_buffer_rsrc_t xbits_rs = make_rsrc(a.u_bits, a.u_full ? 0 : ((a.x_len + 63) >> 6) * 8);
+    const __amdgpu_buffer_rsrc_t xvbits_rs = make_rsrc(a.u_valbits, a.u_valbits ? ((a.x_len + 63) >> 6) * 8 : 0);
     PHASE_STAMP(1);
     EARLY_EXIT(2);
 
@@ -306,8 +308,17 @@ __global__ __launch_bounds__(PULL_BLOCK) void k_mxv_pull(const PullArgs a)
             for (int i = 0; i < IPT; i++) xp[i] = (bw[i] >> (cc[i] & 31)) & 1u;
         }
         if (need_uval && !(a.dbg & 1)) {
+            if constexpr (std::is_same<T, bool>::value) {
+                // BOOL values travel bit-packed (2 MiB at scale 24, its hot head L1-resident) instead of one byte each
+                uint32_t vw[IPT];
 #pragma unroll
-            for (int i = 0; i < IPT; i++) xv[i] = buf_load<T>(xval_rs, xp[i] ? (unsigned)cc[i] * (unsigned)sizeof(T) : 0xfffffff8u);
+                for (int i = 0; i < IPT; i++) vw[i] = buf_load<uint32_t>(xvbits_rs, xp[i] ? (unsigned)(cc[i] >> 5) * 4u : 0xfffffff8u);
+#pragma unroll
+                for (int i = 0; i < IPT; i++) xv[i] = (vw[i] >> (cc[i] & 31)) & 1u;
+            } else {
+#pragma unroll
+                for (int i = 0; i < IPT; i++) xv[i] = buf_load<T>(xval_rs, xp[i] ? (unsigned)cc[i] * (unsigned)sizeof(T) : 0xfffffff8u);
+            }
         } else {
 #pragma unroll
             for (int i = 0; i < IPT; i++) xv[i] = (T)(cc[i] & 7);
@@ -845,6 +856,24 @@ static void mxv_core(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_Binar
             a.u_bits = (const uint32_t *)xcat_bits.p;
             a.x_len = (int64_t)u->n + k;
         }
+    }
+    // BOOL: pack the values of the image the kernel indexes ([hot | u] or u) into bits
+    DevBuf<uint64_t> valbits(0);
+    if (st == TC_BOOL && a.need_uval) {
+        const int64_t len = a.x_len;
+        dev_free(valbits.p);
+        valbits.p = (uint64_t *)dev_alloc(bits_words64((uint64_t)len) * 8);
+        DevBuf<uint64_t> allp(0);
+        const uint64_t *pres = (const uint64_t *)a.u_bits;
+        if (a.u_full) {  // no presence image in this case: every entry is present
+            dev_free(allp.p);
+            allp.p = (uint64_t *)dev_alloc(bits_words64((uint64_t)len) * 8);
+            GRB_HIP(hipMemsetAsync(allp.p, 0xff, bits_words64((uint64_t)len) * 8, ctx().stream));
+            pres = allp.p;
+        }
+        pack_bool_values(pres, (const bool *)a.u_val, len, valbits.p);
+        a.u_valbits = (const uint32_t *)valbits.p;
+        ctx().stats.kernel_launches += 1;
     }
     a.m_bits = m_bits;
     a.has_mask = mask ? 1 : 0;

@@ -415,6 +415,13 @@ static void vector_extract_typed(GB_Vector_opaque *v, uint64_t *I, void *X, int 
     }
 }
 
+// out bit i = present bit i && val[i]   (raw device images; used for the bit-packed BOOL operand of the pull SpMV)
+void pack_bool_values(const uint64_t *present, const bool *val, int64_t n, uint64_t *out)
+{
+    const int64_t nw = (int64_t)bits_words64((uint64_t)n);
+    LAUNCH((k_mask_bits<bool>), nw * 64, present, val, n, out);
+}
+
 // indices of the present entries, ascending, as a fresh device array (caller frees); returns the count
 int64_t vector_index_list(GB_Vector_opaque *v, uint64_t **d_idx)
 {
