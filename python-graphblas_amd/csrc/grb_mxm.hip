@@ -48,6 +48,10 @@ struct MxmArgs {
     uint64_t *spa_bits;
     void *spa_vals;
     int64_t spa_words;  // 64-bit words per slice
+    // column windows of B for the LDS dense-window numeric kernel: woff[k*(n_win+1) + w] = first entry of B(k,:)
+    // (relative to Bp[k]) whose column is >= w * MM_WIN
+    const int32_t *woff;
+    int n_win;
 };
 
 __device__ __forceinline__ unsigned hash_col(int c, int table_mask) { return ((unsigned)c * 2654435761u) & (unsigned)table_mask; }
@@ -294,6 +298,126 @@ __global__ __launch_bounds__(MM_BLOCK) void k_spgemm_spa(const MxmArgs a, const 
     }
 }
 
+// ---- LDS dense-window numeric kernel for rows of T with more than 4096 entries --------------------------------
+// A^2 of a power-law graph is nearly dense per row (R-MAT 18: 4 877 entries per row on average), too many for an LDS
+// hash table; a dense accumulator per workgroup in HBM thrashes (2048 live 2 MB slices).  Here the columns are cut
+// into windows of MM_WIN: the workgroup of a row walks the windows in order, accumulates window w in LDS by direct
+// index (native LDS atomics, no probing), emits it with an ordered bitmap sweep (so T's rows come out sorted, at a
+// running offset) and recycles the accumulator -- no global atomics.  B's rows are sorted, so the part of B(k,:)
+// inside window w is the range [woff[k][w], woff[k][w+1]), cached with B.
+constexpr int MM_WIN = 8192;
+
+__global__ void k_window_offsets(const int64_t *Bp, const int32_t *Bj, int64_t nrowsB, int n_win, int32_t *woff)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nrowsB) return;
+    const int64_t b = Bp[k], e = Bp[k + 1];
+    int32_t *o = woff + k * (int64_t)(n_win + 1);
+    int64_t pos = b;
+    for (int w = 0; w <= n_win; w++) {  // windows are visited in increasing order: each search starts at the last hit
+        const int64_t target = (int64_t)w * MM_WIN;
+        int64_t lo = pos, hi = e;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (Bj[mid] < target) lo = mid + 1;
+            else hi = mid;
+        }
+        pos = lo;
+        o[w] = (int32_t)(pos - b);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(MM_BLOCK) void k_spgemm_win(const MxmArgs a, const uint32_t *rows)
+{
+    using W = typename Widen<T>::type;
+    __shared__ W s_acc[MM_WIN];
+    __shared__ unsigned long long s_bits[MM_WIN / 64];
+    __shared__ int s_wave[MM_BLOCK / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int monoid = a.monoid, mult = a.mult;
+    const T *Ax = (const T *)a.Ax, *Bx = (const T *)a.Bx;
+    const int64_t row = rows[blockIdx.x];
+    const W ident = monoid_identity<T, W>(monoid);
+    for (int k = tid; k < MM_WIN; k += MM_BLOCK) s_acc[k] = ident;
+    if (tid < MM_WIN / 64) s_bits[tid] = 0ull;
+    __syncthreads();
+    constexpr int NG = MM_BLOCK / MM_GROUP;
+    const int g = tid / MM_GROUP, gl = tid % MM_GROUP;
+    const int64_t pbeg = a.Ap[row], pend = a.Ap[row + 1];
+    const int nwin = a.n_win;
+    int64_t out = a.Tp[row];
+    T *Tx = (T *)a.Tx;
+    for (int w = 0; w < nwin; w++) {
+        const int c0 = w * MM_WIN;
+        // products whose column falls in [c0, c0 + MM_WIN): MM_UNROLL entries of the row in flight per 16-lane group
+        for (int64_t p0 = pbeg + g; p0 < pend; p0 += NG * MM_UNROLL) {
+            int k[MM_UNROLL];
+            int64_t qb[MM_UNROLL], qe[MM_UNROLL];
+#pragma unroll
+            for (int u = 0; u < MM_UNROLL; u++) {
+                const int64_t p = p0 + u * NG;
+                k[u] = p < pend ? a.Aj[p] : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < MM_UNROLL; u++) {
+                qb[u] = qe[u] = 0;
+                if (k[u] >= 0) {
+                    const int32_t *o = a.woff + (int64_t)k[u] * (nwin + 1) + w;
+                    const int64_t b = a.Bp[k[u]];
+                    qb[u] = b + o[0] + gl;
+                    qe[u] = b + o[1];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < MM_UNROLL; u++) {
+                const int64_t p = p0 + u * NG;
+                for (int64_t q = qb[u]; q < qe[u]; q += MM_GROUP) {
+                    const int j = a.Bj[q] - c0;
+                    const T av = a.need_a ? Ax[a.a_iso ? 0 : p] : (T)0;
+                    const T bv = a.need_b ? Bx[a.b_iso ? 0 : q] : (T)0;
+                    const W prod = (W)apply_binop<T>(mult, av, bv);
+                    if (monoid == OP_ANY) s_acc[j] = prod;
+                    else atomic_combine<W>(&s_acc[j], prod, monoid);
+                    atomicOr(&s_bits[j >> 6], 1ull << (j & 63));
+                }
+            }
+        }
+        __syncthreads();
+        // ordered sweep of the window's presence words (MM_WIN/64 = 128 words: threads 0..127 take one each)
+        unsigned long long b = (tid < MM_WIN / 64) ? s_bits[tid] : 0ull;
+        const int c = __popcll(b);
+        int incl = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        if (lane == 63) s_wave[wv] = incl;
+        __syncthreads();
+        int wave_off = 0, total = 0;
+        for (int x = 0; x < MM_BLOCK / 64; x++) {
+            if (x < wv) wave_off += s_wave[x];
+            total += s_wave[x];
+        }
+        int64_t o = out + wave_off + (incl - c);
+        if (b) {
+            s_bits[tid] = 0ull;
+            while (b) {
+                const int t = __ffsll(b) - 1;
+                b &= b - 1;
+                const int j = tid * 64 + t;
+                a.Tj[o] = c0 + j;
+                Tx[o] = from_acc<T, W>(s_acc[j]);
+                s_acc[j] = ident;
+                o++;
+            }
+        }
+        out += total;
+        __syncthreads();
+    }
+}
+
 template <typename W>
 __global__ void k_fill_ident(W *p, int64_t n, W v)
 {
@@ -391,8 +515,11 @@ static void run_bins(MxmArgs &a, const RowBins &rb)
     if (rb.count(2)) hipLaunchKernelGGL((k_spgemm_hash<T, T2, NUMERIC>), dim3((unsigned)rb.count(2)), dim3(MM_BLOCK), 0, ctx().stream, a, rb.ptr(2));
     if (rb.count(3)) hipLaunchKernelGGL((k_spgemm_hash<T, T3, NUMERIC>), dim3((unsigned)rb.count(3)), dim3(MM_BLOCK), 0, ctx().stream, a, rb.ptr(3));
     ctx().stats.kernel_launches += 3;
-    if (rb.count(4)) {
-        // dense accumulators: one slice per resident workgroup (8 per CU), as many as fit in ~32 GiB
+    if (rb.count(4) && NUMERIC && a.woff) {
+        hipLaunchKernelGGL((k_spgemm_win<T>), dim3((unsigned)rb.count(4)), dim3(MM_BLOCK), 0, ctx().stream, a, rb.ptr(4));
+        ctx().stats.kernel_launches += 1;
+    } else if (rb.count(4)) {
+        // dense accumulators in HBM: one slice per resident workgroup (8 per CU), as many as fit in ~32 GiB
         const int64_t words = (int64_t)bits_words64((uint64_t)a.n);
         const int64_t slice_bytes = words * 8 + (NUMERIC ? words * 64 * (int64_t)sizeof(W) : 0);
         int64_t G = std::min<int64_t>(std::min<int64_t>((int64_t)ctx().num_cus * 8, rb.count(4)), std::max<int64_t>(1, (32ll << 30) / slice_bytes));
@@ -466,11 +593,24 @@ static GB_Matrix_opaque *spgemm(GB_Matrix_opaque *A, const void *Ax, GB_Matrix_o
         a.Tp = Tp;
         a.Tj = Tm->d_col;
         a.Tx = Tm->d_val;
-        // 5. numeric, binned by the exact row sizes
+        // 5. numeric, binned by the exact row sizes; rows above the LDS hash limit use LDS column windows when the
+        //    offset table (n_B x (windows+1) int32) is affordable, else dense accumulators in HBM
         {
             RowBins rb(m);
             make_bins(rb, A->d_ptr, nullptr, m, rownnz.p, 128, 1024, 4096);
+            DevBuf<int32_t> woff(0);
+            const int64_t n_win = ceil_div((int64_t)B->ncols, MM_WIN);
+            const int64_t woff_entries = (int64_t)B->nrows * (n_win + 1);
+            if (rb.count(4) && !(ctx().debug_flags & 256) && woff_entries * 4 <= (8ll << 30)) {
+                dev_free(woff.p);
+                woff.p = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)woff_entries);
+                hipLaunchKernelGGL(k_window_offsets, dim3((unsigned)ceil_div((int64_t)B->nrows, 256)), dim3(256), 0, ctx().stream,
+                                   (const int64_t *)B->d_ptr, (const int32_t *)B->d_col, (int64_t)B->nrows, (int)n_win, woff.p);
+                a.woff = woff.p;
+                a.n_win = (int)n_win;
+            }
             run_bins<T, true>(a, rb);
+            sync_stream();  // woff is released at the end of this scope
         }
     } catch (...) {
         matrix_free(Tm);
