@@ -418,6 +418,29 @@ __global__ __launch_bounds__(MM_BLOCK) void k_spgemm_win(const MxmArgs a, const 
     }
 }
 
+// ---- symbolic pass for rows whose upper bound exceeds the LDS hash table: the presence bitmap of the WHOLE column
+//      range lives in LDS (n <= 2^20 columns = 128 KiB), filled by LDS atomicOr, counted by a popcount sweep ---------
+template <int WORDS>
+__global__ __launch_bounds__(MM_BLOCK) void k_spgemm_sym_lds(const MxmArgs a, const uint32_t *rows)
+{
+    __shared__ unsigned long long s_bits[WORDS];
+    __shared__ int s_cnt;
+    const int tid = threadIdx.x;
+    const int64_t row = rows[blockIdx.x];
+    for (int k = tid; k < WORDS; k += MM_BLOCK) s_bits[k] = 0ull;
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    foreach_product(a, row, tid / MM_GROUP, tid % MM_GROUP,
+                    [&](int j, int64_t, int64_t) { atomicOr(&s_bits[j >> 6], 1ull << (j & 63)); });
+    __syncthreads();
+    int c = 0;
+    for (int k = tid; k < WORDS; k += MM_BLOCK) c += __popcll(s_bits[k]);
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
+    if ((tid & 63) == 0 && c) atomicAdd(&s_cnt, c);
+    __syncthreads();
+    if (tid == 0) a.row_nnz[row] = s_cnt;
+}
+
 template <typename W>
 __global__ void k_fill_ident(W *p, int64_t n, W v)
 {
@@ -515,7 +538,11 @@ static void run_bins(MxmArgs &a, const RowBins &rb)
     if (rb.count(2)) hipLaunchKernelGGL((k_spgemm_hash<T, T2, NUMERIC>), dim3((unsigned)rb.count(2)), dim3(MM_BLOCK), 0, ctx().stream, a, rb.ptr(2));
     if (rb.count(3)) hipLaunchKernelGGL((k_spgemm_hash<T, T3, NUMERIC>), dim3((unsigned)rb.count(3)), dim3(MM_BLOCK), 0, ctx().stream, a, rb.ptr(3));
     ctx().stats.kernel_launches += 3;
-    if (rb.count(4) && NUMERIC && a.woff) {
+    if (rb.count(4) && !NUMERIC && a.n <= (1 << 20) && !(ctx().debug_flags & 256)) {
+        if (a.n <= (1 << 18)) hipLaunchKernelGGL((k_spgemm_sym_lds<4096>), dim3((unsigned)rb.count(4)), dim3(MM_BLOCK), 0, ctx().stream, a, rb.ptr(4));
+        else hipLaunchKernelGGL((k_spgemm_sym_lds<16384>), dim3((unsigned)rb.count(4)), dim3(MM_BLOCK), 0, ctx().stream, a, rb.ptr(4));
+        ctx().stats.kernel_launches += 1;
+    } else if (rb.count(4) && NUMERIC && a.woff) {
         hipLaunchKernelGGL((k_spgemm_win<T>), dim3((unsigned)rb.count(4)), dim3(MM_BLOCK), 0, ctx().stream, a, rb.ptr(4));
         ctx().stats.kernel_launches += 1;
     } else if (rb.count(4)) {
