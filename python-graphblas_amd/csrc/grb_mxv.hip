@@ -6,19 +6,22 @@
 //   GrB_vxm  graphblas/core/vector.py:1309-1378 (expression :1367-1375)
 // The arithmetic replaced is SuiteSparse:GraphBLAS's GrB_mxv/GrB_vxm (not in /root/reference).
 //
-// Kernel design (DESIGN.md "Kernels"):
+// Kernel design:
 //   * Work = the merge of the row-end list (m items) with the nnz list (nnz items); every 256-thread
 //     workgroup owns TILE = 256*IPT consecutive merge items, so tiles are balanced no matter how
 //     skewed the degree distribution is (R-MAT hubs, empty rows).  Tile start rows are cached with
 //     the matrix (they only depend on the row pointers).
-//   * Column indices / values of the tile are staged through LDS with coalesced loads; each thread
-//     then walks IPT merge items: first pass issues all its x gathers (presence word, then value)
-//     back to back so IPT random accesses per lane are in flight, second pass folds the products.
-//   * Rows completed inside a thread are stored straight into an LDS row accumulator; rows shared by
-//     several threads combine with LDS atomics; rows shared by several tiles leave per-tile carries
-//     that a second small kernel (one wavefront per seam, __shfl_down reduction) folds.
+//   * All HBM loads of a tile are issued up front: each thread's IPT consecutive entries arrive by 16-byte
+//     buffer loads in the registers of the thread that consumes them; LDS holds only per-row state.
+//   * Each non-empty row marks the entry where it starts (LDS u16 array); a wavefront max-scan by __shfl_up
+//     gives every thread the row of its first entry -- no per-thread merge walk.
+//   * x gathers are buffer loads over ONE image [hot-column table | u]; "no column" (-1: masked-out row, tile
+//     tail) is out of range and reads nothing.  IPT independent gathers are in flight per lane.
+//   * Straight-line segmented fold; a finished segment is one native LDS atomic into its row's accumulator;
+//     rows cut by tile boundaries leave per-tile carries that k_mxv_seams folds (one wavefront per seam).
 //   * Epilogue: each wavefront takes 64 consecutive output rows, applies mask / accum / replace
 //     against the old w, writes values coalesced and the presence word with one __ballot.
+//   * Few entries in u: push direction (SpMSpV, k_push) over the rows selected by u.
 #include <algorithm>
 #include <vector>
 
