@@ -174,6 +174,8 @@ extern "C" GrB_Info GrX_option_set(const char *name, int64_t value)
     else if (n == "hot_min_cols") c.hot_min_cols = value;
     else if (n == "hot_k") c.hot_k = value;
     else if (n == "push_mode") c.push_mode = (int)value;
+    else if (n == "split_min_nnz") c.split_min_nnz = value;
+    else if (n == "split_min_len") c.split_min_len = (int)value;
     else return GrB_INVALID_VALUE;
     return GrB_SUCCESS;
 }

@@ -64,6 +64,8 @@ struct Context {
     int tune_pull_ipt = 0;  // GRB_PULL_IPT: merge items per thread of the pull SpMV (0 = default)
     int64_t hot_min_cols = 1 << 20;  // matrices at least this wide get a hot-column table (pull SpMV)
     int64_t hot_k = 0;               // table entries (0 = ~2 MiB of x values)
+    int64_t split_min_nnz = 1 << 22;  // matrices with at least this many entries are analysed for the long/short row split
+    int split_min_len = 64;           // a row is "long" from this many entries
     int push_mode = 1;               // 0 never push, 1 push when u has < n/64 entries, 2 always push (tests)
 };
 Context &ctx();
@@ -159,6 +161,18 @@ struct GB_Matrix_opaque {
     int32_t *d_hot_cols;  // K original column indices, hottest first
     int64_t hot_k;
     int hot_state;        // 0 = not analysed, 1 = enabled, -1 = not worth it
+    // long/short row split for the pull SpMV (grb_mxv.hip): rows with >= split_min_len entries are processed by a
+    // lean wavefront-per-chunk kernel straight from this matrix's arrays; the remaining rows live in `short_part`
+    // (same shape, long rows empty) and go through the merge-path kernel
+    GB_Matrix_opaque *short_part;
+    uint64_t *d_long_bits;    // bit r: row r is long
+    int32_t *d_long_rows;     // n_long row indices
+    int32_t *d_chunk_slot;    // per chunk: index into d_long_rows
+    int64_t *d_chunk_start;   // per chunk: first entry
+    int32_t *d_chunk_len;     // per chunk: entries (<= PULL_CHUNK)
+    int64_t n_long, n_chunks;
+    int split_state;          // 0 = not analysed, 1 = enabled, -1 = not worth it
+    bool split_hot;           // short_part's columns are hot-coded
     std::string err;
 };
 

@@ -61,6 +61,15 @@ struct PullArgs {
     uint8_t *first_has;  // bit0: has a partial, bit1: the tile's first row started in an earlier tile
     const uint32_t *u_valbits;  // BOOL semirings: values of the u image, bit-packed (bit = present and true)
     int64_t x_len;       // entries of the u image the column codes index ([hot table | u] when a hot table is in use)
+    const uint64_t *long_bits;  // rows the merge-path kernel does NOT own (handled by k_mxv_long), or nullptr
+    // long-row kernel (k_mxv_long / k_mxv_long_epilogue)
+    const int32_t *long_rows;
+    const int32_t *chunk_slot;
+    const int64_t *chunk_start;
+    const int32_t *chunk_len;
+    int64_t n_chunks, n_long;
+    void *tl_val;           // per long row: product accumulator (identity-initialised)
+    unsigned char *tl_has;  // per long row: any product present
     long long *dbg_times;  // GRB_DEBUG_FLAGS & 8: 10 phase timestamps per tile (thread 0)
     int dbg;             // ablation switches (GRB_DEBUG): 1 = no x gathers, 2 = no A staging loads, 4 = no epilogue
 };
@@ -361,7 +370,8 @@ __global__ __launch_bounds__(PULL_BLOCK) void k_mxv_pull(const PullArgs a)
         const int64_t g_first = row_lo >> 6, g_last = (row_hi - 1) >> 6;
         for (int64_t g = g_first + wave; g <= g_last; g += PULL_BLOCK / 64) {
             const int64_t row = (g << 6) + lane;
-            const bool owned = row >= row_lo && row < row_hi;
+            bool owned = row >= row_lo && row < row_hi;
+            if (a.long_bits) owned = owned && !((a.long_bits[g] >> lane) & 1ull);  // long rows belong to k_mxv_long
             const uint64_t oldw = (g == pre_g) ? pre_word : a.w_old_bits[g];
             const bool old_has = (oldw >> lane) & 1ull;
             bool new_has = false;
@@ -395,6 +405,172 @@ __global__ __launch_bounds__(PULL_BLOCK) void k_mxv_pull(const PullArgs a)
         ((W *)a.first_val)[tile] = s_tval[0];
     }
     PHASE_STAMP(7);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Long rows (>= split_min_len entries; on power-law graphs 3 % of the rows hold 80 % of the entries): one wavefront
+// per chunk of at most PULL_CHUNK entries of ONE row.  No row bookkeeping at all -- 8 consecutive entries per lane
+// (16-byte buffer loads), 8 gathers in flight, a lane-local fold, one wavefront reduction by __shfl_down, one
+// atomic into the row's accumulator.  A masked-out row returns before touching its entries.
+// ---------------------------------------------------------------------------------------------------
+constexpr int PULL_CHUNK = 2048;
+
+template <typename T, int MONOID_CT, int MULT_CT>
+__global__ __launch_bounds__(PULL_BLOCK) void k_mxv_long(const PullArgs a)
+{
+    using W = typename Widen<T>::type;
+    constexpr int EPL = 8;  // entries per lane per step
+    const int monoid = MONOID_CT >= 0 ? MONOID_CT : a.monoid;
+    const int mult = MULT_CT >= 0 ? MULT_CT : a.mult;
+    const int lane = threadIdx.x & 63;
+    const int64_t chunk = (int64_t)blockIdx.x * (PULL_BLOCK / 64) + (threadIdx.x >> 6);
+    if (chunk >= a.n_chunks) return;  // wave-uniform
+    const int slot = a.chunk_slot[chunk];
+    const int64_t row = a.long_rows[slot];
+    if (a.has_mask) {
+        bool act = (((const uint32_t *)a.m_bits)[row >> 5] >> (row & 31)) & 1u;
+        if (a.m_comp) act = !act;
+        if (!act) return;  // wave-uniform: nothing of this row is read
+    }
+    const int64_t start = a.chunk_start[chunk];
+    const int len = a.chunk_len[chunk];
+    const bool need_aval = a.need_aval != 0, need_uval = a.need_uval != 0;
+    const bool stage_vals = need_aval && !a.a_iso;
+    const T *aval = (const T *)a.aval;
+    const T iso_v = (a.a_iso && need_aval) ? aval[0] : (T)0;
+    const __amdgpu_buffer_rsrc_t crs = make_rsrc(a.col + start, (int64_t)len * 4);
+    const __amdgpu_buffer_rsrc_t vrs = make_rsrc(aval + (a.a_iso ? 0 : start), stage_vals ? (int64_t)len * (int64_t)sizeof(T) : 0);
+    const __amdgpu_buffer_rsrc_t xval_rs = make_rsrc(a.u_val, a.x_len * (int64_t)sizeof(T));
+    const __amdgpu_buffer_rsrc_t xbits_rs = make_rsrc(a.u_bits, a.u_full ? 0 : ((a.x_len + 63) >> 6) * 8);
+    const __amdgpu_buffer_rsrc_t xvbits_rs = make_rsrc(a.u_valbits, a.u_valbits ? ((a.x_len + 63) >> 6) * 8 : 0);
+    T acc = (T)0;
+    bool has = false;
+    for (int base = lane * EPL; base - lane * EPL < len; base += 64 * EPL) {  // wave-uniform trip count
+        int cc[EPL];
+        T av[EPL];
+#pragma unroll
+        for (int i = 0; i < EPL; i++) {
+            // (per-dword range check: entries past the end of the chunk read 0, and are discarded below)
+            const int c = buf_load<int>(crs, (unsigned)(base + i) * 4u);
+            cc[i] = (base + i < len) ? c : -1;
+            av[i] = stage_vals ? buf_load<T>(vrs, (unsigned)(base + i) * (unsigned)sizeof(T)) : iso_v;
+        }
+        bool xp[EPL];
+        T xv[EPL];
+        if (a.u_full) {
+#pragma unroll
+            for (int i = 0; i < EPL; i++) xp[i] = cc[i] >= 0;
+        } else {
+            uint32_t bw[EPL];
+#pragma unroll
+            for (int i = 0; i < EPL; i++) bw[i] = buf_load<uint32_t>(xbits_rs, (unsigned)(cc[i] >> 5) * 4u);
+#pragma unroll
+            for (int i = 0; i < EPL; i++) xp[i] = (bw[i] >> (cc[i] & 31)) & 1u;
+        }
+        if (need_uval) {
+            if constexpr (std::is_same<T, bool>::value) {
+                uint32_t vw[EPL];
+#pragma unroll
+                for (int i = 0; i < EPL; i++) vw[i] = buf_load<uint32_t>(xvbits_rs, xp[i] ? (unsigned)(cc[i] >> 5) * 4u : 0xfffffff8u);
+#pragma unroll
+                for (int i = 0; i < EPL; i++) xv[i] = (vw[i] >> (cc[i] & 31)) & 1u;
+            } else {
+#pragma unroll
+                for (int i = 0; i < EPL; i++) xv[i] = buf_load<T>(xval_rs, xp[i] ? (unsigned)cc[i] * (unsigned)sizeof(T) : 0xfffffff8u);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < EPL; i++) xv[i] = (T)0;
+        }
+#pragma unroll
+        for (int i = 0; i < EPL; i++) {
+            const T prod = apply_binop<T>(mult, need_aval ? av[i] : (T)0, xv[i]);
+            acc = xp[i] ? (has ? apply_binop<T>(monoid, acc, prod) : prod) : acc;
+            has = has || xp[i];
+        }
+    }
+    // wavefront reduction (value + presence)
+    int hasi = has ? 1 : 0;
+    for (int off = 32; off > 0; off >>= 1) {
+        const T o = __shfl_down(acc, off);
+        const int oh = __shfl_down(hasi, off);
+        if (oh) {
+            acc = hasi ? apply_binop<T>(monoid, acc, o) : o;
+            hasi = 1;
+        }
+    }
+    if (lane == 0 && hasi) {
+        W *tl = (W *)a.tl_val;
+        if (monoid == OP_ANY) tl[slot] = (W)acc;
+        else atomic_combine<W>(&tl[slot], (W)acc, monoid);
+        a.tl_has[slot] = 1;
+    }
+}
+
+// the write rule for the long rows, one thread per row
+template <typename T>
+__global__ void k_mxv_long_epilogue(const PullArgs a)
+{
+    using W = typename Widen<T>::type;
+    const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= a.n_long) return;
+    const int64_t row = a.long_rows[slot];
+    bool mact = true;
+    if (a.has_mask) {
+        mact = (((const uint32_t *)a.m_bits)[row >> 5] >> (row & 31)) & 1u;
+        if (a.m_comp) mact = !mact;
+    }
+    const bool old_has = (a.w_old_bits[row >> 6] >> (row & 63)) & 1ull;
+    const T old_val = old_has ? ((const T *)a.w_old_val)[row] : (T)0;
+    const bool new_has = write_rule_row<T>(a, row, mact, old_has, old_val, a.tl_has[slot] != 0, from_acc<T, W>(((const W *)a.tl_val)[slot]));
+    const unsigned long long bit = 1ull << (row & 63);
+    if (new_has) atomicOr((unsigned long long *)&a.w_new_bits[row >> 6], bit);
+    else atomicAnd((unsigned long long *)&a.w_new_bits[row >> 6], ~bit);
+}
+
+// ---- building the split (once per matrix) ---------------------------------------------------------------------
+__global__ void k_split_classify(const int64_t *ptr, int64_t m, int min_len, uint64_t *long_bits, int64_t *slen, int64_t *lflag,
+                                 int64_t *nchunk)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool is_long = false;
+    if (r < m) {
+        const int64_t len = ptr[r + 1] - ptr[r];
+        is_long = len >= min_len;
+        slen[r] = is_long ? 0 : len;
+        lflag[r] = is_long ? 1 : 0;
+        nchunk[r] = is_long ? (len + PULL_CHUNK - 1) / PULL_CHUNK : 0;
+    } else if (r == m) {
+        slen[r] = 0; lflag[r] = 0; nchunk[r] = 0;
+    }
+    const unsigned long long b = __ballot(is_long);
+    if ((threadIdx.x & 63) == 0 && (r >> 6) < ((m + 63) >> 6)) long_bits[r >> 6] = b;
+}
+
+template <typename T>
+__global__ void k_split_fill(const int64_t *ptr, const int32_t *col, const T *val, int iso, int64_t m, int min_len,
+                             const int64_t *sptr, const int64_t *lidx, const int64_t *cidx, int32_t *scol, T *sval,
+                             int32_t *long_rows, int32_t *chunk_slot, int64_t *chunk_start, int32_t *chunk_len)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= m) return;
+    const int64_t b = ptr[r], len = ptr[r + 1] - b;
+    if (len >= min_len) {
+        const int64_t slot = lidx[r];
+        long_rows[slot] = (int32_t)r;
+        int64_t c = cidx[r];
+        for (int64_t off = 0; off < len; off += PULL_CHUNK, c++) {
+            chunk_slot[c] = (int32_t)slot;
+            chunk_start[c] = b + off;
+            chunk_len[c] = (int32_t)(len - off < PULL_CHUNK ? len - off : PULL_CHUNK);
+        }
+    } else {
+        const int64_t o = sptr[r];
+        for (int64_t i = 0; i < len; i++) {
+            scol[o + i] = col[b + i];
+            if (!iso) sval[o + i] = val[b + i];
+        }
+    }
 }
 
 // One wavefront per tile whose first row began in earlier tiles: fold the carries of tiles
@@ -685,10 +861,95 @@ static void report_phase_times(const long long *d_times, int64_t n_tiles)
             sum[5] / n_tiles, sum[6] / n_tiles, tmax - tmin);
 }
 
+// Analyse (once) whether the rows split usefully into long and short ones and build the two parts.
+// `col_src` is the column array the kernels will index (hot-coded or original).
+static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
+{
+    if (A->split_state != 0 && (A->split_state < 0 || A->split_hot == hot)) return;
+    if (A->split_state == 1) {  // built against the other column coding: rebuild
+        matrix_free(A->short_part);
+        A->short_part = nullptr;
+        dev_free(A->d_long_bits); dev_free(A->d_long_rows); dev_free(A->d_chunk_slot); dev_free(A->d_chunk_start); dev_free(A->d_chunk_len);
+        A->d_long_bits = nullptr; A->d_long_rows = nullptr; A->d_chunk_slot = nullptr; A->d_chunk_start = nullptr; A->d_chunk_len = nullptr;
+    }
+    A->split_state = -1;
+    const int64_t m = (int64_t)A->nrows, nnz = A->nvals;
+    if (nnz < ctx().split_min_nnz || m == 0 || (ctx().debug_flags & 128)) return;
+    const int min_len = ctx().split_min_len;
+    DevBuf<uint64_t> lbits(bits_words64((uint64_t)m));
+    DevBuf<int64_t> slen(m + 1), lflag(m + 1), nchunk(m + 1);
+    hipLaunchKernelGGL(k_split_classify, dim3((unsigned)ceil_div((int64_t)bits_words64((uint64_t)m) * 64 + 1, 256)), dim3(256), 0,
+                       ctx().stream, (const int64_t *)A->d_ptr, m, min_len, lbits.p, slen.p, lflag.p, nchunk.p);
+    prim_exclusive_sum_i64(slen.p, slen.p, m + 1);
+    prim_exclusive_sum_i64(lflag.p, lflag.p, m + 1);
+    prim_exclusive_sum_i64(nchunk.p, nchunk.p, m + 1);
+    int64_t nnz_short = 0, nl = 0, nc = 0;
+    d2h(&nnz_short, slen.p + m, 8);
+    d2h(&nl, lflag.p + m, 8);
+    d2h(&nc, nchunk.p + m, 8);
+    if (nl == 0 || (double)(nnz - nnz_short) < 0.3 * (double)nnz) return;  // too few entries in long rows to pay off
+    GB_Matrix_opaque *S = matrix_new(A->type, A->nrows, A->ncols);
+    try {
+        S->d_ptr = slen.release();
+        S->d_col = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)(nnz_short ? nnz_short : 1));
+        S->d_val = dev_alloc(A->type->size * (size_t)(A->iso ? 1 : (nnz_short ? nnz_short : 1)));
+        if (A->iso) d2d(S->d_val, A->d_val, A->type->size);
+        S->iso = A->iso;
+        S->nvals = nnz_short;
+        A->d_long_rows = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)nl);
+        A->d_chunk_slot = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)nc);
+        A->d_chunk_start = (int64_t *)dev_alloc(sizeof(int64_t) * (size_t)nc);
+        A->d_chunk_len = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)nc);
+        GRB_DISPATCH_TYPE(A->type->code, T, {
+            hipLaunchKernelGGL((k_split_fill<T>), dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, ctx().stream,
+                               (const int64_t *)A->d_ptr, col_src, (const T *)A->d_val, A->iso ? 1 : 0, m, min_len,
+                               (const int64_t *)S->d_ptr, (const int64_t *)lflag.p, (const int64_t *)nchunk.p, S->d_col,
+                               (T *)S->d_val, A->d_long_rows, A->d_chunk_slot, A->d_chunk_start, A->d_chunk_len);
+        })
+        sync_stream();
+    } catch (...) {
+        matrix_free(S);
+        throw;
+    }
+    A->short_part = S;
+    A->d_long_bits = lbits.release();
+    A->n_long = nl;
+    A->n_chunks = nc;
+    A->split_hot = hot;
+    A->split_state = 1;
+}
+
 template <typename T, int MON, int MUL, int IPT>
 static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
 {
     using W = typename Widen<T>::type;
+    // long rows first (lean wavefront-per-chunk kernel straight from A's arrays), then the merge-path kernel over
+    // the short part -- when the split exists and the operands are exactly A's own arrays (no typecast copy)
+    const bool use_split = A->split_state == 1 && a.aval == A->d_val &&
+                           a.col == (A->split_hot ? A->d_col_hot : A->d_col) && a.n_chunks > 0;
+    if (use_split) {
+        GB_Matrix_opaque *S = A->short_part;
+        DevBuf<W> tl_val(a.n_long);
+        DevBuf<unsigned char> tl_has(a.n_long, true);
+        hipLaunchKernelGGL((k_fill_w<W>), dim3((unsigned)ceil_div(a.n_long, 256)), dim3(256), 0, ctx().stream, tl_val.p, a.n_long,
+                           monoid_identity<T, W>(a.monoid));
+        a.tl_val = tl_val.p;
+        a.tl_has = tl_has.p;
+        a.dbg = ctx().debug_flags;
+        hipLaunchKernelGGL((k_mxv_long<T, MON, MUL>), dim3((unsigned)ceil_div(a.n_chunks, PULL_BLOCK / 64)), dim3(PULL_BLOCK), 0,
+                           ctx().stream, a);
+        hipLaunchKernelGGL((k_mxv_long_epilogue<T>), dim3((unsigned)ceil_div(a.n_long, 256)), dim3(256), 0, ctx().stream, a);
+        ctx().stats.kernel_launches += 3;
+        PullArgs b = a;
+        b.rowptr = matrix_rowptr(S);
+        b.col = S->d_col;
+        b.aval = S->d_val;
+        b.nnz = S->nvals;
+        b.long_bits = A->d_long_bits;
+        b.n_chunks = 0;
+        launch_pull_ipt<T, MON, MUL, IPT>(S, b);  // S has no split of its own: takes the plain path below
+        return;
+    }
     constexpr int TILE = PULL_BLOCK * IPT;
     a.dbg = ctx().debug_flags;
     ensure_tile_table(A, TILE);
@@ -858,6 +1119,19 @@ static void mxv_core(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_Binar
             a.u_val = xcat_val.p;
             a.u_bits = (const uint32_t *)xcat_bits.p;
             a.x_len = (int64_t)u->n + k;
+        }
+    }
+    // long/short row split (large matrices whose long rows hold a good share of the entries)
+    if (S->nvals && S->type->code == st) {
+        const bool hot = (a.col == S->d_col_hot);
+        ensure_split(S, a.col, hot);
+        if (S->split_state == 1 && S->split_hot == hot) {
+            a.long_rows = S->d_long_rows;
+            a.chunk_slot = S->d_chunk_slot;
+            a.chunk_start = S->d_chunk_start;
+            a.chunk_len = S->d_chunk_len;
+            a.n_chunks = S->n_chunks;
+            a.n_long = S->n_long;
         }
     }
     // BOOL: pack the values of the image the kernel indexes ([hot | u] or u) into bits

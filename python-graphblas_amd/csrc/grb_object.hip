@@ -462,6 +462,15 @@ GB_Matrix_opaque *matrix_new(GrB_Type type, uint64_t nrows, uint64_t ncols)
     A->d_hot_cols = nullptr;
     A->hot_k = 0;
     A->hot_state = 0;
+    A->short_part = nullptr;
+    A->d_long_bits = nullptr;
+    A->d_long_rows = nullptr;
+    A->d_chunk_slot = nullptr;
+    A->d_chunk_start = nullptr;
+    A->d_chunk_len = nullptr;
+    A->n_long = A->n_chunks = 0;
+    A->split_state = 0;
+    A->split_hot = false;
     return A;
 }
 
@@ -481,6 +490,20 @@ void matrix_invalidate_caches(GB_Matrix_opaque *A)
     A->d_hot_cols = nullptr;
     A->hot_k = 0;
     A->hot_state = 0;
+    if (A->short_part) matrix_free(A->short_part);
+    A->short_part = nullptr;
+    dev_free(A->d_long_bits);
+    dev_free(A->d_long_rows);
+    dev_free(A->d_chunk_slot);
+    dev_free(A->d_chunk_start);
+    dev_free(A->d_chunk_len);
+    A->d_long_bits = nullptr;
+    A->d_long_rows = nullptr;
+    A->d_chunk_slot = nullptr;
+    A->d_chunk_start = nullptr;
+    A->d_chunk_len = nullptr;
+    A->n_long = A->n_chunks = 0;
+    A->split_state = 0;
 }
 
 void matrix_release_storage(GB_Matrix_opaque *A)

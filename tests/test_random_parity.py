@@ -373,3 +373,66 @@ def test_push_direction(gb, seed):
         same_vec(q, O.vxm(oq, ob, sr, w=oq, mask=ovis, mask_comp=True, mask_struct=True, replace=True))
     finally:
         _lib.lib.GrX_option_set(b"push_mode", 1)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_long_short_row_split(gb, seed):
+    """Force the long/short row split of the pull SpMV on (tiny thresholds), with and without the hot-column table:
+    rows of every length around the threshold and the chunk size, masks that switch long rows off, accumulators,
+    bitmap and full u, w aliased with u, vxm over the transpose (its own split)."""
+    from graphblas_amd import _lib, device
+
+    rng = np.random.default_rng(1100 + seed)
+    tname = TYPES[seed % 7]
+    sr = semirings_for(tname)[seed % 4]
+    m, n = int(rng.integers(50, 600)), int(rng.integers(2100, 6000))
+    deg = rng.integers(0, 6, m)
+    deg[rng.random(m) < 0.3] = 0
+    for ln in (7, 8, 9, 63, 64, 65, 511, 513, 2047, 2048, 2049, int(rng.integers(2100, n))):
+        deg[rng.integers(0, m)] = min(ln, n)
+    rows = np.repeat(np.arange(m), deg)
+    cols = np.concatenate([rng.choice(n, d, replace=False) for d in deg])
+    vals = rand_vals(rng, rows.size, tname)
+    ui, uv = rand_vec(rng, n, [1.0, 0.5, 0.05][seed % 3], tname)
+    wi, wv = rand_vec(rng, m, 0.5, tname)
+    mi, mv = rand_vec(rng, m, 0.5, "BOOL")
+    accum = [None, "plus", "min"][seed % 3]
+    comp = bool(seed & 1)
+    oa = O.OMat.from_coo(rows, cols, vals, m, n, tname)
+    exp = O.mxv(oa, O.OVec(n, ui, uv, tname), sr, w=O.OVec(m, wi, wv, tname), mask=O.OVec(m, mi, mv, "BOOL"),
+                mask_comp=comp, accum=accum, replace=bool(seed & 2))
+    xi, xv = rand_vec(rng, m, 0.6, tname)
+    exp_t = O.vxm(O.OVec(m, xi, xv, tname), oa, sr)
+    try:
+        _lib.lib.GrX_option_set(b"split_min_nnz", 1)
+        _lib.lib.GrX_option_set(b"split_min_len", 8)
+        _lib.lib.GrX_option_set(b"push_mode", 0)
+        if seed & 4:
+            _lib.lib.GrX_option_set(b"hot_min_cols", 8)
+            _lib.lib.GrX_option_set(b"hot_k", 64)
+        A = gb.Matrix.from_coo(rows, cols, vals, dtype=tname, nrows=m, ncols=n)
+        u = gb.Vector.from_coo(ui, uv, dtype=tname, size=n)
+        w = gb.Vector.from_coo(wi, wv, dtype=tname, size=m)
+        mk = gb.Vector.from_coo(mi, mv, dtype="BOOL", size=m)
+        w(~mk.V if comp else mk.V, accum=accum, replace=bool(seed & 2)) << A.mxv(u, getattr(gb.semiring, sr))
+        assert device.last_stats()["kernel_launches"] >= 5  # fill + long + long epilogue + merge + seams
+        same_vec(w, exp)
+        x = gb.Vector.from_coo(xi, xv, dtype=tname, size=m)
+        same_vec(x.vxm(A, getattr(gb.semiring, sr)).new(), exp_t)
+        # square, w aliased with u
+        k = m
+        r2 = np.repeat(np.arange(k), np.minimum(deg, k))
+        c2 = np.concatenate([rng.choice(k, min(d, k), replace=False) for d in deg])
+        v2 = rand_vals(rng, r2.size, tname)
+        B = gb.Matrix.from_coo(r2, c2, v2, dtype=tname, nrows=k, ncols=k)
+        ob = O.OMat.from_coo(r2, c2, v2, k, k, tname)
+        qi, qv = rand_vec(rng, k, 0.3, tname)
+        q, oq = gb.Vector.from_coo(qi, qv, dtype=tname, size=k), O.OVec(k, qi, qv, tname)
+        q(~mk.S, replace=True) << B.mxv(q, getattr(gb.semiring, sr))
+        same_vec(q, O.mxv(ob, oq, sr, w=oq, mask=O.OVec(m, mi, mv, "BOOL"), mask_comp=True, mask_struct=True, replace=True))
+    finally:
+        _lib.lib.GrX_option_set(b"split_min_nnz", 1 << 22)
+        _lib.lib.GrX_option_set(b"split_min_len", 64)
+        _lib.lib.GrX_option_set(b"push_mode", 1)
+        _lib.lib.GrX_option_set(b"hot_min_cols", 1 << 20)
+        _lib.lib.GrX_option_set(b"hot_k", 0)
