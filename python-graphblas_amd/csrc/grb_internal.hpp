@@ -65,7 +65,7 @@ struct Context {
     int64_t hot_min_cols = 1 << 20;  // matrices at least this wide get a hot-column table (pull SpMV)
     int64_t hot_k = 0;               // table entries (0 = ~2 MiB of x values)
     int64_t split_min_nnz = 1 << 22;  // matrices with at least this many entries are analysed for the long/short row split
-    int split_min_len = 64;           // a row is "long" from this many entries
+    int split_min_len = 256;          // a row is "long" from this many entries
     int push_mode = 1;               // 0 never push, 1 push when u has < n/64 entries, 2 always push (tests)
 };
 Context &ctx();

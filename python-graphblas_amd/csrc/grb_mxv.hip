@@ -414,96 +414,139 @@ __global__ __launch_bounds__(PULL_BLOCK) void k_mxv_pull(const PullArgs a)
 // atomic into the row's accumulator.  A masked-out row returns before touching its entries.
 // ---------------------------------------------------------------------------------------------------
 constexpr int PULL_CHUNK = 2048;
+constexpr int LONG_BLOCK = 1024;        // 16 wavefronts; one persistent workgroup per CU
+constexpr int LONG_LDS_WORDS = 32768;   // 128 KiB: the head of the x image ([hot | u]: hottest columns first)
 
 template <typename T, int MONOID_CT, int MULT_CT>
-__global__ __launch_bounds__(PULL_BLOCK) void k_mxv_long(const PullArgs a)
+__global__ __launch_bounds__(LONG_BLOCK) void k_mxv_long(const PullArgs a)
 {
     using W = typename Widen<T>::type;
     constexpr int EPL = 8;  // entries per lane per step
+    // Every gather that misses L1 moves a 128-byte line from L2 for 4 useful bytes; the workgroup therefore keeps
+    // the head of the x image in LDS for its whole life (hot-coded columns: the most referenced come first --
+    // 32 Ki fp32 entries receive ~45 % of the references of an R-MAT graph; BOOL values are bit-packed: 1 Mi entries).
+    __shared__ uint32_t s_x[LONG_LDS_WORDS];
     const int monoid = MONOID_CT >= 0 ? MONOID_CT : a.monoid;
     const int mult = MULT_CT >= 0 ? MULT_CT : a.mult;
     const int lane = threadIdx.x & 63;
-    const int64_t chunk = (int64_t)blockIdx.x * (PULL_BLOCK / 64) + (threadIdx.x >> 6);
-    if (chunk >= a.n_chunks) return;  // wave-uniform
-    const int slot = a.chunk_slot[chunk];
-    const int64_t row = a.long_rows[slot];
-    if (a.has_mask) {
-        bool act = (((const uint32_t *)a.m_bits)[row >> 5] >> (row & 31)) & 1u;
-        if (a.m_comp) act = !act;
-        if (!act) return;  // wave-uniform: nothing of this row is read
-    }
-    const int64_t start = a.chunk_start[chunk];
-    const int len = a.chunk_len[chunk];
     const bool need_aval = a.need_aval != 0, need_uval = a.need_uval != 0;
     const bool stage_vals = need_aval && !a.a_iso;
     const T *aval = (const T *)a.aval;
     const T iso_v = (a.a_iso && need_aval) ? aval[0] : (T)0;
-    const __amdgpu_buffer_rsrc_t crs = make_rsrc(a.col + start, (int64_t)len * 4);
-    const __amdgpu_buffer_rsrc_t vrs = make_rsrc(aval + (a.a_iso ? 0 : start), stage_vals ? (int64_t)len * (int64_t)sizeof(T) : 0);
     const __amdgpu_buffer_rsrc_t xval_rs = make_rsrc(a.u_val, a.x_len * (int64_t)sizeof(T));
     const __amdgpu_buffer_rsrc_t xbits_rs = make_rsrc(a.u_bits, a.u_full ? 0 : ((a.x_len + 63) >> 6) * 8);
     const __amdgpu_buffer_rsrc_t xvbits_rs = make_rsrc(a.u_valbits, a.u_valbits ? ((a.x_len + 63) >> 6) * 8 : 0);
-    T acc = (T)0;
-    bool has = false;
-    for (int base = lane * EPL; base - lane * EPL < len; base += 64 * EPL) {  // wave-uniform trip count
-        int cc[EPL];
-        T av[EPL];
-#pragma unroll
-        for (int i = 0; i < EPL; i++) {
-            // (per-dword range check: entries past the end of the chunk read 0, and are discarded below)
-            const int c = buf_load<int>(crs, (unsigned)(base + i) * 4u);
-            cc[i] = (base + i < len) ? c : -1;
-            av[i] = stage_vals ? buf_load<T>(vrs, (unsigned)(base + i) * (unsigned)sizeof(T)) : iso_v;
+    constexpr bool IS_BOOL = std::is_same<T, bool>::value;
+    // entries of the image resident in LDS
+    constexpr int64_t LDS_CAP = IS_BOOL ? (int64_t)LONG_LDS_WORDS * 32 : (int64_t)LONG_LDS_WORDS * 4 / (int64_t)(sizeof(T) < 4 ? 4 : sizeof(T));
+    const int lds_n = need_uval ? (int)(a.x_len < LDS_CAP ? a.x_len : LDS_CAP) : 0;
+    if (need_uval) {
+        if constexpr (IS_BOOL) {
+            const int words = (lds_n + 31) >> 5;
+            for (int k = threadIdx.x; k < words; k += LONG_BLOCK) s_x[k] = buf_load<uint32_t>(xvbits_rs, (unsigned)k * 4u);
+        } else if constexpr (sizeof(T) == 8) {
+            for (int k = threadIdx.x; k < lds_n; k += LONG_BLOCK) ((T *)s_x)[k] = buf_load<T>(xval_rs, (unsigned)k * 8u);
+        } else if constexpr (sizeof(T) == 4) {
+            for (int k = threadIdx.x; k < lds_n; k += LONG_BLOCK) s_x[k] = __builtin_bit_cast(uint32_t, buf_load<T>(xval_rs, (unsigned)k * 4u));
+        } else {  // 1- and 2-byte values: one per 32-bit LDS word
+            for (int k = threadIdx.x; k < lds_n; k += LONG_BLOCK) s_x[k] = (uint32_t)buf_load<T>(xval_rs, (unsigned)k * (unsigned)sizeof(T));
         }
-        bool xp[EPL];
-        T xv[EPL];
-        if (a.u_full) {
-#pragma unroll
-            for (int i = 0; i < EPL; i++) xp[i] = cc[i] >= 0;
-        } else {
-            uint32_t bw[EPL];
-#pragma unroll
-            for (int i = 0; i < EPL; i++) bw[i] = buf_load<uint32_t>(xbits_rs, (unsigned)(cc[i] >> 5) * 4u);
-#pragma unroll
-            for (int i = 0; i < EPL; i++) xp[i] = (bw[i] >> (cc[i] & 31)) & 1u;
+    }
+    __syncthreads();
+
+    const int64_t wave0 = (int64_t)blockIdx.x * (LONG_BLOCK / 64) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (LONG_BLOCK / 64);
+    for (int64_t chunk = wave0; chunk < a.n_chunks; chunk += nwaves) {  // persistent: wavefronts stride the chunk list
+        const int slot = a.chunk_slot[chunk];
+        const int64_t row = a.long_rows[slot];
+        if (a.has_mask) {
+            bool act = (((const uint32_t *)a.m_bits)[row >> 5] >> (row & 31)) & 1u;
+            if (a.m_comp) act = !act;
+            if (!act) continue;  // wave-uniform: nothing of this row is read
         }
-        if (need_uval) {
-            if constexpr (std::is_same<T, bool>::value) {
-                uint32_t vw[EPL];
+        const int64_t start = a.chunk_start[chunk];
+        const int len = a.chunk_len[chunk];
+        const __amdgpu_buffer_rsrc_t crs = make_rsrc(a.col + start, (int64_t)len * 4);
+        const __amdgpu_buffer_rsrc_t vrs = make_rsrc(aval + (a.a_iso ? 0 : start), stage_vals ? (int64_t)len * (int64_t)sizeof(T) : 0);
+        T acc = (T)0;
+        bool has = false;
+        for (int base = 0; base < len; base += 64 * EPL) {  // wave-uniform trip count; lane takes entries base + lane + 64 i
+            int cc[EPL];
+            T av[EPL];
 #pragma unroll
-                for (int i = 0; i < EPL; i++) vw[i] = buf_load<uint32_t>(xvbits_rs, xp[i] ? (unsigned)(cc[i] >> 5) * 4u : 0xfffffff8u);
+            for (int i = 0; i < EPL; i++) {
+                // coalesced 4-byte loads; entries past the end of the chunk are out of range (read 0) and discarded
+                const int e = base + i * 64 + lane;
+                const int c = buf_load<int>(crs, (unsigned)e * 4u);
+                cc[i] = (e < len) ? c : -1;
+                av[i] = stage_vals ? buf_load<T>(vrs, (unsigned)e * (unsigned)sizeof(T)) : iso_v;
+            }
+            bool xp[EPL];
+            T xv[EPL];
+            if (a.u_full) {
 #pragma unroll
-                for (int i = 0; i < EPL; i++) xv[i] = (vw[i] >> (cc[i] & 31)) & 1u;
+                for (int i = 0; i < EPL; i++) xp[i] = cc[i] >= 0;
+            } else {
+                uint32_t bw[EPL];
+#pragma unroll
+                for (int i = 0; i < EPL; i++) bw[i] = buf_load<uint32_t>(xbits_rs, (unsigned)(cc[i] >> 5) * 4u);
+#pragma unroll
+                for (int i = 0; i < EPL; i++) xp[i] = (bw[i] >> (cc[i] & 31)) & 1u;
+            }
+            if (need_uval) {
+                // resident entries come from LDS; the others from the image in HBM (an out-of-range offset reads nothing)
+                if constexpr (IS_BOOL) {
+                    uint32_t vw[EPL];
+#pragma unroll
+                    for (int i = 0; i < EPL; i++) vw[i] = buf_load<uint32_t>(xvbits_rs, (xp[i] && cc[i] >= lds_n) ? (unsigned)(cc[i] >> 5) * 4u : 0xfffffff8u);
+#pragma unroll
+                    for (int i = 0; i < EPL; i++) {
+                        const bool in_lds = xp[i] && cc[i] < lds_n;
+                        const uint32_t wv = in_lds ? s_x[cc[i] >> 5] : vw[i];
+                        xv[i] = (wv >> (cc[i] & 31)) & 1u;
+                    }
+                } else {
+                    T xg[EPL];
+#pragma unroll
+                    for (int i = 0; i < EPL; i++) xg[i] = buf_load<T>(xval_rs, (xp[i] && cc[i] >= lds_n) ? (unsigned)cc[i] * (unsigned)sizeof(T) : 0xfffffff8u);
+#pragma unroll
+                    for (int i = 0; i < EPL; i++) {
+                        const bool in_lds = xp[i] && cc[i] < lds_n;
+                        const int li = in_lds ? cc[i] : 0;
+                        T xl;
+                        if constexpr (sizeof(T) == 8) xl = ((const T *)s_x)[li];
+                        else if constexpr (sizeof(T) == 4) xl = __builtin_bit_cast(T, s_x[li]);
+                        else xl = (T)s_x[li];
+                        xv[i] = in_lds ? xl : xg[i];
+                    }
+                }
             } else {
 #pragma unroll
-                for (int i = 0; i < EPL; i++) xv[i] = buf_load<T>(xval_rs, xp[i] ? (unsigned)cc[i] * (unsigned)sizeof(T) : 0xfffffff8u);
+                for (int i = 0; i < EPL; i++) xv[i] = (T)0;
             }
-        } else {
 #pragma unroll
-            for (int i = 0; i < EPL; i++) xv[i] = (T)0;
+            for (int i = 0; i < EPL; i++) {
+                const T prod = apply_binop<T>(mult, need_aval ? av[i] : (T)0, xv[i]);
+                acc = xp[i] ? (has ? apply_binop<T>(monoid, acc, prod) : prod) : acc;
+                has = has || xp[i];
+            }
         }
-#pragma unroll
-        for (int i = 0; i < EPL; i++) {
-            const T prod = apply_binop<T>(mult, need_aval ? av[i] : (T)0, xv[i]);
-            acc = xp[i] ? (has ? apply_binop<T>(monoid, acc, prod) : prod) : acc;
-            has = has || xp[i];
+        // wavefront reduction (value + presence)
+        int hasi = has ? 1 : 0;
+        for (int off = 32; off > 0; off >>= 1) {
+            const T o = __shfl_down(acc, off);
+            const int oh = __shfl_down(hasi, off);
+            if (oh) {
+                acc = hasi ? apply_binop<T>(monoid, acc, o) : o;
+                hasi = 1;
+            }
         }
-    }
-    // wavefront reduction (value + presence)
-    int hasi = has ? 1 : 0;
-    for (int off = 32; off > 0; off >>= 1) {
-        const T o = __shfl_down(acc, off);
-        const int oh = __shfl_down(hasi, off);
-        if (oh) {
-            acc = hasi ? apply_binop<T>(monoid, acc, o) : o;
-            hasi = 1;
+        if (lane == 0 && hasi) {
+            W *tl = (W *)a.tl_val;
+            if (monoid == OP_ANY) tl[slot] = (W)acc;
+            else atomic_combine<W>(&tl[slot], (W)acc, monoid);
+            a.tl_has[slot] = 1;
         }
-    }
-    if (lane == 0 && hasi) {
-        W *tl = (W *)a.tl_val;
-        if (monoid == OP_ANY) tl[slot] = (W)acc;
-        else atomic_combine<W>(&tl[slot], (W)acc, monoid);
-        a.tl_has[slot] = 1;
     }
 }
 
@@ -936,8 +979,11 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
         a.tl_val = tl_val.p;
         a.tl_has = tl_has.p;
         a.dbg = ctx().debug_flags;
-        hipLaunchKernelGGL((k_mxv_long<T, MON, MUL>), dim3((unsigned)ceil_div(a.n_chunks, PULL_BLOCK / 64)), dim3(PULL_BLOCK), 0,
-                           ctx().stream, a);
+        {
+            const int64_t want = ceil_div(a.n_chunks, LONG_BLOCK / 64);
+            const int64_t G = std::min<int64_t>(want, (int64_t)ctx().num_cus);  // persistent: one 1024-thread workgroup per CU
+            hipLaunchKernelGGL((k_mxv_long<T, MON, MUL>), dim3((unsigned)G), dim3(LONG_BLOCK), 0, ctx().stream, a);
+        }
         hipLaunchKernelGGL((k_mxv_long_epilogue<T>), dim3((unsigned)ceil_div(a.n_long, 256)), dim3(256), 0, ctx().stream, a);
         ctx().stats.kernel_launches += 3;
         PullArgs b = a;

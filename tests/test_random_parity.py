@@ -432,7 +432,7 @@ def test_long_short_row_split(gb, seed):
         same_vec(q, O.mxv(ob, oq, sr, w=oq, mask=O.OVec(m, mi, mv, "BOOL"), mask_comp=True, mask_struct=True, replace=True))
     finally:
         _lib.lib.GrX_option_set(b"split_min_nnz", 1 << 22)
-        _lib.lib.GrX_option_set(b"split_min_len", 64)
+        _lib.lib.GrX_option_set(b"split_min_len", 256)
         _lib.lib.GrX_option_set(b"push_mode", 1)
         _lib.lib.GrX_option_set(b"hot_min_cols", 1 << 20)
         _lib.lib.GrX_option_set(b"hot_k", 0)
