@@ -176,6 +176,7 @@ extern "C" GrB_Info GrX_option_set(const char *name, int64_t value)
     else if (n == "push_mode") c.push_mode = (int)value;
     else if (n == "split_min_nnz") c.split_min_nnz = value;
     else if (n == "split_min_len") c.split_min_len = (int)value;
+    else if (n == "short_kernel") c.short_kernel = (int)value;
     else return GrB_INVALID_VALUE;
     return GrB_SUCCESS;
 }

@@ -59,6 +59,7 @@ struct Context {
     int num_cus = 256;
     hipStream_t stream = nullptr;  // null stream: ordered with torch's default stream
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int short_kernel = 1;   // short rows of a split matrix: 1 = row-group kernel (k_mxv_rows), 0 = merge-path kernel
     GrX_Stats stats{};
     int debug_flags = 0;    // GRB_DEBUG: kernel ablation switches (benchmark diagnostics only)
     int tune_pull_ipt = 0;  // GRB_PULL_IPT: merge items per thread of the pull SpMV (0 = default)
@@ -170,6 +171,7 @@ struct GB_Matrix_opaque {
     int32_t *d_chunk_slot;    // per chunk: index into d_long_rows
     int64_t *d_chunk_start;   // per chunk: first entry
     int32_t *d_chunk_len;     // per chunk: entries (<= PULL_CHUNK)
+    int32_t *d_long_prefix;   // per 64-row group: number of long rows before it
     int64_t n_long, n_chunks;
     int split_state;          // 0 = not analysed, 1 = enabled, -1 = not worth it
     bool split_hot;           // short_part's columns are hot-coded

@@ -68,6 +68,8 @@ struct PullArgs {
     const int64_t *chunk_start;
     const int32_t *chunk_len;
     int64_t n_chunks, n_long;
+    int64_t n_long_epi;  // long rows whose write rule the seams launch applies (extra workgroups behind the seam ones)
+    const int32_t *long_prefix;  // per 64-row group: long rows before it (slot of a long row = prefix + rank in its word)
     void *tl_val;           // per long row: product accumulator (identity-initialised)
     unsigned char *tl_has;  // per long row: any product present
     long long *dbg_times;  // GRB_DEBUG_FLAGS & 8: 10 phase timestamps per tile (thread 0)
@@ -306,6 +308,11 @@ __global__ __launch_bounds__(PULL_BLOCK) void k_mxv_pull(const PullArgs a)
             ek[i] = e;
             cc[i] = (base + i < nnz_t && ROW_ACTIVE(e - 1)) ? creg[i] : -1;
         }
+        if (a.dbg & (16384 | 32768)) {  // diagnostic: fold every gather into the first 2^19 / 2^15 entries of the image
+            const int gmask = (a.dbg & 16384) ? 0x7ffff : 0x7fff;
+#pragma unroll
+            for (int i = 0; i < IPT; i++) cc[i] = cc[i] >= 0 ? (cc[i] & gmask) : -1;
+        }
         // ---- gathers: presence words, then values -- IPT independent random accesses in flight per lane --------------
         bool xp[IPT];
         T xv[IPT];
@@ -417,7 +424,7 @@ constexpr int PULL_CHUNK = 2048;
 constexpr int LONG_BLOCK = 1024;        // 16 wavefronts; one persistent workgroup per CU
 constexpr int LONG_LDS_WORDS = 32768;   // 128 KiB: the head of the x image ([hot | u]: hottest columns first)
 
-template <typename T, int MONOID_CT, int MULT_CT>
+template <typename T, int MONOID_CT, int MULT_CT, int LDS_WORDS>
 __global__ __launch_bounds__(LONG_BLOCK) void k_mxv_long(const PullArgs a)
 {
     using W = typename Widen<T>::type;
@@ -425,7 +432,7 @@ __global__ __launch_bounds__(LONG_BLOCK) void k_mxv_long(const PullArgs a)
     // Every gather that misses L1 moves a 128-byte line from L2 for 4 useful bytes; the workgroup therefore keeps
     // the head of the x image in LDS for its whole life (hot-coded columns: the most referenced come first --
     // 32 Ki fp32 entries receive ~45 % of the references of an R-MAT graph; BOOL values are bit-packed: 1 Mi entries).
-    __shared__ uint32_t s_x[LONG_LDS_WORDS];
+    __shared__ uint32_t s_x[LDS_WORDS];
     const int monoid = MONOID_CT >= 0 ? MONOID_CT : a.monoid;
     const int mult = MULT_CT >= 0 ? MULT_CT : a.mult;
     const int lane = threadIdx.x & 63;
@@ -438,8 +445,8 @@ __global__ __launch_bounds__(LONG_BLOCK) void k_mxv_long(const PullArgs a)
     const __amdgpu_buffer_rsrc_t xvbits_rs = make_rsrc(a.u_valbits, a.u_valbits ? ((a.x_len + 63) >> 6) * 8 : 0);
     constexpr bool IS_BOOL = std::is_same<T, bool>::value;
     // entries of the image resident in LDS
-    constexpr int64_t LDS_CAP = IS_BOOL ? (int64_t)LONG_LDS_WORDS * 32 : (int64_t)LONG_LDS_WORDS * 4 / (int64_t)(sizeof(T) < 4 ? 4 : sizeof(T));
-    const int lds_n = need_uval ? (int)(a.x_len < LDS_CAP ? a.x_len : LDS_CAP) : 0;
+    constexpr int64_t LDS_CAP = IS_BOOL ? (int64_t)LDS_WORDS * 32 : (int64_t)LDS_WORDS * 4 / (int64_t)(sizeof(T) < 4 ? 4 : sizeof(T));
+    const int lds_n = (need_uval && !(a.dbg & 4096)) ? (int)(a.x_len < LDS_CAP ? a.x_len : LDS_CAP) : 0;  // (debug flag 4096: no LDS residency)
     if (need_uval) {
         if constexpr (IS_BOOL) {
             const int words = (lds_n + 31) >> 5;
@@ -456,33 +463,85 @@ __global__ __launch_bounds__(LONG_BLOCK) void k_mxv_long(const PullArgs a)
 
     const int64_t wave0 = (int64_t)blockIdx.x * (LONG_BLOCK / 64) + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * (LONG_BLOCK / 64);
-    for (int64_t chunk = wave0; chunk < a.n_chunks; chunk += nwaves) {  // persistent: wavefronts stride the chunk list
-        const int slot = a.chunk_slot[chunk];
-        const int64_t row = a.long_rows[slot];
-        if (a.has_mask) {
-            bool act = (((const uint32_t *)a.m_bits)[row >> 5] >> (row & 31)) & 1u;
-            if (a.m_comp) act = !act;
-            if (!act) continue;  // wave-uniform: nothing of this row is read
+    constexpr int STEP = 64 * EPL;
+    // The wavefront owns chunks wave0, wave0 + nwaves, ...  Their descriptors (slot -> row -> mask bit -> start, len: a
+    // chain of dependent loads) are fetched once, 64 chunks at a time with one chunk per lane, and broadcast from the
+    // lanes as needed; masked-out chunks drop out of the ballot and nothing of their rows is read.
+    for (int64_t first = wave0; first < a.n_chunks; first += 64 * nwaves) {
+        const int64_t my_chunk = first + (int64_t)lane * nwaves;
+        int m_len = 0, m_slot = 0, m_start_lo = 0, m_start_hi = 0;
+        if (my_chunk < a.n_chunks) {
+            m_slot = a.chunk_slot[my_chunk];
+            bool act = true;
+            if (a.has_mask) {
+                const int64_t row = a.long_rows[m_slot];
+                act = (((const uint32_t *)a.m_bits)[row >> 5] >> (row & 31)) & 1u;
+                if (a.m_comp) act = !act;
+            }
+            if (act) {
+                const int64_t st = a.chunk_start[my_chunk];
+                m_start_lo = (int)(uint32_t)st;
+                m_start_hi = (int)(st >> 32);
+                m_len = a.chunk_len[my_chunk];
+            }
         }
-        const int64_t start = a.chunk_start[chunk];
-        const int len = a.chunk_len[chunk];
-        const __amdgpu_buffer_rsrc_t crs = make_rsrc(a.col + start, (int64_t)len * 4);
-        const __amdgpu_buffer_rsrc_t vrs = make_rsrc(aval + (a.a_iso ? 0 : start), stage_vals ? (int64_t)len * (int64_t)sizeof(T) : 0);
+        unsigned long long todo = __ballot(m_len > 0);
+        if (!todo) continue;
+        // software pipeline over the steps (64 * EPL entries) of the active chunks: the entries of step s+1 are in
+        // flight while the gathers of step s are
+        int cur = __ffsll(todo) - 1;
+        todo &= todo - 1;
+        int base = 0;
+        int c_len = __builtin_amdgcn_readfirstlane(__shfl(m_len, cur));
+        int c_slot = __builtin_amdgcn_readfirstlane(__shfl(m_slot, cur));
+        int64_t c_start = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(__shfl(m_start_hi, cur)) << 32) |
+                                    (uint32_t)__builtin_amdgcn_readfirstlane(__shfl(m_start_lo, cur)));
+        int cc_n[EPL];
+        T av_n[EPL];
+        {
+            const __amdgpu_buffer_rsrc_t crs = make_rsrc(a.col + c_start, (int64_t)c_len * 4);
+            const __amdgpu_buffer_rsrc_t vrs = make_rsrc(aval + (a.a_iso ? 0 : c_start), stage_vals ? (int64_t)c_len * (int64_t)sizeof(T) : 0);
+#pragma unroll
+            for (int i = 0; i < EPL; i++) {
+                const int e = i * 64 + lane;  // coalesced 4-byte loads; entries past the end of the chunk read 0 and are discarded
+                const int c = buf_load<int>(crs, (unsigned)e * 4u);
+                cc_n[i] = (e < c_len) ? c : -1;
+                av_n[i] = stage_vals ? buf_load<T>(vrs, (unsigned)e * (unsigned)sizeof(T)) : iso_v;
+            }
+        }
         T acc = (T)0;
         bool has = false;
-        for (int base = 0; base < len; base += 64 * EPL) {  // wave-uniform trip count; lane takes entries base + lane + 64 i
+        while (true) {
             int cc[EPL];
             T av[EPL];
 #pragma unroll
-            for (int i = 0; i < EPL; i++) {
-                // coalesced 4-byte loads; entries past the end of the chunk are out of range (read 0) and discarded
-                const int e = base + i * 64 + lane;
-                const int c = buf_load<int>(crs, (unsigned)e * 4u);
-                cc[i] = (e < len) ? c : -1;
-                av[i] = stage_vals ? buf_load<T>(vrs, (unsigned)e * (unsigned)sizeof(T)) : iso_v;
+            for (int i = 0; i < EPL; i++) { cc[i] = cc_n[i]; av[i] = av_n[i]; }
+            if (a.dbg & (16384 | 32768)) {  // diagnostic: fold every gather into the first 2^19 / 2^15 entries of the image
+                const int gmask = (a.dbg & 16384) ? 0x7ffff : 0x7fff;
+#pragma unroll
+                for (int i = 0; i < EPL; i++) cc[i] = cc[i] >= 0 ? (cc[i] & gmask) : -1;
             }
+            // where the next step lies
+            int n_cur = cur, n_base = base + STEP, n_len = c_len, n_slot = c_slot;
+            int64_t n_start = c_start;
+            bool more = true;
+            if (n_base >= c_len) {
+                n_base = 0;
+                if (todo) {
+                    n_cur = __ffsll(todo) - 1;
+                    todo &= todo - 1;
+                    n_len = __builtin_amdgcn_readfirstlane(__shfl(m_len, n_cur));
+                    n_slot = __builtin_amdgcn_readfirstlane(__shfl(m_slot, n_cur));
+                    n_start = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(__shfl(m_start_hi, n_cur)) << 32) |
+                                        (uint32_t)__builtin_amdgcn_readfirstlane(__shfl(m_start_lo, n_cur)));
+                } else {
+                    more = false;
+                    n_len = 0;
+                }
+            }
+            // gathers of this step
             bool xp[EPL];
-            T xv[EPL];
+            T xg[EPL];
             if (a.u_full) {
 #pragma unroll
                 for (int i = 0; i < EPL; i++) xp[i] = cc[i] >= 0;
@@ -493,25 +552,38 @@ __global__ __launch_bounds__(LONG_BLOCK) void k_mxv_long(const PullArgs a)
 #pragma unroll
                 for (int i = 0; i < EPL; i++) xp[i] = (bw[i] >> (cc[i] & 31)) & 1u;
             }
-            if (need_uval) {
+            uint32_t vw[EPL];
+            if (need_uval && !(a.dbg & 8192)) {
                 // resident entries come from LDS; the others from the image in HBM (an out-of-range offset reads nothing)
                 if constexpr (IS_BOOL) {
-                    uint32_t vw[EPL];
 #pragma unroll
                     for (int i = 0; i < EPL; i++) vw[i] = buf_load<uint32_t>(xvbits_rs, (xp[i] && cc[i] >= lds_n) ? (unsigned)(cc[i] >> 5) * 4u : 0xfffffff8u);
-#pragma unroll
-                    for (int i = 0; i < EPL; i++) {
-                        const bool in_lds = xp[i] && cc[i] < lds_n;
-                        const uint32_t wv = in_lds ? s_x[cc[i] >> 5] : vw[i];
-                        xv[i] = (wv >> (cc[i] & 31)) & 1u;
-                    }
                 } else {
-                    T xg[EPL];
 #pragma unroll
                     for (int i = 0; i < EPL; i++) xg[i] = buf_load<T>(xval_rs, (xp[i] && cc[i] >= lds_n) ? (unsigned)cc[i] * (unsigned)sizeof(T) : 0xfffffff8u);
+                }
+            }
+            // entries of the next step (issued behind the gathers, consumed one iteration later)
+            {
+                const __amdgpu_buffer_rsrc_t crs = make_rsrc(a.col + n_start, (int64_t)n_len * 4);
+                const __amdgpu_buffer_rsrc_t vrs = make_rsrc(aval + (a.a_iso ? 0 : n_start), stage_vals ? (int64_t)n_len * (int64_t)sizeof(T) : 0);
 #pragma unroll
-                    for (int i = 0; i < EPL; i++) {
-                        const bool in_lds = xp[i] && cc[i] < lds_n;
+                for (int i = 0; i < EPL; i++) {
+                    const int e = n_base + i * 64 + lane;
+                    const int c = buf_load<int>(crs, (unsigned)e * 4u);
+                    cc_n[i] = (e < n_len) ? c : -1;
+                    av_n[i] = stage_vals ? buf_load<T>(vrs, (unsigned)e * (unsigned)sizeof(T)) : iso_v;
+                }
+            }
+            T xv[EPL];
+            if (need_uval && !(a.dbg & 8192)) {
+#pragma unroll
+                for (int i = 0; i < EPL; i++) {
+                    const bool in_lds = xp[i] && cc[i] < lds_n;
+                    if constexpr (IS_BOOL) {
+                        const uint32_t wv = in_lds ? s_x[cc[i] >> 5] : vw[i];
+                        xv[i] = (wv >> (cc[i] & 31)) & 1u;
+                    } else {
                         const int li = in_lds ? cc[i] : 0;
                         T xl;
                         if constexpr (sizeof(T) == 8) xl = ((const T *)s_x)[li];
@@ -522,7 +594,7 @@ __global__ __launch_bounds__(LONG_BLOCK) void k_mxv_long(const PullArgs a)
                 }
             } else {
 #pragma unroll
-                for (int i = 0; i < EPL; i++) xv[i] = (T)0;
+                for (int i = 0; i < EPL; i++) xv[i] = (T)(need_uval ? 1 : 0);
             }
 #pragma unroll
             for (int i = 0; i < EPL; i++) {
@@ -530,33 +602,37 @@ __global__ __launch_bounds__(LONG_BLOCK) void k_mxv_long(const PullArgs a)
                 acc = xp[i] ? (has ? apply_binop<T>(monoid, acc, prod) : prod) : acc;
                 has = has || xp[i];
             }
-        }
-        // wavefront reduction (value + presence)
-        int hasi = has ? 1 : 0;
-        for (int off = 32; off > 0; off >>= 1) {
-            const T o = __shfl_down(acc, off);
-            const int oh = __shfl_down(hasi, off);
-            if (oh) {
-                acc = hasi ? apply_binop<T>(monoid, acc, o) : o;
-                hasi = 1;
+            if (n_cur != cur || !more) {
+                // the chunk is complete: wavefront reduction (value + presence), one atomic into the row's accumulator
+                int hasi = has ? 1 : 0;
+                for (int off = 32; off > 0; off >>= 1) {
+                    const T o = __shfl_down(acc, off);
+                    const int oh = __shfl_down(hasi, off);
+                    if (oh) {
+                        acc = hasi ? apply_binop<T>(monoid, acc, o) : o;
+                        hasi = 1;
+                    }
+                }
+                if (lane == 0 && hasi) {
+                    W *tl = (W *)a.tl_val;
+                    if (monoid == OP_ANY) tl[c_slot] = (W)acc;
+                    else atomic_combine<W>(&tl[c_slot], (W)acc, monoid);
+                    a.tl_has[c_slot] = 1;
+                }
+                acc = (T)0;
+                has = false;
             }
-        }
-        if (lane == 0 && hasi) {
-            W *tl = (W *)a.tl_val;
-            if (monoid == OP_ANY) tl[slot] = (W)acc;
-            else atomic_combine<W>(&tl[slot], (W)acc, monoid);
-            a.tl_has[slot] = 1;
+            if (!more) break;
+            cur = n_cur; base = n_base; c_len = n_len; c_slot = n_slot; c_start = n_start;
         }
     }
 }
 
-// the write rule for the long rows, one thread per row
+// the write rule for one long row (run by the extra workgroups of the seams launch, after both kernels)
 template <typename T>
-__global__ void k_mxv_long_epilogue(const PullArgs a)
+__device__ __forceinline__ void long_row_write(const PullArgs &a, int64_t slot)
 {
     using W = typename Widen<T>::type;
-    const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot >= a.n_long) return;
     const int64_t row = a.long_rows[slot];
     bool mact = true;
     if (a.has_mask) {
@@ -569,6 +645,218 @@ __global__ void k_mxv_long_epilogue(const PullArgs a)
     const unsigned long long bit = 1ull << (row & 63);
     if (new_has) atomicOr((unsigned long long *)&a.w_new_bits[row >> 6], bit);
     else atomicAnd((unsigned long long *)&a.w_new_bits[row >> 6], ~bit);
+}
+
+template <typename W>
+__global__ void k_long_init(W *tl_val, unsigned char *tl_has, int64_t n, W identity)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        tl_val[i] = identity;
+        tl_has[i] = 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Short rows of a split matrix (every row below split_min_len entries; the long rows are empty here): one WAVEFRONT per
+// 64 consecutive rows = one word of the presence bitmap.  Nothing is shared between wavefronts: no workgroup barrier, no
+// tile table, no seams.  The group's entries are contiguous in the CSR arrays and are consumed in windows of 64 x 8
+// entries -- each lane takes 8 consecutive entries straight into registers (16-byte loads), the row of each entry
+// comes from row-start marks in LDS plus a wavefront max-scan, products are folded per lane and every finished
+// segment goes to its row's LDS accumulator with one LDS atomic (as in k_mxv_pull).  The epilogue applies the write
+// rule to the 64 rows with coalesced loads and stores and writes the whole presence word; long rows of the group take
+// their product from k_mxv_long's per-row accumulators.
+// ---------------------------------------------------------------------------------------------------
+constexpr int ROWS_BLOCK = 256;
+constexpr int ROWS_EPL = 8;
+
+__device__ __forceinline__ void wave_sync()
+{
+    // LDS operations of one wavefront execute in order; this only stops the compiler from moving them across
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <typename T, int MONOID_CT, int MULT_CT>
+__global__ __launch_bounds__(ROWS_BLOCK) void k_mxv_rows(const PullArgs a)
+{
+    using W = typename Widen<T>::type;
+    constexpr int EPL = ROWS_EPL, WIN = 64 * EPL, NW = ROWS_BLOCK / 64;
+    __shared__ __attribute__((aligned(16))) unsigned char s_mark[NW][WIN];
+    __shared__ W s_acc[NW][128];  // 64 rows + one scratch slot per lane ("nothing to emit" of the branch-free fold)
+    __shared__ unsigned char s_has[NW][128];
+    const int monoid = MONOID_CT >= 0 ? MONOID_CT : a.monoid;
+    const int mult = MULT_CT >= 0 ? MULT_CT : a.mult;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t g = (int64_t)blockIdx.x * NW + wave;
+    if ((g << 6) >= a.m) return;  // wave-uniform; wavefronts never wait for each other
+    const T *aval = (const T *)a.aval;
+    const bool need_aval = a.need_aval != 0, need_uval = a.need_uval != 0;
+    const bool stage_vals = need_aval && !a.a_iso;
+    const bool need_old = (a.accum >= 0) || a.fresh;
+    const int64_t row = (g << 6) + lane;
+    const bool in = row < a.m;
+
+    // ---- everything the group needs from HBM is requested up front: row bounds, mask / presence / long-row words, old w
+    const int64_t p0 = a.rowptr[in ? row : a.m], p1 = a.rowptr[in ? row + 1 : a.m];
+    uint64_t actw = a.has_mask ? (a.m_comp ? ~a.m_bits[g] : a.m_bits[g]) : ~0ull;
+    const uint64_t longw = a.long_bits ? a.long_bits[g] : 0ull;
+    const uint64_t oldw = a.w_old_bits[g];
+    const bool old_has = in && ((oldw >> lane) & 1ull);
+    const T old_val = (need_old && old_has) ? ((const T *)a.w_old_val)[row] : (T)0;
+    const bool is_long = (longw >> lane) & 1ull;
+    int long_slot = 0;
+    if (longw) long_slot = a.long_prefix[g] + __popcll(longw & ((1ull << lane) - 1ull));
+    bool t_has = false;
+    W t_acc = monoid_identity<T, W>(monoid);
+    if (is_long) {
+        t_has = a.tl_has[long_slot] != 0;
+        t_acc = ((const W *)a.tl_val)[long_slot];
+    }
+    const T iso_v = (a.a_iso && need_aval) ? aval[0] : (T)0;
+    const __amdgpu_buffer_rsrc_t xval_rs = make_rsrc(a.u_val, a.x_len * (int64_t)sizeof(T));
+    const __amdgpu_buffer_rsrc_t xbits_rs = make_rsrc(a.u_bits, a.u_full ? 0 : ((a.x_len + 63) >> 6) * 8);
+    const __amdgpu_buffer_rsrc_t xvbits_rs = make_rsrc(a.u_valbits, a.u_valbits ? ((a.x_len + 63) >> 6) * 8 : 0);
+
+    const int p0_lo = __shfl((int)(uint32_t)p0, 0), p0_hi = __shfl((int)(p0 >> 32), 0);
+    const int64_t gbase = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(p0_hi) << 32) |
+                                    (uint32_t)__builtin_amdgcn_readfirstlane(p0_lo));
+    const int rel = (int)(p0 - gbase), len = (int)(p1 - p0);
+    const int total = __builtin_amdgcn_readfirstlane(__shfl(rel + len, 63));  // entries of the group (< 64 * split_min_len)
+
+    s_acc[wave][lane] = monoid_identity<T, W>(monoid);
+    s_acc[wave][64 + lane] = monoid_identity<T, W>(monoid);
+    s_has[wave][lane] = 0;
+    s_has[wave][64 + lane] = 0;
+
+    const int64_t left = a.nnz - gbase;  // entries from the group's first to the end of the arrays
+    const __amdgpu_buffer_rsrc_t crs = make_rsrc(a.col + gbase, left * 4);
+    const __amdgpu_buffer_rsrc_t vrs = make_rsrc(aval + (a.a_iso ? 0 : gbase), stage_vals ? left * (int64_t)sizeof(T) : 0);
+    const bool any_active = (actw & ~longw) != 0;  // (a group without an active short row reads none of its entries)
+
+    for (int wbase = 0; wbase < total && any_active; wbase += WIN) {
+        const int e0 = wbase + lane * EPL;  // my EPL consecutive entries of the group
+        int creg[EPL];
+        T vreg[EPL];
+        const bool whole = left >= (int64_t)wbase + WIN + 4;  // 16-byte loads never straddle the end of the arrays
+#pragma unroll
+        for (int q = 0; q < EPL / 4; q++) {
+            const unsigned k = (unsigned)(e0 + q * 4);
+            if (whole) {
+                const auto c4 = __builtin_amdgcn_raw_buffer_load_b128(crs, k * 4u, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; i++) creg[q * 4 + i] = (int)c4[i];
+                if constexpr (sizeof(T) == 4) {
+                    const auto v4 = __builtin_amdgcn_raw_buffer_load_b128(vrs, k * 4u, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) vreg[q * 4 + i] = __builtin_bit_cast(T, (unsigned int)v4[i]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) vreg[q * 4 + i] = buf_load<T>(vrs, (k + i) * (unsigned)sizeof(T));
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    creg[q * 4 + i] = buf_load<int>(crs, (k + i) * 4u);
+                    vreg[q * 4 + i] = buf_load<T>(vrs, (k + i) * (unsigned)sizeof(T));
+                }
+            }
+        }
+        // ---- row of each entry: marks where rows start inside the window, max-scan across the wavefront -------------
+        *(uint64_t *)&s_mark[wave][lane * EPL] = 0ull;
+        wave_sync();
+        if (len > 0 && rel >= wbase && rel < wbase + WIN) s_mark[wave][rel - wbase] = (unsigned char)(lane + 1);
+        const unsigned long long before = __ballot(len > 0 && rel <= wbase);  // rows begun at or before the window start
+        const int carry_in = 64 - __clzll(before);                            // (1 + the last of them; never 0 inside a group)
+        wave_sync();
+        const uint64_t mk = *(const uint64_t *)&s_mark[wave][lane * EPL];
+        int h[EPL];
+#pragma unroll
+        for (int i = 0; i < EPL; i++) h[i] = (int)((mk >> (8 * i)) & 0xffu);
+        int lastk = 0;
+#pragma unroll
+        for (int i = 0; i < EPL; i++) lastk = h[i] ? h[i] : lastk;  // marks increase along the window: last = max
+        int incl = lastk;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off);
+            if (lane >= off) incl = incl > t ? incl : t;
+        }
+        int e = __shfl_up(incl, 1);
+        if (lane == 0) e = 0;
+        e = e > carry_in ? e : carry_in;
+        // ---- classify: column to gather, or -1 (past the group's end / masked-out row: the gather reads nothing) -----
+        int ek[EPL], cc[EPL];
+#pragma unroll
+        for (int i = 0; i < EPL; i++) {
+            e = h[i] ? h[i] : e;
+            ek[i] = e;
+            cc[i] = (e0 + i < total && ((actw >> (e - 1)) & 1ull)) ? creg[i] : -1;
+        }
+        if (a.dbg & (16384 | 32768)) {  // diagnostic: fold every gather into the first 2^19 / 2^15 entries of the image
+            const int gmask = (a.dbg & 16384) ? 0x7ffff : 0x7fff;
+#pragma unroll
+            for (int i = 0; i < EPL; i++) cc[i] = cc[i] >= 0 ? (cc[i] & gmask) : -1;
+        }
+        // ---- gathers: presence words, then values -- EPL independent random accesses in flight per lane --------------
+        bool xp[EPL];
+        T xv[EPL];
+        if (a.u_full || (a.dbg & 1)) {
+#pragma unroll
+            for (int i = 0; i < EPL; i++) xp[i] = cc[i] >= 0;
+        } else {
+            uint32_t bw[EPL];
+#pragma unroll
+            for (int i = 0; i < EPL; i++) bw[i] = buf_load<uint32_t>(xbits_rs, (unsigned)(cc[i] >> 5) * 4u);
+#pragma unroll
+            for (int i = 0; i < EPL; i++) xp[i] = (bw[i] >> (cc[i] & 31)) & 1u;
+        }
+        if (need_uval && !(a.dbg & 1)) {
+            if constexpr (std::is_same<T, bool>::value) {
+                uint32_t vw[EPL];
+#pragma unroll
+                for (int i = 0; i < EPL; i++) vw[i] = buf_load<uint32_t>(xvbits_rs, xp[i] ? (unsigned)(cc[i] >> 5) * 4u : 0xfffffff8u);
+#pragma unroll
+                for (int i = 0; i < EPL; i++) xv[i] = (vw[i] >> (cc[i] & 31)) & 1u;
+            } else {
+#pragma unroll
+                for (int i = 0; i < EPL; i++) xv[i] = buf_load<T>(xval_rs, xp[i] ? (unsigned)cc[i] * (unsigned)sizeof(T) : 0xfffffff8u);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < EPL; i++) xv[i] = (T)(cc[i] & 7);
+        }
+        // ---- segmented fold of my entries, straight-line: a segment ends where the next entry starts a row (or at the
+        //      end of my entries) and is emitted with ONE LDS atomic into its row's accumulator -------------------------
+        T acc = (T)0;
+        bool has = false;
+#pragma unroll
+        for (int i = 0; i < EPL; i++) {
+            const T av = need_aval ? (a.a_iso ? iso_v : vreg[i]) : (T)0;
+            const T prod = apply_binop<T>(mult, av, xv[i]);
+            const bool keep = has && (i > 0) && (h[i] == 0);
+            acc = xp[i] ? (keep ? apply_binop<T>(monoid, acc, prod) : prod) : (keep ? acc : (T)0);
+            has = xp[i] || keep;
+            const bool seg_end = (i == EPL - 1) ? true : (h[i + 1] != 0);
+            const int k = (seg_end && has) ? ek[i] - 1 : 64 + lane;
+            if (monoid == OP_ANY) s_acc[wave][k] = (W)acc;
+            else atomic_combine<W>(&s_acc[wave][k], (W)acc, monoid);
+            s_has[wave][k] = 1;
+        }
+    }
+    wave_sync();
+
+    // ---- write rule for my row; the wavefront owns the whole presence word ----------------------------------------------
+    if (a.dbg & 4) return;
+    if (!is_long) {
+        t_has = s_has[wave][lane] != 0;
+        t_acc = s_acc[wave][lane];
+    }
+    bool new_has = false;
+    if (in) new_has = write_rule_row<T>(a, row, (actw >> lane) & 1ull, old_has, old_val, t_has, from_acc<T, W>(t_acc));
+    const unsigned long long nb = __ballot(in && new_has);
+    if (lane == 0) a.w_new_bits[g] = nb;
 }
 
 // ---- building the split (once per matrix) ---------------------------------------------------------------------
@@ -593,10 +881,11 @@ __global__ void k_split_classify(const int64_t *ptr, int64_t m, int min_len, uin
 template <typename T>
 __global__ void k_split_fill(const int64_t *ptr, const int32_t *col, const T *val, int iso, int64_t m, int min_len,
                              const int64_t *sptr, const int64_t *lidx, const int64_t *cidx, int32_t *scol, T *sval,
-                             int32_t *long_rows, int32_t *chunk_slot, int64_t *chunk_start, int32_t *chunk_len)
+                             int32_t *long_rows, int32_t *chunk_slot, int64_t *chunk_start, int32_t *chunk_len, int32_t *long_prefix)
 {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= m) return;
+    if ((r & 63) == 0) long_prefix[r >> 6] = (int32_t)lidx[r];
     const int64_t b = ptr[r], len = ptr[r + 1] - b;
     if (len >= min_len) {
         const int64_t slot = lidx[r];
@@ -623,6 +912,12 @@ __global__ __launch_bounds__(PULL_BLOCK) void k_mxv_seams(const PullArgs a)
 {
     using W = typename Widen<T>::type;
     const int lane = threadIdx.x & 63;
+    const int64_t seam_blocks = (a.n_tiles + PULL_BLOCK / 64 - 1) / (PULL_BLOCK / 64);
+    if ((int64_t)blockIdx.x >= seam_blocks) {  // the workgroups behind the seam ones: one thread per long row
+        const int64_t slot = ((int64_t)blockIdx.x - seam_blocks) * PULL_BLOCK + threadIdx.x;
+        if (slot < a.n_long_epi) long_row_write<T>(a, slot);
+        return;
+    }
     const int64_t tile = (int64_t)blockIdx.x * (PULL_BLOCK / 64) + (threadIdx.x >> 6);
     if (tile >= a.n_tiles) return;  // wave-uniform
     const unsigned char flag = a.first_has[tile];
@@ -912,7 +1207,8 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
     if (A->split_state == 1) {  // built against the other column coding: rebuild
         matrix_free(A->short_part);
         A->short_part = nullptr;
-        dev_free(A->d_long_bits); dev_free(A->d_long_rows); dev_free(A->d_chunk_slot); dev_free(A->d_chunk_start); dev_free(A->d_chunk_len);
+        dev_free(A->d_long_bits); dev_free(A->d_long_rows); dev_free(A->d_chunk_slot); dev_free(A->d_chunk_start); dev_free(A->d_chunk_len); dev_free(A->d_long_prefix);
+        A->d_long_prefix = nullptr;
         A->d_long_bits = nullptr; A->d_long_rows = nullptr; A->d_chunk_slot = nullptr; A->d_chunk_start = nullptr; A->d_chunk_len = nullptr;
     }
     A->split_state = -1;
@@ -943,11 +1239,12 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
         A->d_chunk_slot = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)nc);
         A->d_chunk_start = (int64_t *)dev_alloc(sizeof(int64_t) * (size_t)nc);
         A->d_chunk_len = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)nc);
+        A->d_long_prefix = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)bits_words64((uint64_t)m));
         GRB_DISPATCH_TYPE(A->type->code, T, {
             hipLaunchKernelGGL((k_split_fill<T>), dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, ctx().stream,
                                (const int64_t *)A->d_ptr, col_src, (const T *)A->d_val, A->iso ? 1 : 0, m, min_len,
                                (const int64_t *)S->d_ptr, (const int64_t *)lflag.p, (const int64_t *)nchunk.p, S->d_col,
-                               (T *)S->d_val, A->d_long_rows, A->d_chunk_slot, A->d_chunk_start, A->d_chunk_len);
+                               (T *)S->d_val, A->d_long_rows, A->d_chunk_slot, A->d_chunk_start, A->d_chunk_len, A->d_long_prefix);
         })
         sync_stream();
     } catch (...) {
@@ -973,19 +1270,18 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
     if (use_split) {
         GB_Matrix_opaque *S = A->short_part;
         DevBuf<W> tl_val(a.n_long);
-        DevBuf<unsigned char> tl_has(a.n_long, true);
-        hipLaunchKernelGGL((k_fill_w<W>), dim3((unsigned)ceil_div(a.n_long, 256)), dim3(256), 0, ctx().stream, tl_val.p, a.n_long,
-                           monoid_identity<T, W>(a.monoid));
+        DevBuf<unsigned char> tl_has(a.n_long);
+        hipLaunchKernelGGL((k_long_init<W>), dim3((unsigned)ceil_div(a.n_long, 256)), dim3(256), 0, ctx().stream, tl_val.p, tl_has.p,
+                           a.n_long, monoid_identity<T, W>(a.monoid));
         a.tl_val = tl_val.p;
         a.tl_has = tl_has.p;
         a.dbg = ctx().debug_flags;
         {
             const int64_t want = ceil_div(a.n_chunks, LONG_BLOCK / 64);
             const int64_t G = std::min<int64_t>(want, (int64_t)ctx().num_cus);  // persistent: one 1024-thread workgroup per CU
-            hipLaunchKernelGGL((k_mxv_long<T, MON, MUL>), dim3((unsigned)G), dim3(LONG_BLOCK), 0, ctx().stream, a);
+            hipLaunchKernelGGL((k_mxv_long<T, MON, MUL, LONG_LDS_WORDS>), dim3((unsigned)G), dim3(LONG_BLOCK), 0, ctx().stream, a);
         }
-        hipLaunchKernelGGL((k_mxv_long_epilogue<T>), dim3((unsigned)ceil_div(a.n_long, 256)), dim3(256), 0, ctx().stream, a);
-        ctx().stats.kernel_launches += 3;
+        ctx().stats.kernel_launches += 2;
         PullArgs b = a;
         b.rowptr = matrix_rowptr(S);
         b.col = S->d_col;
@@ -993,6 +1289,17 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
         b.nnz = S->nvals;
         b.long_bits = A->d_long_bits;
         b.n_chunks = 0;
+        b.n_long_epi = a.n_long;
+        if (ctx().short_kernel == 1 && S->nrows == A->nrows) {
+            // short rows: one wavefront per 64 consecutive rows, which also applies the write rule of the long rows
+            b.long_prefix = A->d_long_prefix;
+            hipLaunchKernelGGL((k_mxv_rows<T, MON, MUL>), dim3((unsigned)ceil_div(ceil_div(b.m, 64), ROWS_BLOCK / 64)), dim3(ROWS_BLOCK), 0,
+                               ctx().stream, b);
+            GRB_HIP(hipGetLastError());
+            ctx().stats.kernel_launches += 1;
+            ctx().stats.tiles = ceil_div(b.m, 64);
+            return;
+        }
         launch_pull_ipt<T, MON, MUL, IPT>(S, b);  // S has no split of its own: takes the plain path below
         return;
     }
@@ -1012,7 +1319,8 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
     a.dbg_times = (ctx().debug_flags & 8) ? dbg_times.p : nullptr;
     hipLaunchKernelGGL((k_mxv_pull<T, MON, MUL, IPT>), dim3((unsigned)a.n_tiles), dim3(PULL_BLOCK), 0, ctx().stream, a);
     if (a.dbg_times) report_phase_times(dbg_times.p, a.n_tiles);
-    hipLaunchKernelGGL((k_mxv_seams<T, TILE>), dim3((unsigned)ceil_div(a.n_tiles, PULL_BLOCK / 64)), dim3(PULL_BLOCK), 0,
+    hipLaunchKernelGGL((k_mxv_seams<T, TILE>),
+                       dim3((unsigned)(ceil_div(a.n_tiles, PULL_BLOCK / 64) + ceil_div(a.n_long_epi, PULL_BLOCK))), dim3(PULL_BLOCK), 0,
                        ctx().stream, a);
     GRB_HIP(hipGetLastError());
     ctx().stats.kernel_launches += 2;

@@ -468,6 +468,7 @@ GB_Matrix_opaque *matrix_new(GrB_Type type, uint64_t nrows, uint64_t ncols)
     A->d_chunk_slot = nullptr;
     A->d_chunk_start = nullptr;
     A->d_chunk_len = nullptr;
+    A->d_long_prefix = nullptr;
     A->n_long = A->n_chunks = 0;
     A->split_state = 0;
     A->split_hot = false;
@@ -497,11 +498,13 @@ void matrix_invalidate_caches(GB_Matrix_opaque *A)
     dev_free(A->d_chunk_slot);
     dev_free(A->d_chunk_start);
     dev_free(A->d_chunk_len);
+    dev_free(A->d_long_prefix);
     A->d_long_bits = nullptr;
     A->d_long_rows = nullptr;
     A->d_chunk_slot = nullptr;
     A->d_chunk_start = nullptr;
     A->d_chunk_len = nullptr;
+    A->d_long_prefix = nullptr;
     A->n_long = A->n_chunks = 0;
     A->split_state = 0;
 }

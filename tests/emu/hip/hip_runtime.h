@@ -108,6 +108,9 @@ inline int __any(int pred) { return __ballot(pred) != 0; }
 
 inline long long clock64() { return 0; }
 inline void __builtin_amdgcn_s_waitcnt(int) {}
+inline void __builtin_amdgcn_fence(int, const char *) {}
+inline void __builtin_amdgcn_wave_barrier() { emu::wave_exchange(0, -1, false, nullptr); }  // fibers of the wavefront rendezvous
+inline int __builtin_amdgcn_readfirstlane(int v) { return v; }  // callers pass wave-uniform values
 // raw buffer loads: out-of-range offsets return 0 (per dword), like the hardware range check with stride 0
 struct __amdgpu_buffer_rsrc_t { const char *base; unsigned n; };
 inline __amdgpu_buffer_rsrc_t __builtin_amdgcn_make_buffer_rsrc(void *p, short, int n, int) { return {(const char *)p, (unsigned)n}; }
