@@ -3,6 +3,9 @@
 // graphblas/__init__.py:170-173 (there: SuiteSparse GrB_init on the host; here: a gfx950 device is
 // mandatory -- there is no CPU fallback).
 #include <cstdlib>
+#include <mutex>
+#include <unordered_map>
+#include <vector>
 
 #include "grb_internal.hpp"
 
@@ -19,14 +22,77 @@ void require_init()
     if (!ctx().initialized) fail(GrB_PANIC, "GrB_init has not been called (or no HIP device is available)");
 }
 
+// Device memory: hipMallocAsync / hipFreeAsync on the library's stream, behind a size-class cache.  Every kernel of the
+// library runs in order on that one stream, so a block freed by one call can be handed to the next allocation of its
+// size class without touching the HIP allocator (whose stream-ordered calls were measured to leave the GPU idle for
+// tens of microseconds between two GrB calls).  The cache is emptied when an allocation fails, when the stream changes
+// and at GrB_finalize.
+namespace {
+struct BlockCache {
+    std::mutex mu;
+    std::unordered_map<size_t, std::vector<void *>> free_blocks;  // size class -> blocks
+    std::unordered_map<void *, size_t> size_of;                   // live + cached blocks -> size class
+    size_t cached_bytes = 0;
+};
+BlockCache &cache()
+{
+    static BlockCache c;
+    return c;
+}
+// classes: multiples of 512 B up to 64 KiB, then eight steps per power of two (at most 12.5 % over-allocation)
+size_t size_class(size_t bytes)
+{
+    if (bytes <= 65536) return (bytes + 511) & ~(size_t)511;
+    int top = 63 - __builtin_clzll((unsigned long long)bytes);
+    const size_t step = (size_t)1 << (top - 3);
+    return (bytes + step - 1) & ~(step - 1);
+}
+}  // namespace
+
+void dev_cache_release()
+{
+    BlockCache &c = cache();
+    std::lock_guard<std::mutex> lock(c.mu);
+    for (auto &kv : c.free_blocks)
+        for (void *p : kv.second) {
+            c.size_of.erase(p);
+            (void)hipFreeAsync(p, ctx().stream);
+        }
+    c.free_blocks.clear();
+    c.cached_bytes = 0;
+}
+
 void *dev_alloc(size_t bytes)
 {
-    void *p = nullptr;
     if (bytes == 0) bytes = 16;
-    hipError_t e = hipMallocAsync(&p, bytes, ctx().stream);
+    BlockCache &c = cache();
+    const size_t cls = size_class(bytes);
+    if (ctx().alloc_cache) {
+        std::lock_guard<std::mutex> lock(c.mu);
+        auto it = c.free_blocks.find(cls);
+        if (it != c.free_blocks.end() && !it->second.empty()) {
+            void *p = it->second.back();
+            it->second.pop_back();
+            c.cached_bytes -= cls;
+            return p;
+        }
+    }
+    void *p = nullptr;
+    hipError_t e = hipMallocAsync(&p, cls, ctx().stream);
+    if ((e != hipSuccess || !p) && c.cached_bytes) {
+        (void)hipGetLastError();
+        dev_cache_release();
+        (void)hipStreamSynchronize(ctx().stream);
+        p = nullptr;
+        e = hipMallocAsync(&p, cls, ctx().stream);
+    }
     if (e != hipSuccess || !p) {
         (void)hipGetLastError();
         fail(GrB_OUT_OF_MEMORY, "device allocation of " + std::to_string(bytes) + " bytes failed: " + hipGetErrorString(e));
+    }
+    if (ctx().alloc_cache) {
+        std::lock_guard<std::mutex> lock(c.mu);
+        c.size_of[p] = cls;
     }
     return p;
 }
@@ -40,7 +106,21 @@ void *dev_alloc_zero(size_t bytes)
 
 void dev_free(void *p)
 {
-    if (p) (void)hipFreeAsync(p, ctx().stream);
+    if (!p) return;
+    BlockCache &c = cache();
+    {
+        std::lock_guard<std::mutex> lock(c.mu);
+        auto it = c.size_of.find(p);
+        if (it != c.size_of.end()) {
+            if (ctx().alloc_cache && ctx().initialized) {
+                c.free_blocks[it->second].push_back(p);
+                c.cached_bytes += it->second;
+                return;
+            }
+            c.size_of.erase(it);
+        }
+    }
+    (void)hipFreeAsync(p, ctx().stream);
 }
 
 void h2d(void *dst, const void *src, size_t bytes)
@@ -97,6 +177,7 @@ extern "C" GrB_Info GrB_init(GrB_Mode mode)
     if (const char *e = getenv("GRB_HOT_MIN_COLS")) c.hot_min_cols = atoll(e);
     if (const char *e = getenv("GRB_HOT_K")) c.hot_k = atoll(e);
     if (const char *e = getenv("GRB_PUSH_MODE")) c.push_mode = atoi(e);
+    if (const char *e = getenv("GRB_ALLOC_CACHE")) c.alloc_cache = atoi(e);
     c.initialized = true;
     return GrB_SUCCESS;
 }
@@ -105,6 +186,7 @@ extern "C" GrB_Info GrB_finalize(void)
 {
     Context &c = ctx();
     if (!c.initialized) return GrB_SUCCESS;
+    dev_cache_release();
     (void)hipStreamSynchronize(c.stream);
     if (c.ev0) (void)hipEventDestroy(c.ev0);
     if (c.ev1) (void)hipEventDestroy(c.ev1);
@@ -125,6 +207,7 @@ extern "C" GrB_Info GrX_set_stream(void *hip_stream)
 {
     GRB_TRY
     require_init();
+    dev_cache_release();  // cached blocks were last used on the old stream
     sync_stream();
     ctx().stream = static_cast<hipStream_t>(hip_stream);
     GRB_CATCH(nullptr)
@@ -177,6 +260,11 @@ extern "C" GrB_Info GrX_option_set(const char *name, int64_t value)
     else if (n == "split_min_nnz") c.split_min_nnz = value;
     else if (n == "split_min_len") c.split_min_len = (int)value;
     else if (n == "short_kernel") c.short_kernel = (int)value;
+    else if (n == "vec_pad_min_bytes") c.vec_pad_min_bytes = value;
+    else if (n == "alloc_cache") {
+        if (!value) dev_cache_release();
+        c.alloc_cache = (int)value;
+    }
     else return GrB_INVALID_VALUE;
     return GrB_SUCCESS;
 }

@@ -59,6 +59,8 @@ struct Context {
     int num_cus = 256;
     hipStream_t stream = nullptr;  // null stream: ordered with torch's default stream
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int64_t vec_pad_min_bytes = 1 << 20;  // vectors with at least this many bytes of values are allocated with the front pad
+    int alloc_cache = 1;    // 1: freed device blocks are kept per size class and reused without calling the HIP allocator
     int short_kernel = 1;   // short rows of a split matrix: 1 = row-group kernel (k_mxv_rows), 0 = merge-path kernel
     GrX_Stats stats{};
     int debug_flags = 0;    // GRB_DEBUG: kernel ablation switches (benchmark diagnostics only)
@@ -76,6 +78,7 @@ void require_init();
 void *dev_alloc(size_t bytes);
 void *dev_alloc_zero(size_t bytes);
 void dev_free(void *p);
+void dev_cache_release();  // return every cached block to the HIP allocator
 void h2d(void *dst, const void *src, size_t bytes);
 void d2h(void *dst, const void *src, size_t bytes);  // synchronous w.r.t. the host on return
 void d2d(void *dst, const void *src, size_t bytes);
@@ -131,12 +134,17 @@ struct GB_Descriptor_opaque {
     bool builtin;
 };
 
+constexpr size_t VEC_VAL_PAD = (size_t)2 << 20;    // the default hot-column table is 2 MiB of values ...
+constexpr size_t VEC_BITS_PAD = (size_t)256 << 10;  // ... and at most 2 Mi presence bits (1-byte types)
+
 struct GB_Vector_opaque {
     uint64_t magic;
     GrB_Type type;
     uint64_t n;
     void *d_val;       // n values (allocated lazily), nullptr while the vector has never been written
     uint64_t *d_bits;  // presence, ceil(n/64) words, bits >= n are always 0
+    bool padded;       // the allocations start VEC_VAL_PAD / VEC_BITS_PAD bytes before d_val / d_bits: the pull SpMV
+                       // writes its hot-column table there, so that [table | values] is one image without a copy
     int64_t nvals;     // -1 = unknown (counted on demand)
     std::string err;
 };
@@ -201,6 +209,8 @@ inline std::string *errp(GB_Matrix_opaque *A) { return (A && A->magic == MAGIC_M
 // ---- object services implemented in grb_object.hip --------------------------------------------------
 void vector_ensure_storage(GB_Vector_opaque *v);               // allocate zeroed values+bits if absent
 void vector_release_storage(GB_Vector_opaque *v);              // free buffers, nvals = 0
+void vector_alloc_pair(const GB_Vector_opaque *v, bool padded, bool zero_val, void **val, uint64_t **bits);  // presence zeroed
+void vector_free_pair(bool padded, void *val, uint64_t *bits);
 int64_t vector_nvals(GB_Vector_opaque *v);                     // counts if unknown
 int64_t vector_index_list(GB_Vector_opaque *v, uint64_t **d_idx);  // ascending indices of the entries (fresh device array)
 GB_Vector_opaque *vector_new(GrB_Type type, uint64_t n);

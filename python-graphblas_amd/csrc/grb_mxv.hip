@@ -668,7 +668,7 @@ __global__ void k_long_init(W *tl_val, unsigned char *tl_has, int64_t n, W ident
 // their product from k_mxv_long's per-row accumulators.
 // ---------------------------------------------------------------------------------------------------
 constexpr int ROWS_BLOCK = 256;
-constexpr int ROWS_EPL = 8;
+constexpr int ROWS_EPL = 4;
 
 __device__ __forceinline__ void wave_sync()
 {
@@ -689,7 +689,7 @@ __global__ __launch_bounds__(ROWS_BLOCK) void k_mxv_rows(const PullArgs a)
     const int monoid = MONOID_CT >= 0 ? MONOID_CT : a.monoid;
     const int mult = MULT_CT >= 0 ? MULT_CT : a.mult;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t g = (int64_t)blockIdx.x * NW + wave;
+    const int64_t g = (int64_t)blockIdx.x * NW + __builtin_amdgcn_readfirstlane(wave);
     if ((g << 6) >= a.m) return;  // wave-uniform; wavefronts never wait for each other
     const T *aval = (const T *)a.aval;
     const bool need_aval = a.need_aval != 0, need_uval = a.need_uval != 0;
@@ -704,7 +704,7 @@ __global__ __launch_bounds__(ROWS_BLOCK) void k_mxv_rows(const PullArgs a)
     const uint64_t longw = a.long_bits ? a.long_bits[g] : 0ull;
     const uint64_t oldw = a.w_old_bits[g];
     const bool old_has = in && ((oldw >> lane) & 1ull);
-    const T old_val = (need_old && old_has) ? ((const T *)a.w_old_val)[row] : (T)0;
+    const T old_val = (need_old && in) ? ((const T *)a.w_old_val)[row] : (T)0;  // (not waiting for the presence word)
     const bool is_long = (longw >> lane) & 1ull;
     int long_slot = 0;
     if (longw) long_slot = a.long_prefix[g] + __popcll(longw & ((1ull << lane) - 1ull));
@@ -764,13 +764,14 @@ __global__ __launch_bounds__(ROWS_BLOCK) void k_mxv_rows(const PullArgs a)
             }
         }
         // ---- row of each entry: marks where rows start inside the window, max-scan across the wavefront -------------
-        *(uint64_t *)&s_mark[wave][lane * EPL] = 0ull;
+        using MarkWord = typename std::conditional<EPL == 8, uint64_t, uint32_t>::type;  // my EPL marks in one LDS access
+        *(MarkWord *)&s_mark[wave][lane * EPL] = 0;
         wave_sync();
         if (len > 0 && rel >= wbase && rel < wbase + WIN) s_mark[wave][rel - wbase] = (unsigned char)(lane + 1);
         const unsigned long long before = __ballot(len > 0 && rel <= wbase);  // rows begun at or before the window start
         const int carry_in = 64 - __clzll(before);                            // (1 + the last of them; never 0 inside a group)
         wave_sync();
-        const uint64_t mk = *(const uint64_t *)&s_mark[wave][lane * EPL];
+        const uint64_t mk = *(const MarkWord *)&s_mark[wave][lane * EPL];
         int h[EPL];
 #pragma unroll
         for (int i = 0; i < EPL; i++) h[i] = (int)((mk >> (8 * i)) & 0xffu);
@@ -1110,20 +1111,37 @@ __global__ void k_hot_recode(const int32_t *col, int64_t nnz, const int32_t *ran
         col_hot[p] = r >= 0 ? r : k + c;
     }
 }
-// per call: table[r] = x[hot_cols[r]], presence word by ballot
+// per call, the image the kernels index: [ table[r] = u[hot_cols[r]], r < k | u ] -- the first workgroups gather the
+// table (presence word by ballot), the others copy u's values (16 bytes per thread) and presence words behind it
 template <typename T>
-__global__ void k_hot_gather(const int32_t *hot_cols, int k, const T *u_val, const uint32_t *u_bits, int u_full, T *hot_val,
-                             uint64_t *hot_bits)
+__global__ void k_x_image(const int32_t *hot_cols, int k, const T *u_val, const uint32_t *u_bits, int u_full, T *img_val,
+                          uint64_t *img_bits, int64_t n)
 {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    bool p = false;
-    if (r < k) {
-        const int c = hot_cols[r];
-        p = u_full ? true : ((u_bits[c >> 5] >> (c & 31)) & 1u);
-        if (p) hot_val[r] = u_val[c];
+    const int gather_blocks = (k + (int)blockDim.x - 1) / (int)blockDim.x;
+    if ((int)blockIdx.x < gather_blocks) {
+        const int r = blockIdx.x * blockDim.x + threadIdx.x;
+        bool p = false;
+        if (r < k) {
+            const int c = hot_cols[r];
+            p = u_full ? true : ((u_bits[c >> 5] >> (c & 31)) & 1u);
+            if (p) img_val[r] = u_val[c];
+        }
+        const unsigned long long b = __ballot(p);
+        if ((threadIdx.x & 63) == 0 && r < ((k + 63) / 64) * 64) img_bits[r >> 6] = b;
+        return;
     }
-    const unsigned long long b = __ballot(p);
-    if ((threadIdx.x & 63) == 0 && r < ((k + 63) / 64) * 64) hot_bits[r >> 6] = b;
+    const int64_t t = ((int64_t)blockIdx.x - gather_blocks) * blockDim.x + threadIdx.x;
+    const int64_t bytes = n * (int64_t)sizeof(T), n16 = bytes >> 4;
+    const char *src = (const char *)u_val;
+    char *dst = (char *)(img_val + k);
+    if (t < n16) ((uint4 *)dst)[t] = ((const uint4 *)src)[t];
+    else if (t == n16) {
+        for (int64_t b = n16 << 4; b < bytes; b++) dst[b] = src[b];
+    }
+    if (!u_full) {
+        const int64_t words = (n + 63) >> 6;
+        if (t < words) img_bits[(k >> 6) + t] = ((const uint64_t *)u_bits)[t];
+    }
 }
 
 static void ensure_hot(GB_Matrix_opaque *A, size_t value_bytes)
@@ -1456,22 +1474,47 @@ static void mxv_core(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_Binar
         if (S->hot_state == 1 && (uint64_t)(u->n + S->hot_k) * type_size(st) < 0xfffffff0ull) {
             const int k = (int)S->hot_k;  // multiple of 64
             const size_t vb = type_size(st);
-            dev_free(xcat_val.p);
-            xcat_val.p = (char *)dev_alloc(vb * (size_t)(k + u->n));
-            dev_free(xcat_bits.p);
-            xcat_bits.p = (uint64_t *)dev_alloc((size_t)(k / 64 + bits_words64(u->n)) * 8);
-            GRB_DISPATCH_TYPE(st, T, {
-                hipLaunchKernelGGL((k_hot_gather<T>), dim3((unsigned)ceil_div(k, 256)), dim3(256), 0, ctx().stream,
-                                   (const int32_t *)S->d_hot_cols, k, (const T *)uval, (const uint32_t *)u->d_bits, a.u_full,
-                                   (T *)xcat_val.p, xcat_bits.p);
-            })
-            d2d(xcat_val.p + vb * (size_t)k, uval, vb * (size_t)u->n);
-            if (!a.u_full) d2d(xcat_bits.p + k / 64, u->d_bits, bits_words64(u->n) * 8);
+            char *img_val;
+            uint64_t *img_bits;
+            if (u->padded && uval == u->d_val && vb * (size_t)k <= VEC_VAL_PAD && (size_t)k / 8 <= VEC_BITS_PAD) {
+                // u's own allocation has room in front of its values and presence words: the table is gathered there and
+                // [table | u] is one image without copying u
+                img_val = (char *)u->d_val - vb * (size_t)k;
+                img_bits = u->d_bits - k / 64;
+                GRB_DISPATCH_TYPE(st, T, {
+                    hipLaunchKernelGGL((k_x_image<T>), dim3((unsigned)ceil_div(k, 256)), dim3(256), 0, ctx().stream,
+                                       (const int32_t *)S->d_hot_cols, k, (const T *)uval, (const uint32_t *)u->d_bits, a.u_full,
+                                       (T *)img_val, img_bits, (int64_t)u->n);
+                })
+            } else {
+                dev_free(xcat_val.p);
+                xcat_val.p = (char *)dev_alloc(vb * (size_t)(k + u->n));
+                dev_free(xcat_bits.p);
+                xcat_bits.p = (uint64_t *)dev_alloc((size_t)(k / 64 + bits_words64(u->n)) * 8);
+                img_val = xcat_val.p;
+                img_bits = xcat_bits.p;
+                const int64_t copy_threads = std::max<int64_t>(((int64_t)u->n * (int64_t)vb >> 4) + 1, (int64_t)bits_words64(u->n));
+                if (((uintptr_t)uval & 15u) == 0) {
+                    GRB_DISPATCH_TYPE(st, T, {
+                        hipLaunchKernelGGL((k_x_image<T>), dim3((unsigned)(ceil_div(k, 256) + ceil_div(copy_threads, 256))), dim3(256), 0,
+                                           ctx().stream, (const int32_t *)S->d_hot_cols, k, (const T *)uval, (const uint32_t *)u->d_bits,
+                                           a.u_full, (T *)img_val, img_bits, (int64_t)u->n);
+                    })
+                } else {  // (a typecast copy of u need not be 16-byte aligned)
+                    GRB_DISPATCH_TYPE(st, T, {
+                        hipLaunchKernelGGL((k_x_image<T>), dim3((unsigned)ceil_div(k, 256)), dim3(256), 0, ctx().stream,
+                                           (const int32_t *)S->d_hot_cols, k, (const T *)uval, (const uint32_t *)u->d_bits, a.u_full,
+                                           (T *)img_val, img_bits, (int64_t)u->n);
+                    })
+                    d2d(img_val + vb * (size_t)k, uval, vb * (size_t)u->n);
+                    if (!a.u_full) d2d(img_bits + k / 64, u->d_bits, bits_words64(u->n) * 8);
+                }
+            }
             ctx().stats.kernel_launches += 1;
             ctx().stats.hot_k = k;
             a.col = S->d_col_hot;
-            a.u_val = xcat_val.p;
-            a.u_bits = (const uint32_t *)xcat_bits.p;
+            a.u_val = img_val;
+            a.u_bits = (const uint32_t *)img_bits;
             a.x_len = (int64_t)u->n + k;
         }
     }
@@ -1519,8 +1562,7 @@ static void mxv_core(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_Binar
         void *new_val = w->d_val;
         uint64_t *new_bits = w->d_bits;
         if (fresh) {
-            new_val = dev_alloc((size_t)w->n * w->type->size);
-            new_bits = (uint64_t *)dev_alloc_zero(bits_words64(w->n) * 8);
+            vector_alloc_pair(w, w->padded, false, &new_val, &new_bits);
         }
         a.w_old_val = w->d_val;
         a.w_old_bits = w->d_bits;
@@ -1529,8 +1571,7 @@ static void mxv_core(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_Binar
         a.fresh = fresh ? 1 : 0;
         pull_dispatch(S, st, a);
         if (fresh) {
-            dev_free(w->d_val);
-            dev_free(w->d_bits);
+            vector_free_pair(w->padded, w->d_val, w->d_bits);
             w->d_val = new_val;
             w->d_bits = new_bits;
         }

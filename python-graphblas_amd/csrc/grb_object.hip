@@ -250,14 +250,39 @@ GB_Vector_opaque *vector_new(GrB_Type type, uint64_t n)
     v->n = n;
     v->d_val = nullptr;
     v->d_bits = nullptr;
+    v->padded = false;
     v->nvals = 0;
     return v;
 }
 
+// storage of a vector: values + presence words, both optionally behind a front pad (see GB_Vector_opaque::padded)
+void vector_alloc_pair(const GB_Vector_opaque *v, bool padded, bool zero_val, void **val, uint64_t **bits)
+{
+    const size_t vb = (size_t)v->n * v->type->size, bb = bits_words64(v->n) * 8;
+    const size_t vpad = padded ? VEC_VAL_PAD : 0, bpad = padded ? VEC_BITS_PAD : 0;
+    char *pv = (char *)dev_alloc(vb + vpad);
+    char *pb = nullptr;
+    try {
+        pb = (char *)dev_alloc(bb + bpad);
+    } catch (...) {
+        dev_free(pv);
+        throw;
+    }
+    if (zero_val) GRB_HIP(hipMemsetAsync(pv + vpad, 0, vb ? vb : 16, ctx().stream));
+    GRB_HIP(hipMemsetAsync(pb + bpad, 0, bb ? bb : 16, ctx().stream));
+    *val = pv + vpad;
+    *bits = (uint64_t *)(pb + bpad);
+}
+
+void vector_free_pair(bool padded, void *val, uint64_t *bits)
+{
+    if (val) dev_free((char *)val - (padded ? VEC_VAL_PAD : 0));
+    if (bits) dev_free((char *)bits - (padded ? VEC_BITS_PAD : 0));
+}
+
 void vector_release_storage(GB_Vector_opaque *v)
 {
-    dev_free(v->d_val);
-    dev_free(v->d_bits);
+    vector_free_pair(v->padded, v->d_val, v->d_bits);
     v->d_val = nullptr;
     v->d_bits = nullptr;
     v->nvals = 0;
@@ -275,8 +300,8 @@ void vector_ensure_storage(GB_Vector_opaque *v)
 {
     if (v->d_val) return;
     if (v->n > (1ull << 40)) fail(GrB_OUT_OF_MEMORY, "dense-with-presence vector of this size does not fit in HBM");
-    v->d_val = dev_alloc_zero((size_t)v->n * v->type->size);
-    v->d_bits = (uint64_t *)dev_alloc_zero(bits_words64(v->n) * 8);
+    v->padded = (int64_t)((size_t)v->n * v->type->size) >= ctx().vec_pad_min_bytes;
+    vector_alloc_pair(v, v->padded, true, &v->d_val, &v->d_bits);
     v->nvals = 0;
 }
 
