@@ -260,6 +260,7 @@ extern "C" GrB_Info GrX_option_set(const char *name, int64_t value)
     else if (n == "split_min_nnz") c.split_min_nnz = value;
     else if (n == "split_min_len") c.split_min_len = (int)value;
     else if (n == "short_kernel") c.short_kernel = (int)value;
+    else if (n == "long_kernel") c.long_kernel = (int)value;
     else if (n == "vec_pad_min_bytes") c.vec_pad_min_bytes = value;
     else if (n == "alloc_cache") {
         if (!value) dev_cache_release();

@@ -61,6 +61,7 @@ struct Context {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int64_t vec_pad_min_bytes = 1 << 20;  // vectors with at least this many bytes of values are allocated with the front pad
     int alloc_cache = 1;    // 1: freed device blocks are kept per size class and reused without calling the HIP allocator
+    int long_kernel = 1;    // long rows: 1 = class-partitioned kernel (k_mxv_long_cls), 0 = chunk kernel (k_mxv_long)
     int short_kernel = 1;   // short rows of a split matrix: 1 = row-group kernel (k_mxv_rows), 0 = merge-path kernel
     GrX_Stats stats{};
     int debug_flags = 0;    // GRB_DEBUG: kernel ablation switches (benchmark diagnostics only)
@@ -180,6 +181,14 @@ struct GB_Matrix_opaque {
     int64_t *d_chunk_start;   // per chunk: first entry
     int32_t *d_chunk_len;     // per chunk: entries (<= PULL_CHUNK)
     int32_t *d_long_prefix;   // per 64-row group: number of long rows before it
+    // class-partitioned copy of the long rows (k_mxv_long_cls): entries grouped by column class ((code >> 5) & 7), then
+    // by long-row slot; virtual row v = class * n_long + slot spans [d_vptr[v], d_vptr[v+1]) of d_lcol / d_lval
+    int32_t *d_lcol;
+    void *d_lval;             // nullptr for iso matrices
+    int64_t *d_vptr;          // 8 * n_long + 1
+    int32_t *d_unit_row;      // per work unit (LONG_UNIT entries of one class): the class-relative row holding its first entry
+    int64_t unit_begin[9];    // units of class j are [unit_begin[j], unit_begin[j+1])
+    int64_t long_nnz;
     int64_t n_long, n_chunks;
     int split_state;          // 0 = not analysed, 1 = enabled, -1 = not worth it
     bool split_hot;           // short_part's columns are hot-coded

@@ -70,6 +70,14 @@ struct PullArgs {
     int64_t n_chunks, n_long;
     int64_t n_long_epi;  // long rows whose write rule the seams launch applies (extra workgroups behind the seam ones)
     const int32_t *long_prefix;  // per 64-row group: long rows before it (slot of a long row = prefix + rank in its word)
+    // class-partitioned long rows (k_mxv_long_cls)
+    const int32_t *lcol;
+    const void *lval;
+    const int64_t *vptr;
+    const int32_t *unit_row;
+    int64_t unit_begin[9];
+    int64_t long_nnz;
+    uint32_t *long_act;     // per call: bit s = the mask admits long row s
     void *tl_val;           // per long row: product accumulator (identity-initialised)
     unsigned char *tl_has;  // per long row: any product present
     long long *dbg_times;  // GRB_DEBUG_FLAGS & 8: 10 phase timestamps per tile (thread 0)
@@ -124,6 +132,19 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, in
 {
     const int64_t lim = bytes < 0 ? 0 : (bytes > 0xfffffff0ll ? 0xfffffff0ll : bytes);
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)(unsigned)lim, 0x00020000);
+}
+// streaming variant (aux 2 = non-temporal): for data read once, so that it does not displace the x image from the caches
+template <typename T>
+__device__ __forceinline__ T buf_load_nt(__amdgpu_buffer_rsrc_t r, unsigned byte_off)
+{
+    if constexpr (sizeof(T) == 1) return __builtin_bit_cast(T, (unsigned char)__builtin_amdgcn_raw_buffer_load_b8(r, byte_off, 0, 2));
+    else if constexpr (sizeof(T) == 2) return __builtin_bit_cast(T, (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, byte_off, 0, 2));
+    else if constexpr (sizeof(T) == 4) return __builtin_bit_cast(T, (unsigned int)__builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 2));
+    else {
+        const auto v = __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, 2);
+        const unsigned long long u = (unsigned long long)v[0] | ((unsigned long long)v[1] << 32);
+        return __builtin_bit_cast(T, u);
+    }
 }
 template <typename T>
 __device__ __forceinline__ T buf_load(__amdgpu_buffer_rsrc_t r, unsigned byte_off)
@@ -414,6 +435,14 @@ __global__ __launch_bounds__(PULL_BLOCK) void k_mxv_pull(const PullArgs a)
     PHASE_STAMP(7);
 }
 
+__device__ __forceinline__ void wave_sync()
+{
+    // LDS operations of one wavefront execute in order; this only stops the compiler from moving them across
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Long rows (>= split_min_len entries; on power-law graphs 3 % of the rows hold 80 % of the entries): one wavefront
 // per chunk of at most PULL_CHUNK entries of ONE row.  No row bookkeeping at all -- 8 consecutive entries per lane
@@ -464,6 +493,7 @@ __global__ __launch_bounds__(LONG_BLOCK) void k_mxv_long(const PullArgs a)
     const int64_t wave0 = (int64_t)blockIdx.x * (LONG_BLOCK / 64) + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * (LONG_BLOCK / 64);
     constexpr int STEP = 64 * EPL;
+    const bool nt = (a.dbg & 64) != 0;  // diagnostic: non-temporal entry loads
     // The wavefront owns chunks wave0, wave0 + nwaves, ...  Their descriptors (slot -> row -> mask bit -> start, len: a
     // chain of dependent loads) are fetched once, 64 chunks at a time with one chunk per lane, and broadcast from the
     // lanes as needed; masked-out chunks drop out of the ballot and nothing of their rows is read.
@@ -504,9 +534,9 @@ __global__ __launch_bounds__(LONG_BLOCK) void k_mxv_long(const PullArgs a)
 #pragma unroll
             for (int i = 0; i < EPL; i++) {
                 const int e = i * 64 + lane;  // coalesced 4-byte loads; entries past the end of the chunk read 0 and are discarded
-                const int c = buf_load<int>(crs, (unsigned)e * 4u);
+                const int c = nt ? buf_load_nt<int>(crs, (unsigned)e * 4u) : buf_load<int>(crs, (unsigned)e * 4u);
                 cc_n[i] = (e < c_len) ? c : -1;
-                av_n[i] = stage_vals ? buf_load<T>(vrs, (unsigned)e * (unsigned)sizeof(T)) : iso_v;
+                av_n[i] = stage_vals ? (nt ? buf_load_nt<T>(vrs, (unsigned)e * (unsigned)sizeof(T)) : buf_load<T>(vrs, (unsigned)e * (unsigned)sizeof(T))) : iso_v;
             }
         }
         T acc = (T)0;
@@ -570,9 +600,9 @@ __global__ __launch_bounds__(LONG_BLOCK) void k_mxv_long(const PullArgs a)
 #pragma unroll
                 for (int i = 0; i < EPL; i++) {
                     const int e = n_base + i * 64 + lane;
-                    const int c = buf_load<int>(crs, (unsigned)e * 4u);
+                    const int c = nt ? buf_load_nt<int>(crs, (unsigned)e * 4u) : buf_load<int>(crs, (unsigned)e * 4u);
                     cc_n[i] = (e < n_len) ? c : -1;
-                    av_n[i] = stage_vals ? buf_load<T>(vrs, (unsigned)e * (unsigned)sizeof(T)) : iso_v;
+                    av_n[i] = stage_vals ? (nt ? buf_load_nt<T>(vrs, (unsigned)e * (unsigned)sizeof(T)) : buf_load<T>(vrs, (unsigned)e * (unsigned)sizeof(T))) : iso_v;
                 }
             }
             T xv[EPL];
@@ -628,6 +658,267 @@ __global__ __launch_bounds__(LONG_BLOCK) void k_mxv_long(const PullArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Long rows, class-partitioned.  The gathers of the long rows dominate the SpMV, and a gather costs nothing when it
+// hits LDS, one L2 request when it hits L2 and ~3x that when it misses.  So the entries of the long rows are stored a
+// second time grouped by COLUMN CLASS = (code >> 5) & 7 (32 consecutive codes = one 128-byte line of 4-byte values),
+// and a workgroup only ever works on the class of its own index: blocks are dealt round-robin to the 8 XCDs, so the
+// L2 of an XCD sees one eighth of the x image (its hot part fits), and the 128 KiB of LDS a workgroup spends on the
+// image head hold the 32 Ki hottest codes OF ITS CLASS -- 256 Ki distinct codes across the chip instead of 32 Ki.
+// (Placement only changes speed: any workgroup computes any class correctly.)
+//
+// Work is dealt in units of LONG_UNIT consecutive entries of a class (balanced no matter how the rows are cut); a
+// wavefront consumes its unit in windows of 64 x 8 entries like k_mxv_rows: row-start marks in LDS + max-scan give the
+// row of each entry, products fold per lane into per-wavefront LDS accumulators, and at the end of a window the (at most
+// 64) rows it touched are flushed to the long-row accumulators with one global atomic each.
+// ---------------------------------------------------------------------------------------------------
+constexpr int LONG_UNIT = 2048;
+
+template <typename T, int MONOID_CT, int MULT_CT, int LDS_WORDS>
+__global__ __launch_bounds__(LONG_BLOCK) void k_mxv_long_cls(const PullArgs a)
+{
+    using W = typename Widen<T>::type;
+    constexpr int EPL = 8, WIN = 64 * EPL, NWV = LONG_BLOCK / 64;
+    __shared__ uint32_t s_x[LDS_WORDS];
+    __shared__ __attribute__((aligned(16))) unsigned char s_mark[NWV][WIN];
+    __shared__ W s_acc[NWV][128];  // ids 1..64 of a window + one scratch slot per lane
+    __shared__ unsigned char s_has[NWV][128];
+    const int monoid = MONOID_CT >= 0 ? MONOID_CT : a.monoid;
+    const int mult = MULT_CT >= 0 ? MULT_CT : a.mult;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cls = blockIdx.x & 7;
+    const bool need_aval = a.need_aval != 0, need_uval = a.need_uval != 0;
+    const bool stage_vals = need_aval && !a.a_iso;
+    const T *lval = (const T *)a.lval;
+    const T iso_v = (a.a_iso && need_aval) ? ((const T *)a.aval)[0] : (T)0;
+    const __amdgpu_buffer_rsrc_t xval_rs = make_rsrc(a.u_val, a.x_len * (int64_t)sizeof(T));
+    const __amdgpu_buffer_rsrc_t xbits_rs = make_rsrc(a.u_bits, a.u_full ? 0 : ((a.x_len + 63) >> 6) * 8);
+    const __amdgpu_buffer_rsrc_t xvbits_rs = make_rsrc(a.u_valbits, a.u_valbits ? ((a.x_len + 63) >> 6) * 8 : 0);
+    constexpr bool IS_BOOL = std::is_same<T, bool>::value;
+    // LDS residency of my class: BOOL values are bit-packed (word w of the class = image word 8 w + cls), the others
+    // take one LDS slot per code: slot ((c >> 8) << 5) | (c & 31) for the codes c with (c >> 5) & 7 == cls
+    constexpr int LDS_SLOTS = IS_BOOL ? LDS_WORDS : (int)((int64_t)LDS_WORDS * 4 / (int64_t)(sizeof(T) < 4 ? 4 : sizeof(T)));
+    const bool use_lds = need_uval && !(a.dbg & 4096);
+    // codes below lds_lim whose slot is below LDS_SLOTS are resident
+    const int64_t lds_lim_codes = IS_BOOL ? (int64_t)LDS_SLOTS * 256 : (int64_t)LDS_SLOTS * 8;
+    const int lds_lim = use_lds ? (int)(a.x_len < lds_lim_codes ? a.x_len : lds_lim_codes) : 0;
+    if (use_lds) {
+        if constexpr (IS_BOOL) {
+            for (int w = threadIdx.x; w < LDS_SLOTS; w += LONG_BLOCK) s_x[w] = buf_load<uint32_t>(xvbits_rs, (unsigned)((w << 3) | cls) * 4u);
+        } else {
+            for (int k = threadIdx.x; k < LDS_SLOTS; k += LONG_BLOCK) {
+                const unsigned c = ((unsigned)(k >> 5) << 8) | ((unsigned)cls << 5) | (unsigned)(k & 31);
+                const T v = buf_load<T>(xval_rs, c * (unsigned)sizeof(T));  // (past the image: 0, never looked up)
+                if constexpr (sizeof(T) == 8) ((T *)s_x)[k] = v;
+                else if constexpr (sizeof(T) == 4) s_x[k] = __builtin_bit_cast(uint32_t, v);
+                else s_x[k] = (uint32_t)v;
+            }
+        }
+    }
+    s_acc[wave][lane] = monoid_identity<T, W>(monoid);
+    s_acc[wave][64 + lane] = monoid_identity<T, W>(monoid);
+    s_has[wave][lane] = 0;
+    s_has[wave][64 + lane] = 0;
+    __syncthreads();
+
+    const int64_t nl = a.n_long;
+    const int64_t *vp = a.vptr + (int64_t)cls * nl;  // class-relative row (= long-row slot) -> first entry
+    const int64_t cls_begin = a.vptr[(int64_t)cls * nl], cls_end = a.vptr[(int64_t)(cls + 1) * nl];
+    const int64_t ub = a.unit_begin[cls], ue = a.unit_begin[cls + 1];
+    const int64_t nblk = ((int64_t)gridDim.x - cls + 7) >> 3;  // workgroups of my class
+    const int64_t wv = (int64_t)(blockIdx.x >> 3) * NWV + wave, nwv = nblk * NWV;
+    W *tl = (W *)a.tl_val;
+    const int e0 = lane * EPL;
+
+    // One flat loop over the windows of my units.  The loads of a window (my entries, the starts of the 64 rows after
+    // `rcur`, the mask's verdict on rows rcur .. rcur+63) are issued one window ahead -- where the next window begins is
+    // known as soon as the row starts of the current one have arrived -- so they are in flight while the current window
+    // does its marks, scan, gathers, fold and flush.
+    int64_t u = ub + wv;
+    if (u >= ue) return;
+    int64_t pos = cls_begin + (u - ub) * LONG_UNIT;
+    int64_t uend = pos + LONG_UNIT < cls_end ? pos + LONG_UNIT : cls_end;
+    int64_t rcur = a.unit_row[u];  // the last row that starts at or before pos
+    int next_unit_row = (u + nwv < ue) ? a.unit_row[u + nwv] : 0;
+    int n_creg[EPL];
+    T n_vreg[EPL];
+    int64_t n_st;
+    bool n_act;
+#define CLS_WINDOW_LOADS(POS, RCUR)                                                                                          \
+    do {                                                                                                                     \
+        const int64_t left_ = a.long_nnz - (POS);                                                                            \
+        const __amdgpu_buffer_rsrc_t crs_ = make_rsrc(a.lcol + (POS), left_ * 4);                                            \
+        const __amdgpu_buffer_rsrc_t vrs_ = make_rsrc(lval + (stage_vals ? (POS) : 0), stage_vals ? left_ * (int64_t)sizeof(T) : 0); \
+        if (left_ >= (int64_t)WIN + 4) { /* 16-byte loads never straddle the end of the arrays */                            \
+            _Pragma("unroll") for (int q_ = 0; q_ < EPL / 4; q_++) {                                                         \
+                const auto c4_ = __builtin_amdgcn_raw_buffer_load_b128(crs_, (unsigned)(e0 + q_ * 4) * 4u, 0, 0);            \
+                _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++) n_creg[q_ * 4 + i_] = (int)c4_[i_];                         \
+                if constexpr (sizeof(T) == 4) {                                                                              \
+                    const auto v4_ = __builtin_amdgcn_raw_buffer_load_b128(vrs_, (unsigned)(e0 + q_ * 4) * 4u, 0, 0);        \
+                    _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++) n_vreg[q_ * 4 + i_] = __builtin_bit_cast(T, (unsigned int)v4_[i_]); \
+                } else {                                                                                                     \
+                    _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++)                                                         \
+                        n_vreg[q_ * 4 + i_] = buf_load<T>(vrs_, (unsigned)(e0 + q_ * 4 + i_) * (unsigned)sizeof(T));         \
+                }                                                                                                            \
+            }                                                                                                                \
+        } else {                                                                                                             \
+            _Pragma("unroll") for (int i_ = 0; i_ < EPL; i_++) {                                                             \
+                n_creg[i_] = buf_load<int>(crs_, (unsigned)(e0 + i_) * 4u);                                                  \
+                n_vreg[i_] = buf_load<T>(vrs_, (unsigned)(e0 + i_) * (unsigned)sizeof(T));                                   \
+            }                                                                                                                \
+        }                                                                                                                    \
+        const int64_t rr_ = (RCUR) + 1 + lane;                                                                               \
+        n_st = vp[rr_ < nl ? rr_ : nl];                                                                                      \
+        const int64_t ra_ = (RCUR) + lane;                                                                                   \
+        n_act = ra_ < nl && ((a.long_act[ra_ >> 5] >> (ra_ & 31)) & 1u);                                                     \
+    } while (0)
+
+    CLS_WINDOW_LOADS(pos, rcur);
+    for (;;) {
+        int creg[EPL];
+        T vreg[EPL];
+#pragma unroll
+        for (int i = 0; i < EPL; i++) { creg[i] = n_creg[i]; vreg[i] = n_vreg[i]; }
+        const int64_t st = n_st;
+        const unsigned long long actmask = __ballot(n_act);  // bit l <-> row rcur + l <-> id l + 1
+        int wl = (int)((pos + WIN < uend ? pos + WIN : uend) - pos);
+        const int st_rel = (st - pos > (int64_t)WIN) ? WIN + 1 : (int)(st - pos);  // (>= 0)
+        const int st63 = __builtin_amdgcn_readfirstlane(__shfl(st_rel, 63));
+        if (st63 < wl) wl = st63;  // more than 63 rows start inside: cut the window where the 64th starts
+        // ---- where the next window begins; its loads go out now ----------------------------------------------------------
+        const int64_t rcur_here = rcur;
+        bool more = true;
+        if (wl <= 0) {  // 64 rows without entries at this position: nothing to do here but step over them
+            rcur += 64;
+            wl = 0;
+        } else {
+            rcur += __popcll(__ballot(st_rel <= wl));  // the last row that starts at or before the next position
+        }
+        pos += wl;
+        if (pos >= uend) {
+            u += nwv;
+            if (u < ue) {
+                pos = cls_begin + (u - ub) * LONG_UNIT;
+                uend = pos + LONG_UNIT < cls_end ? pos + LONG_UNIT : cls_end;
+                rcur = next_unit_row;
+                next_unit_row = (u + nwv < ue) ? a.unit_row[u + nwv] : 0;
+            } else {
+                more = false;
+            }
+        }
+        if (more) CLS_WINDOW_LOADS(pos, rcur);
+        if (wl > 0) {
+            const int nxt = __shfl_down(st_rel, 1);
+            const bool starter = lane < 63 && st_rel < wl && nxt > st_rel;  // a non-empty row starts inside the window
+            // ---- row of each entry: marks + wavefront max-scan (id 1 = row rcur, id l + 2 = row rcur + 1 + l) ---------
+            using MarkWord = typename std::conditional<EPL == 8, uint64_t, uint32_t>::type;
+            *(MarkWord *)&s_mark[wave][lane * EPL] = 0;
+            wave_sync();
+            if (starter) s_mark[wave][st_rel] = (unsigned char)(lane + 2);
+            wave_sync();
+            const uint64_t mk = *(const MarkWord *)&s_mark[wave][lane * EPL];
+            int h[EPL];
+#pragma unroll
+            for (int i = 0; i < EPL; i++) h[i] = (int)((mk >> (8 * i)) & 0xffu);
+            int lastk = 0;
+#pragma unroll
+            for (int i = 0; i < EPL; i++) lastk = h[i] ? h[i] : lastk;
+            int incl = lastk;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int t = __shfl_up(incl, off);
+                if (lane >= off) incl = incl > t ? incl : t;
+            }
+            int e = __shfl_up(incl, 1);
+            if (lane == 0 || e == 0) e = 1;
+            int ek[EPL], cc[EPL];
+#pragma unroll
+            for (int i = 0; i < EPL; i++) {
+                e = h[i] ? h[i] : e;
+                ek[i] = e;
+                cc[i] = (e0 + i < wl && ((actmask >> (e - 1)) & 1ull)) ? creg[i] : -1;
+            }
+            if (a.dbg & (16384 | 32768)) {  // diagnostic: fold every gather into the first 2^19 / 2^15 entries of the image
+                const int gmask = (a.dbg & 16384) ? 0x7ffff : 0x7fff;
+#pragma unroll
+                for (int i = 0; i < EPL; i++) cc[i] = cc[i] >= 0 ? (cc[i] & gmask) : -1;
+            }
+            // ---- gathers: presence words, then values (LDS for the resident codes of my class, else the image) ---------
+            bool xp[EPL];
+            T xv[EPL];
+            if (a.u_full) {
+#pragma unroll
+                for (int i = 0; i < EPL; i++) xp[i] = cc[i] >= 0;
+            } else {
+                uint32_t bw[EPL];
+#pragma unroll
+                for (int i = 0; i < EPL; i++) bw[i] = buf_load<uint32_t>(xbits_rs, (unsigned)(cc[i] >> 5) * 4u);
+#pragma unroll
+                for (int i = 0; i < EPL; i++) xp[i] = (bw[i] >> (cc[i] & 31)) & 1u;
+            }
+            if (need_uval && !(a.dbg & 8192)) {
+                if constexpr (IS_BOOL) {
+                    uint32_t vw[EPL];
+#pragma unroll
+                    for (int i = 0; i < EPL; i++) vw[i] = buf_load<uint32_t>(xvbits_rs, (xp[i] && cc[i] >= lds_lim) ? (unsigned)(cc[i] >> 5) * 4u : 0xfffffff8u);
+#pragma unroll
+                    for (int i = 0; i < EPL; i++) {
+                        const bool in_lds = xp[i] && cc[i] < lds_lim;
+                        const uint32_t wv32 = in_lds ? s_x[cc[i] >> 8] : vw[i];
+                        xv[i] = (wv32 >> (cc[i] & 31)) & 1u;
+                    }
+                } else {
+                    T xg[EPL];
+#pragma unroll
+                    for (int i = 0; i < EPL; i++) xg[i] = buf_load<T>(xval_rs, (xp[i] && cc[i] >= lds_lim) ? (unsigned)cc[i] * (unsigned)sizeof(T) : 0xfffffff8u);
+#pragma unroll
+                    for (int i = 0; i < EPL; i++) {
+                        const bool in_lds = xp[i] && cc[i] < lds_lim;
+                        const int li = in_lds ? (((cc[i] >> 8) << 5) | (cc[i] & 31)) : 0;
+                        T xl;
+                        if constexpr (sizeof(T) == 8) xl = ((const T *)s_x)[li];
+                        else if constexpr (sizeof(T) == 4) xl = __builtin_bit_cast(T, s_x[li]);
+                        else xl = (T)s_x[li];
+                        xv[i] = in_lds ? xl : xg[i];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < EPL; i++) xv[i] = (T)(need_uval ? 1 : 0);
+            }
+            // ---- segmented fold of my entries into the window's row accumulators (as k_mxv_rows) -------------------------
+            T acc = (T)0;
+            bool has = false;
+#pragma unroll
+            for (int i = 0; i < EPL; i++) {
+                const T av = need_aval ? (a.a_iso ? iso_v : vreg[i]) : (T)0;
+                const T prod = apply_binop<T>(mult, av, xv[i]);
+                const bool keep = has && (i > 0) && (h[i] == 0);
+                acc = xp[i] ? (keep ? apply_binop<T>(monoid, acc, prod) : prod) : (keep ? acc : (T)0);
+                has = xp[i] || keep;
+                const bool seg_end = (i == EPL - 1) ? true : (h[i + 1] != 0);
+                const int k = (seg_end && has) ? ek[i] - 1 : 64 + lane;
+                if (monoid == OP_ANY) s_acc[wave][k] = (W)acc;
+                else atomic_combine<W>(&s_acc[wave][k], (W)acc, monoid);
+                s_has[wave][k] = 1;
+            }
+            wave_sync();
+            // ---- flush: lane l owns id l + 1 = row rcur_here + l ------------------------------------------------------------
+            if (s_has[wave][lane]) {
+                const W v = s_acc[wave][lane];
+                if (monoid == OP_ANY) tl[rcur_here + lane] = v;
+                else atomic_combine<W>(&tl[rcur_here + lane], v, monoid);
+                a.tl_has[rcur_here + lane] = 1;
+                s_acc[wave][lane] = monoid_identity<T, W>(monoid);
+                s_has[wave][lane] = 0;
+            }
+            wave_sync();
+        }
+        if (!more) break;
+    }
+#undef CLS_WINDOW_LOADS
+}
+
 // the write rule for one long row (run by the extra workgroups of the seams launch, after both kernels)
 template <typename T>
 __device__ __forceinline__ void long_row_write(const PullArgs &a, int64_t slot)
@@ -647,13 +938,28 @@ __device__ __forceinline__ void long_row_write(const PullArgs &a, int64_t slot)
     else atomicAnd((unsigned long long *)&a.w_new_bits[row >> 6], ~bit);
 }
 
+// per call: long-row accumulators at the monoid identity; bit s of long_act = the mask admits long row s
 template <typename W>
-__global__ void k_long_init(W *tl_val, unsigned char *tl_has, int64_t n, W identity)
+__global__ void k_long_init(W *tl_val, unsigned char *tl_has, int64_t n, W identity, const int32_t *long_rows, const uint64_t *m_bits,
+                            int has_mask, int m_comp, uint32_t *long_act)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool act = false;
     if (i < n) {
         tl_val[i] = identity;
         tl_has[i] = 0;
+        act = true;
+        if (has_mask) {
+            const int64_t row = long_rows[i];
+            act = (m_bits[row >> 6] >> (row & 63)) & 1ull;
+            if (m_comp) act = !act;
+        }
+    }
+    const unsigned long long b = __ballot(act);
+    const int lane = threadIdx.x & 63;
+    if (long_act && lane == 0 && (i >> 6) < ((n + 63) >> 6)) {
+        long_act[(i >> 6) * 2] = (uint32_t)b;
+        long_act[(i >> 6) * 2 + 1] = (uint32_t)(b >> 32);
     }
 }
 
@@ -669,14 +975,6 @@ __global__ void k_long_init(W *tl_val, unsigned char *tl_has, int64_t n, W ident
 // ---------------------------------------------------------------------------------------------------
 constexpr int ROWS_BLOCK = 256;
 constexpr int ROWS_EPL = 4;
-
-__device__ __forceinline__ void wave_sync()
-{
-    // LDS operations of one wavefront execute in order; this only stops the compiler from moving them across
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 template <typename T, int MONOID_CT, int MULT_CT>
 __global__ __launch_bounds__(ROWS_BLOCK) void k_mxv_rows(const PullArgs a)
@@ -744,11 +1042,13 @@ __global__ __launch_bounds__(ROWS_BLOCK) void k_mxv_rows(const PullArgs a)
         for (int q = 0; q < EPL / 4; q++) {
             const unsigned k = (unsigned)(e0 + q * 4);
             if (whole) {
-                const auto c4 = __builtin_amdgcn_raw_buffer_load_b128(crs, k * 4u, 0, 0);
+                const auto c4 = (a.dbg & 64) ? __builtin_amdgcn_raw_buffer_load_b128(crs, k * 4u, 0, 2)
+                                             : __builtin_amdgcn_raw_buffer_load_b128(crs, k * 4u, 0, 0);
 #pragma unroll
                 for (int i = 0; i < 4; i++) creg[q * 4 + i] = (int)c4[i];
                 if constexpr (sizeof(T) == 4) {
-                    const auto v4 = __builtin_amdgcn_raw_buffer_load_b128(vrs, k * 4u, 0, 0);
+                    const auto v4 = (a.dbg & 64) ? __builtin_amdgcn_raw_buffer_load_b128(vrs, k * 4u, 0, 2)
+                                                 : __builtin_amdgcn_raw_buffer_load_b128(vrs, k * 4u, 0, 0);
 #pragma unroll
                     for (int i = 0; i < 4; i++) vreg[q * 4 + i] = __builtin_bit_cast(T, (unsigned int)v4[i]);
                 } else {
@@ -904,6 +1204,61 @@ __global__ void k_split_fill(const int64_t *ptr, const int32_t *col, const T *va
             if (!iso) sval[o + i] = val[b + i];
         }
     }
+}
+
+// class partition of the long rows (once per matrix): sort key = class * n_long + slot of every entry of a long row
+__global__ void k_long_keys(const int64_t *ptr, const int64_t *sptr, const int32_t *long_rows, const int32_t *col, int64_t n_long,
+                            uint64_t *keys, uint32_t *idx)
+{
+    const int64_t s = blockIdx.x;
+    const int64_t row = long_rows[s];
+    const int64_t b = ptr[row], len = ptr[row + 1] - b;
+    const int64_t o = b - sptr[row];  // entries of long rows before this one
+    for (int64_t i = threadIdx.x; i < len; i += blockDim.x) {
+        const unsigned c = (unsigned)col[b + i];
+        keys[o + i] = (uint64_t)((c >> 5) & 7u) * (uint64_t)n_long + (uint64_t)s;
+        idx[o + i] = (uint32_t)(b + i);
+    }
+}
+template <typename T>
+__global__ void k_long_permute(const uint32_t *idx, int64_t n, const int32_t *col, const T *val, int iso, int32_t *lcol, T *lval)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t j = idx[i];
+    lcol[i] = col[j];
+    if (!iso) lval[i] = val[j];
+}
+// vptr[v] = first position whose key is >= v  (v = 0 .. nv; keys sorted)
+__global__ void k_long_vptr(const uint64_t *keys, int64_t n, int64_t nv, int64_t *vptr)
+{
+    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v > nv) return;
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (keys[mid] < (uint64_t)v) lo = mid + 1;
+        else hi = mid;
+    }
+    vptr[v] = lo;
+}
+struct UnitBegin { int64_t v[9]; };
+// unit_row[u] = the last row of the unit's class that starts at or before the unit's first entry
+__global__ void k_long_units(const int64_t *vptr, int64_t n_long, UnitBegin ub, int32_t *unit_row)
+{
+    const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= ub.v[8]) return;
+    int cls = 0;
+    while (u >= ub.v[cls + 1]) cls++;
+    const int64_t *vp = vptr + (int64_t)cls * n_long;
+    const int64_t pos = vp[0] + (u - ub.v[cls]) * LONG_UNIT;
+    int64_t lo = 0, hi = n_long;  // first row with start > pos
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (vp[mid] <= pos) lo = mid + 1;
+        else hi = mid;
+    }
+    unit_row[u] = (int32_t)(lo - 1);
 }
 
 // One wavefront per tile whose first row began in earlier tiles: fold the carries of tiles
@@ -1226,6 +1581,8 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
         matrix_free(A->short_part);
         A->short_part = nullptr;
         dev_free(A->d_long_bits); dev_free(A->d_long_rows); dev_free(A->d_chunk_slot); dev_free(A->d_chunk_start); dev_free(A->d_chunk_len); dev_free(A->d_long_prefix);
+        dev_free(A->d_lcol); dev_free(A->d_lval); dev_free(A->d_vptr); dev_free(A->d_unit_row);
+        A->d_lcol = nullptr; A->d_lval = nullptr; A->d_vptr = nullptr; A->d_unit_row = nullptr; A->long_nnz = 0;
         A->d_long_prefix = nullptr;
         A->d_long_bits = nullptr; A->d_long_rows = nullptr; A->d_chunk_slot = nullptr; A->d_chunk_start = nullptr; A->d_chunk_len = nullptr;
     }
@@ -1264,6 +1621,43 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
                                (const int64_t *)S->d_ptr, (const int64_t *)lflag.p, (const int64_t *)nchunk.p, S->d_col,
                                (T *)S->d_val, A->d_long_rows, A->d_chunk_slot, A->d_chunk_start, A->d_chunk_len, A->d_long_prefix);
         })
+        // class-partitioned copy of the long rows
+        const int64_t nnz_long = nnz - nnz_short;
+        A->long_nnz = 0;
+        if (nnz_long < 0xffffffffll && nnz < 0xffffffffll) {
+            const int64_t nv = 8 * nl;
+            int bits = 1;
+            while (((int64_t)1 << bits) < nv) bits++;
+            DevBuf<uint64_t> keys(nnz_long), keys2(nnz_long);
+            DevBuf<uint32_t> idx(nnz_long), idx2(nnz_long);
+            hipLaunchKernelGGL(k_long_keys, dim3((unsigned)nl), dim3(256), 0, ctx().stream, (const int64_t *)A->d_ptr,
+                               (const int64_t *)S->d_ptr, (const int32_t *)A->d_long_rows, col_src, nl, keys.p, idx.p);
+            prim_sort_pairs_u64_u32(keys.p, keys2.p, idx.p, idx2.p, nnz_long, bits);
+            A->d_lcol = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)nnz_long);
+            A->d_lval = A->iso ? nullptr : dev_alloc(A->type->size * (size_t)nnz_long);
+            GRB_DISPATCH_TYPE(A->type->code, T, {
+                hipLaunchKernelGGL((k_long_permute<T>), dim3((unsigned)ceil_div(nnz_long, 256)), dim3(256), 0, ctx().stream,
+                                   (const uint32_t *)idx2.p, nnz_long, col_src, (const T *)A->d_val, A->iso ? 1 : 0, A->d_lcol,
+                                   (T *)A->d_lval);
+            })
+            A->d_vptr = (int64_t *)dev_alloc(sizeof(int64_t) * (size_t)(nv + 1));
+            hipLaunchKernelGGL(k_long_vptr, dim3((unsigned)ceil_div(nv + 1, 256)), dim3(256), 0, ctx().stream,
+                               (const uint64_t *)keys2.p, nnz_long, nv, A->d_vptr);
+            UnitBegin ub;
+            ub.v[0] = 0;
+            for (int c = 0; c < 8; c++) {
+                int64_t b0 = 0, b1 = 0;
+                d2h(&b0, A->d_vptr + (int64_t)c * nl, 8);
+                d2h(&b1, A->d_vptr + (int64_t)(c + 1) * nl, 8);
+                ub.v[c + 1] = ub.v[c] + ceil_div(b1 - b0, (int64_t)LONG_UNIT);
+            }
+            for (int c = 0; c < 9; c++) A->unit_begin[c] = ub.v[c];
+            A->d_unit_row = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)(ub.v[8] ? ub.v[8] : 1));
+            if (ub.v[8] > 0)
+                hipLaunchKernelGGL(k_long_units, dim3((unsigned)ceil_div(ub.v[8], 256)), dim3(256), 0, ctx().stream,
+                                   (const int64_t *)A->d_vptr, nl, ub, A->d_unit_row);
+            A->long_nnz = nnz_long;
+        }
         sync_stream();
     } catch (...) {
         matrix_free(S);
@@ -1289,12 +1683,25 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
         GB_Matrix_opaque *S = A->short_part;
         DevBuf<W> tl_val(a.n_long);
         DevBuf<unsigned char> tl_has(a.n_long);
+        const bool by_class = ctx().long_kernel == 1 && A->long_nnz > 0;
+        DevBuf<uint32_t> long_act((size_t)ceil_div(a.n_long, 64) * 2);
+        a.long_act = long_act.p;
         hipLaunchKernelGGL((k_long_init<W>), dim3((unsigned)ceil_div(a.n_long, 256)), dim3(256), 0, ctx().stream, tl_val.p, tl_has.p,
-                           a.n_long, monoid_identity<T, W>(a.monoid));
+                           a.n_long, monoid_identity<T, W>(a.monoid), a.long_rows, a.m_bits, a.has_mask, a.m_comp, long_act.p);
         a.tl_val = tl_val.p;
         a.tl_has = tl_has.p;
         a.dbg = ctx().debug_flags;
-        {
+        if (by_class) {
+            a.lcol = A->d_lcol;
+            a.lval = A->d_lval;
+            a.vptr = A->d_vptr;
+            a.unit_row = A->d_unit_row;
+            a.long_nnz = A->long_nnz;
+            for (int c = 0; c < 9; c++) a.unit_begin[c] = A->unit_begin[c];
+            // one persistent 1024-thread workgroup per CU; block b works on column class b % 8 (= the XCD it runs on)
+            const int64_t G = std::max<int64_t>(8, (int64_t)(ctx().num_cus / 8) * 8);
+            hipLaunchKernelGGL((k_mxv_long_cls<T, MON, MUL, LONG_LDS_WORDS>), dim3((unsigned)G), dim3(LONG_BLOCK), 0, ctx().stream, a);
+        } else {
             const int64_t want = ceil_div(a.n_chunks, LONG_BLOCK / 64);
             const int64_t G = std::min<int64_t>(want, (int64_t)ctx().num_cus);  // persistent: one 1024-thread workgroup per CU
             hipLaunchKernelGGL((k_mxv_long<T, MON, MUL, LONG_LDS_WORDS>), dim3((unsigned)G), dim3(LONG_BLOCK), 0, ctx().stream, a);

@@ -494,6 +494,12 @@ GB_Matrix_opaque *matrix_new(GrB_Type type, uint64_t nrows, uint64_t ncols)
     A->d_chunk_start = nullptr;
     A->d_chunk_len = nullptr;
     A->d_long_prefix = nullptr;
+    A->d_lcol = nullptr;
+    A->d_lval = nullptr;
+    A->d_vptr = nullptr;
+    A->d_unit_row = nullptr;
+    A->long_nnz = 0;
+    for (auto &x : A->unit_begin) x = 0;
     A->n_long = A->n_chunks = 0;
     A->split_state = 0;
     A->split_hot = false;
@@ -524,6 +530,14 @@ void matrix_invalidate_caches(GB_Matrix_opaque *A)
     dev_free(A->d_chunk_start);
     dev_free(A->d_chunk_len);
     dev_free(A->d_long_prefix);
+    dev_free(A->d_lcol);
+    dev_free(A->d_lval);
+    dev_free(A->d_vptr);
+    dev_free(A->d_unit_row);
+    A->d_lcol = nullptr;
+    A->d_lval = nullptr;
+    A->d_vptr = nullptr;
+    A->d_unit_row = nullptr;
     A->d_long_bits = nullptr;
     A->d_long_rows = nullptr;
     A->d_chunk_slot = nullptr;

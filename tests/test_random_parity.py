@@ -487,6 +487,7 @@ def test_long_rows_many_chunks(gb, seed, request):
         _lib.lib.GrX_option_set(b"split_min_nnz", 1)
         _lib.lib.GrX_option_set(b"split_min_len", 2)
         _lib.lib.GrX_option_set(b"push_mode", 0)
+        _lib.lib.GrX_option_set(b"long_kernel", 0 if seed in (1, 5) else 1)  # chunk kernel / class-partitioned kernel
         A = gb.Matrix.from_coo(rows, cols, vals, dtype=tname, nrows=m, ncols=n)
         u = gb.Vector.from_coo(ui, uv, dtype=tname, size=n)
         mk = gb.Vector.from_coo(mi, mv, dtype="BOOL", size=m)
@@ -498,3 +499,4 @@ def test_long_rows_many_chunks(gb, seed, request):
         _lib.lib.GrX_option_set(b"split_min_nnz", 1 << 22)
         _lib.lib.GrX_option_set(b"split_min_len", 256)
         _lib.lib.GrX_option_set(b"push_mode", 1)
+        _lib.lib.GrX_option_set(b"long_kernel", 1)
