@@ -181,14 +181,18 @@ struct GB_Matrix_opaque {
     int64_t *d_chunk_start;   // per chunk: first entry
     int32_t *d_chunk_len;     // per chunk: entries (<= PULL_CHUNK)
     int32_t *d_long_prefix;   // per 64-row group: number of long rows before it
-    // class-partitioned copy of the long rows (k_mxv_long_cls): entries grouped by column class ((code >> 5) & 7), then
-    // by long-row slot; virtual row v = class * n_long + slot spans [d_vptr[v], d_vptr[v+1]) of d_lcol / d_lval
+    // class-partitioned copy of the long rows (k_mxv_long_grp): items = at most LONG_ITEM entries of one (column class,
+    // long row), stored contiguously in d_lcol / d_lval from d_it_start[i] (multiple of 4), sorted by class, then falling length
     int32_t *d_lcol;
     void *d_lval;             // nullptr for iso matrices
-    int64_t *d_vptr;          // 8 * n_long + 1
-    int32_t *d_unit_row;      // per work unit (LONG_UNIT entries of one class): the class-relative row holding its first entry
-    int64_t unit_begin[9];    // units of class j are [unit_begin[j], unit_begin[j+1])
+    int64_t *d_it_start;
+    int32_t *d_it_len;
+    int32_t *d_it_slot;
+    int64_t *d_item_begin;    // device copy of item_begin
+    int64_t item_begin[9];    // items of class c are [item_begin[c], item_begin[c+1])
+    int64_t n_items;
     int64_t long_nnz;
+    int cls_lds_lim;          // codes below it are stored pre-translated to LDS slots in d_lcol
     int64_t n_long, n_chunks;
     int split_state;          // 0 = not analysed, 1 = enabled, -1 = not worth it
     bool split_hot;           // short_part's columns are hot-coded

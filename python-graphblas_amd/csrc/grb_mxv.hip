@@ -70,14 +70,18 @@ struct PullArgs {
     int64_t n_chunks, n_long;
     int64_t n_long_epi;  // long rows whose write rule the seams launch applies (extra workgroups behind the seam ones)
     const int32_t *long_prefix;  // per 64-row group: long rows before it (slot of a long row = prefix + rank in its word)
-    // class-partitioned long rows (k_mxv_long_cls)
+    // class-partitioned long rows (k_mxv_long_grp)
     const int32_t *lcol;
     const void *lval;
-    const int64_t *vptr;
-    const int32_t *unit_row;
-    int64_t unit_begin[9];
-    int64_t long_nnz;
-    uint32_t *long_act;     // per call: bit s = the mask admits long row s
+    const int64_t *it_start;
+    const int32_t *it_len;
+    const int32_t *it_slot;
+    int64_t item_begin[9];
+    int cls_lds_lim;           // codes below it are LDS-resident in their class's workgroups (and pre-translated in lcol)
+    const int64_t *class_off;  // per call with a mask: the admitted items of class c are [class_off[c], class_off[c+1]) of a
+                               // compacted copy of the item fields (it_start / it_len / it_slot then point to it); else nullptr
+    int long_has_known;        // u is full: an admitted long row certainly has a product (tl_has is preset, not stored per item)
+    uint32_t *long_act;        // per call: bit s = the mask admits long row s
     void *tl_val;           // per long row: product accumulator (identity-initialised)
     unsigned char *tl_has;  // per long row: any product present
     long long *dbg_times;  // GRB_DEBUG_FLAGS & 8: 10 phase timestamps per tile (thread 0)
@@ -667,25 +671,34 @@ __global__ __launch_bounds__(LONG_BLOCK) void k_mxv_long(const PullArgs a)
 // image head hold the 32 Ki hottest codes OF ITS CLASS -- 256 Ki distinct codes across the chip instead of 32 Ki.
 // (Placement only changes speed: any workgroup computes any class correctly.)
 //
-// Work is dealt in units of LONG_UNIT consecutive entries of a class (balanced no matter how the rows are cut); a
-// wavefront consumes its unit in windows of 64 x 8 entries like k_mxv_rows: row-start marks in LDS + max-scan give the
-// row of each entry, products fold per lane into per-wavefront LDS accumulators, and at the end of a window the (at most
-// 64) rows it touched are flushed to the long-row accumulators with one global atomic each.
+// The unit of work is an ITEM: at most LONG_ITEM entries of one (class, long row), stored contiguously, starts aligned
+// to 4 entries, items of a class sorted by falling length.  16 lanes take one item (four items per wavefront, of about
+// the same length): 8 consecutive entries per lane and step straight into registers, gathers, a fold in registers,
+// one butterfly reduction over the 16 lanes and ONE atomic into the row's accumulator.  With a mask the admitted items
+// are compacted per call (k_long_compact), so masked-out rows are neither streamed nor scheduled.
 // ---------------------------------------------------------------------------------------------------
-constexpr int LONG_UNIT = 2048;
+constexpr int LONG_ITEM = 1024;
+// codes the image head in LDS can hold per class x 8 classes: BOOL values are bit-packed (word w of a class = image word
+// 8 w + class), the others take one LDS slot of max(4, sizeof) bytes per code
+constexpr int64_t long_lds_codes(int type_size_bytes, bool is_bool, int lds_words)
+{
+    return is_bool ? (int64_t)lds_words * 256 : ((int64_t)lds_words * 4 / (type_size_bytes < 4 ? 4 : type_size_bytes)) * 8;
+}
+// A column code of the class-partitioned copy as the kernel reads it: c itself when it is gathered from the image, or
+// -2 - slot when it is resident in LDS (slot = ((c >> 8) << 5) | (c & 31) within its class; for BOOL the bit slot & 31
+// of LDS word slot >> 5); -1 = padding.  A negative code times the value size is out of range for the buffer gather.
+__device__ __forceinline__ int long_tcode(int c, int lds_lim) { return c < lds_lim ? -2 - (((c >> 8) << 5) | (c & 31)) : c; }
 
 template <typename T, int MONOID_CT, int MULT_CT, int LDS_WORDS>
-__global__ __launch_bounds__(LONG_BLOCK) void k_mxv_long_cls(const PullArgs a)
+__global__ __launch_bounds__(LONG_BLOCK) void k_mxv_long_grp(const PullArgs a)
 {
     using W = typename Widen<T>::type;
-    constexpr int EPL = 8, WIN = 64 * EPL, NWV = LONG_BLOCK / 64;
+    constexpr int EPL = 8, GL = 16, STEP = GL * EPL, NWV = LONG_BLOCK / 64;
     __shared__ uint32_t s_x[LDS_WORDS];
-    __shared__ __attribute__((aligned(16))) unsigned char s_mark[NWV][WIN];
-    __shared__ W s_acc[NWV][128];  // ids 1..64 of a window + one scratch slot per lane
-    __shared__ unsigned char s_has[NWV][128];
     const int monoid = MONOID_CT >= 0 ? MONOID_CT : a.monoid;
     const int mult = MULT_CT >= 0 ? MULT_CT : a.mult;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = lane >> 4, gl = lane & 15;
     const int cls = blockIdx.x & 7;
     const bool need_aval = a.need_aval != 0, need_uval = a.need_uval != 0;
     const bool stage_vals = need_aval && !a.a_iso;
@@ -695,13 +708,9 @@ __global__ __launch_bounds__(LONG_BLOCK) void k_mxv_long_cls(const PullArgs a)
     const __amdgpu_buffer_rsrc_t xbits_rs = make_rsrc(a.u_bits, a.u_full ? 0 : ((a.x_len + 63) >> 6) * 8);
     const __amdgpu_buffer_rsrc_t xvbits_rs = make_rsrc(a.u_valbits, a.u_valbits ? ((a.x_len + 63) >> 6) * 8 : 0);
     constexpr bool IS_BOOL = std::is_same<T, bool>::value;
-    // LDS residency of my class: BOOL values are bit-packed (word w of the class = image word 8 w + cls), the others
-    // take one LDS slot per code: slot ((c >> 8) << 5) | (c & 31) for the codes c with (c >> 5) & 7 == cls
+    // LDS residency of my class (the entries carry pre-translated codes, see long_tcode)
     constexpr int LDS_SLOTS = IS_BOOL ? LDS_WORDS : (int)((int64_t)LDS_WORDS * 4 / (int64_t)(sizeof(T) < 4 ? 4 : sizeof(T)));
-    const bool use_lds = need_uval && !(a.dbg & 4096);
-    // codes below lds_lim whose slot is below LDS_SLOTS are resident
-    const int64_t lds_lim_codes = IS_BOOL ? (int64_t)LDS_SLOTS * 256 : (int64_t)LDS_SLOTS * 8;
-    const int lds_lim = use_lds ? (int)(a.x_len < lds_lim_codes ? a.x_len : lds_lim_codes) : 0;
+    const bool use_lds = need_uval && a.cls_lds_lim > 0;
     if (use_lds) {
         if constexpr (IS_BOOL) {
             for (int w = threadIdx.x; w < LDS_SLOTS; w += LONG_BLOCK) s_x[w] = buf_load<uint32_t>(xvbits_rs, (unsigned)((w << 3) | cls) * 4u);
@@ -715,166 +724,135 @@ __global__ __launch_bounds__(LONG_BLOCK) void k_mxv_long_cls(const PullArgs a)
             }
         }
     }
-    s_acc[wave][lane] = monoid_identity<T, W>(monoid);
-    s_acc[wave][64 + lane] = monoid_identity<T, W>(monoid);
-    s_has[wave][lane] = 0;
-    s_has[wave][64 + lane] = 0;
     __syncthreads();
 
-    const int64_t nl = a.n_long;
-    const int64_t *vp = a.vptr + (int64_t)cls * nl;  // class-relative row (= long-row slot) -> first entry
-    const int64_t cls_begin = a.vptr[(int64_t)cls * nl], cls_end = a.vptr[(int64_t)(cls + 1) * nl];
-    const int64_t ub = a.unit_begin[cls], ue = a.unit_begin[cls + 1];
+    // my class's items: [ib, ib + n_it) of the field arrays (with a mask: of their compacted copy)
+    const int64_t ib = a.class_off ? a.class_off[cls] : a.item_begin[cls];
+    const int64_t n_it = (a.class_off ? a.class_off[cls + 1] : a.item_begin[cls + 1]) - ib;
     const int64_t nblk = ((int64_t)gridDim.x - cls + 7) >> 3;  // workgroups of my class
     const int64_t wv = (int64_t)(blockIdx.x >> 3) * NWV + wave, nwv = nblk * NWV;
     W *tl = (W *)a.tl_val;
-    const int e0 = lane * EPL;
 
-    // One flat loop over the windows of my units.  The loads of a window (my entries, the starts of the 64 rows after
-    // `rcur`, the mask's verdict on rows rcur .. rcur+63) are issued one window ahead -- where the next window begins is
-    // known as soon as the row starts of the current one have arrived -- so they are in flight while the current window
-    // does its marks, scan, gathers, fold and flush.
-    int64_t u = ub + wv;
-    if (u >= ue) return;
-    int64_t pos = cls_begin + (u - ub) * LONG_UNIT;
-    int64_t uend = pos + LONG_UNIT < cls_end ? pos + LONG_UNIT : cls_end;
-    int64_t rcur = a.unit_row[u];  // the last row that starts at or before pos
-    int next_unit_row = (u + nwv < ue) ? a.unit_row[u + nwv] : 0;
-    int n_creg[EPL];
-    T n_vreg[EPL];
-    int64_t n_st;
-    bool n_act;
-#define CLS_WINDOW_LOADS(POS, RCUR)                                                                                          \
-    do {                                                                                                                     \
-        const int64_t left_ = a.long_nnz - (POS);                                                                            \
-        const __amdgpu_buffer_rsrc_t crs_ = make_rsrc(a.lcol + (POS), left_ * 4);                                            \
-        const __amdgpu_buffer_rsrc_t vrs_ = make_rsrc(lval + (stage_vals ? (POS) : 0), stage_vals ? left_ * (int64_t)sizeof(T) : 0); \
-        if (left_ >= (int64_t)WIN + 4) { /* 16-byte loads never straddle the end of the arrays */                            \
-            _Pragma("unroll") for (int q_ = 0; q_ < EPL / 4; q_++) {                                                         \
-                const auto c4_ = __builtin_amdgcn_raw_buffer_load_b128(crs_, (unsigned)(e0 + q_ * 4) * 4u, 0, 0);            \
-                _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++) n_creg[q_ * 4 + i_] = (int)c4_[i_];                         \
-                if constexpr (sizeof(T) == 4) {                                                                              \
-                    const auto v4_ = __builtin_amdgcn_raw_buffer_load_b128(vrs_, (unsigned)(e0 + q_ * 4) * 4u, 0, 0);        \
-                    _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++) n_vreg[q_ * 4 + i_] = __builtin_bit_cast(T, (unsigned int)v4_[i_]); \
-                } else {                                                                                                     \
-                    _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++)                                                         \
-                        n_vreg[q_ * 4 + i_] = buf_load<T>(vrs_, (unsigned)(e0 + q_ * 4 + i_) * (unsigned)sizeof(T));         \
-                }                                                                                                            \
-            }                                                                                                                \
-        } else {                                                                                                             \
-            _Pragma("unroll") for (int i_ = 0; i_ < EPL; i_++) {                                                             \
-                n_creg[i_] = buf_load<int>(crs_, (unsigned)(e0 + i_) * 4u);                                                  \
-                n_vreg[i_] = buf_load<T>(vrs_, (unsigned)(e0 + i_) * (unsigned)sizeof(T));                                   \
-            }                                                                                                                \
-        }                                                                                                                    \
-        const int64_t rr_ = (RCUR) + 1 + lane;                                                                               \
-        n_st = vp[rr_ < nl ? rr_ : nl];                                                                                      \
-        const int64_t ra_ = (RCUR) + lane;                                                                                   \
-        n_act = ra_ < nl && ((a.long_act[ra_ >> 5] >> (ra_ & 31)) & 1u);                                                     \
+    // Software pipeline over the steps (4 items x 128 entries) of my quads: the item fields of quad q+1 and the entries of
+    // the NEXT step (of this quad or the first of the next one) are requested before the gathers of the current step, so a
+    // step waits for one memory round trip (its gathers), not three.
+    int64_t f_st = 0, n_st = 0;
+    int f_len = 0, f_slot = 0, n_len = 0, n_slot = 0;
+#define GRP_ITEM_LOADS(Q)                                                  \
+    do {                                                                   \
+        const int64_t k_ = (Q) * 4 + grp;                                  \
+        n_st = 0; n_len = 0; n_slot = 0;                                   \
+        if (k_ < n_it) {                                                   \
+            const int64_t it_ = ib + k_;                                   \
+            n_st = a.it_start[it_];                                        \
+            n_len = a.it_len[it_];                                         \
+            n_slot = a.it_slot[it_];                                       \
+        }                                                                  \
     } while (0)
-
-    CLS_WINDOW_LOADS(pos, rcur);
+    int n_c[EPL];
+    T n_v[EPL];
+#define GRP_ENTRY_LOADS(ST, BASE)                                                                   \
+    do {                                                                                            \
+        const int32_t *cp_ = a.lcol + ((a.dbg & 2) ? (int64_t)(lane * 8) : (ST) + gl * EPL + (BASE)); /* (2: diagnostic, no streaming) */ \
+        _Pragma("unroll") for (int q_ = 0; q_ < EPL / 4; q_++) {                                    \
+            const uint4 c4_ = *(const uint4 *)(cp_ + q_ * 4);                                       \
+            n_c[q_ * 4 + 0] = (int)c4_.x; n_c[q_ * 4 + 1] = (int)c4_.y;                             \
+            n_c[q_ * 4 + 2] = (int)c4_.z; n_c[q_ * 4 + 3] = (int)c4_.w;                             \
+        }                                                                                           \
+        if (stage_vals) {                                                                           \
+            const T *vp_ = lval + ((a.dbg & 2) ? (int64_t)(lane * 8) : (ST) + gl * EPL + (BASE));   \
+            if constexpr (sizeof(T) == 4) {                                                         \
+                _Pragma("unroll") for (int q_ = 0; q_ < EPL / 4; q_++) {                            \
+                    const uint4 v4_ = *(const uint4 *)(vp_ + q_ * 4);                               \
+                    n_v[q_ * 4 + 0] = __builtin_bit_cast(T, v4_.x); n_v[q_ * 4 + 1] = __builtin_bit_cast(T, v4_.y); \
+                    n_v[q_ * 4 + 2] = __builtin_bit_cast(T, v4_.z); n_v[q_ * 4 + 3] = __builtin_bit_cast(T, v4_.w); \
+                }                                                                                   \
+            } else {                                                                                \
+                _Pragma("unroll") for (int i_ = 0; i_ < EPL; i_++) n_v[i_] = vp_[i_];               \
+            }                                                                                       \
+        } else {                                                                                    \
+            _Pragma("unroll") for (int i_ = 0; i_ < EPL; i_++) n_v[i_] = iso_v;                     \
+        }                                                                                           \
+    } while (0)
+    const bool ident_fold = monoid == OP_MIN || monoid == OP_MAX || monoid == OP_LOR || monoid == OP_LAND;
+    const T ident = from_acc<T, W>(monoid_identity<T, W>(monoid));
+    int64_t q = wv;
+    if (q * 4 >= n_it) return;
+    GRP_ITEM_LOADS(q);
+    f_st = n_st; f_len = n_len; f_slot = n_slot;
+    if ((q + nwv) * 4 < n_it) GRP_ITEM_LOADS(q + nwv);
+    GRP_ENTRY_LOADS(f_st, 0);
     for (;;) {
-        int creg[EPL];
-        T vreg[EPL];
-#pragma unroll
-        for (int i = 0; i < EPL; i++) { creg[i] = n_creg[i]; vreg[i] = n_vreg[i]; }
-        const int64_t st = n_st;
-        const unsigned long long actmask = __ballot(n_act);  // bit l <-> row rcur + l <-> id l + 1
-        int wl = (int)((pos + WIN < uend ? pos + WIN : uend) - pos);
-        const int st_rel = (st - pos > (int64_t)WIN) ? WIN + 1 : (int)(st - pos);  // (>= 0)
-        const int st63 = __builtin_amdgcn_readfirstlane(__shfl(st_rel, 63));
-        if (st63 < wl) wl = st63;  // more than 63 rows start inside: cut the window where the 64th starts
-        // ---- where the next window begins; its loads go out now ----------------------------------------------------------
-        const int64_t rcur_here = rcur;
-        bool more = true;
-        if (wl <= 0) {  // 64 rows without entries at this position: nothing to do here but step over them
-            rcur += 64;
-            wl = 0;
-        } else {
-            rcur += __popcll(__ballot(st_rel <= wl));  // the last row that starts at or before the next position
+        const int64_t st = f_st;
+        const int len = f_len, slot = f_slot;
+        const bool more = (q + nwv) * 4 < n_it;
+        int maxlen = len;
+        {
+            const int o1 = __shfl_xor(maxlen, 16);
+            maxlen = maxlen > o1 ? maxlen : o1;
+            const int o2 = __shfl_xor(maxlen, 32);
+            maxlen = maxlen > o2 ? maxlen : o2;
+            maxlen = __builtin_amdgcn_readfirstlane(maxlen);
         }
-        pos += wl;
-        if (pos >= uend) {
-            u += nwv;
-            if (u < ue) {
-                pos = cls_begin + (u - ub) * LONG_UNIT;
-                uend = pos + LONG_UNIT < cls_end ? pos + LONG_UNIT : cls_end;
-                rcur = next_unit_row;
-                next_unit_row = (u + nwv < ue) ? a.unit_row[u + nwv] : 0;
-            } else {
-                more = false;
-            }
-        }
-        if (more) CLS_WINDOW_LOADS(pos, rcur);
-        if (wl > 0) {
-            const int nxt = __shfl_down(st_rel, 1);
-            const bool starter = lane < 63 && st_rel < wl && nxt > st_rel;  // a non-empty row starts inside the window
-            // ---- row of each entry: marks + wavefront max-scan (id 1 = row rcur, id l + 2 = row rcur + 1 + l) ---------
-            using MarkWord = typename std::conditional<EPL == 8, uint64_t, uint32_t>::type;
-            *(MarkWord *)&s_mark[wave][lane * EPL] = 0;
-            wave_sync();
-            if (starter) s_mark[wave][st_rel] = (unsigned char)(lane + 2);
-            wave_sync();
-            const uint64_t mk = *(const MarkWord *)&s_mark[wave][lane * EPL];
-            int h[EPL];
-#pragma unroll
-            for (int i = 0; i < EPL; i++) h[i] = (int)((mk >> (8 * i)) & 0xffu);
-            int lastk = 0;
-#pragma unroll
-            for (int i = 0; i < EPL; i++) lastk = h[i] ? h[i] : lastk;
-            int incl = lastk;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const int t = __shfl_up(incl, off);
-                if (lane >= off) incl = incl > t ? incl : t;
-            }
-            int e = __shfl_up(incl, 1);
-            if (lane == 0 || e == 0) e = 1;
-            int ek[EPL], cc[EPL];
+        T acc = ident_fold ? ident : (T)0;
+        bool has = false;
+        for (int base = 0; base < maxlen; base += STEP) {
+            int cc[EPL];
+            T av[EPL];
 #pragma unroll
             for (int i = 0; i < EPL; i++) {
-                e = h[i] ? h[i] : e;
-                ek[i] = e;
-                cc[i] = (e0 + i < wl && ((actmask >> (e - 1)) & 1ull)) ? creg[i] : -1;
+                cc[i] = (base + gl * EPL + i < len) ? n_c[i] : -1;  // (entries past my item belong to others: discarded)
+                av[i] = n_v[i];
             }
-            if (a.dbg & (16384 | 32768)) {  // diagnostic: fold every gather into the first 2^19 / 2^15 entries of the image
-                const int gmask = (a.dbg & 16384) ? 0x7ffff : 0x7fff;
-#pragma unroll
-                for (int i = 0; i < EPL; i++) cc[i] = cc[i] >= 0 ? (cc[i] & gmask) : -1;
+            // the next step's entries travel behind this step's gathers
+            if (base + STEP < maxlen) {
+                GRP_ENTRY_LOADS(st, base + STEP);
+            } else if (more) {
+                f_st = n_st; f_len = n_len; f_slot = n_slot;  // (requested one quad ago)
+                GRP_ENTRY_LOADS(f_st, 0);
+                if ((q + 2 * nwv) * 4 < n_it) GRP_ITEM_LOADS(q + 2 * nwv);
             }
-            // ---- gathers: presence words, then values (LDS for the resident codes of my class, else the image) ---------
+            // cc: >= 0 a code to gather from the image, <= -2 an LDS slot, -1 nothing
             bool xp[EPL];
             T xv[EPL];
             if (a.u_full) {
 #pragma unroll
-                for (int i = 0; i < EPL; i++) xp[i] = cc[i] >= 0;
+                for (int i = 0; i < EPL; i++) xp[i] = cc[i] != -1;
             } else {
+                // presence words come from the image for every entry; a resident code is translated back first (its class is
+                // the workgroup's): c = ((slot >> 5) << 8) | (cls << 5) | (slot & 31)
+                int co[EPL];
                 uint32_t bw[EPL];
 #pragma unroll
-                for (int i = 0; i < EPL; i++) bw[i] = buf_load<uint32_t>(xbits_rs, (unsigned)(cc[i] >> 5) * 4u);
+                for (int i = 0; i < EPL; i++) {
+                    const int sl = -2 - cc[i];
+                    co[i] = cc[i] < -1 ? (((sl >> 5) << 8) | (cls << 5) | (sl & 31)) : cc[i];
+                    bw[i] = buf_load<uint32_t>(xbits_rs, (unsigned)(co[i] >> 5) * 4u);  // (-1: out of range, reads 0)
+                }
 #pragma unroll
-                for (int i = 0; i < EPL; i++) xp[i] = (bw[i] >> (cc[i] & 31)) & 1u;
+                for (int i = 0; i < EPL; i++) xp[i] = (bw[i] >> (co[i] & 31)) & 1u;
             }
             if (need_uval && !(a.dbg & 8192)) {
                 if constexpr (IS_BOOL) {
                     uint32_t vw[EPL];
 #pragma unroll
-                    for (int i = 0; i < EPL; i++) vw[i] = buf_load<uint32_t>(xvbits_rs, (xp[i] && cc[i] >= lds_lim) ? (unsigned)(cc[i] >> 5) * 4u : 0xfffffff8u);
+                    for (int i = 0; i < EPL; i++) vw[i] = buf_load<uint32_t>(xvbits_rs, xp[i] ? (unsigned)(cc[i] >> 5) * 4u : 0xfffffff8u);
 #pragma unroll
                     for (int i = 0; i < EPL; i++) {
-                        const bool in_lds = xp[i] && cc[i] < lds_lim;
-                        const uint32_t wv32 = in_lds ? s_x[cc[i] >> 8] : vw[i];
-                        xv[i] = (wv32 >> (cc[i] & 31)) & 1u;
+                        const bool in_lds = cc[i] < -1;
+                        const int sl = in_lds ? -2 - cc[i] : 0;
+                        const uint32_t wv32 = in_lds ? s_x[sl >> 5] : vw[i];
+                        const int bit = in_lds ? (sl & 31) : (cc[i] & 31);
+                        xv[i] = (wv32 >> bit) & 1u;
                     }
                 } else {
                     T xg[EPL];
 #pragma unroll
-                    for (int i = 0; i < EPL; i++) xg[i] = buf_load<T>(xval_rs, (xp[i] && cc[i] >= lds_lim) ? (unsigned)cc[i] * (unsigned)sizeof(T) : 0xfffffff8u);
+                    for (int i = 0; i < EPL; i++) xg[i] = buf_load<T>(xval_rs, (unsigned)cc[i] * (unsigned)sizeof(T));  // (negative: out of range)
 #pragma unroll
                     for (int i = 0; i < EPL; i++) {
-                        const bool in_lds = xp[i] && cc[i] < lds_lim;
-                        const int li = in_lds ? (((cc[i] >> 8) << 5) | (cc[i] & 31)) : 0;
+                        const bool in_lds = cc[i] < -1;
+                        const int li = in_lds ? -2 - cc[i] : 0;
                         T xl;
                         if constexpr (sizeof(T) == 8) xl = ((const T *)s_x)[li];
                         else if constexpr (sizeof(T) == 4) xl = __builtin_bit_cast(T, s_x[li]);
@@ -886,37 +864,109 @@ __global__ __launch_bounds__(LONG_BLOCK) void k_mxv_long_cls(const PullArgs a)
 #pragma unroll
                 for (int i = 0; i < EPL; i++) xv[i] = (T)(need_uval ? 1 : 0);
             }
-            // ---- segmented fold of my entries into the window's row accumulators (as k_mxv_rows) -------------------------
-            T acc = (T)0;
-            bool has = false;
+            if (ident_fold) {
+                // monoids whose identity absorbs "nothing here" exactly: no presence-dependent select in the chain
 #pragma unroll
-            for (int i = 0; i < EPL; i++) {
-                const T av = need_aval ? (a.a_iso ? iso_v : vreg[i]) : (T)0;
-                const T prod = apply_binop<T>(mult, av, xv[i]);
-                const bool keep = has && (i > 0) && (h[i] == 0);
-                acc = xp[i] ? (keep ? apply_binop<T>(monoid, acc, prod) : prod) : (keep ? acc : (T)0);
-                has = xp[i] || keep;
-                const bool seg_end = (i == EPL - 1) ? true : (h[i + 1] != 0);
-                const int k = (seg_end && has) ? ek[i] - 1 : 64 + lane;
-                if (monoid == OP_ANY) s_acc[wave][k] = (W)acc;
-                else atomic_combine<W>(&s_acc[wave][k], (W)acc, monoid);
-                s_has[wave][k] = 1;
+                for (int i = 0; i < EPL; i++) {
+                    const T prod = apply_binop<T>(mult, need_aval ? av[i] : (T)0, xv[i]);
+                    acc = apply_binop<T>(monoid, acc, xp[i] ? prod : ident);
+                    has = has || xp[i];
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < EPL; i++) {
+                    const T prod = apply_binop<T>(mult, need_aval ? av[i] : (T)0, xv[i]);
+                    acc = xp[i] ? (has ? apply_binop<T>(monoid, acc, prod) : prod) : acc;
+                    has = has || xp[i];
+                }
             }
-            wave_sync();
-            // ---- flush: lane l owns id l + 1 = row rcur_here + l ------------------------------------------------------------
-            if (s_has[wave][lane]) {
-                const W v = s_acc[wave][lane];
-                if (monoid == OP_ANY) tl[rcur_here + lane] = v;
-                else atomic_combine<W>(&tl[rcur_here + lane], v, monoid);
-                a.tl_has[rcur_here + lane] = 1;
-                s_acc[wave][lane] = monoid_identity<T, W>(monoid);
-                s_has[wave][lane] = 0;
+        }
+        // butterfly over my 16 lanes (value + presence), one atomic per item
+        int hasi = (has && !(a.dbg & 4)) ? 1 : 0;
+#pragma unroll
+        for (int off = GL / 2; off > 0; off >>= 1) {
+            const T o = __shfl_xor(acc, off);
+            const int oh = __shfl_xor(hasi, off);
+            if (oh) {
+                acc = hasi ? apply_binop<T>(monoid, acc, o) : o;
+                hasi = 1;
             }
-            wave_sync();
+        }
+        if (gl == 0 && hasi) {
+            if (monoid == OP_ANY) tl[slot] = (W)acc;
+            else atomic_combine<W>(&tl[slot], (W)acc, monoid);
+            if (!a.long_has_known) a.tl_has[slot] = 1;
         }
         if (!more) break;
+        q += nwv;
     }
-#undef CLS_WINDOW_LOADS
+#undef GRP_ENTRY_LOADS
+#undef GRP_ITEM_LOADS
+}
+
+// per call with a mask: the (start, length, slot) of the admitted items, compacted in order (classes stay contiguous,
+// lengths stay sorted): admitted items per 1024-item block -> scan -> write; class_off[c] = admitted items before class c
+constexpr int COMPACT_BLOCK = 1024;
+__global__ __launch_bounds__(256) void k_long_compact_count(const int32_t *it_slot, int64_t n_items, const uint32_t *long_act, int64_t *block_cnt)
+{
+    __shared__ int s_cnt[4];
+    const int64_t b0 = (int64_t)blockIdx.x * COMPACT_BLOCK;
+    int c = 0;
+    for (int k = 0; k < COMPACT_BLOCK / 256; k++) {
+        const int64_t i = b0 + k * 256 + threadIdx.x;
+        bool act = false;
+        if (i < n_items) {
+            const int s = it_slot[i];
+            act = (long_act[s >> 5] >> (s & 31)) & 1u;
+        }
+        c += __popcll(__ballot(act));
+    }
+    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        block_cnt[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        if (blockIdx.x == gridDim.x - 1) block_cnt[gridDim.x] = 0;
+    }
+}
+__global__ __launch_bounds__(256) void k_long_compact_write(const int32_t *it_slot, int64_t n_items, const uint32_t *long_act,
+                                                            const int64_t *block_off, const int64_t *item_begin_dev,
+                                                            const int64_t *it_start, const int32_t *it_len, int64_t *act_start,
+                                                            int32_t *act_len, int32_t *act_slot, int64_t *class_off)
+{
+    __shared__ int s_cnt[4];
+    const int64_t b0 = (int64_t)blockIdx.x * COMPACT_BLOCK;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int64_t off = block_off[blockIdx.x];
+    for (int k = 0; k < COMPACT_BLOCK / 256; k++) {
+        const int64_t i = b0 + k * 256 + threadIdx.x;
+        bool act = false;
+        int s = 0;
+        if (i < n_items) {
+            s = it_slot[i];
+            act = (long_act[s >> 5] >> (s & 31)) & 1u;
+        }
+        const unsigned long long m = __ballot(act);
+        if (lane == 0) s_cnt[wave] = __popcll(m);
+        __syncthreads();
+        int before = 0;
+        for (int w = 0; w < wave; w++) before += s_cnt[w];
+        const int64_t rank = off + before + __popcll(m & ((1ull << lane) - 1ull));  // admitted items before item i
+        if (act) {  // the kernel reads the fields of admitted item number `rank` without an indirection
+            act_start[rank] = it_start[i];
+            act_len[rank] = it_len[i];
+            act_slot[rank] = s;
+        }
+        if (i < n_items) {
+            for (int c = 0; c < 9; c++)
+                if (item_begin_dev[c] == i) class_off[c] = rank;
+        }
+        off += s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        __syncthreads();
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        for (int c = 0; c < 9; c++)
+            if (item_begin_dev[c] >= n_items) class_off[c] = off;  // (classes that begin at the end of the list)
+    }
 }
 
 // the write rule for one long row (run by the extra workgroups of the seams launch, after both kernels)
@@ -941,19 +991,20 @@ __device__ __forceinline__ void long_row_write(const PullArgs &a, int64_t slot)
 // per call: long-row accumulators at the monoid identity; bit s of long_act = the mask admits long row s
 template <typename W>
 __global__ void k_long_init(W *tl_val, unsigned char *tl_has, int64_t n, W identity, const int32_t *long_rows, const uint64_t *m_bits,
-                            int has_mask, int m_comp, uint32_t *long_act)
+                            int has_mask, int m_comp, uint32_t *long_act, int has_known)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool act = false;
     if (i < n) {
         tl_val[i] = identity;
-        tl_has[i] = 0;
         act = true;
         if (has_mask) {
             const int64_t row = long_rows[i];
             act = (m_bits[row >> 6] >> (row & 63)) & 1ull;
             if (m_comp) act = !act;
         }
+        // has_known: every entry of an admitted long row meets a present u entry, so the row has a product
+        tl_has[i] = (has_known && act) ? 1 : 0;
     }
     const unsigned long long b = __ballot(act);
     const int lane = threadIdx.x & 63;
@@ -1208,7 +1259,7 @@ __global__ void k_split_fill(const int64_t *ptr, const int32_t *col, const T *va
 
 // class partition of the long rows (once per matrix): sort key = class * n_long + slot of every entry of a long row
 __global__ void k_long_keys(const int64_t *ptr, const int64_t *sptr, const int32_t *long_rows, const int32_t *col, int64_t n_long,
-                            uint64_t *keys, uint32_t *idx)
+                            uint64_t *keys, uint32_t *idx, unsigned hot_k, unsigned cold_per_class)
 {
     const int64_t s = blockIdx.x;
     const int64_t row = long_rows[s];
@@ -1216,7 +1267,12 @@ __global__ void k_long_keys(const int64_t *ptr, const int64_t *sptr, const int32
     const int64_t o = b - sptr[row];  // entries of long rows before this one
     for (int64_t i = threadIdx.x; i < len; i += blockDim.x) {
         const unsigned c = (unsigned)col[b + i];
-        keys[o + i] = (uint64_t)((c >> 5) & 7u) * (uint64_t)n_long + (uint64_t)s;
+        // class: codes of the hot table interleave by 128-byte line (every class gets the same heat, and its hottest codes
+        // fill its workgroups' LDS); the columns behind it split into 8 contiguous ranges (one eighth of the address range
+        // per XCD: fewer pages and L2 lines per class than interleaving them too)
+        unsigned cls = c < hot_k ? ((c >> 5) & 7u) : (c - hot_k) / cold_per_class;
+        cls = cls > 7u ? 7u : cls;
+        keys[o + i] = (uint64_t)cls * (uint64_t)n_long + (uint64_t)s;
         idx[o + i] = (uint32_t)(b + i);
     }
 }
@@ -1242,23 +1298,74 @@ __global__ void k_long_vptr(const uint64_t *keys, int64_t n, int64_t nv, int64_t
     }
     vptr[v] = lo;
 }
-struct UnitBegin { int64_t v[9]; };
-// unit_row[u] = the last row of the unit's class that starts at or before the unit's first entry
-__global__ void k_long_units(const int64_t *vptr, int64_t n_long, UnitBegin ub, int32_t *unit_row)
+// items of virtual row v (class * n_long + slot): pieces of at most LONG_ITEM entries
+__global__ void k_long_item_count(const int64_t *vptr, int64_t nv, int64_t *cnt)
 {
-    const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= ub.v[8]) return;
-    int cls = 0;
-    while (u >= ub.v[cls + 1]) cls++;
-    const int64_t *vp = vptr + (int64_t)cls * n_long;
-    const int64_t pos = vp[0] + (u - ub.v[cls]) * LONG_UNIT;
-    int64_t lo = 0, hi = n_long;  // first row with start > pos
+    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v > nv) return;
+    cnt[v] = v < nv ? (vptr[v + 1] - vptr[v] + LONG_ITEM - 1) / LONG_ITEM : 0;
+}
+// sort key of an item: class, then falling length
+__global__ void k_long_item_fill(const int64_t *vptr, int64_t nv, int64_t n_long, const int64_t *ioff, uint64_t *key, uint32_t *id,
+                                 int64_t *src, int32_t *len, int32_t *slot)
+{
+    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nv) return;
+    const int64_t b = vptr[v], total = vptr[v + 1] - b;
+    int64_t it = ioff[v];
+    for (int64_t off = 0; off < total; off += LONG_ITEM, it++) {
+        const int l = (int)(total - off < LONG_ITEM ? total - off : LONG_ITEM);
+        key[it] = ((uint64_t)(v / n_long) << 11) | (uint64_t)(LONG_ITEM - l);
+        id[it] = (uint32_t)it;
+        src[it] = b + off;
+        len[it] = l;
+        slot[it] = (int32_t)(v % n_long);
+    }
+}
+// items in sorted order: fields + padded length (starts are multiples of 4 entries)
+__global__ void k_long_item_order(const uint32_t *order, int64_t n_items, const int64_t *src, const int32_t *len, const int32_t *slot,
+                                  int64_t *o_src, int32_t *o_len, int32_t *o_slot, int64_t *o_len4)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n_items) return;
+    if (i == n_items) { o_len4[i] = 0; return; }
+    const uint32_t j = order[i];
+    o_src[i] = src[j];
+    o_len[i] = len[j];
+    o_slot[i] = slot[j];
+    o_len4[i] = (len[j] + 3) & ~3;
+}
+// first sorted item of class c (c = 0 .. 8)
+__global__ void k_long_class_bounds(const uint64_t *skeys, int64_t n_items, int64_t *bounds)
+{
+    const int c = threadIdx.x;
+    if (c > 8) return;
+    int64_t lo = 0, hi = n_items;
     while (lo < hi) {
         const int64_t mid = (lo + hi) >> 1;
-        if (vp[mid] <= pos) lo = mid + 1;
+        if ((skeys[mid] >> 11) < (uint64_t)c) lo = mid + 1;
         else hi = mid;
     }
-    unit_row[u] = (int32_t)(lo - 1);
+    bounds[c] = lo;
+}
+// the entries of item i go to [it_start[i], it_start[i] + len4): one wavefront per item
+template <typename T>
+__global__ void k_long_place(const int64_t *it_start, const int64_t *it_src, const int32_t *it_len, const uint32_t *idx,
+                             const int32_t *col, const T *val, int iso, int32_t *lcol, T *lval, int lds_lim)
+{
+    const int64_t i = blockIdx.x;
+    const int64_t dst = it_start[i], src = it_src[i];
+    const int len = it_len[i], len4 = (len + 3) & ~3;
+    for (int e = threadIdx.x; e < len4; e += blockDim.x) {
+        if (e < len) {
+            const uint32_t j = idx[src + e];
+            lcol[dst + e] = long_tcode(col[j], lds_lim);
+            if (!iso) lval[dst + e] = val[j];
+        } else {
+            lcol[dst + e] = -1;
+            if (!iso) lval[dst + e] = (T)0;
+        }
+    }
 }
 
 // One wavefront per tile whose first row began in earlier tiles: fold the carries of tiles
@@ -1581,8 +1688,10 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
         matrix_free(A->short_part);
         A->short_part = nullptr;
         dev_free(A->d_long_bits); dev_free(A->d_long_rows); dev_free(A->d_chunk_slot); dev_free(A->d_chunk_start); dev_free(A->d_chunk_len); dev_free(A->d_long_prefix);
-        dev_free(A->d_lcol); dev_free(A->d_lval); dev_free(A->d_vptr); dev_free(A->d_unit_row);
-        A->d_lcol = nullptr; A->d_lval = nullptr; A->d_vptr = nullptr; A->d_unit_row = nullptr; A->long_nnz = 0;
+        dev_free(A->d_lcol); dev_free(A->d_lval); dev_free(A->d_it_start); dev_free(A->d_it_len); dev_free(A->d_it_slot);
+        dev_free(A->d_item_begin);
+        A->d_lcol = nullptr; A->d_lval = nullptr; A->d_it_start = nullptr; A->d_it_len = nullptr; A->d_it_slot = nullptr;
+        A->d_item_begin = nullptr; A->long_nnz = 0; A->n_items = 0;
         A->d_long_prefix = nullptr;
         A->d_long_bits = nullptr; A->d_long_rows = nullptr; A->d_chunk_slot = nullptr; A->d_chunk_start = nullptr; A->d_chunk_len = nullptr;
     }
@@ -1621,42 +1730,66 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
                                (const int64_t *)S->d_ptr, (const int64_t *)lflag.p, (const int64_t *)nchunk.p, S->d_col,
                                (T *)S->d_val, A->d_long_rows, A->d_chunk_slot, A->d_chunk_start, A->d_chunk_len, A->d_long_prefix);
         })
-        // class-partitioned copy of the long rows
+        // class-partitioned copy of the long rows: sort the entries by (class, slot), cut the runs into items, sort the
+        // items by (class, falling length), lay them out with 4-entry aligned starts
         const int64_t nnz_long = nnz - nnz_short;
         A->long_nnz = 0;
-        if (nnz_long < 0xffffffffll && nnz < 0xffffffffll) {
+        A->n_items = 0;
+        if (nnz_long < 0xf0000000ll && nnz < 0xffffffffll) {
             const int64_t nv = 8 * nl;
             int bits = 1;
             while (((int64_t)1 << bits) < nv) bits++;
             DevBuf<uint64_t> keys(nnz_long), keys2(nnz_long);
             DevBuf<uint32_t> idx(nnz_long), idx2(nnz_long);
             hipLaunchKernelGGL(k_long_keys, dim3((unsigned)nl), dim3(256), 0, ctx().stream, (const int64_t *)A->d_ptr,
-                               (const int64_t *)S->d_ptr, (const int32_t *)A->d_long_rows, col_src, nl, keys.p, idx.p);
+                               (const int64_t *)S->d_ptr, (const int32_t *)A->d_long_rows, col_src, nl, keys.p, idx.p,
+                               (unsigned)(hot ? A->hot_k : 0), (unsigned)std::max<int64_t>(1, ceil_div((int64_t)A->ncols, 8)));
             prim_sort_pairs_u64_u32(keys.p, keys2.p, idx.p, idx2.p, nnz_long, bits);
-            A->d_lcol = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)nnz_long);
-            A->d_lval = A->iso ? nullptr : dev_alloc(A->type->size * (size_t)nnz_long);
-            GRB_DISPATCH_TYPE(A->type->code, T, {
-                hipLaunchKernelGGL((k_long_permute<T>), dim3((unsigned)ceil_div(nnz_long, 256)), dim3(256), 0, ctx().stream,
-                                   (const uint32_t *)idx2.p, nnz_long, col_src, (const T *)A->d_val, A->iso ? 1 : 0, A->d_lcol,
-                                   (T *)A->d_lval);
-            })
-            A->d_vptr = (int64_t *)dev_alloc(sizeof(int64_t) * (size_t)(nv + 1));
+            DevBuf<int64_t> vptr(nv + 1), icnt(nv + 1);
             hipLaunchKernelGGL(k_long_vptr, dim3((unsigned)ceil_div(nv + 1, 256)), dim3(256), 0, ctx().stream,
-                               (const uint64_t *)keys2.p, nnz_long, nv, A->d_vptr);
-            UnitBegin ub;
-            ub.v[0] = 0;
-            for (int c = 0; c < 8; c++) {
-                int64_t b0 = 0, b1 = 0;
-                d2h(&b0, A->d_vptr + (int64_t)c * nl, 8);
-                d2h(&b1, A->d_vptr + (int64_t)(c + 1) * nl, 8);
-                ub.v[c + 1] = ub.v[c] + ceil_div(b1 - b0, (int64_t)LONG_UNIT);
+                               (const uint64_t *)keys2.p, nnz_long, nv, vptr.p);
+            hipLaunchKernelGGL(k_long_item_count, dim3((unsigned)ceil_div(nv + 1, 256)), dim3(256), 0, ctx().stream,
+                               (const int64_t *)vptr.p, nv, icnt.p);
+            prim_exclusive_sum_i64(icnt.p, icnt.p, nv + 1);
+            int64_t ni = 0;
+            d2h(&ni, icnt.p + nv, 8);
+            if (ni > 0 && ni < 0x7fffffffll) {
+                DevBuf<uint64_t> ikey(ni), ikey2(ni);
+                DevBuf<uint32_t> iid(ni), iorder(ni);
+                DevBuf<int64_t> isrc(ni), osrc(ni), len4(ni + 1);
+                DevBuf<int32_t> ilen(ni), islot(ni);
+                hipLaunchKernelGGL(k_long_item_fill, dim3((unsigned)ceil_div(nv, 256)), dim3(256), 0, ctx().stream,
+                                   (const int64_t *)vptr.p, nv, nl, (const int64_t *)icnt.p, ikey.p, iid.p, isrc.p, ilen.p, islot.p);
+                prim_sort_pairs_u64_u32(ikey.p, ikey2.p, iid.p, iorder.p, ni, 14);
+                A->d_it_len = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)ni);
+                A->d_it_slot = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)ni);
+                A->d_it_start = (int64_t *)dev_alloc(sizeof(int64_t) * (size_t)(ni + 1));
+                hipLaunchKernelGGL(k_long_item_order, dim3((unsigned)ceil_div(ni + 1, 256)), dim3(256), 0, ctx().stream,
+                                   (const uint32_t *)iorder.p, ni, (const int64_t *)isrc.p, (const int32_t *)ilen.p,
+                                   (const int32_t *)islot.p, osrc.p, A->d_it_len, A->d_it_slot, len4.p);
+                prim_exclusive_sum_i64(len4.p, A->d_it_start, ni + 1);
+                int64_t padded = 0;
+                d2h(&padded, A->d_it_start + ni, 8);
+                A->d_item_begin = (int64_t *)dev_alloc(sizeof(int64_t) * 9);
+                hipLaunchKernelGGL(k_long_class_bounds, dim3(1), dim3(64), 0, ctx().stream, (const uint64_t *)ikey2.p, ni, A->d_item_begin);
+                d2h(A->item_begin, A->d_item_begin, sizeof(int64_t) * 9);
+                // (+2048 entries: a group's steps run to the longest item of its quad, i.e. past its own entries)
+                // only codes of the hot table are classed by line (k_long_keys): those may live in LDS
+                A->cls_lds_lim = (int)std::min<int64_t>(hot ? A->hot_k : 0,
+                                                        long_lds_codes((int)A->type->size, A->type->code == TC_BOOL, LONG_LDS_WORDS));
+                A->d_lcol = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)(padded + 2048));
+                A->d_lval = A->iso ? nullptr : dev_alloc(A->type->size * (size_t)(padded + 2048));
+                GRB_DISPATCH_TYPE(A->type->code, T, {
+                    hipLaunchKernelGGL((k_long_place<T>), dim3((unsigned)ni), dim3(64), 0, ctx().stream, (const int64_t *)A->d_it_start,
+                                       (const int64_t *)osrc.p, (const int32_t *)A->d_it_len, (const uint32_t *)idx2.p, col_src,
+                                       (const T *)A->d_val, A->iso ? 1 : 0, A->d_lcol, (T *)A->d_lval, A->cls_lds_lim);
+                })
+                GRB_HIP(hipMemsetAsync(A->d_lcol + padded, 0xff, sizeof(int32_t) * 2048, ctx().stream));
+                if (A->d_lval) GRB_HIP(hipMemsetAsync((char *)A->d_lval + A->type->size * (size_t)padded, 0, A->type->size * 2048, ctx().stream));
+                A->n_items = ni;
+                A->long_nnz = nnz_long;
+                sync_stream();  // (the temporaries above are released at the end of this scope)
             }
-            for (int c = 0; c < 9; c++) A->unit_begin[c] = ub.v[c];
-            A->d_unit_row = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)(ub.v[8] ? ub.v[8] : 1));
-            if (ub.v[8] > 0)
-                hipLaunchKernelGGL(k_long_units, dim3((unsigned)ceil_div(ub.v[8], 256)), dim3(256), 0, ctx().stream,
-                                   (const int64_t *)A->d_vptr, nl, ub, A->d_unit_row);
-            A->long_nnz = nnz_long;
         }
         sync_stream();
     } catch (...) {
@@ -1687,20 +1820,42 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
         DevBuf<uint32_t> long_act((size_t)ceil_div(a.n_long, 64) * 2);
         a.long_act = long_act.p;
         hipLaunchKernelGGL((k_long_init<W>), dim3((unsigned)ceil_div(a.n_long, 256)), dim3(256), 0, ctx().stream, tl_val.p, tl_has.p,
-                           a.n_long, monoid_identity<T, W>(a.monoid), a.long_rows, a.m_bits, a.has_mask, a.m_comp, long_act.p);
+                           a.n_long, monoid_identity<T, W>(a.monoid), a.long_rows, a.m_bits, a.has_mask, a.m_comp, long_act.p,
+                           (by_class && a.u_full) ? 1 : 0);
+        a.long_has_known = (by_class && a.u_full) ? 1 : 0;
         a.tl_val = tl_val.p;
         a.tl_has = tl_has.p;
         a.dbg = ctx().debug_flags;
+        const int64_t ncb = ceil_div(A->n_items, (int64_t)COMPACT_BLOCK);
+        const bool compact = by_class && a.has_mask;
+        DevBuf<int64_t> act_start(compact ? (size_t)A->n_items : 1), block_cnt(compact ? (size_t)ncb + 1 : 1), class_off(9);
+        DevBuf<int32_t> act_len(compact ? (size_t)A->n_items : 1), act_slot(compact ? (size_t)A->n_items : 1);
         if (by_class) {
             a.lcol = A->d_lcol;
             a.lval = A->d_lval;
-            a.vptr = A->d_vptr;
-            a.unit_row = A->d_unit_row;
-            a.long_nnz = A->long_nnz;
-            for (int c = 0; c < 9; c++) a.unit_begin[c] = A->unit_begin[c];
+            a.it_start = A->d_it_start;
+            a.it_len = A->d_it_len;
+            a.it_slot = A->d_it_slot;
+            for (int c = 0; c < 9; c++) a.item_begin[c] = A->item_begin[c];
+            a.cls_lds_lim = A->cls_lds_lim;
+            a.class_off = nullptr;
+            if (compact) {
+                hipLaunchKernelGGL(k_long_compact_count, dim3((unsigned)ncb), dim3(256), 0, ctx().stream, (const int32_t *)A->d_it_slot,
+                                   A->n_items, (const uint32_t *)long_act.p, block_cnt.p);
+                prim_exclusive_sum_i64(block_cnt.p, block_cnt.p, ncb + 1);
+                hipLaunchKernelGGL(k_long_compact_write, dim3((unsigned)ncb), dim3(256), 0, ctx().stream, (const int32_t *)A->d_it_slot,
+                                   A->n_items, (const uint32_t *)long_act.p, (const int64_t *)block_cnt.p,
+                                   (const int64_t *)A->d_item_begin, (const int64_t *)A->d_it_start, (const int32_t *)A->d_it_len,
+                                   act_start.p, act_len.p, act_slot.p, class_off.p);
+                a.it_start = act_start.p;
+                a.it_len = act_len.p;
+                a.it_slot = act_slot.p;
+                a.class_off = class_off.p;
+                ctx().stats.kernel_launches += 2;
+            }
             // one persistent 1024-thread workgroup per CU; block b works on column class b % 8 (= the XCD it runs on)
             const int64_t G = std::max<int64_t>(8, (int64_t)(ctx().num_cus / 8) * 8);
-            hipLaunchKernelGGL((k_mxv_long_cls<T, MON, MUL, LONG_LDS_WORDS>), dim3((unsigned)G), dim3(LONG_BLOCK), 0, ctx().stream, a);
+            hipLaunchKernelGGL((k_mxv_long_grp<T, MON, MUL, LONG_LDS_WORDS>), dim3((unsigned)G), dim3(LONG_BLOCK), 0, ctx().stream, a);
         } else {
             const int64_t want = ceil_div(a.n_chunks, LONG_BLOCK / 64);
             const int64_t G = std::min<int64_t>(want, (int64_t)ctx().num_cus);  // persistent: one 1024-thread workgroup per CU
@@ -1870,7 +2025,7 @@ static void mxv_core(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_Binar
     a.need_uval = !(mult == OP_PAIR || mult == OP_FIRST || mult == OP_ANY);
     if (mult == OP_ANY) a.need_aval = S->nvals > 0;
     a.x_len = (int64_t)u->n;
-    if ((uint64_t)u->n * type_size(st) >= 0xfffffff0ull)
+    if ((uint64_t)u->n * type_size(st) >= 0xff000000ull)
         fail(GrB_NOT_IMPLEMENTED, "mxv/vxm: input vectors of 4 GiB or more are not supported by the pull kernel yet");
     // hot-column table (wide matrices with a skewed column-degree distribution): the kernel indexes ONE image
     // [ K hot entries | the n entries of u ] with the re-coded column indices (hot rank, or K + col)
@@ -1878,7 +2033,7 @@ static void mxv_core(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_Binar
     DevBuf<uint64_t> xcat_bits(0);
     if (a.need_uval || !a.u_full) {
         ensure_hot(S, type_size(st));
-        if (S->hot_state == 1 && (uint64_t)(u->n + S->hot_k) * type_size(st) < 0xfffffff0ull) {
+        if (S->hot_state == 1 && (uint64_t)(u->n + S->hot_k) * type_size(st) < 0xff000000ull) {
             const int k = (int)S->hot_k;  // multiple of 64
             const size_t vb = type_size(st);
             char *img_val;

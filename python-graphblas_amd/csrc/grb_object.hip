@@ -496,10 +496,13 @@ GB_Matrix_opaque *matrix_new(GrB_Type type, uint64_t nrows, uint64_t ncols)
     A->d_long_prefix = nullptr;
     A->d_lcol = nullptr;
     A->d_lval = nullptr;
-    A->d_vptr = nullptr;
-    A->d_unit_row = nullptr;
+    A->d_it_start = nullptr;
+    A->d_it_len = nullptr;
+    A->d_it_slot = nullptr;
+    A->d_item_begin = nullptr;
     A->long_nnz = 0;
-    for (auto &x : A->unit_begin) x = 0;
+    A->n_items = 0;
+    for (auto &x : A->item_begin) x = 0;
     A->n_long = A->n_chunks = 0;
     A->split_state = 0;
     A->split_hot = false;
@@ -532,12 +535,18 @@ void matrix_invalidate_caches(GB_Matrix_opaque *A)
     dev_free(A->d_long_prefix);
     dev_free(A->d_lcol);
     dev_free(A->d_lval);
-    dev_free(A->d_vptr);
-    dev_free(A->d_unit_row);
+    dev_free(A->d_it_start);
+    dev_free(A->d_it_len);
+    dev_free(A->d_it_slot);
+    dev_free(A->d_item_begin);
     A->d_lcol = nullptr;
     A->d_lval = nullptr;
-    A->d_vptr = nullptr;
-    A->d_unit_row = nullptr;
+    A->d_it_start = nullptr;
+    A->d_it_len = nullptr;
+    A->d_it_slot = nullptr;
+    A->d_item_begin = nullptr;
+    A->long_nnz = 0;
+    A->n_items = 0;
     A->d_long_bits = nullptr;
     A->d_long_rows = nullptr;
     A->d_chunk_slot = nullptr;

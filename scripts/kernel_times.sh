@@ -8,7 +8,7 @@ for wl in ${WLS:-mxv_min_plus_masked mxv_min_plus mxv_lor_land_masked}; do
     python - "$OUT/$wl.$fl/b_kernel_stats.csv" <<'PY'
 import csv, sys
 for r in csv.DictReader(open(sys.argv[1])):
-    if "grb::k_mxv" in r["Name"] or "k_long_init" in r["Name"] or "grb::k_x_image" in r["Name"] or "rocclr" in r["Name"] or "k_fill_w" in r["Name"] or "k_vec_write" in r["Name"]:
+    if "grb::k_mxv" in r["Name"] or "k_long_" in r["Name"] or "grb::k_x_image" in r["Name"] or "rocclr" in r["Name"] or "k_fill_w" in r["Name"] or "k_vec_write" in r["Name"]:
         print("   ", r["Name"][:60].ljust(60), r["Calls"], round(float(r["AverageNs"]) / 1e3, 1), "us")
 PY
   done
