@@ -301,7 +301,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy_peak_6290": achieved / 6290.0,
                          "traffic": measured_traffic(workload, args.scale) if world == 1 else None,
-                         "kernel": "k_mxv_pull (+ k_mxv_seams)",
+                         "kernel": "one GrB_mxv call: k_mxv_long_grp + k_mxv_rows (+ k_x_image, k_long_init, k_long_compact_*); k_mxv_pull + k_mxv_seams below the split threshold",
                          "kernel_ms_hip_events": kernel_ms, "algorithmic_bytes_per_launch": wl.bytes_per_step()},
             "stats": device.last_stats(),
         }

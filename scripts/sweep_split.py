@@ -10,7 +10,7 @@ from graphblas_amd import _lib, device
 scale = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 gb.init()
 for name, sr, vis in (("min_plus_masked", "min_plus", 0.5), ("min_plus_unmasked", "min_plus", 0.0), ("lor_land_masked", "lor_land", 0.5)):
-    for min_len in (0, 64, 128, 256, 512, 1024, 4096):
+    for min_len in (64, 128, 192, 256, 384, 512):
         _lib.lib.GrX_option_set(b"split_min_nnz", (1 << 22) if min_len else (1 << 60))
         _lib.lib.GrX_option_set(b"split_min_len", max(min_len, 1))
         wl = bench.MxvWorkload(gb, torch, scale, 0, 1, sr, vis)
