@@ -115,6 +115,16 @@ class MxvWorkload:
         if world > 1:
             self.u_vals, _ = device.vector_device_views(self.u)
             self.w_vals, _ = device.vector_device_views(self.w)
+            # The collective normally lands directly in the replicated vector's HBM image (library memory from the
+            # stream-ordered HIP pool).  Should the RCCL build refuse those buffers, stage through torch-owned tensors.
+            self._staged = False
+            try:
+                torch.distributed.all_gather_into_tensor(self.u_vals, self.u_vals[lo:hi].clone())
+                torch.cuda.synchronize()
+            except RuntimeError:
+                self._staged = True
+                self._gather_buf = torch.empty_like(self.u_vals)
+                self._send_buf = torch.empty_like(self.w_vals)
 
     def step(self):
         rc = self._call(*self._args)
@@ -122,7 +132,12 @@ class MxvWorkload:
             raise RuntimeError(f"GrB_mxv failed with GrB_Info {rc}")
         if self.world > 1 and self.semiring == "min_plus":
             # next u = all ranks' w slices (u and w stay full, so only values travel; 4 B * n/N per rank)
-            self.torch.distributed.all_gather_into_tensor(self.u_vals, self.w_vals)
+            if self._staged:
+                self._send_buf.copy_(self.w_vals)
+                self.torch.distributed.all_gather_into_tensor(self._gather_buf, self._send_buf)
+                self.u_vals.copy_(self._gather_buf)
+            else:
+                self.torch.distributed.all_gather_into_tensor(self.u_vals, self.w_vals)
 
     def bytes_per_step(self):
         return algorithmic_bytes_mxv(self.nnz_active_local, self.m, self.n, self.v_a, self.v_u, self.v_w,

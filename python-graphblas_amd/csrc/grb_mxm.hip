@@ -305,7 +305,8 @@ __global__ __launch_bounds__(MM_BLOCK) void k_spgemm_spa(const MxmArgs a, const 
 // index (native LDS atomics, no probing), emits it with an ordered bitmap sweep (so T's rows come out sorted, at a
 // running offset) and recycles the accumulator -- no global atomics.  B's rows are sorted, so the part of B(k,:)
 // inside window w is the range [woff[k][w], woff[k][w+1]), cached with B.
-constexpr int MM_WIN = 8192;
+constexpr int MM_WIN = 16384;   // 128 KiB of 8-byte accumulators: one 1024-thread workgroup per CU
+constexpr int MM_WIN_BLOCK = 1024;
 
 __global__ void k_window_offsets(const int64_t *Bp, const int32_t *Bj, int64_t nrowsB, int n_win, int32_t *woff)
 {
@@ -328,63 +329,80 @@ __global__ void k_window_offsets(const int64_t *Bp, const int32_t *Bj, int64_t n
 }
 
 template <typename T>
-__global__ __launch_bounds__(MM_BLOCK) void k_spgemm_win(const MxmArgs a, const uint32_t *rows)
+__global__ __launch_bounds__(MM_WIN_BLOCK) void k_spgemm_win(const MxmArgs a, const uint32_t *rows)
 {
     using W = typename Widen<T>::type;
     __shared__ W s_acc[MM_WIN];
     __shared__ unsigned long long s_bits[MM_WIN / 64];
-    __shared__ int s_wave[MM_BLOCK / 64];
+    __shared__ int s_wave[MM_WIN_BLOCK / 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int monoid = a.monoid, mult = a.mult;
     const T *Ax = (const T *)a.Ax, *Bx = (const T *)a.Bx;
     const int64_t row = rows[blockIdx.x];
     const W ident = monoid_identity<T, W>(monoid);
-    for (int k = tid; k < MM_WIN; k += MM_BLOCK) s_acc[k] = ident;
+    for (int k = tid; k < MM_WIN; k += MM_WIN_BLOCK) s_acc[k] = ident;
     if (tid < MM_WIN / 64) s_bits[tid] = 0ull;
     __syncthreads();
-    constexpr int NG = MM_BLOCK / MM_GROUP;
-    const int g = tid / MM_GROUP, gl = tid % MM_GROUP;
+    __shared__ int s_scan[MM_WIN_BLOCK + 1];
+    __shared__ int64_t s_qb[MM_WIN_BLOCK];
     const int64_t pbeg = a.Ap[row], pend = a.Ap[row + 1];
     const int nwin = a.n_win;
     int64_t out = a.Tp[row];
     T *Tx = (T *)a.Tx;
     for (int w = 0; w < nwin; w++) {
         const int c0 = w * MM_WIN;
-        // products whose column falls in [c0, c0 + MM_WIN): MM_UNROLL entries of the row in flight per 16-lane group
-        for (int64_t p0 = pbeg + g; p0 < pend; p0 += NG * MM_UNROLL) {
-            int k[MM_UNROLL];
-            int64_t qb[MM_UNROLL], qe[MM_UNROLL];
-#pragma unroll
-            for (int u = 0; u < MM_UNROLL; u++) {
-                const int64_t p = p0 + u * NG;
-                k[u] = p < pend ? a.Aj[p] : -1;
+        // Products whose column falls in [c0, c0 + MM_WIN).  The row's entries come 1024 at a time, one per thread: the
+        // thread fetches the range of B(k,:) inside the window; a workgroup scan of the range lengths numbers the products,
+        // and the threads then take the products round-robin (binary search of the product number in the scan), so a hub
+        // column with thousands of entries in the window is shared by the whole workgroup instead of one 16-lane group.
+        for (int64_t pc = pbeg; pc < pend; pc += MM_WIN_BLOCK) {
+            const int64_t p = pc + tid;
+            int len = 0;
+            int64_t qb = 0;
+            if (p < pend) {
+                const int k = a.Aj[p];
+                const int32_t *o = a.woff + (int64_t)k * (nwin + 1) + w;
+                const int o0 = o[0], o1 = o[1];
+                qb = a.Bp[k] + o0;
+                len = o1 - o0;
             }
+            int incl = len;
 #pragma unroll
-            for (int u = 0; u < MM_UNROLL; u++) {
-                qb[u] = qe[u] = 0;
-                if (k[u] >= 0) {
-                    const int32_t *o = a.woff + (int64_t)k[u] * (nwin + 1) + w;
-                    const int64_t b = a.Bp[k[u]];
-                    qb[u] = b + o[0] + gl;
-                    qe[u] = b + o[1];
+            for (int off = 1; off < 64; off <<= 1) {
+                const int t = __shfl_up(incl, off);
+                if (lane >= off) incl += t;
+            }
+            if (lane == 63) s_wave[wv] = incl;
+            __syncthreads();
+            int wave_off = 0, total = 0;
+            for (int x = 0; x < MM_WIN_BLOCK / 64; x++) {
+                if (x < wv) wave_off += s_wave[x];
+                total += s_wave[x];
+            }
+            s_scan[tid] = wave_off + incl - len;
+            s_qb[tid] = qb;
+            if (tid == 0) s_scan[MM_WIN_BLOCK] = total;
+            __syncthreads();
+            for (int t = tid; t < total; t += MM_WIN_BLOCK) {
+                int lo = 0, hi = MM_WIN_BLOCK;  // the last entry whose first product number is <= t
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (s_scan[mid] <= t) lo = mid;
+                    else hi = mid;
                 }
+                const int64_t q = s_qb[lo] + (t - s_scan[lo]);
+                const int j = a.Bj[q] - c0;
+                const T av = a.need_a ? Ax[a.a_iso ? 0 : pc + lo] : (T)0;
+                const T bv = a.need_b ? Bx[a.b_iso ? 0 : q] : (T)0;
+                const W prod = (W)apply_binop<T>(mult, av, bv);
+                if (monoid == OP_ANY) s_acc[j] = prod;
+                else atomic_combine<W>(&s_acc[j], prod, monoid);
+                atomicOr(&s_bits[j >> 6], 1ull << (j & 63));
             }
-#pragma unroll
-            for (int u = 0; u < MM_UNROLL; u++) {
-                const int64_t p = p0 + u * NG;
-                for (int64_t q = qb[u]; q < qe[u]; q += MM_GROUP) {
-                    const int j = a.Bj[q] - c0;
-                    const T av = a.need_a ? Ax[a.a_iso ? 0 : p] : (T)0;
-                    const T bv = a.need_b ? Bx[a.b_iso ? 0 : q] : (T)0;
-                    const W prod = (W)apply_binop<T>(mult, av, bv);
-                    if (monoid == OP_ANY) s_acc[j] = prod;
-                    else atomic_combine<W>(&s_acc[j], prod, monoid);
-                    atomicOr(&s_bits[j >> 6], 1ull << (j & 63));
-                }
-            }
+            __syncthreads();
         }
         __syncthreads();
-        // ordered sweep of the window's presence words (MM_WIN/64 = 128 words: threads 0..127 take one each)
+        // ordered sweep of the window's presence words (MM_WIN/64 = 256 words: threads 0..255 take one each)
         unsigned long long b = (tid < MM_WIN / 64) ? s_bits[tid] : 0ull;
         const int c = __popcll(b);
         int incl = c;
@@ -396,7 +414,7 @@ __global__ __launch_bounds__(MM_BLOCK) void k_spgemm_win(const MxmArgs a, const 
         if (lane == 63) s_wave[wv] = incl;
         __syncthreads();
         int wave_off = 0, total = 0;
-        for (int x = 0; x < MM_BLOCK / 64; x++) {
+        for (int x = 0; x < MM_WIN_BLOCK / 64; x++) {
             if (x < wv) wave_off += s_wave[x];
             total += s_wave[x];
         }
@@ -543,7 +561,7 @@ static void run_bins(MxmArgs &a, const RowBins &rb)
         else hipLaunchKernelGGL((k_spgemm_sym_lds<16384>), dim3((unsigned)rb.count(4)), dim3(MM_BLOCK), 0, ctx().stream, a, rb.ptr(4));
         ctx().stats.kernel_launches += 1;
     } else if (rb.count(4) && NUMERIC && a.woff) {
-        hipLaunchKernelGGL((k_spgemm_win<T>), dim3((unsigned)rb.count(4)), dim3(MM_BLOCK), 0, ctx().stream, a, rb.ptr(4));
+        hipLaunchKernelGGL((k_spgemm_win<T>), dim3((unsigned)rb.count(4)), dim3(MM_WIN_BLOCK), 0, ctx().stream, a, rb.ptr(4));
         ctx().stats.kernel_launches += 1;
     } else if (rb.count(4)) {
         // dense accumulators in HBM: one slice per resident workgroup (8 per CU), as many as fit in ~32 GiB
