@@ -25,7 +25,6 @@
 namespace grb {
 
 constexpr int MM_BLOCK = 256;
-constexpr int MM_GROUP = 16;  // lanes cooperating on one A(i,k): they stride B(k,:)
 
 struct MxmArgs {
     int64_t m, n;  // T is m x n
@@ -97,38 +96,55 @@ __global__ void k_bin_starts(const uint64_t *keys, int64_t m, int64_t *bin_start
     bin_start[b] = lo;
 }
 
-// Visit every product A(row,k) * B(k,j): 16-lane groups take one A entry each and stride B(k,:).  The pointer
-// chase Aj -> Bp -> Bj is a chain of dependent HBM round trips, so each group keeps MM_UNROLL entries of the
-// row in flight (their k, their B row bounds and their first B entry are fetched before any is consumed).
-constexpr int MM_UNROLL = 4;
+// Visit every product A(row,k) * B(k,j) with the whole workgroup (every thread must call).  The row's entries come
+// MM_BLOCK at a time, one per thread (k, the bounds of B(k,:): dependent loads, but 256 of them in flight); a workgroup
+// scan of the B row lengths numbers the products, and the threads take them round-robin -- product t belongs to the last
+// entry whose first product number is <= t (binary search in LDS).  A hub column with 10^5 entries is thus shared by all
+// threads instead of serialising one 16-lane group, and consecutive threads read consecutive entries of B.
 template <typename F>
-__device__ __forceinline__ void foreach_product(const MxmArgs &a, int64_t row, int g, int gl, F &&f)
+__device__ __forceinline__ void foreach_product(const MxmArgs &a, int64_t row, F &&f)
 {
-    constexpr int NG = MM_BLOCK / MM_GROUP;
+    __shared__ int s_fp_scan[MM_BLOCK + 1];
+    __shared__ int64_t s_fp_qb[MM_BLOCK];
+    __shared__ int s_fp_wave[MM_BLOCK / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int64_t pend = a.Ap[row + 1];
-    for (int64_t p0 = a.Ap[row] + g; p0 < pend; p0 += NG * MM_UNROLL) {
-        int k[MM_UNROLL], jf[MM_UNROLL];
-        int64_t qb[MM_UNROLL], qe[MM_UNROLL];
-#pragma unroll
-        for (int u = 0; u < MM_UNROLL; u++) {
-            const int64_t p = p0 + u * NG;
-            k[u] = p < pend ? a.Aj[p] : -1;
+    for (int64_t pc = a.Ap[row]; pc < pend; pc += MM_BLOCK) {
+        const int64_t p = pc + tid;
+        int len = 0;
+        int64_t qb = 0;
+        if (p < pend) {
+            const int k = a.Aj[p];
+            qb = a.Bp[k];
+            len = (int)(a.Bp[k + 1] - qb);
         }
+        int incl = len;
 #pragma unroll
-        for (int u = 0; u < MM_UNROLL; u++) {
-            qb[u] = k[u] >= 0 ? a.Bp[k[u]] + gl : 0;
-            qe[u] = k[u] >= 0 ? a.Bp[k[u] + 1] : 0;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
         }
-#pragma unroll
-        for (int u = 0; u < MM_UNROLL; u++) jf[u] = qb[u] < qe[u] ? a.Bj[qb[u]] : -1;
-#pragma unroll
-        for (int u = 0; u < MM_UNROLL; u++) {
-            if (jf[u] >= 0) {
-                const int64_t p = p0 + u * NG;
-                f(jf[u], p, qb[u]);
-                for (int64_t q = qb[u] + MM_GROUP; q < qe[u]; q += MM_GROUP) f(a.Bj[q], p, q);
+        if (lane == 63) s_fp_wave[wv] = incl;
+        __syncthreads();
+        int wave_off = 0, total = 0;
+        for (int x = 0; x < MM_BLOCK / 64; x++) {
+            if (x < wv) wave_off += s_fp_wave[x];
+            total += s_fp_wave[x];
+        }
+        s_fp_scan[tid] = wave_off + incl - len;
+        s_fp_qb[tid] = qb;
+        __syncthreads();
+        for (int t = tid; t < total; t += MM_BLOCK) {
+            int lo = 0, hi = MM_BLOCK;
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (s_fp_scan[mid] <= t) lo = mid;
+                else hi = mid;
             }
+            const int64_t q = s_fp_qb[lo] + (t - s_fp_scan[lo]);
+            f(a.Bj[q], pc + lo, q);
         }
+        __syncthreads();
     }
 }
 
@@ -155,9 +171,8 @@ __global__ __launch_bounds__(MM_BLOCK) void k_spgemm_hash(const MxmArgs a, const
     if (tid == 0) s_cnt = 0;
     __syncthreads();
 
-    const int g = tid / MM_GROUP, gl = tid % MM_GROUP;
     int my_new = 0;
-    foreach_product(a, row, g, gl, [&](int j, int64_t p, int64_t q) {
+    foreach_product(a, row, [&](int j, int64_t p, int64_t q) {
         unsigned h = hash_col(j, TABLE - 1);
         while (true) {
             const int old = atomicCAS(&s_key[h], -1, j);
@@ -228,13 +243,12 @@ __global__ __launch_bounds__(MM_BLOCK) void k_spgemm_spa(const MxmArgs a, const 
     const T *Ax = (const T *)a.Ax, *Bx = (const T *)a.Bx;
     unsigned long long *bits = (unsigned long long *)(a.spa_bits + (int64_t)blockIdx.x * a.spa_words);
     W *vals = NUMERIC ? ((W *)a.spa_vals + (int64_t)blockIdx.x * a.spa_words * 64) : nullptr;
-    const int g = tid / MM_GROUP, gl = tid % MM_GROUP;
     for (int64_t r = blockIdx.x; r < nrows_bin; r += gridDim.x) {
         const int64_t row = rows[r];
         if (tid == 0) { s_cnt = 0; s_base = 0; }
         __syncthreads();
         int my_new = 0;
-        foreach_product(a, row, g, gl, [&](int j, int64_t p, int64_t q) {
+        foreach_product(a, row, [&](int j, int64_t p, int64_t q) {
             const unsigned long long bit = 1ull << (j & 63);
             if (NUMERIC) {
                 atomicOr(&bits[j >> 6], bit);
@@ -253,7 +267,7 @@ __global__ __launch_bounds__(MM_BLOCK) void k_spgemm_spa(const MxmArgs a, const 
             __syncthreads();
             if (tid == 0) a.row_nnz[row] = s_cnt;
             // clear the touched words again (second walk over the same products)
-            foreach_product(a, row, g, gl, [&](int j, int64_t, int64_t) { bits[j >> 6] = 0ull; });
+            foreach_product(a, row, [&](int j, int64_t, int64_t) { bits[j >> 6] = 0ull; });
             __syncthreads();
             continue;
         }
@@ -448,7 +462,7 @@ __global__ __launch_bounds__(MM_BLOCK) void k_spgemm_sym_lds(const MxmArgs a, co
     for (int k = tid; k < WORDS; k += MM_BLOCK) s_bits[k] = 0ull;
     if (tid == 0) s_cnt = 0;
     __syncthreads();
-    foreach_product(a, row, tid / MM_GROUP, tid % MM_GROUP,
+    foreach_product(a, row,
                     [&](int j, int64_t, int64_t) { atomicOr(&s_bits[j >> 6], 1ull << (j & 63)); });
     __syncthreads();
     int c = 0;
