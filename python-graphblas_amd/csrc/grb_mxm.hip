@@ -97,19 +97,19 @@ __global__ void k_bin_starts(const uint64_t *keys, int64_t m, int64_t *bin_start
 }
 
 // Visit every product A(row,k) * B(k,j) with the whole workgroup (every thread must call).  The row's entries come
-// MM_BLOCK at a time, one per thread (k, the bounds of B(k,:): dependent loads, but 256 of them in flight); a workgroup
+// BLOCK at a time, one per thread (k, the bounds of B(k,:): dependent loads, but 256 of them in flight); a workgroup
 // scan of the B row lengths numbers the products, and the threads take them round-robin -- product t belongs to the last
 // entry whose first product number is <= t (binary search in LDS).  A hub column with 10^5 entries is thus shared by all
 // threads instead of serialising one 16-lane group, and consecutive threads read consecutive entries of B.
-template <typename F>
+template <int BLOCK = MM_BLOCK, typename F>
 __device__ __forceinline__ void foreach_product(const MxmArgs &a, int64_t row, F &&f)
 {
-    __shared__ int s_fp_scan[MM_BLOCK + 1];
-    __shared__ int64_t s_fp_qb[MM_BLOCK];
-    __shared__ int s_fp_wave[MM_BLOCK / 64];
+    __shared__ int s_fp_scan[BLOCK + 1];
+    __shared__ int64_t s_fp_qb[BLOCK];
+    __shared__ int s_fp_wave[BLOCK / 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int64_t pend = a.Ap[row + 1];
-    for (int64_t pc = a.Ap[row]; pc < pend; pc += MM_BLOCK) {
+    for (int64_t pc = a.Ap[row]; pc < pend; pc += BLOCK) {
         const int64_t p = pc + tid;
         int len = 0;
         int64_t qb = 0;
@@ -127,15 +127,15 @@ __device__ __forceinline__ void foreach_product(const MxmArgs &a, int64_t row, F
         if (lane == 63) s_fp_wave[wv] = incl;
         __syncthreads();
         int wave_off = 0, total = 0;
-        for (int x = 0; x < MM_BLOCK / 64; x++) {
+        for (int x = 0; x < BLOCK / 64; x++) {
             if (x < wv) wave_off += s_fp_wave[x];
             total += s_fp_wave[x];
         }
         s_fp_scan[tid] = wave_off + incl - len;
         s_fp_qb[tid] = qb;
         __syncthreads();
-        for (int t = tid; t < total; t += MM_BLOCK) {
-            int lo = 0, hi = MM_BLOCK;
+        for (int t = tid; t < total; t += BLOCK) {
+            int lo = 0, hi = BLOCK;
             while (hi - lo > 1) {
                 const int mid = (lo + hi) >> 1;
                 if (s_fp_scan[mid] <= t) lo = mid;
@@ -452,21 +452,21 @@ __global__ __launch_bounds__(MM_WIN_BLOCK) void k_spgemm_win(const MxmArgs a, co
 
 // ---- symbolic pass for rows whose upper bound exceeds the LDS hash table: the presence bitmap of the WHOLE column
 //      range lives in LDS (n <= 2^20 columns = 128 KiB), filled by LDS atomicOr, counted by a popcount sweep ---------
-template <int WORDS>
-__global__ __launch_bounds__(MM_BLOCK) void k_spgemm_sym_lds(const MxmArgs a, const uint32_t *rows)
+template <int WORDS, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_spgemm_sym_lds(const MxmArgs a, const uint32_t *rows)
 {
     __shared__ unsigned long long s_bits[WORDS];
     __shared__ int s_cnt;
     const int tid = threadIdx.x;
     const int64_t row = rows[blockIdx.x];
-    for (int k = tid; k < WORDS; k += MM_BLOCK) s_bits[k] = 0ull;
+    for (int k = tid; k < WORDS; k += BLOCK) s_bits[k] = 0ull;
     if (tid == 0) s_cnt = 0;
     __syncthreads();
-    foreach_product(a, row,
+    foreach_product<BLOCK>(a, row,
                     [&](int j, int64_t, int64_t) { atomicOr(&s_bits[j >> 6], 1ull << (j & 63)); });
     __syncthreads();
     int c = 0;
-    for (int k = tid; k < WORDS; k += MM_BLOCK) c += __popcll(s_bits[k]);
+    for (int k = tid; k < WORDS; k += BLOCK) c += __popcll(s_bits[k]);
     for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
     if ((tid & 63) == 0 && c) atomicAdd(&s_cnt, c);
     __syncthreads();
@@ -571,8 +571,9 @@ static void run_bins(MxmArgs &a, const RowBins &rb)
     if (rb.count(3)) hipLaunchKernelGGL((k_spgemm_hash<T, T3, NUMERIC>), dim3((unsigned)rb.count(3)), dim3(MM_BLOCK), 0, ctx().stream, a, rb.ptr(3));
     ctx().stats.kernel_launches += 3;
     if (rb.count(4) && !NUMERIC && a.n <= (1 << 20) && !(ctx().debug_flags & 256)) {
-        if (a.n <= (1 << 18)) hipLaunchKernelGGL((k_spgemm_sym_lds<4096>), dim3((unsigned)rb.count(4)), dim3(MM_BLOCK), 0, ctx().stream, a, rb.ptr(4));
-        else hipLaunchKernelGGL((k_spgemm_sym_lds<16384>), dim3((unsigned)rb.count(4)), dim3(MM_BLOCK), 0, ctx().stream, a, rb.ptr(4));
+        if (a.n <= (1 << 18)) hipLaunchKernelGGL((k_spgemm_sym_lds<4096, MM_BLOCK>), dim3((unsigned)rb.count(4)), dim3(MM_BLOCK), 0, ctx().stream, a, rb.ptr(4));
+        else  // (128 KiB of bitmap: one workgroup per CU, so make it a big one)
+            hipLaunchKernelGGL((k_spgemm_sym_lds<16384, 1024>), dim3((unsigned)rb.count(4)), dim3(1024), 0, ctx().stream, a, rb.ptr(4));
         ctx().stats.kernel_launches += 1;
     } else if (rb.count(4) && NUMERIC && a.woff) {
         hipLaunchKernelGGL((k_spgemm_win<T>), dim3((unsigned)rb.count(4)), dim3(MM_WIN_BLOCK), 0, ctx().stream, a, rb.ptr(4));

@@ -213,6 +213,8 @@ def test_mxm_random(gb, seed):
     big = seed % 4 == 1  # rows whose product exceeds the LDS tables (ub > 16384, nnz(T_i) > 4096)
     if big:
         m, k, n = 40, 700, 9000
+        if seed % 8 == 5:  # more than 2^18 columns: the 1024-thread whole-row bitmap kernel and 19 numeric windows
+            n = 300000
     ar, ac, av = rand_coo(rng, m, k, tname, long_rows=2 if big else int(rng.integers(0, 2)))
     br, bc, bv = rand_coo(rng, k, n, tname, long_rows=int(rng.integers(0, 3)))
     if big:  # dense-ish B rows so that one A row yields thousands of distinct columns
