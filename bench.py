@@ -52,7 +52,7 @@ def parse():
     p.add_argument("--scale", type=int, default=24)
     p.add_argument("--visited", type=float, default=0.5, help="fraction of rows masked out (visited)")
     p.add_argument("--workload", default="mxv_min_plus_masked",
-                   choices=["mxv_min_plus_masked", "mxv_lor_land_masked", "mxv_min_plus", "mxm_plus_times"])
+                   choices=["mxv_min_plus_masked", "mxv_lor_land_masked", "mxv_min_plus", "mxm_plus_times", "mxm_plus_times_masked"])
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--extra", action="store_true", help="also run the secondary workloads (reported under 'extra')")
     return p.parse_args()
@@ -213,9 +213,15 @@ def main_mxm(args, gb, torch, device, rank, world, dist, barrier):
     sr = gb.semiring.plus_times["INT64"]
     L = _lib.lib
 
+    masked = args.workload == "mxm_plus_times_masked"  # triangle-count style: C<A.S> = A (+.x) A
+    desc_s = ctypes.c_void_p(_lib.handle("GrB_DESC_S"))
+
     def step():
         C = gb.Matrix("INT64", hi - lo, n)
-        rc = L.GrB_mxm(C._carg, None, None, sr._carg, A._carg, B._carg, None)
+        if masked:
+            rc = L.GrB_mxm(C._carg, A._carg, None, sr._carg, A._carg, B._carg, desc_s)
+        else:
+            rc = L.GrB_mxm(C._carg, None, None, sr._carg, A._carg, B._carg, None)
         if rc != 0:
             raise RuntimeError(f"GrB_mxm failed with GrB_Info {rc}")
         st = device.last_stats()
@@ -247,10 +253,12 @@ def main_mxm(args, gb, torch, device, rank, world, dist, barrier):
             "metric": "SpGEMM nnz-out/s on R-MAT scale-%d" % args.scale, "value": nnz_c / (ms * 1e-3), "unit": "nnz(C)/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
-            "config": {"workload": f"rmat{args.scale} mxm_plus_times: C = A (+.x) A, INT64 ones", "nnz_A": nnz_a,
+            "config": {"workload": f"rmat{args.scale} {args.workload}: " + ("C<A.S> = A (+.x) A (mask-driven)" if masked else "C = A (+.x) A")
+                       + ", INT64 ones", "nnz_A": nnz_a,
                        "flops": flops, "nnz_C": nnz_c, "parallelism": f"row-shard x{world}, B replicated"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_spgemm_hash / k_spgemm_spa",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_spgemm_mhash / k_spgemm_mwin" if masked else "k_spgemm_hash / k_spgemm_sym_lds / k_spgemm_win",
                          "kernel_ms_hip_events": ev_ms / args.steps, "algorithmic_bytes_per_launch": alg_bytes / world},
             "cpu_baseline": None, "stats": st}))
     if dist is not None:
@@ -322,7 +330,7 @@ def main():
         }
         return wl, res
 
-    if args.workload == "mxm_plus_times":
+    if args.workload in ("mxm_plus_times", "mxm_plus_times_masked"):
         return main_mxm(args, gb, torch, device, rank, world, dist, barrier)
     wl, res = run(args.workload)
     cpu = None

@@ -261,6 +261,7 @@ extern "C" GrB_Info GrX_option_set(const char *name, int64_t value)
     else if (n == "split_min_len") c.split_min_len = (int)value;
     else if (n == "short_kernel") c.short_kernel = (int)value;
     else if (n == "long_kernel") c.long_kernel = (int)value;
+    else if (n == "mxm_mask_mode") c.mxm_mask_mode = (int)value;
     else if (n == "vec_pad_min_bytes") c.vec_pad_min_bytes = value;
     else if (n == "alloc_cache") {
         if (!value) dev_cache_release();

@@ -61,6 +61,7 @@ struct Context {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int64_t vec_pad_min_bytes = 1 << 20;  // vectors with at least this many bytes of values are allocated with the front pad
     int alloc_cache = 1;    // 1: freed device blocks are kept per size class and reused without calling the HIP allocator
+    int mxm_mask_mode = 1;  // mask-driven SpGEMM for non-complemented masks: 0 never, 1 when the full product costs more, 2 always
     int long_kernel = 1;    // long rows: 1 = class-partitioned kernel (k_mxv_long_cls), 0 = chunk kernel (k_mxv_long)
     int short_kernel = 1;   // short rows of a split matrix: 1 = row-group kernel (k_mxv_rows), 0 = merge-path kernel
     GrX_Stats stats{};

@@ -51,6 +51,11 @@ struct MxmArgs {
     // (relative to Bp[k]) whose column is >= w * MM_WIN
     const int32_t *woff;
     int n_win;
+    // mask-driven product (T restricted to the pattern of a non-complemented mask): results land in the mask's own layout
+    const int64_t *Mp;
+    const int32_t *Mj;
+    void *cap_val;           // per mask entry: the product's value ...
+    unsigned char *cap_hit;  // ... and whether any product hit it
 };
 
 __device__ __forceinline__ unsigned hash_col(int c, int table_mask) { return ((unsigned)c * 2654435761u) & (unsigned)table_mask; }
@@ -342,6 +347,59 @@ __global__ void k_window_offsets(const int64_t *Bp, const int32_t *Bj, int64_t n
     }
 }
 
+// Products A(row,k) * B(k,j) with j inside column window w, visited by the whole 1024-thread workgroup (every thread must
+// call).  The row's entries come 1024 at a time, one per thread: the thread fetches the range of B(k,:) inside the window
+// from the offset table; a workgroup scan of the range lengths numbers the products, and the threads take them round-robin
+// (binary search of the product number in the scan) -- a hub column with thousands of entries in the window is shared by the
+// whole workgroup.  f(p, q): p = position of A(row,k), q = position of B(k,j).
+template <typename F>
+__device__ __forceinline__ void foreach_window_product(const MxmArgs &a, int64_t row, int w, F &&f)
+{
+    __shared__ int s_scan[MM_WIN_BLOCK + 1];
+    __shared__ int64_t s_qb[MM_WIN_BLOCK];
+    __shared__ int s_wsum[MM_WIN_BLOCK / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t pend = a.Ap[row + 1];
+    for (int64_t pc = a.Ap[row]; pc < pend; pc += MM_WIN_BLOCK) {
+        const int64_t p = pc + tid;
+        int len = 0;
+        int64_t qb = 0;
+        if (p < pend) {
+            const int k = a.Aj[p];
+            const int32_t *o = a.woff + (int64_t)k * (a.n_win + 1) + w;
+            const int o0 = o[0], o1 = o[1];
+            qb = a.Bp[k] + o0;
+            len = o1 - o0;
+        }
+        int incl = len;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        if (lane == 63) s_wsum[wv] = incl;
+        __syncthreads();
+        int wave_off = 0, total = 0;
+        for (int x = 0; x < MM_WIN_BLOCK / 64; x++) {
+            if (x < wv) wave_off += s_wsum[x];
+            total += s_wsum[x];
+        }
+        s_scan[tid] = wave_off + incl - len;
+        s_qb[tid] = qb;
+        __syncthreads();
+        for (int t = tid; t < total; t += MM_WIN_BLOCK) {
+            int lo = 0, hi = MM_WIN_BLOCK;  // the last entry whose first product number is <= t
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (s_scan[mid] <= t) lo = mid;
+                else hi = mid;
+            }
+            f(pc + lo, s_qb[lo] + (t - s_scan[lo]));
+        }
+        __syncthreads();
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(MM_WIN_BLOCK) void k_spgemm_win(const MxmArgs a, const uint32_t *rows)
 {
@@ -357,64 +415,20 @@ __global__ __launch_bounds__(MM_WIN_BLOCK) void k_spgemm_win(const MxmArgs a, co
     for (int k = tid; k < MM_WIN; k += MM_WIN_BLOCK) s_acc[k] = ident;
     if (tid < MM_WIN / 64) s_bits[tid] = 0ull;
     __syncthreads();
-    __shared__ int s_scan[MM_WIN_BLOCK + 1];
-    __shared__ int64_t s_qb[MM_WIN_BLOCK];
-    const int64_t pbeg = a.Ap[row], pend = a.Ap[row + 1];
     const int nwin = a.n_win;
     int64_t out = a.Tp[row];
     T *Tx = (T *)a.Tx;
     for (int w = 0; w < nwin; w++) {
         const int c0 = w * MM_WIN;
-        // Products whose column falls in [c0, c0 + MM_WIN).  The row's entries come 1024 at a time, one per thread: the
-        // thread fetches the range of B(k,:) inside the window; a workgroup scan of the range lengths numbers the products,
-        // and the threads then take the products round-robin (binary search of the product number in the scan), so a hub
-        // column with thousands of entries in the window is shared by the whole workgroup instead of one 16-lane group.
-        for (int64_t pc = pbeg; pc < pend; pc += MM_WIN_BLOCK) {
-            const int64_t p = pc + tid;
-            int len = 0;
-            int64_t qb = 0;
-            if (p < pend) {
-                const int k = a.Aj[p];
-                const int32_t *o = a.woff + (int64_t)k * (nwin + 1) + w;
-                const int o0 = o[0], o1 = o[1];
-                qb = a.Bp[k] + o0;
-                len = o1 - o0;
-            }
-            int incl = len;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const int t = __shfl_up(incl, off);
-                if (lane >= off) incl += t;
-            }
-            if (lane == 63) s_wave[wv] = incl;
-            __syncthreads();
-            int wave_off = 0, total = 0;
-            for (int x = 0; x < MM_WIN_BLOCK / 64; x++) {
-                if (x < wv) wave_off += s_wave[x];
-                total += s_wave[x];
-            }
-            s_scan[tid] = wave_off + incl - len;
-            s_qb[tid] = qb;
-            if (tid == 0) s_scan[MM_WIN_BLOCK] = total;
-            __syncthreads();
-            for (int t = tid; t < total; t += MM_WIN_BLOCK) {
-                int lo = 0, hi = MM_WIN_BLOCK;  // the last entry whose first product number is <= t
-                while (hi - lo > 1) {
-                    const int mid = (lo + hi) >> 1;
-                    if (s_scan[mid] <= t) lo = mid;
-                    else hi = mid;
-                }
-                const int64_t q = s_qb[lo] + (t - s_scan[lo]);
-                const int j = a.Bj[q] - c0;
-                const T av = a.need_a ? Ax[a.a_iso ? 0 : pc + lo] : (T)0;
-                const T bv = a.need_b ? Bx[a.b_iso ? 0 : q] : (T)0;
-                const W prod = (W)apply_binop<T>(mult, av, bv);
-                if (monoid == OP_ANY) s_acc[j] = prod;
-                else atomic_combine<W>(&s_acc[j], prod, monoid);
-                atomicOr(&s_bits[j >> 6], 1ull << (j & 63));
-            }
-            __syncthreads();
-        }
+        foreach_window_product(a, row, w, [&](int64_t p, int64_t q) {
+            const int j = a.Bj[q] - c0;
+            const T av = a.need_a ? Ax[a.a_iso ? 0 : p] : (T)0;
+            const T bv = a.need_b ? Bx[a.b_iso ? 0 : q] : (T)0;
+            const W prod = (W)apply_binop<T>(mult, av, bv);
+            if (monoid == OP_ANY) s_acc[j] = prod;
+            else atomic_combine<W>(&s_acc[j], prod, monoid);
+            atomicOr(&s_bits[j >> 6], 1ull << (j & 63));
+        });
         __syncthreads();
         // ordered sweep of the window's presence words (MM_WIN/64 = 256 words: threads 0..255 take one each)
         unsigned long long b = (tid < MM_WIN / 64) ? s_bits[tid] : 0ull;
@@ -447,6 +461,164 @@ __global__ __launch_bounds__(MM_WIN_BLOCK) void k_spgemm_win(const MxmArgs a, co
         }
         out += total;
         __syncthreads();
+    }
+}
+
+// ---- mask-driven product: C<M> = A (+.x) B with a non-complemented mask only needs the entries of T inside M's pattern
+//      (the write rule never looks at the others), so the accumulators are keyed by the MASK row: no symbolic pass, no
+//      sort (M's rows are sorted), output size bounded by nnz(M) however dense A*B is -------------------------------------
+// rows with at most TABLE/2 mask entries: LDS hash pre-loaded with the mask row's columns; products only look up
+template <typename T, int TABLE>
+__global__ __launch_bounds__(MM_BLOCK) void k_spgemm_mhash(const MxmArgs a, const uint32_t *rows)
+{
+    using W = typename Widen<T>::type;
+    __shared__ int s_key[TABLE];
+    __shared__ W s_val[TABLE];
+    __shared__ unsigned char s_hit[TABLE];
+    const int tid = threadIdx.x;
+    const int64_t row = rows[blockIdx.x];
+    const int monoid = a.monoid, mult = a.mult;
+    const T *Ax = (const T *)a.Ax, *Bx = (const T *)a.Bx;
+    const int64_t mlo = a.Mp[row], mhi = a.Mp[row + 1];
+    for (int k = tid; k < TABLE; k += MM_BLOCK) {
+        s_key[k] = -1;
+        s_val[k] = monoid_identity<T, W>(monoid);
+        s_hit[k] = 0;
+    }
+    __syncthreads();
+    for (int64_t p = mlo + tid; p < mhi; p += MM_BLOCK) {
+        const int j = a.Mj[p];
+        unsigned h = hash_col(j, TABLE - 1);
+        while (true) {
+            const int old = atomicCAS(&s_key[h], -1, j);
+            if (old == -1 || old == j) break;
+            h = (h + 1) & (TABLE - 1);
+        }
+    }
+    __syncthreads();
+    foreach_product(a, row, [&](int j, int64_t p, int64_t q) {
+        unsigned h = hash_col(j, TABLE - 1);
+        while (true) {
+            const int key = s_key[h];
+            if (key == j) {
+                const T av = a.need_a ? Ax[a.a_iso ? 0 : p] : (T)0;
+                const T bv = a.need_b ? Bx[a.b_iso ? 0 : q] : (T)0;
+                const W prod = (W)apply_binop<T>(mult, av, bv);
+                if (monoid == OP_ANY) s_val[h] = prod;
+                else atomic_combine<W>(&s_val[h], prod, monoid);
+                s_hit[h] = 1;
+                break;
+            }
+            if (key == -1) break;  // not in the mask row
+            h = (h + 1) & (TABLE - 1);
+        }
+    });
+    __syncthreads();
+    T *cv = (T *)a.cap_val;
+    for (int64_t p = mlo + tid; p < mhi; p += MM_BLOCK) {
+        const int j = a.Mj[p];
+        unsigned h = hash_col(j, TABLE - 1);
+        while (s_key[h] != j) h = (h + 1) & (TABLE - 1);
+        const unsigned char hit = s_hit[h];
+        a.cap_hit[p] = hit;
+        if (hit) cv[p] = from_acc<T, W>(s_val[h]);
+    }
+}
+
+// longer mask rows: LDS column windows as k_spgemm_win, plus a bitmap of the mask row inside the window; windows without
+// mask entries are skipped
+template <typename T>
+__global__ __launch_bounds__(MM_WIN_BLOCK) void k_spgemm_mwin(const MxmArgs a, const uint32_t *rows)
+{
+    using W = typename Widen<T>::type;
+    __shared__ W s_acc[MM_WIN];
+    __shared__ unsigned long long s_bits[MM_WIN / 64];
+    __shared__ unsigned long long s_mbits[MM_WIN / 64];
+    __shared__ int64_t s_mrange[2];
+    const int tid = threadIdx.x;
+    const int monoid = a.monoid, mult = a.mult;
+    const T *Ax = (const T *)a.Ax, *Bx = (const T *)a.Bx;
+    const int64_t row = rows[blockIdx.x];
+    const W ident = monoid_identity<T, W>(monoid);
+    for (int k = tid; k < MM_WIN; k += MM_WIN_BLOCK) s_acc[k] = ident;
+    if (tid < MM_WIN / 64) { s_bits[tid] = 0ull; s_mbits[tid] = 0ull; }
+    const int64_t mlo = a.Mp[row], mhi = a.Mp[row + 1];
+    T *cv = (T *)a.cap_val;
+    int64_t mpos = mlo;  // mask entries before it lie in earlier windows
+    __syncthreads();
+    for (int w = 0; w < a.n_win && mpos < mhi; w++) {
+        const int c0 = w * MM_WIN;
+        if (tid == 0) {  // the mask row's entries inside the window: [mpos, first entry with column >= c0 + MM_WIN)
+            int64_t lo = mpos, hi = mhi;
+            const int64_t lim = (int64_t)c0 + MM_WIN;
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) >> 1;
+                if ((int64_t)a.Mj[mid] < lim) lo = mid + 1;
+                else hi = mid;
+            }
+            s_mrange[0] = mpos;
+            s_mrange[1] = lo;
+        }
+        __syncthreads();
+        const int64_t wlo = s_mrange[0], whi = s_mrange[1];
+        __syncthreads();
+        mpos = whi;
+        if (wlo == whi) continue;  // (uniform) no mask entry in this window
+        for (int64_t p = wlo + tid; p < whi; p += MM_WIN_BLOCK) {
+            const int j = a.Mj[p] - c0;
+            atomicOr(&s_mbits[j >> 6], 1ull << (j & 63));
+        }
+        __syncthreads();
+        foreach_window_product(a, row, w, [&](int64_t p, int64_t q) {
+            const int j = a.Bj[q] - c0;
+            if ((s_mbits[j >> 6] >> (j & 63)) & 1ull) {
+                const T av = a.need_a ? Ax[a.a_iso ? 0 : p] : (T)0;
+                const T bv = a.need_b ? Bx[a.b_iso ? 0 : q] : (T)0;
+                const W prod = (W)apply_binop<T>(mult, av, bv);
+                if (monoid == OP_ANY) s_acc[j] = prod;
+                else atomic_combine<W>(&s_acc[j], prod, monoid);
+                atomicOr(&s_bits[j >> 6], 1ull << (j & 63));
+            }
+        });
+        __syncthreads();
+        for (int64_t p = wlo + tid; p < whi; p += MM_WIN_BLOCK) {
+            const int j = a.Mj[p] - c0;
+            const bool hit = (s_bits[j >> 6] >> (j & 63)) & 1ull;
+            a.cap_hit[p] = hit ? 1 : 0;
+            if (hit) {
+                cv[p] = from_acc<T, W>(s_acc[j]);
+                s_acc[j] = ident;
+            }
+        }
+        __syncthreads();
+        if (tid < MM_WIN / 64) { s_bits[tid] = 0ull; s_mbits[tid] = 0ull; }
+        __syncthreads();
+    }
+}
+
+// compaction of the mask-layout results into CSR
+__global__ void k_mask_sizes(const int64_t *Ap, const int64_t *Mp, int64_t m, int64_t *size)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) size[i] = (Ap[i + 1] > Ap[i]) ? Mp[i + 1] - Mp[i] : 0;
+}
+__global__ void k_hits_to_i64(const unsigned char *hit, int64_t n, int64_t *out)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p <= n) out[p] = p < n ? (int64_t)hit[p] : 0;
+}
+__global__ void k_cap_rowptr(const int64_t *Mp, const int64_t *pos, int64_t m, int64_t *Tp)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= m) Tp[i] = pos[Mp[i]];
+}
+template <typename T>
+__global__ void k_cap_scatter(const unsigned char *hit, const int64_t *pos, const int32_t *Mj, const T *cap_val, int64_t n, int32_t *Tj, T *Tx)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n && hit[p]) {
+        Tj[pos[p]] = Mj[p];
+        Tx[pos[p]] = cap_val[p];
     }
 }
 
@@ -679,6 +851,98 @@ static GB_Matrix_opaque *spgemm(GB_Matrix_opaque *A, const void *Ax, GB_Matrix_o
     return Tm;
 }
 
+// T = (A (+.x) B) restricted to the pattern of Mask (non-complemented): mask-driven, see k_spgemm_mhash / k_spgemm_mwin.
+// Returns nullptr when the heavy-row path is unaffordable (offset table too large): the caller then takes the full product.
+template <typename T>
+static GB_Matrix_opaque *spgemm_masked(GB_Matrix_opaque *A, const void *Ax, GB_Matrix_opaque *B, const void *Bx, int st, int monoid,
+                                       int mult, GB_Matrix_opaque *Mask)
+{
+    GB_Matrix_opaque *Tm = matrix_new(type_of_code(st), A->nrows, B->ncols);
+    if (A->nvals == 0 || B->nvals == 0 || Mask->nvals == 0) return Tm;
+    try {
+        const int64_t m = (int64_t)A->nrows, nnzM = Mask->nvals;
+        MxmArgs a{};
+        a.m = m;
+        a.n = (int64_t)B->ncols;
+        a.Ap = A->d_ptr; a.Aj = A->d_col; a.Ax = Ax; a.a_iso = A->iso ? 1 : 0;
+        a.Bp = B->d_ptr; a.Bj = B->d_col; a.Bx = Bx; a.b_iso = B->iso ? 1 : 0;
+        a.monoid = monoid;
+        a.mult = mult;
+        a.need_a = !(mult == OP_PAIR || mult == OP_SECOND);
+        a.need_b = !(mult == OP_PAIR || mult == OP_FIRST || mult == OP_ANY);
+        a.Mp = matrix_rowptr(Mask);
+        a.Mj = Mask->d_col;
+        DevBuf<T> cap_val(nnzM);
+        DevBuf<unsigned char> cap_hit(nnzM, true);
+        a.cap_val = cap_val.p;
+        a.cap_hit = cap_hit.p;
+        // rows binned by the length of their mask row (rows of A without entries produce nothing)
+        DevBuf<int64_t> size(m + 1);
+        hipLaunchKernelGGL(k_mask_sizes, dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, ctx().stream, (const int64_t *)A->d_ptr,
+                           a.Mp, m, size.p);
+        RowBins rb(m);
+        make_bins(rb, A->d_ptr, nullptr, m, size.p, 128, 1024, 4096);
+        DevBuf<int32_t> woff(0);
+        if (rb.count(4)) {
+            const int64_t n_win = ceil_div((int64_t)B->ncols, MM_WIN);
+            const int64_t woff_entries = (int64_t)B->nrows * (n_win + 1);
+            if (woff_entries * 4 > (8ll << 30)) {
+                matrix_free(Tm);
+                return nullptr;
+            }
+            dev_free(woff.p);
+            woff.p = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)woff_entries);
+            hipLaunchKernelGGL(k_window_offsets, dim3((unsigned)ceil_div((int64_t)B->nrows, 256)), dim3(256), 0, ctx().stream,
+                               (const int64_t *)B->d_ptr, (const int32_t *)B->d_col, (int64_t)B->nrows, (int)n_win, woff.p);
+            a.woff = woff.p;
+            a.n_win = (int)n_win;
+        }
+        if (rb.count(1)) hipLaunchKernelGGL((k_spgemm_mhash<T, 256>), dim3((unsigned)rb.count(1)), dim3(MM_BLOCK), 0, ctx().stream, a, rb.ptr(1));
+        if (rb.count(2)) hipLaunchKernelGGL((k_spgemm_mhash<T, 2048>), dim3((unsigned)rb.count(2)), dim3(MM_BLOCK), 0, ctx().stream, a, rb.ptr(2));
+        if (rb.count(3)) hipLaunchKernelGGL((k_spgemm_mhash<T, 8192>), dim3((unsigned)rb.count(3)), dim3(MM_BLOCK), 0, ctx().stream, a, rb.ptr(3));
+        if (rb.count(4)) hipLaunchKernelGGL((k_spgemm_mwin<T>), dim3((unsigned)rb.count(4)), dim3(MM_WIN_BLOCK), 0, ctx().stream, a, rb.ptr(4));
+        GRB_HIP(hipGetLastError());
+        ctx().stats.kernel_launches += 5;
+        // compaction: position of every hit, row pointers, scatter
+        DevBuf<int64_t> pos(nnzM + 1);
+        hipLaunchKernelGGL(k_hits_to_i64, dim3((unsigned)ceil_div(nnzM + 1, 256)), dim3(256), 0, ctx().stream,
+                           (const unsigned char *)cap_hit.p, nnzM, pos.p);
+        prim_exclusive_sum_i64(pos.p, pos.p, nnzM + 1);
+        int64_t nnzT = 0;
+        d2h(&nnzT, pos.p + nnzM, sizeof(int64_t));
+        ctx().stats.out_nvals = nnzT;
+        if (nnzT > 0) {
+            Tm->d_ptr = (int64_t *)dev_alloc(sizeof(int64_t) * (m + 1));
+            hipLaunchKernelGGL(k_cap_rowptr, dim3((unsigned)ceil_div(m + 1, 256)), dim3(256), 0, ctx().stream, a.Mp,
+                               (const int64_t *)pos.p, m, Tm->d_ptr);
+            Tm->d_col = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)nnzT);
+            Tm->d_val = dev_alloc(sizeof(T) * (size_t)nnzT);
+            Tm->nvals = nnzT;
+            hipLaunchKernelGGL((k_cap_scatter<T>), dim3((unsigned)ceil_div(nnzM, 256)), dim3(256), 0, ctx().stream,
+                               (const unsigned char *)cap_hit.p, (const int64_t *)pos.p, a.Mj, (const T *)cap_val.p, nnzM, Tm->d_col,
+                               (T *)Tm->d_val);
+        }
+        sync_stream();  // the temporaries are released at the end of this scope
+    } catch (...) {
+        matrix_free(Tm);
+        throw;
+    }
+    return Tm;
+}
+
+// flops of A (+.x) B = sum over the entries A(i,k) of nnz(B(k,:))
+static int64_t product_flops(GB_Matrix_opaque *A, GB_Matrix_opaque *B)
+{
+    if (A->nvals == 0 || B->nvals == 0) return 0;
+    DevBuf<int64_t> F(A->nvals + 1);
+    hipLaunchKernelGGL(k_nnz_flops, dim3((unsigned)ceil_div(A->nvals + 1, 256)), dim3(256), 0, ctx().stream, A->d_col, A->nvals, B->d_ptr,
+                       F.p);
+    prim_exclusive_sum_i64(F.p, F.p, A->nvals + 1);
+    int64_t flops = 0;
+    d2h(&flops, F.p + A->nvals, sizeof(int64_t));
+    return flops;
+}
+
 struct MDesc {
     bool replace = false, comp = false, structure = false, t0 = false, t1 = false;
 };
@@ -726,7 +990,19 @@ static void mxm_core(GB_Matrix_opaque *C, GB_Matrix_opaque *Mask, const GB_Binar
         Bx = b_cast.p;
     }
     GB_Matrix_opaque *Tm = nullptr;
-    GRB_DISPATCH_TYPE(st, T, { Tm = spgemm<T>(Ae, Ax, Be, Bx, st, monoid, mult); })
+    // A non-complemented mask bounds the useful part of the product by its own pattern: take the mask-driven path when the
+    // full product would cost clearly more than walking it with the mask rows in LDS (always / never: option mxm_mask_mode)
+    if (Mask && !f.comp && ctx().mxm_mask_mode != 0 && Mask->nvals > 0 && Mask->nvals < 0x7fffffffll * 8) {
+        const int64_t flops = product_flops(Ae, Be);
+        if (ctx().mxm_mask_mode == 2 || flops > 4 * (Mask->nvals + Ae->nvals)) {
+            GRB_DISPATCH_TYPE(st, T, { Tm = spgemm_masked<T>(Ae, Ax, Be, Bx, st, monoid, mult, Mask); })
+            if (Tm) {
+                ctx().stats.method = 4;
+                ctx().stats.flops = flops;
+            }
+        }
+    }
+    if (!Tm) GRB_DISPATCH_TYPE(st, T, { Tm = spgemm<T>(Ae, Ax, Be, Bx, st, monoid, mult); })
     try {
         // T in the output type
         if (Tm->nvals && Tm->type->code != C->type->code) {

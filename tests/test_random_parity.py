@@ -247,6 +247,65 @@ def test_mxm_random(gb, seed):
     same_mat(C, exp)
 
 
+@pytest.mark.parametrize("seed", range(16))
+def test_mxm_mask_driven(gb, seed):
+    """Mask-driven SpGEMM (forced on): non-complemented structural and valued masks, every hash table size of the mask
+    rows, mask rows longer than 4096 entries (LDS column windows, one and many windows), accumulators, replace, empty
+    rows of A / of the mask, C aliased with the mask."""
+    from graphblas_amd import _lib, device
+
+    rng = np.random.default_rng(1500 + seed)
+    tname = TYPES[seed % 7]
+    srs = semirings_for(tname)
+    sr = srs[rng.integers(len(srs))]
+    m, k, n = (int(x) for x in rng.integers(1, 300, 3))
+    heavy = seed % 4 == 1
+    if heavy:
+        m, k, n = 30, 500, (9000 if seed % 8 == 1 else 200000)
+    ar, ac, av = rand_coo(rng, m, k, tname, long_rows=2 if heavy else int(rng.integers(0, 2)))
+    br, bc, bv = rand_coo(rng, k, n, tname, long_rows=int(rng.integers(0, 3)))
+    if heavy:
+        deg = rng.integers(20, 60, k)
+        br = np.repeat(np.arange(k), deg)
+        bc = np.concatenate([rng.choice(n, d, replace=False) for d in deg])
+        bv = rand_vals(rng, br.size, tname)
+    mr, mc, mv = rand_coo(rng, m, n, "INT8", long_rows=2)
+    if heavy:  # mask rows of every size class: 5000+ entries (windows), ~2000, ~500, ~50 and empty ones
+        lens = [min(n, x) for x in (6000, 5000, 2000, 500, 50, 0, 1)]
+        rows_ = rng.choice(m, len(lens), replace=False)
+        mr = np.concatenate([np.full(ln, r) for r, ln in zip(rows_, lens)])
+        mc = np.concatenate([rng.choice(n, ln, replace=False) for ln in lens])
+        mv = rng.integers(0, 2, mr.size).astype(np.int8)
+    cr, cc, cv = rand_coo(rng, m, n, tname)
+    struct, repl = bool(seed & 1), bool(seed & 2)
+    accum = [None, "plus", "min", "second"][seed % 4] if seed % 3 else None
+    use_c = bool(rng.integers(2)) or accum is not None
+    oa, ob = O.OMat.from_coo(ar, ac, av, m, k, tname), O.OMat.from_coo(br, bc, bv, k, n, tname)
+    oc = O.OMat.from_coo(cr, cc, cv, m, n, tname) if use_c else None
+    om = O.OMat.from_coo(mr, mc, mv, m, n, "INT8")
+    exp = O.mxm(oa, ob, sr, C=oc, mask=om, mask_struct=struct, accum=accum, replace=repl)
+    try:
+        _lib.lib.GrX_option_set(b"mxm_mask_mode", 2)
+        A = gb.Matrix.from_coo(ar, ac, av, dtype=tname, nrows=m, ncols=k)
+        B = gb.Matrix.from_coo(br, bc, bv, dtype=tname, nrows=k, ncols=n)
+        C = gb.Matrix.from_coo(cr, cc, cv, dtype=tname, nrows=m, ncols=n) if use_c else gb.Matrix(tname, m, n)
+        M = gb.Matrix.from_coo(mr, mc, mv, dtype="INT8", nrows=m, ncols=n)
+        kw = dict(mask=M.S if struct else M.V, replace=repl)
+        if accum:
+            kw["accum"] = accum
+        C(**kw) << A.mxm(B, getattr(gb.semiring, sr))
+        assert device.last_stats()["method"] == 4  # the mask-driven path really ran
+        same_mat(C, exp)
+        if m == n and not accum:  # the mask is the output itself (C<C.S> = A B)
+            D = gb.Matrix.from_coo(mr, mc, mv.astype(np.int64), dtype="INT64", nrows=m, ncols=n)
+            od = O.OMat.from_coo(mr, mc, mv.astype(np.int64), m, n, "INT64")
+            exp2 = O.mxm(O.OMat.from_coo(ar, ac, av, m, k, tname), ob, sr, C=od, mask=od, mask_struct=True)
+            D(D.S) << A.mxm(B, getattr(gb.semiring, sr))
+            same_mat(D, exp2)
+    finally:
+        _lib.lib.GrX_option_set(b"mxm_mask_mode", 1)
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_mxm_transposes_and_types(gb, seed):
     rng = np.random.default_rng(600 + seed)
