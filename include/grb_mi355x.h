@@ -92,6 +92,7 @@ GrB_Info GrB_Matrix_new(GrB_Matrix *A, GrB_Type type, GrB_Index nrows, GrB_Index
 GrB_Info GrB_Matrix_dup(GrB_Matrix *C, const GrB_Matrix A);
 GrB_Info GrB_Matrix_free(GrB_Matrix *A);
 GrB_Info GrB_Matrix_clear(GrB_Matrix A);
+GrB_Info GrB_Matrix_resize(GrB_Matrix A, GrB_Index nrows, GrB_Index ncols); /* core/matrix.py:512-523 */
 GrB_Info GrB_Matrix_nrows(GrB_Index *nrows, const GrB_Matrix A);
 GrB_Info GrB_Matrix_ncols(GrB_Index *ncols, const GrB_Matrix A);
 GrB_Info GrB_Matrix_nvals(GrB_Index *nvals, const GrB_Matrix A);
@@ -108,6 +109,7 @@ GrB_Info GrB_Vector_new(GrB_Vector *v, GrB_Type type, GrB_Index n);
 GrB_Info GrB_Vector_dup(GrB_Vector *w, const GrB_Vector u);
 GrB_Info GrB_Vector_free(GrB_Vector *v);
 GrB_Info GrB_Vector_clear(GrB_Vector v);
+GrB_Info GrB_Vector_resize(GrB_Vector v, GrB_Index size);                    /* core/vector.py:455-463 */
 GrB_Info GrB_Vector_size(GrB_Index *n, const GrB_Vector v);
 GrB_Info GrB_Vector_nvals(GrB_Index *nvals, const GrB_Vector v);
 GrB_Info GrB_Vector_wait(GrB_Vector v, GrB_WaitMode mode);

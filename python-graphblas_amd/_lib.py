@@ -86,6 +86,7 @@ def _declare(L):
     L.GrB_Matrix_dup.argtypes = [P(c_void_p), c_void_p]
     L.GrB_Matrix_free.argtypes = [P(c_void_p)]
     L.GrB_Matrix_clear.argtypes = [c_void_p]
+    L.GrB_Matrix_resize.argtypes = [c_void_p, c_u64, c_u64]
     for name in ("GrB_Matrix_nrows", "GrB_Matrix_ncols", "GrB_Matrix_nvals", "GrB_Vector_size", "GrB_Vector_nvals"):
         getattr(L, name).argtypes = [P(c_u64), c_void_p]
     L.GrB_Matrix_wait.argtypes = [c_void_p, c_int]
@@ -98,6 +99,7 @@ def _declare(L):
     L.GrB_Vector_dup.argtypes = [P(c_void_p), c_void_p]
     L.GrB_Vector_free.argtypes = [P(c_void_p)]
     L.GrB_Vector_clear.argtypes = [c_void_p]
+    L.GrB_Vector_resize.argtypes = [c_void_p, c_u64]
     for t in TYPE_NAMES:
         getattr(L, f"GrB_Matrix_build_{t}").argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_u64, c_void_p]
         getattr(L, f"GrB_Matrix_extractTuples_{t}").argtypes = [c_void_p, c_void_p, c_void_p, P(c_u64), c_void_p]

@@ -1214,3 +1214,138 @@ extern "C" GrB_Info GrX_Vector_modified(GrB_Vector v)
     v->nvals = -1;  // the caller wrote the HBM image obtained from GrX_Vector_export_dense_device
     GRB_CATCH(errp(v))
 }
+
+// ---------------------------------------------------------------------------------------------------
+// resize (reference: Matrix.resize core/matrix.py:512-523, Vector.resize core/vector.py:455-463): growing adds empty
+// positions, shrinking drops the entries beyond the new bounds
+// ---------------------------------------------------------------------------------------------------
+namespace grb {
+__global__ void k_trim_bits(uint64_t *bits, int64_t n)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0 && (n & 63)) bits[n >> 6] &= (1ull << (n & 63)) - 1ull;
+}
+// keep[p] = entry p survives (its row < new_rows and its column < new_cols); row of p by binary search in the row pointers
+__global__ void k_resize_keep(const int64_t *ptr, const int32_t *col, int64_t old_rows, int64_t nnz, int64_t new_rows, int64_t new_cols,
+                              int64_t *keep)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p > nnz) return;
+    if (p == nnz) { keep[p] = 0; return; }
+    int64_t lo = 0, hi = old_rows;  // last row with ptr[row] <= p
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (ptr[mid] <= p) lo = mid;
+        else hi = mid;
+    }
+    keep[p] = (lo < new_rows && (int64_t)col[p] < new_cols) ? 1 : 0;
+}
+__global__ void k_resize_rowptr(const int64_t *old_ptr, const int64_t *pos, int64_t old_rows, int64_t new_rows, int64_t *new_ptr)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= new_rows) new_ptr[i] = pos[old_ptr[i < old_rows ? i : old_rows]];
+}
+template <typename T>
+__global__ void k_resize_scatter(const int64_t *pos, int64_t nnz, const int32_t *col, const T *val, int iso, int32_t *ncol, T *nval)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < nnz && pos[p + 1] != pos[p]) {
+        ncol[pos[p]] = col[p];
+        if (!iso) nval[pos[p]] = val[p];
+    }
+}
+}  // namespace grb
+
+extern "C" GrB_Info GrB_Vector_resize(GrB_Vector v, GrB_Index new_size)
+{
+    GRB_TRY
+    require_init();
+    check_vector(v, "v");
+    if (new_size > GrB_INDEX_MAX + 1) fail(GrB_INVALID_VALUE, "GrB_Vector_resize: size exceeds GrB_INDEX_MAX+1");
+    if (new_size == v->n) return GrB_SUCCESS;
+    if (!v->d_val) {
+        v->n = new_size;
+        return GrB_SUCCESS;
+    }
+    if (new_size > (1ull << 40)) fail(GrB_OUT_OF_MEMORY, "dense-with-presence vector of this size does not fit in HBM");
+    const uint64_t old_n = v->n;
+    void *old_val = v->d_val;
+    uint64_t *old_bits = v->d_bits;
+    const bool old_padded = v->padded;
+    v->n = new_size;
+    const bool padded = (int64_t)((size_t)new_size * v->type->size) >= ctx().vec_pad_min_bytes;
+    void *nv = nullptr;
+    uint64_t *nb = nullptr;
+    try {
+        vector_alloc_pair(v, padded, true, &nv, &nb);
+    } catch (...) {
+        v->n = old_n;
+        throw;
+    }
+    const uint64_t keep = std::min<uint64_t>(old_n, new_size);
+    d2d(nv, old_val, (size_t)keep * v->type->size);
+    d2d(nb, old_bits, bits_words64(keep) * 8);
+    if (new_size < old_n) {
+        LAUNCH(k_trim_bits, 1, nb, (int64_t)new_size);
+        v->nvals = -1;
+    }
+    vector_free_pair(old_padded, old_val, old_bits);
+    v->d_val = nv;
+    v->d_bits = nb;
+    v->padded = padded;
+    if (ctx().blocking) sync_stream();
+    GRB_CATCH(errp(v))
+}
+
+extern "C" GrB_Info GrB_Matrix_resize(GrB_Matrix A, GrB_Index new_nrows, GrB_Index new_ncols)
+{
+    GRB_TRY
+    require_init();
+    check_matrix(A, "A");
+    if (new_nrows > GrB_INDEX_MAX + 1 || new_ncols > GrB_INDEX_MAX + 1) fail(GrB_INVALID_VALUE, "GrB_Matrix_resize: dimension exceeds GrB_INDEX_MAX+1");
+    if (new_nrows == A->nrows && new_ncols == A->ncols) return GrB_SUCCESS;
+    if (A->nvals == 0 || !A->d_ptr) {
+        matrix_release_storage(A);
+        A->nrows = new_nrows;
+        A->ncols = new_ncols;
+        return GrB_SUCCESS;
+    }
+    check_index_width(new_nrows, std::min<uint64_t>(new_ncols, A->ncols));  // (surviving columns are below both bounds)
+    const int64_t nnz = A->nvals, old_rows = (int64_t)A->nrows;
+    DevBuf<int64_t> pos(nnz + 1);
+    LAUNCH(k_resize_keep, nnz + 1, (const int64_t *)A->d_ptr, (const int32_t *)A->d_col, old_rows, nnz, (int64_t)new_nrows,
+           (int64_t)std::min<uint64_t>(new_ncols, 0x7fffffffull), pos.p);
+    prim_exclusive_sum_i64(pos.p, pos.p, nnz + 1);
+    int64_t kept = 0;
+    d2h(&kept, pos.p + nnz, sizeof(int64_t));
+    GB_Matrix_opaque *N = matrix_new(A->type, new_nrows, new_ncols);
+    try {
+        if (kept > 0) {
+            if (new_ncols > 0x7fffffffull) fail(GrB_NOT_IMPLEMENTED, "matrices with entries need ncols < 2^31 (int32 column indices)");
+            N->d_ptr = (int64_t *)dev_alloc(sizeof(int64_t) * (size_t)(new_nrows + 1));
+            LAUNCH(k_resize_rowptr, (int64_t)new_nrows + 1, (const int64_t *)A->d_ptr, (const int64_t *)pos.p, old_rows, (int64_t)new_nrows,
+                   N->d_ptr);
+            N->d_col = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)kept);
+            N->d_val = dev_alloc(A->type->size * (size_t)(A->iso ? 1 : kept));
+            if (A->iso) d2d(N->d_val, A->d_val, A->type->size);
+            GRB_DISPATCH_TYPE(A->type->code, T, {
+                LAUNCH((k_resize_scatter<T>), nnz, (const int64_t *)pos.p, nnz, (const int32_t *)A->d_col, (const T *)A->d_val, A->iso ? 1 : 0,
+                       N->d_col, (T *)N->d_val);
+            })
+            N->nvals = kept;
+            N->iso = A->iso;
+            N->owns = true;
+        }
+        sync_stream();  // `pos` is released at the end of this scope
+        matrix_release_storage(A);  // (also drops the cached transpose, tile table, hot table and split)
+        A->nrows = new_nrows;
+        A->ncols = new_ncols;
+        A->d_ptr = N->d_ptr; A->d_col = N->d_col; A->d_val = N->d_val;
+        A->nvals = N->nvals; A->iso = N->iso; A->owns = true;
+        N->d_ptr = nullptr; N->d_col = nullptr; N->d_val = nullptr; N->nvals = 0;
+    } catch (...) {
+        matrix_free(N);
+        throw;
+    }
+    matrix_free(N);
+    GRB_CATCH(errp(A))
+}

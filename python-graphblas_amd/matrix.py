@@ -185,6 +185,15 @@ class Matrix(BaseType):
     def clear(self):
         call("GrB_Matrix_clear", [self])
 
+    def resize(self, nrows, ncols):
+        """In place: growing adds empty rows / columns, shrinking drops the entries beyond the new bounds
+        (reference core/matrix.py:512-523)."""
+        nrows, ncols = int(nrows), int(ncols)
+        if nrows < 0 or ncols < 0:
+            raise ValueError("nrows and ncols must be non-negative")
+        call("GrB_Matrix_resize", [self, nrows, ncols])
+        self._nrows, self._ncols = nrows, ncols
+
     def isequal(self, other, *, check_dtype=False):
         """Same shape, structure and values (reference core/matrix.py:373-415)."""
         if not isinstance(other, Matrix):

@@ -148,6 +148,15 @@ class Vector(BaseType):
     def clear(self):
         call("GrB_Vector_clear", [self])
 
+    def resize(self, size):
+        """In place: growing adds empty positions, shrinking drops the entries at or above the new size
+        (reference core/vector.py:455-463)."""
+        size = int(size)
+        if size < 0:
+            raise ValueError("size must be non-negative")
+        call("GrB_Vector_resize", [self, size])
+        self._size = size
+
     def isequal(self, other, *, check_dtype=False):
         """Same size, structure and values (reference core/vector.py:340-379)."""
         if not isinstance(other, Vector):

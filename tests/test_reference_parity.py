@@ -224,6 +224,65 @@ def test_roundtrips(gb):
     assert gb.Vector(float, 5).nvals == 0
 
 
+def test_resize(gb, A, v):
+    # graphblas/tests/test_matrix.py:193-206, graphblas/tests/test_vector.py:182-191
+    assert (A.nrows, A.ncols, A.nvals) == (7, 7, 12)
+    A.resize(10, 11)
+    assert (A.nrows, A.ncols, A.nvals) == (10, 11, 12)
+    I, J, _ = A.to_coo()
+    assert not ((I == 9) & (J == 9)).any()
+    A.resize(4, 1)
+    assert (A.nrows, A.ncols, A.nvals) == (4, 1, 1)
+    assert [x.tolist() for x in A.to_coo()] == [[3], [0], [3]]
+    assert (v.size, v.nvals) == (7, 4)
+    v.resize(20)
+    assert (v.size, v.nvals) == (20, 4)
+    assert 19 not in v.to_coo()[0].tolist()
+    v.resize(4)
+    assert (v.size, v.nvals) == (4, 2)
+    assert [x.tolist() for x in v.to_coo()] == [[1, 3], [1, 1]]
+
+
+def test_resize_random(gb):
+    """resize against a numpy restatement (drop what lies beyond the new bounds), then use the result in mxv: caches of the
+    old shape must not survive."""
+    rng = np.random.default_rng(8)
+    for trial in range(6):
+        m, n = int(rng.integers(1, 90)), int(rng.integers(1, 90))
+        r, c = np.nonzero(rng.random((m, n)) < 0.25)
+        x = rng.integers(1, 9, r.size).astype(np.int64) if trial % 2 else np.ones(r.size, np.int64)  # (iso when all ones)
+        M = gb.Matrix.from_coo(r, c, x, nrows=m, ncols=n)
+        u = gb.Vector.from_coo(np.arange(n), np.arange(n) + 1, size=n)
+        M.mxv(u, gb.semiring.plus_times).new()  # builds whatever the library caches for this shape
+        m2, n2 = int(rng.integers(0, 120)), int(rng.integers(0, 120))
+        M.resize(m2, n2)
+        keep = (r < m2) & (c < n2)
+        I, J, X = M.to_coo()
+        order = np.lexsort((c[keep], r[keep]))
+        assert (M.nrows, M.ncols, M.nvals) == (m2, n2, int(keep.sum()))
+        assert I.tolist() == r[keep][order].tolist() and J.tolist() == c[keep][order].tolist() and X.tolist() == x[keep][order].tolist()
+        u.resize(n2)
+        assert u.nvals == min(n, n2)
+        w = M.mxv(u, gb.semiring.plus_times).new()
+        dense = np.zeros((m2, n2), np.int64)
+        dense[r[keep], c[keep]] = x[keep]
+        uu = np.zeros(n2, np.int64)
+        uu[: min(n, n2)] = np.arange(min(n, n2)) + 1
+        pres = np.zeros((m2, n2), bool)
+        pres[r[keep], c[keep]] = True
+        pres[:, min(n, n2):] = False
+        wi, wv = w.to_coo()
+        assert wi.tolist() == np.nonzero(pres.any(axis=1))[0].tolist()
+        assert wv.tolist() == (dense @ uu)[pres.any(axis=1)].tolist()
+    big = gb.Vector.from_coo([0, 5, 70, 128, 129], [1, 2, 3, 4, 5], size=130)
+    big.resize(129)
+    assert big.to_coo()[0].tolist() == [0, 5, 70, 128]
+    big.resize(64)
+    assert big.to_coo()[0].tolist() == [0, 5]
+    big.resize(0)
+    assert big.nvals == 0 and big.size == 0
+
+
 # ---- mxm ------------------------------------------------------------------------------------------------
 def test_mxm(gb, A):
     # graphblas/tests/test_matrix.py:307-314
