@@ -1027,19 +1027,15 @@ __global__ void k_long_init(W *tl_val, unsigned char *tl_has, int64_t n, W ident
 constexpr int ROWS_BLOCK = 256;
 constexpr int ROWS_EPL = 4;
 
+// one group of 64 rows, by one wavefront; mark / acc / has are the wavefront's LDS scratch
 template <typename T, int MONOID_CT, int MULT_CT>
-__global__ __launch_bounds__(ROWS_BLOCK) void k_mxv_rows(const PullArgs a)
+__device__ __forceinline__ void rows_group(const PullArgs &a, int64_t g, int lane, unsigned char *mark,
+                                           typename Widen<T>::type *acc_slots, unsigned char *has_slots)
 {
     using W = typename Widen<T>::type;
-    constexpr int EPL = ROWS_EPL, WIN = 64 * EPL, NW = ROWS_BLOCK / 64;
-    __shared__ __attribute__((aligned(16))) unsigned char s_mark[NW][WIN];
-    __shared__ W s_acc[NW][128];  // 64 rows + one scratch slot per lane ("nothing to emit" of the branch-free fold)
-    __shared__ unsigned char s_has[NW][128];
+    constexpr int EPL = ROWS_EPL, WIN = 64 * EPL;
     const int monoid = MONOID_CT >= 0 ? MONOID_CT : a.monoid;
     const int mult = MULT_CT >= 0 ? MULT_CT : a.mult;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t g = (int64_t)blockIdx.x * NW + __builtin_amdgcn_readfirstlane(wave);
-    if ((g << 6) >= a.m) return;  // wave-uniform; wavefronts never wait for each other
     const T *aval = (const T *)a.aval;
     const bool need_aval = a.need_aval != 0, need_uval = a.need_uval != 0;
     const bool stage_vals = need_aval && !a.a_iso;
@@ -1074,10 +1070,10 @@ __global__ __launch_bounds__(ROWS_BLOCK) void k_mxv_rows(const PullArgs a)
     const int rel = (int)(p0 - gbase), len = (int)(p1 - p0);
     const int total = __builtin_amdgcn_readfirstlane(__shfl(rel + len, 63));  // entries of the group (< 64 * split_min_len)
 
-    s_acc[wave][lane] = monoid_identity<T, W>(monoid);
-    s_acc[wave][64 + lane] = monoid_identity<T, W>(monoid);
-    s_has[wave][lane] = 0;
-    s_has[wave][64 + lane] = 0;
+    acc_slots[lane] = monoid_identity<T, W>(monoid);
+    acc_slots[64 + lane] = monoid_identity<T, W>(monoid);
+    has_slots[lane] = 0;
+    has_slots[64 + lane] = 0;
 
     const int64_t left = a.nnz - gbase;  // entries from the group's first to the end of the arrays
     const __amdgpu_buffer_rsrc_t crs = make_rsrc(a.col + gbase, left * 4);
@@ -1116,13 +1112,13 @@ __global__ __launch_bounds__(ROWS_BLOCK) void k_mxv_rows(const PullArgs a)
         }
         // ---- row of each entry: marks where rows start inside the window, max-scan across the wavefront -------------
         using MarkWord = typename std::conditional<EPL == 8, uint64_t, uint32_t>::type;  // my EPL marks in one LDS access
-        *(MarkWord *)&s_mark[wave][lane * EPL] = 0;
+        *(MarkWord *)&mark[lane * EPL] = 0;
         wave_sync();
-        if (len > 0 && rel >= wbase && rel < wbase + WIN) s_mark[wave][rel - wbase] = (unsigned char)(lane + 1);
+        if (len > 0 && rel >= wbase && rel < wbase + WIN) mark[rel - wbase] = (unsigned char)(lane + 1);
         const unsigned long long before = __ballot(len > 0 && rel <= wbase);  // rows begun at or before the window start
         const int carry_in = 64 - __clzll(before);                            // (1 + the last of them; never 0 inside a group)
         wave_sync();
-        const uint64_t mk = *(const MarkWord *)&s_mark[wave][lane * EPL];
+        const uint64_t mk = *(const MarkWord *)&mark[lane * EPL];
         int h[EPL];
 #pragma unroll
         for (int i = 0; i < EPL; i++) h[i] = (int)((mk >> (8 * i)) & 0xffu);
@@ -1192,9 +1188,9 @@ __global__ __launch_bounds__(ROWS_BLOCK) void k_mxv_rows(const PullArgs a)
             has = xp[i] || keep;
             const bool seg_end = (i == EPL - 1) ? true : (h[i + 1] != 0);
             const int k = (seg_end && has) ? ek[i] - 1 : 64 + lane;
-            if (monoid == OP_ANY) s_acc[wave][k] = (W)acc;
-            else atomic_combine<W>(&s_acc[wave][k], (W)acc, monoid);
-            s_has[wave][k] = 1;
+            if (monoid == OP_ANY) acc_slots[k] = (W)acc;
+            else atomic_combine<W>(&acc_slots[k], (W)acc, monoid);
+            has_slots[k] = 1;
         }
     }
     wave_sync();
@@ -1202,13 +1198,28 @@ __global__ __launch_bounds__(ROWS_BLOCK) void k_mxv_rows(const PullArgs a)
     // ---- write rule for my row; the wavefront owns the whole presence word ----------------------------------------------
     if (a.dbg & 4) return;
     if (!is_long) {
-        t_has = s_has[wave][lane] != 0;
-        t_acc = s_acc[wave][lane];
+        t_has = has_slots[lane] != 0;
+        t_acc = acc_slots[lane];
     }
     bool new_has = false;
     if (in) new_has = write_rule_row<T>(a, row, (actw >> lane) & 1ull, old_has, old_val, t_has, from_acc<T, W>(t_acc));
     const unsigned long long nb = __ballot(in && new_has);
     if (lane == 0) a.w_new_bits[g] = nb;
+}
+
+
+template <typename T, int MONOID_CT, int MULT_CT>
+__global__ __launch_bounds__(ROWS_BLOCK) void k_mxv_rows(const PullArgs a)
+{
+    using W = typename Widen<T>::type;
+    constexpr int WIN = 64 * ROWS_EPL, NW = ROWS_BLOCK / 64;
+    __shared__ __attribute__((aligned(16))) unsigned char s_mark[NW][WIN];
+    __shared__ W s_acc[NW][128];  // 64 rows + one scratch slot per lane ("nothing to emit" of the branch-free fold)
+    __shared__ unsigned char s_has[NW][128];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t g = (int64_t)blockIdx.x * NW + wave;
+    if ((g << 6) >= a.m) return;  // wave-uniform; wavefronts never wait for each other
+    rows_group<T, MONOID_CT, MULT_CT>(a, g, lane, s_mark[wave], s_acc[wave], s_has[wave]);
 }
 
 // ---- building the split (once per matrix) ---------------------------------------------------------------------
@@ -1873,6 +1884,8 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
         if (ctx().short_kernel == 1 && S->nrows == A->nrows) {
             // short rows: one wavefront per 64 consecutive rows, which also applies the write rule of the long rows
             b.long_prefix = A->d_long_prefix;
+            // (persistent variants -- static strides with the next group prefetched, or an LDS work counter per workgroup --
+            //  measured 3-10 % slower than one group per wavefront)
             hipLaunchKernelGGL((k_mxv_rows<T, MON, MUL>), dim3((unsigned)ceil_div(ceil_div(b.m, 64), ROWS_BLOCK / 64)), dim3(ROWS_BLOCK), 0,
                                ctx().stream, b);
             GRB_HIP(hipGetLastError());
