@@ -812,6 +812,11 @@ __global__ __launch_bounds__(LONG_BLOCK) void k_mxv_long_grp(const PullArgs a)
                 GRP_ENTRY_LOADS(f_st, 0);
                 if ((q + 2 * nwv) * 4 < n_it) GRP_ITEM_LOADS(q + 2 * nwv);
             }
+            if (a.dbg & (16384 | 32768)) {  // diagnostic: fold the image gathers into 2^19 / 2^14 entries
+                const int gmask = (a.dbg & 16384) ? 0x7ffff : 0x3fff;
+#pragma unroll
+                for (int i = 0; i < EPL; i++) cc[i] = cc[i] >= 0 ? (cc[i] & gmask) : cc[i];
+            }
             // cc: >= 0 a code to gather from the image, <= -2 an LDS slot, -1 nothing
             bool xp[EPL];
             T xv[EPL];
