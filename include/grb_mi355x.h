@@ -110,6 +110,7 @@ GrB_Info GrB_Vector_dup(GrB_Vector *w, const GrB_Vector u);
 GrB_Info GrB_Vector_free(GrB_Vector *v);
 GrB_Info GrB_Vector_clear(GrB_Vector v);
 GrB_Info GrB_Vector_resize(GrB_Vector v, GrB_Index size);                    /* core/vector.py:455-463 */
+GrB_Info GrB_Vector_removeElement(GrB_Vector w, GrB_Index i);                /* core/vector.py:1916-1930 */
 GrB_Info GrB_Vector_size(GrB_Index *n, const GrB_Vector v);
 GrB_Info GrB_Vector_nvals(GrB_Index *nvals, const GrB_Vector v);
 GrB_Info GrB_Vector_wait(GrB_Vector v, GrB_WaitMode mode);
@@ -142,7 +143,14 @@ GrB_Info GrB_Vector_error(const char **error, const GrB_Vector v);
                                       GrB_Index *Ax_len, GrB_Format format, const GrB_Matrix A);                       \
     GrB_Info GrB_Vector_build_##NAME(GrB_Vector w, const GrB_Index *I, const ctype *X, GrB_Index nvals,                \
                                      const GrB_BinaryOp dup);                                                          \
-    GrB_Info GrB_Vector_extractTuples_##NAME(GrB_Index *I, ctype *X, GrB_Index *nvals, const GrB_Vector v);
+    GrB_Info GrB_Vector_extractTuples_##NAME(GrB_Index *I, ctype *X, GrB_Index *nvals, const GrB_Vector v);               \
+    /* the vector operations around the path (BFS / SSSP loops: core/vector.py:1635-1684, 1840-1930, 1979-2035) */     \
+    GrB_Info GrB_Vector_setElement_##NAME(GrB_Vector w, ctype x, GrB_Index i);                                         \
+    GrB_Info GrB_Vector_extractElement_##NAME(ctype *x, const GrB_Vector u, GrB_Index i);                              \
+    GrB_Info GrB_Vector_assign_##NAME(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, ctype x,          \
+                                      const GrB_Index *indices, GrB_Index nindices, const GrB_Descriptor desc);       \
+    GrB_Info GrB_Vector_reduce_##NAME(ctype *val, const GrB_BinaryOp accum, const GrB_Monoid monoid,                   \
+                                      const GrB_Vector u, const GrB_Descriptor desc);
 GRB_FOR_EACH_TYPE(GRB_DECL_TYPED)
 #undef GRB_DECL_TYPED
 

@@ -356,5 +356,46 @@ def mxm(A: OMat, B: OMat, semiring="plus_times", *, C: OMat | None = None, out_t
     return OMat(C.nrows, C.ncols, p, j, x, ct)
 
 
+def vec_assign_scalar(w: OVec, value, *, mask: OVec | None = None, mask_comp=False, mask_struct=False, accum=None,
+                      replace=False) -> OVec:
+    """w<mask, replace>[:] = accum(w, value): GraphBLAS C API 2.0 GrB_Vector_assign with a scalar and GrB_ALL (the
+    reference's ``w(mask)[:] << s``, core/vector.py:1979-2035) -- T is ``value`` at every index, then the write rule."""
+    n = w.size
+    if mask is not None and mask.size != n:
+        raise ValueError("DimensionMismatch")
+    wt = w.tname
+    w_has, w_val = w.dense()
+    t_has = np.ones(n, np.uint8)
+    t_val = np.ascontiguousarray(cast(np.full(n, value), wt))
+    mt = _dense_mask(mask, mask_struct, n)
+    if n:
+        rc = lib().grbo_vec_write(TYPE_CODES[wt], ctypes.c_int64(n), _p(w_has), _p(w_val), _p(t_has), _p(t_val), _p(mt),
+                                  int(mask_comp), OP_CODES[accum] if accum else -1, int(replace))
+        assert rc == 0
+    return OVec.from_dense(w_has, w_val, wt)
+
+
+def vec_reduce(u: OVec, monoid: str):
+    """Fold of the stored values with ``monoid`` in u's type, ``None`` when u is empty (GrB_Vector_reduce; reference
+    core/vector.py:1635-1684).  Integers wrap like the C types; floating-point sums are left-to-right."""
+    if u.idx.size == 0:
+        return None
+    v = u.vals
+    if u.tname == "BOOL":
+        f = {"lor": np.logical_or, "plus": np.logical_or, "max": np.logical_or, "land": np.logical_and, "times": np.logical_and,
+             "min": np.logical_and, "lxor": np.logical_xor, "lxnor": lambda a, b: ~np.logical_xor(a, b)}[monoid]
+        return bool(f.reduce(v)) if hasattr(f, "reduce") else bool(__import__("functools").reduce(f, v))
+    with np.errstate(over="ignore"):
+        if monoid == "plus":
+            return np.add.reduce(v, dtype=v.dtype).item()
+        if monoid == "times":
+            return np.multiply.reduce(v, dtype=v.dtype).item()
+        if monoid == "min":
+            return v.min().item()
+        if monoid == "max":
+            return v.max().item()
+    raise NotImplementedError(monoid)
+
+
 def num_threads() -> int:
     return int(lib().grbo_num_threads())

@@ -43,5 +43,6 @@ def is_initialized():
 
 from .matrix import Matrix, TransposedMatrix  # noqa: E402
 from .vector import Vector  # noqa: E402
+from .base import Scalar  # noqa: E402
 
-__all__ = ["init", "Matrix", "Vector", "semiring", "binary", "monoid", "op", "dtypes", "replace", "exceptions"]
+__all__ = ["init", "Matrix", "Vector", "Scalar", "semiring", "binary", "monoid", "op", "dtypes", "replace", "exceptions"]

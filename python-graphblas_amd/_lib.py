@@ -99,6 +99,14 @@ def _declare(L):
     L.GrB_Vector_dup.argtypes = [P(c_void_p), c_void_p]
     L.GrB_Vector_free.argtypes = [P(c_void_p)]
     L.GrB_Vector_clear.argtypes = [c_void_p]
+    L.GrB_Vector_removeElement.argtypes = [c_void_p, c_u64]
+    for t, ct in (("BOOL", ctypes.c_bool), ("INT8", ctypes.c_int8), ("INT16", ctypes.c_int16), ("INT32", ctypes.c_int32),
+                  ("INT64", ctypes.c_int64), ("UINT8", ctypes.c_uint8), ("UINT16", ctypes.c_uint16), ("UINT32", ctypes.c_uint32),
+                  ("UINT64", ctypes.c_uint64), ("FP32", ctypes.c_float), ("FP64", ctypes.c_double)):
+        getattr(L, f"GrB_Vector_setElement_{t}").argtypes = [c_void_p, ct, c_u64]
+        getattr(L, f"GrB_Vector_extractElement_{t}").argtypes = [P(ct), c_void_p, c_u64]
+        getattr(L, f"GrB_Vector_assign_{t}").argtypes = [c_void_p, c_void_p, c_void_p, ct, c_void_p, c_u64, c_void_p]
+        getattr(L, f"GrB_Vector_reduce_{t}").argtypes = [P(ct), c_void_p, c_void_p, c_void_p, c_void_p]
     L.GrB_Vector_resize.argtypes = [c_void_p, c_u64]
     for t in TYPE_NAMES:
         getattr(L, f"GrB_Matrix_build_{t}").argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_u64, c_void_p]
@@ -141,3 +149,8 @@ def has_symbol(name: str) -> bool:
         return True
     except ValueError:
         return False
+
+
+def all_indices():
+    """The value of the library's ``GrB_ALL`` pointer (``v[:]``; reference core/expr.py:14)."""
+    return ctypes.c_void_p(ctypes.c_void_p.in_dll(lib, "GrB_ALL").value)

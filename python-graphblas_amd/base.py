@@ -170,6 +170,9 @@ class BaseType:
         """reference core/base.py:338-514."""
         if isinstance(expr, InfixMatMul):
             expr = expr.with_op(semiring.plus_times)
+        if isinstance(expr, Scalar) or _is_python_scalar(expr):
+            # ``w(mask) << 5``: scalar assign over every index (reference core/base.py:352-372 -> Updater[...] << scalar)
+            return self._assign_scalar_all(expr, mask=mask, accum=accum, replace=replace, opts=opts)
         if not isinstance(expr, Expression):
             raise TypeError(f"Assignment value must be a valid expression; got {type(expr).__name__}")
         if type(self) is not expr.output_type:
@@ -183,6 +186,9 @@ class BaseType:
                                  mask_structure=structure, output_replace=replace, **opts)
         args = [self, mask, accum, expr.op, *expr.args, desc]
         call(expr.cfunc_name, args)
+
+    def _assign_scalar_all(self, value, mask=None, accum=None, replace=False, *, opts):
+        raise TypeError(f"Scalar assignment is not supported for {type(self).__name__}")
 
     def wait(self, how="materialize"):
         call(f"GrB_{self._grb_kind}_wait", [self, 1 if how == "materialize" else 0])
@@ -201,6 +207,172 @@ class Updater:
 
     def update(self, expr):
         self.parent._update(expr, mask=self.mask, accum=self.accum, replace=self.replace, opts=self.opts)
+
+    def __getitem__(self, key):
+        if key == slice(None):
+            return AllIndexAssigner(self.parent, mask=self.mask, accum=self.accum, replace=self.replace, opts=self.opts)
+        if self.mask is not None:
+            raise TypeError("Single element assign does not accept a submask")
+        return self.parent._element_assigner(key, accum=self.accum)
+
+    def __setitem__(self, key, value):
+        self[key] << value
+
+
+class AllIndexAssigner:
+    """``w[:]`` / ``w(mask)[:]`` on the left of ``<<``: assign a scalar (or the collection's own kind of expression) to every
+    index under the updater's (mask, accum, replace) -- reference core/expr.py:484-560 restricted to ``[:]``."""
+
+    def __init__(self, parent, *, mask=None, accum=None, replace=False, opts=None):
+        self.parent, self.mask, self.accum, self.replace, self.opts = parent, mask, accum, replace, opts or {}
+
+    def __call__(self, *args, **kwargs):
+        if self.mask is not None or self.accum is not None or self.replace:
+            raise TypeError("mask, accum and replace were already given")
+        up = self.parent(*args, **kwargs)
+        return AllIndexAssigner(self.parent, mask=up.mask, accum=up.accum, replace=up.replace, opts=up.opts)
+
+    def __lshift__(self, value):
+        if not (isinstance(value, (Scalar, Expression, InfixMatMul)) or _is_python_scalar(value)):
+            raise TypeError(f"Bad type for arg `value` in {type(self.parent).__name__}[:] = ...: {type(value).__name__}")
+        self.parent._update(value, mask=self.mask, accum=self.accum, replace=self.replace, opts=self.opts)
+
+    update = __lshift__
+
+
+def _is_python_scalar(x):
+    import numpy as np
+
+    return isinstance(x, (bool, int, float, np.generic))
+
+
+class Scalar:
+    """A host-side scalar that may be empty (reference core/scalar.py, the parts the BFS / SSSP loops use: ``Scalar(dtype)``,
+    ``from_value``, ``s << v.reduce(...)``, ``s(accum=op) << ...``, ``.value``, ``is_empty``, truthiness, comparisons)."""
+
+    def __init__(self, dtype=float, *, name=None):
+        self.dtype = lookup_dtype(dtype)
+        self._value = None
+        self.name = name or "s"
+
+    @classmethod
+    def from_value(cls, value, dtype=None, *, name=None):
+        import numpy as np
+
+        if dtype is None:
+            dtype = lookup_dtype(np.asarray(value).dtype) if not isinstance(value, (bool, int, float)) else \
+                lookup_dtype(bool if isinstance(value, bool) else (np.int64 if isinstance(value, int) else np.float64))
+        s = cls(dtype, name=name)
+        s._value = s.dtype.np_type.type(value) if value is not None else None
+        return s
+
+    @property
+    def value(self):
+        return None if self._value is None else self._value.item()
+
+    @value.setter
+    def value(self, v):
+        self._value = None if v is None else self.dtype.np_type.type(v)
+
+    @property
+    def is_empty(self):
+        return self._value is None
+
+    @property
+    def nvals(self):
+        return 0 if self._value is None else 1
+
+    def clear(self):
+        self._value = None
+
+    def dup(self, dtype=None, *, name=None):
+        out = Scalar(dtype if dtype is not None else self.dtype, name=name)
+        out.value = self.value
+        return out
+
+    def new(self, dtype=None, *, name=None):
+        return self.dup(dtype, name=name)
+
+    def __bool__(self):
+        return bool(self._value) if self._value is not None else False
+
+    def __eq__(self, other):
+        other = other.value if isinstance(other, (Scalar, ScalarExpression)) else other
+        return self.value == other
+
+    def __hash__(self):
+        return id(self)
+
+    def __repr__(self):
+        return f"Scalar<{self.dtype}, value={self.value}>"
+
+    def isequal(self, other, *, check_dtype=False):
+        if isinstance(other, Scalar) and check_dtype and other.dtype is not self.dtype:
+            return False
+        return self == other
+
+    def __call__(self, *, accum=None):
+        return _ScalarUpdater(self, accum)
+
+    def __lshift__(self, expr):
+        _ScalarUpdater(self, None) << expr
+
+    def update(self, expr):
+        _ScalarUpdater(self, None) << expr
+
+
+class _ScalarUpdater:
+    def __init__(self, parent, accum):
+        self.parent, self.accum = parent, accum
+
+    def __lshift__(self, expr):
+        import numpy as np
+
+        s = self.parent
+        new = expr.value if isinstance(expr, (Scalar, ScalarExpression)) else expr
+        if new is not None and self.accum is not None and s._value is not None:
+            op = get_typed_op(self.accum, s.dtype, kind="binary")
+            new = _apply_host_binary(op.name, s.dtype.np_type.type(s.value), s.dtype.np_type.type(new))
+        elif new is None and self.accum is not None:
+            return  # nothing to accumulate
+        s._value = None if new is None else s.dtype.np_type.type(new)
+
+    update = __lshift__
+
+
+def _apply_host_binary(name, a, b):
+    import numpy as np
+
+    with np.errstate(all="ignore"):
+        return {"plus": lambda: a + b, "times": lambda: a * b, "min": lambda: min(a, b), "max": lambda: max(a, b),
+                "first": lambda: a, "second": lambda: b, "any": lambda: b, "minus": lambda: a - b,
+                "lor": lambda: bool(a) or bool(b), "land": lambda: bool(a) and bool(b), "lxor": lambda: bool(a) != bool(b),
+                "pair": lambda: type(a)(1), "oneb": lambda: type(a)(1)}[name]()
+
+
+class ScalarExpression:
+    """A delayed scalar result (``v.reduce(...)``, ``v[i]``): ``.new()`` -> :class:`Scalar`; ``.value`` runs it."""
+
+    def __init__(self, compute, dtype):
+        self._compute, self.dtype = compute, lookup_dtype(dtype)
+
+    @property
+    def value(self):
+        return self._compute()
+
+    def new(self, dtype=None, *, name=None):
+        s = Scalar(dtype if dtype is not None else self.dtype, name=name)
+        s.value = self._compute()
+        return s
+
+    def __eq__(self, other):
+        return self.new() == other
+
+    def __hash__(self):
+        return id(self)
+
+    def __bool__(self):
+        return bool(self.new())
 
 
 class Expression:

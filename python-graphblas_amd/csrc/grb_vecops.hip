@@ -1,0 +1,251 @@
+// grb_vecops.hip -- the vector operations that close the BFS / SSSP loops around the mxv / vxm path on the device
+// (reference notebooks/Example B.1 -- Level BFS.ipynb, docs/getting_started/primer.rst:236-246):
+//
+//   q[s] << True                      GrB_Vector_setElement_<T>      (reference core/vector.py:1880-1910)
+//   v[i].new()                        GrB_Vector_extractElement_<T>  (core/vector.py:1840-1866)
+//   del v[i]                          GrB_Vector_removeElement       (core/vector.py:1916-1930)
+//   v[:](mask=q.V) << d               GrB_Vector_assign_<T> over GrB_ALL (scalar assign, core/vector.py:1979-2035)
+//   succ << q.reduce(monoid.lor)      GrB_Vector_reduce_<T>          (core/vector.py:1635-1684)
+//
+// Vectors are dense-with-presence in HBM (values + bit-packed presence), so these are element-wise kernels over the
+// presence words: one wavefront per 64 elements, the new presence word from one __ballot.
+#include "grb_internal.hpp"
+#include "grb_ops.hpp"
+
+namespace grb {
+
+template <typename T>
+__global__ void k_set_element(T *val, uint64_t *bits, int64_t i, T x)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        val[i] = x;
+        bits[i >> 6] |= 1ull << (i & 63);
+    }
+}
+__global__ void k_remove_element(uint64_t *bits, int64_t i)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) bits[i >> 6] &= ~(1ull << (i & 63));
+}
+
+// w<m, replace> = accum(w, s) for every index: one wavefront per presence word
+template <typename T>
+__global__ void k_assign_all(int64_t n, T *val, uint64_t *bits, const uint64_t *m_bits, int has_mask, int m_comp, int accum,
+                             int replace, T s)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int64_t g = i >> 6;
+    const int64_t nwords = (n + 63) >> 6;
+    bool new_has = false;
+    if (i < n) {
+        const bool old_has = (bits[g] >> lane) & 1ull;
+        bool mact = true;
+        if (has_mask) {
+            mact = (m_bits[g] >> lane) & 1ull;
+            if (m_comp) mact = !mact;
+        }
+        if (!mact) {
+            new_has = replace ? false : old_has;
+        } else {
+            val[i] = (accum >= 0 && old_has) ? apply_binop<T>(accum, val[i], s) : s;
+            new_has = true;
+        }
+    }
+    const unsigned long long b = __ballot(new_has);
+    if (lane == 0 && g < nwords) bits[g] = b;
+}
+
+// out[0] = monoid-fold of the present values (out starts at the identity)
+template <typename T>
+__global__ void k_reduce(const T *val, const uint64_t *bits, int64_t n, int monoid, typename Widen<T>::type *out)
+{
+    using W = typename Widen<T>::type;
+    W acc = monoid_identity<T, W>(monoid);
+    bool any = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if ((bits[i >> 6] >> (i & 63)) & 1ull) {
+            acc = any ? apply_binop<W>(monoid, acc, (W)val[i]) : (W)val[i];
+            any = true;
+        }
+    }
+    int has = any ? 1 : 0;
+    for (int off = 32; off > 0; off >>= 1) {
+        const W o = __shfl_down(acc, off);
+        const int oh = __shfl_down(has, off);
+        if (oh) {
+            acc = has ? apply_binop<W>(monoid, acc, o) : o;
+            has = 1;
+        }
+    }
+    if ((threadIdx.x & 63) == 0 && has) {
+        if (monoid == OP_ANY) out[0] = acc;
+        else atomic_combine<W>(out, acc, monoid);
+    }
+}
+
+struct VDesc {
+    bool replace = false, comp = false, structure = false;
+};
+static VDesc vflags(const GB_Descriptor_opaque *d)
+{
+    VDesc f;
+    if (d) { f.replace = d->replace; f.comp = d->comp; f.structure = d->structure; }
+    return f;
+}
+
+template <typename T>
+static void set_element(GB_Vector_opaque *w, T x, uint64_t i)
+{
+    if (i >= w->n) fail(GrB_INVALID_INDEX, "setElement: index " + std::to_string(i) + " is outside a vector of size " + std::to_string(w->n));
+    vector_ensure_storage(w);
+    GRB_DISPATCH_TYPE(w->type->code, TW, {
+        hipLaunchKernelGGL((k_set_element<TW>), dim3(1), dim3(64), 0, ctx().stream, (TW *)w->d_val, w->d_bits, (int64_t)i,
+                           cast_value<TW, T>(x));
+    })
+    w->nvals = -1;
+    if (ctx().blocking) sync_stream();
+}
+
+template <typename T>
+static GrB_Info extract_element(T *x, GB_Vector_opaque *u, uint64_t i)
+{
+    if (!x) fail(GrB_NULL_POINTER, "extractElement: output pointer is NULL");
+    if (i >= u->n) fail(GrB_INVALID_INDEX, "extractElement: index " + std::to_string(i) + " is outside a vector of size " + std::to_string(u->n));
+    if (!u->d_val) return GrB_NO_VALUE;
+    uint64_t word = 0;
+    d2h(&word, u->d_bits + (i >> 6), sizeof(word));
+    if (!((word >> (i & 63)) & 1ull)) return GrB_NO_VALUE;
+    GRB_DISPATCH_TYPE(u->type->code, TU, {
+        TU v;
+        d2h(&v, (const TU *)u->d_val + i, sizeof(TU));
+        *x = cast_value<T, TU>(v);
+    })
+    return GrB_SUCCESS;
+}
+
+template <typename T>
+static void assign_all(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_BinaryOp_opaque *accum, T x, const GB_Descriptor_opaque *desc)
+{
+    const VDesc f = vflags(desc);
+    if (mask && mask->n != w->n) fail(GrB_DIMENSION_MISMATCH, "assign: mask size does not match the output size");
+    if (accum && accum->type != w->type->code) fail(GrB_DOMAIN_MISMATCH, "assign: accum operator type must equal the output type");
+    if (!mask && f.comp) {  // complement of "no mask": nothing may be written
+        if (f.replace) vector_release_storage(w);
+        return;
+    }
+    if (w->n == 0) return;
+    vector_ensure_storage(w);
+    DevBuf<uint64_t> mbits(mask ? bits_words64(w->n) : 1);
+    if (mask) vector_mask_bits(mask, f.structure, mbits.p);  // (a snapshot: the mask may be w itself)
+    GRB_DISPATCH_TYPE(w->type->code, TW, {
+        const int64_t threads = (int64_t)bits_words64(w->n) * 64;
+        hipLaunchKernelGGL((k_assign_all<TW>), dim3((unsigned)ceil_div(threads, 256)), dim3(256), 0, ctx().stream, (int64_t)w->n,
+                           (TW *)w->d_val, w->d_bits, (const uint64_t *)mbits.p, mask ? 1 : 0, f.comp ? 1 : 0,
+                           accum ? canonical_op(w->type->code, accum->op) : -1, f.replace ? 1 : 0, cast_value<TW, T>(x));
+    })
+    w->nvals = (!mask && true) ? (int64_t)w->n : -1;
+    sync_stream();  // mbits is released at the end of this scope
+}
+
+template <typename T>
+static void reduce_to(T *val, const GB_BinaryOp_opaque *accum, const GB_Monoid_opaque *monoid, GB_Vector_opaque *u)
+{
+    if (!val) fail(GrB_NULL_POINTER, "reduce: output pointer is NULL");
+    if (!monoid) fail(GrB_NULL_POINTER, "reduce: monoid is NULL");
+    const int mt = monoid->type;
+    const int op = canonical_op(mt, monoid->op);
+    T t{};
+    GRB_DISPATCH_TYPE(mt, TM, {
+        using W = typename Widen<TM>::type;
+        W h = monoid_identity<TM, W>(op);
+        if (u->d_val && u->n > 0) {
+            // values in the monoid's type
+            DevBuf<char> cast_buf(0);
+            const void *src = u->d_val;
+            if (u->type->code != mt) {
+                dev_free(cast_buf.p);
+                cast_buf.p = (char *)dev_alloc(sizeof(TM) * (size_t)u->n);
+                cast_array(mt, cast_buf.p, u->type->code, u->d_val, (int64_t)u->n);
+                src = cast_buf.p;
+            }
+            DevBuf<W> out(1);
+            h2d(out.p, &h, sizeof(W));
+            const int64_t blocks = std::min<int64_t>(ceil_div((int64_t)u->n, 256), (int64_t)ctx().num_cus * 8);
+            hipLaunchKernelGGL((k_reduce<TM>), dim3((unsigned)blocks), dim3(256), 0, ctx().stream, (const TM *)src,
+                               (const uint64_t *)u->d_bits, (int64_t)u->n, op, out.p);
+            d2h(&h, out.p, sizeof(W));
+        }
+        const TM r = std::is_same<TM, bool>::value ? (TM)(h != (W)0) : (TM)h;
+        t = cast_value<T, TM>(r);
+    })
+    if (accum) {
+        // val = accum(val, t) in the accumulator's type (host side: one scalar)
+        GRB_DISPATCH_TYPE(accum->type, TA, {
+            *val = cast_value<T, TA>(apply_binop<TA>(canonical_op(accum->type, accum->op), cast_value<TA, T>(*val), cast_value<TA, T>(t)));
+        })
+    } else {
+        *val = t;
+    }
+}
+
+}  // namespace grb
+
+using namespace grb;
+
+extern "C" const uint64_t *GrB_ALL;
+
+extern "C" GrB_Info GrB_Vector_removeElement(GrB_Vector w, GrB_Index i)
+{
+    GRB_TRY
+    require_init();
+    check_vector(w, "w");
+    if (i >= w->n) fail(GrB_INVALID_INDEX, "removeElement: index " + std::to_string(i) + " is outside a vector of size " + std::to_string(w->n));
+    if (w->d_val) {
+        hipLaunchKernelGGL(k_remove_element, dim3(1), dim3(64), 0, ctx().stream, w->d_bits, (int64_t)i);
+        w->nvals = -1;
+        if (ctx().blocking) sync_stream();
+    }
+    GRB_CATCH(errp(w))
+}
+
+#define GRB_VECOPS_TYPED(NAME, ctype)                                                                                                   \
+    extern "C" GrB_Info GrB_Vector_setElement_##NAME(GrB_Vector w, ctype x, GrB_Index i)                                                \
+    {                                                                                                                                   \
+        GRB_TRY                                                                                                                         \
+        require_init();                                                                                                                 \
+        check_vector(w, "w");                                                                                                           \
+        set_element<ctype>(w, x, i);                                                                                                    \
+        GRB_CATCH(errp(w))                                                                                                              \
+    }                                                                                                                                   \
+    extern "C" GrB_Info GrB_Vector_extractElement_##NAME(ctype *x, const GrB_Vector u, GrB_Index i)                                     \
+    {                                                                                                                                   \
+        GRB_TRY                                                                                                                         \
+        require_init();                                                                                                                 \
+        check_vector(u, "u");                                                                                                           \
+        return extract_element<ctype>(x, u, i);                                                                                         \
+        GRB_CATCH(errp(u))                                                                                                              \
+    }                                                                                                                                   \
+    extern "C" GrB_Info GrB_Vector_assign_##NAME(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, ctype x,                \
+                                                 const GrB_Index *indices, GrB_Index nindices, const GrB_Descriptor desc)               \
+    {                                                                                                                                   \
+        GRB_TRY                                                                                                                         \
+        require_init();                                                                                                                 \
+        check_vector(w, "w");                                                                                                           \
+        if (mask) check_vector(mask, "mask");                                                                                           \
+        if (indices != GrB_ALL) fail(GrB_NOT_IMPLEMENTED, "assign: only GrB_ALL index lists are supported");                            \
+        (void)nindices;                                                                                                                 \
+        assign_all<ctype>(w, mask, accum, x, desc);                                                                                     \
+        GRB_CATCH(errp(w))                                                                                                              \
+    }                                                                                                                                   \
+    extern "C" GrB_Info GrB_Vector_reduce_##NAME(ctype *val, const GrB_BinaryOp accum, const GrB_Monoid monoid, const GrB_Vector u,     \
+                                                 const GrB_Descriptor desc)                                                             \
+    {                                                                                                                                   \
+        GRB_TRY                                                                                                                         \
+        require_init();                                                                                                                 \
+        check_vector(u, "u");                                                                                                           \
+        (void)desc;                                                                                                                     \
+        reduce_to<ctype>(val, accum, monoid, u);                                                                                        \
+        GRB_CATCH(errp(u))                                                                                                              \
+    }
+GRB_FOR_EACH_TYPE(GRB_VECOPS_TYPED)
+#undef GRB_VECOPS_TYPED

@@ -8,9 +8,9 @@ import ctypes
 import numpy as np
 
 from . import _lib
-from .base import BaseType, Expression, InfixMatMul, call, call_on
+from .base import AllIndexAssigner, BaseType, Expression, InfixMatMul, Scalar, ScalarExpression, call, call_on
 from .dtypes import lookup_dtype
-from .operators import get_typed_op, semiring as _semiring
+from .operators import Monoid, get_typed_op, monoid as _monoid, semiring as _semiring
 
 _name_counter = iter(range(1 << 62))
 
@@ -176,6 +176,80 @@ class Vector(BaseType):
         (i1, x1), (i2, x2) = self.to_coo(), other.to_coo()
         return bool(np.array_equal(i1, i2) and np.allclose(x1.astype(float), x2.astype(float), rtol=rel_tol, atol=abs_tol))
 
+    # ---- element access, scalar assign, reduce: what the BFS / SSSP loops need around the hot path ----------------
+    def _index(self, key):
+        if isinstance(key, (bool, np.bool_)) or not isinstance(key, (int, np.integer)):
+            raise TypeError(f"Invalid type for index: {type(key).__name__}; only integers and [:] are supported")
+        i = int(key)
+        if i < 0:
+            i += self._size
+        if not 0 <= i < self._size:
+            raise IndexError(f"Index out of range: index={key}, size={self._size}")
+        return i
+
+    def __getitem__(self, key):
+        """``v[i]`` -> scalar expression (reference core/vector.py:1840-1866); ``v[:]`` -> assign-to-everything target."""
+        if isinstance(key, slice) and key == slice(None):
+            return AllIndexAssigner(self)
+        return _ElementExpr(self, self._index(key))
+
+    def __setitem__(self, key, value):
+        if isinstance(key, slice) and key == slice(None):
+            AllIndexAssigner(self) << value
+        else:
+            self._element_assigner(key) << value
+
+    def __delitem__(self, key):
+        """reference core/vector.py:1916-1930"""
+        call("GrB_Vector_removeElement", [self, self._index(key)])
+
+    def _element_assigner(self, key, accum=None):
+        return _ElementAssigner(self, self._index(key), accum)
+
+    def _scalar_carg(self, value):
+        if isinstance(value, Scalar):
+            if value.is_empty:
+                raise ValueError("cannot assign an empty Scalar")
+            value = value.value
+        if not isinstance(value, (bool, int, float, np.generic)):
+            raise TypeError(f"Bad type for arg: {type(value).__name__}")
+        return self.dtype.np_type.type(value)
+
+    def _assign_scalar_all(self, value, mask=None, accum=None, replace=False, *, opts):
+        """``w(mask, accum, replace)[:] << scalar`` -> ``GrB_Vector_assign_<T>`` over ``GrB_ALL``
+        (reference core/vector.py:1979-2035)."""
+        from .base import _check_mask
+        from .descriptor import lookup as descriptor_lookup
+
+        x = self._scalar_carg(value)
+        if mask is None:
+            complement = structure = False
+        else:
+            mask = _check_mask(mask, self)
+            complement, structure = mask.complement, mask.structure
+        desc = descriptor_lookup(mask_complement=complement, mask_structure=structure, output_replace=replace, **opts)
+        ctype = np.ctypeslib.as_ctypes_type(self.dtype.np_type)
+        call(f"GrB_Vector_assign_{self.dtype.name}", [self, mask, accum, ctype(x.item()), _lib.all_indices(), self._size, desc])
+
+    def reduce(self, op=_monoid.plus, *, allow_empty=True):
+        """``s << v.reduce(monoid)`` (reference core/vector.py:1635-1684).  ``allow_empty=False``: an empty vector gives the
+        monoid identity instead of an empty scalar."""
+        op = get_typed_op(op, self.dtype, kind="binary")
+        if op.opclass == "BinaryOp":
+            if not hasattr(_monoid, op.name):
+                raise TypeError(f"Expected type: Monoid; got BinaryOp `{op!r}`")
+            op = getattr(_monoid, op.name)[self.dtype]
+        rtype = op.return_type
+
+        def compute():
+            if allow_empty and self.nvals == 0:
+                return None
+            out = np.ctypeslib.as_ctypes_type(rtype.np_type)()
+            call_on(self, f"GrB_Vector_reduce_{rtype.name}", [ctypes.byref(out), None, op._carg, self._handle, None])
+            return rtype.np_type.type(out.value).item()
+
+        return ScalarExpression(compute, rtype)
+
     # ---- the hot path ---------------------------------------------------------------------------------------
     def vxm(self, other, op=_semiring.plus_times):
         """``w << u.vxm(A, semiring)``  (reference core/vector.py:1309-1378 -> C ``GrB_vxm``)."""
@@ -192,3 +266,48 @@ class Vector(BaseType):
 
     def __matmul__(self, other):
         return InfixMatMul(self, other)
+
+
+class _ElementExpr(ScalarExpression):
+    """``v[i]``: read with ``.new()`` / ``.value``; ``v[i] << x`` assigns (reference core/vector.py:1840-1910)."""
+
+    def __init__(self, parent, index):
+        self.parent, self.index = parent, index
+        super().__init__(self._read, parent.dtype)
+
+    def _read(self):
+        v = self.parent
+        out = np.ctypeslib.as_ctypes_type(v.dtype.np_type)()
+        info = _lib.lib.__getattr__(f"GrB_Vector_extractElement_{v.dtype.name}")(ctypes.byref(out), v._handle, self.index)
+        if info == 1:  # GrB_NO_VALUE
+            return None
+        from .exceptions import check_status
+
+        check_status(info, v)
+        return v.dtype.np_type.type(out.value).item()
+
+    def __lshift__(self, value):
+        _ElementAssigner(self.parent, self.index, None) << value
+
+    def __call__(self, *, accum=None):
+        return _ElementAssigner(self.parent, self.index, accum)
+
+
+class _ElementAssigner:
+    def __init__(self, parent, index, accum):
+        self.parent, self.index, self.accum = parent, index, accum
+
+    def __lshift__(self, value):
+        v = self.parent
+        x = v._scalar_carg(value)
+        if self.accum is not None:
+            old = _ElementExpr(v, self.index).value
+            if old is not None:
+                from .base import _apply_host_binary
+
+                op = get_typed_op(self.accum, v.dtype, kind="binary")
+                x = v.dtype.np_type.type(_apply_host_binary(op.name, v.dtype.np_type.type(old), x))
+        ctype = np.ctypeslib.as_ctypes_type(v.dtype.np_type)
+        call(f"GrB_Vector_setElement_{v.dtype.name}", [v, ctype(x.item()), self.index])
+
+    update = __lshift__

@@ -121,22 +121,23 @@ def test_bfs_levels_match_scipy(gb):
     level[src] = 0
     for x in order[1:]:
         level[x] = level[pred[x]] + 1
-    q = gb.Vector.from_coo([src], [True], dtype="BOOL", size=n)
-    visited_idx = [np.array([src], np.uint64)]
-    visited = gb.Vector.from_coo([src], [True], dtype="BOOL", size=n)
-    depth = 0
+    # the loop of notebooks/Example B.1 -- Level BFS.ipynb, entirely on the device: the level vector doubles as the visited set
+    v = gb.Vector("INT32", n)
+    q = gb.Vector(bool, n)
+    q[src] << True
+    succ = gb.Scalar(bool)
+    d = 0
     while True:
-        depth += 1
-        q(~visited.S, replace=True) << q.vxm(A, gb.semiring.lor_land)
-        qi, qv = q.to_coo()
-        if qi.size == 0:
+        d += 1
+        v[:](mask=q.V) << d
+        q(~v.S, replace=True) << q.vxm(A, gb.semiring.lor_land)
+        succ << q.reduce(gb.monoid.lor, allow_empty=False)
+        if not succ:
             break
-        assert qv.all()
-        assert np.array_equal(qi.astype(np.int64), np.flatnonzero(level == depth))
-        visited_idx.append(qi)
-        allv = np.concatenate(visited_idx)
-        visited = gb.Vector.from_coo(allv, np.ones(allv.size, bool), dtype="BOOL", size=n)
-    assert depth - 1 == level.max()
+    idx, lev = v.to_coo()
+    assert np.array_equal(idx.astype(np.int64), np.flatnonzero(level >= 0))
+    assert np.array_equal(lev.astype(np.int64) - 1, level[level >= 0])
+    assert d - 1 == level.max()
 
 
 def test_full_scale_properties(gb):

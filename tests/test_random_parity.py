@@ -561,3 +561,50 @@ def test_long_rows_many_chunks(gb, seed, request):
         _lib.lib.GrX_option_set(b"split_min_len", 256)
         _lib.lib.GrX_option_set(b"push_mode", 1)
         _lib.lib.GrX_option_set(b"long_kernel", 1)
+
+
+@pytest.mark.parametrize("seed", range(22))
+def test_vector_assign_reduce_random(gb, seed):
+    """Scalar assign over all indices (mask forms, accumulators, replace, a mask aliasing the output) and monoid reduce,
+    every type, against the oracle's write rule / numpy folds."""
+    rng = np.random.default_rng(1700 + seed)
+    tname = ["BOOL", "INT8", "INT16", "INT32", "INT64", "UINT8", "UINT16", "UINT32", "UINT64", "FP32", "FP64"][seed % 11]
+    n = int(rng.integers(1, 700)) if seed % 5 else [1, 63, 64, 65, 128][seed % 4]
+    wi, wv = rand_vec(rng, n, 0.5, tname)
+    mi, mv = rand_vec(rng, n, 0.6, "INT8")
+    comp, struct, repl = (bool(x) for x in rng.integers(0, 2, 3))
+    use_mask = seed % 4 != 0
+    accum = [None, "plus", "min", "second", "max"][seed % 5]
+    value = rand_vals(rng, 1, tname)[0]
+    ow = O.OVec(n, wi, wv, tname)
+    om = O.OVec(n, mi, mv, "INT8")
+    exp = O.vec_assign_scalar(ow, value, mask=om if use_mask else None, mask_comp=comp and use_mask, mask_struct=struct,
+                              accum=accum, replace=repl and use_mask)
+    w = gb.Vector.from_coo(wi, wv, dtype=tname, size=n)
+    kw = {}
+    if use_mask:
+        M = gb.Vector.from_coo(mi, mv, dtype="INT8", size=n)
+        mm = M.S if struct else M.V
+        kw = dict(mask=~mm if comp else mm, replace=repl)
+    if accum:
+        kw["accum"] = accum
+    w(**kw)[:] << value.item()
+    same_vec(w, exp)
+    assert w.nvals == exp.idx.size
+    # the output as its own (structural) mask
+    w2 = gb.Vector.from_coo(wi, wv, dtype=tname, size=n)
+    w2(w2.S)[:] << value.item()
+    same_vec(w2, O.vec_assign_scalar(ow, value, mask=ow, mask_struct=True))
+    # reduce
+    for mon in (["lor", "land", "lxor"] if tname == "BOOL" else ["plus", "times", "min", "max"]):
+        got = w.reduce(getattr(gb.monoid, mon)).new().value
+        ref = O.vec_reduce(exp, mon)
+        if ref is None:
+            assert got is None
+        elif tname in ("FP32", "FP64"):
+            assert np.isclose(got, ref, rtol=1e-5 if tname == "FP32" else 1e-12) or (np.isinf(got) and np.isinf(ref)) \
+                or (np.isnan(got) and np.isnan(ref)), (mon, got, ref)
+        else:
+            assert got == ref, (mon, got, ref)
+    e = gb.Vector(tname, n)
+    assert e.reduce(getattr(gb.monoid, "lor" if tname == "BOOL" else "plus")).new().value is None

@@ -387,3 +387,113 @@ def test_docs_mxm_and_plus_plus(gb):
     assert C2.isequal(exp)
     A2 = gb.Matrix.from_coo([0, 0, 1, 1], [0, 1, 0, 1], [1, 2, 3, 4])
     assert A2.mxm(A2, gb.semiring.plus_plus).new().isequal(gb.Matrix.from_coo([0, 0, 1, 1], [0, 1, 0, 1], [7, 9, 11, 13]))
+
+
+# ---- the vector operations around the path -----------------------------------------------------
+def test_extract_set_remove_element(gb, v):
+    # graphblas/tests/test_vector.py:267-297
+    assert v[1].new() == 1
+    assert v[6].new() == 0
+    with pytest.raises(IndexError):
+        v[100]
+    with pytest.raises(TypeError, match="Invalid type for index"):
+        v[object()]
+    s = gb.Scalar(int)
+    s << v[1]
+    assert s == 1
+    assert v[0].new().value is None
+    v[0] = 12
+    v[1] << 9
+    assert v[0].new() == 12 and v[1].new() == 9
+    del v[1]
+    assert v[1].new().value is None
+    assert v[4].new() == 2
+    assert v.nvals == 4
+
+
+def test_assign_scalar_all_and_mask(gb, v):
+    # graphblas/tests/test_vector.py:528-533, 544-562, 616-628
+    w = gb.Vector.from_coo([0, 1, 2], [1, 1, 1])
+    w[:] = gb.Scalar.from_value(9)
+    assert w.isequal(gb.Vector.from_coo([0, 1, 2], [9, 9, 9]))
+    with pytest.raises(TypeError, match="Bad type for arg"):
+        w[:] = object()
+    w << 2
+    assert w.isequal(gb.Vector.from_coo([0, 1, 2], [2, 2, 2]))
+    mask = gb.Vector.from_coo([1, 2, 5, 6], [0, 0, 1, 0])
+    result = gb.Vector.from_coo([1, 3, 4, 5, 6], [1, 1, 2, 5, 0])
+    for form in range(3):
+        w = v.dup()
+        if form == 0:
+            w[:](mask.V) << 5
+        elif form == 1:
+            w(mask.V) << 5
+        else:
+            w(mask.V)[:] << 5
+        assert w.isequal(result)
+    result2 = gb.Vector.from_coo([0, 1, 2, 3, 4, 6], [5, 5, 5, 5, 5, 5])
+    w = v.dup()
+    w[:](~mask.V) << 5
+    assert w.isequal(result2)
+    w = v.dup()
+    w(~mask.V) << 5
+    assert w.isequal(result2)
+    x = gb.Vector.from_coo([0, 1, 2], [1, 2, 3])
+    m = gb.Vector.from_coo([0, 2], [False, True])
+    x(m.V)[:] << 100
+    assert x.isequal(gb.Vector.from_coo([0, 1, 2], [1, 2, 100]))
+    x(m.V, accum=gb.binary.plus)[:] << 1000
+    assert x.isequal(gb.Vector.from_coo([0, 1, 2], [1, 2, 1100]))
+
+
+def test_reduce(gb, v):
+    # graphblas/tests/test_vector.py:866-882
+    s = v.reduce(gb.monoid.plus).new()
+    assert s == 4
+    assert s.dtype.name == "INT64"
+    assert v.reduce(gb.binary.plus).new() == 4
+    with pytest.raises(TypeError, match="Expected type: Monoid"):
+        v.reduce(gb.binary.minus)
+    s(accum=gb.binary.times) << v.reduce(gb.monoid.plus)
+    assert s == 16
+    assert v.reduce().new() == 4
+    e = gb.Vector(int, 5)
+    assert e.reduce(gb.monoid.plus).new().value is None
+    assert e.reduce(gb.monoid.plus, allow_empty=False).new() == 0
+    assert e.reduce(gb.monoid.min, allow_empty=False).new() == np.iinfo(np.int64).max
+    assert v.reduce(gb.monoid.max).new() == 2 and v.reduce(gb.monoid.min).new() == 0
+
+
+def test_notebook_level_bfs(gb):
+    """notebooks/Example B.1 -- Level BFS.ipynb, cell by cell, entirely through the API (no host-side bookkeeping)."""
+    edges = [[3, 0, 3, 5, 6, 0, 6, 1, 6, 2, 4, 1], [0, 1, 2, 2, 2, 3, 3, 4, 4, 5, 5, 6]]
+    A = gb.Matrix.from_coo(edges[0], edges[1], [True for _ in edges[0]])
+    s = 1
+    n = A.nrows
+    v = gb.Vector("INT32", n)
+    q = gb.Vector(bool, n)
+    q[s] << True
+    succ = gb.Scalar(bool)
+    d = 0
+    while True:
+        d += 1
+        v[:](mask=q.V) << d
+        q(~v.S, replace=True) << q.vxm(A, gb.semiring.lor_land)
+        succ << q.reduce(gb.monoid.lor, allow_empty=False)
+        if not succ:
+            break
+    # levels from vertex 1 in this digraph: 1 -> {4, 6} -> {5, 2, 3} -> {0}
+    idx, lev = v.to_coo()
+    assert idx.tolist() == [0, 1, 2, 3, 4, 5, 6] and lev.tolist() == [4, 1, 3, 3, 2, 3, 2]
+
+
+def test_primer_sssp_loop_on_device(gb):
+    # docs/getting_started/primer.rst:221-251, with the loop's isequal through the API
+    G = gb.Matrix.from_coo([0, 0, 1, 1, 2], [1, 2, 2, 3, 3], [2.0, 5.0, 1.5, 4.25, 0.5], nrows=4, ncols=4)
+    v = gb.Vector.from_coo([0], [0.0], size=4)
+    while True:
+        w = v.dup()
+        v(gb.op.min) << gb.semiring.min_plus(v @ G)
+        if v.isequal(w):
+            break
+    assert v.to_coo()[1].tolist() == [0.0, 2.0, 3.5, 4.0]
