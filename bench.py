@@ -52,7 +52,7 @@ def parse():
     p.add_argument("--scale", type=int, default=24)
     p.add_argument("--visited", type=float, default=0.5, help="fraction of rows masked out (visited)")
     p.add_argument("--workload", default="mxv_min_plus_masked",
-                   choices=["mxv_min_plus_masked", "mxv_lor_land_masked", "mxv_min_plus", "mxm_plus_times", "mxm_plus_times_masked"])
+                   choices=["mxv_min_plus_masked", "mxv_lor_land_masked", "mxv_min_plus", "mxm_plus_times", "mxm_plus_times_masked", "bfs"])
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--extra", action="store_true", help="also run the secondary workloads (reported under 'extra')")
     return p.parse_args()
@@ -265,6 +265,57 @@ def main_mxm(args, gb, torch, device, rank, world, dist, barrier):
         dist.destroy_process_group()
 
 
+def main_bfs(args, gb, torch, device, rank, world):
+    """A whole level-synchronous BFS on the device (notebooks/Example B.1 -- Level BFS.ipynb): per level one masked scalar
+    assign (levels), one vxm over lor_land with the complemented structural mask + replace (push for thin frontiers, pull
+    for thick ones) and one reduce that the host reads to decide whether to stop.  value = Graph500-style TEPS: edges
+    incident to the visited vertices / time of the traversal; a step = one traversal from the largest-degree vertex."""
+    from graphblas_amd import synthetic
+
+    assert world == 1, "the BFS line is a single-GPU measurement"
+    n = 1 << args.scale
+    indptr, col = synthetic.rmat_csr(args.scale, device="cuda")
+    one = torch.ones(1, dtype=torch.bool, device="cuda")
+    A = device.matrix_from_device_csr(indptr, col, one, n, n, "BOOL", iso=True)
+    device.cache_transpose(A)  # vxm pulls over A' and pushes over A
+    deg = indptr[1:] - indptr[:-1]
+    src = int(torch.argmax(deg).item())
+
+    def traverse():
+        v = gb.Vector("INT32", n)
+        q = gb.Vector(bool, n)
+        q[src] << True
+        succ = gb.Scalar(bool)
+        d = 0
+        while True:
+            d += 1
+            v[:](mask=q.V) << d
+            q(~v.S, replace=True) << q.vxm(A, gb.semiring.lor_land)
+            succ << q.reduce(gb.monoid.lor, allow_empty=False)
+            if not succ:
+                break
+        return v, d
+
+    for _ in range(args.warmup):
+        v, depth = traverse()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        v, depth = traverse()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    idx, _lev = v.to_coo()
+    visited = torch.from_numpy(idx.astype("int64")).cuda()
+    edges = int(deg[visited].sum().item())
+    print(json.dumps({
+        "metric": "GTEPS (BFS traversal) on R-MAT scale-%d" % args.scale, "value": edges / dt / 1e9, "unit": "GTEPS", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "bool", "data": "synthetic",
+        "config": {"workload": f"rmat{args.scale} bfs: level BFS from the largest-degree vertex, whole loop through the C ABI",
+                   "levels": depth, "visited_vertices": int(idx.size), "edges_counted_per_step": edges},
+        "roofline": None, "cpu_baseline": None}))
+
+
 def main():
     args = parse()
     import torch
@@ -330,6 +381,8 @@ def main():
         }
         return wl, res
 
+    if args.workload == "bfs":
+        return main_bfs(args, gb, torch, device, rank, world)
     if args.workload in ("mxm_plus_times", "mxm_plus_times_masked"):
         return main_mxm(args, gb, torch, device, rank, world, dist, barrier)
     wl, res = run(args.workload)
