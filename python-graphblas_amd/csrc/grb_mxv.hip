@@ -2201,7 +2201,10 @@ static int widened_type_code(int st)
 }
 
 // w<mask> = accum(w, u (+.x) P) with P's rows indexed like u.  `flip`: multiply evaluates mult(P_kj, u_k).
-static void push_core(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_BinaryOp_opaque *accum,
+// Returns false (nothing done) when the frontier's rows hold so many entries that the pull direction is cheaper: push costs
+// one atomic per entry of the frontier's rows (~20 G/s measured), pull streams all of S once (~270 G entries/s) -- the level
+// after a hub of a power-law graph has few vertices but a large share of the edges.
+static bool push_core(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_BinaryOp_opaque *accum,
                       const GB_Semiring_opaque *sr, GB_Matrix_opaque *P, GB_Vector_opaque *u, bool flip, DescFlags f)
 {
     ctx().stats = GrX_Stats{};
@@ -2246,32 +2249,32 @@ static void push_core(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_Bina
     DevBuf<uint64_t> idx_hold(0);
     dev_free(idx_hold.p);
     idx_hold.p = d_idx;
+    int64_t work = 0;
+    DevBuf<int64_t> pre(fcount + 1);
+    if (fcount > 0 && P->nvals > 0) {
+        hipLaunchKernelGGL(k_push_degrees, dim3((unsigned)ceil_div(fcount + 1, 256)), dim3(256), 0, ctx().stream, d_idx, fcount,
+                           matrix_rowptr(P), pre.p);
+        prim_exclusive_sum_i64(pre.p, pre.p, fcount + 1);
+        d2h(&work, pre.p + fcount, sizeof(int64_t));
+    }
+    if (ctx().push_mode == 1 && work * 12 > P->nvals) return false;
     const int wt = widened_type_code(st);
     const size_t wbytes = type_size(wt);
     // dense accumulator of the product (semiring type, widened) + presence
     DevBuf<char> t_val((size_t)n_out * wbytes);
     DevBuf<uint64_t> t_bits(bits_words64((uint64_t)n_out), true);
-    int64_t work = 0;
     GRB_DISPATCH_TYPE(st, T, {
         using W = typename Widen<T>::type;
         hipLaunchKernelGGL((k_fill_w<W>), dim3((unsigned)ceil_div(n_out, 256)), dim3(256), 0, ctx().stream, (W *)t_val.p, n_out,
                            monoid_identity<T, W>(monoid));
-        if (fcount > 0 && P->nvals > 0) {
-            DevBuf<int64_t> pre(fcount + 1);
-            hipLaunchKernelGGL(k_push_degrees, dim3((unsigned)ceil_div(fcount + 1, 256)), dim3(256), 0, ctx().stream, d_idx, fcount,
-                               matrix_rowptr(P), pre.p);
-            prim_exclusive_sum_i64(pre.p, pre.p, fcount + 1);
-            d2h(&work, pre.p + fcount, sizeof(int64_t));
-            if (work > 0) {
-                const int64_t nthreads = ceil_div(work, PUSH_CHUNK);
-                const int need_a = !(mult == OP_PAIR || mult == OP_FIRST || mult == OP_ANY);
-                const int need_u = !(mult == OP_PAIR || mult == OP_SECOND);
-                hipLaunchKernelGGL((k_push<T>), dim3((unsigned)ceil_div(nthreads, 256)), dim3(256), 0, ctx().stream, d_idx, fcount,
-                                   pre.p, work, matrix_rowptr(P), P->d_col, (const T *)aval, P->iso ? 1 : 0, (const T *)uval,
-                                   monoid, mult, need_a, need_u, m_bits, mask ? 1 : 0, f.comp ? 1 : 0, (W *)t_val.p,
-                                   (unsigned long long *)t_bits.p);
-                sync_stream();  // `pre` is released at the end of this scope
-            }
+        if (work > 0) {
+            const int64_t nthreads = ceil_div(work, PUSH_CHUNK);
+            const int need_a = !(mult == OP_PAIR || mult == OP_FIRST || mult == OP_ANY);
+            const int need_u = !(mult == OP_PAIR || mult == OP_SECOND);
+            hipLaunchKernelGGL((k_push<T>), dim3((unsigned)ceil_div(nthreads, 256)), dim3(256), 0, ctx().stream, d_idx, fcount,
+                               pre.p, work, matrix_rowptr(P), P->d_col, (const T *)aval, P->iso ? 1 : 0, (const T *)uval,
+                               monoid, mult, need_a, need_u, m_bits, mask ? 1 : 0, f.comp ? 1 : 0, (W *)t_val.p,
+                               (unsigned long long *)t_bits.p);
         }
     })
     ctx().stats.flops = work;
@@ -2289,6 +2292,7 @@ static void push_core(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_Bina
     })
     w->nvals = -1;
     if (ctx().blocking) sync_stream();
+    return true;
 }
 
 // choose the direction: push when u has few entries and the matrix whose rows are indexed like u is at hand
@@ -2319,8 +2323,8 @@ extern "C" GrB_Info GrB_mxv(GrB_Vector w, const GrB_Vector mask, const GrB_Binar
     // pull over S = A (or A' with T0); push needs the matrix whose ROWS are indexed like u: S' -- only when cached
     GB_Matrix_opaque *P = f.t0 ? A : A->tr;
     const bool dims_ok = (f.t0 ? A->nrows : A->ncols) == u->n && (f.t0 ? A->ncols : A->nrows) == w->n && (!mask || mask->n == w->n);
-    if (dims_ok && (!accum || accum->type == w->type->code) && !(!mask && f.comp) && w->n > 0 && want_push(u, P)) {
-        push_core(w, mask, accum, semiring, P, u, /*flip=*/true, f);
+    if (dims_ok && (!accum || accum->type == w->type->code) && !(!mask && f.comp) && w->n > 0 && want_push(u, P) &&
+        push_core(w, mask, accum, semiring, P, u, /*flip=*/true, f)) {
     } else {
         GB_Matrix_opaque *S = f.t0 ? matrix_transpose_cached(A) : A;
         mxv_core(w, mask, accum, semiring, S, u, /*flip=*/false, f);
@@ -2343,8 +2347,8 @@ extern "C" GrB_Info GrB_vxm(GrB_Vector w, const GrB_Vector mask, const GrB_Binar
     // push walks the rows of P = A (or A' with T1, when cached) selected by u; pull gathers over S = P'
     GB_Matrix_opaque *P = f.t1 ? A->tr : A;
     const bool dims_ok = (f.t1 ? A->ncols : A->nrows) == u->n && (f.t1 ? A->nrows : A->ncols) == w->n && (!mask || mask->n == w->n);
-    if (dims_ok && (!accum || accum->type == w->type->code) && !(!mask && f.comp) && w->n > 0 && want_push(u, P)) {
-        push_core(w, mask, accum, semiring, P, u, /*flip=*/false, f);
+    if (dims_ok && (!accum || accum->type == w->type->code) && !(!mask && f.comp) && w->n > 0 && want_push(u, P) &&
+        push_core(w, mask, accum, semiring, P, u, /*flip=*/false, f)) {
     } else {
         GB_Matrix_opaque *S = f.t1 ? A : matrix_transpose_cached(A);
         mxv_core(w, mask, accum, semiring, S, u, /*flip=*/true, f);

@@ -27,12 +27,21 @@ static inline dim3 grid_for(int64_t n, int per_block = BS)
 // ---------------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------------
+// grid-stride; one atomic per workgroup (thousands of wavefronts adding to one address serialise for tens of microseconds)
 __global__ void k_popcount_sum(const uint64_t *bits, int64_t nwords, unsigned long long *out)
 {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned long long c = (i < nwords) ? (unsigned long long)__popcll(bits[i]) : 0ull;
+    __shared__ unsigned long long s_part[BS / 64];
+    unsigned long long c = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (int64_t)gridDim.x * blockDim.x)
+        c += (unsigned long long)__popcll(bits[i]);
     for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
-    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); w++) t += s_part[w];
+        if (t) atomicAdd(out, t);
+    }
 }
 
 __global__ void k_word_popcounts(const uint64_t *bits, int64_t nwords, int64_t *cnt)
@@ -311,7 +320,8 @@ int64_t vector_nvals(GB_Vector_opaque *v)
     if (v->nvals >= 0) return v->nvals;
     DevBuf<unsigned long long> cnt(1, true);
     const int64_t nwords = (int64_t)bits_words64(v->n);
-    LAUNCH(k_popcount_sum, nwords, v->d_bits, nwords, cnt.p);
+    hipLaunchKernelGGL(k_popcount_sum, dim3((unsigned)std::min<int64_t>(ceil_div(nwords, BS), 128)), dim3(BS), 0, ctx().stream,
+                       (const uint64_t *)v->d_bits, nwords, cnt.p);
     unsigned long long h = 0;
     d2h(&h, cnt.p, sizeof(h));
     v->nvals = (int64_t)h;

@@ -55,6 +55,12 @@ __global__ void k_assign_all(int64_t n, T *val, uint64_t *bits, const uint64_t *
     if (lane == 0 && g < nwords) bits[g] = b;
 }
 
+template <typename W>
+__global__ void k_fill_one(W *p, W v)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) p[0] = v;
+}
+
 // out[0] = monoid-fold of the present values (out starts at the identity)
 template <typename T>
 __global__ void k_reduce(const T *val, const uint64_t *bits, int64_t n, int monoid, typename Widen<T>::type *out)
@@ -62,9 +68,15 @@ __global__ void k_reduce(const T *val, const uint64_t *bits, int64_t n, int mono
     using W = typename Widen<T>::type;
     W acc = monoid_identity<T, W>(monoid);
     bool any = false;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        if ((bits[i >> 6] >> (i & 63)) & 1ull) {
-            acc = any ? apply_binop<W>(monoid, acc, (W)val[i]) : (W)val[i];
+    // a thread takes whole presence words: empty words (most of a BFS frontier) cost one 8-byte load and no value loads
+    const int64_t nwords = (n + 63) >> 6;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < nwords; g += (int64_t)gridDim.x * blockDim.x) {
+        unsigned long long b = bits[g];
+        while (b) {
+            const int t = __ffsll(b) - 1;
+            b &= b - 1;
+            const W x = (W)val[(g << 6) + t];
+            acc = any ? apply_binop<W>(monoid, acc, x) : x;
             any = true;
         }
     }
@@ -77,9 +89,27 @@ __global__ void k_reduce(const T *val, const uint64_t *bits, int64_t n, int mono
             has = 1;
         }
     }
-    if ((threadIdx.x & 63) == 0 && has) {
-        if (monoid == OP_ANY) out[0] = acc;
-        else atomic_combine<W>(out, acc, monoid);
+    // one atomic per workgroup
+    __shared__ W s_acc[4];
+    __shared__ int s_has[4];
+    if ((threadIdx.x & 63) == 0) {
+        s_acc[threadIdx.x >> 6] = acc;
+        s_has[threadIdx.x >> 6] = has;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        W t = monoid_identity<T, W>(monoid);
+        int th = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); w++) {
+            if (s_has[w]) {
+                t = th ? apply_binop<W>(monoid, t, s_acc[w]) : s_acc[w];
+                th = 1;
+            }
+        }
+        if (th) {
+            if (monoid == OP_ANY) out[0] = t;
+            else atomic_combine<W>(out, t, monoid);
+        }
     }
 }
 
@@ -144,7 +174,7 @@ static void assign_all(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_Bin
                            accum ? canonical_op(w->type->code, accum->op) : -1, f.replace ? 1 : 0, cast_value<TW, T>(x));
     })
     w->nvals = (!mask && true) ? (int64_t)w->n : -1;
-    sync_stream();  // mbits is released at the end of this scope
+    if (ctx().blocking) sync_stream();  // (mbits goes back to the stream-ordered block cache: no wait needed)
 }
 
 template <typename T>
@@ -169,8 +199,8 @@ static void reduce_to(T *val, const GB_BinaryOp_opaque *accum, const GB_Monoid_o
                 src = cast_buf.p;
             }
             DevBuf<W> out(1);
-            h2d(out.p, &h, sizeof(W));
-            const int64_t blocks = std::min<int64_t>(ceil_div((int64_t)u->n, 256), (int64_t)ctx().num_cus * 8);
+            hipLaunchKernelGGL((k_fill_one<W>), dim3(1), dim3(64), 0, ctx().stream, out.p, h);
+            const int64_t blocks = std::min<int64_t>(ceil_div((int64_t)bits_words64(u->n), 256), (int64_t)ctx().num_cus * 4);
             hipLaunchKernelGGL((k_reduce<TM>), dim3((unsigned)blocks), dim3(256), 0, ctx().stream, (const TM *)src,
                                (const uint64_t *)u->d_bits, (int64_t)u->n, op, out.p);
             d2h(&h, out.p, sizeof(W));
