@@ -111,6 +111,15 @@ GrB_Info GrB_Vector_free(GrB_Vector *v);
 GrB_Info GrB_Vector_clear(GrB_Vector v);
 GrB_Info GrB_Vector_resize(GrB_Vector v, GrB_Index size);                    /* core/vector.py:455-463 */
 GrB_Info GrB_Vector_removeElement(GrB_Vector w, GrB_Index i);                /* core/vector.py:1916-1930 */
+/* element-wise union / intersection (core/vector.py:960-1150): op on the entries both have; eWiseAdd passes single entries through */
+GrB_Info GrB_Vector_eWiseAdd_BinaryOp(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_BinaryOp op,
+                                      const GrB_Vector u, const GrB_Vector v, const GrB_Descriptor desc);
+GrB_Info GrB_Vector_eWiseAdd_Monoid(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_Monoid op,
+                                    const GrB_Vector u, const GrB_Vector v, const GrB_Descriptor desc);
+GrB_Info GrB_Vector_eWiseMult_BinaryOp(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_BinaryOp op,
+                                       const GrB_Vector u, const GrB_Vector v, const GrB_Descriptor desc);
+GrB_Info GrB_Vector_eWiseMult_Monoid(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_Monoid op,
+                                     const GrB_Vector u, const GrB_Vector v, const GrB_Descriptor desc);
 GrB_Info GrB_Vector_size(GrB_Index *n, const GrB_Vector v);
 GrB_Info GrB_Vector_nvals(GrB_Index *nvals, const GrB_Vector v);
 GrB_Info GrB_Vector_wait(GrB_Vector v, GrB_WaitMode mode);

@@ -100,6 +100,8 @@ def _declare(L):
     L.GrB_Vector_free.argtypes = [P(c_void_p)]
     L.GrB_Vector_clear.argtypes = [c_void_p]
     L.GrB_Vector_removeElement.argtypes = [c_void_p, c_u64]
+    for name in ("GrB_Vector_eWiseAdd_BinaryOp", "GrB_Vector_eWiseAdd_Monoid", "GrB_Vector_eWiseMult_BinaryOp", "GrB_Vector_eWiseMult_Monoid"):
+        getattr(L, name).argtypes = [c_void_p] * 7
     for t, ct in (("BOOL", ctypes.c_bool), ("INT8", ctypes.c_int8), ("INT16", ctypes.c_int16), ("INT32", ctypes.c_int32),
                   ("INT64", ctypes.c_int64), ("UINT8", ctypes.c_uint8), ("UINT16", ctypes.c_uint16), ("UINT32", ctypes.c_uint32),
                   ("UINT64", ctypes.c_uint64), ("FP32", ctypes.c_float), ("FP64", ctypes.c_double)):

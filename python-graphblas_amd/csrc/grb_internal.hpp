@@ -242,6 +242,8 @@ GB_Matrix_opaque *matrix_cast_copy(GB_Matrix_opaque *A, int type);
 GB_Vector_opaque *vector_cast_copy(GB_Vector_opaque *v, int type);
 // out_bits = present(v) & (structure ? 1 : value != 0)
 void vector_mask_bits(GB_Vector_opaque *m, bool structure, uint64_t *out_bits);
+void vector_write_rule(GB_Vector_opaque *w, const void *t_val, const uint64_t *t_bits, const uint64_t *m_bits, bool comp, int accum,
+                       bool replace);  // w<m, replace> = accum(w, t), in place, t of w's type
 void pack_bool_values(const uint64_t *present, const bool *val, int64_t n, uint64_t *out);
 
 // ---- primitives implemented in grb_prim.hip (rocPRIM-backed) ---------------------------------------

@@ -1473,6 +1473,18 @@ __global__ void k_vec_write(int64_t n, const TW *w_old_val, const uint64_t *w_ol
     if (lane == 0 && g < nwords) w_new_bits[g] = nb;
 }
 
+// w<m_bits (^comp), replace> = accum(w, t), in place, t of w's type (shared with the element-wise operations of grb_vecops.hip)
+void vector_write_rule(GB_Vector_opaque *w, const void *t_val, const uint64_t *t_bits, const uint64_t *m_bits, bool comp, int accum,
+                       bool replace)
+{
+    GRB_DISPATCH_TYPE(w->type->code, TW, {
+        const int64_t nthreads = (int64_t)bits_words64(w->n) * 64;
+        hipLaunchKernelGGL((k_vec_write<TW>), dim3((unsigned)ceil_div(nthreads, 256)), dim3(256), 0, ctx().stream, (int64_t)w->n,
+                           (const TW *)w->d_val, (const uint64_t *)w->d_bits, (TW *)w->d_val, w->d_bits, (const TW *)t_val, t_bits,
+                           m_bits, m_bits ? 1 : 0, comp ? 1 : 0, accum, replace ? 1 : 0, 0);
+    })
+}
+
 // ---------------------------------------------------------------------------------------------------
 // push direction (SpMSpV): few entries in u.  T(j) = (+)_{k in u} mult(u_k, P(k,j)) where P's ROWS are indexed
 // like u (P = A for vxm, A' for mxv).  The work -- all entries of the rows selected by u -- is cut into equal

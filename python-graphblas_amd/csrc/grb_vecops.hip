@@ -113,6 +113,29 @@ __global__ void k_reduce(const T *val, const uint64_t *bits, int64_t n, int mono
     }
 }
 
+// t = u (op) v on the union (eWiseAdd: a value present on one side only passes through) or the intersection (eWiseMult)
+template <typename T>
+__global__ void k_ewise(int64_t n, const T *u_val, const uint64_t *u_bits, const T *v_val, const uint64_t *v_bits, int op, int is_add,
+                        T *t_val, uint64_t *t_bits)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int64_t g = i >> 6;
+    bool has = false;
+    if (i < n) {
+        const bool hu = u_bits && ((u_bits[g] >> lane) & 1ull), hv = v_bits && ((v_bits[g] >> lane) & 1ull);
+        if (hu && hv) {
+            t_val[i] = apply_binop<T>(op, u_val[i], v_val[i]);
+            has = true;
+        } else if (is_add && (hu || hv)) {
+            t_val[i] = hu ? u_val[i] : v_val[i];
+            has = true;
+        }
+    }
+    const unsigned long long b = __ballot(has);
+    if (lane == 0 && g < ((n + 63) >> 6)) t_bits[g] = b;
+}
+
 struct VDesc {
     bool replace = false, comp = false, structure = false;
 };
@@ -218,6 +241,64 @@ static void reduce_to(T *val, const GB_BinaryOp_opaque *accum, const GB_Monoid_o
     }
 }
 
+// w<mask, replace> = accum(w, u (op) v), element-wise over the union (is_add) or the intersection of the patterns
+// (reference core/vector.py:960-1150 -> GrB_Vector_eWiseAdd_* / eWiseMult_*)
+static void ewise_core(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_BinaryOp_opaque *accum, int op_in, int ot,
+                       GB_Vector_opaque *u, GB_Vector_opaque *v, const GB_Descriptor_opaque *desc, bool is_add)
+{
+    const VDesc f = vflags(desc);
+    if (u->n != v->n) fail(GrB_DIMENSION_MISMATCH, "eWise: input sizes " + std::to_string(u->n) + " and " + std::to_string(v->n) + " differ");
+    if (w->n != u->n) fail(GrB_DIMENSION_MISMATCH, "eWise: output size does not match the inputs");
+    if (mask && mask->n != w->n) fail(GrB_DIMENSION_MISMATCH, "eWise: mask size does not match the output size");
+    if (accum && accum->type != w->type->code) fail(GrB_DOMAIN_MISMATCH, "eWise: accum operator type must equal the output type");
+    if (!mask && f.comp) {
+        if (f.replace) vector_release_storage(w);
+        return;
+    }
+    if (w->n == 0) return;
+    const int64_t n = (int64_t)w->n;
+    const int op = canonical_op(ot, op_in);
+    const size_t ob = type_size(ot);
+    // operands in the operator's type
+    DevBuf<char> u_cast(0), v_cast(0);
+    const void *uv = u->d_val, *vv = v->d_val;
+    if (u->d_val && u->type->code != ot) {
+        dev_free(u_cast.p);
+        u_cast.p = (char *)dev_alloc(ob * (size_t)n);
+        cast_array(ot, u_cast.p, u->type->code, u->d_val, n);
+        uv = u_cast.p;
+    }
+    if (v->d_val && v->type->code != ot) {
+        dev_free(v_cast.p);
+        v_cast.p = (char *)dev_alloc(ob * (size_t)n);
+        cast_array(ot, v_cast.p, v->type->code, v->d_val, n);
+        vv = v_cast.p;
+    }
+    DevBuf<char> t_val(ob * (size_t)n);
+    DevBuf<uint64_t> t_bits(bits_words64((uint64_t)n));
+    const int64_t threads = (int64_t)bits_words64((uint64_t)n) * 64;
+    GRB_DISPATCH_TYPE(ot, T, {
+        hipLaunchKernelGGL((k_ewise<T>), dim3((unsigned)ceil_div(threads, 256)), dim3(256), 0, ctx().stream, n, (const T *)uv,
+                           (const uint64_t *)(u->d_val ? u->d_bits : nullptr), (const T *)vv,
+                           (const uint64_t *)(v->d_val ? v->d_bits : nullptr), op, is_add ? 1 : 0, (T *)t_val.p, t_bits.p);
+    })
+    // the write rule in w's type (w may be u or v: t is a separate buffer, the rule is element-wise)
+    DevBuf<uint64_t> mbits(mask ? bits_words64(w->n) : 1);
+    if (mask) vector_mask_bits(mask, f.structure, mbits.p);
+    vector_ensure_storage(w);
+    DevBuf<char> tc(0);
+    const void *tw = t_val.p;
+    if (w->type->code != ot) {
+        dev_free(tc.p);
+        tc.p = (char *)dev_alloc(w->type->size * (size_t)n);
+        cast_array(w->type->code, tc.p, ot, t_val.p, n);
+        tw = tc.p;
+    }
+    vector_write_rule(w, tw, t_bits.p, mask ? mbits.p : nullptr, f.comp, accum ? canonical_op(w->type->code, accum->op) : -1, f.replace);
+    w->nvals = -1;
+    if (ctx().blocking) sync_stream();
+}
+
 }  // namespace grb
 
 using namespace grb;
@@ -279,3 +360,23 @@ extern "C" GrB_Info GrB_Vector_removeElement(GrB_Vector w, GrB_Index i)
     }
 GRB_FOR_EACH_TYPE(GRB_VECOPS_TYPED)
 #undef GRB_VECOPS_TYPED
+
+#define GRB_EWISE(FUNC, HANDLE, IS_ADD)                                                                                        \
+    extern "C" GrB_Info FUNC(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const HANDLE op, const GrB_Vector u,   \
+                             const GrB_Vector v, const GrB_Descriptor desc)                                                      \
+    {                                                                                                                          \
+        GRB_TRY                                                                                                                \
+        require_init();                                                                                                        \
+        check_vector(w, "w");                                                                                                  \
+        if (mask) check_vector(mask, "mask");                                                                                  \
+        check_vector(u, "u");                                                                                                  \
+        check_vector(v, "v");                                                                                                  \
+        if (!op) fail(GrB_NULL_POINTER, "eWise: operator is NULL");                                                            \
+        ewise_core(w, mask, accum, op->op, op->type, u, v, desc, IS_ADD);                                                      \
+        GRB_CATCH(errp(w))                                                                                                     \
+    }
+GRB_EWISE(GrB_Vector_eWiseAdd_BinaryOp, GrB_BinaryOp, true)
+GRB_EWISE(GrB_Vector_eWiseAdd_Monoid, GrB_Monoid, true)
+GRB_EWISE(GrB_Vector_eWiseMult_BinaryOp, GrB_BinaryOp, false)
+GRB_EWISE(GrB_Vector_eWiseMult_Monoid, GrB_Monoid, false)
+#undef GRB_EWISE

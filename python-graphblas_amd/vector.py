@@ -250,6 +250,25 @@ class Vector(BaseType):
 
         return ScalarExpression(compute, rtype)
 
+    def _ewise(self, other, op, method_name, cfunc):
+        if not isinstance(other, Vector):
+            raise TypeError(f"Expected type: Vector; got {type(other).__name__}")
+        op = get_typed_op(op, self.dtype, other.dtype, kind="binary")
+        expr = Expression(method_name, f"{cfunc}_{op.opclass}", [self, other], op=op, output_type=Vector, shape=(self._size,))
+        if self._size != other._size:
+            expr._force_library_error()
+        return expr
+
+    def ewise_add(self, other, op=_monoid.plus):
+        """Union of the patterns; ``op`` where both have an entry (reference core/vector.py:960-1060)."""
+        return self._ewise(other, op, "ewise_add", "GrB_Vector_eWiseAdd")
+
+    def ewise_mult(self, other, op=None):
+        """Intersection of the patterns (reference core/vector.py:1062-1150)."""
+        from .operators import binary as _binary
+
+        return self._ewise(other, op if op is not None else _binary.times, "ewise_mult", "GrB_Vector_eWiseMult")
+
     # ---- the hot path ---------------------------------------------------------------------------------------
     def vxm(self, other, op=_semiring.plus_times):
         """``w << u.vxm(A, semiring)``  (reference core/vector.py:1309-1378 -> C ``GrB_vxm``)."""

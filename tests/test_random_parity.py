@@ -608,3 +608,69 @@ def test_vector_assign_reduce_random(gb, seed):
             assert got == ref, (mon, got, ref)
     e = gb.Vector(tname, n)
     assert e.reduce(getattr(gb.monoid, "lor" if tname == "BOOL" else "plus")).new().value is None
+
+
+@pytest.mark.parametrize("seed", range(22))
+def test_vector_ewise_random(gb, seed):
+    """eWiseAdd / eWiseMult against a numpy restatement (union / intersection, then the oracle's write rule): every type,
+    masks, accumulators, replace, output aliased with an input, mixed input types."""
+    rng = np.random.default_rng(1900 + seed)
+    tname = ["BOOL", "INT8", "INT16", "INT32", "INT64", "UINT8", "UINT16", "UINT32", "UINT64", "FP32", "FP64"][seed % 11]
+    n = int(rng.integers(1, 500)) if seed % 5 else [1, 64, 65, 128][seed % 4]
+    ops = ["lor", "land", "lxor", "first", "second"] if tname == "BOOL" else ["plus", "times", "min", "max", "minus", "first", "second"]
+    opname = ops[seed % len(ops)]
+    ui, uv = rand_vec(rng, n, 0.5, tname)
+    vi, vv = rand_vec(rng, n, 0.5, tname)
+    wi, wv = rand_vec(rng, n, 0.4, tname)
+    mi, mv = rand_vec(rng, n, 0.6, "INT8")
+    np_t = O.NP_OF[tname]
+
+    def dense(i, x):
+        h = np.zeros(n, bool); d = np.zeros(n, np_t); h[i] = True; d[i] = x
+        return h, d
+
+    hu, du = dense(ui, uv); hv, dv = dense(vi, vv)
+    with np.errstate(over="ignore"):
+        if tname == "BOOL":
+            f = {"lor": np.logical_or, "land": np.logical_and, "lxor": np.logical_xor, "first": lambda a, b: a, "second": lambda a, b: b}[opname]
+        else:
+            f = {"plus": np.add, "times": np.multiply, "min": np.minimum, "max": np.maximum, "minus": np.subtract,
+                 "first": lambda a, b: a, "second": lambda a, b: b}[opname]
+        both = np.asarray(f(du, dv)).astype(np_t)
+    for is_add in (True, False):
+        t_has = (hu | hv) if is_add else (hu & hv)
+        t_val = np.where(hu & hv, both, np.where(hu, du, dv)).astype(np_t)
+        comp, struct, repl = (bool(x) for x in rng.integers(0, 2, 3))
+        use_mask = seed % 3 != 0
+        accum = [None, "plus", "min", "second"][seed % 4] if tname != "BOOL" else [None, "lor", "second"][seed % 3]
+        ow = O.OVec(n, wi, wv, tname)
+        om = O.OVec(n, mi, mv, "INT8")
+        # expected: the oracle's write rule with T = (t_has, t_val)
+        w_has, w_val = ow.dense()
+        mt = O._dense_mask(om if use_mask else None, struct, n)
+        import ctypes
+        rc = O.lib().grbo_vec_write(O.TYPE_CODES[tname], ctypes.c_int64(n), O._p(w_has), O._p(w_val), O._p(t_has.astype(np.uint8)),
+                                    O._p(np.ascontiguousarray(t_val)), O._p(mt), int(comp and use_mask),
+                                    O.OP_CODES[accum] if accum else -1, int(repl and use_mask))
+        assert rc == 0
+        exp = O.OVec.from_dense(w_has, w_val, tname)
+        U = gb.Vector.from_coo(ui, uv, dtype=tname, size=n)
+        V = gb.Vector.from_coo(vi, vv, dtype=tname, size=n)
+        W = gb.Vector.from_coo(wi, wv, dtype=tname, size=n)
+        kw = {}
+        if use_mask:
+            M = gb.Vector.from_coo(mi, mv, dtype="INT8", size=n)
+            mm = M.S if struct else M.V
+            kw = dict(mask=~mm if comp else mm, replace=repl)
+        if accum:
+            kw["accum"] = accum
+        op = getattr(gb.binary, opname)
+        W(**kw) << (U.ewise_add(V, op) if is_add else U.ewise_mult(V, op))
+        same_vec(W, exp)
+    # output aliased with an input: u = u (op) v
+    U = gb.Vector.from_coo(ui, uv, dtype=tname, size=n)
+    V = gb.Vector.from_coo(vi, vv, dtype=tname, size=n)
+    U << U.ewise_add(V, getattr(gb.binary, opname))
+    t_has = hu | hv
+    t_val = np.where(hu & hv, both, np.where(hu, du, dv)).astype(np_t)
+    same_vec(U, O.OVec.from_dense(t_has.astype(np.uint8), t_val, tname))

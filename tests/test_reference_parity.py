@@ -497,3 +497,24 @@ def test_primer_sssp_loop_on_device(gb):
         if v.isequal(w):
             break
     assert v.to_coo()[1].tolist() == [0.0, 2.0, 3.5, 4.0]
+
+
+def test_ewise_mult_and_add(gb, v):
+    # graphblas/tests/test_vector.py:371-380, 402-418
+    v2 = gb.Vector.from_coo([0, 3, 5, 6], [2, 3, 2, 1])
+    result = gb.Vector.from_coo([3, 6], [3, 0])
+    w = v.ewise_mult(v2, gb.binary.times).new()
+    assert w.isequal(result)
+    w << v.ewise_mult(v2, gb.monoid.times)
+    assert w.isequal(result)
+    with pytest.raises(TypeError, match="Expected type: BinaryOp, Monoid"):
+        v.ewise_mult(v2, gb.semiring.plus_times)
+    result = gb.Vector.from_coo([0, 1, 3, 4, 5, 6], [2, 1, 3, 2, 2, 1])
+    w = v.ewise_add(v2, gb.binary.max).new()
+    assert w.isequal(result)
+    w.update(v.ewise_add(v2, gb.monoid.max))
+    assert w.isequal(result)
+    with pytest.raises(TypeError, match="Expected type: BinaryOp, Monoid"):
+        v.ewise_add(v2, gb.semiring.max_times)
+    assert v.ewise_add(v2).new().isequal(v.ewise_add(v2, gb.monoid.plus).new())
+    assert v.ewise_add(v2).new().isequal(gb.Vector.from_coo([0, 1, 3, 4, 5, 6], [2, 1, 4, 2, 2, 1]))
