@@ -320,7 +320,7 @@ int64_t vector_nvals(GB_Vector_opaque *v)
     if (v->nvals >= 0) return v->nvals;
     DevBuf<unsigned long long> cnt(1, true);
     const int64_t nwords = (int64_t)bits_words64(v->n);
-    hipLaunchKernelGGL(k_popcount_sum, dim3((unsigned)std::min<int64_t>(ceil_div(nwords, BS), 128)), dim3(BS), 0, ctx().stream,
+    hipLaunchKernelGGL(k_popcount_sum, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(nwords, BS), 128))), dim3(BS), 0, ctx().stream,
                        (const uint64_t *)v->d_bits, nwords, cnt.p);
     unsigned long long h = 0;
     d2h(&h, cnt.p, sizeof(h));

@@ -152,6 +152,12 @@ void run_grid(dim3 grid, dim3 block, const std::function<void()> &body)
         fprintf(stderr, "emu: only 1-D launches are supported\n");
         abort();
     }
+    if (grid.x == 0 || nthreads == 0 || nthreads > 1024) {
+        // the hardware rejects these launches ("invalid configuration argument") and the error surfaces at a later call:
+        // fail at the source instead
+        fprintf(stderr, "emu: invalid launch configuration (grid %u, block %u)\n", grid.x, nthreads);
+        abort();
+    }
     if (g_fibers.size() < nthreads) g_fibers.resize(nthreads);
     for (unsigned t = 0; t < nthreads; t++)
         if (!g_fibers[t].stack) g_fibers[t].stack = (char *)malloc(STACK_BYTES);
