@@ -241,6 +241,7 @@ void cast_array(int dst_type, void *dst, int src_type, const void *src, int64_t 
 GB_Matrix_opaque *matrix_cast_copy(GB_Matrix_opaque *A, int type);
 GB_Vector_opaque *vector_cast_copy(GB_Vector_opaque *v, int type);
 // out_bits = present(v) & (structure ? 1 : value != 0)
+void pack_bool_pv(const uint64_t *present, const bool *val, int64_t n, uint32_t *out);  // 2 bits per element: (present, value)
 void vector_mask_bits(GB_Vector_opaque *m, bool structure, uint64_t *out_bits);
 void vector_write_rule(GB_Vector_opaque *w, const void *t_val, const uint64_t *t_bits, const uint64_t *m_bits, bool comp, int accum,
                        bool replace);  // w<m, replace> = accum(w, t), in place, t of w's type

@@ -60,6 +60,8 @@ struct PullArgs {
     void *first_val;
     uint8_t *first_has;  // bit0: has a partial, bit1: the tile's first row started in an earlier tile
     const uint32_t *u_valbits;  // BOOL semirings: values of the u image, bit-packed (bit = present and true)
+    const uint32_t *u_pv;       // BOOL semirings, u not full: presence AND value of the image in one word per 16 codes (bits 2k, 2k+1
+                                // of word c >> 4 for code c, k = c & 15): one gather per entry instead of two; replaces u_valbits
     int64_t x_len;       // entries of the u image the column codes index ([hot table | u] when a hot table is in use)
     const uint64_t *long_bits;  // rows the merge-path kernel does NOT own (handled by k_mxv_long), or nullptr
     // long-row kernel (k_mxv_long / k_mxv_long_epilogue)
@@ -163,6 +165,22 @@ __device__ __forceinline__ T buf_load(__amdgpu_buffer_rsrc_t r, unsigned byte_of
     }
 }
 
+// BOOL operand whose presence and value share a word (PullArgs::u_pv): xp / xv of N codes from one gather each; a code of
+// -1 (nothing to gather) is out of range and reads 0 = absent
+template <int N>
+__device__ __forceinline__ void bool_pv_gather(__amdgpu_buffer_rsrc_t pv_rs, const int (&cc)[N], bool (&xp)[N], bool (&xv)[N])
+{
+    uint32_t pw[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) pw[i] = buf_load<uint32_t>(pv_rs, (unsigned)(cc[i] >> 4) * 4u);
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const int sh = (cc[i] & 15) * 2;
+        xp[i] = (pw[i] >> sh) & 1u;
+        xv[i] = (pw[i] >> (sh + 1)) & 1u;
+    }
+}
+
 template <typename T, int MONOID_CT, int MULT_CT, int IPT>
 __global__ __launch_bounds__(PULL_BLOCK) void k_mxv_pull(const PullArgs a)
 {
@@ -258,6 +276,7 @@ __global__ __launch_bounds__(PULL_BLOCK) void k_mxv_pull(const PullArgs a)
     const __amdgpu_buffer_rsrc_t xval_rs = make_rsrc(a.u_val, a.x_len * (int64_t)sizeof(T));
     const __amdgpu_buffer_rsrc_t xbits_rs = make_rsrc(a.u_bits, a.u_full ? 0 : ((a.x_len + 63) >> 6) * 8);
     const __amdgpu_buffer_rsrc_t xvbits_rs = make_rsrc(a.u_valbits, a.u_valbits ? ((a.x_len + 63) >> 6) * 8 : 0);
+    const __amdgpu_buffer_rsrc_t xpv_rs = make_rsrc(a.u_pv, a.u_pv ? ((a.x_len + 15) >> 4) * 4 : 0);
     PHASE_STAMP(1);
     EARLY_EXIT(2);
 
@@ -341,7 +360,15 @@ __global__ __launch_bounds__(PULL_BLOCK) void k_mxv_pull(const PullArgs a)
         // ---- gathers: presence words, then values -- IPT independent random accesses in flight per lane --------------
         bool xp[IPT];
         T xv[IPT];
-        if (a.u_full || (a.dbg & 1)) {
+        bool pv_done = false;
+        if constexpr (std::is_same<T, bool>::value) {
+            if (a.u_pv && !(a.dbg & 1)) {  // presence and value from one word
+                bool_pv_gather<IPT>(xpv_rs, cc, xp, xv);
+                pv_done = true;
+            }
+        }
+        if (pv_done) {
+        } else if (a.u_full || (a.dbg & 1)) {
 #pragma unroll
             for (int i = 0; i < IPT; i++) xp[i] = cc[i] >= 0;
         } else {
@@ -351,7 +378,8 @@ __global__ __launch_bounds__(PULL_BLOCK) void k_mxv_pull(const PullArgs a)
 #pragma unroll
             for (int i = 0; i < IPT; i++) xp[i] = (bw[i] >> (cc[i] & 31)) & 1u;
         }
-        if (need_uval && !(a.dbg & 1)) {
+        if (pv_done) {
+        } else if (need_uval && !(a.dbg & 1)) {
             if constexpr (std::is_same<T, bool>::value) {
                 // BOOL values travel bit-packed (2 MiB at scale 24, its hot head L1-resident) instead of one byte each
                 uint32_t vw[IPT];
@@ -476,6 +504,7 @@ __global__ __launch_bounds__(LONG_BLOCK) void k_mxv_long(const PullArgs a)
     const __amdgpu_buffer_rsrc_t xval_rs = make_rsrc(a.u_val, a.x_len * (int64_t)sizeof(T));
     const __amdgpu_buffer_rsrc_t xbits_rs = make_rsrc(a.u_bits, a.u_full ? 0 : ((a.x_len + 63) >> 6) * 8);
     const __amdgpu_buffer_rsrc_t xvbits_rs = make_rsrc(a.u_valbits, a.u_valbits ? ((a.x_len + 63) >> 6) * 8 : 0);
+    const __amdgpu_buffer_rsrc_t xpv_rs = make_rsrc(a.u_pv, a.u_pv ? ((a.x_len + 15) >> 4) * 4 : 0);
     constexpr bool IS_BOOL = std::is_same<T, bool>::value;
     // entries of the image resident in LDS
     constexpr int64_t LDS_CAP = IS_BOOL ? (int64_t)LDS_WORDS * 32 : (int64_t)LDS_WORDS * 4 / (int64_t)(sizeof(T) < 4 ? 4 : sizeof(T));
@@ -678,11 +707,12 @@ __global__ __launch_bounds__(LONG_BLOCK) void k_mxv_long(const PullArgs a)
 // are compacted per call (k_long_compact), so masked-out rows are neither streamed nor scheduled.
 // ---------------------------------------------------------------------------------------------------
 constexpr int LONG_ITEM = 1024;
-// codes the image head in LDS can hold per class x 8 classes: BOOL values are bit-packed (word w of a class = image word
-// 8 w + class), the others take one LDS slot of max(4, sizeof) bytes per code
+// codes the image head in LDS can hold per class x 8 classes: BOOL operands are bit-packed (32 values per word, or 16
+// (presence, value) pairs per word when u is not full -- the limit is set by the latter), the others take one LDS slot of
+// max(4, sizeof) bytes per code
 constexpr int64_t long_lds_codes(int type_size_bytes, bool is_bool, int lds_words)
 {
-    return is_bool ? (int64_t)lds_words * 256 : ((int64_t)lds_words * 4 / (type_size_bytes < 4 ? 4 : type_size_bytes)) * 8;
+    return is_bool ? (int64_t)lds_words * 128 : ((int64_t)lds_words * 4 / (type_size_bytes < 4 ? 4 : type_size_bytes)) * 8;
 }
 // A column code of the class-partitioned copy as the kernel reads it: c itself when it is gathered from the image, or
 // -2 - slot when it is resident in LDS (slot = ((c >> 8) << 5) | (c & 31) within its class; for BOOL the bit slot & 31
@@ -707,13 +737,22 @@ __global__ __launch_bounds__(LONG_BLOCK) void k_mxv_long_grp(const PullArgs a)
     const __amdgpu_buffer_rsrc_t xval_rs = make_rsrc(a.u_val, a.x_len * (int64_t)sizeof(T));
     const __amdgpu_buffer_rsrc_t xbits_rs = make_rsrc(a.u_bits, a.u_full ? 0 : ((a.x_len + 63) >> 6) * 8);
     const __amdgpu_buffer_rsrc_t xvbits_rs = make_rsrc(a.u_valbits, a.u_valbits ? ((a.x_len + 63) >> 6) * 8 : 0);
+    const __amdgpu_buffer_rsrc_t xpv_rs = make_rsrc(a.u_pv, a.u_pv ? ((a.x_len + 15) >> 4) * 4 : 0);
     constexpr bool IS_BOOL = std::is_same<T, bool>::value;
     // LDS residency of my class (the entries carry pre-translated codes, see long_tcode)
     constexpr int LDS_SLOTS = IS_BOOL ? LDS_WORDS : (int)((int64_t)LDS_WORDS * 4 / (int64_t)(sizeof(T) < 4 ? 4 : sizeof(T)));
     const bool use_lds = need_uval && a.cls_lds_lim > 0;
     if (use_lds) {
         if constexpr (IS_BOOL) {
-            for (int w = threadIdx.x; w < LDS_SLOTS; w += LONG_BLOCK) s_x[w] = buf_load<uint32_t>(xvbits_rs, (unsigned)((w << 3) | cls) * 4u);
+            if (a.u_pv) {  // LDS word w = (presence, value) pairs of my class's slots 16 w .. 16 w + 15 = 16 consecutive codes
+                for (int w = threadIdx.x; w < LDS_SLOTS; w += LONG_BLOCK) {
+                    const unsigned s0 = (unsigned)w << 4;
+                    const unsigned c0 = ((s0 >> 5) << 8) | ((unsigned)cls << 5) | (s0 & 31u);
+                    s_x[w] = buf_load<uint32_t>(xpv_rs, (c0 >> 4) * 4u);
+                }
+            } else {
+                for (int w = threadIdx.x; w < LDS_SLOTS; w += LONG_BLOCK) s_x[w] = buf_load<uint32_t>(xvbits_rs, (unsigned)((w << 3) | cls) * 4u);
+            }
         } else {
             for (int k = threadIdx.x; k < LDS_SLOTS; k += LONG_BLOCK) {
                 const unsigned c = ((unsigned)(k >> 5) << 8) | ((unsigned)cls << 5) | (unsigned)(k & 31);
@@ -820,7 +859,26 @@ __global__ __launch_bounds__(LONG_BLOCK) void k_mxv_long_grp(const PullArgs a)
             // cc: >= 0 a code to gather from the image, <= -2 an LDS slot, -1 nothing
             bool xp[EPL];
             T xv[EPL];
-            if (a.u_full) {
+            bool pv_done = false;
+            if constexpr (IS_BOOL) {
+                if (a.u_pv && !(a.dbg & 8192)) {  // presence and value from one word (LDS for the resident codes)
+                    uint32_t pw[EPL];
+#pragma unroll
+                    for (int i = 0; i < EPL; i++) pw[i] = buf_load<uint32_t>(xpv_rs, cc[i] >= 0 ? (unsigned)(cc[i] >> 4) * 4u : 0xfffffff8u);
+#pragma unroll
+                    for (int i = 0; i < EPL; i++) {
+                        const bool in_lds = cc[i] < -1;
+                        const int sl = in_lds ? -2 - cc[i] : cc[i];
+                        const uint32_t wv32 = in_lds ? s_x[sl >> 4] : pw[i];
+                        const int sh = (sl & 15) * 2;
+                        xp[i] = (wv32 >> sh) & 1u;
+                        xv[i] = (wv32 >> (sh + 1)) & 1u;
+                    }
+                    pv_done = true;
+                }
+            }
+            if (pv_done) {
+            } else if (a.u_full) {
 #pragma unroll
                 for (int i = 0; i < EPL; i++) xp[i] = cc[i] != -1;
             } else {
@@ -837,7 +895,8 @@ __global__ __launch_bounds__(LONG_BLOCK) void k_mxv_long_grp(const PullArgs a)
 #pragma unroll
                 for (int i = 0; i < EPL; i++) xp[i] = (bw[i] >> (co[i] & 31)) & 1u;
             }
-            if (need_uval && !(a.dbg & 8192)) {
+            if (pv_done) {
+            } else if (need_uval && !(a.dbg & 8192)) {
                 if constexpr (IS_BOOL) {
                     uint32_t vw[EPL];
 #pragma unroll
@@ -1068,6 +1127,7 @@ __device__ __forceinline__ void rows_group(const PullArgs &a, int64_t g, int lan
     const __amdgpu_buffer_rsrc_t xval_rs = make_rsrc(a.u_val, a.x_len * (int64_t)sizeof(T));
     const __amdgpu_buffer_rsrc_t xbits_rs = make_rsrc(a.u_bits, a.u_full ? 0 : ((a.x_len + 63) >> 6) * 8);
     const __amdgpu_buffer_rsrc_t xvbits_rs = make_rsrc(a.u_valbits, a.u_valbits ? ((a.x_len + 63) >> 6) * 8 : 0);
+    const __amdgpu_buffer_rsrc_t xpv_rs = make_rsrc(a.u_pv, a.u_pv ? ((a.x_len + 15) >> 4) * 4 : 0);
 
     const int p0_lo = __shfl((int)(uint32_t)p0, 0), p0_hi = __shfl((int)(p0 >> 32), 0);
     const int64_t gbase = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(p0_hi) << 32) |
@@ -1155,7 +1215,15 @@ __device__ __forceinline__ void rows_group(const PullArgs &a, int64_t g, int lan
         // ---- gathers: presence words, then values -- EPL independent random accesses in flight per lane --------------
         bool xp[EPL];
         T xv[EPL];
-        if (a.u_full || (a.dbg & 1)) {
+        bool pv_done = false;
+        if constexpr (std::is_same<T, bool>::value) {
+            if (a.u_pv && !(a.dbg & 1)) {  // presence and value from one word
+                bool_pv_gather<EPL>(xpv_rs, cc, xp, xv);
+                pv_done = true;
+            }
+        }
+        if (pv_done) {
+        } else if (a.u_full || (a.dbg & 1)) {
 #pragma unroll
             for (int i = 0; i < EPL; i++) xp[i] = cc[i] >= 0;
         } else {
@@ -1165,7 +1233,8 @@ __device__ __forceinline__ void rows_group(const PullArgs &a, int64_t g, int lan
 #pragma unroll
             for (int i = 0; i < EPL; i++) xp[i] = (bw[i] >> (cc[i] & 31)) & 1u;
         }
-        if (need_uval && !(a.dbg & 1)) {
+        if (pv_done) {
+        } else if (need_uval && !(a.dbg & 1)) {
             if constexpr (std::is_same<T, bool>::value) {
                 uint32_t vw[EPL];
 #pragma unroll
@@ -2125,7 +2194,17 @@ static void mxv_core(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_Binar
     }
     // BOOL: pack the values of the image the kernel indexes ([hot | u] or u) into bits
     DevBuf<uint64_t> valbits(0);
-    if (st == TC_BOOL && a.need_uval) {
+    // (u not full: presence and value share one word per 16 codes, one gather per entry instead of two -- every pull kernel
+    //  but the chunk kernel of the long rows reads that form)
+    const bool chunk_kernel = S->split_state == 1 && !(ctx().long_kernel == 1 && S->long_nnz > 0);
+    if (st == TC_BOOL && a.need_uval && !a.u_full && !chunk_kernel && !(ctx().debug_flags & 2048)) {
+        const int64_t len = a.x_len;
+        dev_free(valbits.p);
+        valbits.p = (uint64_t *)dev_alloc((size_t)((len + 15) >> 4) * 4 + 8);
+        pack_bool_pv((const uint64_t *)a.u_bits, (const bool *)a.u_val, len, (uint32_t *)valbits.p);
+        a.u_pv = (const uint32_t *)valbits.p;
+        ctx().stats.kernel_launches += 1;
+    } else if (st == TC_BOOL && a.need_uval) {
         const int64_t len = a.x_len;
         dev_free(valbits.p);
         valbits.p = (uint64_t *)dev_alloc(bits_words64((uint64_t)len) * 8);

@@ -457,6 +457,25 @@ void pack_bool_values(const uint64_t *present, const bool *val, int64_t n, uint6
     LAUNCH((k_mask_bits<bool>), nw * 64, present, val, n, out);
 }
 
+// out word w, bits (2k, 2k+1) = (present, present && value) of element 16 w + k: presence and value of a BOOL operand in one
+// gather (pull SpMV with a u that is not full)
+__global__ void k_pack_pv(const uint64_t *present, const bool *val, int64_t n, uint32_t *out)
+{
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= ((n + 15) >> 4)) return;
+    const uint32_t p16 = (uint32_t)(present[w >> 2] >> ((w & 3) * 16)) & 0xffffu;
+    uint32_t o = 0;
+    for (int k = 0; k < 16; k++) {
+        const int64_t i = (w << 4) + k;
+        if (i < n && ((p16 >> k) & 1u)) o |= (1u | (val[i] ? 2u : 0u)) << (2 * k);
+    }
+    out[w] = o;
+}
+void pack_bool_pv(const uint64_t *present, const bool *val, int64_t n, uint32_t *out)
+{
+    LAUNCH(k_pack_pv, (n + 15) >> 4, present, val, n, out);
+}
+
 // indices of the present entries, ascending, as a fresh device array (caller frees); returns the count
 int64_t vector_index_list(GB_Vector_opaque *v, uint64_t **d_idx)
 {
