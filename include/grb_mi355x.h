@@ -183,6 +183,8 @@ extern GrB_Descriptor
 #define GRB_DECL_BINOPS(T)                                                                                             \
     extern GrB_BinaryOp GrB_FIRST_##T, GrB_SECOND_##T, GrB_ONEB_##T, GxB_PAIR_##T, GrB_PLUS_##T, GrB_MINUS_##T,        \
         GrB_TIMES_##T, GrB_MIN_##T, GrB_MAX_##T, GxB_ANY_##T, GxB_LOR_##T, GxB_LAND_##T, GxB_LXOR_##T;                 \
+    /* comparisons (T x T -> BOOL): operands of GrB_Vector_eWiseAdd / eWiseMult only (isequal, core/vector.py:340-379) */  \
+    extern GrB_BinaryOp GrB_EQ_##T, GrB_NE_##T, GrB_GT_##T, GrB_LT_##T, GrB_GE_##T, GrB_LE_##T;                        \
     extern GrB_Monoid GxB_ANY_##T##_MONOID;                                                                            \
     extern GrB_Semiring GxB_ANY_PAIR_##T, GxB_ANY_FIRST_##T, GxB_ANY_SECOND_##T;
 GRB_FOR_EACH_TNAME(GRB_DECL_BINOPS)

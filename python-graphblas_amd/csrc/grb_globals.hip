@@ -50,6 +50,12 @@ GrB_Type type_of_code(int code)
     DEF_BINOP(GxB_LOR_##T, OP_LOR, T)              \
     DEF_BINOP(GxB_LAND_##T, OP_LAND, T)            \
     DEF_BINOP(GxB_LXOR_##T, OP_LXOR, T)            \
+    DEF_BINOP(GrB_EQ_##T, OP_EQ, T)                \
+    DEF_BINOP(GrB_NE_##T, OP_NE, T)                \
+    DEF_BINOP(GrB_GT_##T, OP_GT, T)                \
+    DEF_BINOP(GrB_LT_##T, OP_LT, T)                \
+    DEF_BINOP(GrB_GE_##T, OP_GE, T)                \
+    DEF_BINOP(GrB_LE_##T, OP_LE, T)                \
     DEF_MONOID(GxB_ANY_##T##_MONOID, OP_ANY, T)    \
     DEF_SEMIRING(GxB_ANY_PAIR_##T, OP_ANY, OP_PAIR, T)   \
     DEF_SEMIRING(GxB_ANY_FIRST_##T, OP_ANY, OP_FIRST, T) \

@@ -28,8 +28,11 @@ enum TypeCode : int {
 enum OpCode : int {
     OP_NONE = -1,
     OP_FIRST = 0, OP_SECOND, OP_PAIR, OP_PLUS, OP_MINUS, OP_RMINUS, OP_TIMES, OP_MIN, OP_MAX,
-    OP_LOR, OP_LAND, OP_LXOR, OP_LXNOR, OP_ANY, OP_COUNT
+    OP_LOR, OP_LAND, OP_LXOR, OP_LXNOR, OP_ANY, OP_COUNT,
+    // comparisons: T x T -> BOOL; accepted by the element-wise vector operations only (grb_vecops.hip)
+    OP_EQ = 32, OP_NE, OP_GT, OP_LT, OP_GE, OP_LE
 };
+inline bool op_is_comparison(int op) { return op >= OP_EQ && op <= OP_LE; }
 
 constexpr uint64_t MAGIC_VECTOR = 0x4752425645435452ULL;  // "GRBVECTR"
 constexpr uint64_t MAGIC_MATRIX = 0x4752424d41545258ULL;  // "GRBMATRX"

@@ -963,7 +963,7 @@ static void mxm_core(GB_Matrix_opaque *C, GB_Matrix_opaque *Mask, const GB_Binar
     if (Ae->ncols != Be->nrows) fail(GrB_DIMENSION_MISMATCH, "mxm: inner dimensions " + std::to_string(Ae->ncols) + " and " + std::to_string(Be->nrows) + " differ");
     if (C->nrows != Ae->nrows || C->ncols != Be->ncols) fail(GrB_DIMENSION_MISMATCH, "mxm: output is " + std::to_string(C->nrows) + "x" + std::to_string(C->ncols) + ", product is " + std::to_string(Ae->nrows) + "x" + std::to_string(Be->ncols));
     if (Mask && (Mask->nrows != C->nrows || Mask->ncols != C->ncols)) fail(GrB_DIMENSION_MISMATCH, "mxm: mask shape does not match the output");
-    if (accum && accum->type != C->type->code) fail(GrB_DOMAIN_MISMATCH, "mxm: accum operator type must equal the output type");
+    if (accum && (accum->type != C->type->code || op_is_comparison(accum->op))) fail(GrB_DOMAIN_MISMATCH, "mxm: accum operator type must equal the output type");
     ctx().stats = GrX_Stats{};
     ctx().stats.method = 3;
     if (!Mask && f.comp) {

@@ -399,7 +399,7 @@ static void mxv_core(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_Binar
     if (S->ncols != u->n) fail(GrB_DIMENSION_MISMATCH, "mxv/vxm: matrix inner dimension " + std::to_string(S->ncols) + " does not match vector size " + std::to_string(u->n));
     if (w->n != S->nrows) fail(GrB_DIMENSION_MISMATCH, "mxv/vxm: output size " + std::to_string(w->n) + " does not match matrix dimension " + std::to_string(S->nrows));
     if (mask && mask->n != w->n) fail(GrB_DIMENSION_MISMATCH, "mxv/vxm: mask size does not match output size");
-    if (accum && accum->type != w->type->code) fail(GrB_DOMAIN_MISMATCH, "mxv/vxm: accum operator type must equal the output type");
+    if (accum && (accum->type != w->type->code || op_is_comparison(accum->op))) fail(GrB_DOMAIN_MISMATCH, "mxv/vxm: accum operator type must equal the output type");
     ctx().stats = GrX_Stats{};
     ctx().stats.method = 1;
     ctx().stats.flops = S->nvals;
@@ -754,7 +754,7 @@ extern "C" GrB_Info GrB_mxv(GrB_Vector w, const GrB_Vector mask, const GrB_Binar
     // pull over S = A (or A' with T0); push needs the matrix whose ROWS are indexed like u: S' -- only when cached
     GB_Matrix_opaque *P = f.t0 ? A : A->tr;
     const bool dims_ok = (f.t0 ? A->nrows : A->ncols) == u->n && (f.t0 ? A->ncols : A->nrows) == w->n && (!mask || mask->n == w->n);
-    if (dims_ok && (!accum || accum->type == w->type->code) && !(!mask && f.comp) && w->n > 0 && want_push(u, P) &&
+    if (dims_ok && (!accum || (accum->type == w->type->code && !op_is_comparison(accum->op))) && !(!mask && f.comp) && w->n > 0 && want_push(u, P) &&
         push_core(w, mask, accum, semiring, P, u, /*flip=*/true, f)) {
     } else {
         GB_Matrix_opaque *S = f.t0 ? matrix_transpose_cached(A) : A;
@@ -778,7 +778,7 @@ extern "C" GrB_Info GrB_vxm(GrB_Vector w, const GrB_Vector mask, const GrB_Binar
     // push walks the rows of P = A (or A' with T1, when cached) selected by u; pull gathers over S = P'
     GB_Matrix_opaque *P = f.t1 ? A->tr : A;
     const bool dims_ok = (f.t1 ? A->ncols : A->nrows) == u->n && (f.t1 ? A->nrows : A->ncols) == w->n && (!mask || mask->n == w->n);
-    if (dims_ok && (!accum || accum->type == w->type->code) && !(!mask && f.comp) && w->n > 0 && want_push(u, P) &&
+    if (dims_ok && (!accum || (accum->type == w->type->code && !op_is_comparison(accum->op))) && !(!mask && f.comp) && w->n > 0 && want_push(u, P) &&
         push_core(w, mask, accum, semiring, P, u, /*flip=*/false, f)) {
     } else {
         GB_Matrix_opaque *S = f.t1 ? A : matrix_transpose_cached(A);

@@ -393,7 +393,7 @@ static void vector_build_typed(GB_Vector_opaque *w, const uint64_t *I, const voi
     if (vector_nvals(w) > 0) fail(GrB_OUTPUT_NOT_EMPTY, "GrB_Vector_build: output already has entries");
     if (n == 0) return;
     if (!I || !X_host) fail(GrB_NULL_POINTER, "GrB_Vector_build: NULL index or value array");
-    if (dup && dup->type != w->type->code) fail(GrB_DOMAIN_MISMATCH, "dup operator type must match the vector type");
+    if (dup && (dup->type != w->type->code || op_is_comparison(dup->op))) fail(GrB_DOMAIN_MISMATCH, "dup operator type must match the vector type");
     if ((uint64_t)n > 0xffffffffull) fail(GrB_NOT_IMPLEMENTED, "more than 2^32 tuples in one build");
     vector_ensure_storage(w);
     DevBuf<uint64_t> dI(n);
@@ -696,7 +696,7 @@ static void matrix_build_typed(GB_Matrix_opaque *C, const uint64_t *I, const uin
     if (C->nvals > 0) fail(GrB_OUTPUT_NOT_EMPTY, "GrB_Matrix_build: output already has entries");
     if (n == 0) return;
     if (!I || !J || !X_host) fail(GrB_NULL_POINTER, "GrB_Matrix_build: NULL index or value array");
-    if (dup && dup->type != C->type->code) fail(GrB_DOMAIN_MISMATCH, "dup operator type must match the matrix type");
+    if (dup && (dup->type != C->type->code || op_is_comparison(dup->op))) fail(GrB_DOMAIN_MISMATCH, "dup operator type must match the matrix type");
     DevBuf<uint64_t> dI(n), dJ(n);
     h2d(dI.p, I, sizeof(uint64_t) * n);
     h2d(dJ.p, J, sizeof(uint64_t) * n);

@@ -181,7 +181,7 @@ static void assign_all(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_Bin
 {
     const VDesc f = vflags(desc);
     if (mask && mask->n != w->n) fail(GrB_DIMENSION_MISMATCH, "assign: mask size does not match the output size");
-    if (accum && accum->type != w->type->code) fail(GrB_DOMAIN_MISMATCH, "assign: accum operator type must equal the output type");
+    if (accum && (accum->type != w->type->code || op_is_comparison(accum->op))) fail(GrB_DOMAIN_MISMATCH, "assign: accum operator type must equal the output type");
     if (!mask && f.comp) {  // complement of "no mask": nothing may be written
         if (f.replace) vector_release_storage(w);
         return;
@@ -241,6 +241,41 @@ static void reduce_to(T *val, const GB_BinaryOp_opaque *accum, const GB_Monoid_o
     }
 }
 
+template <typename T>
+__device__ __forceinline__ bool apply_cmp(int op, T a, T b)
+{
+    switch (op) {
+    case OP_EQ: return a == b;
+    case OP_NE: return a != b;
+    case OP_GT: return a > b;
+    case OP_LT: return a < b;
+    case OP_GE: return a >= b;
+    default: return a <= b;
+    }
+}
+// comparison operators: t (BOOL) = u cmp v on the intersection; eWiseAdd passes single entries through cast to BOOL
+template <typename T>
+__global__ void k_ewise_cmp(int64_t n, const T *u_val, const uint64_t *u_bits, const T *v_val, const uint64_t *v_bits, int op, int is_add,
+                            bool *t_val, uint64_t *t_bits)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int64_t g = i >> 6;
+    bool has = false;
+    if (i < n) {
+        const bool hu = u_bits && ((u_bits[g] >> lane) & 1ull), hv = v_bits && ((v_bits[g] >> lane) & 1ull);
+        if (hu && hv) {
+            t_val[i] = apply_cmp<T>(op, u_val[i], v_val[i]);
+            has = true;
+        } else if (is_add && (hu || hv)) {
+            t_val[i] = (hu ? u_val[i] : v_val[i]) != (T)0;
+            has = true;
+        }
+    }
+    const unsigned long long b = __ballot(has);
+    if (lane == 0 && g < ((n + 63) >> 6)) t_bits[g] = b;
+}
+
 // w<mask, replace> = accum(w, u (op) v), element-wise over the union (is_add) or the intersection of the patterns
 // (reference core/vector.py:960-1150 -> GrB_Vector_eWiseAdd_* / eWiseMult_*)
 static void ewise_core(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_BinaryOp_opaque *accum, int op_in, int ot,
@@ -250,14 +285,16 @@ static void ewise_core(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_Bin
     if (u->n != v->n) fail(GrB_DIMENSION_MISMATCH, "eWise: input sizes " + std::to_string(u->n) + " and " + std::to_string(v->n) + " differ");
     if (w->n != u->n) fail(GrB_DIMENSION_MISMATCH, "eWise: output size does not match the inputs");
     if (mask && mask->n != w->n) fail(GrB_DIMENSION_MISMATCH, "eWise: mask size does not match the output size");
-    if (accum && accum->type != w->type->code) fail(GrB_DOMAIN_MISMATCH, "eWise: accum operator type must equal the output type");
+    if (accum && (accum->type != w->type->code || op_is_comparison(accum->op))) fail(GrB_DOMAIN_MISMATCH, "eWise: accum operator type must equal the output type");
     if (!mask && f.comp) {
         if (f.replace) vector_release_storage(w);
         return;
     }
     if (w->n == 0) return;
     const int64_t n = (int64_t)w->n;
-    const int op = canonical_op(ot, op_in);
+    const bool cmp = op_is_comparison(op_in);
+    const int op = cmp ? op_in : canonical_op(ot, op_in);
+    const int tt = cmp ? (int)TC_BOOL : ot;  // type of the element-wise result
     const size_t ob = type_size(ot);
     // operands in the operator's type
     DevBuf<char> u_cast(0), v_cast(0);
@@ -274,13 +311,18 @@ static void ewise_core(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_Bin
         cast_array(ot, v_cast.p, v->type->code, v->d_val, n);
         vv = v_cast.p;
     }
-    DevBuf<char> t_val(ob * (size_t)n);
+    DevBuf<char> t_val(std::max(ob, type_size(tt)) * (size_t)n);
     DevBuf<uint64_t> t_bits(bits_words64((uint64_t)n));
     const int64_t threads = (int64_t)bits_words64((uint64_t)n) * 64;
     GRB_DISPATCH_TYPE(ot, T, {
-        hipLaunchKernelGGL((k_ewise<T>), dim3((unsigned)ceil_div(threads, 256)), dim3(256), 0, ctx().stream, n, (const T *)uv,
-                           (const uint64_t *)(u->d_val ? u->d_bits : nullptr), (const T *)vv,
-                           (const uint64_t *)(v->d_val ? v->d_bits : nullptr), op, is_add ? 1 : 0, (T *)t_val.p, t_bits.p);
+        if (cmp)
+            hipLaunchKernelGGL((k_ewise_cmp<T>), dim3((unsigned)ceil_div(threads, 256)), dim3(256), 0, ctx().stream, n, (const T *)uv,
+                               (const uint64_t *)(u->d_val ? u->d_bits : nullptr), (const T *)vv,
+                               (const uint64_t *)(v->d_val ? v->d_bits : nullptr), op, is_add ? 1 : 0, (bool *)t_val.p, t_bits.p);
+        else
+            hipLaunchKernelGGL((k_ewise<T>), dim3((unsigned)ceil_div(threads, 256)), dim3(256), 0, ctx().stream, n, (const T *)uv,
+                               (const uint64_t *)(u->d_val ? u->d_bits : nullptr), (const T *)vv,
+                               (const uint64_t *)(v->d_val ? v->d_bits : nullptr), op, is_add ? 1 : 0, (T *)t_val.p, t_bits.p);
     })
     // the write rule in w's type (w may be u or v: t is a separate buffer, the rule is element-wise)
     DevBuf<uint64_t> mbits(mask ? bits_words64(w->n) : 1);
@@ -288,10 +330,10 @@ static void ewise_core(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_Bin
     vector_ensure_storage(w);
     DevBuf<char> tc(0);
     const void *tw = t_val.p;
-    if (w->type->code != ot) {
+    if (w->type->code != tt) {
         dev_free(tc.p);
         tc.p = (char *)dev_alloc(w->type->size * (size_t)n);
-        cast_array(w->type->code, tc.p, ot, t_val.p, n);
+        cast_array(w->type->code, tc.p, tt, t_val.p, n);
         tw = tc.p;
     }
     vector_write_rule(w, tw, t_bits.p, mask ? mbits.p : nullptr, f.comp, accum ? canonical_op(w->type->code, accum->op) : -1, f.replace);

@@ -14,7 +14,8 @@ from . import _lib
 from .dtypes import BOOL, DataType, lookup_dtype, unify
 
 _BINARY_NAMES = ["first", "second", "pair", "oneb", "plus", "minus", "times", "min", "max", "any", "lor", "land",
-                 "lxor", "lxnor"]
+                 "lxor", "lxnor", "eq", "ne", "gt", "lt", "ge", "le"]
+_COMPARISONS = {"eq", "ne", "gt", "lt", "ge", "le"}  # T x T -> BOOL: element-wise vector operations only
 _MONOID_NAMES = ["plus", "times", "min", "max", "any", "lor", "land", "lxor", "lxnor"]
 _BOOL_ONLY = {"lor", "land", "lxor", "lxnor"}
 _SYMBOLS = {"+": "plus", "*": "times", "-": "minus", "|": "lor", "&": "land", "^": "lxor", "==": "lxnor", "eq": "lxnor"}
@@ -65,7 +66,7 @@ class _OpBase:
         if t is None:
             for gb_name in self._gb_candidates(dtype):
                 if _lib.has_symbol(gb_name):
-                    t = TypedOp(self, self.name, dtype, dtype, gb_name, self.opclass)
+                    t = TypedOp(self, self.name, dtype, BOOL if self.name in _COMPARISONS else dtype, gb_name, self.opclass)
                     break
             else:
                 raise KeyError(f"{self.name} does not work with {dtype}")
@@ -166,7 +167,7 @@ for _n in _MONOID_NAMES:
     setattr(monoid, _n, Monoid(_n))
 for _m in _MONOID_NAMES:
     for _b in _BINARY_NAMES:
-        if _b == "oneb":
+        if _b == "oneb" or _b in _COMPARISONS:
             continue
         _s = Semiring(f"{_m}_{_b}", getattr(monoid, _m), getattr(binary, _b))
         setattr(semiring, _s.name, _s)

@@ -158,15 +158,25 @@ class Vector(BaseType):
         self._size = size
 
     def isequal(self, other, *, check_dtype=False):
-        """Same size, structure and values (reference core/vector.py:340-379)."""
+        """Same size, structure and values, decided on the device exactly as the reference does (core/vector.py:340-379):
+        equal ``nvals``, ``ewise_mult(eq)`` keeps every entry, and the ``land`` of the comparisons is true."""
         if not isinstance(other, Vector):
             raise TypeError(f"Expected type: Vector; got {type(other).__name__}")
         if check_dtype and self.dtype is not other.dtype:
             return False
-        if self._size != other._size or self.nvals != other.nvals:
+        if self._size != other._size:
             return False
-        (i1, x1), (i2, x2) = self.to_coo(), other.to_coo()
-        return bool(np.array_equal(i1, i2) and np.array_equal(x1, x2))
+        nv = self.nvals
+        if nv != other.nvals:
+            return False
+        if nv == 0:
+            return True
+        from .operators import binary as _binary
+
+        matches = self.ewise_mult(other, _binary.eq).new()
+        if matches.nvals != nv:
+            return False
+        return bool(matches.reduce(_monoid.land, allow_empty=False).new().value)
 
     def isclose(self, other, *, rel_tol=1e-7, abs_tol=0.0, check_dtype=False):
         if check_dtype and self.dtype is not other.dtype:

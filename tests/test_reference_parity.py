@@ -518,3 +518,23 @@ def test_ewise_mult_and_add(gb, v):
         v.ewise_add(v2, gb.semiring.max_times)
     assert v.ewise_add(v2).new().isequal(v.ewise_add(v2, gb.monoid.plus).new())
     assert v.ewise_add(v2).new().isequal(gb.Vector.from_coo([0, 1, 3, 4, 5, 6], [2, 1, 4, 2, 2, 1]))
+
+
+def test_comparisons_and_isequal_on_device(gb, v):
+    """binary.eq & co. (T x T -> BOOL) through eWiseMult / eWiseAdd, and Vector.isequal the way the reference computes it
+    (graphblas/core/vector.py:340-379: nvals, ewise_mult(eq), reduce(land))."""
+    v2 = gb.Vector.from_coo([1, 3, 4, 6], [1, 2, 2, 0])
+    m = v.ewise_mult(v2, gb.binary.eq).new()
+    assert m.dtype.name == "BOOL"
+    assert [x.tolist() for x in m.to_coo()] == [[1, 3, 4, 6], [True, False, True, True]]
+    assert v.ewise_mult(v2, gb.binary.gt).new().to_coo()[1].tolist() == [False, False, False, False]
+    assert v.ewise_mult(v2, gb.binary.le).new().to_coo()[1].tolist() == [True, True, True, True]
+    assert not v.isequal(v2)
+    assert v.isequal(v.dup())
+    assert not v.isequal(gb.Vector.from_coo([1, 3, 4, 5], [1, 1, 2, 0], size=7))  # same nvals, other pattern
+    assert not v.isequal(gb.Vector.from_coo([1, 3, 4, 6], [1, 1, 2, 0], size=8))  # other size
+    assert gb.Vector(int, 3).isequal(gb.Vector(int, 3))
+    f = gb.Vector.from_coo([0, 2], [1.5, float("inf")])
+    assert f.isequal(gb.Vector.from_coo([0, 2], [1.5, float("inf")]))
+    with pytest.raises(Exception):
+        v(accum=gb.binary.eq) << v.ewise_mult(v2, gb.binary.plus)  # a comparison is not an accumulator
