@@ -52,7 +52,7 @@ def parse():
     p.add_argument("--scale", type=int, default=24)
     p.add_argument("--visited", type=float, default=0.5, help="fraction of rows masked out (visited)")
     p.add_argument("--workload", default="mxv_min_plus_masked",
-                   choices=["mxv_min_plus_masked", "mxv_lor_land_masked", "mxv_min_plus", "mxm_plus_times", "mxm_plus_times_masked", "bfs"])
+                   choices=["mxv_min_plus_masked", "mxv_lor_land_masked", "mxv_min_plus", "mxm_plus_times", "mxm_plus_times_masked", "bfs", "sssp"])
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--extra", action="store_true", help="also run the secondary workloads (reported under 'extra')")
     return p.parse_args()
@@ -316,6 +316,53 @@ def main_bfs(args, gb, torch, device, rank, world):
         "roofline": None, "cpu_baseline": None}))
 
 
+def main_sssp(args, gb, torch, device, rank, world):
+    """The primer's SSSP loop (docs/getting_started/primer.rst:236-246) on the device: ``v(min) << min_plus(v @ G)`` until
+    ``v.isequal(w)`` -- Bellman-Ford by vxm, fixed-point test by eWiseMult(eq) + reduce(land).  FP32 weights U{1..255}.
+    value = Graph500-style TEPS: edges incident to the reached vertices / time of the whole loop."""
+    from graphblas_amd import synthetic
+
+    assert world == 1, "the SSSP line is a single-GPU measurement"
+    n = 1 << args.scale
+    indptr, col = synthetic.rmat_csr(args.scale, device="cuda")
+    vals = synthetic.edge_weights(col, args.scale)
+    G = device.matrix_from_device_csr(indptr, col, vals, n, n, "FP32")
+    device.cache_transpose(G)
+    deg = indptr[1:] - indptr[:-1]
+    src = int(torch.argmax(deg).item())
+
+    def solve():
+        v = gb.Vector("FP32", n)
+        v[src] << 0.0
+        its = 0
+        while True:
+            its += 1
+            w = v.dup()
+            v(gb.op.min) << gb.semiring.min_plus(v @ G)
+            if v.isequal(w):
+                break
+        return v, its
+
+    for _ in range(args.warmup):
+        v, its = solve()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        v, its = solve()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    idx, _d = v.to_coo()
+    reached = torch.from_numpy(idx.astype("int64")).cuda()
+    edges = int(deg[reached].sum().item())
+    print(json.dumps({
+        "metric": "GTEPS (SSSP) on R-MAT scale-%d" % args.scale, "value": edges / dt / 1e9, "unit": "GTEPS", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"rmat{args.scale} sssp: Bellman-Ford by vxm(min_plus) with accum min until isequal, whole loop through the C ABI",
+                   "iterations": its, "reached_vertices": int(idx.size), "edges_counted_per_step": edges},
+        "roofline": None, "cpu_baseline": None}))
+
+
 def main():
     args = parse()
     import torch
@@ -383,6 +430,8 @@ def main():
 
     if args.workload == "bfs":
         return main_bfs(args, gb, torch, device, rank, world)
+    if args.workload == "sssp":
+        return main_sssp(args, gb, torch, device, rank, world)
     if args.workload in ("mxm_plus_times", "mxm_plus_times_masked"):
         return main_mxm(args, gb, torch, device, rank, world, dist, barrier)
     wl, res = run(args.workload)

@@ -37,6 +37,7 @@ rec = {"workload": "mxv_min_plus_masked", "scale": 24, "kernels": sorted(per_ker
 json.dump(rec, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
 PY
 echo "== bfs"; for s in 20 24; do timeout 600 python bench.py --workload bfs --scale $s --steps 5 --warmup 1 > "$OUT/bfs_s$s.json" 2> "$OUT/bfs_s$s.err"; echo "rc=$?"; cut -c1-300 "$OUT/bfs_s$s.json"; done
+echo "== sssp"; for s in 20 24; do timeout 600 python bench.py --workload sssp --scale $s --steps 3 --warmup 1 > "$OUT/sssp_s$s.json" 2> "$OUT/sssp_s$s.err"; echo "rc=$?"; cut -c1-300 "$OUT/sssp_s$s.json"; done
 echo "== mxm masked (C<A.S> = A A)"; for s in 20 22; do timeout 900 python bench.py --workload mxm_plus_times_masked --scale $s --steps 2 --warmup 1 > "$OUT/mxm_masked_s$s.json" 2> "$OUT/mxm_masked_s$s.err"; echo "rc=$?"; cut -c1-500 "$OUT/mxm_masked_s$s.json"; done
 echo "== mxm"; for s in 18 20; do timeout 900 python bench.py --workload mxm_plus_times --scale $s --steps 2 --warmup 1 > "$OUT/mxm_s$s.json" 2> "$OUT/mxm_s$s.err"; echo "rc=$?"; cut -c1-500 "$OUT/mxm_s$s.json"; done
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_mxm" -o mxm -- python bench.py --workload mxm_plus_times --scale 18 --steps 2 --warmup 1 > "$OUT/prof_mxm.json" 2> "$OUT/prof_mxm.err"; grep -E "grb::" "$OUT/prof_mxm/mxm_kernel_stats.csv" | cut -c1-160
