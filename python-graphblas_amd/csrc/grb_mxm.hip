@@ -352,51 +352,95 @@ __global__ void k_window_offsets(const int64_t *Bp, const int32_t *Bj, int64_t n
 // from the offset table; a workgroup scan of the range lengths numbers the products, and the threads take them round-robin
 // (binary search of the product number in the scan) -- a hub column with thousands of entries in the window is shared by the
 // whole workgroup.  f(p, q): p = position of A(row,k), q = position of B(k,j).
+// the products of up to MM_WIN_BLOCK entries of a row -- thread t brings `len` products starting at position qb of B --
+// dealt round-robin to the workgroup: scan of the lengths, binary search of the product number.  f(e, q): e = the entry
+// (thread) the product belongs to, q = position of B(k,j).  Every thread must call.
 template <typename F>
-__device__ __forceinline__ void foreach_window_product(const MxmArgs &a, int64_t row, int w, F &&f)
+__device__ __forceinline__ void deal_products(int len, int64_t qb, F &&f)
 {
     __shared__ int s_scan[MM_WIN_BLOCK + 1];
     __shared__ int64_t s_qb[MM_WIN_BLOCK];
     __shared__ int s_wsum[MM_WIN_BLOCK / 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int64_t pend = a.Ap[row + 1];
-    for (int64_t pc = a.Ap[row]; pc < pend; pc += MM_WIN_BLOCK) {
-        const int64_t p = pc + tid;
-        int len = 0;
-        int64_t qb = 0;
-        if (p < pend) {
-            const int k = a.Aj[p];
-            const int32_t *o = a.woff + (int64_t)k * (a.n_win + 1) + w;
-            const int o0 = o[0], o1 = o[1];
-            qb = a.Bp[k] + o0;
-            len = o1 - o0;
-        }
-        int incl = len;
+    int incl = len;
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int t = __shfl_up(incl, off);
-            if (lane >= off) incl += t;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) s_wsum[wv] = incl;
+    __syncthreads();
+    int wave_off = 0, total = 0;
+    for (int x = 0; x < MM_WIN_BLOCK / 64; x++) {
+        if (x < wv) wave_off += s_wsum[x];
+        total += s_wsum[x];
+    }
+    s_scan[tid] = wave_off + incl - len;
+    s_qb[tid] = qb;
+    __syncthreads();
+    for (int t = tid; t < total; t += MM_WIN_BLOCK) {
+        int lo = 0, hi = MM_WIN_BLOCK;  // the last entry whose first product number is <= t
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (s_scan[mid] <= t) lo = mid;
+            else hi = mid;
         }
-        if (lane == 63) s_wsum[wv] = incl;
-        __syncthreads();
-        int wave_off = 0, total = 0;
-        for (int x = 0; x < MM_WIN_BLOCK / 64; x++) {
-            if (x < wv) wave_off += s_wsum[x];
-            total += s_wsum[x];
+        f(lo, s_qb[lo] + (t - s_scan[lo]));
+    }
+    __syncthreads();
+}
+
+// Walks the column windows of one row with a 1024-thread workgroup; body(w, visit) is called once per window (uniformly),
+// and visit(f) delivers the window's products to f(p, q) (p = position of A(row,k), q = position of B(k,j)).  The part of
+// B(k,:) inside window w is [woff[k][w], woff[k][w+1]).  Rows with at most 1024 entries (all but the hubs) keep one entry
+// per thread in registers for the whole walk: k and Bp[k] are loaded once, and the only load a window adds -- woff[k][w+2],
+// the end of the NEXT window's range -- is issued a window ahead, so a window's dependent chain is scan -> B loads ->
+// LDS atomics instead of Aj -> woff/Bp -> scan -> B loads.  Hub rows re-read their entries per window, 1024 at a time.
+template <typename Body>
+__device__ __forceinline__ void walk_windows(const MxmArgs &a, int64_t row, Body &&body)
+{
+    const int tid = threadIdx.x;
+    const int64_t pbeg = a.Ap[row], pend = a.Ap[row + 1];
+    const int nwin = a.n_win;
+    if (pend - pbeg <= MM_WIN_BLOCK) {
+        const int64_t p = pbeg + tid;
+        const bool mine = p < pend;
+        int64_t bp = 0;
+        const int32_t *wo = nullptr;
+        int o_cur = 0, o_nxt = 0;
+        if (mine) {
+            const int k = a.Aj[p];
+            bp = a.Bp[k];
+            wo = a.woff + (int64_t)k * (nwin + 1);
+            o_cur = wo[0];
+            o_nxt = wo[1];
         }
-        s_scan[tid] = wave_off + incl - len;
-        s_qb[tid] = qb;
-        __syncthreads();
-        for (int t = tid; t < total; t += MM_WIN_BLOCK) {
-            int lo = 0, hi = MM_WIN_BLOCK;  // the last entry whose first product number is <= t
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (s_scan[mid] <= t) lo = mid;
-                else hi = mid;
-            }
-            f(pc + lo, s_qb[lo] + (t - s_scan[lo]));
+        for (int w = 0; w < nwin; w++) {
+            const int o_ahead = (mine && w + 2 <= nwin) ? wo[w + 2] : 0;
+            const int len = o_nxt - o_cur;
+            const int64_t qb = bp + o_cur;
+            body(w, [&](auto &&f) { deal_products(len, qb, [&](int e, int64_t q) { f(pbeg + e, q); }); });
+            o_cur = o_nxt;
+            o_nxt = o_ahead;
         }
-        __syncthreads();
+    } else {
+        for (int w = 0; w < nwin; w++) {
+            body(w, [&](auto &&f) {
+                for (int64_t pc = pbeg; pc < pend; pc += MM_WIN_BLOCK) {
+                    const int64_t p = pc + tid;
+                    int len = 0;
+                    int64_t qb = 0;
+                    if (p < pend) {
+                        const int k = a.Aj[p];
+                        const int32_t *o = a.woff + (int64_t)k * (nwin + 1) + w;
+                        const int o0 = o[0], o1 = o[1];
+                        qb = a.Bp[k] + o0;
+                        len = o1 - o0;
+                    }
+                    deal_products(len, qb, [&](int e, int64_t q) { f(pc + e, q); });
+                }
+            });
+        }
     }
 }
 
@@ -415,12 +459,11 @@ __global__ __launch_bounds__(MM_WIN_BLOCK) void k_spgemm_win(const MxmArgs a, co
     for (int k = tid; k < MM_WIN; k += MM_WIN_BLOCK) s_acc[k] = ident;
     if (tid < MM_WIN / 64) s_bits[tid] = 0ull;
     __syncthreads();
-    const int nwin = a.n_win;
     int64_t out = a.Tp[row];
     T *Tx = (T *)a.Tx;
-    for (int w = 0; w < nwin; w++) {
+    walk_windows(a, row, [&](int w, auto &&visit) {
         const int c0 = w * MM_WIN;
-        foreach_window_product(a, row, w, [&](int64_t p, int64_t q) {
+        visit([&](int64_t p, int64_t q) {
             const int j = a.Bj[q] - c0;
             const T av = a.need_a ? Ax[a.a_iso ? 0 : p] : (T)0;
             const T bv = a.need_b ? Bx[a.b_iso ? 0 : q] : (T)0;
@@ -461,7 +504,7 @@ __global__ __launch_bounds__(MM_WIN_BLOCK) void k_spgemm_win(const MxmArgs a, co
         }
         out += total;
         __syncthreads();
-    }
+    });
 }
 
 // ---- mask-driven product: C<M> = A (+.x) B with a non-complemented mask only needs the entries of T inside M's pattern
@@ -546,7 +589,8 @@ __global__ __launch_bounds__(MM_WIN_BLOCK) void k_spgemm_mwin(const MxmArgs a, c
     T *cv = (T *)a.cap_val;
     int64_t mpos = mlo;  // mask entries before it lie in earlier windows
     __syncthreads();
-    for (int w = 0; w < a.n_win && mpos < mhi; w++) {
+    walk_windows(a, row, [&](int w, auto &&visit) {
+        if (mpos >= mhi) return;  // (uniform) the mask row is exhausted
         const int c0 = w * MM_WIN;
         if (tid == 0) {  // the mask row's entries inside the window: [mpos, first entry with column >= c0 + MM_WIN)
             int64_t lo = mpos, hi = mhi;
@@ -563,13 +607,13 @@ __global__ __launch_bounds__(MM_WIN_BLOCK) void k_spgemm_mwin(const MxmArgs a, c
         const int64_t wlo = s_mrange[0], whi = s_mrange[1];
         __syncthreads();
         mpos = whi;
-        if (wlo == whi) continue;  // (uniform) no mask entry in this window
+        if (wlo == whi) return;  // (uniform) no mask entry in this window
         for (int64_t p = wlo + tid; p < whi; p += MM_WIN_BLOCK) {
             const int j = a.Mj[p] - c0;
             atomicOr(&s_mbits[j >> 6], 1ull << (j & 63));
         }
         __syncthreads();
-        foreach_window_product(a, row, w, [&](int64_t p, int64_t q) {
+        visit([&](int64_t p, int64_t q) {
             const int j = a.Bj[q] - c0;
             if ((s_mbits[j >> 6] >> (j & 63)) & 1ull) {
                 const T av = a.need_a ? Ax[a.a_iso ? 0 : p] : (T)0;
@@ -593,7 +637,7 @@ __global__ __launch_bounds__(MM_WIN_BLOCK) void k_spgemm_mwin(const MxmArgs a, c
         __syncthreads();
         if (tid < MM_WIN / 64) { s_bits[tid] = 0ull; s_mbits[tid] = 0ull; }
         __syncthreads();
-    }
+    });
 }
 
 // compaction of the mask-layout results into CSR
