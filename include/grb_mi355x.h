@@ -93,6 +93,9 @@ GrB_Info GrB_Matrix_dup(GrB_Matrix *C, const GrB_Matrix A);
 GrB_Info GrB_Matrix_free(GrB_Matrix *A);
 GrB_Info GrB_Matrix_clear(GrB_Matrix A);
 GrB_Info GrB_Matrix_resize(GrB_Matrix A, GrB_Index nrows, GrB_Index ncols); /* core/matrix.py:512-523 */
+/* row-wise (desc T0: column-wise) reduction with a monoid: core/matrix.py:2636-2710; the pull SpMV over (monoid, FIRST) */
+GrB_Info GrB_Matrix_reduce_Monoid(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_Monoid monoid,
+                                  const GrB_Matrix A, const GrB_Descriptor desc);
 GrB_Info GrB_Matrix_nrows(GrB_Index *nrows, const GrB_Matrix A);
 GrB_Info GrB_Matrix_ncols(GrB_Index *ncols, const GrB_Matrix A);
 GrB_Info GrB_Matrix_nvals(GrB_Index *nvals, const GrB_Matrix A);

@@ -87,6 +87,7 @@ def _declare(L):
     L.GrB_Matrix_free.argtypes = [P(c_void_p)]
     L.GrB_Matrix_clear.argtypes = [c_void_p]
     L.GrB_Matrix_resize.argtypes = [c_void_p, c_u64, c_u64]
+    L.GrB_Matrix_reduce_Monoid.argtypes = [c_void_p] * 6
     for name in ("GrB_Matrix_nrows", "GrB_Matrix_ncols", "GrB_Matrix_nvals", "GrB_Vector_size", "GrB_Vector_nvals"):
         getattr(L, name).argtypes = [P(c_u64), c_void_p]
     L.GrB_Matrix_wait.argtypes = [c_void_p, c_int]

@@ -786,3 +786,34 @@ extern "C" GrB_Info GrB_vxm(GrB_Vector w, const GrB_Vector mask, const GrB_Binar
     }
     GRB_CATCH(errp(w))
 }
+
+// w<mask, replace> = accum(w, reduce of the rows of A with a monoid)  (reference Matrix.reduce_rowwise / reduce_columnwise,
+// core/matrix.py:2636-2710 -> GrB_Matrix_reduce_Monoid).  A row reduction is the pull SpMV over the semiring (monoid, FIRST)
+// with an operand that is present everywhere and never read: the kernels then stream A once and gather nothing.
+extern "C" GrB_Info GrB_Matrix_reduce_Monoid(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_Monoid monoid,
+                                             const GrB_Matrix A, const GrB_Descriptor desc)
+{
+    GRB_TRY
+    require_init();
+    check_vector(w, "w");
+    if (mask) check_vector(mask, "mask");
+    check_matrix(A, "A");
+    if (!monoid) fail(GrB_NULL_POINTER, "monoid is NULL");
+    DescFlags f = flags_of(desc);
+    GB_Matrix_opaque *S = f.t0 ? matrix_transpose_cached(A) : A;
+    f.t0 = false;
+    const GB_Semiring_opaque sr = {monoid->op, OP_FIRST, monoid->type, "reduce"};
+    GB_Vector_opaque *ones = vector_new(type_of_code(monoid->type), S->ncols);
+    // "full"; FIRST never reads its values and a full operand needs no presence lookups: token storage only
+    ones->d_val = dev_alloc(16);
+    ones->d_bits = (uint64_t *)dev_alloc(16);
+    ones->nvals = (int64_t)S->ncols;
+    try {
+        mxv_core(w, mask, accum, &sr, S, ones, /*flip=*/false, f);
+    } catch (...) {
+        vector_free(ones);
+        throw;
+    }
+    vector_free(ones);
+    GRB_CATCH(errp(w))
+}

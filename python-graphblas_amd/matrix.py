@@ -223,6 +223,12 @@ class Matrix(BaseType):
         """``C << A.mxm(B, semiring)``  (reference core/matrix.py:2264-2331 -> C ``GrB_mxm``)."""
         return _mxm(self, other, op)
 
+    def reduce_rowwise(self, op="plus"):
+        return _reduce_vector(self, op, "reduce_rowwise", False)
+
+    def reduce_columnwise(self, op="plus"):
+        return _reduce_vector(self, op, "reduce_columnwise", True)
+
     def __matmul__(self, other):
         return InfixMatMul(self, other)
 
@@ -253,6 +259,12 @@ class TransposedMatrix:
     def mxm(self, other, op=_semiring.plus_times):
         return _mxm(self, other, op)
 
+    def reduce_rowwise(self, op="plus"):
+        return _reduce_vector(self, op, "reduce_rowwise", False)
+
+    def reduce_columnwise(self, op="plus"):
+        return _reduce_vector(self, op, "reduce_columnwise", True)
+
     def __matmul__(self, other):
         return InfixMatMul(self, other)
 
@@ -260,6 +272,22 @@ class TransposedMatrix:
         C = Matrix(dtype or self.dtype, self._nrows, self._ncols, name=name)
         call("GrB_transpose", [C, None, None, self._matrix, None])
         return C
+
+
+def _reduce_vector(A, op, method_name, transpose):
+    """``w << A.reduce_rowwise(monoid)`` / ``reduce_columnwise`` (reference core/matrix.py:2636-2710 -> ``GrB_Matrix_reduce_Monoid``;
+    column-wise = row-wise over the transpose, descriptor T0)."""
+    from .operators import monoid as _monoid_ns
+
+    op = get_typed_op(op, A.dtype, kind="binary")
+    if op.opclass == "BinaryOp":
+        if not hasattr(_monoid_ns, op.name):
+            raise TypeError(f"Expected type: Monoid; got BinaryOp `{op!r}`")
+        op = getattr(_monoid_ns, op.name)[A.dtype]
+    at = A._is_transposed != transpose
+    base = A._matrix
+    out_size = base._ncols if at else base._nrows
+    return Expression(method_name, "GrB_Matrix_reduce_Monoid", [base], op=op, output_type=Vector, shape=(out_size,), at=at)
 
 
 def _mxv(A, v, op):

@@ -209,3 +209,27 @@ def test_mxm_rmat_vs_scipy(gb, scale):
     Mp, Mj, Mx = M.to_csr()
     assert np.array_equal(Mp.astype(np.int64), exp.indptr) and np.array_equal(Mj.astype(np.int64), exp.indices)
     assert np.array_equal(Mx, exp.values)
+
+
+@pytest.mark.gpu
+def test_reduce_rowwise_is_the_degree_vector(gb):
+    """A.reduce_rowwise(plus) over an iso-ones R-MAT matrix = the out-degrees, reduce_columnwise = the in-degrees (scale 18):
+    the pull SpMV over (plus, first) with an operand that is never read."""
+    import torch
+
+    from graphblas_amd import device, synthetic
+
+    scale = 18
+    n = 1 << scale
+    indptr, col = synthetic.rmat_csr(scale, device="cuda")
+    one = torch.ones(1, dtype=torch.int64, device="cuda")
+    A = device.matrix_from_device_csr(indptr, col, one, n, n, "INT64", iso=True)
+    out_deg = (indptr[1:] - indptr[:-1]).cpu().numpy()
+    in_deg = torch.bincount(col.long(), minlength=n).cpu().numpy()
+    w = A.reduce_rowwise(gb.monoid.plus).new()
+    i, x = w.to_coo()
+    assert np.array_equal(i.astype(np.int64), np.flatnonzero(out_deg)) and np.array_equal(x, out_deg[out_deg > 0])
+    w = A.reduce_columnwise(gb.monoid.plus).new()
+    i, x = w.to_coo()
+    assert np.array_equal(i.astype(np.int64), np.flatnonzero(in_deg)) and np.array_equal(x, in_deg[in_deg > 0])
+    assert w.reduce(gb.monoid.plus).new() == int(col.numel())

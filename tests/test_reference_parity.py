@@ -538,3 +538,25 @@ def test_comparisons_and_isequal_on_device(gb, v):
     assert f.isequal(gb.Vector.from_coo([0, 2], [1.5, float("inf")]))
     with pytest.raises(Exception):
         v(accum=gb.binary.eq) << v.ewise_mult(v2, gb.binary.plus)  # a comparison is not an accumulator
+
+
+def test_reduce_rowwise_columnwise(gb, A):
+    # graphblas/tests/test_matrix.py:1355-1360, 1648-1653
+    result = gb.Vector.from_coo([0, 1, 2, 3, 4, 5, 6], [5, 12, 1, 6, 7, 1, 15])
+    assert A.reduce_rowwise(gb.monoid.plus).new().isequal(result)
+    assert A.reduce_rowwise(gb.binary.plus).new().isequal(result)
+    assert A.T.reduce_columnwise(gb.monoid.plus).new().isequal(result)
+    result = gb.Vector.from_coo([0, 1, 2, 3, 4, 5, 6], [3, 2, 9, 10, 11, 8, 4])
+    assert A.reduce_columnwise(gb.monoid.plus).new().isequal(result)
+    assert A.T.reduce_rowwise(gb.binary.plus).new().isequal(result)
+    with pytest.raises(TypeError, match="Expected type: Monoid"):
+        A.reduce_rowwise(gb.binary.minus)
+    # max / min and a masked, accumulated form
+    I, J, X = A.to_coo()
+    dense = np.full((7, 7), -1)
+    dense[I.astype(int), J.astype(int)] = X
+    assert A.reduce_rowwise(gb.monoid.max).new().to_coo()[1].tolist() == dense.max(axis=1).tolist()
+    w = gb.Vector.from_coo([0, 1, 2], [100, 100, 100], size=7)
+    m = gb.Vector.from_coo([0, 2, 4], [True, True, True], size=7)
+    w(m.S, accum=gb.binary.plus) << A.reduce_rowwise(gb.monoid.plus)
+    assert [x.tolist() for x in w.to_coo()] == [[0, 1, 2, 4], [105, 100, 101, 7]]
