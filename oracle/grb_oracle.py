@@ -397,5 +397,33 @@ def vec_reduce(u: OVec, monoid: str):
     raise NotImplementedError(monoid)
 
 
+def vec_ewise(u: OVec, v: OVec, binop: str, *, union: bool) -> OVec:
+    """T = u (op) v on the union (eWiseAdd: single entries pass through) or the intersection (eWiseMult) of the patterns, in
+    the unified type (GraphBLAS C API 2.0 eWiseAdd / eWiseMult; reference core/vector.py:960-1150)."""
+    if u.size != v.size:
+        raise ValueError("DimensionMismatch")
+    t = unify(u.tname, v.tname)
+    hu, du = u.dense(t)
+    hv, dv = v.dense(t)
+    hu, hv = hu.astype(bool), hv.astype(bool)
+    f = {"plus": np.add, "times": np.multiply, "min": np.minimum, "max": np.maximum, "minus": np.subtract,
+         "first": lambda a, b: a, "second": lambda a, b: b, "lor": np.logical_or, "land": np.logical_and,
+         "lxor": np.logical_xor}[binop]
+    with np.errstate(over="ignore"):
+        both = np.asarray(f(du, dv)).astype(NP_OF[t])
+    has = (hu | hv) if union else (hu & hv)
+    val = np.where(hu & hv, both, np.where(hu, du, dv)).astype(NP_OF[t])
+    return OVec.from_dense(has.astype(np.uint8), val, t)
+
+
+def mat_reduce_rows(A: OMat, monoid: str, *, columns=False) -> OVec:
+    """w(i) = fold of row i of A with the monoid (rows without entries stay empty) -- GrB_Matrix_reduce_Monoid; as the
+    library does, stated as the mxv over (monoid, first) with a full operand."""
+    if columns:
+        A = A.transpose()
+    ones = OVec(A.ncols, np.arange(A.ncols), np.ones(A.ncols, NP_OF[A.tname]), A.tname)
+    return mxv(A, ones, f"{monoid}_first")
+
+
 def num_threads() -> int:
     return int(lib().grbo_num_threads())

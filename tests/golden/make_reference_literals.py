@@ -150,8 +150,35 @@ sssp = {"name": "primer_sssp", "cite": "docs/getting_started/primer.rst:221-251"
         "start": {"kind": "vector", "dtype": "FP64", "size": 4, "idx": [0], "vals": [0.0]},
         "expect": V([0, 1, 2, 3], [0.0, 2.0, 3.5, 4.0], 4, "FP64")}
 
+# The vector operations around the path: literals of the reference's own tests
+vector_ops = [
+    {"name": "assign_scalar_mask_V", "cite": "graphblas/tests/test_vector.py:544-555", "op": "assign_scalar", "w": "v7",
+     "value": 5, "mask": V([1, 2, 5, 6], [0, 0, 1, 0]), "expect": V([1, 3, 4, 5, 6], [1, 1, 2, 5, 0])},
+    {"name": "assign_scalar_mask_compV", "cite": "graphblas/tests/test_vector.py:556-562", "op": "assign_scalar", "w": "v7",
+     "value": 5, "mask": V([1, 2, 5, 6], [0, 0, 1, 0]), "mask_comp": True, "expect": V([0, 1, 2, 3, 4, 6], [5, 5, 5, 5, 5, 5])},
+    {"name": "assign_scalar_all", "cite": "graphblas/tests/test_vector.py:528-533", "op": "assign_scalar",
+     "w": V([0, 1, 2], [1, 1, 1], 3), "value": 9, "expect": V([0, 1, 2], [9, 9, 9], 3)},
+    {"name": "assign_scalar_with_mask", "cite": "graphblas/tests/test_vector.py:616-628", "op": "assign_scalar",
+     "w": V([0, 1, 2], [1, 2, 3], 3), "value": 100, "mask": V([0, 2], [False, True], 3, "BOOL"),
+     "expect": V([0, 1, 2], [1, 2, 100], 3)},
+    {"name": "reduce_plus", "cite": "graphblas/tests/test_vector.py:866-870", "op": "reduce", "u": "v7", "monoid": "plus",
+     "expect_scalar": 4},
+    {"name": "ewise_mult_times", "cite": "graphblas/tests/test_vector.py:371-378", "op": "ewise_mult", "u": "v7",
+     "v": V([0, 3, 5, 6], [2, 3, 2, 1]), "binop": "times", "expect": V([3, 6], [3, 0])},
+    {"name": "ewise_add_max", "cite": "graphblas/tests/test_vector.py:402-411", "op": "ewise_add", "u": "v7",
+     "v": V([0, 3, 5, 6], [2, 3, 2, 1]), "binop": "max", "expect": V([0, 1, 3, 4, 5, 6], [2, 1, 3, 2, 2, 1])},
+    {"name": "reduce_rowwise_plus", "cite": "graphblas/tests/test_matrix.py:1355-1360", "op": "reduce_rowwise", "A": "A7",
+     "monoid": "plus", "expect": V([0, 1, 2, 3, 4, 5, 6], [5, 12, 1, 6, 7, 1, 15])},
+    {"name": "reduce_columnwise_plus", "cite": "graphblas/tests/test_matrix.py:1648-1653", "op": "reduce_columnwise", "A": "A7",
+     "monoid": "plus", "expect": V([0, 1, 2, 3, 4, 5, 6], [3, 2, 9, 10, 11, 8, 4])},
+    {"name": "resize_matrix", "cite": "graphblas/tests/test_matrix.py:193-206", "op": "resize", "A": "A7", "to": [4, 1],
+     "expect": M([3], [0], [3], 4, 1)},
+    {"name": "resize_vector", "cite": "graphblas/tests/test_vector.py:182-191", "op": "resize", "w": "v7", "to": [4],
+     "expect": V([1, 3], [1, 1], 4)},
+]
+
 if __name__ == "__main__":
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_literals.json")
     with open(out, "w") as f:
-        json.dump({"inputs": inputs, "cases": cases, "sssp": sssp}, f, indent=1)
-    print("wrote", out, len(cases), "cases")
+        json.dump({"inputs": inputs, "cases": cases, "sssp": sssp, "vector_ops": vector_ops}, f, indent=1)
+    print("wrote", out, len(cases), "cases +", len(vector_ops), "vector-operation cases")

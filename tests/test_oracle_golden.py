@@ -23,6 +23,38 @@ def test_reference_literal(case):
         same(got, case["expect"])
 
 
+@pytest.mark.parametrize("case", _G["vector_ops"], ids=[c["name"] for c in _G["vector_ops"]])
+def test_reference_literal_vector_ops(case):
+    """The operations around the path (assign, reduce, eWise, row reduce, resize): oracle vs the reference's literals."""
+    def get(x):
+        return o_obj(_G["inputs"][x] if isinstance(x, str) else x)
+
+    op = case["op"]
+    if op == "assign_scalar":
+        got = O.vec_assign_scalar(get(case["w"]), case["value"], mask=get(case["mask"]) if "mask" in case else None,
+                                  mask_comp=case.get("mask_comp", False))
+        same(got, case["expect"])
+    elif op == "reduce":
+        assert O.vec_reduce(get(case["u"]), case["monoid"]) == case["expect_scalar"]
+    elif op in ("ewise_mult", "ewise_add"):
+        same(O.vec_ewise(get(case["u"]), get(case["v"]), case["binop"], union=op == "ewise_add"), case["expect"])
+    elif op in ("reduce_rowwise", "reduce_columnwise"):
+        same(O.mat_reduce_rows(get(case["A"]), case["monoid"], columns=op == "reduce_columnwise"), case["expect"])
+    elif op == "resize":
+        src = get(case["A"] if "A" in case else case["w"])
+        if "A" in case:
+            nr, nc = case["to"]
+            r = np.repeat(np.arange(src.nrows), np.diff(src.indptr))
+            keep = (r < nr) & (src.indices < nc)
+            got = O.OMat.from_coo(r[keep], src.indices[keep], src.values[keep], nr, nc, src.tname)
+        else:
+            keep = src.idx < case["to"][0]
+            got = O.OVec(case["to"][0], src.idx[keep], src.vals[keep], src.tname)
+        same(got, case["expect"])
+    else:
+        raise AssertionError(op)
+
+
 def test_primer_sssp():
     s = _G["sssp"]
     G = o_obj(_G["inputs"][s["G"]])
