@@ -217,7 +217,10 @@ __global__ void k_mask_bits(const uint64_t *bits, const T *val, int64_t n, uint6
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // blockDim is a multiple of 64
     bool p = false;
-    if (i < n) p = ((bits[i >> 6] >> (i & 63)) & 1ull) && (val[i] != (T)0);
+    if (i < n) {
+        const uint64_t w = bits[i >> 6];  // (wave-uniform: an empty presence word -- most of a sparse frontier -- loads no values)
+        if (w) p = ((w >> (i & 63)) & 1ull) && (val[i] != (T)0);
+    }
     unsigned long long b = __ballot(p);
     if ((threadIdx.x & 63) == 0 && (i >> 6) < (int64_t)((n + 63) / 64)) out[i >> 6] = b;
 }
