@@ -14,7 +14,7 @@ syntax ``C(mask, accum, replace) << A.mxm(B, semiring)`` documented at
 from . import _lib, descriptor, dtypes, exceptions
 from .base import _replace_singleton as replace
 from .base import record_calls
-from .operators import binary, monoid, op, semiring
+from .operators import agg, binary, monoid, op, semiring
 
 _initialized = False
 backend = "mi355x"
@@ -45,4 +45,4 @@ from .matrix import Matrix, TransposedMatrix  # noqa: E402
 from .vector import Vector  # noqa: E402
 from .base import Scalar  # noqa: E402
 
-__all__ = ["init", "Matrix", "Vector", "Scalar", "semiring", "binary", "monoid", "op", "dtypes", "replace", "exceptions"]
+__all__ = ["init", "Matrix", "Vector", "Scalar", "semiring", "binary", "monoid", "op", "agg", "dtypes", "replace", "exceptions"]

@@ -173,6 +173,21 @@ class BaseType:
         if isinstance(expr, Scalar) or _is_python_scalar(expr):
             # ``w(mask) << 5``: scalar assign over every index (reference core/base.py:352-372 -> Updater[...] << scalar)
             return self._assign_scalar_all(expr, mask=mask, accum=accum, replace=replace, opts=opts)
+        if self._grb_kind == "Matrix":
+            from .matrix import PowerCopy, PowerExpression, _power
+
+            if isinstance(expr, PowerExpression):
+                # evaluated by repeated squaring; (mask, accum, replace) apply to the last product (reference core/matrix.py:99-155)
+                return _power(Updater(self, mask=mask, accum=accum, replace=replace, opts=opts), expr.A, expr.n, expr.op)
+            if isinstance(expr, PowerCopy):
+                complement = structure = False
+                if mask is not None:
+                    mask = _check_mask(mask, self)
+                    complement, structure = mask.complement, mask.structure
+                src = expr.matrix  # (A.T.power(1) is a real transpose: no T0)
+                desc = descriptor_lookup(transpose_first=not src._is_transposed, mask_complement=complement,
+                                         mask_structure=structure, output_replace=replace, **opts)
+                return call("GrB_transpose", [self, mask, accum, src._matrix, desc])
         if not isinstance(expr, Expression):
             raise TypeError(f"Assignment value must be a valid expression; got {type(expr).__name__}")
         if type(self) is not expr.output_type:

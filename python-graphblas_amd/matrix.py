@@ -11,6 +11,7 @@ import numpy as np
 from . import _lib
 from .base import BaseType, Expression, InfixMatMul, call, call_on
 from .dtypes import lookup_dtype
+from .exceptions import DimensionMismatch
 from .operators import get_typed_op, semiring as _semiring
 from .vector import Vector, _name_counter, _ptr
 
@@ -229,6 +230,10 @@ class Matrix(BaseType):
     def reduce_columnwise(self, op="plus"):
         return _reduce_vector(self, op, "reduce_columnwise", True)
 
+    def power(self, n, op=_semiring.plus_times):
+        """``C << A.power(n, semiring)`` by repeated squaring (reference core/matrix.py:2840-2905)."""
+        return _matrix_power(self, n, op)
+
     def __matmul__(self, other):
         return InfixMatMul(self, other)
 
@@ -265,6 +270,9 @@ class TransposedMatrix:
     def reduce_columnwise(self, op="plus"):
         return _reduce_vector(self, op, "reduce_columnwise", True)
 
+    def power(self, n, op=_semiring.plus_times):
+        return _matrix_power(self, n, op)
+
     def __matmul__(self, other):
         return InfixMatMul(self, other)
 
@@ -276,18 +284,117 @@ class TransposedMatrix:
 
 def _reduce_vector(A, op, method_name, transpose):
     """``w << A.reduce_rowwise(monoid)`` / ``reduce_columnwise`` (reference core/matrix.py:2636-2710 -> ``GrB_Matrix_reduce_Monoid``;
-    column-wise = row-wise over the transpose, descriptor T0)."""
+    column-wise = row-wise over the transpose, descriptor T0).  An aggregator is either its monoid or, for ``count`` /
+    ``exists``, the mat-vec ``semiring(A @ init)`` with a dense iso vector (reference core/operator/agg.py:264-283)."""
+    from .operators import Aggregator
     from .operators import monoid as _monoid_ns
 
+    at = A._is_transposed != transpose
+    base = A._matrix
+    if isinstance(op, Aggregator):
+        if op.semiring is not None:
+            view = base.T if at else base
+            init = Vector(op.any_dtype, view._ncols, name="init")
+            init[:] = 1
+            expr = _mxv(view, init, op.semiring[op.any_dtype])
+            expr.method_name = method_name
+            return expr
+        op = op.monoid
     op = get_typed_op(op, A.dtype, kind="binary")
     if op.opclass == "BinaryOp":
         if not hasattr(_monoid_ns, op.name):
             raise TypeError(f"Expected type: Monoid; got BinaryOp `{op!r}`")
         op = getattr(_monoid_ns, op.name)[A.dtype]
-    at = A._is_transposed != transpose
-    base = A._matrix
     out_size = base._ncols if at else base._nrows
     return Expression(method_name, "GrB_Matrix_reduce_Monoid", [base], op=op, output_type=Vector, shape=(out_size,), at=at)
+
+
+def _power(updater, A, n, op):
+    """Repeated squaring over the mxm path (reference core/matrix.py:99-155): A^2, A^4, ... are formed in ``square`` and
+    multiplied into ``result`` for each set bit of ``n``; the last product goes through the caller's updater so that its
+    mask / accum / replace apply to the final multiplication only."""
+    opts = updater.opts
+    if n == 0:
+        ident = op.parent.binaryop.monoid.identity(A.dtype)
+        idx = np.arange(A._nrows, dtype=np.uint64)
+        D = Matrix.from_coo(idx, idx, np.full(A._nrows, ident), dtype=A.dtype, nrows=A._nrows, ncols=A._ncols, name="M_diag")
+        updater << PowerCopy(D)
+        return
+    if n == 1:
+        updater << PowerCopy(A)
+        return
+    result = square = None  # square = A^(2^k) once k >= 1; result = product of the squares of the bits seen so far
+    owned = False           # result is a matrix of ours (not A itself)
+    k = 0
+    while True:
+        n, bit = divmod(n, 2)
+        if k:
+            src = A if square is None else square
+            squaring = _mxm(src, src, op)
+            if n == 0 and result is None:  # n was a power of two: the last squaring is the answer
+                updater << squaring
+                return
+            if square is None:
+                square = squaring.new(name="Squares", **opts)
+            else:
+                square(**opts) << squaring
+        k += 1
+        if not bit:
+            continue
+        cur = A if square is None else square
+        if result is None:
+            result, owned = (A, False) if square is None else (square.dup(name="Power"), True)
+        elif n == 0:
+            updater << _mxm(result, cur, op)
+            return
+        elif not owned:
+            result, owned = _mxm(result, cur, op).new(name="Power", **opts), True
+        else:
+            result(**opts) << _mxm(result, cur, op)
+
+
+class PowerCopy:
+    """``C << A`` for the degenerate powers (n = 0, 1): a copy through ``GrB_transpose`` with descriptor T0."""
+
+    def __init__(self, matrix):
+        self.matrix = matrix
+
+
+class PowerExpression:
+    """``A.power(n, op)`` (reference core/matrix.py:2840-2905): evaluated by ``_power`` when assigned."""
+
+    def __init__(self, A, n, op):
+        self.A, self.n, self.op = A, n, op
+        self.shape = (A._nrows, A._ncols)
+        self.dtype = op.return_type
+
+    def new(self, dtype=None, *, mask=None, name=None, **opts):
+        out = Matrix(dtype or self.dtype, *self.shape, name=name)
+        if mask is None:
+            out(**opts) << self
+        else:
+            out(mask=mask, **opts) << self
+        return out
+
+
+def _matrix_power(A, n, op):
+    from numbers import Integral
+
+    if A._nrows != A._ncols:
+        raise DimensionMismatch(f"power only works for square Matrix; shape is {A.shape}")
+    if isinstance(n, bool) or not (isinstance(n, (Integral, np.integer)) or (isinstance(n, float) and n.is_integer())):
+        raise TypeError(f"n must be a nonnegative integer; got bad type: {type(n)}")
+    N = int(n)
+    if N < 0:
+        raise ValueError(f"n must be a nonnegative integer; got: {N}")
+    op = get_typed_op(op, A.dtype, kind="semiring")
+    if N == 0 and op.parent.binaryop.monoid is None:
+        raise ValueError(
+            f"Binary operator of {op} semiring does not have a monoid with an identity. "
+            "When n=0, the result is a diagonal matrix with values equal to the "
+            "identity of the binaryop, so the binaryop must be associated with a monoid."
+        )
+    return PowerExpression(A, N, op)
 
 
 def _mxv(A, v, op):

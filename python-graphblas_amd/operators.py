@@ -5,8 +5,10 @@ Mirrors, for the builtin operators on the mxm/mxv/vxm path only, the reference's
 (core/operator/utils.py:60-157), handle naming (core/operator/semiring.py:185-219: ``GrB_<MONOID>_
 <BINARY>_SEMIRING_<TYPE>`` / ``GxB_<MONOID>_<BINARY>_<TYPE>``), BOOL coercions
 (semiring.py:538-548, 568-587) and string spellings such as ``"min_plus"`` / ``"+"``
-(tests/test_vector.py:362-368, docs/user_guide/operations.rst:44).  User-defined functions, UDTs,
-aggregators and positional ops need a JIT and are outside the path.
+(tests/test_vector.py:362-368, docs/user_guide/operations.rst:44).  Of the aggregators, the ones that are a monoid
+reduction or one semiring mat-vec (``agg.sum/prod/min/max/all/any/any_value/count/exists``, core/operator/agg.py:356-378) are
+here; user-defined functions, UDTs, composite aggregators and positional ops need a JIT and are outside the path
+(SURVEY.md section 2 #6).
 """
 from __future__ import annotations
 
@@ -101,6 +103,11 @@ class BinaryOp(_OpBase):
             return [f"GrB_{n}", f"GxB_{n}_{t}"]
         return [f"GrB_{n}_{t}", f"GxB_{n}_{t}"]
 
+    @property
+    def monoid(self):
+        """The monoid built on this operator, or None (reference: ``BinaryOp.monoid``, core/operator/binary.py)."""
+        return getattr(monoid, self.name, None)
+
 
 class Monoid(_OpBase):
     opclass = "Monoid"
@@ -116,6 +123,38 @@ class Monoid(_OpBase):
     @property
     def binaryop(self):
         return getattr(binary, self.name)
+
+    def identity(self, dtype):
+        """The monoid's identity as a numpy scalar of ``dtype`` (reference: ``TypedBuiltinMonoid.identity``,
+        core/operator/monoid.py:34-60)."""
+        import numpy as np
+
+        dtype = self._coerce(lookup_dtype(dtype))
+        t = dtype.np_type
+        name = _canon(self.name, dtype)
+        if name in ("plus", "lor", "lxor", "any"):
+            return t.type(0)
+        if name in ("times", "land", "lxnor"):
+            return t.type(1)
+        if name not in ("min", "max"):
+            raise ValueError(f"{self!r} has no identity for {dtype}")
+        if np.issubdtype(t, np.floating):
+            return t.type(np.inf if name == "min" else -np.inf)
+        info = np.iinfo(t)
+        return t.type(info.max if name == "min" else info.min)
+
+
+class Aggregator:
+    """The aggregators that are one monoid reduction or one semiring mat-vec with a dense iso vector
+    (reference core/operator/agg.py:264-283 builds ``semiring(A @ init)``; the table at :356-378 names them)."""
+
+    opclass = "Aggregator"
+
+    def __init__(self, name, *, monoid=None, semiring=None, any_dtype=None):
+        self.name, self.monoid, self.semiring, self.any_dtype = name, monoid, semiring, any_dtype
+
+    def __repr__(self):
+        return f"agg.{self.name}"
 
 
 class Semiring(_OpBase):
@@ -159,6 +198,7 @@ binary = _Namespace("binary")
 monoid = _Namespace("monoid")
 semiring = _Namespace("semiring")
 op = _Namespace("op")
+agg = _Namespace("agg")
 
 for _n in _BINARY_NAMES:
     setattr(binary, _n, BinaryOp(_n))
@@ -172,6 +212,15 @@ for _m in _MONOID_NAMES:
         _s = Semiring(f"{_m}_{_b}", getattr(monoid, _m), getattr(binary, _b))
         setattr(semiring, _s.name, _s)
         setattr(op, _s.name, _s)
+
+
+from .dtypes import INT64 as _INT64  # noqa: E402
+
+for _a, _m in [("sum", "plus"), ("prod", "times"), ("all", "land"), ("any", "lor"), ("min", "min"), ("max", "max"),
+               ("any_value", "any")]:
+    setattr(agg, _a, Aggregator(_a, monoid=getattr(monoid, _m)))
+agg.count = Aggregator("count", semiring=semiring.plus_pair, any_dtype=_INT64)
+agg.exists = Aggregator("exists", semiring=semiring.any_pair, any_dtype=_INT64)
 
 
 def _from_string(string, kind):

@@ -243,7 +243,23 @@ class Vector(BaseType):
 
     def reduce(self, op=_monoid.plus, *, allow_empty=True):
         """``s << v.reduce(monoid)`` (reference core/vector.py:1635-1684).  ``allow_empty=False``: an empty vector gives the
-        monoid identity instead of an empty scalar."""
+        monoid identity instead of an empty scalar.  Aggregators: the monoid ones reduce with their monoid; ``agg.count`` and
+        ``agg.exists`` are the plus_pair / any_pair products with a dense iso operand (reference core/operator/agg.py:284-303),
+        i.e. the number of entries and whether there is one."""
+        from .operators import Aggregator
+
+        if isinstance(op, Aggregator):
+            if op.semiring is not None:
+                count = op.name == "count"
+
+                def compute_agg():
+                    nv = self.nvals
+                    if nv == 0 and (allow_empty or not count):
+                        return None if allow_empty else 0
+                    return int(nv) if count else 1
+
+                return ScalarExpression(compute_agg, op.any_dtype)
+            op = op.monoid
         op = get_typed_op(op, self.dtype, kind="binary")
         if op.opclass == "BinaryOp":
             if not hasattr(_monoid, op.name):

@@ -233,3 +233,44 @@ def test_reduce_rowwise_is_the_degree_vector(gb):
     i, x = w.to_coo()
     assert np.array_equal(i.astype(np.int64), np.flatnonzero(in_deg)) and np.array_equal(x, in_deg[in_deg > 0])
     assert w.reduce(gb.monoid.plus).new() == int(col.numel())
+
+
+@pytest.mark.gpu
+def test_count_aggregator_and_power_at_scale(gb):
+    """``agg.count`` (the plus_pair mat-vec with a dense iso operand) = the degree vectors at scale 18; ``A.power(5)`` over
+    plus_times INT64 on a scale-9 R-MAT graph against scipy's repeated product (integer, bit-exact)."""
+    sp = pytest.importorskip("scipy.sparse")
+    import torch
+
+    from graphblas_amd import device, synthetic
+
+    scale = 18
+    n = 1 << scale
+    indptr, col = synthetic.rmat_csr(scale, device="cuda")
+    w8 = torch.randint(1, 200, (col.numel(),), dtype=torch.float32, device="cuda")
+    A = device.matrix_from_device_csr(indptr, col, w8, n, n, "FP32")
+    out_deg = (indptr[1:] - indptr[:-1]).cpu().numpy()
+    in_deg = torch.bincount(col.long(), minlength=n).cpu().numpy()
+    w = A.reduce_rowwise(gb.agg.count).new()
+    assert w.dtype == gb.dtypes.INT64
+    i, x = w.to_coo()
+    assert np.array_equal(i.astype(np.int64), np.flatnonzero(out_deg)) and np.array_equal(x, out_deg[out_deg > 0])
+    i, x = A.reduce_columnwise(gb.agg.count).new().to_coo()
+    assert np.array_equal(i.astype(np.int64), np.flatnonzero(in_deg)) and np.array_equal(x, in_deg[in_deg > 0])
+    i, x = A.reduce_columnwise(gb.agg.exists).new().to_coo()
+    assert np.array_equal(i.astype(np.int64), np.flatnonzero(in_deg)) and np.all(x == 1)
+
+    scale = 9
+    n = 1 << scale
+    indptr, col = synthetic.rmat_csr(scale, device="cuda")
+    one = torch.ones(1, dtype=torch.int64, device="cuda")
+    B = device.matrix_from_device_csr(indptr, col, one, n, n, "INT64", iso=True)
+    ip, cj = indptr.cpu().numpy(), col.cpu().numpy()
+    S = sp.csr_matrix((np.ones(cj.size, np.int64), cj, ip), shape=(n, n))
+    ref = S
+    for _ in range(4):
+        ref = (ref @ S).tocsr()
+    ref.sort_indices()
+    Cp, Cj, Cx = B.power(5).new().to_csr()
+    assert np.array_equal(Cp.astype(np.int64), ref.indptr) and np.array_equal(Cj.astype(np.int64), ref.indices)
+    assert np.array_equal(Cx, ref.data)

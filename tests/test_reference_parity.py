@@ -560,3 +560,96 @@ def test_reduce_rowwise_columnwise(gb, A):
     m = gb.Vector.from_coo([0, 2, 4], [True, True, True], size=7)
     w(m.S, accum=gb.binary.plus) << A.reduce_rowwise(gb.monoid.plus)
     assert [x.tolist() for x in w.to_coo()] == [[0, 1, 2, 4], [105, 100, 101, 7]]
+
+
+def test_reduce_agg(gb, A):
+    # graphblas/tests/test_matrix.py:1364-1417 (the aggregators that are a monoid or one semiring mat-vec)
+    result = gb.Vector.from_coo([0, 1, 2, 3, 4, 5, 6], [5, 12, 1, 6, 7, 1, 15])
+    assert A.reduce_rowwise(gb.agg.sum).new().isequal(result)
+    assert A.T.reduce_columnwise(gb.agg.sum).new().isequal(result)
+    counts = gb.Vector.from_coo([0, 1, 2, 3, 4, 5, 6], [2, 2, 1, 2, 1, 1, 3])  # (= A.dup(bool).reduce_rowwise(plus[int]))
+    w3 = A.reduce_rowwise(gb.agg.count).new()
+    assert w3.dtype == gb.dtypes.INT64
+    assert w3.isequal(counts)
+    assert A.T.reduce_columnwise(gb.agg.count).new().isequal(counts)
+    result = gb.Vector.from_coo([0, 1, 2, 3, 4, 5, 6], [3, 2, 9, 10, 11, 8, 4])
+    assert A.reduce_columnwise(gb.agg.sum).new().isequal(result)
+    assert A.T.reduce_rowwise(gb.agg.sum).new().isequal(result)
+    counts = gb.Vector.from_coo([0, 1, 2, 3, 4, 5, 6], [1, 1, 3, 2, 2, 2, 1])
+    assert A.reduce_columnwise(gb.agg.count).new().isequal(counts)
+    assert A.T.reduce_rowwise(gb.agg.count).new().isequal(counts)
+    expected = gb.Vector.from_coo([0, 1, 2, 3, 4, 5, 6], [1, 1, 1, 1, 1, 1, 1])
+    assert A.reduce_rowwise(gb.agg.exists).new().isequal(expected)
+    assert A.reduce_columnwise(gb.agg.exists).new().isequal(expected)
+    # rows without entries get no count (the product has no entry there)
+    B = gb.Matrix.from_coo([0, 0, 3], [1, 2, 0], [1.5, 2.5, 3.5], nrows=5, ncols=4)
+    assert B.reduce_rowwise(gb.agg.count).new().isequal(gb.Vector.from_coo([0, 3], [2, 1], size=5))
+    assert B.reduce_columnwise(gb.agg.min).new().isequal(gb.Vector.from_coo([0, 1, 2], [3.5, 1.5, 2.5], size=4))
+
+
+def test_vector_reduce_agg(gb, v):
+    # graphblas/tests/test_vector.py:1033-1060 (the same subset)
+    s = gb.Scalar(int)
+    s << v.reduce(gb.agg.sum)
+    assert s == 4
+    s << v.reduce(gb.agg.count)
+    assert s == 4
+    s << v.reduce(gb.agg.exists)
+    assert s == 1
+    s << v.reduce(gb.agg.max)
+    assert s == 2
+    empty = gb.Vector(int, size=3)
+    s << empty.reduce(gb.agg.count)
+    assert s.is_empty
+
+
+def test_power(gb, A):
+    # graphblas/tests/test_matrix.py:4379-4415
+    expected = A.dup()
+    for i in range(1, 50):
+        result = A.power(i).new()
+        assert result.isequal(expected), i
+        expected << A @ expected
+    expected = A.T.new()
+    for i in range(1, 10):
+        result = A.T.power(i).new()
+        assert result.isequal(expected), i
+        expected << A.T @ expected
+    expected = A.dup()
+    for i in range(1, 10):
+        result = A.power(i, gb.semiring.min_plus).new()
+        assert result.isequal(expected), i
+        expected << gb.semiring.min_plus(A @ expected)
+    result = A.power(0).new()
+    idx = list(range(7))
+    assert result.isequal(gb.Matrix.from_coo(idx, idx, [1] * 7))
+    result = A.power(0, gb.semiring.plus_min).new()
+    identity = gb.monoid.min.identity(A.dtype)
+    assert identity != 1
+    assert result.isequal(gb.Matrix.from_coo(idx, idx, [identity] * 7, dtype=A.dtype))
+    with pytest.raises(TypeError, match="must be a nonnegative integer"):
+        A.power(1.5)
+    with pytest.raises(ValueError, match="must be a nonnegative integer"):
+        A.power(-1)
+    with pytest.raises(ValueError, match="binaryop must be associated with a monoid"):
+        A.power(0, gb.semiring.min_first)
+    B = gb.Matrix.from_coo([0, 1], [2, 0], [1, 2], nrows=2, ncols=3)
+    with pytest.raises(gb.exceptions.DimensionMismatch):
+        B.power(2)
+
+
+def test_power_masked_final_product(gb, A):
+    # the updater's (mask, accum) apply to the last multiplication (reference core/matrix.py:99-155)
+    for n in (2, 3, 4, 5, 6, 7, 12):
+        C = A.dup()
+        C(A.S, gb.binary.plus) << A.power(n)
+        D = A.dup()
+        D(A.S, gb.binary.plus) << A.power(n - 1).new() @ A
+        assert C.isequal(D), n
+        C = A.dup()
+        C(~A.S, replace=True) << A.power(n, gb.semiring.min_plus)
+        D = A.dup()
+        D(~A.S, replace=True) << gb.semiring.min_plus(A.power(n - 1, gb.semiring.min_plus).new() @ A)
+        assert C.isequal(D), n
+    with pytest.raises(gb.exceptions.NotImplementedException):
+        C(A.S) << A.power(1)  # a masked copy is a Matrix assign: outside this library's path
