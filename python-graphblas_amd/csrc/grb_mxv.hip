@@ -361,6 +361,15 @@ static void launch_pull(GB_Matrix_opaque *A, PullArgs &a)
 static void pull_dispatch(GB_Matrix_opaque *A, int type, PullArgs &a)
 {
     const int mon = a.monoid, mul = a.mult;
+    if (mul == OP_PAIR && a.u_full && !(ctx().debug_flags & 65536)) {
+        GRB_DISPATCH_TYPE(type, T, {
+            const int64_t nthreads = (int64_t)bits_words64((uint64_t)a.m) * 64;
+            hipLaunchKernelGGL((k_mxv_rowlen<T>), dim3((unsigned)ceil_div(nthreads, 256)), dim3(256), 0, ctx().stream, a);
+        })
+        ctx().stats.kernel_launches += 1;
+        ctx().stats.method = 5;
+        return;
+    }
     // hot semirings get fully specialised kernels; everything else runs the runtime-operator kernel
 #define SPECIAL(TC, CT, MON, MUL)                                \
     if (type == TC && mon == MON && mul == MUL) {                \
@@ -415,10 +424,13 @@ static void mxv_core(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_Binar
     int mult = canonical_op(st, sr->mult);
     if (flip) mult = flip_op(mult);
 
-    // ---- operands in the semiring's type --------------------------------------------------------------
+    // ---- operands in the semiring's type (only the ones the multiply operator reads) ------------------------------------
+    bool need_aval = !(mult == OP_PAIR || mult == OP_SECOND) && S->nvals > 0;
+    const bool need_uval = !(mult == OP_PAIR || mult == OP_FIRST || mult == OP_ANY);
+    if (mult == OP_ANY) need_aval = S->nvals > 0;
     DevBuf<char> a_cast(0), u_cast(0);
     const void *aval = S->d_val;
-    if (S->nvals && S->type->code != st) {
+    if (need_aval && S->type->code != st) {
         const int64_t nv = S->iso ? 1 : S->nvals;
         dev_free(a_cast.p);
         a_cast.p = (char *)dev_alloc(type_size(st) * (size_t)nv);
@@ -427,7 +439,7 @@ static void mxv_core(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_Binar
     }
     vector_ensure_storage(u);
     const void *uval = u->d_val;
-    if (u->type->code != st) {
+    if (need_uval && u->type->code != st) {
         dev_free(u_cast.p);
         u_cast.p = (char *)dev_alloc(type_size(st) * (size_t)u->n);
         cast_array(st, u_cast.p, u->type->code, u->d_val, (int64_t)u->n);
@@ -460,9 +472,11 @@ static void mxv_core(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_Binar
     a.u_full = (u->nvals == (int64_t)u->n) ? 1 : 0;
     a.monoid = monoid;
     a.mult = mult;
-    a.need_aval = !(mult == OP_PAIR || mult == OP_SECOND) && S->nvals > 0;
-    a.need_uval = !(mult == OP_PAIR || mult == OP_FIRST || mult == OP_ANY);
-    if (mult == OP_ANY) a.need_aval = S->nvals > 0;
+    a.need_aval = need_aval;
+    a.need_uval = need_uval;
+    // PAIR over a full operand: every entry of a row contributes the same 1, so the product is a function of the row length
+    // alone (k_mxv_rowlen) -- the aggregators count / exists are this case (reference core/operator/agg.py:264-283, :360-378)
+    const bool by_rowlen = (mult == OP_PAIR && a.u_full && !(ctx().debug_flags & 65536));
     a.x_len = (int64_t)u->n;
     if ((uint64_t)u->n * type_size(st) >= 0xff000000ull)
         fail(GrB_NOT_IMPLEMENTED, "mxv/vxm: input vectors of 4 GiB or more are not supported by the pull kernel yet");
@@ -520,7 +534,7 @@ static void mxv_core(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_Binar
         }
     }
     // long/short row split (large matrices whose long rows hold a good share of the entries)
-    if (S->nvals && S->type->code == st) {
+    if (S->nvals && (S->type->code == st || !need_aval) && !by_rowlen) {
         const bool hot = (a.col == S->d_col_hot);
         ensure_split(S, a.col, hot);
         if (S->split_state == 1 && S->split_hot == hot) {

@@ -674,3 +674,60 @@ def test_vector_ewise_random(gb, seed):
     t_has = hu | hv
     t_val = np.where(hu & hv, both, np.where(hu, du, dv)).astype(np_t)
     same_vec(U, O.OVec.from_dense(t_has.astype(np.uint8), t_val, tname))
+
+
+@pytest.mark.parametrize("seed", range(18))
+def test_pair_over_full_operand(gb, seed):
+    """(monoid, PAIR) with a full operand is computed from the row lengths alone (GrX_Stats.method 5): every monoid, every
+    type, all mask forms / accumulators / replace, an output of another type, the output aliasing the operand -- against the
+    oracle, and against the general pull kernels (debug flag 65536 turns the shortcut off)."""
+    from graphblas_amd import _lib, device
+
+    rng = np.random.default_rng(4100 + seed)
+    tname = TYPES[seed % 7]
+    monoids = ["lor", "land", "lxor", "any"] if tname == "BOOL" else ["plus", "min", "max", "any", "times"]
+    sr = f"{monoids[seed % len(monoids)]}_pair"
+    if not hasattr(gb.semiring, sr) or tname not in getattr(gb.semiring, sr):
+        sr = "any_pair"
+    m, n = int(rng.integers(1, 2500)), int(rng.integers(1, 2500))
+    square = seed % 6 == 5
+    if square:
+        n = m
+    r, c, v = rand_coo(rng, m, n, tname, long_rows=int(rng.integers(0, 3)))
+    ui, uv = np.arange(n), rand_vals(rng, n, tname)
+    wname = tname if seed % 3 else ["INT64", "FP64", "INT32"][seed % 3]
+    wi, wv = rand_vec(rng, m, 0.4, wname)
+    mi, mv = rand_vec(rng, m, 0.5, "INT8")
+    use_mask = seed % 4 != 0
+    comp, struct, repl = (bool(x) for x in rng.integers(0, 2, 3))
+    accum = [None, "plus", "min", "second"][rng.integers(4)]
+    oa = O.OMat.from_coo(r, c, v, m, n, tname)
+    A = gb.Matrix.from_coo(r, c, v, dtype=tname, nrows=m, ncols=n)
+    kw = {}
+    if use_mask:
+        mk = gb.Vector.from_coo(mi, mv, dtype="INT8", size=m)
+        mm = mk.S if struct else mk.V
+        kw = dict(mask=~mm if comp else mm, replace=repl)
+    if accum:
+        kw["accum"] = accum
+    okw = dict(mask=O.OVec(m, mi, mv, "INT8") if use_mask else None, mask_comp=comp and use_mask, mask_struct=struct,
+               accum=accum, replace=repl and use_mask)
+    if square and wname == tname:  # w aliases u
+        exp = O.mxv(oa, O.OVec(n, ui, uv, tname), sr, w=O.OVec(n, ui, uv, tname), **okw)
+    else:
+        exp = O.mxv(oa, O.OVec(n, ui, uv, tname), sr, w=O.OVec(m, wi, wv, wname), **okw)
+    for flags in (0, 65536):
+        _lib.lib.GrX_option_set(b"debug_flags", flags)
+        try:
+            u = gb.Vector.from_coo(ui, uv, dtype=tname, size=n)
+            w = u if (square and wname == tname) else gb.Vector.from_coo(wi, wv, dtype=wname, size=m)
+            w(**kw) << A.mxv(u, getattr(gb.semiring, sr))
+            assert device.last_stats()["method"] == (5 if flags == 0 else 1)
+            same_vec(w, exp)
+            # vxm over the transpose view is the same product
+            w2 = gb.Vector.from_coo(wi, wv, dtype=wname, size=m) if not (square and wname == tname) else None
+            if w2 is not None:
+                w2(**kw) << u.vxm(A.T, getattr(gb.semiring, sr))
+                same_vec(w2, exp)
+        finally:
+            _lib.lib.GrX_option_set(b"debug_flags", 0)
