@@ -491,7 +491,8 @@ def test_long_short_row_split(gb, seed):
         w = gb.Vector.from_coo(wi, wv, dtype=tname, size=m)
         mk = gb.Vector.from_coo(mi, mv, dtype="BOOL", size=m)
         w(~mk.V if comp else mk.V, accum=accum, replace=bool(seed & 2)) << A.mxv(u, getattr(gb.semiring, sr))
-        assert device.last_stats()["kernel_launches"] >= 3  # init + long rows + short rows (with the write rule of every row)
+        st = device.last_stats()  # init + long rows + short rows (with the write rule of every row); PAIR over a full u reads no rows
+        assert st["kernel_launches"] >= 3 or st["method"] == 5
         same_vec(w, exp)
         x = gb.Vector.from_coo(xi, xv, dtype=tname, size=m)
         same_vec(x.vxm(A, getattr(gb.semiring, sr)).new(), exp_t)
