@@ -230,6 +230,12 @@ class Matrix(BaseType):
     def reduce_columnwise(self, op="plus"):
         return _reduce_vector(self, op, "reduce_columnwise", True)
 
+    def reduce_scalar(self, op="plus", *, allow_empty=True):
+        """``s << A.reduce_scalar(monoid)`` (reference core/matrix.py:2712-2770): here the row reduction on the pull SpMV path
+        followed by the vector reduction -- Matrix -> Vector -> Scalar, as the reference's aggregators do (core/operator/agg.py:
+        304-330); ``agg.count`` / ``agg.exists`` are the number of entries / whether there is one."""
+        return _reduce_scalar(self, op, allow_empty)
+
     def power(self, n, op=_semiring.plus_times):
         """``C << A.power(n, semiring)`` by repeated squaring (reference core/matrix.py:2840-2905)."""
         return _matrix_power(self, n, op)
@@ -270,6 +276,9 @@ class TransposedMatrix:
     def reduce_columnwise(self, op="plus"):
         return _reduce_vector(self, op, "reduce_columnwise", True)
 
+    def reduce_scalar(self, op="plus", *, allow_empty=True):
+        return _reduce_scalar(self, op, allow_empty)
+
     def power(self, n, op=_semiring.plus_times):
         return _matrix_power(self, n, op)
 
@@ -307,6 +316,30 @@ def _reduce_vector(A, op, method_name, transpose):
         op = getattr(_monoid_ns, op.name)[A.dtype]
     out_size = base._ncols if at else base._nrows
     return Expression(method_name, "GrB_Matrix_reduce_Monoid", [base], op=op, output_type=Vector, shape=(out_size,), at=at)
+
+
+def _reduce_scalar(A, op, allow_empty):
+    from .base import ScalarExpression
+    from .operators import Aggregator
+
+    base = A._matrix
+    if isinstance(op, Aggregator) and op.semiring is not None:
+        count = op.name == "count"
+
+        def compute_agg():
+            nv = base.nvals
+            if nv == 0 and (allow_empty or not count):
+                return None if allow_empty else 0
+            return int(nv) if count else 1
+
+        return ScalarExpression(compute_agg, op.any_dtype)
+    mon = op.monoid if isinstance(op, Aggregator) else op
+    rows = _reduce_vector(base, mon, "reduce_scalar", False)
+
+    def compute():
+        return rows.new().reduce(mon, allow_empty=allow_empty).value
+
+    return ScalarExpression(compute, rows.dtype)
 
 
 def _power(updater, A, n, op):

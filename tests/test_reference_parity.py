@@ -587,6 +587,21 @@ def test_reduce_agg(gb, A):
     assert B.reduce_columnwise(gb.agg.min).new().isequal(gb.Vector.from_coo([0, 1, 2], [3.5, 1.5, 2.5], size=4))
 
 
+def test_reduce_scalar(gb, A):
+    # graphblas/tests/test_matrix.py:1419-1429 (monoid and count / exists aggregators), :1448-1451 (empty)
+    assert A.reduce_scalar(gb.agg.sum).new() == 47
+    assert A.reduce_scalar(gb.monoid.plus).new() == 47
+    assert A.reduce_scalar().new() == 47
+    assert A.T.reduce_scalar(gb.agg.prod).new() == 1270080
+    assert A.reduce_scalar(gb.agg.count).new() == 12
+    assert A.reduce_scalar(gb.agg.exists).new() == 1
+    assert A.reduce_scalar(gb.agg.min).new() == 1
+    assert A.reduce_scalar(gb.agg.max).new() == 8
+    B = gb.Matrix(int, 3, 4)
+    assert B.reduce_scalar(gb.agg.sum, allow_empty=True).new().is_empty
+    assert B.reduce_scalar(gb.agg.sum, allow_empty=False).new() == 0
+
+
 def test_vector_reduce_agg(gb, v):
     # graphblas/tests/test_vector.py:1033-1060 (the same subset)
     s = gb.Scalar(int)
