@@ -173,6 +173,16 @@ vector_ops = [
      "monoid": "plus", "expect": V([0, 1, 2, 3, 4, 5, 6], [3, 2, 9, 10, 11, 8, 4])},
     {"name": "resize_matrix", "cite": "graphblas/tests/test_matrix.py:193-206", "op": "resize", "A": "A7", "to": [4, 1],
      "expect": M([3], [0], [3], 4, 1)},
+    {"name": "agg_exists_rowwise", "cite": "graphblas/tests/test_matrix.py:1413-1417", "op": "agg_matvec", "A": "A7",
+     "semiring": "any_pair", "expect": V([0, 1, 2, 3, 4, 5, 6], [1, 1, 1, 1, 1, 1, 1])},
+    {"name": "agg_exists_columnwise", "cite": "graphblas/tests/test_matrix.py:1413-1417", "op": "agg_matvec", "A": "A7",
+     "semiring": "any_pair", "columns": True, "expect": V([0, 1, 2, 3, 4, 5, 6], [1, 1, 1, 1, 1, 1, 1])},
+    {"name": "reduce_scalar_sum", "cite": "graphblas/tests/test_matrix.py:1419", "op": "reduce_scalar", "A": "A7",
+     "monoid": "plus", "expect_scalar": 47},
+    {"name": "reduce_scalar_prod", "cite": "graphblas/tests/test_matrix.py:1420", "op": "reduce_scalar", "A": "A7",
+     "monoid": "times", "expect_scalar": 1270080},
+    {"name": "reduce_scalar_count", "cite": "graphblas/tests/test_matrix.py:1421", "op": "agg_matvec_scalar", "A": "A7",
+     "semiring": "plus_pair", "expect_scalar": 12},
     {"name": "resize_vector", "cite": "graphblas/tests/test_vector.py:182-191", "op": "resize", "w": "v7", "to": [4],
      "expect": V([1, 3], [1, 1], 4)},
 ]

@@ -40,6 +40,18 @@ def test_reference_literal_vector_ops(case):
         same(O.vec_ewise(get(case["u"]), get(case["v"]), case["binop"], union=op == "ewise_add"), case["expect"])
     elif op in ("reduce_rowwise", "reduce_columnwise"):
         same(O.mat_reduce_rows(get(case["A"]), case["monoid"], columns=op == "reduce_columnwise"), case["expect"])
+    elif op in ("agg_matvec", "agg_matvec_scalar"):
+        # count / exists: semiring(A @ init) with a dense iso INT64 operand (reference core/operator/agg.py:264-283)
+        A = get(case["A"])
+        size = A.nrows if case.get("columns") else A.ncols
+        init = O.OVec(size, np.arange(size), np.ones(size, np.int64), "INT64")
+        got = O.vxm(init, A, case["semiring"]) if case.get("columns") else O.mxv(A, init, case["semiring"])
+        if op == "agg_matvec":
+            same(got, case["expect"])
+        else:
+            assert O.vec_reduce(got, "plus") == case["expect_scalar"]
+    elif op == "reduce_scalar":
+        assert O.vec_reduce(O.mat_reduce_rows(get(case["A"]), case["monoid"]), case["monoid"]) == case["expect_scalar"]
     elif op == "resize":
         src = get(case["A"] if "A" in case else case["w"])
         if "A" in case:
