@@ -65,6 +65,9 @@ struct Context {
     int64_t vec_pad_min_bytes = 1 << 20;  // vectors with at least this many bytes of values are allocated with the front pad
     int alloc_cache = 1;    // 1: freed device blocks are kept per size class and reused without calling the HIP allocator
     int mxm_mask_mode = 1;  // mask-driven SpGEMM for non-complemented masks: 0 never, 1 when the full product costs more, 2 always
+    int long_sub = 0;       // sub-ranges per class of the cold columns of the long rows (items of a class are walked sub-range by
+                            // sub-range); 0 = sized from the operand image (~2 MiB per sub-range)
+    int long_sub_min_len = 0;  // ... for rows with at least this many entries (0 = 512 per sub-range)
     int long_kernel = 1;    // long rows: 1 = class-partitioned kernel (k_mxv_long_cls), 0 = chunk kernel (k_mxv_long)
     int short_kernel = 1;   // short rows of a split matrix: 1 = row-group kernel (k_mxv_rows), 0 = merge-path kernel
     GrX_Stats stats{};

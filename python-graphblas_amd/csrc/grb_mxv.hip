@@ -173,14 +173,23 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
         A->long_nnz = 0;
         A->n_items = 0;
         if (nnz_long < 0xf0000000ll && nnz < 0xffffffffll) {
-            const int64_t nv = 8 * nl;
+            // sub-ranges per class: sized so that one sub-range of the operand image is ~2 MiB (half an XCD's L2; BOOL images are
+            // bit-packed and fit as they are); measured on R-MAT scale 24 fp32: 4 sub-ranges -3 % per call, and rows need ~512
+            // entries per sub-range or their items get too small (sub 8 from 2048 entries: +3 %)
+            unsigned sub = 1;
+            if (ctx().long_sub > 0) sub = (unsigned)std::min(16, ctx().long_sub);
+            else if (A->type->code != TC_BOOL)
+                while (sub < 16 && (int64_t)A->ncols * (int64_t)A->type->size > (int64_t)sub * 8 * (3ll << 20)) sub *= 2;
+            const int64_t sub_min_len = ctx().long_sub_min_len > 0 ? ctx().long_sub_min_len : 512 * (int64_t)sub;
+            const int64_t nv = 8 * (int64_t)sub * nl;
             int bits = 1;
             while (((int64_t)1 << bits) < nv) bits++;
             DevBuf<uint64_t> keys(nnz_long), keys2(nnz_long);
             DevBuf<uint32_t> idx(nnz_long), idx2(nnz_long);
             hipLaunchKernelGGL(k_long_keys, dim3((unsigned)nl), dim3(256), 0, ctx().stream, (const int64_t *)A->d_ptr,
                                (const int64_t *)S->d_ptr, (const int32_t *)A->d_long_rows, col_src, nl, keys.p, idx.p,
-                               (unsigned)(hot ? A->hot_k : 0), (unsigned)std::max<int64_t>(1, ceil_div((int64_t)A->ncols, 8)));
+                               (unsigned)(hot ? A->hot_k : 0), (unsigned)std::max<int64_t>(1, ceil_div((int64_t)A->ncols, 8 * (int64_t)sub)),
+                               sub, sub_min_len);
             prim_sort_pairs_u64_u32(keys.p, keys2.p, idx.p, idx2.p, nnz_long, bits);
             DevBuf<int64_t> vptr(nv + 1), icnt(nv + 1);
             hipLaunchKernelGGL(k_long_vptr, dim3((unsigned)ceil_div(nv + 1, 256)), dim3(256), 0, ctx().stream,
@@ -197,7 +206,7 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
                 DevBuf<int32_t> ilen(ni), islot(ni);
                 hipLaunchKernelGGL(k_long_item_fill, dim3((unsigned)ceil_div(nv, 256)), dim3(256), 0, ctx().stream,
                                    (const int64_t *)vptr.p, nv, nl, (const int64_t *)icnt.p, ikey.p, iid.p, isrc.p, ilen.p, islot.p);
-                prim_sort_pairs_u64_u32(ikey.p, ikey2.p, iid.p, iorder.p, ni, 14);
+                prim_sort_pairs_u64_u32(ikey.p, ikey2.p, iid.p, iorder.p, ni, 19);  // 11 bits of length under the virtual class (< 128)
                 A->d_it_len = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)ni);
                 A->d_it_slot = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)ni);
                 A->d_it_start = (int64_t *)dev_alloc(sizeof(int64_t) * (size_t)(ni + 1));
@@ -208,7 +217,7 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
                 int64_t padded = 0;
                 d2h(&padded, A->d_it_start + ni, 8);
                 A->d_item_begin = (int64_t *)dev_alloc(sizeof(int64_t) * 9);
-                hipLaunchKernelGGL(k_long_class_bounds, dim3(1), dim3(64), 0, ctx().stream, (const uint64_t *)ikey2.p, ni, A->d_item_begin);
+                hipLaunchKernelGGL(k_long_class_bounds, dim3(1), dim3(64), 0, ctx().stream, (const uint64_t *)ikey2.p, ni, A->d_item_begin, sub);
                 d2h(A->item_begin, A->d_item_begin, sizeof(int64_t) * 9);
                 // (+2048 entries: a group's steps run to the longest item of its quad, i.e. past its own entries)
                 // only codes of the hot table are classed by line (k_long_keys): those may live in LDS

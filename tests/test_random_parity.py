@@ -486,6 +486,8 @@ def test_long_short_row_split(gb, seed):
         if seed & 4:
             _lib.lib.GrX_option_set(b"hot_min_cols", 8)
             _lib.lib.GrX_option_set(b"hot_k", 64)
+        _lib.lib.GrX_option_set(b"long_sub", 1 + seed % 5)
+        _lib.lib.GrX_option_set(b"long_sub_min_len", 64 if seed & 1 else 8)
         A = gb.Matrix.from_coo(rows, cols, vals, dtype=tname, nrows=m, ncols=n)
         u = gb.Vector.from_coo(ui, uv, dtype=tname, size=n)
         w = gb.Vector.from_coo(wi, wv, dtype=tname, size=m)
@@ -514,6 +516,8 @@ def test_long_short_row_split(gb, seed):
         _lib.lib.GrX_option_set(b"short_kernel", 1)
         _lib.lib.GrX_option_set(b"hot_min_cols", 1 << 20)
         _lib.lib.GrX_option_set(b"hot_k", 0)
+        _lib.lib.GrX_option_set(b"long_sub", 0)
+        _lib.lib.GrX_option_set(b"long_sub_min_len", 0)
 
 
 @pytest.mark.parametrize("seed", range(6))
@@ -550,6 +554,8 @@ def test_long_rows_many_chunks(gb, seed, request):
         _lib.lib.GrX_option_set(b"split_min_len", 2)
         _lib.lib.GrX_option_set(b"push_mode", 0)
         _lib.lib.GrX_option_set(b"long_kernel", 0 if seed in (1, 5) else 1)  # chunk kernel / class-partitioned kernel
+        _lib.lib.GrX_option_set(b"long_sub", [2, 1, 4, 3, 16, 1][seed])  # sub-ranges per class of the cold columns
+        _lib.lib.GrX_option_set(b"long_sub_min_len", [2, 2, 600, 1025, 2, 2][seed])
         A = gb.Matrix.from_coo(rows, cols, vals, dtype=tname, nrows=m, ncols=n)
         u = gb.Vector.from_coo(ui, uv, dtype=tname, size=n)
         mk = gb.Vector.from_coo(mi, mv, dtype="BOOL", size=m)
@@ -562,6 +568,8 @@ def test_long_rows_many_chunks(gb, seed, request):
         _lib.lib.GrX_option_set(b"split_min_len", 256)
         _lib.lib.GrX_option_set(b"push_mode", 1)
         _lib.lib.GrX_option_set(b"long_kernel", 1)
+        _lib.lib.GrX_option_set(b"long_sub", 0)
+        _lib.lib.GrX_option_set(b"long_sub_min_len", 0)
 
 
 @pytest.mark.parametrize("seed", range(22))
