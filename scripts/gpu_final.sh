@@ -1,8 +1,6 @@
 #!/bin/bash
 # Round-end measurement set: bench lines, rocprofv3 kernel stats, PMC counters (separate passes), mxm lines.
 TAG=${1:-r01z}; OUT=gpurun_out/$TAG; mkdir -p "$OUT"; export TMPDIR=/tmp
-echo "== bench default + extra"; timeout 900 python bench.py --steps 20 --extra > "$OUT/bench_s24.json" 2> "$OUT/bench_s24.err"; echo "rc=$?"; cut -c1-600 "$OUT/bench_s24.json"
-echo "== bench scale 20 (configs[1])"; timeout 600 python bench.py --scale 20 --steps 20 --workload mxv_min_plus > "$OUT/bench_s20_minplus.json" 2> "$OUT/bench_s20.err"; echo "rc=$?"; cut -c1-400 "$OUT/bench_s20_minplus.json"
 echo "== rocprofv3 stats"; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -o bench -- python bench.py --steps 20 --no-cpu-baseline > "$OUT/prof_bench.json" 2> "$OUT/prof.err"; echo "rc=$?"; grep -E "grb::" "$OUT/prof/bench_kernel_stats.csv" | cut -c1-160
 echo "== pmc FETCH_SIZE"; timeout 420 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -o p -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/pmc_fetch.json" 2> "$OUT/pmc_fetch.err"; echo "rc=$?"
 echo "== pmc WRITE_SIZE"; timeout 420 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -o p -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/pmc_write.json" 2> "$OUT/pmc_write.err"; echo "rc=$?"
@@ -36,6 +34,10 @@ rec = {"workload": "mxv_min_plus_masked", "scale": 24, "kernels": sorted(per_ker
                  "between the uncorrected and the corrected value."}
 json.dump(rec, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
 PY
+# the bench line reports roofline.traffic from profiles/r01/pmc_traffic.json: refresh it first (same kernels, this box)
+cp "$OUT/pmc_traffic.json" profiles/r01/pmc_traffic.json
+echo "== bench default + extra"; timeout 900 python bench.py --steps 20 --extra > "$OUT/bench_s24.json" 2> "$OUT/bench_s24.err"; echo "rc=$?"; cut -c1-600 "$OUT/bench_s24.json"
+echo "== bench scale 20 (configs[1])"; timeout 600 python bench.py --scale 20 --steps 20 --workload mxv_min_plus > "$OUT/bench_s20_minplus.json" 2> "$OUT/bench_s20.err"; echo "rc=$?"; cut -c1-400 "$OUT/bench_s20_minplus.json"
 echo "== bfs"; for s in 20 24; do timeout 600 python bench.py --workload bfs --scale $s --steps 5 --warmup 1 > "$OUT/bfs_s$s.json" 2> "$OUT/bfs_s$s.err"; echo "rc=$?"; cut -c1-300 "$OUT/bfs_s$s.json"; done
 echo "== sssp"; for s in 20 24; do timeout 600 python bench.py --workload sssp --scale $s --steps 3 --warmup 1 > "$OUT/sssp_s$s.json" 2> "$OUT/sssp_s$s.err"; echo "rc=$?"; cut -c1-300 "$OUT/sssp_s$s.json"; done
 echo "== mxm masked (C<A.S> = A A)"; for s in 20 22; do timeout 900 python bench.py --workload mxm_plus_times_masked --scale $s --steps 2 --warmup 1 > "$OUT/mxm_masked_s$s.json" 2> "$OUT/mxm_masked_s$s.err"; echo "rc=$?"; cut -c1-500 "$OUT/mxm_masked_s$s.json"; done
