@@ -740,3 +740,42 @@ def test_pair_over_full_operand(gb, seed):
                 same_vec(w2, exp)
         finally:
             _lib.lib.GrX_option_set(b"debug_flags", 0)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_long_rows_terminal_monoids(gb, seed):
+    """LOR / LAND / ANY stop early in the long-row kernel: items of a row whose accumulator already holds the terminal value
+    (or, for ANY, any product) are dropped before their entries are read.  Rows with several items per class, so that later
+    quads find finished rows; checked against the oracle with and without the early exit (debug flag 262144)."""
+    from graphblas_amd import _lib
+
+    rng = np.random.default_rng(5200 + seed)
+    sr = ["lor_land", "any_pair", "land_lor", "lor_land", "any_pair", "land_land"][seed]
+    m, n, rl = 40, 30000, 9000
+    rows = np.repeat(np.arange(m), rl)
+    cols = np.concatenate([rng.choice(n, rl, replace=False) for _ in range(m)])
+    vals = rng.random(rows.size) < (0.5 if "land_l" in sr and sr.startswith("land") else 0.9)
+    dens = [0.3, 0.5, 1.0, 0.002, 0.4, 0.7][seed]
+    ui = np.flatnonzero(rng.random(n) < dens)
+    uv = rng.random(ui.size) < (0.5 if sr.startswith("land") else 0.8)
+    mi, mv = rand_vec(rng, m, 0.7, "BOOL")
+    oa = O.OMat.from_coo(rows, cols, vals, m, n, "BOOL")
+    ou = O.OVec(n, ui, uv, "BOOL")
+    exp = O.mxv(oa, ou, sr)
+    exp_m = O.mxv(oa, ou, sr, mask=O.OVec(m, mi, mv, "BOOL"), mask_comp=True, mask_struct=True, replace=True)
+    try:
+        _lib.lib.GrX_option_set(b"split_min_nnz", 1)
+        _lib.lib.GrX_option_set(b"push_mode", 0)
+        A = gb.Matrix.from_coo(rows, cols, vals, dtype="BOOL", nrows=m, ncols=n)
+        u = gb.Vector.from_coo(ui, uv, dtype="BOOL", size=n)
+        mk = gb.Vector.from_coo(mi, mv, dtype="BOOL", size=m)
+        for flags in (0, 262144):
+            _lib.lib.GrX_option_set(b"debug_flags", flags)
+            same_vec(A.mxv(u, getattr(gb.semiring, sr)).new(), exp)
+            w = gb.Vector("BOOL", size=m)
+            w(~mk.S, replace=True) << A.mxv(u, getattr(gb.semiring, sr))
+            same_vec(w, exp_m)
+    finally:
+        _lib.lib.GrX_option_set(b"debug_flags", 0)
+        _lib.lib.GrX_option_set(b"split_min_nnz", 1 << 22)
+        _lib.lib.GrX_option_set(b"push_mode", 1)
