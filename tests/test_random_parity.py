@@ -779,3 +779,46 @@ def test_long_rows_terminal_monoids(gb, seed):
         _lib.lib.GrX_option_set(b"debug_flags", 0)
         _lib.lib.GrX_option_set(b"split_min_nnz", 1 << 22)
         _lib.lib.GrX_option_set(b"push_mode", 1)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_reductions_over_split_matrices(gb, seed):
+    """Row / column reductions and (monoid, FIRST) products with a full operand on matrices with the long / short row split:
+    the kernels then read no column index at all (debug flag 524288 turns that off) -- against the oracle."""
+    from graphblas_amd import _lib
+
+    rng = np.random.default_rng(6100 + seed)
+    tname = TYPES[seed % 7]
+    mon = (["lor", "land", "lxor"] if tname == "BOOL" else ["plus", "min", "max", "times"])[seed % (3 if tname == "BOOL" else 4)]
+    m, n = int(rng.integers(80, 400)), int(rng.integers(2100, 5000))
+    deg = rng.integers(0, 6, m)
+    deg[rng.random(m) < 0.3] = 0
+    for ln in (8, 9, 63, 65, 511, 1025, 2050, int(rng.integers(1500, n))):
+        deg[rng.integers(0, m)] = min(ln, n)
+    rows = np.repeat(np.arange(m), deg)
+    cols = np.concatenate([rng.choice(n, d, replace=False) for d in deg])
+    vals = rand_vals(rng, rows.size, tname)
+    if mon == "times":
+        vals = (vals % 3).astype(vals.dtype)
+    oa = O.OMat.from_coo(rows, cols, vals, m, n, tname)
+    mi, mv = rand_vec(rng, m, 0.5, "BOOL")
+    try:
+        _lib.lib.GrX_option_set(b"split_min_nnz", 1)
+        _lib.lib.GrX_option_set(b"split_min_len", 8)
+        A = gb.Matrix.from_coo(rows, cols, vals, dtype=tname, nrows=m, ncols=n)
+        mk = gb.Vector.from_coo(mi, mv, dtype="BOOL", size=m)
+        ui, uv = np.arange(n), rand_vals(rng, n, tname)
+        u = gb.Vector.from_coo(ui, uv, dtype=tname, size=n)
+        for flags in (0, 524288):
+            _lib.lib.GrX_option_set(b"debug_flags", flags)
+            same_vec(A.reduce_rowwise(getattr(gb.monoid, mon)).new(), O.mat_reduce_rows(oa, mon))
+            same_vec(A.reduce_columnwise(getattr(gb.monoid, mon)).new(), O.mat_reduce_rows(oa, mon, columns=True))
+            sr = f"{mon}_first"
+            if tname != "BOOL" and hasattr(gb.semiring, sr) and tname in getattr(gb.semiring, sr):
+                w = gb.Vector(tname, size=m)
+                w(mk.V) << A.mxv(u, getattr(gb.semiring, sr))
+                same_vec(w, O.mxv(oa, O.OVec(n, ui, uv, tname), sr, mask=O.OVec(m, mi, mv, "BOOL")))
+    finally:
+        _lib.lib.GrX_option_set(b"debug_flags", 0)
+        _lib.lib.GrX_option_set(b"split_min_nnz", 1 << 22)
+        _lib.lib.GrX_option_set(b"split_min_len", 256)
