@@ -274,3 +274,57 @@ def test_count_aggregator_and_power_at_scale(gb):
     Cp, Cj, Cx = B.power(5).new().to_csr()
     assert np.array_equal(Cp.astype(np.int64), ref.indptr) and np.array_equal(Cj.astype(np.int64), ref.indices)
     assert np.array_equal(Cx, ref.data)
+
+
+@pytest.mark.gpu
+def test_row_block_of_a_sharded_graph(gb):
+    """One rank's share of the 8-way row-sharded scale-22 graph (a 524 288 x 4 194 304 block: hot-column table, long / short row
+    split, sub-ranged long rows -- the shapes `bench.py --gpus 8` runs): the masked min_plus and lor_land steps of the block are
+    bit-exact against the CPU oracle and equal to the block's rows of the single-GPU product."""
+    import torch
+
+    from graphblas_amd import device, synthetic
+    from oracle import grb_oracle as O
+
+    scale, world, rank = 22, 8, 5
+    n = 1 << scale
+    rows = n // world
+    lo, hi = rank * rows, (rank + 1) * rows
+    indptr, col = synthetic.rmat_csr(scale, device="cuda")
+    vals = synthetic.edge_weights(col, scale)
+    e0, e1 = int(indptr[lo].item()), int(indptr[hi].item())
+    ip_b = (indptr[lo:hi + 1] - indptr[lo]).contiguous()
+    col_b, val_b = col[e0:e1].contiguous(), vals[e0:e1].contiguous()
+    A = device.matrix_from_device_csr(indptr, col, vals, n, n, "FP32")
+    B = device.matrix_from_device_csr(ip_b, col_b, val_b, rows, n, "FP32")
+    rng = np.random.default_rng(22)
+    uv = rng.integers(0, 1000, n).astype(np.float32)
+    vi = np.flatnonzero(rng.random(n) < 0.5)
+    u = gb.Vector.from_coo(np.arange(n), uv, dtype="FP32", size=n)
+    vis = gb.Vector.from_coo(vi, np.ones(vi.size, bool), dtype="BOOL", size=n)
+    w_full = u.dup()
+    w_full(~vis.S, accum="min") << A.mxv(u, gb.semiring.min_plus)
+    vb = vi[(vi >= lo) & (vi < hi)] - lo
+    vis_b = gb.Vector.from_coo(vb, np.ones(vb.size, bool), dtype="BOOL", size=rows)
+    w_b = gb.Vector.from_coo(np.arange(rows), uv[lo:hi], dtype="FP32", size=rows)
+    w_b(~vis_b.S, accum="min") << B.mxv(u, gb.semiring.min_plus)
+    assert device.last_stats()["hot_k"] > 0
+    gi, gv = w_b.to_coo()
+    fi, fv = w_full.to_coo()
+    assert np.array_equal(gi, np.arange(rows, dtype=gi.dtype)) and np.array_equal(gv, fv[lo:hi])
+    ob = O.OMat(rows, n, ip_b.cpu().numpy(), col_b.cpu().numpy().astype(np.int64), val_b.cpu().numpy(), "FP32")
+    exp = O.mxv(ob, O.OVec(n, np.arange(n), uv, "FP32"), "min_plus", w=O.OVec(rows, np.arange(rows), uv[lo:hi], "FP32"),
+                mask=O.OVec(rows, vb, np.ones(vb.size, bool), "BOOL"), mask_comp=True, mask_struct=True, accum="min")
+    assert np.array_equal(gv, exp.vals)
+    # the BFS step on the same block (iso-True BOOL, frontier of density 0.3, replace)
+    one = torch.ones(1, dtype=torch.bool, device="cuda")
+    Bb = device.matrix_from_device_csr(ip_b, col_b, one, rows, n, "BOOL", iso=True)
+    qi = np.flatnonzero(rng.random(n) < 0.3)
+    q = gb.Vector.from_coo(qi, np.ones(qi.size, bool), dtype="BOOL", size=n)
+    nxt = gb.Vector("BOOL", size=rows)
+    nxt(~vis_b.S, replace=True) << Bb.mxv(q, gb.semiring.lor_land)
+    obb = O.OMat(rows, n, ip_b.cpu().numpy(), col_b.cpu().numpy().astype(np.int64), np.ones(col_b.numel(), bool), "BOOL")
+    expb = O.mxv(obb, O.OVec(n, qi, np.ones(qi.size, bool), "BOOL"), "lor_land", mask=O.OVec(rows, vb, np.ones(vb.size, bool), "BOOL"),
+                 mask_comp=True, mask_struct=True, replace=True)
+    bi, bv = nxt.to_coo()
+    assert np.array_equal(bi.astype(np.int64), expb.idx) and np.array_equal(bv, expb.vals)
