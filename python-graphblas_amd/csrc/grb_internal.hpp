@@ -69,7 +69,8 @@ struct Context {
                             // sub-range); 0 = sized from the operand image (~2 MiB per sub-range)
     int long_sub_min_len = 0;  // ... for rows with at least this many entries (0 = 512 per sub-range)
     int long_kernel = 1;    // long rows: 1 = class-partitioned kernel (k_mxv_long_cls), 0 = chunk kernel (k_mxv_long)
-    int short_kernel = 1;   // short rows of a split matrix: 1 = row-group kernel (k_mxv_rows), 0 = merge-path kernel
+    int short_kernel = 1;   // short rows of a split matrix: 1 = row-group kernel (k_mxv_rows), 0 = merge-path kernel, 2 = sliced ELLPACK (k_mxv_sell)
+    int sell_sigma = 4096;  // rows per sort window of the sliced-ELLPACK form
     GrX_Stats stats{};
     int debug_flags = 0;    // GRB_DEBUG: kernel ablation switches (benchmark diagnostics only)
     int tune_pull_ipt = 0;  // GRB_PULL_IPT: merge items per thread of the pull SpMV (0 = default)
@@ -200,6 +201,13 @@ struct GB_Matrix_opaque {
     int64_t n_items;
     int64_t long_nnz;
     int cls_lds_lim;          // codes below it are stored pre-translated to LDS slots in d_lcol
+    // the short rows once more in sliced-ELLPACK form (k_mxv_sell; built on first use when short_kernel = 2)
+    int32_t *d_sell_perm;
+    int64_t *d_sell_off;
+    int32_t *d_sell_col;
+    void *d_sell_val;
+    int64_t sell_slices, sell_slots;
+    int sell_state;           // 0 = not built, 1 = built
     int64_t n_long, n_chunks;
     int split_state;          // 0 = not analysed, 1 = enabled, -1 = not worth it
     bool split_hot;           // short_part's columns are hot-coded

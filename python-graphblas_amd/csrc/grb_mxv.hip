@@ -35,6 +35,7 @@ namespace grb {
 #include "grb_mxv_pull.inc"
 #include "grb_mxv_long.inc"
 #include "grb_mxv_rows.inc"
+#include "grb_mxv_sell.inc"
 #include "grb_mxv_split_build.inc"
 #include "grb_mxv_write.inc"
 #include "grb_mxv_push.inc"
@@ -250,6 +251,42 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
     A->split_state = 1;
 }
 
+// sliced-ELLPACK copy of the short part S of A (once per matrix; see grb_mxv_sell.inc)
+static void ensure_sell(GB_Matrix_opaque *A)
+{
+    if (A->sell_state == 1) return;
+    GB_Matrix_opaque *S = A->short_part;
+    const int64_t m = (int64_t)S->nrows;
+    const int64_t sigma = std::max<int64_t>(64, ((int64_t)ctx().sell_sigma / 64) * 64);
+    const int64_t n_slices = ceil_div(m, 64);
+    const int64_t *sptr = matrix_rowptr(S);
+    DevBuf<uint64_t> keys(m), keys2(m);
+    DevBuf<uint32_t> idx(m), order(m);
+    hipLaunchKernelGGL(k_sell_keys, dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, ctx().stream, sptr, m, sigma, keys.p, idx.p);
+    int bits = 10;
+    while (((int64_t)1 << (bits - 9)) < ceil_div(m, sigma) + 1) bits++;
+    prim_sort_pairs_u64_u32(keys.p, keys2.p, idx.p, order.p, m, bits);
+    A->d_sell_perm = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)(n_slices * 64));
+    A->d_sell_off = (int64_t *)dev_alloc(sizeof(int64_t) * (size_t)(n_slices + 1));
+    hipLaunchKernelGGL(k_sell_slices, dim3((unsigned)ceil_div(n_slices * 64, 256)), dim3(256), 0, ctx().stream, sptr,
+                       (const uint32_t *)order.p, m, n_slices, A->d_sell_perm, A->d_sell_off);
+    prim_exclusive_sum_i64(A->d_sell_off, A->d_sell_off, n_slices + 1);
+    int64_t slots = 0;
+    d2h(&slots, A->d_sell_off + n_slices, 8);
+    if (slots >= 0xf0000000ll / 8) fail(GrB_NOT_IMPLEMENTED, "sliced-ELLPACK form: too many slots for 32-bit offsets");
+    A->d_sell_col = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)std::max<int64_t>(slots, 1));
+    A->d_sell_val = S->iso ? nullptr : dev_alloc(S->type->size * (size_t)std::max<int64_t>(slots, 1));
+    GRB_DISPATCH_TYPE(S->type->code, T, {
+        hipLaunchKernelGGL((k_sell_fill<T>), dim3((unsigned)ceil_div(n_slices * 64, 256)), dim3(256), 0, ctx().stream, sptr,
+                           (const int32_t *)S->d_col, (const T *)S->d_val, S->iso ? 1 : 0, (const int32_t *)A->d_sell_perm,
+                           (const int64_t *)A->d_sell_off, n_slices, A->d_sell_col, (T *)A->d_sell_val);
+    })
+    sync_stream();  // (the temporaries above are released at the end of this scope)
+    A->sell_slices = n_slices;
+    A->sell_slots = slots;
+    A->sell_state = 1;
+}
+
 template <typename T, int MON, int MUL, int IPT>
 static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
 {
@@ -316,6 +353,24 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
         b.long_bits = A->d_long_bits;
         b.n_chunks = 0;
         b.n_long_epi = a.n_long;
+        if (ctx().short_kernel == 2 && S->nrows == A->nrows && A->nrows < 0x7fffffffll) {
+            // short rows in sliced-ELLPACK form: a lane per row, which also applies the write rule of the long rows
+            ensure_sell(A);
+            b.long_prefix = A->d_long_prefix;
+            b.sell_perm = A->d_sell_perm;
+            b.sell_off = A->d_sell_off;
+            b.sell_col = A->d_sell_col;
+            b.sell_val = A->d_sell_val;
+            b.sell_iso = S->d_val;
+            b.sell_slices = A->sell_slices;
+            if (b.fresh) GRB_HIP(hipMemsetAsync(b.w_new_bits, 0, bits_words64((uint64_t)b.m) * 8, ctx().stream));
+            hipLaunchKernelGGL((k_mxv_sell<T, MON, MUL>), dim3((unsigned)ceil_div(b.sell_slices, SELL_BLOCK / 64)), dim3(SELL_BLOCK), 0,
+                               ctx().stream, b);
+            GRB_HIP(hipGetLastError());
+            ctx().stats.kernel_launches += 1;
+            ctx().stats.tiles = A->sell_slots;  // (slots incl. padding; the short part holds S->nvals entries)
+            return;
+        }
         if (ctx().short_kernel == 1 && S->nrows == A->nrows) {
             // short rows: one wavefront per 64 consecutive rows, which also applies the write rule of the long rows
             b.long_prefix = A->d_long_prefix;

@@ -532,6 +532,12 @@ GB_Matrix_opaque *matrix_new(GrB_Type type, uint64_t nrows, uint64_t ncols)
     A->d_it_len = nullptr;
     A->d_it_slot = nullptr;
     A->d_item_begin = nullptr;
+    A->d_sell_perm = nullptr;
+    A->d_sell_off = nullptr;
+    A->d_sell_col = nullptr;
+    A->d_sell_val = nullptr;
+    A->sell_slices = A->sell_slots = 0;
+    A->sell_state = 0;
     A->long_nnz = 0;
     A->n_items = 0;
     for (auto &x : A->item_begin) x = 0;
@@ -571,6 +577,16 @@ void matrix_invalidate_caches(GB_Matrix_opaque *A)
     dev_free(A->d_it_len);
     dev_free(A->d_it_slot);
     dev_free(A->d_item_begin);
+    dev_free(A->d_sell_perm);
+    dev_free(A->d_sell_off);
+    dev_free(A->d_sell_col);
+    dev_free(A->d_sell_val);
+    A->d_sell_perm = nullptr;
+    A->d_sell_off = nullptr;
+    A->d_sell_col = nullptr;
+    A->d_sell_val = nullptr;
+    A->sell_slices = A->sell_slots = 0;
+    A->sell_state = 0;
     A->d_lcol = nullptr;
     A->d_lval = nullptr;
     A->d_it_start = nullptr;

@@ -169,3 +169,4 @@ inline float atomicMax(float *p, float v) { auto o = *p; if (v > o || o != o) *p
 inline double atomicMin(double *p, double v) { auto o = *p; if (v < o || o != o) *p = v; return o; }
 inline double atomicMax(double *p, double v) { auto o = *p; if (v > o || o != o) *p = v; return o; }
 inline unsigned int atomicXor(unsigned int *p, unsigned int v) { auto o = *p; *p = o ^ v; return o; }
+inline unsigned long long atomicXor(unsigned long long *p, unsigned long long v) { auto o = *p; *p = o ^ v; return o; }

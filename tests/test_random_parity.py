@@ -482,7 +482,9 @@ def test_long_short_row_split(gb, seed):
         _lib.lib.GrX_option_set(b"split_min_nnz", 1)
         _lib.lib.GrX_option_set(b"split_min_len", 8)
         _lib.lib.GrX_option_set(b"push_mode", 0)
-        _lib.lib.GrX_option_set(b"short_kernel", 0 if seed & 8 else 1)  # merge-path kernel / row-group kernel for the short rows
+        # merge-path kernel / row-group kernel / sliced-ELLPACK kernel for the short rows
+        _lib.lib.GrX_option_set(b"short_kernel", 2 if seed % 3 == 1 else (0 if seed & 8 else 1))
+        _lib.lib.GrX_option_set(b"sell_sigma", [64, 128, 4096, 256][seed % 4])
         if seed & 4:
             _lib.lib.GrX_option_set(b"hot_min_cols", 8)
             _lib.lib.GrX_option_set(b"hot_k", 64)
@@ -514,6 +516,7 @@ def test_long_short_row_split(gb, seed):
         _lib.lib.GrX_option_set(b"split_min_len", 256)
         _lib.lib.GrX_option_set(b"push_mode", 1)
         _lib.lib.GrX_option_set(b"short_kernel", 1)
+        _lib.lib.GrX_option_set(b"sell_sigma", 4096)
         _lib.lib.GrX_option_set(b"hot_min_cols", 1 << 20)
         _lib.lib.GrX_option_set(b"hot_k", 0)
         _lib.lib.GrX_option_set(b"long_sub", 0)
@@ -822,3 +825,103 @@ def test_reductions_over_split_matrices(gb, seed):
         _lib.lib.GrX_option_set(b"debug_flags", 0)
         _lib.lib.GrX_option_set(b"split_min_nnz", 1 << 22)
         _lib.lib.GrX_option_set(b"split_min_len", 256)
+
+
+@pytest.mark.parametrize("seed", range(28))
+def test_sell_short_rows(gb, seed):
+    """short_kernel = 2: the short rows in sliced-ELLPACK form, a lane per row (k_mxv_sell) -- every type and semiring, all mask
+    forms, accumulators, replace, full / sparse operands, an output of another type, the output aliasing the operand, row counts
+    that are no multiple of 64, sort windows from 64 rows up -- against the oracle."""
+    from graphblas_amd import _lib, device
+
+    rng = np.random.default_rng(7300 + seed)
+    tname = TYPES[seed % 7]
+    srs = semirings_for(tname)
+    sr = srs[seed % len(srs)]
+    m, n = int(rng.integers(1, 900)), int(rng.integers(300, 3000))
+    square = seed % 5 == 4
+    if square:
+        n = m = max(m, 300)
+    deg = rng.integers(0, 9, m)
+    deg[rng.random(m) < 0.3] = 0
+    for ln in (40, 100, 255, 256, 300, int(rng.integers(200, n)), n, n - 1, n - 7):  # rows around and above the long-row threshold
+        deg[rng.integers(0, m)] = min(ln, n)
+    rows = np.repeat(np.arange(m), deg)
+    cols = np.concatenate([rng.choice(n, d, replace=False) for d in deg]) if deg.sum() else np.zeros(0, np.int64)
+    vals = rand_vals(rng, rows.size, tname)
+    ui, uv = rand_vec(rng, n, [1.0, 0.5, 0.05][seed % 3], tname)
+    wname = tname if seed % 4 else ["INT64", "FP64", "INT32", "FP32"][(seed // 4) % 4]
+    wi, wv = rand_vec(rng, m, 0.5, wname)
+    mi, mv = rand_vec(rng, m, 0.5, "INT8")
+    use_mask = seed % 6 != 0
+    comp, struct, repl = (bool(x) for x in rng.integers(0, 2, 3))
+    accum = [None, "plus", "min", "second"][rng.integers(4)]
+    oa = O.OMat.from_coo(rows, cols, vals, m, n, tname)
+    alias = square and wname == tname
+    ow = O.OVec(n, ui, uv, tname) if alias else O.OVec(m, wi, wv, wname)
+    exp = O.mxv(oa, O.OVec(n, ui, uv, tname), sr, w=ow, mask=O.OVec(m, mi, mv, "INT8") if use_mask else None,
+                mask_comp=comp and use_mask, mask_struct=struct, accum=accum, replace=repl and use_mask)
+    try:
+        _lib.lib.GrX_option_set(b"split_min_nnz", 1)
+        _lib.lib.GrX_option_set(b"split_min_len", 256 if seed % 2 else 64)
+        _lib.lib.GrX_option_set(b"push_mode", 0)
+        _lib.lib.GrX_option_set(b"short_kernel", 2)
+        _lib.lib.GrX_option_set(b"sell_sigma", [64, 192, 4096, 1024][seed % 4])
+        A = gb.Matrix.from_coo(rows, cols, vals, dtype=tname, nrows=m, ncols=n)
+        u = gb.Vector.from_coo(ui, uv, dtype=tname, size=n)
+        w = u if alias else gb.Vector.from_coo(wi, wv, dtype=wname, size=m)
+        kw = {}
+        if use_mask:
+            mk = gb.Vector.from_coo(mi, mv, dtype="INT8", size=m)
+            mm = mk.S if struct else mk.V
+            kw = dict(mask=~mm if comp else mm, replace=repl)
+        if accum:
+            kw["accum"] = accum
+        w(**kw) << A.mxv(u, getattr(gb.semiring, sr))
+        same_vec(w, exp)
+    finally:
+        _lib.lib.GrX_option_set(b"split_min_nnz", 1 << 22)
+        _lib.lib.GrX_option_set(b"split_min_len", 256)
+        _lib.lib.GrX_option_set(b"push_mode", 1)
+        _lib.lib.GrX_option_set(b"short_kernel", 1)
+        _lib.lib.GrX_option_set(b"sell_sigma", 4096)
+
+
+@pytest.mark.parametrize("dummy", [0])
+def test_sell_layout(gb, dummy):
+    """The sliced-ELLPACK form of a known matrix: GrX_Stats.tiles reports its slots -- 64 x the longest row of every slice after
+    sorting the rows by falling length inside windows of sigma rows."""
+    from graphblas_amd import _lib, device
+
+    m, n = 300, 2000
+    rng = np.random.default_rng(1)
+    deg = rng.integers(0, 20, m)
+    deg[7], deg[150] = 1200, 1900  # long rows (empty in the short part; they must hold 30 % of the entries for the split)
+    rows = np.repeat(np.arange(m), deg)
+    cols = np.concatenate([rng.choice(n, d, replace=False) for d in deg])
+    vals = np.ones(rows.size)
+    short = np.where(deg >= 64, 0, deg)
+    for sigma in (64, 128, 4096):
+        expect = 0
+        for w0 in range(0, m, sigma):
+            srt = np.sort(short[w0:w0 + sigma])[::-1]
+            expect += sum(64 * int(srt[k]) for k in range(0, len(srt), 64))
+        if sigma == 4096:  # one window: slices cut the globally sorted rows
+            srt = np.sort(short)[::-1]
+            expect = sum(64 * int(srt[k]) for k in range(0, m, 64))
+        try:
+            _lib.lib.GrX_option_set(b"split_min_nnz", 1)
+            _lib.lib.GrX_option_set(b"split_min_len", 64)
+            _lib.lib.GrX_option_set(b"short_kernel", 2)
+            _lib.lib.GrX_option_set(b"sell_sigma", sigma)
+            A = gb.Matrix.from_coo(rows, cols, vals, nrows=m, ncols=n)
+            u = gb.Vector.from_coo(np.arange(n), np.ones(n), size=n)
+            w = A.mxv(u, gb.semiring.plus_times).new()
+            assert device.last_stats()["tiles"] == expect, sigma
+            gi, gv = w.to_coo()
+            assert np.array_equal(gi, np.flatnonzero(deg)) and np.array_equal(gv, deg[deg > 0].astype(float))
+        finally:
+            _lib.lib.GrX_option_set(b"split_min_nnz", 1 << 22)
+            _lib.lib.GrX_option_set(b"split_min_len", 256)
+            _lib.lib.GrX_option_set(b"short_kernel", 1)
+            _lib.lib.GrX_option_set(b"sell_sigma", 4096)
