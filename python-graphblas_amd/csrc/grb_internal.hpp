@@ -204,6 +204,7 @@ struct GB_Matrix_opaque {
     // the short rows once more in sliced-ELLPACK form (k_mxv_sell; built on first use when short_kernel = 2)
     int32_t *d_sell_perm;
     int64_t *d_sell_off;
+    uint32_t *d_sell_order;   // slices by falling length (launch order)
     int32_t *d_sell_col;
     void *d_sell_val;
     int64_t sell_slices, sell_slots;

@@ -281,6 +281,15 @@ static void ensure_sell(GB_Matrix_opaque *A)
                            (const int32_t *)S->d_col, (const T *)S->d_val, S->iso ? 1 : 0, (const int32_t *)A->d_sell_perm,
                            (const int64_t *)A->d_sell_off, n_slices, A->d_sell_col, (T *)A->d_sell_val);
     })
+    {
+        DevBuf<uint64_t> okeys(n_slices), okeys2(n_slices);
+        DevBuf<uint32_t> oidx(n_slices);
+        A->d_sell_order = (uint32_t *)dev_alloc(sizeof(uint32_t) * (size_t)n_slices);
+        hipLaunchKernelGGL(k_sell_order_keys, dim3((unsigned)ceil_div(n_slices, 256)), dim3(256), 0, ctx().stream,
+                           (const int64_t *)A->d_sell_off, n_slices, okeys.p, oidx.p);
+        prim_sort_pairs_u64_u32(okeys.p, okeys2.p, oidx.p, A->d_sell_order, n_slices, 9);
+        sync_stream();
+    }
     sync_stream();  // (the temporaries above are released at the end of this scope)
     A->sell_slices = n_slices;
     A->sell_slots = slots;
@@ -359,6 +368,7 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
             b.long_prefix = A->d_long_prefix;
             b.sell_perm = A->d_sell_perm;
             b.sell_off = A->d_sell_off;
+            b.sell_order = A->d_sell_order;
             b.sell_col = A->d_sell_col;
             b.sell_val = A->d_sell_val;
             b.sell_iso = S->d_val;

@@ -534,6 +534,7 @@ GB_Matrix_opaque *matrix_new(GrB_Type type, uint64_t nrows, uint64_t ncols)
     A->d_item_begin = nullptr;
     A->d_sell_perm = nullptr;
     A->d_sell_off = nullptr;
+    A->d_sell_order = nullptr;
     A->d_sell_col = nullptr;
     A->d_sell_val = nullptr;
     A->sell_slices = A->sell_slots = 0;
@@ -579,6 +580,8 @@ void matrix_invalidate_caches(GB_Matrix_opaque *A)
     dev_free(A->d_item_begin);
     dev_free(A->d_sell_perm);
     dev_free(A->d_sell_off);
+    dev_free(A->d_sell_order);
+    A->d_sell_order = nullptr;
     dev_free(A->d_sell_col);
     dev_free(A->d_sell_val);
     A->d_sell_perm = nullptr;
