@@ -266,6 +266,8 @@ GrB_Info GrX_last_stats(GrX_Stats *stats);
  *   "hot_k"         entries of that table (0 = sized to ~2 MiB of x values)
  *   "split_min_nnz" matrices with at least this many entries get the long/short row split of the pull SpMV
  *   "split_min_len" a row is "long" (lean wavefront kernel) from this many entries (default 256)
+ *   "short_kernel"  short rows of a split matrix: 1 (default) one wavefront per 64 rows, 0 merge-path tiles, 2 sliced ELLPACK
+ *                   with a lane per row ("sell_sigma" rows per sort window; measured slower)
  *   "long_sub"      sub-ranges per class of the cold columns of the long rows (0 = sized from the operand image),
  *   "long_sub_min_len"  for rows from this many entries (0 = 512 per sub-range)
  *   "push_mode"     mxv/vxm direction: 0 always pull, 1 (default) push when u has fewer than n/64 entries and the
