@@ -513,7 +513,10 @@ static void mxv_core(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_Binar
     }
     vector_ensure_storage(u);
     const void *uval = u->d_val;
-    if (need_uval && u->type->code != st) {
+    // (values nobody reads still travel with the presence image [hot table | u] that is built when u is not full, and that
+    //  image is laid out in the semiring's type: only a full operand whose values are unused skips the cast)
+    const bool u_full_now = u->nvals == (int64_t)u->n;
+    if ((need_uval || !u_full_now) && u->type->code != st) {
         dev_free(u_cast.p);
         u_cast.p = (char *)dev_alloc(type_size(st) * (size_t)u->n);
         cast_array(st, u_cast.p, u->type->code, u->d_val, (int64_t)u->n);

@@ -925,3 +925,52 @@ def test_sell_layout(gb, dummy):
             _lib.lib.GrX_option_set(b"split_min_len", 256)
             _lib.lib.GrX_option_set(b"short_kernel", 1)
             _lib.lib.GrX_option_set(b"sell_sigma", 4096)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_mixed_types_unread_operands(gb, seed):
+    """Multiply operators that ignore an operand's values (PAIR, FIRST, SECOND, ANY) with operands of ANOTHER type than the
+    semiring's: the cast of an unread operand is skipped only where nothing is laid out in the semiring's type -- with a sparse
+    u the presence image [hot table | u] still is.  Hot table and row split forced on; full and sparse u; mxv and vxm."""
+    from graphblas_amd import _lib
+
+    rng = np.random.default_rng(8400 + seed)
+    ta, tu = [("INT64", "BOOL"), ("FP64", "INT8"), ("FP32", "BOOL"), ("INT8", "INT64"), ("BOOL", "FP64"), ("UINT16", "FP32")][seed % 6]
+    sr = ["any_pair", "plus_pair", "min_first", "max_second", "plus_first", "any_pair"][(seed // 2) % 6]
+    m, n = int(rng.integers(60, 500)), int(rng.integers(2100, 5000))
+    deg = rng.integers(0, 6, m)
+    deg[rng.random(m) < 0.3] = 0
+    for ln in (9, 65, 513, 2049, int(rng.integers(1500, n))):
+        deg[rng.integers(0, m)] = min(ln, n)
+    rows = np.repeat(np.arange(m), deg)
+    cols = np.concatenate([rng.choice(n, d, replace=False) for d in deg])
+    vals = rand_vals(rng, rows.size, ta)
+    ui, uv = rand_vec(rng, n, [0.4, 1.0, 0.03][seed % 3], tu)
+    mi, mv = rand_vec(rng, m, 0.5, "BOOL")
+    st = O.unify(ta, tu)
+    if st == "BOOL" or sr.split("_")[0] not in ("any", "plus", "min", "max"):
+        pytest.skip("no such semiring for the unified type")
+    oa = O.OMat.from_coo(rows, cols, vals, m, n, ta)
+    exp = O.mxv(oa, O.OVec(n, ui, uv, tu), sr, mask=O.OVec(m, mi, mv, "BOOL"), mask_comp=bool(seed & 1))
+    xi, xv = rand_vec(rng, m, [0.5, 1.0][seed % 2], tu)
+    exp_t = O.vxm(O.OVec(m, xi, xv, tu), oa, sr)
+    try:
+        _lib.lib.GrX_option_set(b"split_min_nnz", 1)
+        _lib.lib.GrX_option_set(b"split_min_len", 8)
+        _lib.lib.GrX_option_set(b"push_mode", 0)
+        _lib.lib.GrX_option_set(b"hot_min_cols", 8)
+        _lib.lib.GrX_option_set(b"hot_k", 64)
+        A = gb.Matrix.from_coo(rows, cols, vals, dtype=ta, nrows=m, ncols=n)
+        u = gb.Vector.from_coo(ui, uv, dtype=tu, size=n)
+        mk = gb.Vector.from_coo(mi, mv, dtype="BOOL", size=m)
+        w = gb.Vector(st, size=m)
+        w(~mk.V if seed & 1 else mk.V) << A.mxv(u, getattr(gb.semiring, sr))
+        same_vec(w, exp)
+        x = gb.Vector.from_coo(xi, xv, dtype=tu, size=m)
+        same_vec(x.vxm(A, getattr(gb.semiring, sr)).new(), exp_t)
+    finally:
+        _lib.lib.GrX_option_set(b"split_min_nnz", 1 << 22)
+        _lib.lib.GrX_option_set(b"split_min_len", 256)
+        _lib.lib.GrX_option_set(b"push_mode", 1)
+        _lib.lib.GrX_option_set(b"hot_min_cols", 1 << 20)
+        _lib.lib.GrX_option_set(b"hot_k", 0)
