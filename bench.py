@@ -426,6 +426,9 @@ def main():
                          "kernel_ms_hip_events": kernel_ms, "algorithmic_bytes_per_launch": wl.bytes_per_step()},
             "stats": device.last_stats(),
         }
+        if res["roofline"]["traffic"]:
+            # the PMC traffic (L2 misses x 128 B, measured in separate profiled runs of this workload) over this run's kernel time
+            res["roofline"]["traffic_GBps"] = res["roofline"]["traffic"] / (kernel_ms * 1e-3) / 1e9
         return wl, res
 
     if args.workload == "bfs":
