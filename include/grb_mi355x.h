@@ -249,7 +249,7 @@ typedef struct {
     int64_t tiles;            /* merge-path tiles (mxv/vxm) or row bins (mxm) */
     int64_t flops;            /* mxm: sum_k nnz(A(:,k)) nnz(B(k,:)) from the symbolic pass; mxv: nnz(A) */
     int64_t out_nvals;        /* mxm: nnz(T); mxv: -1 (not counted) */
-    int32_t method;           /* 1 pull SpMV, 2 push (SpMSpV), 3 hash SpGEMM, 4 mask-driven SpGEMM, 5 mxv by row length (PAIR, full operand) */
+    int32_t method;           /* 1 pull SpMV, 2 push (SpMSpV), 3 hash SpGEMM, 4 mask-driven SpGEMM, 5 mxv by row length (PAIR, full operand), 6 empty operand: write rule only */
     int32_t fused_epilogue;   /* 1 if mask/accum/replace were applied inside the product kernel */
     int64_t hot_k;            /* mxv/vxm: entries of the hot-column table used by the call (0 = none) */
 } GrX_Stats;

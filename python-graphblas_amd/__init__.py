@@ -18,6 +18,7 @@ from .operators import agg, binary, monoid, op, semiring
 
 _initialized = False
 backend = "mi355x"
+MAX_SIZE = 1 << 60  # largest Vector / Matrix dimension: GrB_INDEX_MAX + 1 (reference graphblas/__init__.py:42,210; tests/test_core.py:95-96)
 
 
 def init(backend="mi355x", blocking=False, *, lib_path=None):
@@ -45,4 +46,4 @@ from .matrix import Matrix, TransposedMatrix  # noqa: E402
 from .vector import Vector  # noqa: E402
 from .base import Scalar  # noqa: E402
 
-__all__ = ["init", "Matrix", "Vector", "Scalar", "semiring", "binary", "monoid", "op", "agg", "dtypes", "replace", "exceptions"]
+__all__ = ["init", "MAX_SIZE", "Matrix", "Vector", "Scalar", "semiring", "binary", "monoid", "op", "agg", "dtypes", "replace", "exceptions"]

@@ -498,6 +498,40 @@ static void mxv_core(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_Binar
     int mult = canonical_op(st, sr->mult);
     if (flip) mult = flip_op(mult);
 
+    // ---- mask bits ------------------------------------------------------------------------------------------
+    DevBuf<uint64_t> mbits_tmp(0);
+    const uint64_t *m_bits = nullptr;
+    if (mask) {
+        // (a mask that aliases w is snapshotted: tiles update w's presence words while others still read them)
+        if (f.structure && mask->d_val && mask != w) m_bits = mask->d_bits;
+        else {
+            dev_free(mbits_tmp.p);
+            mbits_tmp.p = (uint64_t *)dev_alloc(bits_words64(mask->n) * 8);
+            vector_mask_bits(mask, f.structure, mbits_tmp.p);
+            m_bits = mbits_tmp.p;
+        }
+    }
+
+    // ---- an operand without entries: T is empty, only the write rule remains (and nothing of the size of u is touched: empty
+    //      objects may be as large as GrB_INDEX_MAX + 1) ---------------------------------------------------------------------
+    if (S->nvals == 0 || u->nvals == 0) {
+        ctx().stats.method = 6;
+        if (w->nvals == 0) return;  // nothing to keep, nothing to write
+        if (!mask && !accum) {      // w = T = empty
+            vector_release_storage(w);
+            return;
+        }
+        vector_ensure_storage(w);
+        DevBuf<uint64_t> t_bits(bits_words64(w->n), true);
+        const int acc_op = accum ? canonical_op(w->type->code, accum->op) : -1;
+        vector_write_rule(w, w->d_val, t_bits.p, m_bits, f.comp, acc_op, f.replace);
+        ctx().stats.kernel_launches += 1;
+        ctx().stats.method = 6;
+        w->nvals = -1;
+        if (ctx().blocking) sync_stream();
+        return;
+    }
+
     // ---- operands in the semiring's type (only the ones the multiply operator reads) ------------------------------------
     bool need_aval = !(mult == OP_PAIR || mult == OP_SECOND) && S->nvals > 0;
     const bool need_uval = !(mult == OP_PAIR || mult == OP_FIRST || mult == OP_ANY);
@@ -521,20 +555,6 @@ static void mxv_core(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_Binar
         u_cast.p = (char *)dev_alloc(type_size(st) * (size_t)u->n);
         cast_array(st, u_cast.p, u->type->code, u->d_val, (int64_t)u->n);
         uval = u_cast.p;
-    }
-
-    // ---- mask bits ------------------------------------------------------------------------------------------
-    DevBuf<uint64_t> mbits_tmp(0);
-    const uint64_t *m_bits = nullptr;
-    if (mask) {
-        // (a mask that aliases w is snapshotted: tiles update w's presence words while others still read them)
-        if (f.structure && mask->d_val && mask != w) m_bits = mask->d_bits;
-        else {
-            dev_free(mbits_tmp.p);
-            mbits_tmp.p = (uint64_t *)dev_alloc(bits_words64(mask->n) * 8);
-            vector_mask_bits(mask, f.structure, mbits_tmp.p);
-            m_bits = mbits_tmp.p;
-        }
     }
 
     PullArgs a{};
@@ -822,6 +842,7 @@ static bool want_push(GB_Vector_opaque *u, GB_Matrix_opaque *P_or_null)
 {
     if (!P_or_null) return false;
     if (ctx().push_mode == 0) return false;
+    if (u->nvals == 0 || P_or_null->nvals == 0) return false;  // (nothing to push: the pull entry applies the write rule alone)
     if (ctx().push_mode == 2) return true;
     const int64_t nv = vector_nvals(u);
     return nv * 64 < (int64_t)u->n;  // fewer than n/64 entries

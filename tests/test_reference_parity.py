@@ -668,3 +668,33 @@ def test_power_masked_final_product(gb, A):
         assert C.isequal(D), n
     with pytest.raises(gb.exceptions.NotImplementedException):
         C(A.S) << A.power(1)  # a masked copy is a Matrix assign: outside this library's path
+
+
+def test_index_max(gb):
+    # graphblas/tests/test_core.py:95-96; objects of that size exist as long as they hold no entries (GrB_INDEX_MAX)
+    assert gb.MAX_SIZE == 2**60
+    v = gb.Vector(int, gb.MAX_SIZE)
+    assert v.size == 2**60 and v.nvals == 0
+    A = gb.Matrix(float, gb.MAX_SIZE, gb.MAX_SIZE)
+    assert A.shape == (2**60, 2**60) and A.nvals == 0
+    with pytest.raises(gb.exceptions.InvalidValue):
+        gb.Vector(int, gb.MAX_SIZE + 1)
+    with pytest.raises(gb.exceptions.InvalidValue):
+        gb.Matrix(int, 1, gb.MAX_SIZE + 1)
+    B = gb.Matrix(float, 3, gb.MAX_SIZE)
+    u = gb.Vector(float, gb.MAX_SIZE)
+    w = B.mxv(u, gb.semiring.plus_times).new()  # a product of empty operands of the largest inner dimension
+    assert w.size == 3 and w.nvals == 0
+    # ... also under a mask with replace and an accumulator: only the write rule acts
+    w = gb.Vector.from_coo([0, 2], [1.5, 2.5], size=3)
+    mk = gb.Vector.from_coo([0, 1], [True, True], size=3)
+    w(mk.S, gb.binary.plus, replace=True) << B.mxv(u, gb.semiring.plus_times)
+    assert w.isequal(gb.Vector.from_coo([0], [1.5], size=3))
+    x = gb.Vector(float, 3)
+    y = x.vxm(B, gb.semiring.min_plus).new()
+    assert y.size == gb.MAX_SIZE and y.nvals == 0
+    C = gb.Matrix(float, gb.MAX_SIZE, 4)
+    P = B.mxm(C, gb.semiring.plus_times).new()
+    assert P.shape == (3, 4) and P.nvals == 0
+    B.resize(3, 5)
+    assert B.shape == (3, 5)
