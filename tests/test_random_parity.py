@@ -425,13 +425,13 @@ def test_push_direction(gb, seed):
         if accum:
             kw["accum"] = accum
         w(**kw) << u.vxm(A, getattr(gb.semiring, sr))
-        assert device.last_stats()["method"] == 2
+        assert device.last_stats()["method"] == (2 if ui.size and r.size else 6)  # (an empty operand: the write rule alone)
         same_vec(w, exp)
         # mxv pushes over the transpose once it is cached
         x = gb.Vector.from_coo(xi, xv, dtype=tname, size=n)
         device.cache_transpose(A)
         y = A.mxv(x, getattr(gb.semiring, sr)).new()
-        assert device.last_stats()["method"] == 2
+        assert device.last_stats()["method"] == (2 if xi.size and r.size else 6)
         same_vec(y, exp_mxv)
         if m == n:
             pass
