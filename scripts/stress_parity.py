@@ -11,7 +11,8 @@ lo, hi = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (100, 14
 gb = bind(dev)
 names = ["test_mxv_random", "test_vxm_and_transposes_random", "test_hot_column_table", "test_push_direction",
          "test_long_short_row_split", "test_mxm_random", "test_mxm_mask_driven", "test_vector_assign_reduce_random",
-         "test_vector_ewise_random", "test_pair_over_full_operand"]
+         "test_vector_ewise_random", "test_pair_over_full_operand", "test_sell_short_rows", "test_reductions_over_split_matrices",
+         "test_mixed_types_unread_operands"]
 fails = 0
 for name in names:
     f = getattr(T, name)
@@ -19,7 +20,9 @@ for name in names:
     for seed in range(lo, hi):
         try:
             f(gb, seed)
-        except Exception:
+        except BaseException as e:
+            if type(e).__name__ == "Skipped":  # pytest.skip inside a test (no such semiring for the drawn types)
+                continue
             fails += 1
             print("FAIL", name, seed)
             traceback.print_exc(limit=3)
