@@ -252,6 +252,10 @@ typedef struct {
     int32_t method;           /* 1 pull SpMV, 2 push (SpMSpV), 3 hash SpGEMM, 4 mask-driven SpGEMM, 5 mxv by row length (PAIR, full operand), 6 empty operand: write rule only */
     int32_t fused_epilogue;   /* 1 if mask/accum/replace were applied inside the product kernel */
     int64_t hot_k;            /* mxv/vxm: entries of the hot-column table used by the call (0 = none) */
+    int64_t long_entries;     /* mxv/vxm over a split matrix: entries held by the long rows (0 = no split) */
+    int64_t long_segments;    /* ... as class strips: (class, sub-range, row) segments = atomics of an unmasked call */
+    int32_t long_kernel;      /* ... long-row kernel that ran: 0 chunks, 1 class items, 2 class strips; -1 = no split */
+    int32_t reserved_;
 } GrX_Stats;
 GrB_Info GrX_last_stats(GrX_Stats *stats);
 /* Tuning / diagnostics knobs (also read from the environment at GrB_init as GRB_<NAME upper-case>):

@@ -180,6 +180,8 @@ extern "C" GrB_Info GrB_init(GrB_Mode mode)
     if (const char *e = getenv("GRB_ALLOC_CACHE")) c.alloc_cache = atoi(e);
     if (const char *e = getenv("GRB_SHORT_KERNEL")) c.short_kernel = atoi(e);
     if (const char *e = getenv("GRB_SELL_SIGMA")) c.sell_sigma = atoi(e);
+    if (const char *e = getenv("GRB_LONG_KERNEL")) c.long_kernel = atoi(e);
+    if (const char *e = getenv("GRB_SPLIT_MIN_LEN")) c.split_min_len = atoi(e);
     if (const char *e = getenv("GRB_LONG_SUB")) c.long_sub = atoi(e);
     if (const char *e = getenv("GRB_LONG_SUB_MIN_LEN")) c.long_sub_min_len = atoi(e);
     c.initialized = true;

@@ -68,7 +68,7 @@ struct Context {
     int long_sub = 0;       // sub-ranges per class of the cold columns of the long rows (items of a class are walked sub-range by
                             // sub-range); 0 = sized from the operand image (~2 MiB per sub-range)
     int long_sub_min_len = 0;  // ... for rows with at least this many entries (0 = 512 per sub-range)
-    int long_kernel = 1;    // long rows: 1 = class-partitioned kernel (k_mxv_long_cls), 0 = chunk kernel (k_mxv_long)
+    int long_kernel = 2;    // long rows: 2 = flat class strips (k_mxv_strip), 1 = class-partitioned items (k_mxv_long_grp), 0 = chunk kernel (k_mxv_long)
     int short_kernel = 1;   // short rows of a split matrix: 1 = row-group kernel (k_mxv_rows), 0 = merge-path kernel, 2 = sliced ELLPACK (k_mxv_sell)
     int sell_sigma = 4096;  // rows per sort window of the sliced-ELLPACK form
     GrX_Stats stats{};
@@ -201,6 +201,14 @@ struct GB_Matrix_opaque {
     int64_t n_items;
     int64_t long_nnz;
     int cls_lds_lim;          // codes below it are stored pre-translated to LDS slots in d_lcol
+    // ... or as flat class strips (k_mxv_strip, long_kernel = 2): d_lcol / d_lval hold the entries of class c in chunks
+    // [strip_cb[c], strip_cb[c+1]) of 512 entries, sorted by (sub-range, row); a flag bit per entry starts a segment
+    unsigned char *d_sflag = nullptr;  // 1 bit per strip entry
+    int32_t *d_sseg0 = nullptr;        // per chunk: segments that start before it
+    int32_t *d_sslot = nullptr;        // per segment: accumulator slot (index into d_long_rows)
+    int64_t strip_cb[9] = {0};
+    int64_t strip_nseg = 0;
+    int split_kind = 0;                // value of the long_kernel option the split was built for
     // the short rows once more in sliced-ELLPACK form (k_mxv_sell; built on first use when short_kernel = 2)
     int32_t *d_sell_perm;
     int64_t *d_sell_off;

@@ -34,6 +34,7 @@ namespace grb {
 #include "grb_mxv_common.inc"
 #include "grb_mxv_pull.inc"
 #include "grb_mxv_long.inc"
+#include "grb_mxv_strip.inc"
 #include "grb_mxv_rows.inc"
 #include "grb_mxv_sell.inc"
 #include "grb_mxv_split_build.inc"
@@ -121,13 +122,15 @@ static void report_phase_times(const long long *d_times, int64_t n_tiles)
 // `col_src` is the column array the kernels will index (hot-coded or original).
 static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
 {
-    if (A->split_state != 0 && (A->split_state < 0 || A->split_hot == hot)) return;
-    if (A->split_state == 1) {  // built against the other column coding: rebuild
+    if (A->split_state != 0 && (A->split_state < 0 || (A->split_hot == hot && A->split_kind == ctx().long_kernel))) return;
+    if (A->split_state == 1) {  // built against the other column coding (or for another long-row kernel): rebuild
         matrix_free(A->short_part);
         A->short_part = nullptr;
         dev_free(A->d_long_bits); dev_free(A->d_long_rows); dev_free(A->d_chunk_slot); dev_free(A->d_chunk_start); dev_free(A->d_chunk_len); dev_free(A->d_long_prefix);
         dev_free(A->d_lcol); dev_free(A->d_lval); dev_free(A->d_it_start); dev_free(A->d_it_len); dev_free(A->d_it_slot);
         dev_free(A->d_item_begin);
+        dev_free(A->d_sflag); dev_free(A->d_sseg0); dev_free(A->d_sslot);
+        A->d_sflag = nullptr; A->d_sseg0 = nullptr; A->d_sslot = nullptr; A->strip_nseg = 0;
         A->d_lcol = nullptr; A->d_lval = nullptr; A->d_it_start = nullptr; A->d_it_len = nullptr; A->d_it_slot = nullptr;
         A->d_item_begin = nullptr; A->long_nnz = 0; A->n_items = 0;
         A->d_long_prefix = nullptr;
@@ -192,7 +195,45 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
                                (unsigned)(hot ? A->hot_k : 0), (unsigned)std::max<int64_t>(1, ceil_div((int64_t)A->ncols, 8 * (int64_t)sub)),
                                sub, sub_min_len);
             prim_sort_pairs_u64_u32(keys.p, keys2.p, idx.p, idx2.p, nnz_long, bits);
-            DevBuf<int64_t> vptr(nv + 1), icnt(nv + 1);
+            if (ctx().long_kernel == 2) {
+                // flat class strips (grb_mxv_strip.inc): the sorted entries laid out class by class in whole chunks, a flag per
+                // entry where a (class, sub-range, row) segment starts, the accumulator slot of every segment
+                DevBuf<int64_t> cstart(9), cbase(9);
+                hipLaunchKernelGGL(k_strip_bounds, dim3(1), dim3(64), 0, ctx().stream, (const uint64_t *)keys2.p, nnz_long, nl, sub,
+                                   cstart.p, cbase.p);
+                int64_t h_cbase[9];
+                d2h(h_cbase, cbase.p, sizeof(h_cbase));
+                const int64_t padded = h_cbase[8], nch = padded / STRIP_CH;
+                A->cls_lds_lim = (int)std::min<int64_t>(hot ? A->hot_k : 0,
+                                                        long_lds_codes((int)A->type->size, A->type->code == TC_BOOL, LONG_LDS_WORDS));
+                if (padded > 0 && padded < 0x7fffffff0ll) {
+                    A->d_lcol = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)padded);
+                    A->d_lval = A->iso ? nullptr : dev_alloc(A->type->size * (size_t)padded);
+                    A->d_sflag = (unsigned char *)dev_alloc((size_t)padded / 8);
+                    DevBuf<int64_t> ccnt(nch + 1, true);
+                    GRB_DISPATCH_TYPE(A->type->code, T, {
+                        hipLaunchKernelGGL((k_strip_place<T>), dim3((unsigned)(padded / 256)), dim3(256), 0, ctx().stream,
+                                           (const uint64_t *)keys2.p, (const uint32_t *)idx2.p, (const int64_t *)cstart.p,
+                                           (const int64_t *)cbase.p, padded, col_src, (const T *)A->d_val, A->iso ? 1 : 0,
+                                           A->cls_lds_lim, A->d_lcol, (T *)A->d_lval, A->d_sflag, (unsigned long long *)ccnt.p);
+                    })
+                    prim_exclusive_sum_i64(ccnt.p, ccnt.p, nch + 1);
+                    int64_t nseg = 0;
+                    d2h(&nseg, ccnt.p + nch, 8);
+                    if (nseg >= 0x7ffffff0ll) fail(GrB_NOT_IMPLEMENTED, "class strips: too many segments for 32-bit numbering");
+                    A->d_sseg0 = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)nch);
+                    A->d_sslot = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)std::max<int64_t>(nseg, 1));
+                    hipLaunchKernelGGL(k_strip_segs, dim3((unsigned)nch), dim3(STRIP_CH), 0, ctx().stream, (const unsigned char *)A->d_sflag,
+                                       (const int64_t *)ccnt.p, (const uint64_t *)keys2.p, (const int64_t *)cstart.p,
+                                       (const int64_t *)cbase.p, nl, A->d_sseg0, A->d_sslot);
+                    for (int c = 0; c < 9; c++) A->strip_cb[c] = h_cbase[c] / STRIP_CH;
+                    A->strip_nseg = nseg;
+                    A->long_nnz = nnz_long;
+                    sync_stream();  // (the temporaries above are released at the end of this scope)
+                }
+            }
+            DevBuf<int64_t> vptr(ctx().long_kernel == 2 ? 0 : nv + 1), icnt(ctx().long_kernel == 2 ? 0 : nv + 1);
+            if (ctx().long_kernel != 2) {
             hipLaunchKernelGGL(k_long_vptr, dim3((unsigned)ceil_div(nv + 1, 256)), dim3(256), 0, ctx().stream,
                                (const uint64_t *)keys2.p, nnz_long, nv, vptr.p);
             hipLaunchKernelGGL(k_long_item_count, dim3((unsigned)ceil_div(nv + 1, 256)), dim3(256), 0, ctx().stream,
@@ -237,6 +278,7 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
                 A->long_nnz = nnz_long;
                 sync_stream();  // (the temporaries above are released at the end of this scope)
             }
+            }
         }
         sync_stream();
     } catch (...) {
@@ -248,6 +290,7 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
     A->n_long = nl;
     A->n_chunks = nc;
     A->split_hot = hot;
+    A->split_kind = ctx().long_kernel;
     A->split_state = 1;
 }
 
@@ -308,13 +351,17 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
         GB_Matrix_opaque *S = A->short_part;
         DevBuf<W> tl_val(a.n_long);
         DevBuf<unsigned char> tl_has(a.n_long);
-        const bool by_class = ctx().long_kernel == 1 && A->long_nnz > 0;
+        const bool by_strip = A->split_kind == 2 && A->long_nnz > 0 && A->strip_nseg > 0;
+        ctx().stats.long_entries = A->nvals - S->nvals;
+        ctx().stats.long_segments = by_strip ? A->strip_nseg : 0;
+        const bool by_class = A->split_kind == 1 && ctx().long_kernel == 1 && A->long_nnz > 0;
+        ctx().stats.long_kernel = by_strip ? 2 : (by_class ? 1 : 0);
         DevBuf<uint32_t> long_act((size_t)ceil_div(a.n_long, 64) * 2);
         a.long_act = long_act.p;
         hipLaunchKernelGGL((k_long_init<W>), dim3((unsigned)ceil_div(a.n_long, 256)), dim3(256), 0, ctx().stream, tl_val.p, tl_has.p,
                            a.n_long, monoid_identity<T, W>(a.monoid), a.long_rows, a.m_bits, a.has_mask, a.m_comp, long_act.p,
-                           (by_class && a.u_full) ? 1 : 0);
-        a.long_has_known = (by_class && a.u_full) ? 1 : 0;
+                           ((by_class || by_strip) && a.u_full) ? 1 : 0);
+        a.long_has_known = ((by_class || by_strip) && a.u_full) ? 1 : 0;
         a.tl_val = tl_val.p;
         a.tl_has = tl_has.p;
         a.dbg = ctx().debug_flags;
@@ -322,7 +369,27 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
         const bool compact = by_class && a.has_mask;
         DevBuf<int64_t> act_start(compact ? (size_t)A->n_items : 1), block_cnt(compact ? (size_t)ncb + 1 : 1), class_off(9);
         DevBuf<int32_t> act_len(compact ? (size_t)A->n_items : 1), act_slot(compact ? (size_t)A->n_items : 1);
-        if (by_class) {
+        DevBuf<uint64_t> strip_act((by_strip && a.has_mask) ? (size_t)((A->strip_nseg + 1 + 63) / 64 + 1) : 1);
+        if (by_strip) {
+            a.lcol = A->d_lcol;
+            a.lval = A->d_lval;
+            a.cls_lds_lim = A->cls_lds_lim;
+            a.strip_flag = A->d_sflag;
+            a.strip_seg0 = A->d_sseg0;
+            a.strip_slot = A->d_sslot;
+            a.strip_nseg = A->strip_nseg;
+            for (int c = 0; c < 9; c++) a.strip_cb[c] = A->strip_cb[c];
+            a.strip_act = nullptr;
+            if (a.has_mask) {
+                const int64_t nw = (A->strip_nseg + 1 + 63) / 64 + 1;
+                hipLaunchKernelGGL(k_strip_act, dim3((unsigned)ceil_div(nw * 64, 256)), dim3(256), 0, ctx().stream, (const int32_t *)A->d_sslot,
+                                   A->strip_nseg, (const uint32_t *)long_act.p, strip_act.p, nw);
+                a.strip_act = (const uint32_t *)strip_act.p;
+                ctx().stats.kernel_launches += 1;
+            }
+            const int64_t G = std::max<int64_t>(8, (int64_t)(ctx().num_cus / 8) * 8);
+            hipLaunchKernelGGL((k_mxv_strip<T, MON, MUL, LONG_LDS_WORDS>), dim3((unsigned)G), dim3(LONG_BLOCK), 0, ctx().stream, a);
+        } else if (by_class) {
             a.lcol = A->d_lcol;
             a.lval = A->d_lval;
             a.it_start = A->d_it_start;
@@ -485,6 +552,7 @@ static void mxv_core(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_Binar
     if (accum && (accum->type != w->type->code || op_is_comparison(accum->op))) fail(GrB_DOMAIN_MISMATCH, "mxv/vxm: accum operator type must equal the output type");
     ctx().stats = GrX_Stats{};
     ctx().stats.method = 1;
+    ctx().stats.long_kernel = -1;
     ctx().stats.flops = S->nvals;
     ctx().stats.out_nvals = -1;
     const int64_t m = (int64_t)w->n;
@@ -647,7 +715,7 @@ static void mxv_core(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_Binar
     DevBuf<uint64_t> valbits(0);
     // (u not full: presence and value share one word per 16 codes, one gather per entry instead of two -- every pull kernel
     //  but the chunk kernel of the long rows reads that form)
-    const bool chunk_kernel = S->split_state == 1 && !(ctx().long_kernel == 1 && S->long_nnz > 0);
+    const bool chunk_kernel = S->split_state == 1 && !((S->split_kind == 1 || S->split_kind == 2) && S->long_nnz > 0);
     if (st == TC_BOOL && a.need_uval && !a.u_full && !chunk_kernel && !(ctx().debug_flags & 2048)) {
         const int64_t len = a.x_len;
         dev_free(valbits.p);

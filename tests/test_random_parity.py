@@ -12,6 +12,9 @@ from oracle import grb_oracle as O
 from tests.backend import DEVICES, bind
 
 TYPES = ["INT64", "FP32", "BOOL", "FP64", "INT8", "UINT16", "INT32"]
+import os
+
+DEFAULT_LONG_KERNEL = int(os.environ.get("GRB_LONG_KERNEL", "2"))  # what tests restore after forcing a long-row kernel
 
 
 @pytest.fixture(params=DEVICES)
@@ -497,6 +500,8 @@ def test_long_short_row_split(gb, seed):
         w(~mk.V if comp else mk.V, accum=accum, replace=bool(seed & 2)) << A.mxv(u, getattr(gb.semiring, sr))
         st = device.last_stats()  # init + long rows + short rows (with the write rule of every row); PAIR over a full u reads no rows
         assert st["kernel_launches"] >= 3 or st["method"] == 5
+        assert st["method"] == 5 or (st["long_kernel"] == DEFAULT_LONG_KERNEL and st["long_entries"] > 0)
+        assert DEFAULT_LONG_KERNEL != 2 or st["method"] == 5 or st["long_segments"] > 0
         same_vec(w, exp)
         x = gb.Vector.from_coo(xi, xv, dtype=tname, size=m)
         same_vec(x.vxm(A, getattr(gb.semiring, sr)).new(), exp_t)
@@ -556,7 +561,7 @@ def test_long_rows_many_chunks(gb, seed, request):
         _lib.lib.GrX_option_set(b"split_min_nnz", 1)
         _lib.lib.GrX_option_set(b"split_min_len", 2)
         _lib.lib.GrX_option_set(b"push_mode", 0)
-        _lib.lib.GrX_option_set(b"long_kernel", 0 if seed in (1, 5) else 1)  # chunk kernel / class-partitioned kernel
+        _lib.lib.GrX_option_set(b"long_kernel", 0 if seed in (1, 5) else (1 if seed == 2 else 2))  # chunk kernel / item kernel / class strips
         _lib.lib.GrX_option_set(b"long_sub", [2, 1, 4, 3, 16, 1][seed])  # sub-ranges per class of the cold columns
         _lib.lib.GrX_option_set(b"long_sub_min_len", [2, 2, 600, 1025, 2, 2][seed])
         A = gb.Matrix.from_coo(rows, cols, vals, dtype=tname, nrows=m, ncols=n)
@@ -570,7 +575,7 @@ def test_long_rows_many_chunks(gb, seed, request):
         _lib.lib.GrX_option_set(b"split_min_nnz", 1 << 22)
         _lib.lib.GrX_option_set(b"split_min_len", 256)
         _lib.lib.GrX_option_set(b"push_mode", 1)
-        _lib.lib.GrX_option_set(b"long_kernel", 1)
+        _lib.lib.GrX_option_set(b"long_kernel", DEFAULT_LONG_KERNEL)
         _lib.lib.GrX_option_set(b"long_sub", 0)
         _lib.lib.GrX_option_set(b"long_sub_min_len", 0)
 
