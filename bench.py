@@ -90,6 +90,8 @@ class MxvWorkload:
             vals = synthetic.edge_weights(col, scale)
             self.A = device.matrix_from_device_csr(indptr, col, vals, rows, n, "FP32")
             dist = torch.randint(0, 1000, (n,), generator=gen, device="cuda").to(torch.float32)
+            self._dist = dist
+            self._vals = vals
             self.u = device.vector_from_device(dist)
             self.w = device.vector_from_device(dist[lo:hi].contiguous())
             self.sr = gb.semiring.min_plus["FP32"]
@@ -99,6 +101,7 @@ class MxvWorkload:
             one = torch.ones(1, dtype=torch.bool, device="cuda")
             self.A = device.matrix_from_device_csr(indptr, col, one, rows, n, "BOOL", iso=True)
             frontier = torch.rand(n, generator=gen, device="cuda") < 0.3
+            self._frontier = frontier
             self.u = device.vector_from_device(torch.ones(n, dtype=torch.bool, device="cuda"), present=frontier)
             self.w = device.vector_from_device(torch.ones(rows, dtype=torch.bool, device="cuda"),
                                                present=frontier[lo:hi].contiguous())
@@ -138,6 +141,34 @@ class MxvWorkload:
                 self.u_vals.copy_(self._gather_buf)
             else:
                 self.torch.distributed.all_gather_into_tensor(self.u_vals, self.w_vals)
+
+    def verify(self):
+        """Check the output of the timed calls against a torch segment reduction of the same products (single GPU: u is fixed,
+        so K steps of  w<mask> = min(w, A min.+ u)  leave what one step leaves; the BFS step has no accumulator at all).
+        min_plus over integer-valued fp32 operands is exact, so the comparison is bit for bit."""
+        import numpy as np
+
+        from graphblas_amd import device
+
+        torch = self.torch
+        if self.world > 1:
+            return None
+        indptr, col = self._keep
+        n, m = self.n, self.m
+        rows = torch.repeat_interleave(torch.arange(m, device="cuda"), indptr[1:] - indptr[:-1])
+        active = ~self.visited_local
+        wv, wb = device.vector_device_views(self.w)
+        got_has = torch.from_numpy(np.unpackbits(wb.cpu().numpy().view(np.uint8), bitorder="little")[:m].astype(bool)).cuda()
+        if self.semiring == "min_plus":
+            cand = self._vals + self._dist[col.long()]
+            ref = torch.full((m,), float("inf"), device="cuda").scatter_reduce(0, rows, cand, "amin")
+            del cand
+            exp = torch.where(active, torch.minimum(self._dist[self.lo:self.hi], ref), self._dist[self.lo:self.hi])
+            return bool(got_has.all().item()) and bool(torch.equal(wv, exp))
+        hit = torch.zeros(m, dtype=torch.bool, device="cuda")
+        hit.index_put_((rows[self._frontier[col.long()]],), torch.tensor(True, device="cuda"))
+        exp_has = hit & active
+        return bool(torch.equal(got_has, exp_has)) and bool(wv[exp_has].all().item())
 
     def bytes_per_step(self):
         return algorithmic_bytes_mxv(self.nnz_active_local, self.m, self.n, self.v_a, self.v_u, self.v_w,
@@ -414,7 +445,9 @@ def main():
         ms_per_step = dt / args.steps * 1e3
         kernel_ms = ev_ms / args.steps
         achieved = wl.bytes_per_step() / (kernel_ms * 1e-3) / 1e9
+        verified = wl.verify()
         res = {
+            "verified": verified,
             "value": edges / (ms_per_step * 1e-3) / 1e9,
             "ms_per_step": ms_per_step,
             "dtype": wl.dtype_name,
@@ -451,7 +484,7 @@ def main():
             if name == args.workload:
                 continue
             _, r = run(name)
-            extra.append({"workload": name, **{k: r[k] for k in ("value", "ms_per_step", "dtype", "roofline")}})
+            extra.append({"workload": name, **{k: r[k] for k in ("value", "ms_per_step", "dtype", "roofline", "verified")}})
     if rank == 0:
         out = {
             "metric": "GTEPS (mxv) on R-MAT scale-%d" % args.scale,
@@ -471,6 +504,7 @@ def main():
                        if args.workload == "mxv_min_plus_masked" else f"rmat{args.scale} {args.workload}",
                        "edges_counted_per_step": res["edges_per_step"],
                        "parallelism": f"row-shard x{world}" + (" + RCCL all-gather of w" if world > 1 else "")},
+            "verified": res["verified"],
             "roofline": res["roofline"] if world == 1 else {**res["roofline"], "note": "per-rank max over ranks"},
             "cpu_baseline": cpu,
             "stats": res["stats"],

@@ -269,7 +269,10 @@ GrB_Info GrX_last_stats(GrX_Stats *stats);
  *   "hot_min_cols"  matrices with at least this many columns get a hot-column table for the pull SpMV
  *   "hot_k"         entries of that table (0 = sized to ~2 MiB of x values)
  *   "split_min_nnz" matrices with at least this many entries get the long/short row split of the pull SpMV
- *   "split_min_len" a row is "long" (lean wavefront kernel) from this many entries (default 256)
+ *   "split_min_len" a row is "long" from this many entries (default 0 = 64 for the class strips, 256 for the item kernel)
+ *   "long_kernel"   layout / kernel of the long rows: 3 (default) class strips, items for BOOL matrices; 2 class strips (k_mxv_strip);
+ *                   1 class-partitioned items (k_mxv_long_grp); 0 chunks straight from the CSR arrays (k_mxv_long)
+ *   "long_classes"  column classes of the class strips: 8, 16 (default), 32 or 64 distinct LDS heads across the chip
  *   "short_kernel"  short rows of a split matrix: 1 (default) one wavefront per 64 rows, 0 merge-path tiles, 2 sliced ELLPACK
  *                   with a lane per row ("sell_sigma" rows per sort window; measured slower)
  *   "long_sub"      sub-ranges per class of the cold columns of the long rows (0 = sized from the operand image),

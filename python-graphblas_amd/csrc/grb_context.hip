@@ -181,6 +181,7 @@ extern "C" GrB_Info GrB_init(GrB_Mode mode)
     if (const char *e = getenv("GRB_SHORT_KERNEL")) c.short_kernel = atoi(e);
     if (const char *e = getenv("GRB_SELL_SIGMA")) c.sell_sigma = atoi(e);
     if (const char *e = getenv("GRB_LONG_KERNEL")) c.long_kernel = atoi(e);
+    if (const char *e = getenv("GRB_LONG_CLASSES")) c.long_classes = atoi(e);
     if (const char *e = getenv("GRB_SPLIT_MIN_LEN")) c.split_min_len = atoi(e);
     if (const char *e = getenv("GRB_LONG_SUB")) c.long_sub = atoi(e);
     if (const char *e = getenv("GRB_LONG_SUB_MIN_LEN")) c.long_sub_min_len = atoi(e);
@@ -267,6 +268,7 @@ extern "C" GrB_Info GrX_option_set(const char *name, int64_t value)
     else if (n == "split_min_len") c.split_min_len = (int)value;
     else if (n == "short_kernel") c.short_kernel = (int)value;
     else if (n == "long_kernel") c.long_kernel = (int)value;
+    else if (n == "long_classes") c.long_classes = (value == 16 || value == 32 || value == 64) ? (int)value : 8;
     else if (n == "sell_sigma") c.sell_sigma = (int)value;
     else if (n == "long_sub") c.long_sub = (int)value;
     else if (n == "long_sub_min_len") c.long_sub_min_len = (int)value;

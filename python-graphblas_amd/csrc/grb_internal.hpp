@@ -68,7 +68,8 @@ struct Context {
     int long_sub = 0;       // sub-ranges per class of the cold columns of the long rows (items of a class are walked sub-range by
                             // sub-range); 0 = sized from the operand image (~2 MiB per sub-range)
     int long_sub_min_len = 0;  // ... for rows with at least this many entries (0 = 512 per sub-range)
-    int long_kernel = 2;    // long rows: 2 = flat class strips (k_mxv_strip), 1 = class-partitioned items (k_mxv_long_grp), 0 = chunk kernel (k_mxv_long)
+    int long_kernel = 3;    // long rows: 3 = by matrix type (strips; items for BOOL), 2 = flat class strips (k_mxv_strip), 1 = class-partitioned
+                            // items (k_mxv_long_grp), 0 = chunk kernel (k_mxv_long)
     int short_kernel = 1;   // short rows of a split matrix: 1 = row-group kernel (k_mxv_rows), 0 = merge-path kernel, 2 = sliced ELLPACK (k_mxv_sell)
     int sell_sigma = 4096;  // rows per sort window of the sliced-ELLPACK form
     GrX_Stats stats{};
@@ -77,7 +78,8 @@ struct Context {
     int64_t hot_min_cols = 1 << 20;  // matrices at least this wide get a hot-column table (pull SpMV)
     int64_t hot_k = 0;               // table entries (0 = ~2 MiB of x values)
     int64_t split_min_nnz = 1 << 22;  // matrices with at least this many entries are analysed for the long/short row split
-    int split_min_len = 256;          // a row is "long" from this many entries
+    int split_min_len = 0;            // a row is "long" from this many entries (0 = 64 for the class strips, 256 for the item kernel)
+    int long_classes = 16;            // column classes of the class strips (8, 16, 32, 64): distinct LDS heads across the chip
     int push_mode = 1;               // 0 never push, 1 push when u has < n/64 entries, 2 always push (tests)
 };
 Context &ctx();
@@ -143,7 +145,7 @@ struct GB_Descriptor_opaque {
     bool builtin;
 };
 
-constexpr size_t VEC_VAL_PAD = (size_t)2 << 20;    // the default hot-column table is 2 MiB of values ...
+constexpr size_t VEC_VAL_PAD = (size_t)8 << 20;    // the default hot-column table is 2 MiB of values ...
 constexpr size_t VEC_BITS_PAD = (size_t)256 << 10;  // ... and at most 2 Mi presence bits (1-byte types)
 
 struct GB_Vector_opaque {
@@ -202,11 +204,11 @@ struct GB_Matrix_opaque {
     int64_t long_nnz;
     int cls_lds_lim;          // codes below it are stored pre-translated to LDS slots in d_lcol
     // ... or as flat class strips (k_mxv_strip, long_kernel = 2): d_lcol / d_lval hold the entries of class c in chunks
-    // [strip_cb[c], strip_cb[c+1]) of 512 entries, sorted by (sub-range, row); a flag bit per entry starts a segment
-    unsigned char *d_sflag = nullptr;  // 1 bit per strip entry
-    int32_t *d_sseg0 = nullptr;        // per chunk: segments that start before it
-    int32_t *d_sslot = nullptr;        // per segment: accumulator slot (index into d_long_rows)
-    int64_t strip_cb[9] = {0};
+    // [strip_cb[c], strip_cb[c+1]) of 512 entries, sorted by (sub-range, row); segments start at multiples of 8 entries
+    unsigned long long *d_sstart = nullptr;  // per chunk: bit l = a segment starts at lane l's 8 entries
+    int32_t *d_sslot = nullptr;        // per lane (8 entries): accumulator slot (index into d_long_rows), -1 = padding
+    int64_t strip_cb[65] = {0};
+    int strip_ncls = 8;
     int64_t strip_nseg = 0;
     int split_kind = 0;                // value of the long_kernel option the split was built for
     // the short rows once more in sliced-ELLPACK form (k_mxv_sell; built on first use when short_kernel = 2)

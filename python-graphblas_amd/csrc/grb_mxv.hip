@@ -52,6 +52,11 @@ static void ensure_hot(GB_Matrix_opaque *A, size_t value_bytes)
     const int64_t n = (int64_t)A->ncols, nnz = A->nvals;
     if (n < ctx().hot_min_cols || nnz == 0 || n + (int64_t)(1 << 22) > 0x7fffffff) return;
     int64_t k = ctx().hot_k > 0 ? ctx().hot_k : (int64_t)((2u << 20) / (value_bytes ? value_bytes : 1));
+    // (the class strips keep the hottest codes of every class in LDS: the table has to hold at least those)
+    if (ctx().hot_k <= 0 && value_bytes > 1 && (ctx().long_kernel == 2 || ctx().long_kernel == 3)) {
+        const int ncls = (ctx().long_classes == 16 || ctx().long_classes == 32 || ctx().long_classes == 64) ? ctx().long_classes : 8;
+        k = std::max<int64_t>(k, long_lds_codes((int)value_bytes, false, LONG_LDS_WORDS) / 8 * ncls);
+    }
     k = std::min<int64_t>(k, n / 4);
     k &= ~(int64_t)63;
     if (k < 64) return;
@@ -122,15 +127,19 @@ static void report_phase_times(const long long *d_times, int64_t n_tiles)
 // `col_src` is the column array the kernels will index (hot-coded or original).
 static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
 {
-    if (A->split_state != 0 && (A->split_state < 0 || (A->split_hot == hot && A->split_kind == ctx().long_kernel))) return;
+    const int ncls_opt = (ctx().long_classes == 16 || ctx().long_classes == 32 || ctx().long_classes == 64) ? ctx().long_classes : 8;
+    // which long-row kernel this matrix is laid out for: option 3 (default) = class strips, except for BOOL matrices -- their
+    // products are terminal monoids (the BFS step), where the item kernel's per-row early exit wins
+    const int kind = ctx().long_kernel == 3 ? (A->type->code == TC_BOOL ? 1 : 2) : ctx().long_kernel;
+    if (A->split_state != 0 && (A->split_state < 0 || (A->split_hot == hot && A->split_kind == kind && (A->split_kind != 2 || A->strip_nseg == 0 || A->strip_ncls == ncls_opt)))) return;
     if (A->split_state == 1) {  // built against the other column coding (or for another long-row kernel): rebuild
         matrix_free(A->short_part);
         A->short_part = nullptr;
         dev_free(A->d_long_bits); dev_free(A->d_long_rows); dev_free(A->d_chunk_slot); dev_free(A->d_chunk_start); dev_free(A->d_chunk_len); dev_free(A->d_long_prefix);
         dev_free(A->d_lcol); dev_free(A->d_lval); dev_free(A->d_it_start); dev_free(A->d_it_len); dev_free(A->d_it_slot);
         dev_free(A->d_item_begin);
-        dev_free(A->d_sflag); dev_free(A->d_sseg0); dev_free(A->d_sslot);
-        A->d_sflag = nullptr; A->d_sseg0 = nullptr; A->d_sslot = nullptr; A->strip_nseg = 0;
+        dev_free(A->d_sstart); dev_free(A->d_sslot);
+        A->d_sstart = nullptr; A->d_sslot = nullptr; A->strip_nseg = 0;
         A->d_lcol = nullptr; A->d_lval = nullptr; A->d_it_start = nullptr; A->d_it_len = nullptr; A->d_it_slot = nullptr;
         A->d_item_begin = nullptr; A->long_nnz = 0; A->n_items = 0;
         A->d_long_prefix = nullptr;
@@ -139,7 +148,7 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
     A->split_state = -1;
     const int64_t m = (int64_t)A->nrows, nnz = A->nvals;
     if (nnz < ctx().split_min_nnz || m == 0 || (ctx().debug_flags & 128)) return;
-    const int min_len = ctx().split_min_len;
+    const int min_len = ctx().split_min_len > 0 ? ctx().split_min_len : (kind == 2 ? 64 : 256);  // (measured optima, scripts/gpu_r02_nc.sh)
     DevBuf<uint64_t> lbits(bits_words64((uint64_t)m));
     DevBuf<int64_t> slen(m + 1), lflag(m + 1), nchunk(m + 1);
     hipLaunchKernelGGL(k_split_classify, dim3((unsigned)ceil_div((int64_t)bits_words64((uint64_t)m) * 64 + 1, 256)), dim3(256), 0,
@@ -180,60 +189,88 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
             // sub-ranges per class: sized so that one sub-range of the operand image is ~2 MiB (half an XCD's L2; BOOL images are
             // bit-packed and fit as they are); measured on R-MAT scale 24 fp32: 4 sub-ranges -3 % per call, and rows need ~512
             // entries per sub-range or their items get too small (sub 8 from 2048 entries: +3 %)
+            const int ncls = (kind == 2 && (ctx().long_classes == 16 || ctx().long_classes == 32 || ctx().long_classes == 64))
+                                 ? ctx().long_classes : 8;
             unsigned sub = 1;
             if (ctx().long_sub > 0) sub = (unsigned)std::min(16, ctx().long_sub);
             else if (A->type->code != TC_BOOL)
-                while (sub < 16 && (int64_t)A->ncols * (int64_t)A->type->size > (int64_t)sub * 8 * (3ll << 20)) sub *= 2;
+                while (sub < 16 && (int64_t)A->ncols * (int64_t)A->type->size > (int64_t)sub * ncls * (3ll << 20)) sub *= 2;
             const int64_t sub_min_len = ctx().long_sub_min_len > 0 ? ctx().long_sub_min_len : 512 * (int64_t)sub;
-            const int64_t nv = 8 * (int64_t)sub * nl;
+            const int64_t nv = (int64_t)ncls * (int64_t)sub * nl;
             int bits = 1;
             while (((int64_t)1 << bits) < nv) bits++;
             DevBuf<uint64_t> keys(nnz_long), keys2(nnz_long);
             DevBuf<uint32_t> idx(nnz_long), idx2(nnz_long);
             hipLaunchKernelGGL(k_long_keys, dim3((unsigned)nl), dim3(256), 0, ctx().stream, (const int64_t *)A->d_ptr,
                                (const int64_t *)S->d_ptr, (const int32_t *)A->d_long_rows, col_src, nl, keys.p, idx.p,
-                               (unsigned)(hot ? A->hot_k : 0), (unsigned)std::max<int64_t>(1, ceil_div((int64_t)A->ncols, 8 * (int64_t)sub)),
-                               sub, sub_min_len);
+                               (unsigned)(hot ? A->hot_k : 0), (unsigned)std::max<int64_t>(1, ceil_div((int64_t)A->ncols, (int64_t)ncls * (int64_t)sub)),
+                               sub, sub_min_len, (unsigned)ncls);
             prim_sort_pairs_u64_u32(keys.p, keys2.p, idx.p, idx2.p, nnz_long, bits);
-            if (ctx().long_kernel == 2) {
-                // flat class strips (grb_mxv_strip.inc): the sorted entries laid out class by class in whole chunks, a flag per
-                // entry where a (class, sub-range, row) segment starts, the accumulator slot of every segment
-                DevBuf<int64_t> cstart(9), cbase(9);
-                hipLaunchKernelGGL(k_strip_bounds, dim3(1), dim3(64), 0, ctx().stream, (const uint64_t *)keys2.p, nnz_long, nl, sub,
-                                   cstart.p, cbase.p);
-                int64_t h_cbase[9];
-                d2h(h_cbase, cbase.p, sizeof(h_cbase));
-                const int64_t padded = h_cbase[8], nch = padded / STRIP_CH;
+            if (kind == 2) {
+                // flat class strips (grb_mxv_strip.inc): segments = runs of equal keys; every segment padded to a multiple of 8
+                // entries, every class to whole chunks of 512
+                const int64_t nblk = ceil_div(nnz_long, STRIP_CH);
+                DevBuf<int64_t> blk(nblk + 1);
+                hipLaunchKernelGGL(k_strip_count, dim3((unsigned)nblk), dim3(STRIP_CH), 0, ctx().stream, (const uint64_t *)keys2.p, nnz_long, blk.p);
+                prim_exclusive_sum_i64(blk.p, blk.p, nblk + 1);
+                int64_t nseg = 0;
+                d2h(&nseg, blk.p + nblk, 8);
+                if (nseg >= 0x7ffffff0ll) fail(GrB_NOT_IMPLEMENTED, "class strips: too many segments for 32-bit numbering");
+                DevBuf<int64_t> seg_first(nseg + 1), off(nseg + 1);
+                hipLaunchKernelGGL(k_strip_seg_fill, dim3((unsigned)nblk), dim3(STRIP_CH), 0, ctx().stream, (const uint64_t *)keys2.p, nnz_long,
+                                   (const int64_t *)blk.p, seg_first.p);
+                hipLaunchKernelGGL(k_strip_plen, dim3((unsigned)ceil_div(nseg + 1, 256)), dim3(256), 0, ctx().stream, (const int64_t *)seg_first.p,
+                                   nseg, off.p);
+                prim_exclusive_sum_i64(off.p, off.p, nseg + 1);
+                DevBuf<int64_t> sc(65), raw(65), cshift(64);
+                hipLaunchKernelGGL(k_strip_class_bounds, dim3(1), dim3(128), 0, ctx().stream, (const uint64_t *)keys2.p, (const int64_t *)seg_first.p,
+                                   nseg, nl, sub, (const int64_t *)off.p, sc.p, raw.p, ncls);
+                int64_t h_raw[65], h_shift[64], h_cb[65];
+                d2h(h_raw, raw.p, sizeof(int64_t) * (size_t)(ncls + 1));
+                int64_t base = 0;
+                for (int c = 0; c < ncls; c++) {
+                    h_cb[c] = base / STRIP_CH;
+                    h_shift[c] = base - h_raw[c];
+                    base += ceil_div(h_raw[c + 1] - h_raw[c], STRIP_CH) * STRIP_CH;
+                }
+                h_cb[ncls] = base / STRIP_CH;
+                const int64_t padded = base, nch = padded / STRIP_CH;
+                h2d(cshift.p, h_shift, sizeof(int64_t) * (size_t)ncls);
                 A->cls_lds_lim = (int)std::min<int64_t>(hot ? A->hot_k : 0,
-                                                        long_lds_codes((int)A->type->size, A->type->code == TC_BOOL, LONG_LDS_WORDS));
+                                                        long_lds_codes((int)A->type->size, A->type->code == TC_BOOL, LONG_LDS_WORDS) / 8 * ncls);
                 if (padded > 0 && padded < 0x7fffffff0ll) {
                     A->d_lcol = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)padded);
                     A->d_lval = A->iso ? nullptr : dev_alloc(A->type->size * (size_t)padded);
-                    A->d_sflag = (unsigned char *)dev_alloc((size_t)padded / 8);
-                    DevBuf<int64_t> ccnt(nch + 1, true);
+                    A->d_sstart = (unsigned long long *)dev_alloc(sizeof(unsigned long long) * (size_t)nch);
+                    A->d_sslot = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)(padded / 8));
+                    GRB_HIP(hipMemsetAsync(A->d_sslot, 0xff, sizeof(int32_t) * (size_t)(padded / 8), ctx().stream));
+                    GRB_HIP(hipMemsetAsync(A->d_lcol, 0xff, sizeof(int32_t) * (size_t)padded, ctx().stream));
+                    if (A->d_lval) GRB_HIP(hipMemsetAsync(A->d_lval, 0, A->type->size * (size_t)padded, ctx().stream));
+                    GRB_HIP(hipMemsetAsync(A->d_sstart, 0, sizeof(unsigned long long) * (size_t)nch, ctx().stream));
                     GRB_DISPATCH_TYPE(A->type->code, T, {
-                        hipLaunchKernelGGL((k_strip_place<T>), dim3((unsigned)(padded / 256)), dim3(256), 0, ctx().stream,
-                                           (const uint64_t *)keys2.p, (const uint32_t *)idx2.p, (const int64_t *)cstart.p,
-                                           (const int64_t *)cbase.p, padded, col_src, (const T *)A->d_val, A->iso ? 1 : 0,
-                                           A->cls_lds_lim, A->d_lcol, (T *)A->d_lval, A->d_sflag, (unsigned long long *)ccnt.p);
+                        hipLaunchKernelGGL((k_strip_place<T>), dim3((unsigned)nblk), dim3(STRIP_CH), 0, ctx().stream, (const uint64_t *)keys2.p,
+                                           (const uint32_t *)idx2.p, nnz_long, (const int64_t *)blk.p, (const int64_t *)seg_first.p,
+                                           (const int64_t *)off.p, (const int64_t *)cshift.p, nl, sub, col_src, (const T *)A->d_val,
+                                           A->iso ? 1 : 0, A->cls_lds_lim, ncls, A->d_lcol, (T *)A->d_lval, A->d_sstart, A->d_sslot);
                     })
-                    prim_exclusive_sum_i64(ccnt.p, ccnt.p, nch + 1);
-                    int64_t nseg = 0;
-                    d2h(&nseg, ccnt.p + nch, 8);
-                    if (nseg >= 0x7ffffff0ll) fail(GrB_NOT_IMPLEMENTED, "class strips: too many segments for 32-bit numbering");
-                    A->d_sseg0 = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)nch);
-                    A->d_sslot = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)std::max<int64_t>(nseg, 1));
-                    hipLaunchKernelGGL(k_strip_segs, dim3((unsigned)nch), dim3(STRIP_CH), 0, ctx().stream, (const unsigned char *)A->d_sflag,
-                                       (const int64_t *)ccnt.p, (const uint64_t *)keys2.p, (const int64_t *)cstart.p,
-                                       (const int64_t *)cbase.p, nl, A->d_sseg0, A->d_sslot);
-                    for (int c = 0; c < 9; c++) A->strip_cb[c] = h_cbase[c] / STRIP_CH;
+                    {
+                        int64_t h_end[64];
+                        for (int c = 0; c < ncls; c++) h_end[c] = h_cb[c + 1] * STRIP_CH;
+                        DevBuf<int64_t> cend(64);
+                        h2d(cend.p, h_end, sizeof(int64_t) * (size_t)ncls);
+                        hipLaunchKernelGGL(k_strip_pad_starts, dim3(1), dim3(64), 0, ctx().stream, (const int64_t *)sc.p, (const int64_t *)off.p,
+                                           (const int64_t *)cshift.p, (const int64_t *)cend.p, ncls, A->d_sstart);
+                        sync_stream();
+                    }
+                    for (int c = 0; c <= ncls; c++) A->strip_cb[c] = h_cb[c];
+                    A->strip_ncls = ncls;
                     A->strip_nseg = nseg;
                     A->long_nnz = nnz_long;
                     sync_stream();  // (the temporaries above are released at the end of this scope)
                 }
             }
-            DevBuf<int64_t> vptr(ctx().long_kernel == 2 ? 0 : nv + 1), icnt(ctx().long_kernel == 2 ? 0 : nv + 1);
-            if (ctx().long_kernel != 2) {
+            DevBuf<int64_t> vptr(kind == 2 ? 0 : nv + 1), icnt(kind == 2 ? 0 : nv + 1);
+            if (kind != 2) {
             hipLaunchKernelGGL(k_long_vptr, dim3((unsigned)ceil_div(nv + 1, 256)), dim3(256), 0, ctx().stream,
                                (const uint64_t *)keys2.p, nnz_long, nv, vptr.p);
             hipLaunchKernelGGL(k_long_item_count, dim3((unsigned)ceil_div(nv + 1, 256)), dim3(256), 0, ctx().stream,
@@ -290,7 +327,7 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
     A->n_long = nl;
     A->n_chunks = nc;
     A->split_hot = hot;
-    A->split_kind = ctx().long_kernel;
+    A->split_kind = kind;
     A->split_state = 1;
 }
 
@@ -354,13 +391,14 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
         const bool by_strip = A->split_kind == 2 && A->long_nnz > 0 && A->strip_nseg > 0;
         ctx().stats.long_entries = A->nvals - S->nvals;
         ctx().stats.long_segments = by_strip ? A->strip_nseg : 0;
-        const bool by_class = A->split_kind == 1 && ctx().long_kernel == 1 && A->long_nnz > 0;
+        const bool by_class = A->split_kind == 1 && A->long_nnz > 0 && A->n_items > 0;
         ctx().stats.long_kernel = by_strip ? 2 : (by_class ? 1 : 0);
         DevBuf<uint32_t> long_act((size_t)ceil_div(a.n_long, 64) * 2);
         a.long_act = long_act.p;
         hipLaunchKernelGGL((k_long_init<W>), dim3((unsigned)ceil_div(a.n_long, 256)), dim3(256), 0, ctx().stream, tl_val.p, tl_has.p,
                            a.n_long, monoid_identity<T, W>(a.monoid), a.long_rows, a.m_bits, a.has_mask, a.m_comp, long_act.p,
-                           ((by_class || by_strip) && a.u_full) ? 1 : 0);
+                           ((by_class || by_strip) && a.u_full) ? 1 : 0, (by_strip && acc_is_ordered<W>(a.monoid)) ? 1 : 0);
+        a.tl_ord = (by_strip && acc_is_ordered<W>(a.monoid)) ? 1 : 0;
         a.long_has_known = ((by_class || by_strip) && a.u_full) ? 1 : 0;
         a.tl_val = tl_val.p;
         a.tl_has = tl_has.p;
@@ -369,25 +407,16 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
         const bool compact = by_class && a.has_mask;
         DevBuf<int64_t> act_start(compact ? (size_t)A->n_items : 1), block_cnt(compact ? (size_t)ncb + 1 : 1), class_off(9);
         DevBuf<int32_t> act_len(compact ? (size_t)A->n_items : 1), act_slot(compact ? (size_t)A->n_items : 1);
-        DevBuf<uint64_t> strip_act((by_strip && a.has_mask) ? (size_t)((A->strip_nseg + 1 + 63) / 64 + 1) : 1);
         if (by_strip) {
             a.lcol = A->d_lcol;
             a.lval = A->d_lval;
             a.cls_lds_lim = A->cls_lds_lim;
-            a.strip_flag = A->d_sflag;
-            a.strip_seg0 = A->d_sseg0;
+            a.strip_start = A->d_sstart;
             a.strip_slot = A->d_sslot;
             a.strip_nseg = A->strip_nseg;
-            for (int c = 0; c < 9; c++) a.strip_cb[c] = A->strip_cb[c];
-            a.strip_act = nullptr;
-            if (a.has_mask) {
-                const int64_t nw = (A->strip_nseg + 1 + 63) / 64 + 1;
-                hipLaunchKernelGGL(k_strip_act, dim3((unsigned)ceil_div(nw * 64, 256)), dim3(256), 0, ctx().stream, (const int32_t *)A->d_sslot,
-                                   A->strip_nseg, (const uint32_t *)long_act.p, strip_act.p, nw);
-                a.strip_act = (const uint32_t *)strip_act.p;
-                ctx().stats.kernel_launches += 1;
-            }
-            const int64_t G = std::max<int64_t>(8, (int64_t)(ctx().num_cus / 8) * 8);
+            for (int c = 0; c <= A->strip_ncls; c++) a.strip_cb[c] = A->strip_cb[c];
+            a.strip_ncls = A->strip_ncls;
+            const int64_t G = std::max<int64_t>(A->strip_ncls, (int64_t)(ctx().num_cus / A->strip_ncls) * A->strip_ncls);
             hipLaunchKernelGGL((k_mxv_strip<T, MON, MUL, LONG_LDS_WORDS>), dim3((unsigned)G), dim3(LONG_BLOCK), 0, ctx().stream, a);
         } else if (by_class) {
             a.lcol = A->d_lcol;

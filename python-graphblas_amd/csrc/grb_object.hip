@@ -578,11 +578,9 @@ void matrix_invalidate_caches(GB_Matrix_opaque *A)
     dev_free(A->d_it_len);
     dev_free(A->d_it_slot);
     dev_free(A->d_item_begin);
-    dev_free(A->d_sflag);
-    dev_free(A->d_sseg0);
+    dev_free(A->d_sstart);
     dev_free(A->d_sslot);
-    A->d_sflag = nullptr;
-    A->d_sseg0 = nullptr;
+    A->d_sstart = nullptr;
     A->d_sslot = nullptr;
     A->strip_nseg = 0;
     dev_free(A->d_sell_perm);

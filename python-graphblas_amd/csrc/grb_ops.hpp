@@ -48,10 +48,13 @@ GRB_HD T apply_binop(int op, T a, T b)
         case OP_RMINUS: return (T)((U)b - (U)a);
         case OP_TIMES: return (T)((U)a * (U)b);
         case OP_MIN:
-            if constexpr (std::is_floating_point<T>::value) return (a != a) ? b : ((b != b) ? a : (a < b ? a : b));
+            // (fmin / fmax: a NaN operand is ignored -- one v_min / v_max instruction instead of compares and branches)
+            if constexpr (std::is_same<T, float>::value) return __builtin_fminf(a, b);
+            else if constexpr (std::is_same<T, double>::value) return __builtin_fmin(a, b);
             else return a < b ? a : b;
         case OP_MAX:
-            if constexpr (std::is_floating_point<T>::value) return (a != a) ? b : ((b != b) ? a : (a > b ? a : b));
+            if constexpr (std::is_same<T, float>::value) return __builtin_fmaxf(a, b);
+            else if constexpr (std::is_same<T, double>::value) return __builtin_fmax(a, b);
             else return a > b ? a : b;
         case OP_LOR: return (T)((a != (T)0) || (b != (T)0));
         case OP_LAND: return (T)((a != (T)0) && (b != (T)0));
@@ -246,6 +249,66 @@ __device__ __forceinline__ void atomic_combine(W *slot, W v, int monoid)
     } else {
         atomic_combine_cas<W>(slot, v, monoid);
     }
+}
+
+// ---- ordered-integer form of floating-point accumulators -------------------------------------------------------------
+// gfx950 has no 32-bit floating-point min / max atomic in global memory (atomicMin(float *) is a compare-and-swap loop with a
+// returned value); unsigned min / max are single fire-and-forget instructions.  The map below is strictly increasing from the
+// floats (NaN excluded: a NaN product is not emitted) to the unsigned integers, so MIN / MAX accumulators of the class-strip
+// kernel are kept in this form: initialised by k_long_init, combined by atomic_combine_ord, read back by acc_from_ord.
+__device__ __forceinline__ uint32_t ord_of(float v)
+{
+    const uint32_t u = __builtin_bit_cast(uint32_t, v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord_to_f32(uint32_t e)
+{
+    return __builtin_bit_cast(float, (e & 0x80000000u) ? (e & 0x7fffffffu) : ~e);
+}
+__device__ __forceinline__ uint64_t ord_of(double v)
+{
+    const uint64_t u = __builtin_bit_cast(uint64_t, v);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double ord_to_f64(uint64_t e)
+{
+    return __builtin_bit_cast(double, (e >> 63) ? (e & 0x7fffffffffffffffull) : ~e);
+}
+template <typename W> GRB_HD constexpr bool acc_is_ordered(int monoid)
+{
+    return (std::is_same<W, float>::value || std::is_same<W, double>::value) && (monoid == OP_MIN || monoid == OP_MAX);
+}
+// the stored form of accumulator value v / the value of a stored accumulator (ord = acc_is_ordered for the call's monoid)
+template <typename W> __device__ __forceinline__ W acc_to_stored(W v, bool ord)
+{
+    if constexpr (std::is_same<W, float>::value) return ord ? __builtin_bit_cast(float, ord_of(v)) : v;
+    else if constexpr (std::is_same<W, double>::value) return ord ? __builtin_bit_cast(double, ord_of(v)) : v;
+    else return v;
+}
+template <typename W> __device__ __forceinline__ W acc_from_stored(W s, bool ord)
+{
+    if constexpr (std::is_same<W, float>::value) return ord ? ord_to_f32(__builtin_bit_cast(uint32_t, s)) : s;
+    else if constexpr (std::is_same<W, double>::value) return ord ? ord_to_f64(__builtin_bit_cast(uint64_t, s)) : s;
+    else return s;
+}
+template <typename W> __device__ __forceinline__ void atomic_combine_ord(W *slot, W v, int monoid)
+{
+    if constexpr (std::is_same<W, float>::value) {
+        if (monoid == OP_MIN || monoid == OP_MAX) {
+            if (v != v) return;
+            if (monoid == OP_MIN) atomicMin((unsigned int *)slot, ord_of(v));
+            else atomicMax((unsigned int *)slot, ord_of(v));
+            return;
+        }
+    } else if constexpr (std::is_same<W, double>::value) {
+        if (monoid == OP_MIN || monoid == OP_MAX) {
+            if (v != v) return;
+            if (monoid == OP_MIN) atomicMin((unsigned long long *)slot, (unsigned long long)ord_of(v));
+            else atomicMax((unsigned long long *)slot, (unsigned long long)ord_of(v));
+            return;
+        }
+    }
+    atomic_combine<W>(slot, v, monoid);
 }
 
 // ---- presence-bit helpers -------------------------------------------------------------------------

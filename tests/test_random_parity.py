@@ -14,7 +14,7 @@ from tests.backend import DEVICES, bind
 TYPES = ["INT64", "FP32", "BOOL", "FP64", "INT8", "UINT16", "INT32"]
 import os
 
-DEFAULT_LONG_KERNEL = int(os.environ.get("GRB_LONG_KERNEL", "2"))  # what tests restore after forcing a long-row kernel
+DEFAULT_LONG_KERNEL = int(os.environ.get("GRB_LONG_KERNEL", "3"))  # what tests restore after forcing a long-row kernel
 
 
 @pytest.fixture(params=DEVICES)
@@ -500,8 +500,8 @@ def test_long_short_row_split(gb, seed):
         w(~mk.V if comp else mk.V, accum=accum, replace=bool(seed & 2)) << A.mxv(u, getattr(gb.semiring, sr))
         st = device.last_stats()  # init + long rows + short rows (with the write rule of every row); PAIR over a full u reads no rows
         assert st["kernel_launches"] >= 3 or st["method"] == 5
-        assert st["method"] == 5 or (st["long_kernel"] == DEFAULT_LONG_KERNEL and st["long_entries"] > 0)
-        assert DEFAULT_LONG_KERNEL != 2 or st["method"] == 5 or st["long_segments"] > 0
+        want = DEFAULT_LONG_KERNEL if DEFAULT_LONG_KERNEL != 3 else (1 if tname == "BOOL" else 2)
+        assert st["method"] == 5 or (st["long_kernel"] == want and st["long_entries"] > 0)
         same_vec(w, exp)
         x = gb.Vector.from_coo(xi, xv, dtype=tname, size=m)
         same_vec(x.vxm(A, getattr(gb.semiring, sr)).new(), exp_t)
@@ -518,7 +518,7 @@ def test_long_short_row_split(gb, seed):
         same_vec(q, O.mxv(ob, oq, sr, w=oq, mask=O.OVec(m, mi, mv, "BOOL"), mask_comp=True, mask_struct=True, replace=True))
     finally:
         _lib.lib.GrX_option_set(b"split_min_nnz", 1 << 22)
-        _lib.lib.GrX_option_set(b"split_min_len", 256)
+        _lib.lib.GrX_option_set(b"split_min_len", 0)
         _lib.lib.GrX_option_set(b"push_mode", 1)
         _lib.lib.GrX_option_set(b"short_kernel", 1)
         _lib.lib.GrX_option_set(b"sell_sigma", 4096)
@@ -573,7 +573,7 @@ def test_long_rows_many_chunks(gb, seed, request):
         same_vec(A.mxv(u, getattr(gb.semiring, sr)).new(), exp_nomask)
     finally:
         _lib.lib.GrX_option_set(b"split_min_nnz", 1 << 22)
-        _lib.lib.GrX_option_set(b"split_min_len", 256)
+        _lib.lib.GrX_option_set(b"split_min_len", 0)
         _lib.lib.GrX_option_set(b"push_mode", 1)
         _lib.lib.GrX_option_set(b"long_kernel", DEFAULT_LONG_KERNEL)
         _lib.lib.GrX_option_set(b"long_sub", 0)
@@ -829,7 +829,7 @@ def test_reductions_over_split_matrices(gb, seed):
     finally:
         _lib.lib.GrX_option_set(b"debug_flags", 0)
         _lib.lib.GrX_option_set(b"split_min_nnz", 1 << 22)
-        _lib.lib.GrX_option_set(b"split_min_len", 256)
+        _lib.lib.GrX_option_set(b"split_min_len", 0)
 
 
 @pytest.mark.parametrize("seed", range(28))
@@ -886,7 +886,7 @@ def test_sell_short_rows(gb, seed):
         same_vec(w, exp)
     finally:
         _lib.lib.GrX_option_set(b"split_min_nnz", 1 << 22)
-        _lib.lib.GrX_option_set(b"split_min_len", 256)
+        _lib.lib.GrX_option_set(b"split_min_len", 0)
         _lib.lib.GrX_option_set(b"push_mode", 1)
         _lib.lib.GrX_option_set(b"short_kernel", 1)
         _lib.lib.GrX_option_set(b"sell_sigma", 4096)
@@ -927,7 +927,7 @@ def test_sell_layout(gb, dummy):
             assert np.array_equal(gi, np.flatnonzero(deg)) and np.array_equal(gv, deg[deg > 0].astype(float))
         finally:
             _lib.lib.GrX_option_set(b"split_min_nnz", 1 << 22)
-            _lib.lib.GrX_option_set(b"split_min_len", 256)
+            _lib.lib.GrX_option_set(b"split_min_len", 0)
             _lib.lib.GrX_option_set(b"short_kernel", 1)
             _lib.lib.GrX_option_set(b"sell_sigma", 4096)
 
@@ -975,7 +975,7 @@ def test_mixed_types_unread_operands(gb, seed):
         same_vec(x.vxm(A, getattr(gb.semiring, sr)).new(), exp_t)
     finally:
         _lib.lib.GrX_option_set(b"split_min_nnz", 1 << 22)
-        _lib.lib.GrX_option_set(b"split_min_len", 256)
+        _lib.lib.GrX_option_set(b"split_min_len", 0)
         _lib.lib.GrX_option_set(b"push_mode", 1)
         _lib.lib.GrX_option_set(b"hot_min_cols", 1 << 20)
         _lib.lib.GrX_option_set(b"hot_k", 0)
