@@ -20,7 +20,11 @@ _BINARY_NAMES = ["first", "second", "pair", "oneb", "plus", "minus", "times", "m
 _COMPARISONS = {"eq", "ne", "gt", "lt", "ge", "le"}  # T x T -> BOOL: element-wise vector operations only
 _MONOID_NAMES = ["plus", "times", "min", "max", "any", "lor", "land", "lxor", "lxnor"]
 _BOOL_ONLY = {"lor", "land", "lxor", "lxnor"}
-_SYMBOLS = {"+": "plus", "*": "times", "-": "minus", "|": "lor", "&": "land", "^": "lxor", "==": "lxnor", "eq": "lxnor"}
+# symbol spellings per operator kind (reference core/operator/utils.py:347-370: "==" is binary.eq among the binary
+# operators and monoid.eq -- the BOOL-only lxnor -- among the monoids; the NAME "eq" always means binary.eq for a BinaryOp)
+_BINARY_SYMBOLS = {"+": "plus", "*": "times", "-": "minus", "|": "lor", "&": "land", "^": "lxor", "==": "eq", "!=": "ne",
+                   "<": "lt", ">": "gt", "<=": "le", ">=": "ge"}
+_MONOID_SYMBOLS = {"+": "plus", "*": "times", "|": "lor", "&": "land", "^": "lxor", "==": "lxnor", "eq": "lxnor"}
 # BOOL renames (SuiteSparse convention; reference semiring.py:568-587)
 _BOOL_RENAME = {"plus": "lor", "times": "land", "min": "land", "max": "lor", "minus": "lxor"}
 
@@ -229,11 +233,11 @@ def _from_string(string, kind):
         for sep in ("_", "."):
             if sep in s:
                 left, right = s.split(sep, 1)
-                left, right = _SYMBOLS.get(left, left), _SYMBOLS.get(right, right)
-                if hasattr(monoid, left) and hasattr(binary, right):
+                left, right = _MONOID_SYMBOLS.get(left, left), _BINARY_SYMBOLS.get(right, right)
+                if hasattr(monoid, left) and hasattr(binary, right) and hasattr(semiring, f"{left}_{right}"):
                     return getattr(semiring, f"{left}_{right}")
         raise ValueError(f"Unknown semiring string: {string!r}")
-    name = _SYMBOLS.get(s, s)
+    name = (_MONOID_SYMBOLS if kind == "monoid" else _BINARY_SYMBOLS).get(s, s)
     ns = monoid if kind == "monoid" else binary
     if not hasattr(ns, name):
         raise ValueError(f"Unknown {kind} string: {string!r}")

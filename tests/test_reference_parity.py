@@ -10,6 +10,18 @@ import pytest
 from tests.backend import DEVICES, bind
 
 
+
+def heq(a, b):
+    """Host-side equality of two Vectors / Matrices: same class, shape, dtype, and identical to_coo() tuples.  The literal tests
+    assert through this, not through the library's own device-side isequal (which has its own test below)."""
+    if type(a) is not type(b) or a.dtype != b.dtype:
+        return False
+    if getattr(a, "shape", None) != getattr(b, "shape", None) or getattr(a, "size", None) != getattr(b, "size", None):
+        return False
+    ta, tb = a.to_coo(), b.to_coo()
+    return len(ta) == len(tb) and all(x.dtype == y.dtype and x.tolist() == y.tolist() for x, y in zip(ta, tb))
+
+
 @pytest.fixture(params=DEVICES)
 def gb(request):
     return bind(request.param)
@@ -36,21 +48,21 @@ def test_mxv(gb, A, v):
     # graphblas/tests/test_matrix.py:389-392
     w = A.mxv(v, gb.semiring.plus_times).new()
     result = gb.Vector.from_coo([0, 1, 6], [5, 16, 13])
-    assert w.isequal(result)
+    assert heq(w, result)
 
 
 def test_vxm(gb, A, v):
     # graphblas/tests/test_vector.py:299-302  (explicit zero at index 3 is kept)
     w = v.vxm(A, gb.semiring.plus_times).new()
     result = gb.Vector.from_coo([0, 2, 3, 4, 5, 6], [3, 3, 0, 8, 14, 4])
-    assert w.isequal(result)
+    assert heq(w, result)
 
 
 def test_vxm_transpose(gb, A, v):
     # graphblas/tests/test_vector.py:305-308
     w = v.vxm(A.T, gb.semiring.plus_times).new()
     result = gb.Vector.from_coo([0, 1, 6], [5, 16, 13])
-    assert w.isequal(result)
+    assert heq(w, result)
 
 
 def test_vxm_nonsquare(gb, v):
@@ -59,9 +71,9 @@ def test_vxm_nonsquare(gb, v):
     u = gb.Vector(v.dtype, size=2)
     u().update(v.vxm(A, gb.semiring.min_plus))
     result = gb.Vector.from_coo([1], [21])
-    assert u.isequal(result)
+    assert heq(u, result)
     w1 = v.vxm(A, gb.semiring.min_plus).new()
-    assert w1.isequal(u)
+    assert heq(w1, u)
     v2 = gb.Vector.from_coo([0, 1], [1, 2])
     w2 = v2.vxm(A.T, gb.semiring.min_plus).new()
     assert w2.size == 7
@@ -75,23 +87,23 @@ def test_vxm_mask(gb, A, v):
     u = v.dup()
     u(struct_mask.S) << v.vxm(A, semiring.plus_times)
     result = Vector.from_coo([0, 1, 3, 4, 6], [3, 1, 0, 8, 0], size=7)
-    assert u.isequal(result)
+    assert heq(u, result)
     u = v.dup()
     u(~~struct_mask.S) << v.vxm(A, semiring.plus_times)
-    assert u.isequal(result)
+    assert heq(u, result)
     u = v.dup()
     u(~struct_mask.S) << v.vxm(A, semiring.plus_times)
     result2 = Vector.from_coo([2, 3, 4, 5, 6], [3, 1, 2, 14, 4], size=7)
-    assert u.isequal(result2)
+    assert heq(u, result2)
     u = v.dup()
     u(replace=True, mask=val_mask.V) << v.vxm(A, semiring.plus_times)
     result3 = Vector.from_coo([0, 3, 4], [3, 0, 8], size=7)
-    assert u.isequal(result3)
+    assert heq(u, result3)
     u = v.dup()
     u(replace=True, mask=~~val_mask.V) << v.vxm(A, semiring.plus_times)
-    assert u.isequal(result3)
+    assert heq(u, result3)
     w = v.vxm(A, semiring.plus_times).new(mask=val_mask.V)
-    assert w.isequal(result3)
+    assert heq(w, result3)
 
 
 def test_vxm_accum(gb, A, v):
@@ -100,19 +112,19 @@ def test_vxm_accum(gb, A, v):
     w1 = v.dup()
     w1(binary.plus) << v.vxm(A, semiring.plus_times)
     result = Vector.from_coo([0, 1, 2, 3, 4, 5, 6], [3, 1, 3, 1, 10, 14, 4], size=7)
-    assert w1.isequal(result)
+    assert heq(w1, result)
     w2 = v.dup()
     w2(monoid.plus) << v.vxm(A, semiring.plus_times)
-    assert w2.isequal(result)
+    assert heq(w2, result)
     w3 = v.dup()
     w3(accum=monoid.plus) << v.vxm(A, semiring.plus_times)
-    assert w3.isequal(result)
+    assert heq(w3, result)
     w4 = v.dup()
     w4("+") << v.vxm(A, semiring.plus_times)
-    assert w4.isequal(result)
+    assert heq(w4, result)
     w5 = v.dup()
     w5(accum="plus") << v.vxm(A, semiring.plus_times)
-    assert w5.isequal(result)
+    assert heq(w5, result)
 
 
 def test_parameterized_plus_plus(gb):
@@ -120,8 +132,8 @@ def test_parameterized_plus_plus(gb):
     A = gb.Matrix.from_coo([0, 0, 1, 1], [0, 1, 0, 1], [1, 2, 3, 4])
     x = gb.Vector.from_coo([0, 1], [10, 20])
     y = A.mxv(x, gb.semiring.plus_plus).new()
-    assert y.isequal(x.vxm(A.T, gb.semiring.plus_plus).new())
-    assert y.isequal(gb.Vector.from_coo([0, 1], [33, 37]))
+    assert heq(y, x.vxm(A.T, gb.semiring.plus_plus).new())
+    assert heq(y, gb.Vector.from_coo([0, 1], [33, 37]))
 
 
 def test_docs_mxv_vxm(gb):
@@ -130,14 +142,14 @@ def test_docs_mxv_vxm(gb):
     v = gb.Vector.from_coo([0, 1, 3], [10.0, 20.0, 40.0])
     w = gb.Vector(float, A.nrows)
     w << A.mxv(v, op="plus_times")
-    assert w.isequal(gb.Vector.from_coo([0, 1, 2], [40.0, 170.0, 20.0], size=4))
+    assert heq(w, gb.Vector.from_coo([0, 1, 2], [40.0, 170.0, 20.0], size=4))
     w2 = gb.Vector(float, A.nrows)
     w2 << gb.semiring.plus_times(A @ v)
-    assert w2.isequal(w)
+    assert heq(w2, w)
     B = gb.Matrix.from_coo([0, 0, 1, 1, 2, 2, 3, 3], [1, 2, 0, 1, 1, 2, 0, 1], [3.0, 2.0, 9.0, 6.0, 3.0, 1.0, 0.0, 5.0])
     u = gb.Vector(float, B.ncols)
     u << v.vxm(B, op="plus_plus")
-    assert u.isequal(gb.Vector.from_coo([0, 1, 2], [69.0, 84.0, 12.0]))
+    assert heq(u, gb.Vector.from_coo([0, 1, 2], [69.0, 84.0, 12.0]))
 
 
 def test_primer_sssp(gb):
@@ -149,7 +161,7 @@ def test_primer_sssp(gb):
         v(gb.op.min) << gb.semiring.min_plus(v @ G)
         if v.isequal(w):
             break
-    assert v.isequal(gb.Vector.from_coo([0, 1, 2, 3], [0.0, 2.0, 3.5, 4.0]))
+    assert heq(v, gb.Vector.from_coo([0, 1, 2, 3], [0.0, 2.0, 3.5, 4.0]))
 
 
 def test_semiring_handles(gb):
@@ -213,11 +225,11 @@ def test_roundtrips(gb):
     assert I.tolist() == r[order].tolist() and J.tolist() == c[order].tolist() and X.tolist() == x[order].tolist()
     Ap, Aj, Ax = M.to_csr()
     M2 = gb.Matrix.from_csr(Ap, Aj, Ax, ncols=33)
-    assert M2.isequal(M)
+    assert heq(M2, M)
     Cp, Ci, Cx = M.to_csc()
     M3 = gb.Matrix.from_csc(Cp, Ci, Cx, nrows=40)
-    assert M3.isequal(M)
-    assert M.T.new().T.new().isequal(M)
+    assert heq(M3, M)
+    assert heq(M.T.new().T.new(), M)
     d = rng.random(50)
     vd = gb.Vector.from_dense(d)
     assert vd.nvals == 50 and np.array_equal(vd.to_dense(), d)
@@ -292,7 +304,7 @@ def test_mxm(gb, A):
         [0, 2, 4, 6, 2, 3, 4, 5, 2, 1, 3, 5, 2, 5, 0, 2, 5],
         [9, 9, 16, 8, 20, 28, 12, 56, 1, 6, 9, 3, 7, 1, 21, 21, 26],
     )
-    assert C.isequal(result)
+    assert heq(C, result)
 
 
 def test_mxm_transpose(gb, A):
@@ -304,14 +316,14 @@ def test_mxm_transpose(gb, A):
         [0, 6, 1, 6, 2, 4, 3, 5, 6, 2, 4, 3, 5, 6, 0, 1, 3, 5, 6],
         [13, 21, 80, 24, 1, 7, 18, 3, 15, 7, 49, 3, 1, 5, 21, 24, 15, 5, 83],
     )
-    assert C.isequal(result)
+    assert heq(C, result)
     C << A.T.mxm(A, gb.semiring.plus_times)
     result2 = gb.Matrix.from_coo(
         [0, 0, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 6, 6],
         [0, 2, 1, 3, 0, 2, 3, 4, 1, 2, 3, 4, 2, 3, 4, 6, 5, 4, 6],
         [9, 9, 4, 6, 9, 35, 35, 15, 6, 35, 58, 21, 15, 21, 73, 32, 50, 32, 16],
     )
-    assert C.isequal(result2)
+    assert heq(C, result2)
 
 
 def test_mxm_nonsquare(gb):
@@ -322,7 +334,7 @@ def test_mxm_nonsquare(gb):
     C << A.mxm(B, gb.semiring.max_plus)
     assert C.to_coo()[2].tolist() == [33]
     C1 = A.mxm(B, gb.semiring.max_plus).new()
-    assert C1.isequal(C)
+    assert heq(C1, C)
     C2 = A.T.mxm(B.T, gb.semiring.max_plus).new()
     assert C2.nrows == 5
     assert C2.ncols == 5
@@ -340,7 +352,7 @@ def test_mxm_mask(gb, A):
         [1, 2, 3, 4, 6, 5, 0, 2, 3, 2, 5, 2, 2, 3, 4],
         [2, 9, 3, 8, 4, 1, 3, 3, 9, 7, 7, 1, 5, 7, 3],
     )
-    assert C.isequal(result)
+    assert heq(C, result)
     C = A.dup()
     C(~val_mask.V) << A.mxm(A, semiring.plus_times)
     result2 = Matrix.from_coo(
@@ -348,13 +360,13 @@ def test_mxm_mask(gb, A):
         [0, 4, 6, 2, 3, 4, 5, 2, 1, 5, 5, 0, 2, 5],
         [9, 16, 8, 20, 28, 12, 56, 1, 6, 3, 1, 21, 21, 26],
     )
-    assert C.isequal(result2)
+    assert heq(C, result2)
     C = A.dup()
     C(struct_mask.S, replace=True).update(A.mxm(A, semiring.plus_times))
     result3 = Matrix.from_coo([0, 3, 4], [2, 3, 2], [9, 9, 7], nrows=7, ncols=7)
-    assert C.isequal(result3)
+    assert heq(C, result3)
     C2 = A.mxm(A, semiring.plus_times).new(mask=struct_mask.S)
-    assert C2.isequal(result3)
+    assert heq(C2, result3)
     with pytest.raises(TypeError, match="Mask must be"):
         A.mxm(A).new(mask=struct_mask)  # would be okay if bool mask, but it's not
 
@@ -369,7 +381,7 @@ def test_mxm_accum(gb, A):
         [9, 2, 9, 3, 16, 8, 20, 28, 20, 56, 4, 1, 1, 3, 6, 3, 9, 3, 7, 7, 1, 1, 21, 26, 7, 3, 26],
     )
     # fmt: on
-    assert A.isequal(result)
+    assert heq(A, result)
 
 
 def test_docs_mxm_and_plus_plus(gb):
@@ -381,12 +393,12 @@ def test_docs_mxm_and_plus_plus(gb):
     C << A.mxm(B, op="min_plus")
     exp = gb.Matrix.from_coo([0, 0, 0, 1, 1, 1, 2, 2], [0, 1, 2, 0, 1, 2, 0, 1], [11.0, 8.0, 6.0, 4.25, 4.5, 2.5, 0.5, 5.5],
                              nrows=4, ncols=3)
-    assert C.isequal(exp)
+    assert heq(C, exp)
     C2 = gb.Matrix(float, A.nrows, B.ncols)
     C2 << gb.semiring.min_plus(A @ B)
-    assert C2.isequal(exp)
+    assert heq(C2, exp)
     A2 = gb.Matrix.from_coo([0, 0, 1, 1], [0, 1, 0, 1], [1, 2, 3, 4])
-    assert A2.mxm(A2, gb.semiring.plus_plus).new().isequal(gb.Matrix.from_coo([0, 0, 1, 1], [0, 1, 0, 1], [7, 9, 11, 13]))
+    assert heq(A2.mxm(A2, gb.semiring.plus_plus).new(), gb.Matrix.from_coo([0, 0, 1, 1], [0, 1, 0, 1], [7, 9, 11, 13]))
 
 
 # ---- the vector operations around the path -----------------------------------------------------
@@ -415,11 +427,11 @@ def test_assign_scalar_all_and_mask(gb, v):
     # graphblas/tests/test_vector.py:528-533, 544-562, 616-628
     w = gb.Vector.from_coo([0, 1, 2], [1, 1, 1])
     w[:] = gb.Scalar.from_value(9)
-    assert w.isequal(gb.Vector.from_coo([0, 1, 2], [9, 9, 9]))
+    assert heq(w, gb.Vector.from_coo([0, 1, 2], [9, 9, 9]))
     with pytest.raises(TypeError, match="Bad type for arg"):
         w[:] = object()
     w << 2
-    assert w.isequal(gb.Vector.from_coo([0, 1, 2], [2, 2, 2]))
+    assert heq(w, gb.Vector.from_coo([0, 1, 2], [2, 2, 2]))
     mask = gb.Vector.from_coo([1, 2, 5, 6], [0, 0, 1, 0])
     result = gb.Vector.from_coo([1, 3, 4, 5, 6], [1, 1, 2, 5, 0])
     for form in range(3):
@@ -430,20 +442,20 @@ def test_assign_scalar_all_and_mask(gb, v):
             w(mask.V) << 5
         else:
             w(mask.V)[:] << 5
-        assert w.isequal(result)
+        assert heq(w, result)
     result2 = gb.Vector.from_coo([0, 1, 2, 3, 4, 6], [5, 5, 5, 5, 5, 5])
     w = v.dup()
     w[:](~mask.V) << 5
-    assert w.isequal(result2)
+    assert heq(w, result2)
     w = v.dup()
     w(~mask.V) << 5
-    assert w.isequal(result2)
+    assert heq(w, result2)
     x = gb.Vector.from_coo([0, 1, 2], [1, 2, 3])
     m = gb.Vector.from_coo([0, 2], [False, True])
     x(m.V)[:] << 100
-    assert x.isequal(gb.Vector.from_coo([0, 1, 2], [1, 2, 100]))
+    assert heq(x, gb.Vector.from_coo([0, 1, 2], [1, 2, 100]))
     x(m.V, accum=gb.binary.plus)[:] << 1000
-    assert x.isequal(gb.Vector.from_coo([0, 1, 2], [1, 2, 1100]))
+    assert heq(x, gb.Vector.from_coo([0, 1, 2], [1, 2, 1100]))
 
 
 def test_reduce(gb, v):
@@ -504,20 +516,20 @@ def test_ewise_mult_and_add(gb, v):
     v2 = gb.Vector.from_coo([0, 3, 5, 6], [2, 3, 2, 1])
     result = gb.Vector.from_coo([3, 6], [3, 0])
     w = v.ewise_mult(v2, gb.binary.times).new()
-    assert w.isequal(result)
+    assert heq(w, result)
     w << v.ewise_mult(v2, gb.monoid.times)
-    assert w.isequal(result)
+    assert heq(w, result)
     with pytest.raises(TypeError, match="Expected type: BinaryOp, Monoid"):
         v.ewise_mult(v2, gb.semiring.plus_times)
     result = gb.Vector.from_coo([0, 1, 3, 4, 5, 6], [2, 1, 3, 2, 2, 1])
     w = v.ewise_add(v2, gb.binary.max).new()
-    assert w.isequal(result)
+    assert heq(w, result)
     w.update(v.ewise_add(v2, gb.monoid.max))
-    assert w.isequal(result)
+    assert heq(w, result)
     with pytest.raises(TypeError, match="Expected type: BinaryOp, Monoid"):
         v.ewise_add(v2, gb.semiring.max_times)
-    assert v.ewise_add(v2).new().isequal(v.ewise_add(v2, gb.monoid.plus).new())
-    assert v.ewise_add(v2).new().isequal(gb.Vector.from_coo([0, 1, 3, 4, 5, 6], [2, 1, 4, 2, 2, 1]))
+    assert heq(v.ewise_add(v2).new(), v.ewise_add(v2, gb.monoid.plus).new())
+    assert heq(v.ewise_add(v2).new(), gb.Vector.from_coo([0, 1, 3, 4, 5, 6], [2, 1, 4, 2, 2, 1]))
 
 
 def test_comparisons_and_isequal_on_device(gb, v):
@@ -540,15 +552,32 @@ def test_comparisons_and_isequal_on_device(gb, v):
         v(accum=gb.binary.eq) << v.ewise_mult(v2, gb.binary.plus)  # a comparison is not an accumulator
 
 
+def test_operator_strings_match_objects(gb):
+    """String spellings resolve like the reference's (core/operator/utils.py:347-370): "==" / "eq" name binary.eq for a
+    BinaryOp (T x T -> BOOL), the BOOL-only lxnor only for a monoid; the symbol and the object give the same result."""
+    u = gb.Vector.from_coo([0, 1], [2, 3])
+    w = gb.Vector.from_coo([0, 1], [3, 3])
+    want = u.ewise_mult(w, gb.binary.eq).new()
+    assert [x.tolist() for x in want.to_coo()] == [[0, 1], [False, True]]
+    for spelling in ("eq", "=="):
+        assert heq(u.ewise_mult(w, spelling).new(), want)
+    for sym, name in (("+", "plus"), ("*", "times"), ("-", "minus"), ("<", "lt"), (">=", "ge"), ("!=", "ne")):
+        assert heq(u.ewise_mult(w, sym).new(), u.ewise_mult(w, getattr(gb.binary, name)).new())
+    from graphblas_amd import operators
+
+    assert operators._from_string("==", "monoid") is gb.monoid.lxnor
+    assert operators._from_string("min.+", "semiring") is gb.semiring.min_plus
+
+
 def test_reduce_rowwise_columnwise(gb, A):
     # graphblas/tests/test_matrix.py:1355-1360, 1648-1653
     result = gb.Vector.from_coo([0, 1, 2, 3, 4, 5, 6], [5, 12, 1, 6, 7, 1, 15])
-    assert A.reduce_rowwise(gb.monoid.plus).new().isequal(result)
-    assert A.reduce_rowwise(gb.binary.plus).new().isequal(result)
-    assert A.T.reduce_columnwise(gb.monoid.plus).new().isequal(result)
+    assert heq(A.reduce_rowwise(gb.monoid.plus).new(), result)
+    assert heq(A.reduce_rowwise(gb.binary.plus).new(), result)
+    assert heq(A.T.reduce_columnwise(gb.monoid.plus).new(), result)
     result = gb.Vector.from_coo([0, 1, 2, 3, 4, 5, 6], [3, 2, 9, 10, 11, 8, 4])
-    assert A.reduce_columnwise(gb.monoid.plus).new().isequal(result)
-    assert A.T.reduce_rowwise(gb.binary.plus).new().isequal(result)
+    assert heq(A.reduce_columnwise(gb.monoid.plus).new(), result)
+    assert heq(A.T.reduce_rowwise(gb.binary.plus).new(), result)
     with pytest.raises(TypeError, match="Expected type: Monoid"):
         A.reduce_rowwise(gb.binary.minus)
     # max / min and a masked, accumulated form
@@ -565,26 +594,26 @@ def test_reduce_rowwise_columnwise(gb, A):
 def test_reduce_agg(gb, A):
     # graphblas/tests/test_matrix.py:1364-1417 (the aggregators that are a monoid or one semiring mat-vec)
     result = gb.Vector.from_coo([0, 1, 2, 3, 4, 5, 6], [5, 12, 1, 6, 7, 1, 15])
-    assert A.reduce_rowwise(gb.agg.sum).new().isequal(result)
-    assert A.T.reduce_columnwise(gb.agg.sum).new().isequal(result)
+    assert heq(A.reduce_rowwise(gb.agg.sum).new(), result)
+    assert heq(A.T.reduce_columnwise(gb.agg.sum).new(), result)
     counts = gb.Vector.from_coo([0, 1, 2, 3, 4, 5, 6], [2, 2, 1, 2, 1, 1, 3])  # (= A.dup(bool).reduce_rowwise(plus[int]))
     w3 = A.reduce_rowwise(gb.agg.count).new()
     assert w3.dtype == gb.dtypes.INT64
-    assert w3.isequal(counts)
-    assert A.T.reduce_columnwise(gb.agg.count).new().isequal(counts)
+    assert heq(w3, counts)
+    assert heq(A.T.reduce_columnwise(gb.agg.count).new(), counts)
     result = gb.Vector.from_coo([0, 1, 2, 3, 4, 5, 6], [3, 2, 9, 10, 11, 8, 4])
-    assert A.reduce_columnwise(gb.agg.sum).new().isequal(result)
-    assert A.T.reduce_rowwise(gb.agg.sum).new().isequal(result)
+    assert heq(A.reduce_columnwise(gb.agg.sum).new(), result)
+    assert heq(A.T.reduce_rowwise(gb.agg.sum).new(), result)
     counts = gb.Vector.from_coo([0, 1, 2, 3, 4, 5, 6], [1, 1, 3, 2, 2, 2, 1])
-    assert A.reduce_columnwise(gb.agg.count).new().isequal(counts)
-    assert A.T.reduce_rowwise(gb.agg.count).new().isequal(counts)
+    assert heq(A.reduce_columnwise(gb.agg.count).new(), counts)
+    assert heq(A.T.reduce_rowwise(gb.agg.count).new(), counts)
     expected = gb.Vector.from_coo([0, 1, 2, 3, 4, 5, 6], [1, 1, 1, 1, 1, 1, 1])
-    assert A.reduce_rowwise(gb.agg.exists).new().isequal(expected)
-    assert A.reduce_columnwise(gb.agg.exists).new().isequal(expected)
+    assert heq(A.reduce_rowwise(gb.agg.exists).new(), expected)
+    assert heq(A.reduce_columnwise(gb.agg.exists).new(), expected)
     # rows without entries get no count (the product has no entry there)
     B = gb.Matrix.from_coo([0, 0, 3], [1, 2, 0], [1.5, 2.5, 3.5], nrows=5, ncols=4)
-    assert B.reduce_rowwise(gb.agg.count).new().isequal(gb.Vector.from_coo([0, 3], [2, 1], size=5))
-    assert B.reduce_columnwise(gb.agg.min).new().isequal(gb.Vector.from_coo([0, 1, 2], [3.5, 1.5, 2.5], size=4))
+    assert heq(B.reduce_rowwise(gb.agg.count).new(), gb.Vector.from_coo([0, 3], [2, 1], size=5))
+    assert heq(B.reduce_columnwise(gb.agg.min).new(), gb.Vector.from_coo([0, 1, 2], [3.5, 1.5, 2.5], size=4))
 
 
 def test_reduce_scalar(gb, A):
@@ -637,11 +666,11 @@ def test_power(gb, A):
         expected << gb.semiring.min_plus(A @ expected)
     result = A.power(0).new()
     idx = list(range(7))
-    assert result.isequal(gb.Matrix.from_coo(idx, idx, [1] * 7))
+    assert heq(result, gb.Matrix.from_coo(idx, idx, [1] * 7))
     result = A.power(0, gb.semiring.plus_min).new()
     identity = gb.monoid.min.identity(A.dtype)
     assert identity != 1
-    assert result.isequal(gb.Matrix.from_coo(idx, idx, [identity] * 7, dtype=A.dtype))
+    assert heq(result, gb.Matrix.from_coo(idx, idx, [identity] * 7, dtype=A.dtype))
     with pytest.raises(TypeError, match="must be a nonnegative integer"):
         A.power(1.5)
     with pytest.raises(ValueError, match="must be a nonnegative integer"):
@@ -689,7 +718,7 @@ def test_index_max(gb):
     w = gb.Vector.from_coo([0, 2], [1.5, 2.5], size=3)
     mk = gb.Vector.from_coo([0, 1], [True, True], size=3)
     w(mk.S, gb.binary.plus, replace=True) << B.mxv(u, gb.semiring.plus_times)
-    assert w.isequal(gb.Vector.from_coo([0], [1.5], size=3))
+    assert heq(w, gb.Vector.from_coo([0], [1.5], size=3))
     x = gb.Vector(float, 3)
     y = x.vxm(B, gb.semiring.min_plus).new()
     assert y.size == gb.MAX_SIZE and y.nvals == 0
