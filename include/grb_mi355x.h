@@ -259,12 +259,11 @@ typedef struct {
 } GrX_Stats;
 GrB_Info GrX_last_stats(GrX_Stats *stats);
 /* Tuning / diagnostics knobs (also read from the environment at GrB_init as GRB_<NAME upper-case>):
- *   "debug_flags"   kernel ablation switches for benchmarking; non-zero values make results WRONG on purpose
- *                   (1 skips the x gathers, 2 the A staging loads, 4 the epilogue, 8192 the gathers of the long rows,
- *                   16384 / 32768 fold every gather into 2^19 / 2^15 entries); the ones that keep results right:
- *                   64 non-temporal entry loads, 2048 no (presence, value) packing for BOOL, 4096 no LDS-resident head,
- *                   65536 no row-length path for (monoid, PAIR) over a full operand, 131072 no next-window prefetch,
- *                   262144 no early exit of the terminal monoids in the long-row kernel
+ *   "debug_flags"   path selectors that keep results right: 128 no long/short row split, 256 no LDS bitmap in the symbolic
+ *                   SpGEMM pass, 2048 no (presence, value) packing for BOOL, 65536 no row-length path for (monoid, PAIR) over a
+ *                   full operand; any other bit is GrB_INVALID_VALUE.  The kernel ablation switches of the benchmark scripts
+ *                   (some make results WRONG on purpose) exist only in a -DGRB_ABLATE build (`make -C csrc ablate`, and the
+ *                   emulator build of the CPU test tier), never in the shipped library.
  *   "pull_ipt"      merge items per thread of the pull SpMV (0 = default)
  *   "hot_min_cols"  matrices with at least this many columns get a hot-column table for the pull SpMV
  *   "hot_k"         entries of that table (0 = sized to ~2 MiB of x values)

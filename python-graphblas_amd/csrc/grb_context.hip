@@ -11,6 +11,17 @@
 
 namespace grb {
 
+// "debug_flags": the shipped library only knows the switches that choose between two correct paths on the host side
+// (128 no long/short row split, 256 no LDS bitmap in the symbolic SpGEMM pass, 2048 no (presence, value) packing, 65536 no
+// row-length path); the kernel ablation switches -- some of which make results wrong on purpose -- are compiled in by
+// -DGRB_ABLATE only (make ablate; the emulator build of the CPU test tier).
+#ifdef GRB_ABLATE
+static constexpr int DEBUG_FLAGS_MASK = ~0;
+#else
+static constexpr int DEBUG_FLAGS_MASK = 128 | 256 | 2048 | 65536;
+#endif
+
+
 Context &ctx()
 {
     static Context c;
@@ -172,7 +183,7 @@ extern "C" GrB_Info GrB_init(GrB_Mode mode)
     }
     (void)hipGetLastError();
     if (hipEventCreate(&c.ev0) != hipSuccess || hipEventCreate(&c.ev1) != hipSuccess) return GrB_PANIC;
-    if (const char *e = getenv("GRB_DEBUG_FLAGS")) c.debug_flags = atoi(e);
+    if (const char *e = getenv("GRB_DEBUG_FLAGS")) c.debug_flags = atoi(e) & DEBUG_FLAGS_MASK;
     if (const char *e = getenv("GRB_PULL_IPT")) c.tune_pull_ipt = atoi(e);
     if (const char *e = getenv("GRB_HOT_MIN_COLS")) c.hot_min_cols = atoll(e);
     if (const char *e = getenv("GRB_HOT_K")) c.hot_k = atoll(e);
@@ -259,7 +270,10 @@ extern "C" GrB_Info GrX_option_set(const char *name, int64_t value)
     if (!name) return GrB_NULL_POINTER;
     Context &c = ctx();
     const std::string n(name);
-    if (n == "debug_flags") c.debug_flags = (int)value;
+    if (n == "debug_flags") {
+        if ((int)value & ~DEBUG_FLAGS_MASK) return GrB_INVALID_VALUE;  // kernel ablation switches exist in -DGRB_ABLATE builds only
+        c.debug_flags = (int)value;
+    }
     else if (n == "pull_ipt") c.tune_pull_ipt = (int)value;
     else if (n == "hot_min_cols") c.hot_min_cols = value;
     else if (n == "hot_k") c.hot_k = value;

@@ -10,7 +10,7 @@ pids=()
 for f in "$SRC"/*.hip; do
   o="$HERE/obj/$(basename "${f%.hip}").o"
   if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ -n "$(find "$SRC" "$HERE/hip" "$HERE/rocprim" "$ROOT/include" -newer "$o" \( -name '*.hpp' -o -name '*.h' -o -name '*.inc' \) | head -1)" ]; then
-    g++ -O1 -g -std=c++17 -fPIC -x c++ -I"$HERE" -I"$ROOT/include" -I"$SRC" -Wno-attributes -w -c "$f" -o "$o" &
+    g++ -O1 -g -std=c++17 -fPIC -DGRB_ABLATE -x c++ -I"$HERE" -I"$ROOT/include" -I"$SRC" -Wno-attributes -w -c "$f" -o "$o" &
     pids+=($!)
   fi
 done
