@@ -277,8 +277,10 @@ def test_count_aggregator_and_power_at_scale(gb):
 
 
 @pytest.mark.gpu
-def test_row_block_of_a_sharded_graph(gb):
-    """One rank's share of the 8-way row-sharded scale-22 graph (a 524 288 x 4 194 304 block: hot-column table, long / short row
+@pytest.mark.parametrize("scale,world,rank", [(22, 8, 5), (24, 16, 11)])
+def test_row_block_of_a_sharded_graph(gb, scale, world, rank):
+    """(scale 24: a 16th of the headline graph -- 1 Mi x 16 Mi, 16 M entries, the layout of the bench call with 2 sub-ranges per
+    class -- against the CPU oracle.)  One rank's share of the 8-way row-sharded scale-22 graph (a 524 288 x 4 194 304 block: hot-column table, long / short row
     split, sub-ranged long rows -- the shapes `bench.py --gpus 8` runs): the masked min_plus and lor_land steps of the block are
     bit-exact against the CPU oracle and equal to the block's rows of the single-GPU product."""
     import torch
@@ -286,7 +288,6 @@ def test_row_block_of_a_sharded_graph(gb):
     from graphblas_amd import device, synthetic
     from oracle import grb_oracle as O
 
-    scale, world, rank = 22, 8, 5
     n = 1 << scale
     rows = n // world
     lo, hi = rank * rows, (rank + 1) * rows
@@ -297,7 +298,7 @@ def test_row_block_of_a_sharded_graph(gb):
     col_b, val_b = col[e0:e1].contiguous(), vals[e0:e1].contiguous()
     A = device.matrix_from_device_csr(indptr, col, vals, n, n, "FP32")
     B = device.matrix_from_device_csr(ip_b, col_b, val_b, rows, n, "FP32")
-    rng = np.random.default_rng(22)
+    rng = np.random.default_rng(scale)
     uv = rng.integers(0, 1000, n).astype(np.float32)
     vi = np.flatnonzero(rng.random(n) < 0.5)
     u = gb.Vector.from_coo(np.arange(n), uv, dtype="FP32", size=n)
@@ -328,3 +329,59 @@ def test_row_block_of_a_sharded_graph(gb):
                  mask_comp=True, mask_struct=True, replace=True)
     bi, bv = nxt.to_coo()
     assert np.array_equal(bi.astype(np.int64), expb.idx) and np.array_equal(bv, expb.vals)
+
+
+
+@pytest.mark.gpu
+def test_scale24_headline_calls(gb):
+    """The two calls bench.py times, at full size (R-MAT scale 24, 263 M entries): the masked SSSP relaxation
+    w<~visited.S> = min(w, A min.+ u) and the BFS level step q<~visited.S, replace> = A lor.land q, checked against torch
+    segment reductions of the same products (min over integer-valued fp32 sums is exact: bit for bit); then the relaxation
+    once more with real-valued U[0,1) weights and distances (fp32 sums of two terms, min exact: still bit for bit)."""
+    import torch
+
+    from graphblas_amd import device, synthetic
+
+    scale = 24
+    n = 1 << scale
+    indptr, col = synthetic.rmat_csr(scale, device="cuda")
+    rows = torch.repeat_interleave(torch.arange(n, device="cuda"), indptr[1:] - indptr[:-1])
+    cl = col.long()
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(99)
+    visited = torch.rand(n, generator=gen, device="cuda") < 0.5
+    vis = device.vector_from_device(torch.ones(n, dtype=torch.bool, device="cuda"), present=visited)
+
+    def bits(words):
+        return torch.from_numpy(np.unpackbits(words.cpu().numpy().view(np.uint8), bitorder="little")[:n].astype(bool)).cuda()
+
+    for weights in ("integer", "real"):
+        if weights == "integer":
+            vals = synthetic.edge_weights(col, scale)
+            dist = torch.randint(0, 1000, (n,), generator=gen, device="cuda").to(torch.float32)
+        else:
+            vals = torch.rand(col.numel(), generator=gen, device="cuda", dtype=torch.float32)
+            dist = torch.rand(n, generator=gen, device="cuda", dtype=torch.float32) * 8
+        A = device.matrix_from_device_csr(indptr, col, vals, n, n, "FP32")
+        u = device.vector_from_device(dist)
+        w = device.vector_from_device(dist.clone())
+        w(~vis.S, accum=gb.binary.min) << A.mxv(u, gb.semiring.min_plus)
+        st = device.last_stats()
+        assert st["long_kernel"] == 2 and st["long_entries"] > 100_000_000 and st["hot_k"] > 0
+        ref = torch.full((n,), float("inf"), device="cuda").scatter_reduce(0, rows, vals + dist[cl], "amin")
+        exp = torch.where(~visited, torch.minimum(dist, ref), dist)
+        wv, wb = device.vector_device_views(w)
+        assert bool(bits(wb).all()) and torch.equal(wv, exp)
+        del A, u, w, ref, exp
+    one = torch.ones(1, dtype=torch.bool, device="cuda")
+    Ab = device.matrix_from_device_csr(indptr, col, one, n, n, "BOOL", iso=True)
+    frontier = torch.rand(n, generator=gen, device="cuda") < 0.3
+    q = device.vector_from_device(torch.ones(n, dtype=torch.bool, device="cuda"), present=frontier)
+    nxt = device.vector_from_device(torch.ones(n, dtype=torch.bool, device="cuda"), present=frontier)
+    nxt(~vis.S, replace=True) << Ab.mxv(q, gb.semiring.lor_land)
+    assert device.last_stats()["long_kernel"] == 1
+    hit = torch.zeros(n, dtype=torch.bool, device="cuda")
+    hit.index_put_((rows[frontier[cl]],), torch.tensor(True, device="cuda"))
+    nv, nb = device.vector_device_views(nxt)
+    got = bits(nb)
+    assert torch.equal(got, hit & ~visited) and bool(nv[got].all())
