@@ -258,6 +258,8 @@ typedef struct {
     int32_t reserved_;
 } GrX_Stats;
 GrB_Info GrX_last_stats(GrX_Stats *stats);
+/* Device bytes of the SpMV layouts cached with A so far (hot-coded columns, short part, long-row strips / items). */
+GrB_Info GrX_Matrix_cache_bytes(const GrB_Matrix A, uint64_t *bytes);
 /* Tuning / diagnostics knobs (also read from the environment at GrB_init as GRB_<NAME upper-case>):
  *   "debug_flags"   path selectors that keep results right: 128 no long/short row split, 256 no LDS bitmap in the symbolic
  *                   SpGEMM pass, 2048 no (presence, value) packing for BOOL, 65536 no row-length path for (monoid, PAIR) over a
@@ -269,6 +271,8 @@ GrB_Info GrX_last_stats(GrX_Stats *stats);
  *   "hot_k"         entries of that table (0 = sized to ~2 MiB of x values)
  *   "split_min_nnz" matrices with at least this many entries get the long/short row split of the pull SpMV
  *   "split_min_len" a row is "long" from this many entries (default 0 = 64 for the class strips, 256 for the item kernel)
+ *   "lazy_layout"   1 (default): the cached SpMV layouts of a matrix with at least "lazy_min_nnz" (4 Mi) entries are built at its
+ *                   second pull product; the first one runs on the CSR arrays as they are.  0: built at the first product.
  *   "long_kernel"   layout / kernel of the long rows: 3 (default) class strips, items for BOOL matrices; 2 class strips (k_mxv_strip);
  *                   1 class-partitioned items (k_mxv_long_grp); 0 chunks straight from the CSR arrays (k_mxv_long)
  *   "long_classes"  column classes of the class strips: 8, 16 (default), 32 or 64 distinct LDS heads across the chip

@@ -47,12 +47,27 @@ def build():
     return so
 
 
+_MAX_THREADS = None
+
+
 def lib():
-    global _LIB
+    global _LIB, _MAX_THREADS
     if _LIB is None:
         _LIB = ctypes.CDLL(build())
         _LIB.grbo_num_threads.restype = ctypes.c_int
+        _MAX_THREADS = int(_LIB.grbo_num_threads())
     return _LIB
+
+
+def use_threads(work: int):
+    """Size the OpenMP team to the work of the next call (one thread per 64 Ki units): waking a team of hundreds of threads for a
+    50-entry test matrix costs 0.2 s per call on a large host -- 300 calls of it dominated the GPU test tier."""
+    L = lib()
+    L.grbo_set_num_threads(int(max(1, min(_MAX_THREADS, 1 + int(work) // 65536))))
+
+
+def use_all_threads():
+    lib().grbo_set_num_threads(int(_MAX_THREADS))
 
 
 def type_name(dtype) -> str:
@@ -252,6 +267,7 @@ def mxv(A: OMat, u: OVec, semiring="plus_times", *, w: OVec | None = None, out_t
     row_active = None
     if skip_masked_rows and mt is not None:
         row_active = (mt == 0).astype(np.uint8) if mask_comp else mt.copy()
+    use_threads(A.indices.size + A.nrows)
     rc = lib().grbo_mxv(TYPE_CODES[st], OP_CODES[monoid], OP_CODES[mult], ctypes.c_int64(A.nrows),
                         _p(A.indptr), _p(A.indices), _p(Ax), 0, _p(u_has), _p(u_val), _p(row_active),
                         _p(t_has), _p(t_val))
@@ -306,6 +322,7 @@ def mxm_product(A: OMat, B: OMat, semiring="plus_times", filt: OMat | None = Non
     Tp = ctypes.POINTER(ctypes.c_int64)()
     Tj = ctypes.POINTER(ctypes.c_int64)()
     Tx = ctypes.c_void_p()
+    use_threads(16 * (A.indices.size + B.indices.size) + A.nrows)
     rc = lib().grbo_mxm(TYPE_CODES[st], OP_CODES[monoid], OP_CODES[mult], ctypes.c_int64(A.nrows),
                         ctypes.c_int64(B.ncols), _p(A.indptr), _p(A.indices), _p(Ax), 0,
                         _p(B.indptr), _p(B.indices), _p(Bx), 0,
@@ -360,6 +377,7 @@ def vec_assign_scalar(w: OVec, value, *, mask: OVec | None = None, mask_comp=Fal
                       replace=False) -> OVec:
     """w<mask, replace>[:] = accum(w, value): GraphBLAS C API 2.0 GrB_Vector_assign with a scalar and GrB_ALL (the
     reference's ``w(mask)[:] << s``, core/vector.py:1979-2035) -- T is ``value`` at every index, then the write rule."""
+    use_threads(w.n)
     n = w.size
     if mask is not None and mask.size != n:
         raise ValueError("DimensionMismatch")
@@ -378,6 +396,7 @@ def vec_assign_scalar(w: OVec, value, *, mask: OVec | None = None, mask_comp=Fal
 def vec_reduce(u: OVec, monoid: str):
     """Fold of the stored values with ``monoid`` in u's type, ``None`` when u is empty (GrB_Vector_reduce; reference
     core/vector.py:1635-1684).  Integers wrap like the C types; floating-point sums are left-to-right."""
+    use_threads(u.n)
     if u.idx.size == 0:
         return None
     v = u.vals
@@ -400,6 +419,7 @@ def vec_reduce(u: OVec, monoid: str):
 def vec_ewise(u: OVec, v: OVec, binop: str, *, union: bool) -> OVec:
     """T = u (op) v on the union (eWiseAdd: single entries pass through) or the intersection (eWiseMult) of the patterns, in
     the unified type (GraphBLAS C API 2.0 eWiseAdd / eWiseMult; reference core/vector.py:960-1150)."""
+    use_threads(u.n)
     if u.size != v.size:
         raise ValueError("DimensionMismatch")
     t = unify(u.tname, v.tname)
@@ -426,4 +446,6 @@ def mat_reduce_rows(A: OMat, monoid: str, *, columns=False) -> OVec:
 
 
 def num_threads() -> int:
-    return int(lib().grbo_num_threads())
+    """threads of a full-size call (the host's OpenMP default)"""
+    lib()
+    return int(_MAX_THREADS)

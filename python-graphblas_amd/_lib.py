@@ -134,6 +134,7 @@ def _declare(L):
     L.GrX_timer_start.argtypes = []
     L.GrX_timer_stop.argtypes = [P(ctypes.c_float)]
     L.GrX_last_stats.argtypes = [P(GrX_Stats)]
+    L.GrX_Matrix_cache_bytes.argtypes = [c_void_p, P(c_u64)]
     L.GrX_version_string.restype = ctypes.c_char_p
 
 

@@ -191,6 +191,7 @@ extern "C" GrB_Info GrB_init(GrB_Mode mode)
     if (const char *e = getenv("GRB_ALLOC_CACHE")) c.alloc_cache = atoi(e);
     if (const char *e = getenv("GRB_SHORT_KERNEL")) c.short_kernel = atoi(e);
     if (const char *e = getenv("GRB_SELL_SIGMA")) c.sell_sigma = atoi(e);
+    if (const char *e = getenv("GRB_LAZY_LAYOUT")) c.lazy_layout = atoi(e);
     if (const char *e = getenv("GRB_LONG_KERNEL")) c.long_kernel = atoi(e);
     if (const char *e = getenv("GRB_LONG_CLASSES")) c.long_classes = atoi(e);
     if (const char *e = getenv("GRB_SPLIT_MIN_LEN")) c.split_min_len = atoi(e);
@@ -281,6 +282,8 @@ extern "C" GrB_Info GrX_option_set(const char *name, int64_t value)
     else if (n == "split_min_nnz") c.split_min_nnz = value;
     else if (n == "split_min_len") c.split_min_len = (int)value;
     else if (n == "short_kernel") c.short_kernel = (int)value;
+    else if (n == "lazy_layout") c.lazy_layout = (int)value;
+    else if (n == "lazy_min_nnz") c.lazy_min_nnz = value;
     else if (n == "long_kernel") c.long_kernel = (int)value;
     else if (n == "long_classes") c.long_classes = (value == 16 || value == 32 || value == 64) ? (int)value : 8;
     else if (n == "sell_sigma") c.sell_sigma = (int)value;

@@ -80,6 +80,8 @@ struct Context {
     int64_t split_min_nnz = 1 << 22;  // matrices with at least this many entries are analysed for the long/short row split
     int split_min_len = 0;            // a row is "long" from this many entries (0 = 64 for the class strips, 256 for the item kernel)
     int long_classes = 16;            // column classes of the class strips (8, 16, 32, 64): distinct LDS heads across the chip
+    int lazy_layout = 1;             // 1: the SpMV layouts of a large matrix are built at its SECOND pull product, not its first
+    int64_t lazy_min_nnz = 1 << 22;  // ... for matrices with at least this many entries (smaller ones build at once)
     int push_mode = 1;               // 0 never push, 1 push when u has < n/64 entries, 2 always push (tests)
 };
 Context &ctx();
@@ -211,6 +213,7 @@ struct GB_Matrix_opaque {
     int strip_ncls = 8;
     int64_t strip_nseg = 0;
     int split_kind = 0;                // value of the long_kernel option the split was built for
+    int pull_calls = 0;                // pull products run on this matrix since its layouts were last dropped
     // the short rows once more in sliced-ELLPACK form (k_mxv_sell; built on first use when short_kernel = 2)
     int32_t *d_sell_perm;
     int64_t *d_sell_off;
@@ -275,6 +278,9 @@ void pack_bool_values(const uint64_t *present, const bool *val, int64_t n, uint6
 // ---- primitives implemented in grb_prim.hip (rocPRIM-backed) ---------------------------------------
 void prim_sort_pairs_u64_u32(const uint64_t *keys_in, uint64_t *keys_out, const uint32_t *vals_in, uint32_t *vals_out,
                              int64_t n, int end_bit);
+// (stable; orders by key bits [begin_bit, end_bit) only)
+void prim_sort_pairs_u64_u32_bits(const uint64_t *keys_in, uint64_t *keys_out, const uint32_t *vals_in, uint32_t *vals_out,
+                                  int64_t n, int begin_bit, int end_bit);
 void prim_exclusive_sum_i64(const int64_t *in, int64_t *out, int64_t n);  // in == out allowed
 
 }  // namespace grb

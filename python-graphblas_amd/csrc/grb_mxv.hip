@@ -61,7 +61,8 @@ static void ensure_hot(GB_Matrix_opaque *A, size_t value_bytes)
     k &= ~(int64_t)63;
     if (k < 64) return;
     DevBuf<unsigned int> cnt(n, true);
-    hipLaunchKernelGGL(k_hot_hist, dim3((unsigned)ceil_div(nnz, 256)), dim3(256), 0, ctx().stream, A->d_col, nnz, cnt.p);
+    const int hstride = nnz >= ((int64_t)1 << 26) ? 8 : 1;
+    hipLaunchKernelGGL(k_hot_hist, dim3((unsigned)ceil_div(nnz, 256 * hstride)), dim3(256), 0, ctx().stream, A->d_col, nnz, cnt.p, hstride);
     DevBuf<uint64_t> keys(n), keys2(n);
     DevBuf<uint32_t> ids(n), ids2(n);
     hipLaunchKernelGGL(k_hot_keys, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx().stream, cnt.p, n, keys.p, ids.p);
@@ -74,7 +75,7 @@ static void ensure_hot(GB_Matrix_opaque *A, size_t value_bytes)
                        hot_cols, covered.p);
     unsigned long long cov = 0;
     d2h(&cov, covered.p, sizeof(cov));
-    if ((double)cov < 0.25 * (double)nnz) {  // flat degree distribution: the table would not pay for itself
+    if ((double)cov * hstride < 0.25 * (double)nnz) {  // flat degree distribution: the table would not pay for itself
         dev_free(hot_cols);
         return;
     }
@@ -204,8 +205,14 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
             hipLaunchKernelGGL(k_long_keys, dim3((unsigned)nl), dim3(256), 0, ctx().stream, (const int64_t *)A->d_ptr,
                                (const int64_t *)S->d_ptr, (const int32_t *)A->d_long_rows, col_src, nl, keys.p, idx.p,
                                (unsigned)(hot ? A->hot_k : 0), (unsigned)std::max<int64_t>(1, ceil_div((int64_t)A->ncols, (int64_t)ncls * (int64_t)sub)),
-                               sub, sub_min_len, (unsigned)ncls);
-            prim_sort_pairs_u64_u32(keys.p, keys2.p, idx.p, idx2.p, nnz_long, bits);
+                               sub, sub_min_len, (unsigned)ncls, kind == 2 ? 1 : 0);
+            if (kind == 2) {
+                int vbits = 1;
+                while ((1 << vbits) < ncls * (int)sub) vbits++;
+                prim_sort_pairs_u64_u32_bits(keys.p, keys2.p, idx.p, idx2.p, nnz_long, 32, 32 + vbits);
+            } else {
+                prim_sort_pairs_u64_u32(keys.p, keys2.p, idx.p, idx2.p, nnz_long, bits);
+            }
             if (kind == 2) {
                 // flat class strips (grb_mxv_strip.inc): segments = runs of equal keys; every segment padded to a multiple of 8
                 // entries, every class to whole chunks of 512
@@ -678,7 +685,11 @@ static void mxv_core(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_Binar
     // [ K hot entries | the n entries of u ] with the re-coded column indices (hot rank, or K + col)
     DevBuf<char> xcat_val(0);
     DevBuf<uint64_t> xcat_bits(0);
-    if (a.need_uval || !a.u_full) {
+    // the first pull over a large matrix runs on the CSR arrays as they are; the layouts below (tens of milliseconds to build at
+    // scale 24) are built when the matrix comes back for a second product
+    const bool lazy = ctx().lazy_layout && S->nvals >= ctx().lazy_min_nnz && S->pull_calls == 0 && S->hot_state == 0 && S->split_state == 0;
+    S->pull_calls++;
+    if ((a.need_uval || !a.u_full) && !lazy) {
         ensure_hot(S, type_size(st));
         if (S->hot_state == 1 && (uint64_t)(u->n + S->hot_k) * type_size(st) < 0xff000000ull) {
             const int k = (int)S->hot_k;  // multiple of 64
@@ -728,7 +739,7 @@ static void mxv_core(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_Binar
         }
     }
     // long/short row split (large matrices whose long rows hold a good share of the entries)
-    if (S->nvals && (S->type->code == st || !need_aval) && !by_rowlen) {
+    if (S->nvals && (S->type->code == st || !need_aval) && !by_rowlen && !lazy) {
         const bool hot = (a.col == S->d_col_hot);
         ensure_split(S, a.col, hot);
         if (S->split_state == 1 && S->split_hot == hot) {
@@ -994,6 +1005,34 @@ extern "C" GrB_Info GrB_vxm(GrB_Vector w, const GrB_Vector mask, const GrB_Binar
         mxv_core(w, mask, accum, semiring, S, u, /*flip=*/true, f);
     }
     GRB_CATCH(errp(w))
+}
+
+// Device bytes of the layouts the pull SpMV caches with a matrix (hot-coded columns, short part, long-row strips / items,
+// tile table, transpose not included), for the bench line's bookkeeping.
+extern "C" GrB_Info GrX_Matrix_cache_bytes(const GrB_Matrix A, uint64_t *bytes)
+{
+    GRB_TRY
+    require_init();
+    check_matrix(A, "A");
+    if (!bytes) fail(GrB_NULL_POINTER, "bytes is NULL");
+    uint64_t b = 0;
+    const uint64_t vs = A->type->size;
+    if (A->d_tile_row) b += 8ull * (uint64_t)(A->n_tiles + 1);
+    if (A->d_col_hot) b += 4ull * (uint64_t)A->nvals + 4ull * (uint64_t)A->hot_k;
+    if (A->split_state == 1) {
+        const GB_Matrix_opaque *S = A->short_part;
+        b += 8ull * (A->nrows + 1) + 4ull * (uint64_t)S->nvals + (S->iso ? vs : vs * (uint64_t)S->nvals);
+        b += bits_words64(A->nrows) * 8 + 4ull * (uint64_t)A->n_long + 4ull * bits_words64(A->nrows) + 16ull * (uint64_t)A->n_chunks;
+        if (A->split_kind == 2 && A->strip_nseg > 0) {
+            const uint64_t padded = (uint64_t)A->strip_cb[A->strip_ncls] * STRIP_CH;
+            b += padded * 4 + (A->d_lval ? padded * vs : 0) + padded / 2 + padded / STRIP_CH * 8;
+        } else if (A->n_items > 0) {
+            const uint64_t padded = (uint64_t)A->long_nnz + 4ull * (uint64_t)A->n_items;
+            b += padded * 4 + (A->d_lval ? padded * vs : 0) + 16ull * (uint64_t)A->n_items;
+        }
+    }
+    *bytes = b;
+    GRB_CATCH(errp(A))
 }
 
 // w<mask, replace> = accum(w, reduce of the rows of A with a monoid)  (reference Matrix.reduce_rowwise / reduce_columnwise,

@@ -583,6 +583,7 @@ void matrix_invalidate_caches(GB_Matrix_opaque *A)
     A->d_sstart = nullptr;
     A->d_sslot = nullptr;
     A->strip_nseg = 0;
+    A->pull_calls = 0;
     dev_free(A->d_sell_perm);
     dev_free(A->d_sell_off);
     dev_free(A->d_sell_order);

@@ -9,16 +9,21 @@
 
 namespace grb {
 
-void prim_sort_pairs_u64_u32(const uint64_t *keys_in, uint64_t *keys_out, const uint32_t *vals_in, uint32_t *vals_out,
-                             int64_t n, int end_bit)
+void prim_sort_pairs_u64_u32_bits(const uint64_t *keys_in, uint64_t *keys_out, const uint32_t *vals_in, uint32_t *vals_out,
+                                  int64_t n, int begin_bit, int end_bit)
 {
     if (n <= 0) return;
     size_t tmp_bytes = 0;
-    GRB_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u,
+    GRB_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, (unsigned)begin_bit,
                                       (unsigned)end_bit, ctx().stream));
     DevBuf<char> tmp(tmp_bytes);
-    GRB_HIP(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u,
+    GRB_HIP(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, (unsigned)begin_bit,
                                       (unsigned)end_bit, ctx().stream));
+}
+void prim_sort_pairs_u64_u32(const uint64_t *keys_in, uint64_t *keys_out, const uint32_t *vals_in, uint32_t *vals_out,
+                             int64_t n, int end_bit)
+{
+    prim_sort_pairs_u64_u32_bits(keys_in, keys_out, vals_in, vals_out, n, 0, end_bit);
 }
 
 void prim_exclusive_sum_i64(const int64_t *in, int64_t *out, int64_t n)
