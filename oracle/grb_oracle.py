@@ -377,7 +377,7 @@ def vec_assign_scalar(w: OVec, value, *, mask: OVec | None = None, mask_comp=Fal
                       replace=False) -> OVec:
     """w<mask, replace>[:] = accum(w, value): GraphBLAS C API 2.0 GrB_Vector_assign with a scalar and GrB_ALL (the
     reference's ``w(mask)[:] << s``, core/vector.py:1979-2035) -- T is ``value`` at every index, then the write rule."""
-    use_threads(w.n)
+    use_threads(w.size)
     n = w.size
     if mask is not None and mask.size != n:
         raise ValueError("DimensionMismatch")
@@ -396,7 +396,7 @@ def vec_assign_scalar(w: OVec, value, *, mask: OVec | None = None, mask_comp=Fal
 def vec_reduce(u: OVec, monoid: str):
     """Fold of the stored values with ``monoid`` in u's type, ``None`` when u is empty (GrB_Vector_reduce; reference
     core/vector.py:1635-1684).  Integers wrap like the C types; floating-point sums are left-to-right."""
-    use_threads(u.n)
+    use_threads(u.size)
     if u.idx.size == 0:
         return None
     v = u.vals
@@ -419,7 +419,7 @@ def vec_reduce(u: OVec, monoid: str):
 def vec_ewise(u: OVec, v: OVec, binop: str, *, union: bool) -> OVec:
     """T = u (op) v on the union (eWiseAdd: single entries pass through) or the intersection (eWiseMult) of the patterns, in
     the unified type (GraphBLAS C API 2.0 eWiseAdd / eWiseMult; reference core/vector.py:960-1150)."""
-    use_threads(u.n)
+    use_threads(u.size)
     if u.size != v.size:
         raise ValueError("DimensionMismatch")
     t = unify(u.tname, v.tname)
