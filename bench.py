@@ -53,7 +53,9 @@ def parse():
     p.add_argument("--visited", type=float, default=0.5, help="fraction of rows masked out (visited)")
     p.add_argument("--workload", default="mxv_min_plus_masked",
                    choices=["mxv_min_plus_masked", "mxv_lor_land_masked", "mxv_min_plus", "mxm_plus_times", "mxm_plus_times_masked", "bfs", "sssp",
-                            "uniform_fp64"])
+                            "uniform_fp64", "kron26"])
+    p.add_argument("--block", default=None, metavar="R/W",
+                   help="single GPU: run rank R's row block of a W-way sharded run (the compute part of one rank's step; no exchange)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--extra", action="store_true", help="also run the secondary workloads (reported under 'extra')")
     return p.parse_args()
@@ -69,16 +71,19 @@ class MxvWorkload:
     """Holds the HBM-resident operands of one masked mxv and launches it through the C ABI directly
     (ctypes call with pre-resolved handles: no per-step Python marshalling beyond one FFI call)."""
 
-    def __init__(self, gb, torch, scale, rank, world, semiring, visited_frac, seed=0):
+    def __init__(self, gb, torch, scale, rank, world, semiring, visited_frac, seed=0, block=None):
         from graphblas_amd import _lib, device, synthetic
 
         self.gb, self.torch, self.rank, self.world = gb, torch, rank, world
         n = 1 << scale
-        assert n % (64 * world) == 0
-        rows = n // world
-        lo, hi = rank * rows, (rank + 1) * rows
+        # (--block r/w: this process computes rank r's rows of a w-way run, alone: no exchange)
+        shard_rank, shard_world = block if block else (rank, world)
+        assert n % (64 * shard_world) == 0
+        rows = n // shard_world
+        lo, hi = shard_rank * rows, (shard_rank + 1) * rows
         self.n, self.m, self.lo, self.hi = n, rows, lo, hi
-        indptr, col = synthetic.rmat_csr(scale, device="cuda", row_range=(lo, hi) if world > 1 else None)
+        self.block = block
+        indptr, col = synthetic.rmat_csr(scale, device="cuda", row_range=(lo, hi) if shard_world > 1 else None)
         self.nnz_local = int(col.numel())
         gen = torch.Generator(device="cuda")
         gen.manual_seed(4242 + seed)
@@ -458,11 +463,16 @@ def main_sssp(args, gb, torch, device, rank, world):
 
 def main():
     args = parse()
+    if args.workload == "kron26":  # configs[4]: Kronecker scale-26 min_plus mxv fp32 (8 GPUs; one rank's block with --block r/8)
+        args.workload, args.scale = "mxv_min_plus", 26
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    block = None
+    if args.block and world == 1:
+        block = tuple(int(x) for x in args.block.split("/"))
     if world != args.gpus and world > 1:
         args.gpus = world
     torch.cuda.set_device(local_rank)
@@ -485,7 +495,7 @@ def main():
     def run(workload):
         sr = {"mxv_min_plus_masked": "min_plus", "mxv_lor_land_masked": "lor_land", "mxv_min_plus": "min_plus"}[workload]
         visited = 0.0 if workload == "mxv_min_plus" else args.visited
-        wl = MxvWorkload(gb, torch, args.scale, rank, world, sr, visited)
+        wl = MxvWorkload(gb, torch, args.scale, rank, world, sr, visited, block=block)
         # The first product of a matrix runs on its CSR arrays as they are; the second builds the cached layouts (hot-column coding,
         # long / short split, class strips).  Both are part of the warm-up and are timed apart (wall clock around a synchronised call).
         def timed_call():
@@ -585,7 +595,8 @@ def main():
                                    f"edge factor 16, visited density {args.visited}, dense u"
                        if args.workload == "mxv_min_plus_masked" else f"rmat{args.scale} {args.workload}",
                        "edges_counted_per_step": res["edges_per_step"],
-                       "parallelism": f"row-shard x{world}" + (" + RCCL all-gather of w" if world > 1 else "")},
+                       "parallelism": (f"rank {block[0]} of a {block[1]}-way row shard, compute only" if block else
+                                       f"row-shard x{world}" + (" + RCCL all-gather of w" if world > 1 else ""))},
             "verified": res["verified"],
             "first_call_ms": res["first_call_ms"],
             "layout_build_call_ms": res["layout_build_call_ms"],

@@ -1,21 +1,64 @@
-"""1-D row sharding of mxv over the GPUs of one node: rank r owns the row block
-[lo, hi) of A and a full replica of u; after the local product the ranks all-gather their w slices into
-the next u (RCCL over xGMI on GPUs -- torch.distributed backend "nccl"; "gloo" in the CPU tests).
+"""1-D row sharding of mxv / vxm / mxm over the GPUs of one node.  One process per GPU; collectives
+go through torch.distributed (backend "nccl" = RCCL over xGMI on GPUs, "gloo" in the CPU tests):
 
-Blocks are equal and 64-row aligned, so the all-gather lands directly in the replicated vector's HBM
-image (values AND bit-packed presence words), with no staging copy."""
+* **mxv (pull)**: rank r owns the row block [cuts[r], cuts[r+1]) of A and a full replica of u; after the local product the
+  ranks exchange their w slices into the next u -- an all-gather with per-rank sizes (``allgatherv_into``; equal blocks take
+  the single-collective fast path ``allgather_into``).  Slices are 64-row aligned, so values AND bit-packed presence words
+  land directly in the replicated vector's HBM image, with no staging copy.
+* **vxm (push) / mxv with T0**: rank r owns rows [cuts[r], cuts[r+1]) of A and the matching slice of u; its product is a
+  PARTIAL result over all n columns; the partials are combined with the semiring's monoid by an all-reduce
+  (``allreduce_monoid``: ncclMin / ncclMax / ncclSum on the values with absent entries set to the identity, bit-or on the
+  presence words), then the write rule (mask, accumulator, replace) is applied to the replicated result.
+* **mxm**: rows of A sharded, B replicated: no collective in the product (the result stays row-sharded).
+
+Row cuts are balanced by the work they carry -- entries for mxv, flops (sum over the entries of A of the length of the B row
+they select) for mxm -- not by row count: on a power-law graph equal row blocks differ by 2x and more in entries.
+"""
 from __future__ import annotations
+
+import numpy as np
 
 
 def row_block(n, rank, world):
+    """Equal 64-row-aligned blocks (the single-collective all-gather needs them)."""
     if n % (64 * world):
         raise ValueError("n must be a multiple of 64 * world_size for zero-copy all-gather")
     rows = n // world
     return rank * rows, (rank + 1) * rows
 
 
+def balanced_cuts(weight_prefix, world, align=64):
+    """Row cuts [c_0 = 0, c_1, ..., c_world = m] such that every block carries about the same weight.
+
+    ``weight_prefix``: array of m+1 non-decreasing numbers, prefix sums of the per-row work (the CSR row pointer for
+    entry-balanced mxv blocks; ``flops_prefix`` for mxm).  Cuts are multiples of ``align`` rows (64: one presence word), except
+    the last one; a block may be empty when one row outweighs a whole share."""
+    wp = np.asarray(weight_prefix)
+    m = wp.size - 1
+    total = float(wp[-1])
+    cuts = [0]
+    for r in range(1, world):
+        target = total * r / world
+        c = int(np.searchsorted(wp, target, side="left"))
+        c = min(m, max(cuts[-1], int(round(c / align)) * align))
+        cuts.append(c)
+    cuts.append(m)
+    return cuts
+
+
+def flops_prefix(indptr_a, col_a, rowlen_b):
+    """Prefix sums (m+1) of the per-row multiply counts of A @ B: sum over the entries (i, k) of row i of nnz(B(k, :))."""
+    import torch
+
+    ip = torch.as_tensor(indptr_a)
+    per_entry = torch.as_tensor(rowlen_b)[torch.as_tensor(col_a).long()].to(torch.int64)
+    csum = torch.zeros(per_entry.numel() + 1, dtype=torch.int64, device=per_entry.device)
+    csum[1:] = torch.cumsum(per_entry, 0)
+    return csum[ip.long()].cpu().numpy()
+
+
 def allgather_into(u_full, w_local, *, device="cuda", values=True, presence=True):
-    """u_full[lo_r:hi_r] = w_local of rank r, for every r (one collective per array)."""
+    """u_full[lo_r:hi_r] = w_local of rank r, for every r -- equal blocks, one collective per array."""
     import torch.distributed as dist
 
     from . import device as dev
@@ -27,6 +70,91 @@ def allgather_into(u_full, w_local, *, device="cuda", values=True, presence=True
     if presence:
         _gather(dist, u_words, w_words)
         dev.vector_modified(u_full)
+
+
+def allgatherv_into(u_full, w_local, cuts, *, device="cuda", values=True, presence=True, async_op=False):
+    """u_full[cuts[r]:cuts[r+1]] = w_local of rank r, for every r -- blocks of any (64-row aligned) sizes: rank r broadcasts its
+    slice in place (an all-gather-v as grouped broadcasts: what RCCL does for uneven all-gathers as well).  With ``async_op``
+    returns the work handles (wait on them before reading u_full); the caller must not hand u_full to a product meanwhile."""
+    import torch.distributed as dist
+
+    from . import device as dev
+
+    rank, world = dist.get_rank(), dist.get_world_size()
+    u_vals, u_words = dev.vector_device_views(u_full, device)
+    w_vals, w_words = dev.vector_device_views(w_local, device)
+    lo, hi = cuts[rank], cuts[rank + 1]
+    if hi > lo:
+        if values:
+            u_vals[lo:hi].copy_(w_vals[: hi - lo])
+        if presence:
+            u_words[lo // 32: (hi + 31) // 32].copy_(w_words[: (hi - lo + 31) // 32])
+    works = []
+    for r in range(world):
+        a, b = cuts[r], cuts[r + 1]
+        if b <= a:
+            continue
+        if values:
+            works.append(dist.broadcast(u_vals[a:b], src=r, async_op=async_op))
+        if presence:
+            works.append(dist.broadcast(u_words[a // 32: (b + 31) // 32], src=r, async_op=async_op))
+    if presence:
+        dev.vector_modified(u_full)
+    return [w for w in works if w is not None] if async_op else None
+
+
+_REDUCE_OF = {"min": "MIN", "max": "MAX", "plus": "SUM", "lor": "MAX", "land": "MIN", "any": "MAX"}
+
+
+def allreduce_monoid(t, monoid_name, identity, *, device="cuda"):
+    """Combine the ranks' PARTIAL products t (same size on every rank) with the monoid, in place: entries a rank does not have
+    are set to the monoid's identity, the values are all-reduced with the matching collective operator (ncclMin / ncclMax /
+    ncclSum; lor = max and land = min on 0/1), the presence words with a bit-or.  Returns nothing; t then holds the full product
+    on every rank."""
+    import torch
+    import torch.distributed as dist
+
+    from . import device as dev
+
+    if monoid_name not in _REDUCE_OF:
+        raise NotImplementedError(f"no collective operator for the monoid {monoid_name!r} (times / lxor / lxnor need a gather + local fold)")
+    vals, words = dev.vector_device_views(t, device)
+    n = vals.numel()
+    shifts = torch.arange(32, device=words.device, dtype=torch.int32)
+    present = ((words.view(-1, 1) >> shifts) & 1).to(torch.bool).view(-1)[:n]
+    as_num = vals.view(torch.uint8) if vals.dtype == torch.bool else vals
+    ident = torch.as_tensor(identity, dtype=as_num.dtype, device=as_num.device)
+    as_num.copy_(torch.where(present, as_num, ident))
+    dist.all_reduce(as_num, op=getattr(dist.ReduceOp, _REDUCE_OF[monoid_name]))
+    dist.all_reduce(words, op=dist.ReduceOp.BOR)
+    dev.vector_modified(t)
+
+
+def sharded_vxm(gb, w, u_local, A_local, semiring, *, mask=None, accum=None, replace=False, device="cuda"):
+    """w<mask, replace> = accum(w, u' A) with the ROWS of A (and u) sharded: ``A_local`` holds this rank's rows (all n columns),
+    ``u_local`` the matching slice of u; w, mask are replicated (size n).  Local partial product -> monoid all-reduce -> the
+    write rule on the replicated result (reference call graphblas/core/vector.py:1309-1378)."""
+    from . import operators
+
+    sr = semiring if isinstance(semiring, operators.TypedOp) else operators.get_typed_op(semiring, u_local.dtype, A_local.dtype, kind="semiring")
+    n = A_local.ncols
+    t = gb.Vector(sr.return_type, size=n)
+    t << u_local.vxm(A_local, sr)
+    mon = operators._canon(sr.parent.monoid.name, sr.type)
+    ident = sr.parent.monoid.identity(sr.type)
+    _ensure_dense_storage(gb, t)
+    allreduce_monoid(t, mon, ident, device=device)
+    # the write rule over the replicated product: first(t, t) = t through eWiseAdd's mask / accumulator / replace handling
+    out = w(accum=accum) if mask is None else w(mask, accum=accum, replace=replace)
+    out << t.ewise_add(t, gb.binary.first)
+    return w
+
+
+def _ensure_dense_storage(gb, t):
+    """A vector that never received an entry has no storage yet: give it one (an entry set and removed)."""
+    if t.nvals == 0:
+        t[0] << t.dtype.np_type.type(0)
+        del t[0]
 
 
 def _gather(dist, out, part):

@@ -82,3 +82,228 @@ def test_row_sharded_mxv_two_ranks():
         ou = O.mxv(oa, ou, "min_plus", w=ou, mask=ovis, mask_comp=True, mask_struct=True, accum="min")
     assert ui == ou.idx.tolist()
     assert uv == ou.vals.tolist()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the other exchanges of SURVEY.md section 8e: monoid all-reduce of partial products (vxm with the rows sharded), entry-balanced
+# row cuts with an all-gather-v, and the row-sharded mxm with flop-balanced cuts
+# ---------------------------------------------------------------------------------------------------------------------
+def _spawn(worker, world, args, timeout=600):
+    import subprocess
+
+    import torch.multiprocessing as mp
+
+    subprocess.check_call([os.path.join(ROOT, "tests", "emu", "build_emu.sh")], stdout=subprocess.DEVNULL)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=worker, args=(r, world, port, q) + tuple(args)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=timeout) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return dict(out)
+
+
+def _init(rank, world, port):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), GRB_EMU_PREBUILT="1")
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests.backend import bind
+
+    return bind("emu"), dist
+
+
+def _vxm_worker(rank, world, port, q, scale, case):
+    gb, dist = _init(rank, world, port)
+    import torch
+
+    from graphblas_amd import device, sharded, synthetic
+
+    n = 1 << scale
+    ip, col = synthetic.rmat_csr(scale, device="cpu")
+    cuts = sharded.balanced_cuts(ip.numpy(), world)
+    lo, hi = cuts[rank], cuts[rank + 1]
+    tname, srname, accum = case
+    wts = synthetic.edge_weights(col, scale, dtype=torch.int64 if tname == "INT64" else None)
+    e0, e1 = int(ip[lo]), int(ip[hi])
+    vals = torch.ones(1, dtype=torch.bool) if tname == "BOOL" else wts[e0:e1].contiguous()
+    A = device.matrix_from_device_csr((ip[lo:hi + 1] - ip[lo]).contiguous(), col[e0:e1].contiguous(), vals, hi - lo, n, tname,
+                                      copy=True, iso=(tname == "BOOL"))
+    rng = np.random.default_rng(5)
+    ui = np.flatnonzero(rng.random(n) < 0.3)
+    uv = (np.ones(ui.size, bool) if tname == "BOOL" else rng.integers(1, 50, ui.size)).astype({"BOOL": bool, "INT64": np.int64, "FP32": np.float32}[tname])
+    sel = (ui >= lo) & (ui < hi)
+    u_loc = gb.Vector.from_coo(ui[sel] - lo, uv[sel], dtype=tname, size=hi - lo)
+    wi = np.flatnonzero(rng.random(n) < 0.5)
+    wv = (np.ones(wi.size, bool) if tname == "BOOL" else rng.integers(1, 2000, wi.size)).astype(uv.dtype)
+    mi = np.flatnonzero(rng.random(n) < 0.5)
+    w = gb.Vector.from_coo(wi, wv, dtype=tname, size=n)
+    mk = gb.Vector.from_coo(mi, np.ones(mi.size, bool), dtype="BOOL", size=n)
+    sharded.sharded_vxm(gb, w, u_loc, A, getattr(gb.semiring, srname), mask=~mk.S, accum=accum, replace=(accum is None), device="cpu")
+    gi, gv = w.to_coo()
+    q.put((rank, (gi.tolist(), gv.tolist(), cuts)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", [("FP32", "min_plus", "min"), ("INT64", "plus_times", "plus"), ("BOOL", "lor_land", None)])
+def test_row_sharded_vxm_monoid_allreduce(case):
+    """vxm with the rows of A (and u) sharded over two ranks: each rank's partial product over all columns, combined by the
+    monoid all-reduce (min / sum / max on the values, bit-or on the presence words), then the write rule on the replicated
+    result -- equal to the single-process oracle on both ranks."""
+    import torch
+
+    from graphblas_amd import synthetic
+    from oracle import grb_oracle as O
+
+    scale, world = 9, 2
+    tname, srname, accum = case
+    res = _spawn(_vxm_worker, world, (scale, case))
+    n = 1 << scale
+    ip, col = synthetic.rmat_csr(scale, device="cpu")
+    wts = synthetic.edge_weights(col, scale, dtype=torch.int64 if tname == "INT64" else None).numpy()
+    np_t = {"BOOL": bool, "INT64": np.int64, "FP32": np.float32}[tname]
+    oa = O.OMat(n, n, ip.numpy(), col.numpy().astype(np.int64), np.ones(col.numel(), bool) if tname == "BOOL" else wts.astype(np_t), tname)
+    rng = np.random.default_rng(5)
+    ui = np.flatnonzero(rng.random(n) < 0.3)
+    uv = (np.ones(ui.size, bool) if tname == "BOOL" else rng.integers(1, 50, ui.size)).astype(np_t)
+    wi = np.flatnonzero(rng.random(n) < 0.5)
+    wv = (np.ones(wi.size, bool) if tname == "BOOL" else rng.integers(1, 2000, wi.size)).astype(np_t)
+    mi = np.flatnonzero(rng.random(n) < 0.5)
+    exp = O.vxm(O.OVec(n, ui, uv, tname), oa, srname, w=O.OVec(n, wi, wv, tname), mask=O.OVec(n, mi, np.ones(mi.size, bool), "BOOL"),
+                mask_comp=True, mask_struct=True, accum=accum, replace=(accum is None))
+    cuts = res[0][2]
+    assert cuts[0] == 0 and cuts[-1] == n and all(c % 64 == 0 for c in cuts)
+    for r in range(world):
+        assert res[r][0] == exp.idx.tolist() and res[r][1] == exp.vals.tolist()
+
+
+def _mxv_cuts_worker(rank, world, port, q, scale, iters):
+    gb, dist = _init(rank, world, port)
+    import torch
+
+    from graphblas_amd import device, sharded, synthetic
+
+    n = 1 << scale
+    ip, col = synthetic.rmat_csr(scale, device="cpu")
+    wts = synthetic.edge_weights(col, scale)
+    cuts = sharded.balanced_cuts(ip.numpy(), world)
+    lo, hi = cuts[rank], cuts[rank + 1]
+    e0, e1 = int(ip[lo]), int(ip[hi])
+    A = device.matrix_from_device_csr((ip[lo:hi + 1] - ip[lo]).contiguous(), col[e0:e1].contiguous(), wts[e0:e1].contiguous(), hi - lo, n,
+                                      "FP32", copy=True)
+    g = torch.Generator().manual_seed(11)
+    dist0 = torch.randint(0, 1000, (n,), generator=g).to(torch.float32).numpy()
+    present = (torch.rand(n, generator=g) < 0.4).numpy()
+    visited = (torch.rand(n, generator=g) < 0.5).numpy()
+    idx = np.flatnonzero(present)
+    # two replicas of u: the exchange of step k lands in the one step k does not read (what lets it overlap with compute)
+    u = [gb.Vector.from_coo(idx, dist0[idx], dtype="FP32", size=n) for _ in range(2)]
+    loc = idx[(idx >= lo) & (idx < hi)]
+    w = gb.Vector.from_coo(loc - lo, dist0[loc], dtype="FP32", size=hi - lo)
+    vloc = np.flatnonzero(visited[lo:hi])
+    vis = gb.Vector.from_coo(vloc, np.ones(vloc.size, bool), dtype="BOOL", size=hi - lo)
+    for k in range(iters):
+        w(~vis.S, accum=gb.binary.min) << A.mxv(u[k & 1], gb.semiring.min_plus)
+        works = sharded.allgatherv_into(u[(k + 1) & 1], w, cuts, device="cpu", async_op=True)
+        for wk in works:
+            wk.wait()
+    ui, uv = u[iters & 1].to_coo()
+    q.put((rank, (ui.tolist(), uv.tolist(), cuts, int(e1 - e0))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_entry_balanced_cuts_and_allgatherv():
+    """Three ranks, row cuts balanced by entries (not rows), the w slices exchanged by an all-gather-v into the other replica
+    of u: three relaxation steps equal the single-process oracle; the blocks' entry counts are within 25 % of each other while
+    their row counts are not equal."""
+    from graphblas_amd import synthetic
+    from oracle import grb_oracle as O
+
+    scale, iters, world = 10, 3, 3
+    res = _spawn(_mxv_cuts_worker, world, (scale, iters))
+    n = 1 << scale
+    ip, col = synthetic.rmat_csr(scale, device="cpu")
+    wts = synthetic.edge_weights(col, scale).numpy()
+    import torch
+
+    g = torch.Generator().manual_seed(11)
+    dist0 = torch.randint(0, 1000, (n,), generator=g).to(torch.float32).numpy()
+    present = (torch.rand(n, generator=g) < 0.4).numpy()
+    visited = (torch.rand(n, generator=g) < 0.5).numpy()
+    idx = np.flatnonzero(present)
+    oa = O.OMat(n, n, ip.numpy(), col.numpy().astype(np.int64), wts, "FP32")
+    ou = O.OVec(n, idx, dist0[idx], "FP32")
+    ovis = O.OVec(n, np.flatnonzero(visited), np.ones(int(visited.sum()), bool), "BOOL")
+    for _ in range(iters):
+        ou = O.mxv(oa, ou, "min_plus", w=ou, mask=ovis, mask_comp=True, mask_struct=True, accum="min")
+    for r in range(world):
+        assert res[r][0] == ou.idx.tolist() and res[r][1] == ou.vals.tolist()
+    cuts = res[0][2]
+    nnz = [res[r][3] for r in range(world)]
+    rows = [cuts[r + 1] - cuts[r] for r in range(world)]
+    assert max(nnz) <= 1.25 * min(nnz), (nnz, rows)
+    assert len(set(rows)) > 1
+
+
+def _mxm_worker(rank, world, port, q, scale):
+    gb, dist = _init(rank, world, port)
+    import torch
+
+    from graphblas_amd import device, sharded, synthetic
+
+    n = 1 << scale
+    ip, col = synthetic.rmat_csr(scale, device="cpu")
+    one = torch.ones(1, dtype=torch.int64)
+    B = device.matrix_from_device_csr(ip, col, one, n, n, "INT64", copy=True, iso=True)
+    fp = sharded.flops_prefix(ip, col, ip[1:] - ip[:-1])
+    cuts = sharded.balanced_cuts(fp, world)
+    lo, hi = cuts[rank], cuts[rank + 1]
+    e0, e1 = int(ip[lo]), int(ip[hi])
+    A = device.matrix_from_device_csr((ip[lo:hi + 1] - ip[lo]).contiguous(), col[e0:e1].contiguous(), one, hi - lo, n, "INT64", copy=True,
+                                      iso=True)
+    C = A.mxm(B, gb.semiring.plus_times).new()
+    flops = device.last_stats()["flops"]
+    M = gb.Matrix("INT64", hi - lo, n)
+    M(A.S) << A.mxm(B, gb.semiring.plus_times)
+    cp, cj, cx = C.to_csr()
+    mp_, mj, mx = M.to_csr()
+    q.put((rank, (cuts, int(flops), cp.tolist(), cj.tolist(), cx.tolist(), mp_.tolist(), mj.tolist(), mx.tolist())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_row_sharded_mxm_flop_balanced():
+    """C = A (+.x) A and C<A.S> = A (+.x) A with the rows of the left operand sharded over two ranks by flop-balanced cuts and B
+    replicated: the stacked row blocks equal scipy's product; the ranks' flop counts are within 20 % of each other."""
+    import scipy.sparse as sp
+
+    from graphblas_amd import synthetic
+
+    scale, world = 8, 2
+    res = _spawn(_mxm_worker, world, (scale,))
+    n = 1 << scale
+    ip, col = synthetic.rmat_csr(scale, device="cpu")
+    S = sp.csr_matrix((np.ones(col.numel(), np.int64), col.numpy(), ip.numpy()), shape=(n, n))
+    ref = (S @ S).tocsr()
+    ref.sort_indices()
+    refm = ref.multiply(S.astype(bool)).tocsr()
+    refm.sort_indices()
+    cuts = res[0][0]
+    flops = [res[r][1] for r in range(world)]
+    assert max(flops) <= 1.2 * min(flops), flops
+    for r in range(world):
+        lo, hi = cuts[r], cuts[r + 1]
+        blk = ref[lo:hi]
+        assert res[r][2] == blk.indptr.tolist() and res[r][3] == blk.indices.tolist() and res[r][4] == blk.data.tolist()
+        blkm = refm[lo:hi]
+        assert res[r][5] == blkm.indptr.tolist() and res[r][6] == blkm.indices.tolist() and res[r][7] == blkm.data.tolist()
