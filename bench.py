@@ -57,6 +57,8 @@ def parse():
     p.add_argument("--block", default=None, metavar="R/W",
                    help="single GPU: run rank R's row block of a W-way sharded run (the compute part of one rank's step; no exchange)")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--streamed", action="store_true", help="mxm: run the unmasked product in row batches with the output streamed")
+    p.add_argument("--stream-budget-gb", type=float, default=64.0, help="mxm --streamed: device bytes one batch's product may take")
     p.add_argument("--extra", action="store_true", help="also run the secondary workloads (reported under 'extra')")
     return p.parse_args()
 
@@ -253,8 +255,21 @@ def main_mxm(args, gb, torch, device, rank, world, dist, barrier):
 
     masked = args.workload == "mxm_plus_times_masked"  # triangle-count style: C<A.S> = A (+.x) A
     desc_s = ctypes.c_void_p(_lib.handle("GrB_DESC_S"))
+    # the unmasked product of scale >= 21 does not fit one GPU (scale 22: 900 GB): it runs in row batches whose products fit
+    # `budget`, every batch through the full symbolic + numeric pipeline; count and checksum leave the batch (GrX_mxm_streamed)
+    streamed = (not masked) and (args.streamed or args.scale - (world.bit_length() - 1) // 2 >= 21)
+    budget = int(args.stream_budget_gb * (1 << 30))
+    stream_out = {}
 
     def step():
+        if streamed:
+            nv, cs, fl, nb = (ctypes.c_uint64(0) for _ in range(4))
+            rc = L.GrX_mxm_streamed(sr._carg, A._carg, B._carg, ctypes.c_uint64(budget), ctypes.byref(nv), ctypes.byref(cs),
+                                    ctypes.byref(fl), ctypes.byref(nb))
+            if rc != 0:
+                raise RuntimeError(f"GrX_mxm_streamed failed with GrB_Info {rc}")
+            stream_out.update(batches=int(nb.value), checksum=int(cs.value))
+            return device.last_stats()
         C = gb.Matrix("INT64", hi - lo, n)
         if masked:
             rc = L.GrB_mxm(C._carg, A._carg, None, sr._carg, A._carg, B._carg, desc_s)
@@ -286,21 +301,53 @@ def main_mxm(args, gb, torch, device, rank, world, dist, barrier):
     nnz_a = float(col_b.numel())
     alg_bytes = nnz_a * 12 + flops * 12 + nnz_c * 12 + 3 * (n + 1) * 8  # SURVEY.md section 8d, I = 4, V = 8
     achieved = alg_bytes / world / (ev_ms / args.steps * 1e-3) / 1e9
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            cpu = cpu_baseline_mxm(ip_b, col_b, n, flops, masked)
+        except Exception as e:  # the baseline must never take the bench line down
+            cpu = {"value": None, "unit": "nnz(C)/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
     if rank == 0:
         print(json.dumps({
             "metric": "SpGEMM nnz-out/s on R-MAT scale-%d" % args.scale, "value": nnz_c / (ms * 1e-3), "unit": "nnz(C)/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
             "config": {"workload": f"rmat{args.scale} {args.workload}: " + ("C<A.S> = A (+.x) A (mask-driven)" if masked else "C = A (+.x) A")
-                       + ", INT64 ones", "nnz_A": nnz_a,
-                       "flops": flops, "nnz_C": nnz_c, "parallelism": f"row-shard x{world}, B replicated"},
+                       + ", INT64 ones" + (f"; row batches under {args.stream_budget_gb:g} GiB, output streamed (count + checksum)" if streamed else ""),
+                       "nnz_A": nnz_a, "flops": flops, "nnz_C": nnz_c, "parallelism": f"row-shard x{world}, B replicated", **stream_out},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "k_spgemm_mhash / k_spgemm_mwin" if masked else "k_spgemm_hash / k_spgemm_sym_lds / k_spgemm_win",
                          "kernel_ms_hip_events": ev_ms / args.steps, "algorithmic_bytes_per_launch": alg_bytes / world},
-            "cpu_baseline": None, "stats": st}))
+            "cpu_baseline": cpu, "stats": st}))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def cpu_baseline_mxm(indptr, col, n, flops_total, masked, target_flops=1.5e9):
+    """The C oracle (OpenMP, all host cores) on a bounded sample of the same product: the first rows of A (as many as carry about
+    `target_flops` multiplies) times the whole B; value = nnz(C_sample) / s."""
+    import numpy as np
+
+    from oracle import grb_oracle as O
+
+    ip = indptr.cpu().numpy()
+    cj = col.cpu().numpy().astype(np.int64)
+    rowlen = np.diff(ip)
+    fl_prefix = np.concatenate([[0], np.cumsum(rowlen[cj])])[ip]
+    rows = int(min(n, max(64, np.searchsorted(fl_prefix, min(target_flops, float(fl_prefix[-1])), side="right"))))
+    e1 = int(ip[rows])
+    ones = np.ones(cj.size, np.int64)
+    ob = O.OMat(n, n, ip, cj, ones, "INT64")
+    oa = O.OMat(rows, n, ip[: rows + 1].copy(), cj[:e1].copy(), ones[:e1].copy(), "INT64")
+    O.use_all_threads()
+    t0 = time.perf_counter()
+    T = O.mxm(oa, ob, "plus_times", mask=oa if masked else None, mask_struct=masked) if masked else O.mxm_product(oa, ob, "plus_times")
+    dt = time.perf_counter() - t0
+    nnz_c = int(T.indices.size) if hasattr(T, "indices") else int(T[1].size)
+    return {"value": nnz_c / dt, "unit": "nnz(C)/s", "cores": O.num_threads(), "kind": "port",
+            "sample": f"rows 0..{rows - 1} of A ({int(fl_prefix[rows]):,} of {int(flops_total):,} multiplies) times the whole B, one pass "
+                      f"({dt:.2f} s); C oracle (oracle/grb_oracle.c, OpenMP) -- a CPU restatement, not SuiteSparse"}
 
 
 def main_uniform(args, gb, torch, device, rank, world):

@@ -258,6 +258,12 @@ typedef struct {
     int32_t reserved_;
 } GrX_Stats;
 GrB_Info GrX_last_stats(GrX_Stats *stats);
+/* T = A (+.x) B in row batches of A whose products fit `budget_bytes` of device memory; every batch runs the full two-pass
+ * SpGEMM, then only its entry count and the (wrapping, integer) sum of its values are kept: the product of a matrix whose result
+ * does not fit one GPU (R-MAT scale 22: 900 GB), e.g. as the single-GPU denominator of a row-sharded multi-GPU run.  Operands must
+ * have the semiring's type.  Replaces nothing in the reference: GrB_mxm (graphblas/core/matrix.py:2264-2331) materialises C. */
+GrB_Info GrX_mxm_streamed(const GrB_Semiring semiring, const GrB_Matrix A, const GrB_Matrix B, uint64_t budget_bytes,
+                          uint64_t *nvals, uint64_t *checksum, uint64_t *flops, uint64_t *batches);
 /* Device bytes of the SpMV layouts cached with A so far (hot-coded columns, short part, long-row strips / items). */
 GrB_Info GrX_Matrix_cache_bytes(const GrB_Matrix A, uint64_t *bytes);
 /* Tuning / diagnostics knobs (also read from the environment at GrB_init as GRB_<NAME upper-case>):

@@ -675,17 +675,25 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_sym_lds(const MxmArgs a, const
     __shared__ int s_cnt;
     const int tid = threadIdx.x;
     const int64_t row = rows[blockIdx.x];
-    for (int k = tid; k < WORDS; k += BLOCK) s_bits[k] = 0ull;
     if (tid == 0) s_cnt = 0;
-    __syncthreads();
-    foreach_product<BLOCK>(a, row,
-                    [&](int j, int64_t, int64_t) { atomicOr(&s_bits[j >> 6], 1ull << (j & 63)); });
-    __syncthreads();
-    int c = 0;
-    for (int k = tid; k < WORDS; k += BLOCK) c += __popcll(s_bits[k]);
-    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
-    if ((tid & 63) == 0 && c) atomicAdd(&s_cnt, c);
-    __syncthreads();
+    // wider matrices: the column range is covered in passes of WORDS * 64 columns (every pass visits all products and keeps the
+    // ones of its range -- a pass in LDS is still far cheaper than one round of global atomics on a bitmap in HBM)
+    const int passes = (int)((a.n + (int64_t)WORDS * 64 - 1) / ((int64_t)WORDS * 64));
+    for (int pass = 0; pass < passes; pass++) {
+        for (int k = tid; k < WORDS; k += BLOCK) s_bits[k] = 0ull;
+        __syncthreads();
+        const int jlo = pass * WORDS * 64;
+        foreach_product<BLOCK>(a, row, [&](int j, int64_t, int64_t) {
+            const unsigned r = (unsigned)(j - jlo);
+            if (r < (unsigned)(WORDS * 64)) atomicOr(&s_bits[r >> 6], 1ull << (r & 63));
+        });
+        __syncthreads();
+        int c = 0;
+        for (int k = tid; k < WORDS; k += BLOCK) c += __popcll(s_bits[k]);
+        for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
+        if ((tid & 63) == 0 && c) atomicAdd(&s_cnt, c);
+        __syncthreads();
+    }
     if (tid == 0) a.row_nnz[row] = s_cnt;
 }
 
@@ -786,7 +794,7 @@ static void run_bins(MxmArgs &a, const RowBins &rb)
     if (rb.count(2)) hipLaunchKernelGGL((k_spgemm_hash<T, T2, NUMERIC>), dim3((unsigned)rb.count(2)), dim3(MM_BLOCK), 0, ctx().stream, a, rb.ptr(2));
     if (rb.count(3)) hipLaunchKernelGGL((k_spgemm_hash<T, T3, NUMERIC>), dim3((unsigned)rb.count(3)), dim3(MM_BLOCK), 0, ctx().stream, a, rb.ptr(3));
     ctx().stats.kernel_launches += 3;
-    if (rb.count(4) && !NUMERIC && a.n <= (1 << 20) && !(ctx().debug_flags & 256)) {
+    if (rb.count(4) && !NUMERIC && a.n <= (1 << 24) && !(ctx().debug_flags & 256)) {
         if (a.n <= (1 << 18)) hipLaunchKernelGGL((k_spgemm_sym_lds<4096, MM_BLOCK>), dim3((unsigned)rb.count(4)), dim3(MM_BLOCK), 0, ctx().stream, a, rb.ptr(4));
         else  // (128 KiB of bitmap: one workgroup per CU, so make it a big one)
             hipLaunchKernelGGL((k_spgemm_sym_lds<16384, 1024>), dim3((unsigned)rb.count(4)), dim3(1024), 0, ctx().stream, a, rb.ptr(4));
@@ -1114,9 +1122,128 @@ static void mxm_core(GB_Matrix_opaque *C, GB_Matrix_opaque *Mask, const GB_Binar
     if (ctx().blocking) sync_stream();
 }
 
+// ---- row-batched product with the output streamed through a bounded buffer ---------------------------------------------------
+// C = A (+.x) B of a power-law graph can outgrow any one GPU (R-MAT scale 22: 7.5e10 entries, 900 GB): the product is then run
+// over row batches of A whose products fit `budget_bytes`, each batch through the full two-pass pipeline (symbolic + numeric,
+// sorted rows), and what leaves a batch is its entry count and a checksum of its values -- the single-GPU denominator of the
+// row-sharded multi-GPU product, where every rank holds only its rows of C.
+__global__ void k_rebase_rowptr(const int64_t *Ap, int64_t r0, int64_t rows, int64_t *out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= rows) out[i] = Ap[r0 + i] - Ap[r0];
+}
+template <typename T>
+__global__ void k_value_checksum(const T *x, int64_t n, unsigned long long *sum)
+{
+    unsigned long long s = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if constexpr (std::is_floating_point<T>::value) s += (unsigned long long)(long long)x[i];
+        else s += (unsigned long long)x[i];
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(sum, s);
+}
+// first row r1 > r0 such that flops of rows [r0, r1) stay within the share (at least one row)
+__global__ void k_batch_end(const int64_t *Ap, const int64_t *F, int64_t m, int64_t r0, int64_t max_flops, int64_t *out)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    const int64_t base = F[Ap[r0]];
+    int64_t lo = r0 + 1, hi = m;
+    while (lo < hi) {  // largest r1 with F[Ap[r1]] - base <= max_flops
+        const int64_t mid = (lo + hi + 1) >> 1;
+        if (F[Ap[mid]] - base <= max_flops) lo = mid;
+        else hi = mid - 1;
+    }
+    out[0] = lo;
+    out[1] = F[Ap[lo]] - base;
+}
+
 }  // namespace grb
 
 using namespace grb;
+
+extern "C" GrB_Info GrX_mxm_streamed(const GrB_Semiring semiring, const GrB_Matrix A, const GrB_Matrix B, uint64_t budget_bytes,
+                                     uint64_t *nvals_out, uint64_t *checksum_out, uint64_t *flops_out, uint64_t *batches_out)
+{
+    GRB_TRY
+    require_init();
+    check_matrix(A, "A");
+    check_matrix(B, "B");
+    if (!semiring) fail(GrB_NULL_POINTER, "semiring is NULL");
+    if (A->ncols != B->nrows) fail(GrB_DIMENSION_MISMATCH, "mxm: inner dimensions differ");
+    const int st = semiring->type;
+    if (A->type->code != st || B->type->code != st) fail(GrB_DOMAIN_MISMATCH, "GrX_mxm_streamed: operands must have the semiring's type");
+    const int monoid = canonical_op(st, semiring->monoid), mult = canonical_op(st, semiring->mult);
+    uint64_t nv = 0, fl = 0, nb = 0;
+    DevBuf<unsigned long long> csum(1, true);
+    const int64_t m = (int64_t)A->nrows;
+    if (A->nvals && B->nvals) {
+        DevBuf<int64_t> F(A->nvals + 1);
+        hipLaunchKernelGGL(k_nnz_flops, dim3((unsigned)ceil_div(A->nvals + 1, 256)), dim3(256), 0, ctx().stream, A->d_col, A->nvals, B->d_ptr, F.p);
+        prim_exclusive_sum_i64(F.p, F.p, A->nvals + 1);
+        // a product entry costs 4 + sizeof(T) bytes, and a row of T never has more entries than multiplies
+        const int64_t per_entry = 4 + (int64_t)type_size(st);
+        const int64_t max_flops = std::max<int64_t>(1, (int64_t)(budget_bytes / (uint64_t)per_entry));
+        DevBuf<int64_t> cut(2);
+        int64_t r0 = 0;
+        while (r0 < m) {
+            int64_t h[2];
+            hipLaunchKernelGGL(k_batch_end, dim3(1), dim3(64), 0, ctx().stream, (const int64_t *)A->d_ptr, (const int64_t *)F.p, m, r0, max_flops, cut.p);
+            d2h(h, cut.p, sizeof(h));
+            const int64_t r1 = h[0], rows = r1 - r0;
+            int64_t e0 = 0, e1 = 0;
+            d2h(&e0, A->d_ptr + r0, 8);
+            d2h(&e1, A->d_ptr + r1, 8);
+            if (e1 > e0) {
+                GB_Matrix_opaque *V = matrix_new(A->type, (uint64_t)rows, A->ncols);  // rows [r0, r1) of A: a view on its arrays
+                GB_Matrix_opaque *Tm = nullptr;
+                try {
+                    V->d_ptr = (int64_t *)dev_alloc(sizeof(int64_t) * (size_t)(rows + 1));
+                    hipLaunchKernelGGL(k_rebase_rowptr, dim3((unsigned)ceil_div(rows + 1, 256)), dim3(256), 0, ctx().stream,
+                                       (const int64_t *)A->d_ptr, r0, rows, V->d_ptr);
+                    V->d_col = A->d_col + e0;
+                    V->d_val = A->iso ? A->d_val : (void *)((char *)A->d_val + (size_t)e0 * A->type->size);
+                    V->iso = A->iso;
+                    V->nvals = e1 - e0;
+                    V->owns = false;
+                    GRB_DISPATCH_TYPE(st, T, {
+                        Tm = spgemm<T>(V, V->d_val, B, B->d_val, st, monoid, mult);
+                        if (Tm->nvals) {
+                            hipLaunchKernelGGL((k_value_checksum<T>), dim3(1024), dim3(256), 0, ctx().stream, (const T *)Tm->d_val, Tm->nvals,
+                                               csum.p);
+                        }
+                    })
+                    nv += (uint64_t)Tm->nvals;
+                    fl += (uint64_t)h[1];
+                    nb++;
+                    sync_stream();
+                } catch (...) {
+                    if (Tm) matrix_free(Tm);
+                    dev_free(V->d_ptr);
+                    V->d_ptr = nullptr; V->d_col = nullptr; V->d_val = nullptr;
+                    matrix_free(V);
+                    throw;
+                }
+                matrix_free(Tm);
+                dev_free(V->d_ptr);
+                V->d_ptr = nullptr; V->d_col = nullptr; V->d_val = nullptr;
+                matrix_free(V);
+            }
+            r0 = r1;
+        }
+    }
+    unsigned long long hsum = 0;
+    d2h(&hsum, csum.p, 8);
+    if (nvals_out) *nvals_out = nv;
+    if (checksum_out) *checksum_out = hsum;
+    if (flops_out) *flops_out = fl;
+    if (batches_out) *batches_out = nb;
+    ctx().stats = GrX_Stats{};
+    ctx().stats.method = 3;
+    ctx().stats.flops = (int64_t)fl;
+    ctx().stats.out_nvals = (int64_t)nv;
+    GRB_CATCH(errp(A))
+}
 
 extern "C" GrB_Info GrB_mxm(GrB_Matrix C, const GrB_Matrix Mask, const GrB_BinaryOp accum, const GrB_Semiring semiring,
                             const GrB_Matrix A, const GrB_Matrix B, const GrB_Descriptor desc)

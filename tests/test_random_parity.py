@@ -979,3 +979,67 @@ def test_mixed_types_unread_operands(gb, seed):
         _lib.lib.GrX_option_set(b"push_mode", 1)
         _lib.lib.GrX_option_set(b"hot_min_cols", 1 << 20)
         _lib.lib.GrX_option_set(b"hot_k", 0)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_mxm_streamed_row_batches(gb, seed, request):
+    """GrX_mxm_streamed: the product in row batches under a byte budget (down to one row per batch), only count and value
+    checksum kept -- equal to the materialised product's (scipy, exact in INT64 / small-integer FP64)."""
+    import ctypes
+
+    import scipy.sparse as sp
+
+    from graphblas_amd import _lib
+
+    rng = np.random.default_rng(9100 + seed)
+    tname = ["INT64", "FP64", "INT32", "INT64"][seed]
+    on_gpu = request.node.callspec.params["gb"] == "gpu"
+    m, k, n = int(rng.integers(40, 200) if on_gpu else rng.integers(12, 30)), int(rng.integers(40, 200)), int(rng.integers(40, 300))
+    ar, ac, av = rand_coo(rng, m, k, tname, long_rows=2)
+    br, bc, bv = rand_coo(rng, k, n, tname, long_rows=1)
+    A = gb.Matrix.from_coo(ar, ac, av, dtype=tname, nrows=m, ncols=k)
+    B = gb.Matrix.from_coo(br, bc, bv, dtype=tname, nrows=k, ncols=n)
+    Sa = sp.csr_matrix((av.astype(np.int64), (ar, ac)), shape=(m, k))
+    Sb = sp.csr_matrix((bv.astype(np.int64), (br, bc)), shape=(k, n))
+    pat = (sp.csr_matrix((np.ones(ar.size, np.int64), (ar, ac)), shape=(m, k)) @ sp.csr_matrix((np.ones(br.size, np.int64), (br, bc)), shape=(k, n))).tocsr()
+    ref = (Sa @ Sb).tocsr()
+    want_sum = int(ref.data.astype(np.int64).sum()) & 0xFFFFFFFFFFFFFFFF
+    sr = gb.semiring.plus_times[tname]
+    for budget in (1, 4096, 1 << 30):
+        nv, cs, fl, nb = (ctypes.c_uint64(0) for _ in range(4))
+        rc = _lib.lib.GrX_mxm_streamed(sr._carg, A._carg, B._carg, budget, ctypes.byref(nv), ctypes.byref(cs), ctypes.byref(fl), ctypes.byref(nb))
+        assert rc == 0
+        assert nv.value == pat.nnz
+        assert fl.value == int((np.diff(Sb.indptr)[ac]).sum())
+        if tname != "INT32":  # (INT32 entries are summed after sign extension: not comparable with the int64 product's sum)
+            assert cs.value == want_sum
+        assert nb.value >= 1 and (budget > 1 or nb.value > m // 4) and (budget < (1 << 30) or nb.value == 1)
+
+
+def test_mxm_wide_heavy_rows(gb):
+    """A product with more than 2^20 columns and rows whose multiply count exceeds the LDS hash table: the symbolic pass covers
+    the column range in passes of 2^20 columns of LDS bitmap (two passes here), the numeric pass walks column windows."""
+    import scipy.sparse as sp
+
+    rng = np.random.default_rng(4242)
+    m, k, n = 6, 400, (1 << 20) + 70_000
+    deg = np.array([300, 0, 5, 350, 1, 280])
+    ar = np.repeat(np.arange(m), deg)
+    ac = np.concatenate([rng.choice(k, d, replace=False) for d in deg])
+    av = rng.integers(1, 5, ar.size).astype(np.int64)
+    bdeg = rng.integers(40, 120, k)
+    br = np.repeat(np.arange(k), bdeg)
+    bc = np.concatenate([np.sort(rng.choice(n, d, replace=False)) for d in bdeg])
+    bc[:50] = np.sort(rng.choice(np.arange(n - 60_000, n), 50, replace=False))  # make sure the second pass has work
+    key = np.unique(br * n + bc)
+    br, bc = key // n, key % n
+    bv = rng.integers(1, 5, br.size).astype(np.int64)
+    A = gb.Matrix.from_coo(ar, ac, av, dtype="INT64", nrows=m, ncols=k)
+    B = gb.Matrix.from_coo(br, bc, bv, dtype="INT64", nrows=k, ncols=n)
+    C = A.mxm(B, gb.semiring.plus_times).new()
+    ref = (sp.csr_matrix((av, (ar, ac)), shape=(m, k)) @ sp.csr_matrix((bv, (br, bc)), shape=(k, n))).tocsr()
+    ref.sort_indices()
+    cp, cj, cx = C.to_csr()
+    assert np.array_equal(cp.astype(np.int64), ref.indptr) and np.array_equal(cj.astype(np.int64), ref.indices)
+    assert np.array_equal(cx, ref.data)
+    assert int(np.diff(ref.indptr).max()) > 16384  # (heavy rows really took the LDS-bitmap / window path)
