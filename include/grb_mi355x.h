@@ -113,6 +113,13 @@ GrB_Info GrB_Vector_dup(GrB_Vector *w, const GrB_Vector u);
 GrB_Info GrB_Vector_free(GrB_Vector *v);
 GrB_Info GrB_Vector_clear(GrB_Vector v);
 GrB_Info GrB_Vector_resize(GrB_Vector v, GrB_Index size);                    /* core/vector.py:455-463 */
+/* w<mask>(I) = accum(w(I), u) / w<mask> = accum(w, u(I)): index lists of any length, or GrB_ALL (reference core/vector.py:1906-2035,
+ * core/expr.py:404-560; C API 2.0 GrB_assign -- the mask has w's size -- and GrB_extract).  The typed scalar form
+ * GrB_Vector_assign_<T> below takes index lists too. */
+GrB_Info GrB_Vector_assign(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_Vector u, const GrB_Index *indices,
+                           GrB_Index nindices, const GrB_Descriptor desc);
+GrB_Info GrB_Vector_extract(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_Vector u, const GrB_Index *indices,
+                            GrB_Index nindices, const GrB_Descriptor desc);
 GrB_Info GrB_Vector_removeElement(GrB_Vector w, GrB_Index i);                /* core/vector.py:1916-1930 */
 /* element-wise union / intersection (core/vector.py:960-1150): op on the entries both have; eWiseAdd passes single entries through */
 GrB_Info GrB_Vector_eWiseAdd_BinaryOp(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_BinaryOp op,

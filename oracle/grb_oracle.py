@@ -393,6 +393,72 @@ def vec_assign_scalar(w: OVec, value, *, mask: OVec | None = None, mask_comp=Fal
     return OVec.from_dense(w_has, w_val, wt)
 
 
+_NP_BINOP = {"plus": np.add, "times": np.multiply, "min": np.minimum, "max": np.maximum, "minus": np.subtract,
+             "first": lambda a, b: a, "second": lambda a, b: b, "lor": np.logical_or, "land": np.logical_and, "lxor": np.logical_xor}
+
+
+def _write(w: OVec, t_has, t_val, mask, mask_comp, mask_struct, accum, replace) -> OVec:
+    """w<mask, replace> = accum(w, T) through the C oracle's write rule (T dense, in w's type)."""
+    n, wt = w.size, w.tname
+    w_has, w_val = w.dense()
+    mt = _dense_mask(mask, mask_struct, n)
+    if n:
+        rc = lib().grbo_vec_write(TYPE_CODES[wt], ctypes.c_int64(n), _p(w_has), _p(w_val), _p(np.ascontiguousarray(t_has, np.uint8)),
+                                  _p(np.ascontiguousarray(cast(t_val, wt))), _p(mt), int(mask_comp), OP_CODES[accum] if accum else -1,
+                                  int(replace))
+        assert rc == 0
+    return OVec.from_dense(w_has, w_val, wt)
+
+
+def vec_assign(w: OVec, u, indices, *, mask: OVec | None = None, mask_comp=False, mask_struct=False, accum=None, replace=False) -> OVec:
+    """w<mask, replace>(I) = accum(w(I), u) -- GraphBLAS C API 2.0 section 4.3.7.1 (GrB_Vector_assign; the mask has w's size) and
+    4.3.7.5 (u a scalar); the reference's ``w(mask, accum)[I] << u`` (core/vector.py:1906-2035).  Restated: Z = w; for every k,
+    i = I[k]: without an accumulator Z(i) = u(k) (an absent u(k) deletes Z(i)); with one Z(i) = accum(w(i), u(k)) where both are
+    present, u(k) where only it is, w(i) otherwise.  Then w<mask, replace> = Z.  Duplicate indices are undefined in the
+    specification and not exercised."""
+    use_threads(w.size)
+    n, wt = w.size, w.tname
+    I = np.asarray(indices, np.int64)
+    if I.size and (I.min() < 0 or I.max() >= n):
+        raise IndexError("IndexOutOfBound")
+    z_has, z_val = w.dense()
+    if isinstance(u, OVec):
+        if u.size != I.size:
+            raise ValueError("DimensionMismatch")
+        u_has, u_val = u.dense(wt)
+        u_has = u_has.astype(bool)
+    else:
+        u_has, u_val = np.ones(I.size, bool), cast(np.full(I.size, u), wt)
+    if accum:
+        both = u_has & z_has[I].astype(bool)
+        with np.errstate(over="ignore"):
+            comb = np.asarray(_NP_BINOP[accum](z_val[I], u_val)).astype(NP_OF[wt])
+        z_val[I[both]] = comb[both]
+        only_u = u_has & ~both
+        z_val[I[only_u]] = u_val[only_u]
+        z_has[I[u_has]] = 1
+    else:
+        z_val[I[u_has]] = u_val[u_has]
+        z_has[I] = u_has.astype(np.uint8)
+    if mask is None and not mask_comp:
+        return OVec.from_dense(z_has, z_val, wt)
+    return _write(w, z_has, z_val, mask, mask_comp, mask_struct, None, replace)
+
+
+def vec_extract(w: OVec, u: OVec, indices, *, mask: OVec | None = None, mask_comp=False, mask_struct=False, accum=None,
+                replace=False) -> OVec:
+    """w<mask, replace> = accum(w, u(I)) -- GraphBLAS C API 2.0 section 4.3.6.1 (GrB_Vector_extract); the reference's
+    ``w(mask, accum) << u[I]`` (core/vector.py:1906-1975): T(k) = u(I[k]), then the write rule in w's type."""
+    use_threads(w.size)
+    I = np.asarray(indices, np.int64)
+    if I.size != w.size:
+        raise ValueError("DimensionMismatch")
+    if I.size and (I.min() < 0 or I.max() >= u.size):
+        raise IndexError("IndexOutOfBound")
+    u_has, u_val = u.dense()
+    return _write(w, u_has[I], cast(u_val[I], w.tname), mask, mask_comp, mask_struct, accum, replace)
+
+
 def vec_reduce(u: OVec, monoid: str):
     """Fold of the stored values with ``monoid`` in u's type, ``None`` when u is empty (GrB_Vector_reduce; reference
     core/vector.py:1635-1684).  Integers wrap like the C types; floating-point sums are left-to-right."""

@@ -174,7 +174,16 @@ class BaseType:
             # ``w(mask) << 5``: scalar assign over every index (reference core/base.py:352-372 -> Updater[...] << scalar)
             return self._assign_scalar_all(expr, mask=mask, accum=accum, replace=replace, opts=opts)
         if self._grb_kind == "Matrix":
-            from .matrix import PowerCopy, PowerExpression, _power
+            from .matrix import PowerCopy, PowerExpression, TransposedMatrix, _power
+
+            if isinstance(expr, TransposedMatrix):
+                # ``C(mask, accum, replace) << A.T`` -> GrB_transpose (reference core/base.py:401-411)
+                complement = structure = False
+                if mask is not None:
+                    mask = _check_mask(mask, self)
+                    complement, structure = mask.complement, mask.structure
+                desc = descriptor_lookup(mask_complement=complement, mask_structure=structure, output_replace=replace, **opts)
+                return call("GrB_transpose", [self, mask, accum, expr._matrix, desc])
 
             if isinstance(expr, PowerExpression):
                 # evaluated by repeated squaring; (mask, accum, replace) apply to the last product (reference core/matrix.py:99-155)
@@ -199,7 +208,8 @@ class BaseType:
             complement, structure = mask.complement, mask.structure
         desc = descriptor_lookup(transpose_first=expr.at, transpose_second=expr.bt, mask_complement=complement,
                                  mask_structure=structure, output_replace=replace, **opts)
-        args = [self, mask, accum, expr.op, *expr.args, desc]
+        # (extract has no operator argument: GrB_Vector_extract(w, mask, accum, u, I, ni, desc))
+        args = [self, mask, accum, *([expr.op] if expr.op is not None else []), *expr.args, desc]
         call(expr.cfunc_name, args)
 
     def _assign_scalar_all(self, value, mask=None, accum=None, replace=False, *, opts):
@@ -224,8 +234,11 @@ class Updater:
         self.parent._update(expr, mask=self.mask, accum=self.accum, replace=self.replace, opts=self.opts)
 
     def __getitem__(self, key):
-        if key == slice(None):
+        if isinstance(key, slice) and key == slice(None):
             return AllIndexAssigner(self.parent, mask=self.mask, accum=self.accum, replace=self.replace, opts=self.opts)
+        if hasattr(self.parent, "_indexed_assigner") and not self.parent._is_scalar_index(key) and not isinstance(key, bool):
+            # ``w(mask, accum, replace)[I] << value`` with an index list / slice (reference core/expr.py:404-481, 484-560)
+            return self.parent._indexed_assigner(key, mask=self.mask, accum=self.accum, replace=self.replace, opts=self.opts)
         if self.mask is not None:
             raise TypeError("Single element assign does not accept a submask")
         return self.parent._element_assigner(key, accum=self.accum)

@@ -275,6 +275,10 @@ void vector_write_rule(GB_Vector_opaque *w, const void *t_val, const uint64_t *t
                        bool replace);  // w<m, replace> = accum(w, t), in place, t of w's type
 void pack_bool_values(const uint64_t *present, const bool *val, int64_t n, uint64_t *out);
 
+// C<Mask, replace> = accum(C, T), T in C's type with sorted rows (grb_mxm.hip); takes T's storage when nothing masks or accumulates
+void matrix_apply_write_rule(GB_Matrix_opaque *C, GB_Matrix_opaque *Mask, const GB_BinaryOp_opaque *accum, GB_Matrix_opaque *T,
+                             bool replace, bool comp, bool structure);
+
 // ---- primitives implemented in grb_prim.hip (rocPRIM-backed) ---------------------------------------
 void prim_sort_pairs_u64_u32(const uint64_t *keys_in, uint64_t *keys_out, const uint32_t *vals_in, uint32_t *vals_out,
                              int64_t n, int end_bit);

@@ -1007,6 +1007,64 @@ static void take_storage(GB_Matrix_opaque *C, GB_Matrix_opaque *src)
     src->d_ptr = nullptr; src->d_col = nullptr; src->d_val = nullptr; src->nvals = 0;
 }
 
+// C<Mask, replace> = accum(C, T) for a product / copy T already in C's type (sorted rows); T's storage is taken when nothing masks
+// or accumulates.  Shared by GrB_mxm and GrB_transpose.
+void matrix_apply_write_rule(GB_Matrix_opaque *C, GB_Matrix_opaque *Mask, const GB_BinaryOp_opaque *accum, GB_Matrix_opaque *Tm,
+                             bool replace, bool comp, bool structure)
+{
+    struct { bool replace, comp, structure; } f{replace, comp, structure};
+    if (!Mask && !accum) {
+        take_storage(C, Tm);  // C = T (aliasing with A/B is safe: T is a fresh object)
+    } else {
+        const int64_t m = (int64_t)C->nrows;
+        const int64_t *Tp = matrix_rowptr(Tm);
+        const int acc_op = accum ? canonical_op(C->type->code, accum->op) : -1;
+        const int64_t *Mp = Mask ? matrix_rowptr(Mask) : nullptr;
+        GB_Matrix_opaque *N = matrix_new(C->type, C->nrows, C->ncols);
+        try {
+            DevBuf<int64_t> cnt(m + 1, true);
+            int64_t *Np = (int64_t *)dev_alloc(sizeof(int64_t) * (m + 1));
+            N->d_ptr = Np;
+            int64_t nnzN = 0;
+            GRB_DISPATCH_TYPE(C->type->code, TW, {
+                const dim3 grid((unsigned)ceil_div(m, 256)), block(256);
+                hipLaunchKernelGGL((k_mat_write<TW, false>), grid, block, 0, ctx().stream, m, (const int64_t *)C->d_ptr,
+                                   (const int32_t *)C->d_col, (const TW *)C->d_val, C->iso ? 1 : 0, Tp,
+                                   (const int32_t *)Tm->d_col, (const TW *)Tm->d_val, Mp,
+                                   Mask ? (const int32_t *)Mask->d_col : nullptr, Mask ? (const void *)Mask->d_val : nullptr,
+                                   Mask ? Mask->type->code : 0, Mask && Mask->iso ? 1 : 0, Mask ? 1 : 0,
+                                   f.structure ? 1 : 0, f.comp ? 1 : 0, acc_op, f.replace ? 1 : 0, cnt.p,
+                                   (const int64_t *)nullptr, (int32_t *)nullptr, (TW *)nullptr);
+                prim_exclusive_sum_i64(cnt.p, Np, m + 1);
+                d2h(&nnzN, Np + m, sizeof(int64_t));
+                if (nnzN) {
+                    N->d_col = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)nnzN);
+                    N->d_val = dev_alloc(sizeof(TW) * (size_t)nnzN);
+                    hipLaunchKernelGGL((k_mat_write<TW, true>), grid, block, 0, ctx().stream, m, (const int64_t *)C->d_ptr,
+                                       (const int32_t *)C->d_col, (const TW *)C->d_val, C->iso ? 1 : 0, Tp,
+                                       (const int32_t *)Tm->d_col, (const TW *)Tm->d_val, Mp,
+                                       Mask ? (const int32_t *)Mask->d_col : nullptr,
+                                       Mask ? (const void *)Mask->d_val : nullptr, Mask ? Mask->type->code : 0,
+                                       Mask && Mask->iso ? 1 : 0, Mask ? 1 : 0, f.structure ? 1 : 0, f.comp ? 1 : 0, acc_op,
+                                       f.replace ? 1 : 0, (int64_t *)nullptr, (const int64_t *)Np, N->d_col, (TW *)N->d_val);
+                }
+            })
+            N->nvals = nnzN;
+            ctx().stats.kernel_launches += 2;
+            if (nnzN == 0) {
+                dev_free(N->d_ptr);
+                N->d_ptr = nullptr;
+            }
+            sync_stream();
+            take_storage(C, N);
+        } catch (...) {
+            matrix_free(N);
+            throw;
+        }
+        matrix_free(N);
+    }
+}
+
 static void mxm_core(GB_Matrix_opaque *C, GB_Matrix_opaque *Mask, const GB_BinaryOp_opaque *accum,
                      const GB_Semiring_opaque *sr, GB_Matrix_opaque *A, GB_Matrix_opaque *B, MDesc f)
 {
@@ -1064,56 +1122,7 @@ static void mxm_core(GB_Matrix_opaque *C, GB_Matrix_opaque *Mask, const GB_Binar
             Tm->d_val = cv;
         }
         Tm->type = C->type;
-        if (!Mask && !accum) {
-            take_storage(C, Tm);  // C = T (aliasing with A/B is safe: T is a fresh object)
-        } else {
-            const int64_t m = (int64_t)C->nrows;
-            const int64_t *Tp = matrix_rowptr(Tm);
-            const int acc_op = accum ? canonical_op(C->type->code, accum->op) : -1;
-            const int64_t *Mp = Mask ? matrix_rowptr(Mask) : nullptr;
-            GB_Matrix_opaque *N = matrix_new(C->type, C->nrows, C->ncols);
-            try {
-                DevBuf<int64_t> cnt(m + 1, true);
-                int64_t *Np = (int64_t *)dev_alloc(sizeof(int64_t) * (m + 1));
-                N->d_ptr = Np;
-                int64_t nnzN = 0;
-                GRB_DISPATCH_TYPE(C->type->code, TW, {
-                    const dim3 grid((unsigned)ceil_div(m, 256)), block(256);
-                    hipLaunchKernelGGL((k_mat_write<TW, false>), grid, block, 0, ctx().stream, m, (const int64_t *)C->d_ptr,
-                                       (const int32_t *)C->d_col, (const TW *)C->d_val, C->iso ? 1 : 0, Tp,
-                                       (const int32_t *)Tm->d_col, (const TW *)Tm->d_val, Mp,
-                                       Mask ? (const int32_t *)Mask->d_col : nullptr, Mask ? (const void *)Mask->d_val : nullptr,
-                                       Mask ? Mask->type->code : 0, Mask && Mask->iso ? 1 : 0, Mask ? 1 : 0,
-                                       f.structure ? 1 : 0, f.comp ? 1 : 0, acc_op, f.replace ? 1 : 0, cnt.p,
-                                       (const int64_t *)nullptr, (int32_t *)nullptr, (TW *)nullptr);
-                    prim_exclusive_sum_i64(cnt.p, Np, m + 1);
-                    d2h(&nnzN, Np + m, sizeof(int64_t));
-                    if (nnzN) {
-                        N->d_col = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)nnzN);
-                        N->d_val = dev_alloc(sizeof(TW) * (size_t)nnzN);
-                        hipLaunchKernelGGL((k_mat_write<TW, true>), grid, block, 0, ctx().stream, m, (const int64_t *)C->d_ptr,
-                                           (const int32_t *)C->d_col, (const TW *)C->d_val, C->iso ? 1 : 0, Tp,
-                                           (const int32_t *)Tm->d_col, (const TW *)Tm->d_val, Mp,
-                                           Mask ? (const int32_t *)Mask->d_col : nullptr,
-                                           Mask ? (const void *)Mask->d_val : nullptr, Mask ? Mask->type->code : 0,
-                                           Mask && Mask->iso ? 1 : 0, Mask ? 1 : 0, f.structure ? 1 : 0, f.comp ? 1 : 0, acc_op,
-                                           f.replace ? 1 : 0, (int64_t *)nullptr, (const int64_t *)Np, N->d_col, (TW *)N->d_val);
-                    }
-                })
-                N->nvals = nnzN;
-                ctx().stats.kernel_launches += 2;
-                if (nnzN == 0) {
-                    dev_free(N->d_ptr);
-                    N->d_ptr = nullptr;
-                }
-                sync_stream();
-                take_storage(C, N);
-            } catch (...) {
-                matrix_free(N);
-                throw;
-            }
-            matrix_free(N);
-        }
+        matrix_apply_write_rule(C, Mask, accum, Tm, f.replace, f.comp, f.structure);
     } catch (...) {
         matrix_free(Tm);
         throw;

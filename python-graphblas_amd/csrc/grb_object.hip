@@ -1075,17 +1075,35 @@ extern "C" GrB_Info GrB_transpose(GrB_Matrix C, const GrB_Matrix Mask, const GrB
     require_init();
     check_matrix(C, "C");
     check_matrix(A, "A");
-    if (Mask || accum) fail(GrB_NOT_IMPLEMENTED, "GrB_transpose: mask/accum are outside this library's path");
-    if (desc && (desc->replace || desc->comp || desc->structure)) fail(GrB_NOT_IMPLEMENTED, "GrB_transpose: only T0 descriptor");
+    if (Mask) check_matrix(Mask, "Mask");
     const bool t0 = desc && desc->t0;
+    const bool replace = desc && desc->replace, comp = desc && desc->comp, structure = desc && desc->structure;
     GB_Matrix_opaque *S = t0 ? A : matrix_transpose_cached(A);  // transposing a transpose is a copy
     if (C->nrows != S->nrows || C->ncols != S->ncols) fail(GrB_DIMENSION_MISMATCH, "GrB_transpose: output shape mismatch");
+    if (Mask && (Mask->nrows != C->nrows || Mask->ncols != C->ncols)) fail(GrB_DIMENSION_MISMATCH, "GrB_transpose: mask shape does not match the output");
+    if (accum && (accum->type != C->type->code || op_is_comparison(accum->op))) fail(GrB_DOMAIN_MISMATCH, "GrB_transpose: accum operator type must equal the output type");
+    if (!Mask && comp) {  // complement of "no mask": nothing may be written
+        if (replace) matrix_release_storage(C);
+        return GrB_SUCCESS;
+    }
+    // T = the (transposed) copy in C's type -- a fresh object, so C may alias A or the mask -- then the write rule
+    // (reference core/base.py:401-411: C(mask, accum, replace) << A.T)
     GB_Matrix_opaque *copy = matrix_cast_copy(S, C->type->code);
-    if (C == A) matrix_invalidate_caches(C);
-    matrix_release_storage(C);
-    C->d_ptr = copy->d_ptr; C->d_col = copy->d_col; C->d_val = copy->d_val;
-    C->nvals = copy->nvals; C->iso = copy->iso; C->owns = true;
-    copy->d_ptr = nullptr; copy->d_col = nullptr; copy->d_val = nullptr; copy->nvals = 0;
+    if (copy->iso && copy->nvals && (Mask || accum)) {  // (the write rule reads one value per entry)
+        GRB_DISPATCH_TYPE(C->type->code, TC_, {
+            void *full = matrix_values_expanded<TC_>(copy);
+            dev_free(copy->d_val);
+            copy->d_val = full;
+        })
+        copy->iso = false;
+    }
+    try {
+        if (C == A) matrix_invalidate_caches(C);
+        matrix_apply_write_rule(C, Mask, accum, copy, replace, comp, structure);
+    } catch (...) {
+        matrix_free(copy);
+        throw;
+    }
     matrix_free(copy);
     GRB_CATCH(errp(C))
 }

@@ -9,6 +9,8 @@
 //
 // Vectors are dense-with-presence in HBM (values + bit-packed presence), so these are element-wise kernels over the
 // presence words: one wavefront per 64 elements, the new presence word from one __ballot.
+#include <vector>
+
 #include "grb_internal.hpp"
 #include "grb_ops.hpp"
 
@@ -196,7 +198,7 @@ static void assign_all(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_Bin
                            (TW *)w->d_val, w->d_bits, (const uint64_t *)mbits.p, mask ? 1 : 0, f.comp ? 1 : 0,
                            accum ? canonical_op(w->type->code, accum->op) : -1, f.replace ? 1 : 0, cast_value<TW, T>(x));
     })
-    w->nvals = (!mask && true) ? (int64_t)w->n : -1;
+    w->nvals = !mask ? (int64_t)w->n : -1;
     if (ctx().blocking) sync_stream();  // (mbits goes back to the stream-ordered block cache: no wait needed)
 }
 
@@ -341,11 +343,227 @@ static void ewise_core(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_Bin
     if (ctx().blocking) sync_stream();
 }
 
+// ---- assign / extract with an index list (reference core/vector.py:1906-2035 -> GrB_Vector_assign, GrB_Vector_assign_<T>,
+//      GrB_Vector_extract; C API 2.0 sections 4.3.7 / 4.3.6) --------------------------------------------------------------
+// Z = w; Z(I) = accum ? accum(w(I), u) : u   (no accumulator: positions of I without an entry in u lose theirs), then
+// w<mask, replace> = Z over the WHOLE of w (GrB_assign, not subassign: the mask has w's size).  Duplicate indices in I are
+// undefined behaviour in the specification; here the last writer wins per element.
+template <typename T>
+__global__ void k_assign_scatter(T *z_val, unsigned long long *z_bits, const uint64_t *I, int64_t ni, int64_t n, const T *u_val,
+                                 const uint64_t *u_bits, T scalar, int accum, int *oob)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= ni) return;
+    const uint64_t i = I[k];
+    if (i >= (uint64_t)n) {
+        *oob = 1;
+        return;
+    }
+    const bool up = u_bits ? ((u_bits[k >> 6] >> (k & 63)) & 1ull) : true;
+    const T uv = u_val ? u_val[k] : scalar;
+    const unsigned long long bit = 1ull << (i & 63);
+    if (accum >= 0) {
+        if (up) {
+            const bool zp = (z_bits[i >> 6] & bit) != 0;
+            z_val[i] = zp ? apply_binop<T>(accum, z_val[i], uv) : uv;
+            if (!zp) atomicOr(&z_bits[i >> 6], bit);
+        }
+    } else if (up) {
+        z_val[i] = uv;
+        atomicOr(&z_bits[i >> 6], bit);
+    } else {
+        atomicAnd(&z_bits[i >> 6], ~bit);
+    }
+}
+// t(k) = u(I[k])
+template <typename T>
+__global__ void k_extract_gather(T *t_val, uint64_t *t_bits, const uint64_t *I, int64_t ni, int64_t n, const T *u_val,
+                                 const uint64_t *u_bits, int *oob)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool has = false;
+    if (k < ni) {
+        const uint64_t i = I[k];
+        if (i >= (uint64_t)n) *oob = 1;
+        else if (u_bits && ((u_bits[i >> 6] >> (i & 63)) & 1ull)) {
+            has = true;
+            t_val[k] = u_val[i];
+        }
+    }
+    const unsigned long long b = __ballot(has);
+    if ((threadIdx.x & 63) == 0 && (k >> 6) < ((ni + 63) >> 6)) t_bits[k >> 6] = b;
+}
+
+static void check_oob(int *d_flag, const char *what)
+{
+    int h = 0;
+    d2h(&h, d_flag, sizeof(int));
+    if (h) fail(GrB_INDEX_OUT_OF_BOUNDS, std::string(what) + ": an index is outside the vector");
+}
+
+// u == nullptr: scalar assign of `scalar_w` (already in w's type, as raw bytes)
+static void assign_indexed(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_BinaryOp_opaque *accum, GB_Vector_opaque *u,
+                           const void *scalar_w, const uint64_t *indices, uint64_t ni, const GB_Descriptor_opaque *desc)
+{
+    const VDesc f = vflags(desc);
+    if (mask && mask->n != w->n) fail(GrB_DIMENSION_MISMATCH, "assign: mask size does not match the output size");
+    if (u && u->n != ni) fail(GrB_DIMENSION_MISMATCH, "assign: the input has " + std::to_string(u->n) + " elements, the index list " + std::to_string(ni));
+    if (accum && (accum->type != w->type->code || op_is_comparison(accum->op))) fail(GrB_DOMAIN_MISMATCH, "assign: accum operator type must equal the output type");
+    if (!indices) fail(GrB_NULL_POINTER, "assign: index list is NULL");
+    if (!mask && f.comp) {
+        if (f.replace) vector_release_storage(w);
+        return;
+    }
+    if (w->n == 0) return;
+    vector_ensure_storage(w);
+    const int wt = w->type->code;
+    DevBuf<uint64_t> d_idx(ni);
+    if (ni) h2d(d_idx.p, indices, sizeof(uint64_t) * (size_t)ni);
+    // u in w's type
+    DevBuf<char> u_cast(0);
+    const void *uval = nullptr;
+    const uint64_t *ubits = nullptr;
+    if (u) {
+        vector_ensure_storage(u);
+        uval = u->d_val;
+        ubits = u->d_bits;
+        if (u->type->code != wt) {
+            dev_free(u_cast.p);
+            u_cast.p = (char *)dev_alloc(w->type->size * (size_t)std::max<uint64_t>(u->n, 1));
+            cast_array(wt, u_cast.p, u->type->code, u->d_val, (int64_t)u->n);
+            uval = u_cast.p;
+        }
+    }
+    // Z: w itself when nothing masks the write, else a copy
+    void *z_val = w->d_val;
+    uint64_t *z_bits = w->d_bits;
+    DevBuf<char> zv(0);
+    DevBuf<uint64_t> zb(0);
+    const bool in_place = !mask && !(u == w);
+    DevBuf<char> u_snap(0);
+    DevBuf<uint64_t> ub_snap(0);
+    if (u == w) {  // (aliased input: read a snapshot)
+        dev_free(u_snap.p); dev_free(ub_snap.p);
+        u_snap.p = (char *)dev_alloc(w->type->size * (size_t)w->n);
+        ub_snap.p = (uint64_t *)dev_alloc(bits_words64(w->n) * 8);
+        d2d(u_snap.p, w->d_val, w->type->size * (size_t)w->n);
+        d2d(ub_snap.p, w->d_bits, bits_words64(w->n) * 8);
+        uval = u_snap.p;
+        ubits = ub_snap.p;
+    }
+    if (!in_place && mask) {
+        dev_free(zv.p); dev_free(zb.p);
+        zv.p = (char *)dev_alloc(w->type->size * (size_t)w->n);
+        zb.p = (uint64_t *)dev_alloc(bits_words64(w->n) * 8);
+        d2d(zv.p, w->d_val, w->type->size * (size_t)w->n);
+        d2d(zb.p, w->d_bits, bits_words64(w->n) * 8);
+        z_val = zv.p;
+        z_bits = zb.p;
+    }
+    DevBuf<int> oob(1, true);
+    if (ni) {
+        GRB_DISPATCH_TYPE(wt, TW, {
+            TW sc{};
+            if (scalar_w) memcpy(&sc, scalar_w, sizeof(TW));
+            hipLaunchKernelGGL((k_assign_scatter<TW>), dim3((unsigned)ceil_div((int64_t)ni, 256)), dim3(256), 0, ctx().stream, (TW *)z_val,
+                               (unsigned long long *)z_bits, (const uint64_t *)d_idx.p, (int64_t)ni, (int64_t)w->n, (const TW *)uval, ubits,
+                               sc, accum ? canonical_op(wt, accum->op) : -1, oob.p);
+        })
+    }
+    check_oob(oob.p, "assign");
+    if (mask) {
+        DevBuf<uint64_t> mbits(bits_words64(w->n));
+        vector_mask_bits(mask, f.structure, mbits.p);
+        vector_write_rule(w, z_val, z_bits, mbits.p, f.comp, -1, f.replace);
+    }
+    w->nvals = -1;
+    sync_stream();  // (the index list was a host array borrowed for the call; temporaries go back to the block cache)
+}
+
+static void extract_indexed(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_BinaryOp_opaque *accum, GB_Vector_opaque *u,
+                            const uint64_t *indices, uint64_t ni, const GB_Descriptor_opaque *desc)
+{
+    const VDesc f = vflags(desc);
+    if (w->n != ni) fail(GrB_DIMENSION_MISMATCH, "extract: the output has " + std::to_string(w->n) + " elements, the index list " + std::to_string(ni));
+    if (mask && mask->n != w->n) fail(GrB_DIMENSION_MISMATCH, "extract: mask size does not match the output size");
+    if (accum && (accum->type != w->type->code || op_is_comparison(accum->op))) fail(GrB_DOMAIN_MISMATCH, "extract: accum operator type must equal the output type");
+    if (!indices) fail(GrB_NULL_POINTER, "extract: index list is NULL");
+    if (!mask && f.comp) {
+        if (f.replace) vector_release_storage(w);
+        return;
+    }
+    if (ni == 0) return;
+    DevBuf<uint64_t> d_idx(ni);
+    h2d(d_idx.p, indices, sizeof(uint64_t) * (size_t)ni);
+    const int ut = u->type->code;
+    DevBuf<char> t_val(u->type->size * (size_t)ni);
+    DevBuf<uint64_t> t_bits(bits_words64(ni), true);
+    DevBuf<int> oob(1, true);
+    GRB_DISPATCH_TYPE(ut, TU, {
+        hipLaunchKernelGGL((k_extract_gather<TU>), dim3((unsigned)ceil_div((int64_t)bits_words64(ni) * 64, 256)), dim3(256), 0, ctx().stream,
+                           (TU *)t_val.p, t_bits.p, (const uint64_t *)d_idx.p, (int64_t)ni, (int64_t)u->n, (const TU *)u->d_val,
+                           (const uint64_t *)(u->d_val ? u->d_bits : nullptr), oob.p);
+    })
+    check_oob(oob.p, "extract");
+    vector_ensure_storage(w);
+    DevBuf<char> tc(0);
+    const void *tw = t_val.p;
+    if (w->type->code != ut) {
+        dev_free(tc.p);
+        tc.p = (char *)dev_alloc(w->type->size * (size_t)ni);
+        cast_array(w->type->code, tc.p, ut, t_val.p, (int64_t)ni);
+        tw = tc.p;
+    }
+    DevBuf<uint64_t> mbits(mask ? bits_words64(w->n) : 1);
+    if (mask) vector_mask_bits(mask, f.structure, mbits.p);
+    vector_write_rule(w, tw, t_bits.p, mask ? mbits.p : nullptr, f.comp, accum ? canonical_op(w->type->code, accum->op) : -1, f.replace);
+    w->nvals = -1;
+    sync_stream();
+}
+
 }  // namespace grb
 
 using namespace grb;
 
 extern "C" const uint64_t *GrB_ALL;
+
+extern "C" GrB_Info GrB_Vector_assign(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_Vector u,
+                                      const GrB_Index *indices, GrB_Index nindices, const GrB_Descriptor desc)
+{
+    GRB_TRY
+    require_init();
+    check_vector(w, "w");
+    if (mask) check_vector(mask, "mask");
+    check_vector(u, "u");
+    if (indices == GrB_ALL) {
+        // every index, in order: the identity list (a plain copy under the write rule)
+        if (u->n != w->n) fail(GrB_DIMENSION_MISMATCH, "assign: input and output sizes differ");
+        std::vector<uint64_t> all(w->n);
+        for (uint64_t i = 0; i < w->n; i++) all[i] = i;
+        assign_indexed(w, mask, accum, u, nullptr, all.data(), w->n, desc);
+    } else {
+        assign_indexed(w, mask, accum, u, nullptr, indices, nindices, desc);
+    }
+    GRB_CATCH(errp(w))
+}
+
+extern "C" GrB_Info GrB_Vector_extract(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_Vector u,
+                                       const GrB_Index *indices, GrB_Index nindices, const GrB_Descriptor desc)
+{
+    GRB_TRY
+    require_init();
+    check_vector(w, "w");
+    if (mask) check_vector(mask, "mask");
+    check_vector(u, "u");
+    if (indices == GrB_ALL) {
+        std::vector<uint64_t> all(u->n);
+        for (uint64_t i = 0; i < u->n; i++) all[i] = i;
+        extract_indexed(w, mask, accum, u, all.data(), u->n, desc);
+    } else {
+        extract_indexed(w, mask, accum, u, indices, nindices, desc);
+    }
+    GRB_CATCH(errp(w))
+}
 
 extern "C" GrB_Info GrB_Vector_removeElement(GrB_Vector w, GrB_Index i)
 {
@@ -385,9 +603,14 @@ extern "C" GrB_Info GrB_Vector_removeElement(GrB_Vector w, GrB_Index i)
         require_init();                                                                                                                 \
         check_vector(w, "w");                                                                                                           \
         if (mask) check_vector(mask, "mask");                                                                                           \
-        if (indices != GrB_ALL) fail(GrB_NOT_IMPLEMENTED, "assign: only GrB_ALL index lists are supported");                            \
-        (void)nindices;                                                                                                                 \
-        assign_all<ctype>(w, mask, accum, x, desc);                                                                                     \
+        if (indices != GrB_ALL) {                                                                                                       \
+            GRB_DISPATCH_TYPE(w->type->code, TW_, {                                                                                     \
+                const TW_ xs = cast_value<TW_, ctype>(x);                                                                               \
+                assign_indexed(w, mask, accum, nullptr, &xs, indices, nindices, desc);                                                  \
+            })                                                                                                                          \
+        } else {                                                                                                                        \
+            assign_all<ctype>(w, mask, accum, x, desc);                                                                                 \
+        }                                                                                                                               \
         GRB_CATCH(errp(w))                                                                                                              \
     }                                                                                                                                   \
     extern "C" GrB_Info GrB_Vector_reduce_##NAME(ctype *val, const GrB_BinaryOp accum, const GrB_Monoid monoid, const GrB_Vector u,     \

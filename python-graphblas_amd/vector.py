@@ -19,6 +19,14 @@ def _ptr(a):
     return a.ctypes.data_as(ctypes.c_void_p) if a is not None and a.size else None
 
 
+_EMPTY_INDEX = np.zeros(1, np.uint64)
+
+
+def _iptr(idx):
+    """pointer to an index list (never NULL: NULL is not a legal list, an empty one is)"""
+    return (idx if idx.size else _EMPTY_INDEX).ctypes.data_as(ctypes.c_void_p)
+
+
 class Vector(BaseType):
     _grb_kind = "Vector"
     ndim = 1
@@ -197,17 +205,67 @@ class Vector(BaseType):
             raise IndexError(f"Index out of range: index={key}, size={self._size}")
         return i
 
+    def _index_list(self, key):
+        """Slices, lists and integer arrays as an explicit uint64 index array (reference core/expr.py IndexerResolver)."""
+        if isinstance(key, slice):
+            return np.arange(*key.indices(self._size), dtype=np.uint64)
+        a = np.asarray(key)
+        if a.ndim != 1 or a.dtype.kind not in "iu":
+            raise TypeError(f"Invalid type for index: {type(key).__name__}; integers, slices and integer lists are supported")
+        a = a.astype(np.int64)
+        a = np.where(a < 0, a + self._size, a)
+        if a.size and (a.min() < 0 or a.max() >= self._size):
+            raise IndexError(f"Index out of range: size={self._size}")
+        return np.ascontiguousarray(a, dtype=np.uint64)
+
+    @staticmethod
+    def _is_scalar_index(key):
+        return isinstance(key, (int, np.integer)) and not isinstance(key, (bool, np.bool_))
+
     def __getitem__(self, key):
-        """``v[i]`` -> scalar expression (reference core/vector.py:1840-1866); ``v[:]`` -> assign-to-everything target."""
+        """``v[i]`` -> scalar expression (reference core/vector.py:1840-1866); ``v[:]`` -> assign-to-everything target; ``v[I]``
+        with a slice or an index list -> extract expression / assign target (reference core/vector.py:1906-2035)."""
         if isinstance(key, slice) and key == slice(None):
             return AllIndexAssigner(self)
-        return _ElementExpr(self, self._index(key))
+        if self._is_scalar_index(key) or isinstance(key, (bool, np.bool_)):
+            return _ElementExpr(self, self._index(key))
+        return IndexedVector(self, self._index_list(key))
 
     def __setitem__(self, key, value):
         if isinstance(key, slice) and key == slice(None):
             AllIndexAssigner(self) << value
-        else:
+        elif self._is_scalar_index(key):
             self._element_assigner(key) << value
+        else:
+            IndexedVector(self, self._index_list(key)) << value
+
+    def _indexed_assigner(self, key, *, mask=None, accum=None, replace=False, opts=None):
+        return IndexedVector(self, self._index_list(key), mask=mask, accum=accum, replace=replace, opts=opts)
+
+    def _assign_indexed(self, value, idx, mask=None, accum=None, replace=False, *, opts):
+        """``w(mask, accum, replace)[I] << u`` -> GrB_Vector_assign; ``... << scalar`` -> GrB_Vector_assign_<T> with the index list
+        (reference core/vector.py:1979-2035)."""
+        from .base import InfixMatMul, _check_mask
+        from .descriptor import lookup as descriptor_lookup
+
+        if mask is None:
+            complement = structure = False
+        else:
+            mask = _check_mask(mask, self)
+            complement, structure = mask.complement, mask.structure
+        if accum is not None:
+            accum = get_typed_op(accum, self.dtype, kind="binary")
+            if hasattr(accum, "opclass") and accum.opclass == "Monoid":
+                accum = accum.binaryop
+        desc = descriptor_lookup(mask_complement=complement, mask_structure=structure, output_replace=replace, **(opts or {}))
+        if isinstance(value, (Expression, InfixMatMul)):
+            value = value.new()
+        if isinstance(value, Vector):
+            call("GrB_Vector_assign", [self, mask, accum, value, _iptr(idx), ctypes.c_uint64(idx.size), desc])
+            return
+        x = self._scalar_carg(value)
+        ctype = np.ctypeslib.as_ctypes_type(self.dtype.np_type)
+        call(f"GrB_Vector_assign_{self.dtype.name}", [self, mask, accum, ctype(x.item()), _iptr(idx), ctypes.c_uint64(idx.size), desc])
 
     def __delitem__(self, key):
         """reference core/vector.py:1916-1930"""
@@ -311,6 +369,31 @@ class Vector(BaseType):
 
     def __matmul__(self, other):
         return InfixMatMul(self, other)
+
+
+class IndexedVector(Expression):
+    """``v[I]`` with a slice or an index list: on the right of ``<<`` (or with ``.new()``) it extracts -- GrB_Vector_extract --,
+    on the left it is an assign target -- GrB_Vector_assign / GrB_Vector_assign_<T> (the reference's AmbiguousAssignOrExtract,
+    core/expr.py:240-400)."""
+
+    def __init__(self, parent, idx, *, mask=None, accum=None, replace=False, opts=None):
+        self.parent, self.idx = parent, idx
+        self.mask, self.accum, self.replace, self.opts = mask, accum, replace, opts or {}
+        super().__init__("extract", "GrB_Vector_extract", [parent, _iptr(idx), ctypes.c_uint64(idx.size)], op=None,
+                         output_type=Vector, shape=(int(idx.size),))
+
+    @property
+    def dtype(self):
+        return self.parent.dtype
+
+    def __call__(self, *args, **kwargs):
+        up = self.parent(*args, **kwargs)
+        return IndexedVector(self.parent, self.idx, mask=up.mask, accum=up.accum, replace=up.replace, opts=up.opts)
+
+    def __lshift__(self, value):
+        self.parent._assign_indexed(value, self.idx, mask=self.mask, accum=self.accum, replace=self.replace, opts=self.opts)
+
+    update = __lshift__
 
 
 class _ElementExpr(ScalarExpression):

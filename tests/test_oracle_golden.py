@@ -181,3 +181,18 @@ def test_scipy_crosscheck_plus_times():
     nz = np.diff(A.indptr) > 0
     assert y.idx.tolist() == np.flatnonzero(nz).tolist()
     np.testing.assert_allclose(y.vals, ref[nz], rtol=1e-12)
+
+
+def test_oracle_assign_extract_literals():
+    """The oracle's restatement of GrB_Vector_assign / GrB_Vector_extract reproduces the reference's literals
+    (graphblas/tests/test_vector.py:428-443, 505-541)."""
+    from oracle import grb_oracle as O
+
+    v = O.OVec(7, [1, 3, 4, 6], np.array([1, 1, 2, 0], np.int64), "INT64")
+    w = O.vec_extract(O.OVec.empty(3, "INT64"), v, [1, 3, 5])
+    assert w.idx.tolist() == [0, 1] and w.vals.tolist() == [1, 1]
+    u = O.OVec(3, [0, 2], np.array([9, 8], np.int64), "INT64")
+    w = O.vec_assign(v, u, [0, 2, 4])
+    assert w.idx.tolist() == [0, 1, 3, 4, 6] and w.vals.tolist() == [9, 1, 1, 8, 0]
+    w = O.vec_assign(v, 9, [1, 3, 5])
+    assert w.idx.tolist() == [1, 3, 4, 5, 6] and w.vals.tolist() == [9, 9, 2, 9, 0]

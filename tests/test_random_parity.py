@@ -1043,3 +1043,65 @@ def test_mxm_wide_heavy_rows(gb):
     assert np.array_equal(cp.astype(np.int64), ref.indptr) and np.array_equal(cj.astype(np.int64), ref.indices)
     assert np.array_equal(cx, ref.data)
     assert int(np.diff(ref.indptr).max()) > 16384  # (heavy rows really took the LDS-bitmap / window path)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_vector_assign_extract_random(gb, seed):
+    """GrB_Vector_assign (vector and scalar sources) and GrB_Vector_extract with random index lists (no duplicates for assign),
+    every mask form, accumulators, replace, typecasts between source and output -- against the oracle's restatement."""
+    rng = np.random.default_rng(7700 + seed)
+    tname = TYPES[seed % 7]
+    src_t = TYPES[(seed // 2) % 7] if seed % 3 == 0 and tname != "BOOL" else tname
+    if src_t == "BOOL" and tname != "BOOL":
+        src_t = tname
+    n = int(rng.integers(1, 400))
+    ni = int(rng.integers(0, n + 1))
+    I = rng.choice(n, ni, replace=False)
+    if seed % 4 == 0:
+        I = np.sort(I)
+    wi, wv = rand_vec(rng, n, 0.5, tname)
+    ui, uv = rand_vec(rng, ni, 0.6, src_t)
+    mi, mv = rand_vec(rng, n, 0.5, "BOOL")
+    accum = [None, "plus", "min", None][seed % 4] if tname != "BOOL" else [None, "lor"][seed % 2]
+    comp, struct, repl = bool(seed & 1), bool(seed & 2), bool(seed & 4)
+    use_mask = seed % 5 != 0
+    ow, ou, om = O.OVec(n, wi, wv, tname), O.OVec(ni, ui, uv, src_t), O.OVec(n, mi, mv, "BOOL")
+
+    def target(w):
+        mk = gb.Vector.from_coo(mi, mv, dtype="BOOL", size=n)
+        if not use_mask:
+            return w(accum=accum)
+        m = mk.S if struct else mk.V
+        return w(~m if comp else m, accum=accum, replace=repl)
+
+    kw = dict(mask=om if use_mask else None, mask_comp=comp and use_mask, mask_struct=struct, accum=accum, replace=repl and use_mask)
+    # vector source
+    w = gb.Vector.from_coo(wi, wv, dtype=tname, size=n)
+    u = gb.Vector.from_coo(ui, uv, dtype=src_t, size=ni)
+    target(w)[I] << u
+    same_vec(w, O.vec_assign(ow, ou, I, **kw))
+    # scalar source
+    w = gb.Vector.from_coo(wi, wv, dtype=tname, size=n)
+    sval = rand_vals(rng, 1, tname)[0]
+    target(w)[I] << sval
+    same_vec(w, O.vec_assign(ow, sval, I, **kw))
+    # extract (duplicates allowed): output of size nj from u2 of size n
+    nj = int(rng.integers(1, 300))
+    J = rng.integers(0, n, nj)
+    xi, xv = rand_vec(rng, nj, 0.5, tname)
+    m2i, m2v = rand_vec(rng, nj, 0.5, "BOOL")
+    x = gb.Vector.from_coo(xi, xv, dtype=tname, size=nj)
+    src = gb.Vector.from_coo(wi, wv, dtype=tname if src_t == tname else src_t, size=n) if False else gb.Vector.from_coo(wi, cast_to(wv, src_t), dtype=src_t, size=n)
+    mk2 = gb.Vector.from_coo(m2i, m2v, dtype="BOOL", size=nj)
+    if use_mask:
+        m = mk2.S if struct else mk2.V
+        x(~m if comp else m, accum=accum, replace=repl) << src[J]
+    else:
+        x(accum=accum) << src[J]
+    exp = O.vec_extract(O.OVec(nj, xi, xv, tname), O.OVec(n, wi, cast_to(wv, src_t), src_t), J, mask=O.OVec(nj, m2i, m2v, "BOOL") if use_mask else None,
+                        mask_comp=comp and use_mask, mask_struct=struct, accum=accum, replace=repl and use_mask)
+    same_vec(x, exp)
+
+
+def cast_to(vals, tname):
+    return O.cast(np.asarray(vals), tname)

@@ -695,8 +695,38 @@ def test_power_masked_final_product(gb, A):
         D = A.dup()
         D(~A.S, replace=True) << gb.semiring.min_plus(A.power(n - 1, gb.semiring.min_plus).new() @ A)
         assert C.isequal(D), n
-    with pytest.raises(gb.exceptions.NotImplementedException):
-        C(A.S) << A.power(1)  # a masked copy is a Matrix assign: outside this library's path
+    # the degenerate powers take the write rule too (a copy through GrB_transpose): equal to the product with the identity matrix
+    eye = gb.Matrix.from_coo(range(7), range(7), [1] * 7, dtype=A.dtype)
+    M = gb.Matrix.from_coo([0, 1, 3, 6, 6], [1, 4, 0, 2, 3], [True, False, True, True, True], nrows=7, ncols=7)
+    for n in (0, 1):
+        want = eye if n == 0 else A
+        for upd in (lambda X: X(M.S), lambda X: X(M.V, gb.binary.plus), lambda X: X(~M.S, replace=True), lambda X: X(accum=gb.binary.min)):
+            C = A.dup()
+            upd(C) << A.power(n)
+            D = A.dup()
+            upd(D) << eye.mxm(want, gb.semiring.plus_times)
+            assert heq(C, D), n
+
+
+def test_masked_transpose(gb, A):
+    """``C(mask, accum, replace) << A.T`` -> GrB_transpose with the write rule (reference core/base.py:401-411): equal to the
+    product of the identity matrix with the transposed operand under the same mask / accumulator (mxm's own write rule)."""
+    eye = gb.Matrix.from_coo(range(7), range(7), [1] * 7, dtype=A.dtype)
+    M = gb.Matrix.from_coo([0, 1, 3, 3, 6, 6, 5], [1, 4, 0, 2, 2, 3, 2], [True, False, True, True, True, False, True], nrows=7, ncols=7)
+    rows, cols, vals = A.to_coo()
+    assert heq(A.T.new(), gb.Matrix.from_coo(cols, rows, vals, nrows=7, ncols=7))  # graphblas/tests/test_matrix.py:1700-1711
+    for upd in (lambda X: X(M.S), lambda X: X(M.V), lambda X: X(~M.V, replace=True), lambda X: X(M.S, gb.binary.plus),
+                lambda X: X(accum=gb.binary.times), lambda X: X(~M.S, gb.binary.min, replace=True)):
+        C = A.dup()
+        upd(C) << A.T
+        D = A.dup()
+        upd(D) << eye.mxm(A.T, gb.semiring.plus_times)
+        assert heq(C, D)
+    C = A.dup()
+    C(C.S) << C.T  # output aliased with the input and the mask
+    D = A.dup()
+    D(A.S) << eye.mxm(A.T, gb.semiring.plus_times)
+    assert heq(C, D)
 
 
 def test_index_max(gb):
@@ -727,3 +757,43 @@ def test_index_max(gb):
     assert P.shape == (3, 4) and P.nvals == 0
     B.resize(3, 5)
     assert B.shape == (3, 5)
+
+
+def test_extract_and_assign_with_index_lists(gb, v):
+    # graphblas/tests/test_vector.py:428-443 (extract), :505-517 (assign), :520-541 (assign a scalar)
+    w = gb.Vector(v.dtype, 3)
+    result = gb.Vector.from_coo([0, 1], [1, 1], size=3)
+    w << v[[1, 3, 5]]
+    assert heq(w, result)
+    w() << v[1::2]
+    assert heq(w, result)
+    assert heq(v[1::2].new(), w)
+    w << v[np.array([1, 3, 5])]
+    assert heq(w, result)
+    u = gb.Vector.from_coo([0, 2], [9, 8])
+    result = gb.Vector.from_coo([0, 1, 3, 4, 6], [9, 1, 1, 8, 0])
+    w = v.dup()
+    w[[0, 2, 4]] = u
+    assert heq(w, result)
+    w = v.dup()
+    w[:5:2] << u
+    assert heq(w, result)
+    with pytest.raises(TypeError, match="Invalid type for index"):
+        w[w] = 1
+    result = gb.Vector.from_coo([1, 3, 4, 5, 6], [9, 9, 2, 9, 0])
+    w = v.dup()
+    w[[1, 3, 5]] = 9
+    assert heq(w, result)
+    w = v.dup()
+    w[1::2] = 9
+    assert heq(w, result)
+    with pytest.raises(IndexError):
+        v[[-v.size - 1]]
+    # accumulate into a sub-vector, and a mask of the output's size with replace (C API 2.0 GrB_assign)
+    w = v.dup()
+    w(gb.binary.plus)[[1, 2, 4]] << gb.Vector.from_coo([0, 1], [10, 20], size=3)
+    assert heq(w, gb.Vector.from_coo([1, 2, 3, 4, 6], [11, 20, 1, 2, 0]))
+    m = gb.Vector.from_coo([1, 2, 3], [True, True, False], size=7)
+    w = v.dup()
+    w(m.V, replace=True)[[1, 2, 4]] << gb.Vector.from_coo([0, 1], [10, 20], size=3)
+    assert heq(w, gb.Vector.from_coo([1, 2], [10, 20], size=7))
