@@ -70,6 +70,9 @@ typedef struct GB_Semiring_opaque *GrB_Semiring;
 typedef struct GB_Descriptor_opaque *GrB_Descriptor;
 typedef struct GB_Vector_opaque *GrB_Vector;
 typedef struct GB_Matrix_opaque *GrB_Matrix;
+typedef struct GB_UnaryOp_opaque *GrB_UnaryOp;           /* handles only: see "import-time surface" below */
+typedef struct GB_IndexUnaryOp_opaque *GrB_IndexUnaryOp;
+typedef struct GB_Scalar_opaque *GrB_Scalar;
 
 /* GrB_ALL: the reference only compares this pointer (core/expr.py:14) */
 extern const uint64_t *GrB_ALL;
@@ -297,6 +300,101 @@ GrB_Info GrX_Matrix_cache_bytes(const GrB_Matrix A, uint64_t *bytes);
  *                   matrix indexed like u is at hand, 2 always push when possible */
 GrB_Info GrX_option_set(const char *name, int64_t value);
 const char *GrX_version_string(void);
+
+/* ================================================================================================================
+ * Import-time surface beyond the hot path: what an unmodified python-graphblas resolves on `lib`
+ * while it is IMPORTED -- handle types, builtin unary / index-unary / remaining binary operators as data symbols
+ * (graphblas/core/mask.py:1-5 `select.valuene`, `unary.one`; core/operator/base.py:803-893 regex discovery) -- and the entry
+ * points of the operations this library does not accelerate.  Those entry points exist with their C API 2.0 signatures and
+ * return GrB_NOT_IMPLEMENTED; operator handles the kernels do not implement are rejected with GrB_NOT_IMPLEMENTED wherever
+ * a call consumes them.  GrB_Scalar is real (a host-side value + presence).  scripts/lib_surface_report.py diffs the names
+ * the reference touches against `nm -D` of the built library.
+ * ================================================================================================================ */
+#define GRB_DECL_UNARY(T)                                                                                              \
+    extern GrB_UnaryOp GrB_IDENTITY_##T, GrB_AINV_##T, GrB_MINV_##T, GrB_ABS_##T, GxB_ONE_##T, GxB_LNOT_##T;           \
+    extern GrB_IndexUnaryOp GrB_VALUEEQ_##T, GrB_VALUENE_##T, GrB_VALUEGT_##T, GrB_VALUEGE_##T, GrB_VALUELT_##T,       \
+        GrB_VALUELE_##T;                                                                                               \
+    extern GrB_BinaryOp GrB_DIV_##T, GxB_RDIV_##T, GxB_RMINUS_##T, GxB_ISEQ_##T, GxB_ISNE_##T, GxB_ISGT_##T,           \
+        GxB_ISLT_##T, GxB_ISGE_##T, GxB_ISLE_##T, GxB_POW_##T;
+GRB_FOR_EACH_TNAME(GRB_DECL_UNARY)
+#undef GRB_DECL_UNARY
+extern GrB_UnaryOp GrB_LNOT, GrB_BNOT_INT8, GrB_BNOT_INT16, GrB_BNOT_INT32, GrB_BNOT_INT64, GrB_BNOT_UINT8, GrB_BNOT_UINT16,
+    GrB_BNOT_UINT32, GrB_BNOT_UINT64;
+extern GrB_IndexUnaryOp GrB_ROWINDEX_INT32, GrB_ROWINDEX_INT64, GrB_COLINDEX_INT32, GrB_COLINDEX_INT64, GrB_DIAGINDEX_INT32,
+    GrB_DIAGINDEX_INT64, GrB_TRIL, GrB_TRIU, GrB_DIAG, GrB_OFFDIAG, GrB_COLLE, GrB_COLGT, GrB_ROWLE, GrB_ROWGT;
+
+GrB_Info GrB_Scalar_new(GrB_Scalar *s, GrB_Type type);
+GrB_Info GrB_Scalar_dup(GrB_Scalar *s, const GrB_Scalar t);
+GrB_Info GrB_Scalar_free(GrB_Scalar *s);
+GrB_Info GrB_Scalar_clear(GrB_Scalar s);
+GrB_Info GrB_Scalar_nvals(GrB_Index *nvals, const GrB_Scalar s);
+GrB_Info GrB_Scalar_wait(GrB_Scalar s, GrB_WaitMode mode);
+GrB_Info GrB_Scalar_error(const char **error, const GrB_Scalar s);
+
+GrB_Info GrB_Vector_apply(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_UnaryOp op, const GrB_Vector u, const GrB_Descriptor desc);
+GrB_Info GrB_Matrix_apply(GrB_Matrix C, const GrB_Matrix Mask, const GrB_BinaryOp accum, const GrB_UnaryOp op, const GrB_Matrix A, const GrB_Descriptor desc);
+GrB_Info GrB_Vector_eWiseAdd_Semiring(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_Semiring op, const GrB_Vector u, const GrB_Vector v, const GrB_Descriptor desc);
+GrB_Info GrB_Vector_eWiseMult_Semiring(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_Semiring op, const GrB_Vector u, const GrB_Vector v, const GrB_Descriptor desc);
+#define GRB_DECL_MAT_BINARY(FN, HANDLE) \
+    GrB_Info FN(GrB_Matrix C, const GrB_Matrix Mask, const GrB_BinaryOp accum, const HANDLE op, const GrB_Matrix A, const GrB_Matrix B, const GrB_Descriptor desc);
+GRB_DECL_MAT_BINARY(GrB_Matrix_eWiseAdd_BinaryOp, GrB_BinaryOp)
+GRB_DECL_MAT_BINARY(GrB_Matrix_eWiseAdd_Monoid, GrB_Monoid)
+GRB_DECL_MAT_BINARY(GrB_Matrix_eWiseAdd_Semiring, GrB_Semiring)
+GRB_DECL_MAT_BINARY(GrB_Matrix_eWiseMult_BinaryOp, GrB_BinaryOp)
+GRB_DECL_MAT_BINARY(GrB_Matrix_eWiseMult_Monoid, GrB_Monoid)
+GRB_DECL_MAT_BINARY(GrB_Matrix_eWiseMult_Semiring, GrB_Semiring)
+GRB_DECL_MAT_BINARY(GrB_Matrix_kronecker_BinaryOp, GrB_BinaryOp)
+GRB_DECL_MAT_BINARY(GrB_Matrix_kronecker_Monoid, GrB_Monoid)
+GRB_DECL_MAT_BINARY(GrB_Matrix_kronecker_Semiring, GrB_Semiring)
+#undef GRB_DECL_MAT_BINARY
+GrB_Info GrB_Matrix_assign(GrB_Matrix C, const GrB_Matrix Mask, const GrB_BinaryOp accum, const GrB_Matrix A, const GrB_Index *I, GrB_Index ni, const GrB_Index *J, GrB_Index nj, const GrB_Descriptor desc);
+GrB_Info GrB_Row_assign(GrB_Matrix C, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_Vector u, GrB_Index i, const GrB_Index *J, GrB_Index nj, const GrB_Descriptor desc);
+GrB_Info GrB_Col_assign(GrB_Matrix C, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_Vector u, const GrB_Index *I, GrB_Index ni, GrB_Index j, const GrB_Descriptor desc);
+GrB_Info GrB_Matrix_extract(GrB_Matrix C, const GrB_Matrix Mask, const GrB_BinaryOp accum, const GrB_Matrix A, const GrB_Index *I, GrB_Index ni, const GrB_Index *J, GrB_Index nj, const GrB_Descriptor desc);
+GrB_Info GrB_Col_extract(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_Matrix A, const GrB_Index *I, GrB_Index ni, GrB_Index j, const GrB_Descriptor desc);
+GrB_Info GrB_Matrix_reduce_BinaryOp(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_BinaryOp op, const GrB_Matrix A, const GrB_Descriptor desc);
+GrB_Info GrB_Matrix_reduce_Monoid_Scalar(GrB_Scalar s, const GrB_BinaryOp accum, const GrB_Monoid monoid, const GrB_Matrix A, const GrB_Descriptor desc);
+GrB_Info GrB_Vector_reduce_Monoid_Scalar(GrB_Scalar s, const GrB_BinaryOp accum, const GrB_Monoid monoid, const GrB_Vector u, const GrB_Descriptor desc);
+GrB_Info GrB_Matrix_removeElement(GrB_Matrix C, GrB_Index i, GrB_Index j);
+GrB_Info GrB_Matrix_diag(GrB_Matrix *C, const GrB_Vector v, int64_t k);
+GrB_Info GrB_Vector_assign_Scalar(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_Scalar s, const GrB_Index *I, GrB_Index ni, const GrB_Descriptor desc);
+GrB_Info GrB_Vector_setElement_Scalar(GrB_Vector w, const GrB_Scalar s, GrB_Index i);
+GrB_Info GrB_Vector_extractElement_Scalar(GrB_Scalar s, const GrB_Vector u, GrB_Index i);
+GrB_Info GrB_Matrix_assign_Scalar(GrB_Matrix C, const GrB_Matrix Mask, const GrB_BinaryOp accum, const GrB_Scalar s, const GrB_Index *I, GrB_Index ni, const GrB_Index *J, GrB_Index nj, const GrB_Descriptor desc);
+GrB_Info GrB_Matrix_setElement_Scalar(GrB_Matrix C, const GrB_Scalar s, GrB_Index i, GrB_Index j);
+GrB_Info GrB_Matrix_extractElement_Scalar(GrB_Scalar s, const GrB_Matrix A, GrB_Index i, GrB_Index j);
+GrB_Info GrB_Vector_select_Scalar(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_IndexUnaryOp op, const GrB_Vector u, const GrB_Scalar y, const GrB_Descriptor desc);
+GrB_Info GrB_Matrix_select_Scalar(GrB_Matrix C, const GrB_Matrix Mask, const GrB_BinaryOp accum, const GrB_IndexUnaryOp op, const GrB_Matrix A, const GrB_Scalar y, const GrB_Descriptor desc);
+GrB_Info GrB_Vector_apply_BinaryOp1st_Scalar(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_BinaryOp op, const GrB_Scalar x, const GrB_Vector u, const GrB_Descriptor desc);
+GrB_Info GrB_Vector_apply_BinaryOp2nd_Scalar(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_BinaryOp op, const GrB_Vector u, const GrB_Scalar y, const GrB_Descriptor desc);
+GrB_Info GrB_Vector_apply_IndexOp_Scalar(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_IndexUnaryOp op, const GrB_Vector u, const GrB_Scalar y, const GrB_Descriptor desc);
+GrB_Info GrB_Matrix_apply_BinaryOp1st_Scalar(GrB_Matrix C, const GrB_Matrix Mask, const GrB_BinaryOp accum, const GrB_BinaryOp op, const GrB_Scalar x, const GrB_Matrix A, const GrB_Descriptor desc);
+GrB_Info GrB_Matrix_apply_BinaryOp2nd_Scalar(GrB_Matrix C, const GrB_Matrix Mask, const GrB_BinaryOp accum, const GrB_BinaryOp op, const GrB_Matrix A, const GrB_Scalar y, const GrB_Descriptor desc);
+GrB_Info GrB_Matrix_apply_IndexOp_Scalar(GrB_Matrix C, const GrB_Matrix Mask, const GrB_BinaryOp accum, const GrB_IndexUnaryOp op, const GrB_Matrix A, const GrB_Scalar y, const GrB_Descriptor desc);
+/* user-defined types and operators need a JIT (numba -> C callbacks in the reference): not on this library's path */
+GrB_Info GrB_Type_new(GrB_Type *type, size_t size);
+GrB_Info GrB_UnaryOp_new(GrB_UnaryOp *op, void *fn, GrB_Type ztype, GrB_Type xtype);
+GrB_Info GrB_BinaryOp_new(GrB_BinaryOp *op, void *fn, GrB_Type ztype, GrB_Type xtype, GrB_Type ytype);
+GrB_Info GrB_IndexUnaryOp_new(GrB_IndexUnaryOp *op, void *fn, GrB_Type ztype, GrB_Type xtype, GrB_Type ytype);
+GrB_Info GrB_Semiring_new(GrB_Semiring *semiring, GrB_Monoid add, GrB_BinaryOp mult);
+#define GRB_DECL_SURFACE_TYPED(NAME, ctype)                                                                                                  \
+    GrB_Info GrB_Scalar_setElement_##NAME(GrB_Scalar s, ctype x);                                                                            \
+    GrB_Info GrB_Scalar_extractElement_##NAME(ctype *x, const GrB_Scalar s);                                                                 \
+    GrB_Info GrB_Monoid_new_##NAME(GrB_Monoid *monoid, GrB_BinaryOp op, ctype identity);                                                     \
+    GrB_Info GrB_Matrix_setElement_##NAME(GrB_Matrix C, ctype x, GrB_Index i, GrB_Index j);                                                  \
+    GrB_Info GrB_Matrix_extractElement_##NAME(ctype *x, const GrB_Matrix A, GrB_Index i, GrB_Index j);                                       \
+    GrB_Info GrB_Matrix_reduce_##NAME(ctype *val, const GrB_BinaryOp accum, const GrB_Monoid monoid, const GrB_Matrix A, const GrB_Descriptor desc); \
+    GrB_Info GrB_Matrix_assign_##NAME(GrB_Matrix C, const GrB_Matrix Mask, const GrB_BinaryOp accum, ctype x, const GrB_Index *I, GrB_Index ni, const GrB_Index *J, GrB_Index nj, const GrB_Descriptor desc); \
+    GrB_Info GrB_Vector_select_##NAME(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_IndexUnaryOp op, const GrB_Vector u, ctype y, const GrB_Descriptor desc); \
+    GrB_Info GrB_Matrix_select_##NAME(GrB_Matrix C, const GrB_Matrix Mask, const GrB_BinaryOp accum, const GrB_IndexUnaryOp op, const GrB_Matrix A, ctype y, const GrB_Descriptor desc); \
+    GrB_Info GrB_Vector_apply_BinaryOp1st_##NAME(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_BinaryOp op, ctype x, const GrB_Vector u, const GrB_Descriptor desc); \
+    GrB_Info GrB_Vector_apply_BinaryOp2nd_##NAME(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_BinaryOp op, const GrB_Vector u, ctype y, const GrB_Descriptor desc); \
+    GrB_Info GrB_Vector_apply_IndexOp_##NAME(GrB_Vector w, const GrB_Vector mask, const GrB_BinaryOp accum, const GrB_IndexUnaryOp op, const GrB_Vector u, ctype y, const GrB_Descriptor desc); \
+    GrB_Info GrB_Matrix_apply_BinaryOp1st_##NAME(GrB_Matrix C, const GrB_Matrix Mask, const GrB_BinaryOp accum, const GrB_BinaryOp op, ctype x, const GrB_Matrix A, const GrB_Descriptor desc); \
+    GrB_Info GrB_Matrix_apply_BinaryOp2nd_##NAME(GrB_Matrix C, const GrB_Matrix Mask, const GrB_BinaryOp accum, const GrB_BinaryOp op, const GrB_Matrix A, ctype y, const GrB_Descriptor desc); \
+    GrB_Info GrB_Matrix_apply_IndexOp_##NAME(GrB_Matrix C, const GrB_Matrix Mask, const GrB_BinaryOp accum, const GrB_IndexUnaryOp op, const GrB_Matrix A, ctype y, const GrB_Descriptor desc);
+GRB_FOR_EACH_TYPE(GRB_DECL_SURFACE_TYPED)
+#undef GRB_DECL_SURFACE_TYPED
 
 #ifdef __cplusplus
 }

@@ -30,7 +30,10 @@ enum OpCode : int {
     OP_FIRST = 0, OP_SECOND, OP_PAIR, OP_PLUS, OP_MINUS, OP_RMINUS, OP_TIMES, OP_MIN, OP_MAX,
     OP_LOR, OP_LAND, OP_LXOR, OP_LXNOR, OP_ANY, OP_COUNT,
     // comparisons: T x T -> BOOL; accepted by the element-wise vector operations only (grb_vecops.hip)
-    OP_EQ = 32, OP_NE, OP_GT, OP_LT, OP_GE, OP_LE
+    OP_EQ = 32, OP_NE, OP_GT, OP_LT, OP_GE, OP_LE,
+    // builtin operators that exist as handles (import-time surface, grb_surface.hip) but that no kernel implements: every entry
+    // point rejects them with GrB_NOT_IMPLEMENTED (canonical_op)
+    OP_UNSUPPORTED = 1000
 };
 inline bool op_is_comparison(int op) { return op >= OP_EQ && op <= OP_LE; }
 

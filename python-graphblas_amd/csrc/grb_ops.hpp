@@ -115,6 +115,7 @@ GRB_HD bool monoid_is_terminal(int op, T v)
 
 inline int canonical_op(int type, int op)
 {
+    if (op >= OP_UNSUPPORTED) fail(GrB_NOT_IMPLEMENTED, "this builtin operator is not implemented by libgrb_mi355x (handle-only: import-time surface)");
     if (type != TC_BOOL) return op;
     switch (op) {
     case OP_PLUS: case OP_MAX: return OP_LOR;

@@ -69,3 +69,31 @@ def test_init_needs_a_device(lib):
         pass
     lib.GrB_init.argtypes = [ctypes.c_int]
     assert lib.GrB_init(0) == -101
+
+
+def test_import_time_surface(lib, declared):
+    """Handle types, builtin unary / index-unary operator handles and the entry points of the operations outside the path exist
+    (python-graphblas resolves them while it is imported: graphblas/core/mask.py:1-5, core/operator/base.py:803-893); GrB_Scalar
+    is real and needs no device."""
+    funcs, data = declared
+    for d in ("GrB_VALUENE_INT64", "GxB_ONE_BOOL", "GrB_IDENTITY_FP64", "GrB_LNOT", "GrB_TRIL", "GrB_ROWINDEX_INT64", "GrB_DIV_FP32",
+              "GxB_RMINUS_INT32"):
+        assert d in data and ctypes.c_void_p.in_dll(lib, d).value
+    for f in ("GrB_Matrix_apply", "GrB_Vector_select_INT64", "GrB_Matrix_eWiseAdd_BinaryOp", "GrB_Matrix_assign_FP64", "GrB_Matrix_extract",
+              "GrB_Matrix_kronecker_Semiring", "GrB_Scalar_new", "GrB_Vector_assign", "GrB_Vector_extract", "GrX_mxm_streamed"):
+        assert f in funcs and hasattr(lib, f)
+    s = ctypes.c_void_p()
+    assert lib.GrB_Scalar_new(ctypes.byref(s), ctypes.c_void_p.in_dll(lib, "GrB_FP64")) == 0
+    n = ctypes.c_uint64(7)
+    assert lib.GrB_Scalar_nvals(ctypes.byref(n), s) == 0 and n.value == 0
+    x = ctypes.c_double(0)
+    assert lib.GrB_Scalar_extractElement_FP64(ctypes.byref(x), s) == 1  # GrB_NO_VALUE
+    lib.GrB_Scalar_setElement_INT32.argtypes = [ctypes.c_void_p, ctypes.c_int32]
+    assert lib.GrB_Scalar_setElement_INT32(s, -5) == 0
+    assert lib.GrB_Scalar_extractElement_FP64(ctypes.byref(x), s) == 0 and x.value == -5.0
+    assert lib.GrB_Scalar_nvals(ctypes.byref(n), s) == 0 and n.value == 1
+    assert lib.GrB_Scalar_clear(s) == 0 and lib.GrB_Scalar_nvals(ctypes.byref(n), s) == 0 and n.value == 0
+    assert lib.GrB_Scalar_free(ctypes.byref(s)) == 0 and s.value is None
+    # an entry point outside the path answers GrB_NOT_IMPLEMENTED (-8) even on NULL arguments
+    lib.GrB_Matrix_apply.argtypes = [ctypes.c_void_p] * 6
+    assert lib.GrB_Matrix_apply(None, None, None, None, None, None) == -8
