@@ -34,13 +34,13 @@ def measured_traffic(workload, scale):
     import glob
 
     best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_traffic.json"))):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_traffic*.json"))):
         try:
             rec = json.load(open(path))
         except (OSError, ValueError):
             continue
         if rec.get("workload") == workload and rec.get("scale") == scale:
-            best = rec
+            best = rec  # (directories sort by round: the newest matching profile wins)
     return best["traffic_bytes_per_launch"] if best else None
 
 
@@ -210,7 +210,7 @@ def cpu_baseline_suitesparse(lib, wl, torch, reps=3):
     from graphblas_amd import device, synthetic
 
     P, c_u64, vp = ctypes.POINTER, ctypes.c_uint64, ctypes.c_void_p
-    if lib.GrB_init(0) not in (0, -1 if False else 0):  # GrB_NONBLOCKING
+    if lib.GrB_init(0) != 0:  # GrB_NONBLOCKING
         return None
     ip, cj = (t.cpu().numpy() for t in wl._keep)
     m, n = wl.m, wl.n
