@@ -274,6 +274,9 @@ GrB_Info GrX_last_stats(GrX_Stats *stats);
  * have the semiring's type.  Replaces nothing in the reference: GrB_mxm (graphblas/core/matrix.py:2264-2331) materialises C. */
 GrB_Info GrX_mxm_streamed(const GrB_Semiring semiring, const GrB_Matrix A, const GrB_Matrix B, uint64_t budget_bytes,
                           uint64_t *nvals, uint64_t *checksum, uint64_t *flops, uint64_t *batches);
+/* Same shape, same pattern and values equal (rel_tol = abs_tol = 0) or close (|a - b| <= rel_tol |b| + abs_tol), compared on the
+ * device in a common type (reference Matrix.isequal / isclose, core/matrix.py:373-467, do it with eWiseMult + reduce). */
+GrB_Info GrX_Matrix_isclose(bool *result, const GrB_Matrix A, const GrB_Matrix B, double rel_tol, double abs_tol);
 /* Device bytes of the SpMV layouts cached with A so far (hot-coded columns, short part, long-row strips / items). */
 GrB_Info GrX_Matrix_cache_bytes(const GrB_Matrix A, uint64_t *bytes);
 /* Tuning / diagnostics knobs (also read from the environment at GrB_init as GRB_<NAME upper-case>):

@@ -484,6 +484,17 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
             ctx().stats.tiles = A->sell_slots;  // (slots incl. padding; the short part holds S->nvals entries)
             return;
         }
+        if (ctx().short_kernel == 3 && S->nrows == A->nrows) {
+            // short rows from persistent workgroups that keep the head of the operand image in LDS
+            b.long_prefix = A->d_long_prefix;
+            const int64_t groups = ceil_div(b.m, 64);
+            const int64_t G = std::max<int64_t>(1, std::min<int64_t>((int64_t)ctx().num_cus, ceil_div(groups, ROWS_HEAD_BLOCK / 64)));
+            hipLaunchKernelGGL((k_mxv_rows_head<T, MON, MUL>), dim3((unsigned)G), dim3(ROWS_HEAD_BLOCK), 0, ctx().stream, b);
+            GRB_HIP(hipGetLastError());
+            ctx().stats.kernel_launches += 1;
+            ctx().stats.tiles = groups;
+            return;
+        }
         if (ctx().short_kernel == 1 && S->nrows == A->nrows) {
             // short rows: one wavefront per 64 consecutive rows, which also applies the write rule of the long rows
             b.long_prefix = A->d_long_prefix;
@@ -679,7 +690,8 @@ static void mxv_core(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_Binar
     // alone (k_mxv_rowlen) -- the aggregators count / exists are this case (reference core/operator/agg.py:264-283, :360-378)
     const bool by_rowlen = (mult == OP_PAIR && a.u_full && !(ctx().debug_flags & 65536));
     a.x_len = (int64_t)u->n;
-    if ((uint64_t)u->n * type_size(st) >= 0xff000000ull)
+    // (an operand that is never read -- full, values unused: the row reductions -- is not subject to the 32-bit buffer range)
+    if ((a.need_uval || !a.u_full) && (uint64_t)u->n * type_size(st) >= 0xff000000ull)
         fail(GrB_NOT_IMPLEMENTED, "mxv/vxm: input vectors of 4 GiB or more are not supported by the pull kernel yet");
     // hot-column table (wide matrices with a skewed column-degree distribution): the kernel indexes ONE image
     // [ K hot entries | the n entries of u ] with the re-coded column indices (hot rank, or K + col)

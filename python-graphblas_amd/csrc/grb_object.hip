@@ -1068,6 +1068,61 @@ extern "C" GrB_Info GrB_Matrix_exportHint(GrB_Format *format, const GrB_Matrix A
     return GrB_SUCCESS;
 }
 
+// ---- device-side comparison (reference Matrix.isequal / isclose, core/matrix.py:373-467: same shape, same pattern, values equal /
+//      within rel_tol * |b| + abs_tol after a cast to a common type) -- nothing travels to the host but the verdict ----------------
+template <typename T>
+__global__ void k_mat_compare(const int64_t *Ap, const int64_t *Bp, int64_t m1, const int32_t *Aj, const int32_t *Bj, const T *Ax, int a_iso,
+                              const T *Bx, int b_iso, int64_t nnz, double rel_tol, double abs_tol, int *differ)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool bad = false;
+    if (i < m1) bad = Ap[i] != Bp[i];
+    if (i < nnz) {
+        bad = bad || Aj[i] != Bj[i];
+        const T x = Ax[a_iso ? 0 : i], y = Bx[b_iso ? 0 : i];
+        if (rel_tol == 0.0 && abs_tol == 0.0) bad = bad || !(x == y);
+        else {
+            const double dx = (double)x, dy = (double)y;
+            const double d = dx > dy ? dx - dy : dy - dx, ay = dy < 0 ? -dy : dy;
+            bad = bad || !(d <= rel_tol * ay + abs_tol || dx == dy);
+        }
+    }
+    if (__ballot(bad) && (threadIdx.x & 63) == 0) *differ = 1;
+}
+
+extern "C" GrB_Info GrX_Matrix_isclose(bool *result, const GrB_Matrix A, const GrB_Matrix B, double rel_tol, double abs_tol)
+{
+    GRB_TRY
+    require_init();
+    check_matrix(A, "A");
+    check_matrix(B, "B");
+    if (!result) fail(GrB_NULL_POINTER, "result is NULL");
+    *result = false;
+    if (A->nrows != B->nrows || A->ncols != B->ncols || A->nvals != B->nvals) return GrB_SUCCESS;
+    if (A->nvals == 0) {
+        *result = true;
+        return GrB_SUCCESS;
+    }
+    // values in a common type: the wider of the two (FP64 when they differ in kind)
+    int ct = A->type->code;
+    if (B->type->code != ct) ct = (A->type->code >= TC_FP32 || B->type->code >= TC_FP32) ? TC_FP64 : (A->type->size >= B->type->size ? A->type->code : B->type->code);
+    GB_Matrix_opaque *Ac = ct == A->type->code ? nullptr : matrix_cast_copy(A, ct);
+    GB_Matrix_opaque *Bc = ct == B->type->code ? nullptr : matrix_cast_copy(B, ct);
+    const GB_Matrix_opaque *X = Ac ? Ac : A, *Y = Bc ? Bc : B;
+    DevBuf<int> differ(1, true);
+    const int64_t threads = std::max<int64_t>((int64_t)A->nrows + 1, A->nvals);
+    GRB_DISPATCH_TYPE(ct, T, {
+        LAUNCH((k_mat_compare<T>), threads, (const int64_t *)X->d_ptr, (const int64_t *)Y->d_ptr, (int64_t)A->nrows + 1, (const int32_t *)X->d_col,
+               (const int32_t *)Y->d_col, (const T *)X->d_val, X->iso ? 1 : 0, (const T *)Y->d_val, Y->iso ? 1 : 0, A->nvals, rel_tol, abs_tol, differ.p);
+    })
+    int h = 0;
+    d2h(&h, differ.p, sizeof(int));
+    if (Ac) matrix_free(Ac);
+    if (Bc) matrix_free(Bc);
+    *result = h == 0;
+    GRB_CATCH(errp(A))
+}
+
 extern "C" GrB_Info GrB_transpose(GrB_Matrix C, const GrB_Matrix Mask, const GrB_BinaryOp accum, const GrB_Matrix A,
                                   const GrB_Descriptor desc)
 {

@@ -203,17 +203,20 @@ class Matrix(BaseType):
             return False
         if self.shape != other.shape or self.nvals != other.nvals:
             return False
-        a, b = self.to_coo(), other.to_coo()
-        return bool(all(np.array_equal(x, y) for x, y in zip(a, b)))
+        return self._compare_on_device(other, 0.0, 0.0)
+
+    def _compare_on_device(self, other, rel_tol, abs_tol):
+        """pattern and values compared by the library on the device: only the verdict comes back"""
+        eq = ctypes.c_bool(False)
+        call_on(self, "GrX_Matrix_isclose", [ctypes.byref(eq), self._handle, other._handle, ctypes.c_double(rel_tol), ctypes.c_double(abs_tol)])
+        return bool(eq.value)
 
     def isclose(self, other, *, rel_tol=1e-7, abs_tol=0.0, check_dtype=False):
         if check_dtype and self.dtype is not other.dtype:
             return False
         if self.shape != other.shape or self.nvals != other.nvals:
             return False
-        a, b = self.to_coo(), other.to_coo()
-        return bool(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
-                    and np.allclose(a[2].astype(float), b[2].astype(float), rtol=rel_tol, atol=abs_tol))
+        return self._compare_on_device(other, float(rel_tol), float(abs_tol))
 
     # ---- the hot path ---------------------------------------------------------------------------------------
     def mxv(self, other, op=_semiring.plus_times):

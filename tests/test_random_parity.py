@@ -14,6 +14,7 @@ from tests.backend import DEVICES, bind
 TYPES = ["INT64", "FP32", "BOOL", "FP64", "INT8", "UINT16", "INT32"]
 import os
 
+DEFAULT_SHORT_KERNEL = int(os.environ.get("GRB_SHORT_KERNEL", "1"))
 DEFAULT_LONG_KERNEL = int(os.environ.get("GRB_LONG_KERNEL", "3"))  # what tests restore after forcing a long-row kernel
 
 
@@ -486,7 +487,8 @@ def test_long_short_row_split(gb, seed):
         _lib.lib.GrX_option_set(b"split_min_len", 8)
         _lib.lib.GrX_option_set(b"push_mode", 0)
         # merge-path kernel / row-group kernel / sliced-ELLPACK kernel for the short rows
-        _lib.lib.GrX_option_set(b"short_kernel", 2 if seed % 3 == 1 else (0 if seed & 8 else 1))
+        # sliced ELLPACK / persistent row groups with an LDS head / merge path / row groups
+        _lib.lib.GrX_option_set(b"short_kernel", 2 if seed % 3 == 1 else (3 if seed % 3 == 2 else (0 if seed & 8 else 1)))
         _lib.lib.GrX_option_set(b"sell_sigma", [64, 128, 4096, 256][seed % 4])
         if seed & 4:
             _lib.lib.GrX_option_set(b"hot_min_cols", 8)
@@ -520,7 +522,7 @@ def test_long_short_row_split(gb, seed):
         _lib.lib.GrX_option_set(b"split_min_nnz", 1 << 22)
         _lib.lib.GrX_option_set(b"split_min_len", 0)
         _lib.lib.GrX_option_set(b"push_mode", 1)
-        _lib.lib.GrX_option_set(b"short_kernel", 1)
+        _lib.lib.GrX_option_set(b"short_kernel", DEFAULT_SHORT_KERNEL)
         _lib.lib.GrX_option_set(b"sell_sigma", 4096)
         _lib.lib.GrX_option_set(b"hot_min_cols", 1 << 20)
         _lib.lib.GrX_option_set(b"hot_k", 0)
@@ -888,7 +890,7 @@ def test_sell_short_rows(gb, seed):
         _lib.lib.GrX_option_set(b"split_min_nnz", 1 << 22)
         _lib.lib.GrX_option_set(b"split_min_len", 0)
         _lib.lib.GrX_option_set(b"push_mode", 1)
-        _lib.lib.GrX_option_set(b"short_kernel", 1)
+        _lib.lib.GrX_option_set(b"short_kernel", DEFAULT_SHORT_KERNEL)
         _lib.lib.GrX_option_set(b"sell_sigma", 4096)
 
 
@@ -928,7 +930,7 @@ def test_sell_layout(gb, dummy):
         finally:
             _lib.lib.GrX_option_set(b"split_min_nnz", 1 << 22)
             _lib.lib.GrX_option_set(b"split_min_len", 0)
-            _lib.lib.GrX_option_set(b"short_kernel", 1)
+            _lib.lib.GrX_option_set(b"short_kernel", DEFAULT_SHORT_KERNEL)
             _lib.lib.GrX_option_set(b"sell_sigma", 4096)
 
 

@@ -797,3 +797,23 @@ def test_extract_and_assign_with_index_lists(gb, v):
     w = v.dup()
     w(m.V, replace=True)[[1, 2, 4]] << gb.Vector.from_coo([0, 1], [10, 20], size=3)
     assert heq(w, gb.Vector.from_coo([1, 2], [10, 20], size=7))
+
+
+def test_matrix_isequal_isclose_on_device(gb, A):
+    """Matrix.isequal / isclose compare pattern and values in the library (GrX_Matrix_isclose), across types and iso storage."""
+    assert A.isequal(A.dup())
+    rows, cols, vals = A.to_coo()
+    B = gb.Matrix.from_coo(rows, cols, vals.astype(np.float64), nrows=7, ncols=7)
+    assert A.isequal(B) and not A.isequal(B, check_dtype=True)
+    v2 = vals.copy()
+    v2[3] += 1
+    assert not A.isequal(gb.Matrix.from_coo(rows, cols, v2, nrows=7, ncols=7))
+    c2 = cols.copy()
+    c2[0] = (c2[0] + 1) % 7 if (rows[0], (c2[0] + 1) % 7) not in set(zip(rows.tolist(), cols.tolist())) else c2[0]
+    assert np.array_equal(c2, cols) or not A.isequal(gb.Matrix.from_coo(rows, c2, vals, nrows=7, ncols=7))
+    assert not A.isequal(gb.Matrix.from_coo(rows, cols, vals, nrows=8, ncols=7))
+    near = gb.Matrix.from_coo(rows, cols, vals.astype(np.float64) * (1 + 1e-9), nrows=7, ncols=7)
+    assert B.isclose(near) and not B.isequal(near) and not B.isclose(near, rel_tol=1e-12)
+    ones = gb.Matrix.from_coo(rows, cols, np.ones(rows.size, np.int64), nrows=7, ncols=7)  # stored as one value (iso)
+    assert ones.isequal(gb.Matrix.from_coo(rows, cols, np.ones(rows.size), nrows=7, ncols=7))
+    assert gb.Matrix(int, 3, 4).isequal(gb.Matrix(float, 3, 4))
