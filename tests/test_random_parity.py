@@ -495,6 +495,10 @@ def test_long_short_row_split(gb, seed):
             _lib.lib.GrX_option_set(b"hot_k", 64)
         _lib.lib.GrX_option_set(b"long_sub", 1 + seed % 5)
         _lib.lib.GrX_option_set(b"long_sub_min_len", 64 if seed & 1 else 8)
+        # long rows: by matrix type (strips, items for BOOL) / strips for every type incl. BOOL / items for every type
+        forced_long = [DEFAULT_LONG_KERNEL, 2, 1, DEFAULT_LONG_KERNEL, 2][seed % 5]
+        _lib.lib.GrX_option_set(b"long_kernel", forced_long)
+        _lib.lib.GrX_option_set(b"long_classes", [16, 8, 32, 16, 64][seed % 5])
         A = gb.Matrix.from_coo(rows, cols, vals, dtype=tname, nrows=m, ncols=n)
         u = gb.Vector.from_coo(ui, uv, dtype=tname, size=n)
         w = gb.Vector.from_coo(wi, wv, dtype=tname, size=m)
@@ -502,7 +506,7 @@ def test_long_short_row_split(gb, seed):
         w(~mk.V if comp else mk.V, accum=accum, replace=bool(seed & 2)) << A.mxv(u, getattr(gb.semiring, sr))
         st = device.last_stats()  # init + long rows + short rows (with the write rule of every row); PAIR over a full u reads no rows
         assert st["kernel_launches"] >= 3 or st["method"] == 5
-        want = DEFAULT_LONG_KERNEL if DEFAULT_LONG_KERNEL != 3 else (1 if tname == "BOOL" else 2)
+        want = forced_long if forced_long != 3 else (1 if tname == "BOOL" else 2)
         assert st["method"] == 5 or (st["long_kernel"] == want and st["long_entries"] > 0)
         same_vec(w, exp)
         x = gb.Vector.from_coo(xi, xv, dtype=tname, size=m)
@@ -528,6 +532,8 @@ def test_long_short_row_split(gb, seed):
         _lib.lib.GrX_option_set(b"hot_k", 0)
         _lib.lib.GrX_option_set(b"long_sub", 0)
         _lib.lib.GrX_option_set(b"long_sub_min_len", 0)
+        _lib.lib.GrX_option_set(b"long_kernel", DEFAULT_LONG_KERNEL)
+        _lib.lib.GrX_option_set(b"long_classes", 16)
 
 
 @pytest.mark.parametrize("seed", range(6))
