@@ -192,6 +192,12 @@ extern "C" GrB_Info GrB_init(GrB_Mode mode)
     if (const char *e = getenv("GRB_SHORT_KERNEL")) c.short_kernel = atoi(e);
     if (const char *e = getenv("GRB_SELL_SIGMA")) c.sell_sigma = atoi(e);
     if (const char *e = getenv("GRB_LAZY_LAYOUT")) c.lazy_layout = atoi(e);
+    if (const char *e = getenv("GRB_MXM_HEAVY_KERNEL")) c.mxm_heavy_kernel = atoi(e);
+    if (const char *e = getenv("GRB_MXM_UNIT_MIN_FLOPS")) c.mxm_unit_min_flops = atoll(e);
+    if (const char *e = getenv("GRB_MXM_UNIT_SMALL")) c.mxm_unit_small = atoi(e);
+    if (const char *e = getenv("GRB_MXM_UNIT_DENSE")) c.mxm_unit_dense = atoi(e);
+    if (const char *e = getenv("GRB_MXM_UNIT_MID")) c.mxm_unit_mid = atoi(e);
+    if (const char *e = getenv("GRB_MXM_BITMAP_POOL_MB")) c.mxm_bitmap_pool_mb = atoll(e);
     if (const char *e = getenv("GRB_LONG_KERNEL")) c.long_kernel = atoi(e);
     if (const char *e = getenv("GRB_LONG_CLASSES")) c.long_classes = atoi(e);
     if (const char *e = getenv("GRB_SPLIT_MIN_LEN")) c.split_min_len = atoi(e);
@@ -290,6 +296,13 @@ extern "C" GrB_Info GrX_option_set(const char *name, int64_t value)
     else if (n == "long_sub") c.long_sub = (int)value;
     else if (n == "long_sub_min_len") c.long_sub_min_len = (int)value;
     else if (n == "mxm_mask_mode") c.mxm_mask_mode = (int)value;
+    else if (n == "mxm_heavy_kernel") c.mxm_heavy_kernel = (int)value;
+    else if (n == "mxm_unit_min_flops") c.mxm_unit_min_flops = value;
+    else if (n == "mxm_unit_small") c.mxm_unit_small = (int)value;
+    else if (n == "mxm_unit_dense") c.mxm_unit_dense = (int)value;
+    else if (n == "mxm_unit_mid") c.mxm_unit_mid = (int)value;
+    else if (n == "mxm_bitmap_pool_mb") c.mxm_bitmap_pool_mb = value;
+    else if (n == "mxm_bitmap_pool_cap") c.mxm_bitmap_pool_cap = value;
     else if (n == "vec_pad_min_bytes") c.vec_pad_min_bytes = value;
     else if (n == "alloc_cache") {
         if (!value) dev_cache_release();

@@ -67,6 +67,13 @@ struct Context {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int64_t vec_pad_min_bytes = 1 << 20;  // vectors with at least this many bytes of values are allocated with the front pad
     int alloc_cache = 1;    // 1: freed device blocks are kept per size class and reused without calling the HIP allocator
+    int mxm_heavy_kernel = 1;  // SpGEMM rows beyond the LDS hash: 1 = a wavefront per row over column windows (k_spgemm_wave), 0 = the
+                            // 1024-thread kernels of round 1 (k_spgemm_sym_lds / k_spgemm_win)
+    int mxm_unit_small = 512, mxm_unit_mid = 1024, mxm_unit_dense = 4096;  // entry counts of a unit up to which one wavefront / four wavefronts with compact
+                                                      // accumulators take it; denser units get an accumulator per column
+    int64_t mxm_unit_min_flops = 1024;
+    int64_t mxm_bitmap_pool_cap = INT32_MAX;  // ... and at most this many bitmaps (tests: a pool that runs out)
+    int64_t mxm_bitmap_pool_mb = 16384;  // bitmaps of the denser units kept from the symbolic for the numeric pass: at most this much  // rows with more products than this (and than 32 per window) are walked as units
     int mxm_mask_mode = 1;  // mask-driven SpGEMM for non-complemented masks: 0 never, 1 when the full product costs more, 2 always
     int long_sub = 0;       // sub-ranges per class of the cold columns of the long rows (items of a class are walked sub-range by
                             // sub-range); 0 = sized from the operand image (~2 MiB per sub-range)

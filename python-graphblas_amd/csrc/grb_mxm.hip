@@ -51,6 +51,20 @@ struct MxmArgs {
     // (relative to Bp[k]) whose column is >= w * MM_WIN
     const int32_t *woff;
     int n_win;
+    // (row, window) units (k_spgemm_unit): per row of the symbolic pass n_win + 1 numbers -- counts, then offsets inside the row;
+    // wrow[row] = the row's slot in wcnt (-1: the symbolic pass counted the row with a hash kernel)
+    int32_t *wcnt;
+    int32_t *wrow;
+    // bitmaps of the units the symbolic pass found beyond bm_min_cnt entries, kept for the numeric pass (which then skips its own
+    // pass A): a pool of bm_cap bitmaps of MM_WIN bits handed out by an atomic cursor, wbm[slot * n_win + w] = the unit's
+    // bitmap or -1 (small unit, or the pool ran out: the numeric pass recomputes)
+    unsigned long long *bm_pool;
+    unsigned long long *bm_cursor;
+    int64_t bm_cap;  // (per sub-pool)
+    int bm_pools;    // (a power of two)
+    int32_t *wbm;
+    int bm_min_cnt;
+    int abl;  // -DGRB_ABLATE builds: timing switches of the unit kernels (bits 20.. of debug_flags); results are wrong on purpose
     // mask-driven product (T restricted to the pattern of a non-complemented mask): results land in the mask's own layout
     const int64_t *Mp;
     const int32_t *Mj;
@@ -76,14 +90,15 @@ __device__ __forceinline__ int bin_of(int64_t x, int64_t b1, int64_t b2, int64_t
 }
 
 // size[i] = F[Ap[i+1]] - F[Ap[i]]  (F == nullptr: size[i] is already in `size`);  key = bin, payload = row
+// (wrow: rows with a slot in the unit tables -- wrow[i] >= 0 -- go to bin 4 whatever their size)
 __global__ void k_row_bins(const int64_t *Ap, const int64_t *F, int64_t m, int64_t *size, int64_t b1, int64_t b2,
-                           int64_t b3, uint64_t *binkey, uint32_t *rowid)
+                           int64_t b3, uint64_t *binkey, uint32_t *rowid, const int32_t *wrow)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
     int64_t s = F ? F[Ap[i + 1]] - F[Ap[i]] : size[i];
     if (F) size[i] = s;
-    binkey[i] = (uint64_t)bin_of(s, b1, b2, b3);
+    binkey[i] = (wrow && wrow[i] >= 0 && s > 0) ? 4ull : (uint64_t)bin_of(s, b1, b2, b3);
     rowid[i] = (uint32_t)i;
 }
 
@@ -455,6 +470,7 @@ __global__ __launch_bounds__(MM_WIN_BLOCK) void k_spgemm_win(const MxmArgs a, co
     const int monoid = a.monoid, mult = a.mult;
     const T *Ax = (const T *)a.Ax, *Bx = (const T *)a.Bx;
     const int64_t row = rows[blockIdx.x];
+    if (a.wrow && a.wrow[row] >= 0) return;  // (the row's windows are units of k_spgemm_unit)
     const W ident = monoid_identity<T, W>(monoid);
     for (int k = tid; k < MM_WIN; k += MM_WIN_BLOCK) s_acc[k] = ident;
     if (tid < MM_WIN / 64) s_bits[tid] = 0ull;
@@ -505,6 +521,407 @@ __global__ __launch_bounds__(MM_WIN_BLOCK) void k_spgemm_win(const MxmArgs a, co
         out += total;
         __syncthreads();
     });
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Heavy rows as (row, column window) WORK UNITS (round 2; replaces k_spgemm_sym_lds / k_spgemm_win where the window offsets
+// are at hand).  The 1024-thread window kernel above walks the windows of a row one after the other, with workgroup barriers
+// and scans around a few hundred products per window; here every (row, window) pair is a unit of its own, so the windows of
+// one row run side by side, and nothing heavier than a wavefront synchronises for the small ones.  A unit:
+//   pass A  every product sets its column's bit in the unit's 2 KiB LDS bitmap;
+//   count   popcounts per word + a wavefront scan: the unit's entry count and, per word, how many set columns precede it.
+//           The symbolic kernel stops here and stores the count (k_unit_prefix turns the counts of a row into offsets);
+//   pass B  (numeric) every product finds its RANK among the unit's columns (word prefix + popcount below its bit) and
+//           combines into a COMPACT accumulator array -- rank order is column order: no hash, no sort;  units with more
+//           distinct columns than accumulators take ceil(count / CAP) passes over their products;
+//   emit    columns from the bitmap, values from the accumulators, at the unit's offset inside the row: rows come out sorted.
+// Products are dealt round-robin to the lanes (adjacent lanes read adjacent entries of a row of B) with a binary search in
+// the wavefront's scan of the B-range lengths.  WPU = wavefronts per unit: 1 (four units per workgroup, 512 accumulators
+// each) for units of up to 512 entries -- and every unit of the symbolic pass --, 4 (one unit per workgroup, 4096 accumulators,
+// the entries of A dealt to the wavefronts 64 at a time) for the denser ones.
+// ---------------------------------------------------------------------------------------------------
+#ifdef GRB_ABLATE
+#define MXM_ABL(a, bit) (((a).abl & (bit)) != 0)
+#else
+#define MXM_ABL(a, bit) false
+#endif
+constexpr int MU_ILP = 4;     // products a lane has in flight
+constexpr int MU_POOLS = 1024;  // sub-pools of the bitmap pool
+constexpr int MU_SMALL = 512;  // entries of a unit a single wavefront accumulates
+
+__device__ __forceinline__ void mw_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <typename T, bool NUMERIC, int WPU, int CAP>
+__global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const MxmArgs a, const uint32_t *rows, int64_t ridx0,
+                                                                          int64_t nrows_here, const uint64_t *units, int64_t nunits)
+{
+    using W = typename Widen<T>::type;
+    constexpr int WORDS = MM_WIN / 64, WPL = WORDS / 64;
+    constexpr int WAVES = WPU > 4 ? WPU : 4;  // wavefronts per workgroup
+    constexpr int UPB = WAVES / WPU;          // units per workgroup
+    constexpr int NB = 2;  // batches of entries of A a wavefront keeps (range of B inside the window) from pass A for pass B
+    __shared__ unsigned long long s_bits[UPB][WORDS];
+    __shared__ int s_wpre[NUMERIC ? UPB : 1][NUMERIC ? WORDS : 1];
+    __shared__ int s_scan[WAVES][64];
+    __shared__ int64_t s_qb[WAVES][64];
+    __shared__ int64_t s_pa[WAVES][64];
+    __shared__ W s_acc[NUMERIC ? UPB : 1][NUMERIC ? CAP : 1];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int uib = WPU == 1 ? wave : 0, sub = WPU == 1 ? 0 : wave;  // unit inside the workgroup, wavefront inside the unit
+    const int nwin = a.n_win;
+    const int64_t unit = (int64_t)blockIdx.x * UPB + uib;
+    int64_t ridx = 0, row, out = 0;
+    int w, bslot = -1;
+    if constexpr (NUMERIC) {  // a unit of the class list: (row << 16) | window
+        if (unit >= nunits) return;  // (uniform over the unit's threads)
+        const uint64_t e = units[unit];
+        row = (int64_t)(e >> 16);
+        w = (int)(e & 0xFFFFu);
+        const int64_t slot = a.wrow[row];
+        out = a.Tp[row] + a.wcnt[slot * (nwin + 1) + w];
+        if (a.wbm) bslot = a.wbm[slot * nwin + w];
+    } else {  // every (row, window) of the rows [ridx0, ridx0 + nrows_here) of the bin
+        if (unit >= nrows_here * nwin) return;
+        ridx = ridx0 + unit / nwin;
+        w = (int)(unit % nwin);
+        row = rows[ridx];
+    }
+    auto usync = [&]() {
+        if constexpr (WPU == 1) mw_sync();
+        else __syncthreads();
+    };
+    unsigned long long *bits = s_bits[uib];
+    int *wpre = s_wpre[NUMERIC ? uib : 0], *scan = s_scan[wave];
+    int64_t *sqb = s_qb[wave], *spa = s_pa[wave];
+    W *acc = s_acc[NUMERIC ? uib : 0];
+    const int monoid = a.monoid, mult = a.mult;
+    const T *Ax = (const T *)a.Ax, *Bx = (const T *)a.Bx;
+    const W ident = monoid_identity<T, W>(monoid);
+    const int64_t pbeg = a.Ap[row], pend = a.Ap[row + 1];
+    const int c0 = w * MM_WIN;
+    const int tiu = sub * 64 + lane;  // thread inside the unit
+    if (bslot >= 0) {  // (numeric pass: the symbolic pass kept the unit's bitmap)
+        for (int k = tiu; k < WORDS; k += 64 * WPU) bits[k] = a.bm_pool[(int64_t)bslot * WORDS + k];
+    } else {
+        for (int k = tiu; k < WORDS; k += 64 * WPU) bits[k] = 0ull;
+    }
+    usync();
+    // every product of the row inside the window: d = load(p, q), then apply(d) -- MU_ILP products per lane at a time, their loads
+    // issued before the first apply (the LDS atomics would otherwise serialise the global load latencies).  The wavefronts of
+    // a unit take the entries of A 64 at a time.
+    int c_len[NB];
+    int64_t c_qb[NB];
+    auto visit = [&](auto first, auto &&load, auto &&apply) {
+        constexpr bool FIRST = decltype(first)::value;
+        auto fetch = [&](int64_t p, int &len, int64_t &qb) {
+            len = 0;
+            qb = 0;
+            if (p < pend) {
+                const int k = a.Aj[p];
+                const int32_t *o = a.woff + (int64_t)k * (nwin + 1) + w;
+                const int o0 = o[0], o1 = o[1];
+                qb = a.Bp[k] + o0;
+                len = o1 - o0;
+            }
+        };
+        auto process = [&](int64_t p, int len, int64_t qb) {
+            int incl = len;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int t = __shfl_up(incl, off);
+                if (lane >= off) incl += t;
+            }
+            const int total = __shfl(incl, 63);
+            if (total == 0) return;  // (wave-uniform)
+            scan[lane] = incl - len;
+            sqb[lane] = qb;
+            spa[lane] = p;
+            mw_sync();
+            for (int t0 = lane; t0 < total; t0 += 64 * MU_ILP) {
+                decltype(load((int64_t)0, (int64_t)0)) d[MU_ILP];
+#pragma unroll
+                for (int u = 0; u < MU_ILP; u++) {
+                    const int t = t0 + 64 * u;
+                    if (t < total) {
+                        int lo = 0, hi = 64;  // the last entry whose first product number is <= t
+#pragma unroll
+                        for (int step = 0; step < 6; step++) {
+                            const int mid = (lo + hi) >> 1;
+                            if (scan[mid] <= t) lo = mid;
+                            else hi = mid;
+                        }
+                        d[u] = load(spa[lo], sqb[lo] + (t - scan[lo]));
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < MU_ILP; u++)
+                    if (t0 + 64 * u < total) apply(d[u]);
+            }
+            mw_sync();
+        };
+        int64_t pc = pbeg + sub * 64;
+#pragma unroll
+        for (int b = 0; b < NB; b++, pc += 64 * WPU) {
+            if (pc >= pend) return;  // (wave-uniform)
+            if constexpr (FIRST) fetch(pc + lane, c_len[b], c_qb[b]);
+            process(pc + lane, c_len[b], c_qb[b]);
+        }
+        for (; pc < pend; pc += 64 * WPU) {
+            int len;
+            int64_t qb;
+            fetch(pc + lane, len, qb);
+            process(pc + lane, len, qb);
+        }
+    };
+    // ---- pass A: which columns of the window does the row reach
+    if (bslot < 0 && !(NUMERIC && MXM_ABL(a, 16)))
+        visit(std::true_type{}, [&](int64_t, int64_t q) { return a.Bj[q] - c0; }, [&](int j) { atomicOr(&bits[j >> 6], 1ull << (j & 63)); });
+    usync();
+    // ---- counts: lane l looks at words 4 l .. 4 l + 3 (every wavefront of the unit computes the same numbers)
+    unsigned long long mine[WPL];
+    int c = 0;
+#pragma unroll
+    for (int x = 0; x < WPL; x++) {
+        mine[x] = bits[lane * WPL + x];
+        c += __popcll(mine[x]);
+    }
+    int incl = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+    }
+    const int cnt = __shfl(incl, 63);
+    if constexpr (!NUMERIC) {
+        if (lane == 0) a.wcnt[ridx * (nwin + 1) + w] = cnt;
+        if (a.wbm) {
+            int slot = -1;
+            if (cnt > a.bm_min_cnt) {
+                if (lane == 0) {  // (MU_POOLS sub-pools, a cursor each on its own 128-byte line: one cursor serialises millions of atomics)
+                    const int sp = (int)(blockIdx.x & (a.bm_pools - 1));
+                    const unsigned long long got = atomicAdd(&a.bm_cursor[sp * 16], 1ull);
+                    slot = got < (unsigned long long)a.bm_cap ? (int)(sp * a.bm_cap + (int64_t)got) : -1;
+                }
+                slot = __shfl(slot, 0);
+                if (slot >= 0) {
+#pragma unroll
+                    for (int x = 0; x < WPL; x++) a.bm_pool[(int64_t)slot * WORDS + lane * WPL + x] = mine[x];
+                }
+            }
+            if (lane == 0) a.wbm[ridx * nwin + w] = slot;
+        }
+    } else {
+        if (sub == 0) {
+            int pre = incl - c;
+#pragma unroll
+            for (int x = 0; x < WPL; x++) {
+                wpre[lane * WPL + x] = pre;
+                pre += __popcll(mine[x]);
+            }
+        }
+        usync();
+        // ---- pass B: values into the compact accumulators, CAP ranks at a time
+        T *Tx = (T *)a.Tx;
+        for (int r0 = 0; r0 < cnt; r0 += CAP) {
+            const int here = cnt - r0 < CAP ? cnt - r0 : CAP;
+            for (int i = tiu; i < here; i += 64 * WPU) acc[i] = ident;
+            usync();
+            struct Prod {
+                int j;
+                W v;
+            };
+            auto load_b = [&](int64_t p, int64_t q) {
+                const T av = a.need_a ? Ax[a.a_iso ? 0 : p] : (T)0;
+                const T bv = a.need_b ? Bx[a.b_iso ? 0 : q] : (T)0;
+                return Prod{a.Bj[q] - c0, (W)apply_binop<T>(mult, av, bv)};
+            };
+            auto apply_b = [&](const Prod &d) {
+                const int rank = wpre[d.j >> 6] + __popcll(bits[d.j >> 6] & ((1ull << (d.j & 63)) - 1ull)) - r0;
+                if ((unsigned)rank < (unsigned)CAP && !MXM_ABL(a, 4)) {
+                    if (monoid == OP_ANY) acc[rank] = d.v;
+                    else atomic_combine<W>(&acc[rank], d.v, monoid);
+                }
+            };
+            if (!MXM_ABL(a, 8)) {
+                if (bslot >= 0 && r0 == 0) visit(std::true_type{}, load_b, apply_b);  // (no pass A ran: the ranges of B are fetched here)
+                else visit(std::false_type{}, load_b, apply_b);
+            }
+            usync();
+            if (!MXM_ABL(a, 2))
+                for (int i = tiu; i < here; i += 64 * WPU) Tx[out + r0 + i] = from_acc<T, W>(acc[i]);
+            usync();
+        }
+        // ---- columns, in order: the wavefronts of the unit share the (lane, word) pairs -- every wavefront holds all of them
+        constexpr int LSPLIT = WPU > WPL ? WPU / WPL : 1;  // wavefronts per word index
+        int pre = incl - c;
+#pragma unroll
+        for (int x = 0; x < WPL; x++) {
+            unsigned long long b = mine[x];
+            const bool take = WPU == 1 || (WPU <= WPL ? (x % WPU == sub) : (x == sub % WPL && lane % LSPLIT == sub / WPL));
+            if (take && !MXM_ABL(a, 1)) {
+                int64_t o = out + pre;
+                while (b) {
+                    const int t = __ffsll(b) - 1;
+                    b &= b - 1;
+                    a.Tj[o++] = c0 + (lane * WPL + x) * 64 + t;
+                }
+            }
+            pre += __popcll(mine[x]);
+        }
+    }
+}
+
+// a DENSE unit (more than MU_DENSE of the window's MM_WIN columns): compact accumulators would take several passes over the
+// products; a 1024-thread workgroup with one accumulator per column of the window (k_spgemm_win's, 128 KiB of LDS for 8-byte
+// values) takes one, the bitmap filled on the way.  The offset of the unit inside its row is known from the symbolic pass.
+constexpr int MU_DENSE = 4096;
+
+template <typename T>
+__global__ __launch_bounds__(MM_WIN_BLOCK) void k_spgemm_unit_dense(const MxmArgs a, const uint64_t *units)
+{
+    using W = typename Widen<T>::type;
+    __shared__ W s_acc[MM_WIN];
+    __shared__ unsigned long long s_bits[MM_WIN / 64];
+    __shared__ int s_wave[MM_WIN_BLOCK / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nwin = a.n_win;
+    const uint64_t e = units[blockIdx.x];
+    const int64_t row = (int64_t)(e >> 16);
+    const int w = (int)(e & 0xFFFFu);
+    const int64_t slot = a.wrow[row];
+    const int o0 = a.wcnt[slot * (nwin + 1) + w];
+    const int bslot = a.wbm ? a.wbm[slot * nwin + w] : -1;  // (the symbolic pass kept the bitmap: no atomics on it here)
+    const int monoid = a.monoid, mult = a.mult;
+    const T *Ax = (const T *)a.Ax, *Bx = (const T *)a.Bx;
+    const W ident = monoid_identity<T, W>(monoid);
+    for (int k = tid; k < MM_WIN; k += MM_WIN_BLOCK) s_acc[k] = ident;
+    if (tid < MM_WIN / 64) s_bits[tid] = bslot >= 0 ? a.bm_pool[(int64_t)bslot * (MM_WIN / 64) + tid] : 0ull;
+    __syncthreads();
+    const int64_t pbeg = a.Ap[row], pend = a.Ap[row + 1];
+    const int c0 = w * MM_WIN;
+    for (int64_t pc = pbeg; pc < pend; pc += MM_WIN_BLOCK) {
+        const int64_t p = pc + tid;
+        int len = 0;
+        int64_t qb = 0;
+        if (p < pend) {
+            const int k = a.Aj[p];
+            const int32_t *o = a.woff + (int64_t)k * (nwin + 1) + w;
+            const int b0 = o[0], b1 = o[1];
+            qb = a.Bp[k] + b0;
+            len = b1 - b0;
+        }
+        if (!MXM_ABL(a, 8)) deal_products(len, qb, [&](int e, int64_t q) {
+            const int j = a.Bj[q] - c0;
+            if (MXM_ABL(a, 4)) return;
+            const T av = a.need_a ? Ax[a.a_iso ? 0 : pc + e] : (T)0;
+            const T bv = a.need_b ? Bx[a.b_iso ? 0 : q] : (T)0;
+            const W prod = (W)apply_binop<T>(mult, av, bv);
+            if (monoid == OP_ANY) s_acc[j] = prod;
+            else atomic_combine<W>(&s_acc[j], prod, monoid);
+            if (bslot < 0) atomicOr(&s_bits[j >> 6], 1ull << (j & 63));
+        });
+    }
+    __syncthreads();
+    // emit: thread t takes 16 columns (a quarter of word t / 4)
+    const unsigned long long word = s_bits[tid >> 2];
+    const int q4 = tid & 3;
+    unsigned b16 = (unsigned)(word >> (16 * q4)) & 0xFFFFu;
+    const int c = __popc(b16);
+    int incl = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) s_wave[wv] = incl;
+    __syncthreads();
+    int wave_off = 0;
+    for (int x = 0; x < wv; x++) wave_off += s_wave[x];
+    int64_t o = a.Tp[row] + o0 + wave_off + (incl - c);
+    T *Tx = (T *)a.Tx;
+    while (b16) {
+        const int t = __ffs(b16) - 1;
+        b16 &= b16 - 1;
+        const int j = tid * 16 + t;
+        if (!MXM_ABL(a, 1)) a.Tj[o] = c0 + j;
+        if (!MXM_ABL(a, 2)) Tx[o] = from_acc<T, W>(s_acc[j]);
+        o++;
+    }
+}
+
+// the units of the rows of the numeric bin, by class (the first class whose limit the entry count does not exceed, MU_NCLS - 1
+// = dense beyond the last limit; empty units are dropped): counts (FILL = false) or the lists themselves, (row << 16) |
+// window, class c from cursor[c] on.  One wavefront per row, lanes over the windows, one atomic per wavefront, class and batch
+// of 64 windows.
+constexpr int MU_NCLS = 4;
+struct UnitLimits {
+    int lim[MU_NCLS - 1];
+};
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_unit_classify(const int32_t *wcnt, const int32_t *wrow, int nwin, const uint32_t *rows, int64_t nrows_bin,
+                                                       unsigned long long *cursor, uint64_t *lists, UnitLimits L)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t ridx = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ridx >= nrows_bin) return;
+    const int64_t row = rows[ridx];
+    const int slot = wrow[row];
+    if (slot < 0) return;
+    const int32_t *wc = wcnt + (int64_t)slot * (nwin + 1);
+    for (int b = 0; b < nwin; b += 64) {
+        const int w = b + lane;
+        const int cnt = w < nwin ? wc[w + 1] - wc[w] : 0;
+        int cls = -1;
+        if (cnt > 0) {
+            cls = MU_NCLS - 1;
+            for (int c = MU_NCLS - 2; c >= 0; c--)
+                if (cnt <= L.lim[c]) cls = c;
+        }
+        for (int c = 0; c < MU_NCLS; c++) {
+            const unsigned long long mk = __ballot(cls == c);
+            if (mk == 0) continue;
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(&cursor[c], (unsigned long long)__popcll(mk));
+            base = __shfl(base, 0);
+            if (FILL && cls == c) lists[base + __popcll(mk & ((1ull << lane) - 1ull))] = ((uint64_t)row << 16) | (uint64_t)w;
+        }
+    }
+}
+
+// the per-window counts of the rows of the symbolic unit pass -> offsets inside the row (exclusive scan in place, n_win + 1
+// numbers per row), the row's entry count, and the row -> slot map the numeric pass finds its units' offsets with.
+// One wavefront per row.
+__global__ __launch_bounds__(256) void k_unit_prefix(int32_t *wcnt, int nwin, const uint32_t *rows, int64_t nrows_bin, int64_t *row_nnz,
+                                                     int32_t *wrow)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t ridx = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ridx >= nrows_bin) return;
+    int32_t *wc = wcnt + ridx * (nwin + 1);
+    int carry = 0;
+    for (int b = 0; b < nwin; b += 64) {
+        const int v = b + lane < nwin ? wc[b + lane] : 0;
+        int incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        if (b + lane < nwin) wc[b + lane] = carry + incl - v;
+        carry += __shfl(incl, 63);
+    }
+    if (lane == 0) {
+        wc[nwin] = carry;
+        const uint32_t row = rows[ridx];
+        row_nnz[row] = carry;
+        wrow[row] = (int32_t)ridx;
+    }
 }
 
 // ---- mask-driven product: C<M> = A (+.x) B with a non-complemented mask only needs the entries of T inside M's pattern
@@ -582,6 +999,7 @@ __global__ __launch_bounds__(MM_WIN_BLOCK) void k_spgemm_mwin(const MxmArgs a, c
     const int monoid = a.monoid, mult = a.mult;
     const T *Ax = (const T *)a.Ax, *Bx = (const T *)a.Bx;
     const int64_t row = rows[blockIdx.x];
+    if (a.wrow && a.wrow[row] >= 0) return;  // (the row's windows are units of k_spgemm_unit)
     const W ident = monoid_identity<T, W>(monoid);
     for (int k = tid; k < MM_WIN; k += MM_WIN_BLOCK) s_acc[k] = ident;
     if (tid < MM_WIN / 64) { s_bits[tid] = 0ull; s_mbits[tid] = 0ull; }
@@ -772,12 +1190,12 @@ struct RowBins {
 
 // stable sort of rows by bin(size): rows inside a bin stay in increasing order
 static void make_bins(RowBins &rb, const int64_t *Ap, const int64_t *F, int64_t m, int64_t *size, int64_t b1, int64_t b2,
-                      int64_t b3)
+                      int64_t b3, const int32_t *wrow = nullptr)
 {
     DevBuf<uint64_t> key(m), key2(m);
     DevBuf<uint32_t> rid(m);
     hipLaunchKernelGGL(k_row_bins, dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, ctx().stream, Ap, F, m, size, b1, b2, b3,
-                       key.p, rid.p);
+                       key.p, rid.p, wrow);
     prim_sort_pairs_u64_u32(key.p, key2.p, rid.p, rb.rows.p, m, 3);
     DevBuf<int64_t> bs(6);
     hipLaunchKernelGGL(k_bin_starts, dim3(1), dim3(64), 0, ctx().stream, key2.p, m, bs.p);
@@ -794,7 +1212,61 @@ static void run_bins(MxmArgs &a, const RowBins &rb)
     if (rb.count(2)) hipLaunchKernelGGL((k_spgemm_hash<T, T2, NUMERIC>), dim3((unsigned)rb.count(2)), dim3(MM_BLOCK), 0, ctx().stream, a, rb.ptr(2));
     if (rb.count(3)) hipLaunchKernelGGL((k_spgemm_hash<T, T3, NUMERIC>), dim3((unsigned)rb.count(3)), dim3(MM_BLOCK), 0, ctx().stream, a, rb.ptr(3));
     ctx().stats.kernel_launches += 3;
-    if (rb.count(4) && !NUMERIC && a.n <= (1 << 24) && !(ctx().debug_flags & 256)) {
+    if (rb.count(4) && a.woff && a.wrow && a.wcnt) {
+        if constexpr (NUMERIC) {
+            // the bin's units by class, then one launch per class (and 2^21 units: a grid holds fewer than 2^32 threads)
+            DevBuf<unsigned long long> cur(8, true);
+            UnitLimits L;
+            L.lim[0] = std::min(MU_SMALL, ctx().mxm_unit_small);
+            L.lim[1] = std::max(L.lim[0], ctx().mxm_unit_mid);
+            L.lim[2] = std::max(L.lim[1], ctx().mxm_unit_dense);
+            hipLaunchKernelGGL((k_unit_classify<false>), dim3((unsigned)ceil_div(rb.count(4), 4)), dim3(256), 0, ctx().stream, (const int32_t *)a.wcnt,
+                               (const int32_t *)a.wrow, a.n_win, rb.ptr(4), rb.count(4), cur.p, (uint64_t *)nullptr, L);
+            unsigned long long cnt[MU_NCLS], start[MU_NCLS + 1] = {0};
+            d2h(cnt, cur.p, sizeof(cnt));
+            for (int c = 0; c < MU_NCLS; c++) start[c + 1] = start[c] + cnt[c];
+            if (getenv("GRB_MXM_TRACE"))
+                fprintf(stderr, "[mxm] numeric bin 4: %lld rows x %d windows; units by class %llu %llu %llu %llu\n", (long long)rb.count(4), a.n_win,
+                        cnt[0], cnt[1], cnt[2], cnt[3]);
+            DevBuf<uint64_t> lists((size_t)start[MU_NCLS]);
+            h2d(cur.p, start, sizeof(unsigned long long) * MU_NCLS);
+            hipLaunchKernelGGL((k_unit_classify<true>), dim3((unsigned)ceil_div(rb.count(4), 4)), dim3(256), 0, ctx().stream, (const int32_t *)a.wcnt,
+                               (const int32_t *)a.wrow, a.n_win, rb.ptr(4), rb.count(4), cur.p, lists.p, L);
+            constexpr int64_t PER = 1ll << 21;
+            auto per_class = [&](int c, auto &&launch) {
+                for (int64_t u0 = 0; u0 < (int64_t)cnt[c]; u0 += PER)
+                    launch(lists.p + start[c] + u0, std::min<int64_t>(PER, (int64_t)cnt[c] - u0));
+            };
+            per_class(0, [&](const uint64_t *u, int64_t nu) {
+                hipLaunchKernelGGL((k_spgemm_unit<T, true, 1, MU_SMALL>), dim3((unsigned)ceil_div(nu, 4)), dim3(256), 0, ctx().stream, a, rb.ptr(4), 0, 0, u, nu);
+            });
+            per_class(1, [&](const uint64_t *u, int64_t nu) {
+                hipLaunchKernelGGL((k_spgemm_unit<T, true, 4, 1024>), dim3((unsigned)nu), dim3(256), 0, ctx().stream, a, rb.ptr(4), 0, 0, u, nu);
+            });
+            per_class(2, [&](const uint64_t *u, int64_t nu) {
+                hipLaunchKernelGGL((k_spgemm_unit<T, true, 4, 4096>), dim3((unsigned)nu), dim3(256), 0, ctx().stream, a, rb.ptr(4), 0, 0, u, nu);
+            });
+            per_class(3, [&](const uint64_t *u, int64_t nu) {
+                hipLaunchKernelGGL((k_spgemm_unit_dense<T>), dim3((unsigned)nu), dim3(MM_WIN_BLOCK), 0, ctx().stream, a, u);
+            });
+            // rows of the bin the symbolic pass counted with a hash kernel (few products, but more entries than the numeric
+            // hash table holds): the 1024-thread window walk
+            hipLaunchKernelGGL((k_spgemm_win<T>), dim3((unsigned)rb.count(4)), dim3(MM_WIN_BLOCK), 0, ctx().stream, a, rb.ptr(4));
+            ctx().stats.kernel_launches += 6;
+            sync_stream();  // (the lists are freed at the end of this scope)
+        } else {
+            const int64_t rows_per_launch = std::max<int64_t>(1, (1ll << 22) / a.n_win);
+            for (int64_t r0 = 0; r0 < rb.count(4); r0 += rows_per_launch) {
+                const int64_t nr = std::min(rows_per_launch, rb.count(4) - r0);
+                hipLaunchKernelGGL((k_spgemm_unit<T, false, 1, 1>), dim3((unsigned)ceil_div(nr * a.n_win, 4)), dim3(256), 0, ctx().stream, a, rb.ptr(4), r0,
+                                   nr, (const uint64_t *)nullptr, 0);
+                ctx().stats.kernel_launches += 1;
+            }
+            hipLaunchKernelGGL(k_unit_prefix, dim3((unsigned)ceil_div(rb.count(4), 4)), dim3(256), 0, ctx().stream, a.wcnt, a.n_win, rb.ptr(4),
+                               rb.count(4), a.row_nnz, a.wrow);
+            ctx().stats.kernel_launches += 1;
+        }
+    } else if (rb.count(4) && !NUMERIC && a.n <= (1 << 24) && !(ctx().debug_flags & 256)) {
         if (a.n <= (1 << 18)) hipLaunchKernelGGL((k_spgemm_sym_lds<4096, MM_BLOCK>), dim3((unsigned)rb.count(4)), dim3(MM_BLOCK), 0, ctx().stream, a, rb.ptr(4));
         else  // (128 KiB of bitmap: one workgroup per CU, so make it a big one)
             hipLaunchKernelGGL((k_spgemm_sym_lds<16384, 1024>), dim3((unsigned)rb.count(4)), dim3(1024), 0, ctx().stream, a, rb.ptr(4));
@@ -842,6 +1314,9 @@ static GB_Matrix_opaque *spgemm(GB_Matrix_opaque *A, const void *Ax, GB_Matrix_o
         a.mult = mult;
         a.need_a = !(mult == OP_PAIR || mult == OP_SECOND);
         a.need_b = !(mult == OP_PAIR || mult == OP_FIRST || mult == OP_ANY);
+#ifdef GRB_ABLATE
+        a.abl = (ctx().debug_flags >> 20) & 0xFF;
+#endif
         // 1. flops per stored entry of A, scanned
         DevBuf<int64_t> F(nnzA + 1);
         hipLaunchKernelGGL(k_nnz_flops, dim3((unsigned)ceil_div(nnzA + 1, 256)), dim3(256), 0, ctx().stream, A->d_col, nnzA,
@@ -853,10 +1328,59 @@ static GB_Matrix_opaque *spgemm(GB_Matrix_opaque *A, const void *Ax, GB_Matrix_o
         // 2./3. symbolic
         DevBuf<int64_t> rownnz(m + 1, true);
         a.row_nnz = rownnz.p;
+        // column-window offsets of B's rows (heavy rows walk the windows in both passes): n_B x (windows + 1) int32, per call
+        DevBuf<int32_t> woff(0), wcnt(0), wrow(0), wbm(0);
+        DevBuf<unsigned long long> bm_pool(0), bm_cur(16 * MU_POOLS);
+        const int64_t n_win = ceil_div((int64_t)B->ncols, MM_WIN);
+        const int64_t woff_entries = (int64_t)B->nrows * (n_win + 1);
+        auto ensure_woff = [&]() {
+            if (a.woff || (ctx().debug_flags & 256) || woff_entries * 4 > (8ll << 30)) return;
+            dev_free(woff.p);
+            woff.p = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)woff_entries);
+            hipLaunchKernelGGL(k_window_offsets, dim3((unsigned)ceil_div((int64_t)B->nrows, 256)), dim3(256), 0, ctx().stream,
+                               (const int64_t *)B->d_ptr, (const int32_t *)B->d_col, (int64_t)B->nrows, (int)n_win, woff.p);
+            a.woff = woff.p;
+            a.n_win = (int)n_win;
+        };
         {
             RowBins rb(m);
-            make_bins(rb, A->d_ptr, F.p, m, rownnz.p, 128, 1024, 16384);
+            // rows beyond the LDS hash tables are walked as (row, window) units; with the unit kernels at hand the hash kernels
+            // only keep the rows of up to max(4096, 32 per window) products (units of a handful of products do not pay)
+            const bool units_ok = ctx().mxm_heavy_kernel == 1 && !(ctx().debug_flags & 256) && woff_entries * 4 <= (8ll << 30);
+            const int64_t sym_b3 = units_ok ? std::min<int64_t>(16384, std::max<int64_t>(ctx().mxm_unit_min_flops, 32 * n_win)) : 16384;
+            make_bins(rb, A->d_ptr, F.p, m, rownnz.p, 128, 1024, sym_b3);
             GRB_HIP(hipMemsetAsync(rownnz.p, 0, sizeof(int64_t) * (m + 1), ctx().stream));
+            if (rb.count(4) && units_ok && rb.count(4) * (n_win + 1) * 4 <= (8ll << 30)) {
+                ensure_woff();
+                if (a.woff) {
+                    dev_free(wcnt.p);
+                    wcnt.p = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)(rb.count(4) * (n_win + 1)));
+                    dev_free(wrow.p);
+                    wrow.p = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)m);
+                    GRB_HIP(hipMemsetAsync(wrow.p, 0xFF, sizeof(int32_t) * (size_t)m, ctx().stream));
+                    a.wcnt = wcnt.p;
+                    a.wrow = wrow.p;
+                    // the bitmap pool: as many bitmaps as the option allows and a quarter of the free memory holds
+                    size_t free_b = 0, total_b = 0;
+                    GRB_HIP(hipMemGetInfo(&free_b, &total_b));
+                    const int64_t bm_bytes = MM_WIN / 8;
+                    const int64_t cap = std::min<int64_t>({rb.count(4) * n_win, (int64_t)(ctx().mxm_bitmap_pool_mb << 20) / bm_bytes,
+                                                           (int64_t)(free_b / 4) / bm_bytes, ctx().mxm_bitmap_pool_cap});
+                    if (cap > 0) {
+                        dev_free(wbm.p);
+                        wbm.p = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)(rb.count(4) * n_win));
+                        dev_free(bm_pool.p);
+                        bm_pool.p = (unsigned long long *)dev_alloc((size_t)(cap * bm_bytes));
+                        GRB_HIP(hipMemsetAsync(bm_cur.p, 0, sizeof(unsigned long long) * 16 * MU_POOLS, ctx().stream));
+                        a.wbm = wbm.p;
+                        a.bm_pool = bm_pool.p;
+                        a.bm_cursor = bm_cur.p;
+                        a.bm_pools = cap >= 64 * MU_POOLS ? MU_POOLS : 1;
+                        a.bm_cap = cap / a.bm_pools;
+                        a.bm_min_cnt = std::min(MU_SMALL, ctx().mxm_unit_small);
+                    }
+                }
+            }
             run_bins<T, false>(a, rb);
         }
         // 4. row pointers of T (counts stay in rownnz for the numeric binning)
@@ -881,18 +1405,8 @@ static GB_Matrix_opaque *spgemm(GB_Matrix_opaque *A, const void *Ax, GB_Matrix_o
         //    offset table (n_B x (windows+1) int32) is affordable, else dense accumulators in HBM
         {
             RowBins rb(m);
-            make_bins(rb, A->d_ptr, nullptr, m, rownnz.p, 128, 1024, 4096);
-            DevBuf<int32_t> woff(0);
-            const int64_t n_win = ceil_div((int64_t)B->ncols, MM_WIN);
-            const int64_t woff_entries = (int64_t)B->nrows * (n_win + 1);
-            if (rb.count(4) && !(ctx().debug_flags & 256) && woff_entries * 4 <= (8ll << 30)) {
-                dev_free(woff.p);
-                woff.p = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)woff_entries);
-                hipLaunchKernelGGL(k_window_offsets, dim3((unsigned)ceil_div((int64_t)B->nrows, 256)), dim3(256), 0, ctx().stream,
-                                   (const int64_t *)B->d_ptr, (const int32_t *)B->d_col, (int64_t)B->nrows, (int)n_win, woff.p);
-                a.woff = woff.p;
-                a.n_win = (int)n_win;
-            }
+            make_bins(rb, A->d_ptr, nullptr, m, rownnz.p, 128, 1024, 4096, a.wrow);
+            if (rb.count(4)) ensure_woff();
             run_bins<T, true>(a, rb);
             sync_stream();  // woff is released at the end of this scope
         }

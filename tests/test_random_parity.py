@@ -1053,6 +1053,57 @@ def test_mxm_wide_heavy_rows(gb):
     assert int(np.diff(ref.indptr).max()) > 16384  # (heavy rows really took the LDS-bitmap / window path)
 
 
+@pytest.mark.parametrize("sr,tname", [("plus_times", "INT64"), ("min_plus", "FP64"), ("max_second", "INT32"), ("any_pair", "BOOL"), ("plus_pair", "UINT16")])
+@pytest.mark.parametrize("pool", [None, 0, 3])
+def test_mxm_unit_classes(gb, sr, tname, pool):
+    """Heavy rows as (row, column window) units: three windows whose entry counts fall into the three classes of the numeric pass
+    -- dense (> 4096 of the window's 16384 columns: one accumulator per column), medium (compact accumulators, four
+    wavefronts), small (<= 512: one wavefront) --, light rows, empty rows.  ``pool``: the number of unit bitmaps the symbolic
+    pass may keep for the numeric pass (None: no limit; 0: none, the numeric pass recomputes all; 3: the pool runs out)."""
+    import scipy.sparse as sp
+
+    from graphblas_amd import _lib
+
+    rng = np.random.default_rng(99)
+    m, k, n = 9, 220, 40_000
+    np_t = O.NP_OF[tname]
+    bc, br = [], []
+    for r in range(k):
+        cols = np.concatenate([rng.choice(16384, 150, replace=False), 16384 + rng.choice(16384, 40, replace=False),
+                               32768 + rng.choice(n - 32768, 3, replace=False)])
+        bc.append(np.sort(cols))
+        br.append(np.full(cols.size, r))
+    br, bc = np.concatenate(br), np.concatenate(bc)
+    deg = np.array([100, 0, 25, 3, 180, 1, 60, 0, 26])
+    ar = np.repeat(np.arange(m), deg)
+    ac = np.concatenate([np.sort(rng.choice(k, d, replace=False)) for d in deg])
+    if tname == "BOOL":
+        av, bv = np.ones(ar.size, bool), np.ones(br.size, bool)
+    else:
+        av, bv = rng.integers(1, 6, ar.size).astype(np_t), rng.integers(1, 6, br.size).astype(np_t)
+    A = gb.Matrix.from_coo(ar, ac, av, dtype=tname, nrows=m, ncols=k)
+    B = gb.Matrix.from_coo(br, bc, bv, dtype=tname, nrows=k, ncols=n)
+    try:
+        if pool is not None:
+            _lib.lib.GrX_option_set(b"mxm_bitmap_pool_cap", pool)
+        C = A.mxm(B, getattr(gb.semiring, sr)).new()
+    finally:
+        _lib.lib.GrX_option_set(b"mxm_bitmap_pool_cap", (1 << 31) - 1)
+    oc = O.mxm(O.OMat.from_coo(ar, ac, av, m, k, tname), O.OMat.from_coo(br, bc, bv, k, n, tname), sr)
+    cp, cj, cx = C.to_csr()
+    assert np.array_equal(cp.astype(np.int64), oc.indptr) and np.array_equal(cj.astype(np.int64), oc.indices)
+    if sr.startswith("any_") and not sr.endswith("pair"):
+        return
+    assert np.array_equal(cx, oc.values)
+    # the classes the rows were built for
+    P = (sp.csr_matrix((np.ones(ar.size), (ar, ac)), shape=(m, k)) @ sp.csr_matrix((np.ones(br.size), (br, bc)), shape=(k, n))).tocsr()
+    w0 = np.diff(P[:, :16384].tocsr().indptr)
+    w1 = np.diff(P[:, 16384:32768].tocsr().indptr)
+    w2 = np.diff(P[:, 32768:].tocsr().indptr)
+    assert w0[0] > 4096 and 512 < w1[0] <= 4096 and 0 < w2[0] <= 512 and w0[4] > 4096
+    assert np.diff(P.indptr)[2] > 4096 and deg[2] * 193 <= 16384
+
+
 @pytest.mark.parametrize("seed", range(24))
 def test_vector_assign_extract_random(gb, seed):
     """GrB_Vector_assign (vector and scalar sources) and GrB_Vector_extract with random index lists (no duplicates for assign),
