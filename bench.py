@@ -386,8 +386,8 @@ def main_mxm(args, gb, torch, device, rank, world, dist, barrier):
                        + ", INT64 ones" + (f"; row batches under {args.stream_budget_gb:g} GiB, output streamed (count + checksum)" if streamed else ""),
                        "nnz_A": nnz_a, "flops": flops, "nnz_C": nnz_c, "parallelism": f"row-shard x{world} (flop-balanced cuts), B replicated", **stream_out},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_spgemm_mhash / k_spgemm_mwin" if masked else "k_spgemm_hash / k_spgemm_sym_lds / k_spgemm_win",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None if streamed else measured_traffic(args.workload, args.scale),
+                         "kernel": "k_spgemm_mhash / k_spgemm_mwin" if masked else "k_spgemm_unit (symbolic + numeric classes) / k_spgemm_unit_dense / k_spgemm_hash",
                          "kernel_ms_hip_events": ev_ms / args.steps, "algorithmic_bytes_per_launch": alg_bytes / world},
             "cpu_baseline": cpu, "stats": st}))
     if dist is not None:

@@ -545,7 +545,13 @@ __global__ __launch_bounds__(MM_WIN_BLOCK) void k_spgemm_win(const MxmArgs a, co
 #else
 #define MXM_ABL(a, bit) false
 #endif
-constexpr int MU_ILP = 4;     // products a lane has in flight
+#ifndef GRB_MU_ILP
+#define GRB_MU_ILP 4
+#endif
+#ifndef GRB_MU_M2_WPU
+#define GRB_MU_M2_WPU 4
+#endif
+constexpr int MU_ILP = GRB_MU_ILP;  // products a lane has in flight
 constexpr int MU_POOLS = 1024;  // sub-pools of the bitmap pool
 constexpr int MU_SMALL = 512;  // entries of a unit a single wavefront accumulates
 
@@ -664,18 +670,20 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const 
             }
             mw_sync();
         };
-        int64_t pc = pbeg + sub * 64;
+        // wavefront s of the unit takes the entries s, s + WPU, s + 2 WPU, ... of the row (64 of them per batch): dealt in
+        // blocks of 64, the first wavefront would own the smallest k -- on a graph numbered by degree, the hub rows of B
+        int64_t pc = pbeg + sub;  // the batch's first entry (lane 0's)
 #pragma unroll
         for (int b = 0; b < NB; b++, pc += 64 * WPU) {
             if (pc >= pend) return;  // (wave-uniform)
-            if constexpr (FIRST) fetch(pc + lane, c_len[b], c_qb[b]);
-            process(pc + lane, c_len[b], c_qb[b]);
+            if constexpr (FIRST) fetch(pc + (int64_t)lane * WPU, c_len[b], c_qb[b]);
+            process(pc + (int64_t)lane * WPU, c_len[b], c_qb[b]);
         }
         for (; pc < pend; pc += 64 * WPU) {
             int len;
             int64_t qb;
-            fetch(pc + lane, len, qb);
-            process(pc + lane, len, qb);
+            fetch(pc + (int64_t)lane * WPU, len, qb);
+            process(pc + (int64_t)lane * WPU, len, qb);
         }
     };
     // ---- pass A: which columns of the window does the row reach
@@ -1244,7 +1252,7 @@ static void run_bins(MxmArgs &a, const RowBins &rb)
                 hipLaunchKernelGGL((k_spgemm_unit<T, true, 4, 1024>), dim3((unsigned)nu), dim3(256), 0, ctx().stream, a, rb.ptr(4), 0, 0, u, nu);
             });
             per_class(2, [&](const uint64_t *u, int64_t nu) {
-                hipLaunchKernelGGL((k_spgemm_unit<T, true, 4, 4096>), dim3((unsigned)nu), dim3(256), 0, ctx().stream, a, rb.ptr(4), 0, 0, u, nu);
+                hipLaunchKernelGGL((k_spgemm_unit<T, true, GRB_MU_M2_WPU, 4096>), dim3((unsigned)nu), dim3(64 * GRB_MU_M2_WPU), 0, ctx().stream, a, rb.ptr(4), 0, 0, u, nu);
             });
             per_class(3, [&](const uint64_t *u, int64_t nu) {
                 hipLaunchKernelGGL((k_spgemm_unit_dense<T>), dim3((unsigned)nu), dim3(MM_WIN_BLOCK), 0, ctx().stream, a, u);
