@@ -552,6 +552,7 @@ __global__ __launch_bounds__(MM_WIN_BLOCK) void k_spgemm_win(const MxmArgs a, co
 #define GRB_MU_M2_WPU 4
 #endif
 constexpr int MU_ILP = GRB_MU_ILP;  // products a lane has in flight
+constexpr int MU_SYMBOLIC = 0, MU_NUMERIC = 1, MU_MASKED = 2;  // what a unit kernel does
 constexpr int MU_POOLS = 1024;  // sub-pools of the bitmap pool
 constexpr int MU_SMALL = 512;  // entries of a unit a single wavefront accumulates
 
@@ -562,11 +563,12 @@ __device__ __forceinline__ void mw_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <typename T, bool NUMERIC, int WPU, int CAP>
+template <typename T, int MODE, int WPU, int CAP>
 __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const MxmArgs a, const uint32_t *rows, int64_t ridx0,
                                                                           int64_t nrows_here, const uint64_t *units, int64_t nunits)
 {
     using W = typename Widen<T>::type;
+    constexpr bool NUMERIC = MODE != MU_SYMBOLIC, MASKED = MODE == MU_MASKED;
     constexpr int WORDS = MM_WIN / 64, WPL = WORDS / 64;
     constexpr int WAVES = WPU > 4 ? WPU : 4;  // wavefronts per workgroup
     constexpr int UPB = WAVES / WPU;          // units per workgroup
@@ -577,20 +579,27 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const 
     __shared__ int64_t s_qb[WAVES][64];
     __shared__ int64_t s_pa[WAVES][64];
     __shared__ W s_acc[NUMERIC ? UPB : 1][NUMERIC ? CAP : 1];
+    __shared__ unsigned long long s_hit[MASKED ? UPB : 1][MASKED ? (CAP + 63) / 64 : 1];  // (masked: which accumulators received a product)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int uib = WPU == 1 ? wave : 0, sub = WPU == 1 ? 0 : wave;  // unit inside the workgroup, wavefront inside the unit
     const int nwin = a.n_win;
     const int64_t unit = (int64_t)blockIdx.x * UPB + uib;
     int64_t ridx = 0, row, out = 0;
-    int w, bslot = -1;
+    int w, bslot = -1, mcnt = 0;
     if constexpr (NUMERIC) {  // a unit of the class list: (row << 16) | window
         if (unit >= nunits) return;  // (uniform over the unit's threads)
         const uint64_t e = units[unit];
         row = (int64_t)(e >> 16);
         w = (int)(e & 0xFFFFu);
         const int64_t slot = a.wrow[row];
-        out = a.Tp[row] + a.wcnt[slot * (nwin + 1) + w];
-        if (a.wbm) bslot = a.wbm[slot * nwin + w];
+        if constexpr (MASKED) {  // (wcnt = the window offsets of the mask rows: the unit's mask entries are Mj[out .. out + mcnt))
+            const int32_t *mw = a.wcnt + slot * (nwin + 1) + w;
+            out = a.Mp[row] + mw[0];
+            mcnt = mw[1] - mw[0];
+        } else {
+            out = a.Tp[row] + a.wcnt[slot * (nwin + 1) + w];
+            if (a.wbm) bslot = a.wbm[slot * nwin + w];
+        }
     } else {  // every (row, window) of the rows [ridx0, ridx0 + nrows_here) of the bin
         if (unit >= nrows_here * nwin) return;
         ridx = ridx0 + unit / nwin;
@@ -617,6 +626,13 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const 
         for (int k = tiu; k < WORDS; k += 64 * WPU) bits[k] = 0ull;
     }
     usync();
+    if constexpr (MASKED) {  // the bitmap is the mask row's part inside the window: products outside it are dropped
+        for (int i = tiu; i < mcnt; i += 64 * WPU) {
+            const int j = a.Mj[out + i] - c0;
+            atomicOr(&bits[j >> 6], 1ull << (j & 63));
+        }
+        usync();
+    }
     // every product of the row inside the window: d = load(p, q), then apply(d) -- MU_ILP products per lane at a time, their loads
     // issued before the first apply (the LDS atomics would otherwise serialise the global load latencies).  The wavefronts of
     // a unit take the entries of A 64 at a time.
@@ -687,7 +703,7 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const 
         }
     };
     // ---- pass A: which columns of the window does the row reach
-    if (bslot < 0 && !(NUMERIC && MXM_ABL(a, 16)))
+    if (!MASKED && bslot < 0 && !(NUMERIC && MXM_ABL(a, 16)))
         visit(std::true_type{}, [&](int64_t, int64_t q) { return a.Bj[q] - c0; }, [&](int j) { atomicOr(&bits[j >> 6], 1ull << (j & 63)); });
     usync();
     // ---- counts: lane l looks at words 4 l .. 4 l + 3 (every wavefront of the unit computes the same numbers)
@@ -738,6 +754,8 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const 
         for (int r0 = 0; r0 < cnt; r0 += CAP) {
             const int here = cnt - r0 < CAP ? cnt - r0 : CAP;
             for (int i = tiu; i < here; i += 64 * WPU) acc[i] = ident;
+            if constexpr (MASKED)
+                for (int i = tiu; i < (CAP + 63) / 64; i += 64 * WPU) s_hit[uib][i] = 0ull;
             usync();
             struct Prod {
                 int j;
@@ -749,21 +767,33 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const 
                 return Prod{a.Bj[q] - c0, (W)apply_binop<T>(mult, av, bv)};
             };
             auto apply_b = [&](const Prod &d) {
-                const int rank = wpre[d.j >> 6] + __popcll(bits[d.j >> 6] & ((1ull << (d.j & 63)) - 1ull)) - r0;
+                const unsigned long long word = bits[d.j >> 6];
+                if (MASKED && !((word >> (d.j & 63)) & 1ull)) return;
+                const int rank = wpre[d.j >> 6] + __popcll(word & ((1ull << (d.j & 63)) - 1ull)) - r0;
                 if ((unsigned)rank < (unsigned)CAP && !MXM_ABL(a, 4)) {
                     if (monoid == OP_ANY) acc[rank] = d.v;
                     else atomic_combine<W>(&acc[rank], d.v, monoid);
+                    if constexpr (MASKED) atomicOr(&s_hit[uib][rank >> 6], 1ull << (rank & 63));
                 }
             };
             if (!MXM_ABL(a, 8)) {
-                if (bslot >= 0 && r0 == 0) visit(std::true_type{}, load_b, apply_b);  // (no pass A ran: the ranges of B are fetched here)
+                if ((MASKED || bslot >= 0) && r0 == 0) visit(std::true_type{}, load_b, apply_b);  // (no pass A ran: the ranges of B are fetched here)
                 else visit(std::false_type{}, load_b, apply_b);
             }
             usync();
-            if (!MXM_ABL(a, 2))
+            if constexpr (MASKED) {  // per mask entry: hit or not, and the value
+                T *cv = (T *)a.cap_val;
+                for (int i = tiu; i < here; i += 64 * WPU) {
+                    const bool hit = (s_hit[uib][i >> 6] >> (i & 63)) & 1ull;
+                    a.cap_hit[out + r0 + i] = hit ? 1 : 0;
+                    if (hit) cv[out + r0 + i] = from_acc<T, W>(acc[i]);
+                }
+            } else if (!MXM_ABL(a, 2)) {
                 for (int i = tiu; i < here; i += 64 * WPU) Tx[out + r0 + i] = from_acc<T, W>(acc[i]);
+            }
             usync();
         }
+        if constexpr (MASKED) return;
         // ---- columns, in order: the wavefronts of the unit share the (lane, word) pairs -- every wavefront holds all of them
         constexpr int LSPLIT = WPU > WPL ? WPU / WPL : 1;  // wavefronts per word index
         int pre = incl - c;
@@ -1067,6 +1097,13 @@ __global__ __launch_bounds__(MM_WIN_BLOCK) void k_spgemm_mwin(const MxmArgs a, c
 }
 
 // compaction of the mask-layout results into CSR
+// urow[i] = i for the rows of a masked product that are walked as units (more than min_flops products and a mask row), else -1
+__global__ void k_mask_unit_rows(const int64_t *Ap, const int64_t *F, const int64_t *Mp, int64_t m, int64_t min_flops, int32_t *urow)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) urow[i] = (F[Ap[i + 1]] - F[Ap[i]] > min_flops && Mp[i + 1] > Mp[i]) ? (int32_t)i : -1;
+}
+
 __global__ void k_mask_sizes(const int64_t *Ap, const int64_t *Mp, int64_t m, int64_t *size)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1211,6 +1248,51 @@ static void make_bins(RowBins &rb, const int64_t *Ap, const int64_t *F, int64_t 
     ctx().stats.kernel_launches += 2;
 }
 
+// the units of the rows `rows` (those with a slot: wrow[row] >= 0) by class, then one launch per class (and 2^21 units: a grid holds
+// fewer than 2^32 threads).  MODE = MU_NUMERIC: classes by the entry counts of the symbolic pass; MU_MASKED: by the number of mask
+// entries inside the window (a.wcnt = the window offsets of the mask rows), the densest class takes several passes.
+template <typename T, int MODE>
+static void launch_unit_classes(MxmArgs &a, const uint32_t *rows, int64_t nrows)
+{
+    DevBuf<unsigned long long> cur(8, true);
+    UnitLimits L;
+    L.lim[0] = std::min(MU_SMALL, ctx().mxm_unit_small);
+    L.lim[1] = std::max(L.lim[0], ctx().mxm_unit_mid);
+    L.lim[2] = MODE == MU_MASKED ? INT32_MAX : std::max(L.lim[1], ctx().mxm_unit_dense);
+    hipLaunchKernelGGL((k_unit_classify<false>), dim3((unsigned)ceil_div(nrows, 4)), dim3(256), 0, ctx().stream, (const int32_t *)a.wcnt,
+                       (const int32_t *)a.wrow, a.n_win, rows, nrows, cur.p, (uint64_t *)nullptr, L);
+    unsigned long long cnt[MU_NCLS], start[MU_NCLS + 1] = {0};
+    d2h(cnt, cur.p, sizeof(cnt));
+    for (int c = 0; c < MU_NCLS; c++) start[c + 1] = start[c] + cnt[c];
+    if (getenv("GRB_MXM_TRACE"))
+        fprintf(stderr, "[mxm] %s units: %lld rows x %d windows; by class %llu %llu %llu %llu\n", MODE == MU_MASKED ? "masked" : "numeric",
+                (long long)nrows, a.n_win, cnt[0], cnt[1], cnt[2], cnt[3]);
+    DevBuf<uint64_t> lists((size_t)start[MU_NCLS]);
+    h2d(cur.p, start, sizeof(unsigned long long) * MU_NCLS);
+    hipLaunchKernelGGL((k_unit_classify<true>), dim3((unsigned)ceil_div(nrows, 4)), dim3(256), 0, ctx().stream, (const int32_t *)a.wcnt,
+                       (const int32_t *)a.wrow, a.n_win, rows, nrows, cur.p, lists.p, L);
+    constexpr int64_t PER = 1ll << 21;
+    auto per_class = [&](int c, auto &&launch) {
+        for (int64_t u0 = 0; u0 < (int64_t)cnt[c]; u0 += PER)
+            launch(lists.p + start[c] + u0, std::min<int64_t>(PER, (int64_t)cnt[c] - u0));
+    };
+    per_class(0, [&](const uint64_t *u, int64_t nu) {
+        hipLaunchKernelGGL((k_spgemm_unit<T, MODE, 1, MU_SMALL>), dim3((unsigned)ceil_div(nu, 4)), dim3(256), 0, ctx().stream, a, rows, 0, 0, u, nu);
+    });
+    per_class(1, [&](const uint64_t *u, int64_t nu) {
+        hipLaunchKernelGGL((k_spgemm_unit<T, MODE, 4, 1024>), dim3((unsigned)nu), dim3(256), 0, ctx().stream, a, rows, 0, 0, u, nu);
+    });
+    per_class(2, [&](const uint64_t *u, int64_t nu) {
+        hipLaunchKernelGGL((k_spgemm_unit<T, MODE, GRB_MU_M2_WPU, 4096>), dim3((unsigned)nu), dim3(64 * GRB_MU_M2_WPU), 0, ctx().stream, a, rows, 0, 0, u, nu);
+    });
+    if constexpr (MODE == MU_NUMERIC)
+        per_class(3, [&](const uint64_t *u, int64_t nu) {
+            hipLaunchKernelGGL((k_spgemm_unit_dense<T>), dim3((unsigned)nu), dim3(MM_WIN_BLOCK), 0, ctx().stream, a, u);
+        });
+    ctx().stats.kernel_launches += 6;
+    sync_stream();  // (the lists are freed at the end of this scope)
+}
+
 template <typename T, bool NUMERIC>
 static void run_bins(MxmArgs &a, const RowBins &rb)
 {
@@ -1222,51 +1304,16 @@ static void run_bins(MxmArgs &a, const RowBins &rb)
     ctx().stats.kernel_launches += 3;
     if (rb.count(4) && a.woff && a.wrow && a.wcnt) {
         if constexpr (NUMERIC) {
-            // the bin's units by class, then one launch per class (and 2^21 units: a grid holds fewer than 2^32 threads)
-            DevBuf<unsigned long long> cur(8, true);
-            UnitLimits L;
-            L.lim[0] = std::min(MU_SMALL, ctx().mxm_unit_small);
-            L.lim[1] = std::max(L.lim[0], ctx().mxm_unit_mid);
-            L.lim[2] = std::max(L.lim[1], ctx().mxm_unit_dense);
-            hipLaunchKernelGGL((k_unit_classify<false>), dim3((unsigned)ceil_div(rb.count(4), 4)), dim3(256), 0, ctx().stream, (const int32_t *)a.wcnt,
-                               (const int32_t *)a.wrow, a.n_win, rb.ptr(4), rb.count(4), cur.p, (uint64_t *)nullptr, L);
-            unsigned long long cnt[MU_NCLS], start[MU_NCLS + 1] = {0};
-            d2h(cnt, cur.p, sizeof(cnt));
-            for (int c = 0; c < MU_NCLS; c++) start[c + 1] = start[c] + cnt[c];
-            if (getenv("GRB_MXM_TRACE"))
-                fprintf(stderr, "[mxm] numeric bin 4: %lld rows x %d windows; units by class %llu %llu %llu %llu\n", (long long)rb.count(4), a.n_win,
-                        cnt[0], cnt[1], cnt[2], cnt[3]);
-            DevBuf<uint64_t> lists((size_t)start[MU_NCLS]);
-            h2d(cur.p, start, sizeof(unsigned long long) * MU_NCLS);
-            hipLaunchKernelGGL((k_unit_classify<true>), dim3((unsigned)ceil_div(rb.count(4), 4)), dim3(256), 0, ctx().stream, (const int32_t *)a.wcnt,
-                               (const int32_t *)a.wrow, a.n_win, rb.ptr(4), rb.count(4), cur.p, lists.p, L);
-            constexpr int64_t PER = 1ll << 21;
-            auto per_class = [&](int c, auto &&launch) {
-                for (int64_t u0 = 0; u0 < (int64_t)cnt[c]; u0 += PER)
-                    launch(lists.p + start[c] + u0, std::min<int64_t>(PER, (int64_t)cnt[c] - u0));
-            };
-            per_class(0, [&](const uint64_t *u, int64_t nu) {
-                hipLaunchKernelGGL((k_spgemm_unit<T, true, 1, MU_SMALL>), dim3((unsigned)ceil_div(nu, 4)), dim3(256), 0, ctx().stream, a, rb.ptr(4), 0, 0, u, nu);
-            });
-            per_class(1, [&](const uint64_t *u, int64_t nu) {
-                hipLaunchKernelGGL((k_spgemm_unit<T, true, 4, 1024>), dim3((unsigned)nu), dim3(256), 0, ctx().stream, a, rb.ptr(4), 0, 0, u, nu);
-            });
-            per_class(2, [&](const uint64_t *u, int64_t nu) {
-                hipLaunchKernelGGL((k_spgemm_unit<T, true, GRB_MU_M2_WPU, 4096>), dim3((unsigned)nu), dim3(64 * GRB_MU_M2_WPU), 0, ctx().stream, a, rb.ptr(4), 0, 0, u, nu);
-            });
-            per_class(3, [&](const uint64_t *u, int64_t nu) {
-                hipLaunchKernelGGL((k_spgemm_unit_dense<T>), dim3((unsigned)nu), dim3(MM_WIN_BLOCK), 0, ctx().stream, a, u);
-            });
+            launch_unit_classes<T, MU_NUMERIC>(a, rb.ptr(4), rb.count(4));
             // rows of the bin the symbolic pass counted with a hash kernel (few products, but more entries than the numeric
             // hash table holds): the 1024-thread window walk
             hipLaunchKernelGGL((k_spgemm_win<T>), dim3((unsigned)rb.count(4)), dim3(MM_WIN_BLOCK), 0, ctx().stream, a, rb.ptr(4));
-            ctx().stats.kernel_launches += 6;
-            sync_stream();  // (the lists are freed at the end of this scope)
+            ctx().stats.kernel_launches += 1;
         } else {
             const int64_t rows_per_launch = std::max<int64_t>(1, (1ll << 22) / a.n_win);
             for (int64_t r0 = 0; r0 < rb.count(4); r0 += rows_per_launch) {
                 const int64_t nr = std::min(rows_per_launch, rb.count(4) - r0);
-                hipLaunchKernelGGL((k_spgemm_unit<T, false, 1, 1>), dim3((unsigned)ceil_div(nr * a.n_win, 4)), dim3(256), 0, ctx().stream, a, rb.ptr(4), r0,
+                hipLaunchKernelGGL((k_spgemm_unit<T, MU_SYMBOLIC, 1, 1>), dim3((unsigned)ceil_div(nr * a.n_win, 4)), dim3(256), 0, ctx().stream, a, rb.ptr(4), r0,
                                    nr, (const uint64_t *)nullptr, 0);
                 ctx().stats.kernel_launches += 1;
             }
@@ -1450,16 +1497,29 @@ static GB_Matrix_opaque *spgemm_masked(GB_Matrix_opaque *A, const void *Ax, GB_M
         DevBuf<unsigned char> cap_hit(nnzM, true);
         a.cap_val = cap_val.p;
         a.cap_hit = cap_hit.p;
-        // rows binned by the length of their mask row (rows of A without entries produce nothing)
+        // rows binned by the length of their mask row (rows of A without entries produce nothing); rows with many products
+        // (and a mask row) are walked as (row, window) units whatever the length of their mask row: urow[row] = row for them
         DevBuf<int64_t> size(m + 1);
         hipLaunchKernelGGL(k_mask_sizes, dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, ctx().stream, (const int64_t *)A->d_ptr,
                            a.Mp, m, size.p);
+        const int64_t n_win = ceil_div((int64_t)B->ncols, MM_WIN);
+        const int64_t woff_entries = (int64_t)B->nrows * (n_win + 1), mwoff_entries = m * (n_win + 1);
+        const bool units_ok = ctx().mxm_heavy_kernel == 1 && !(ctx().debug_flags & 256) && woff_entries * 4 <= (8ll << 30) &&
+                              mwoff_entries * 4 <= (8ll << 30) && Mask->ncols == B->ncols;
+        DevBuf<int32_t> urow(units_ok ? m : 0), mwoff(0);
+        if (units_ok) {
+            const int64_t nnzA = A->nvals;
+            DevBuf<int64_t> F(nnzA + 1);
+            hipLaunchKernelGGL(k_nnz_flops, dim3((unsigned)ceil_div(nnzA + 1, 256)), dim3(256), 0, ctx().stream, A->d_col, nnzA, B->d_ptr, F.p);
+            prim_exclusive_sum_i64(F.p, F.p, nnzA + 1);
+            hipLaunchKernelGGL(k_mask_unit_rows, dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, ctx().stream, (const int64_t *)A->d_ptr,
+                               (const int64_t *)F.p, a.Mp, m, std::max<int64_t>(ctx().mxm_unit_min_flops, 32 * n_win), urow.p);
+            sync_stream();  // (F is freed at the end of this scope)
+        }
         RowBins rb(m);
-        make_bins(rb, A->d_ptr, nullptr, m, size.p, 128, 1024, 4096);
+        make_bins(rb, A->d_ptr, nullptr, m, size.p, 128, 1024, 4096, units_ok ? urow.p : nullptr);
         DevBuf<int32_t> woff(0);
         if (rb.count(4)) {
-            const int64_t n_win = ceil_div((int64_t)B->ncols, MM_WIN);
-            const int64_t woff_entries = (int64_t)B->nrows * (n_win + 1);
             if (woff_entries * 4 > (8ll << 30)) {
                 matrix_free(Tm);
                 return nullptr;
@@ -1470,6 +1530,14 @@ static GB_Matrix_opaque *spgemm_masked(GB_Matrix_opaque *A, const void *Ax, GB_M
                                (const int64_t *)B->d_ptr, (const int32_t *)B->d_col, (int64_t)B->nrows, (int)n_win, woff.p);
             a.woff = woff.p;
             a.n_win = (int)n_win;
+            if (units_ok) {  // the mask rows' window offsets play the part of the symbolic pass's counts
+                dev_free(mwoff.p);
+                mwoff.p = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)mwoff_entries);
+                hipLaunchKernelGGL(k_window_offsets, dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, ctx().stream, a.Mp, a.Mj, m, (int)n_win, mwoff.p);
+                a.wcnt = mwoff.p;
+                a.wrow = urow.p;
+                launch_unit_classes<T, MU_MASKED>(a, rb.ptr(4), rb.count(4));
+            }
         }
         if (rb.count(1)) hipLaunchKernelGGL((k_spgemm_mhash<T, 256>), dim3((unsigned)rb.count(1)), dim3(MM_BLOCK), 0, ctx().stream, a, rb.ptr(1));
         if (rb.count(2)) hipLaunchKernelGGL((k_spgemm_mhash<T, 2048>), dim3((unsigned)rb.count(2)), dim3(MM_BLOCK), 0, ctx().stream, a, rb.ptr(2));
@@ -1644,7 +1712,10 @@ static void mxm_core(GB_Matrix_opaque *C, GB_Matrix_opaque *Mask, const GB_Binar
             Tm->d_val = cv;
         }
         Tm->type = C->type;
-        matrix_apply_write_rule(C, Mask, accum, Tm, f.replace, f.comp, f.structure);
+        // a mask-driven product lies inside the mask's pattern: under a structural mask, with nothing to accumulate into and
+        // nothing of C to keep (C empty, or replace), the write rule is C = T
+        if (ctx().stats.method == 4 && !accum && f.structure && !f.comp && (C->nvals == 0 || f.replace)) take_storage(C, Tm);
+        else matrix_apply_write_rule(C, Mask, accum, Tm, f.replace, f.comp, f.structure);
     } catch (...) {
         matrix_free(Tm);
         throw;

@@ -1104,6 +1104,51 @@ def test_mxm_unit_classes(gb, sr, tname, pool):
     assert np.diff(P.indptr)[2] > 4096 and deg[2] * 193 <= 16384
 
 
+@pytest.mark.parametrize("sr,tname", [("plus_times", "INT64"), ("min_plus", "FP64"), ("any_pair", "BOOL"), ("plus_pair", "UINT16")])
+def test_mxm_masked_unit_classes(gb, sr, tname):
+    """C<M.S> = A (+.x) B, mask-driven, with the heavy rows walked as (row, column window) units: the bitmap of a unit is the mask
+    row's part inside the window, the accumulators are keyed by the mask entry.  Mask rows with > 4096 entries in a window (several
+    passes of 4096 accumulators), 512 .. 4096 (four wavefronts), a few (one wavefront), none; a heavy row without mask entries;
+    light rows (LDS hash keyed by the mask row)."""
+    rng = np.random.default_rng(199)
+    m, k, n = 9, 220, 40_000
+    np_t = O.NP_OF[tname]
+    bc, br = [], []
+    for r in range(k):
+        cols = np.concatenate([rng.choice(16384, 150, replace=False), 16384 + rng.choice(16384, 40, replace=False),
+                               32768 + rng.choice(n - 32768, 3, replace=False)])
+        bc.append(np.sort(cols))
+        br.append(np.full(cols.size, r))
+    br, bc = np.concatenate(br), np.concatenate(bc)
+    deg = np.array([100, 0, 25, 3, 180, 1, 60, 0, 26])
+    ar = np.repeat(np.arange(m), deg)
+    ac = np.concatenate([np.sort(rng.choice(k, d, replace=False)) for d in deg])
+    # the mask: per row, how many entries in each of the three windows
+    per_win = {0: (6000, 800, 100), 2: (20, 5, 0), 3: (10, 0, 2), 4: (3000, 1500, 0), 5: (4, 4, 4), 8: (600, 30, 7000)}
+    mr, mc = [], []
+    for r, (n0, n1, n2) in per_win.items():
+        cols = np.concatenate([rng.choice(16384, n0, replace=False), 16384 + rng.choice(16384, n1, replace=False),
+                               32768 + rng.choice(n - 32768, n2, replace=False)])
+        mr.append(np.full(cols.size, r))
+        mc.append(np.sort(cols))
+    mr, mc = np.concatenate(mr), np.concatenate(mc)
+    if tname == "BOOL":
+        av, bv = np.ones(ar.size, bool), np.ones(br.size, bool)
+    else:
+        av, bv = rng.integers(1, 6, ar.size).astype(np_t), rng.integers(1, 6, br.size).astype(np_t)
+    A = gb.Matrix.from_coo(ar, ac, av, dtype=tname, nrows=m, ncols=k)
+    B = gb.Matrix.from_coo(br, bc, bv, dtype=tname, nrows=k, ncols=n)
+    M = gb.Matrix.from_coo(mr, mc, np.ones(mr.size, bool), dtype="BOOL", nrows=m, ncols=n)
+    C = gb.Matrix(tname, m, n)
+    C(M.S) << A.mxm(B, getattr(gb.semiring, sr))
+    om = O.OMat.from_coo(mr, mc, np.ones(mr.size, bool), m, n, "BOOL")
+    oc = O.mxm(O.OMat.from_coo(ar, ac, av, m, k, tname), O.OMat.from_coo(br, bc, bv, k, n, tname), sr, mask=om, mask_struct=True)
+    cp, cj, cx = C.to_csr()
+    assert np.array_equal(cp.astype(np.int64), oc.indptr) and np.array_equal(cj.astype(np.int64), oc.indices)
+    assert np.array_equal(cx, oc.values)
+    assert oc.nvals > 3000  # (the mask really met the product)
+
+
 @pytest.mark.parametrize("seed", range(24))
 def test_vector_assign_extract_random(gb, seed):
     """GrB_Vector_assign (vector and scalar sources) and GrB_Vector_extract with random index lists (no duplicates for assign),
