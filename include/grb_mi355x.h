@@ -299,6 +299,16 @@ GrB_Info GrX_Matrix_cache_bytes(const GrB_Matrix A, uint64_t *bytes);
  *                   with a lane per row ("sell_sigma" rows per sort window; measured slower)
  *   "long_sub"      sub-ranges per class of the cold columns of the long rows (0 = sized from the operand image),
  *   "long_sub_min_len"  for rows from this many entries (0 = 512 per sub-range)
+ *   "mxm_mask_mode" mask-driven SpGEMM for non-complemented masks: 1 (default) when the product costs clearly more than the mask,
+ *                   0 never, 2 always
+ *   "mxm_heavy_kernel"  SpGEMM rows beyond the LDS hash tables: 1 (default) (row, column window) work units (k_spgemm_unit),
+ *                   0 the 1024-thread row kernels of round 1
+ *   "mxm_unit_min_flops"  rows with more products than this (default 1024; and than 32 per column window) are walked as units
+ *   "mxm_unit_small" / "mxm_unit_mid" / "mxm_unit_dense"  entry counts of a unit up to which one wavefront with 512 accumulators /
+ *                   four wavefronts with 1024 / with 4096 accumulators take it (512, 1024, 4096); denser units get an
+ *                   accumulator per column of the window
+ *   "mxm_bitmap_pool_mb"  device memory (MiB, default 16384; never more than a quarter of the free memory) for the bitmaps of
+ *                   units the symbolic pass keeps for the numeric pass; "mxm_bitmap_pool_cap": the same as a count of bitmaps
  *   "push_mode"     mxv/vxm direction: 0 always pull, 1 (default) push when u has fewer than n/64 entries and the
  *                   matrix indexed like u is at hand, 2 always push when possible */
 GrB_Info GrX_option_set(const char *name, int64_t value);
