@@ -211,6 +211,74 @@ def test_mxm_rmat_vs_scipy(gb, scale):
     assert np.array_equal(Mx, exp.values)
 
 
+@pytest.mark.parametrize("scale,weighted", [(18, False), (17, True)])
+def test_mxm_unit_kernels_against_row_kernels_at_scale(gb, scale, weighted):
+    """configs[3] sizes beyond what scipy multiplies in seconds: the (row, column window) unit kernels of round 2 against the
+    1024-thread row kernels of round 1 (two independent implementations of the heavy rows), with other class limits and without
+    the bitmap pool -- identical matrices, compared on the device; for a matrix of ones the sum of the product's values equals
+    the number of multiplies (GrX_mxm_streamed's checksum, one batch and many)."""
+    import ctypes
+
+    import torch
+
+    from graphblas_amd import _lib, device, synthetic
+
+    L = _lib.lib
+    n = 1 << scale
+    indptr, col = synthetic.rmat_csr(scale, device="cuda")
+    if weighted:
+        vals = synthetic.edge_weights(col, scale, dtype=torch.int64)
+        A = device.matrix_from_device_csr(indptr, col, vals, n, n, "INT64")
+    else:
+        A = device.matrix_from_device_csr(indptr, col, torch.ones(1, dtype=torch.int64, device="cuda"), n, n, "INT64", iso=True)
+    sr = gb.semiring.plus_times if not weighted else gb.semiring.min_plus
+
+    def product(**opts):
+        try:
+            for k, v in opts.items():
+                L.GrX_option_set(k.encode(), v)
+            C = A.mxm(A, sr).new()
+            return C, device.last_stats()
+        finally:
+            for k, v in dict(mxm_heavy_kernel=1, mxm_unit_small=512, mxm_unit_mid=1024, mxm_unit_dense=4096,
+                             mxm_bitmap_pool_cap=(1 << 31) - 1, mxm_unit_min_flops=1024).items():
+                L.GrX_option_set(k.encode(), v)
+
+    C1, st1 = product()
+    C0, st0 = product(mxm_heavy_kernel=0)
+    assert st0["out_nvals"] == st1["out_nvals"] and st0["flops"] == st1["flops"] and st1["out_nvals"] > 100 * n
+    assert C1.isequal(C0)
+    del C0
+    C2, _ = product(mxm_unit_small=64, mxm_unit_mid=300, mxm_unit_dense=1500, mxm_bitmap_pool_cap=5000, mxm_unit_min_flops=128)
+    assert C1.isequal(C2)
+    del C2
+    C3, _ = product(mxm_bitmap_pool_cap=0, mxm_unit_min_flops=16384)
+    assert C1.isequal(C3)
+    del C3
+    if not weighted:
+        for budget in (1 << 40, 2 << 30):
+            nv, cs, fl, nb = (ctypes.c_uint64() for _ in range(4))
+            rc = L.GrX_mxm_streamed(gb.semiring.plus_times["INT64"]._carg, A._carg, A._carg, ctypes.c_uint64(budget), ctypes.byref(nv),
+                                    ctypes.byref(cs), ctypes.byref(fl), ctypes.byref(nb))
+            assert rc == 0
+            assert nv.value == st1["out_nvals"] and fl.value == st1["flops"] and cs.value == st1["flops"]
+            assert (nb.value == 1) == (budget == 1 << 40)
+        # the mask-driven product: units keyed by the mask row against the row kernels, and against the full product under the mask
+        M1 = A.mxm(A, sr).new(mask=A.S)
+        try:
+            L.GrX_option_set(b"mxm_heavy_kernel", 0)
+            M0 = A.mxm(A, sr).new(mask=A.S)
+        finally:
+            L.GrX_option_set(b"mxm_heavy_kernel", 1)
+        assert M1.isequal(M0)
+        try:
+            L.GrX_option_set(b"mxm_mask_mode", 0)  # (the full product, then the write rule)
+            M2 = A.mxm(A, sr).new(mask=A.S)
+        finally:
+            L.GrX_option_set(b"mxm_mask_mode", 1)
+        assert M1.isequal(M2) and M1.nvals > n
+
+
 @pytest.mark.gpu
 def test_reduce_rowwise_is_the_degree_vector(gb):
     """A.reduce_rowwise(plus) over an iso-ones R-MAT matrix = the out-degrees, reduce_columnwise = the in-degrees (scale 18):
