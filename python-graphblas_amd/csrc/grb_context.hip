@@ -183,6 +183,16 @@ extern "C" GrB_Info GrB_init(GrB_Mode mode)
     }
     (void)hipGetLastError();
     if (hipEventCreate(&c.ev0) != hipSuccess || hipEventCreate(&c.ev1) != hipSuccess) return GrB_PANIC;
+    // The HIP runtime loads a translation unit's code object at the first launch of one of its kernels: several ms for the
+    // SpMV unit with its template instantiations -- paid by whichever product came first (it showed up as 8 of the 12.7 ms of
+    // the first GrB_mxv of the scale-24 bench).  Load them here, once per process (GRB_PRELOAD=0: on demand, as before).
+    if (const char *e = getenv("GRB_PRELOAD"); !e || atoi(e) != 0) {
+        preload_mxv();
+        preload_mxm();
+        preload_vecops();
+        preload_object();
+        preload_prim();
+    }
     if (const char *e = getenv("GRB_DEBUG_FLAGS")) c.debug_flags = atoi(e) & DEBUG_FLAGS_MASK;
     if (const char *e = getenv("GRB_PULL_IPT")) c.tune_pull_ipt = atoi(e);
     if (const char *e = getenv("GRB_HOT_MIN_COLS")) c.hot_min_cols = atoll(e);

@@ -125,6 +125,13 @@ struct DevBuf {  // RAII temporary
     }
 };
 
+// one per translation unit with kernels: touches a kernel so that the HIP runtime loads the unit's code object (GrB_init)
+void preload_mxv();
+void preload_mxm();
+void preload_vecops();
+void preload_object();
+void preload_prim();
+
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 inline size_t bits_words64(uint64_t n) { return (size_t)((n + 63) / 64); }
 

@@ -1862,3 +1862,7 @@ extern "C" GrB_Info GrB_mxm(GrB_Matrix C, const GrB_Matrix Mask, const GrB_Binar
     mxm_core(C, Mask, accum, semiring, A, B, f);
     GRB_CATCH(errp(C))
 }
+
+namespace grb {
+void preload_mxm() { hipFuncAttributes at; (void)hipFuncGetAttributes(&at, reinterpret_cast<const void *>(&k_window_offsets)); (void)hipGetLastError(); }
+}  // namespace grb

@@ -1077,3 +1077,8 @@ extern "C" GrB_Info GrB_Matrix_reduce_Monoid(GrB_Vector w, const GrB_Vector mask
     vector_free(ones);
     GRB_CATCH(errp(w))
 }
+
+// GrB_init: load this file's code object now instead of at the first product (see preload_code_objects)
+namespace grb {
+void preload_mxv() { hipFuncAttributes at; (void)hipFuncGetAttributes(&at, reinterpret_cast<const void *>(&k_hot_hist)); (void)hipGetLastError(); }
+}  // namespace grb

@@ -1479,3 +1479,7 @@ extern "C" GrB_Info GrB_Matrix_resize(GrB_Matrix A, GrB_Index new_nrows, GrB_Ind
     matrix_free(N);
     GRB_CATCH(errp(A))
 }
+
+namespace grb {
+void preload_object() { hipFuncAttributes at; (void)hipFuncGetAttributes(&at, reinterpret_cast<const void *>(&k_popcount_sum)); (void)hipGetLastError(); }
+}  // namespace grb

@@ -37,4 +37,9 @@ void prim_exclusive_sum_i64(const int64_t *in, int64_t *out, int64_t n)
                                     ctx().stream));
 }
 
+__global__ void k_prim_touch() {}
+
+// (GrB_init: this unit's code object holds the rocPRIM sort / scan kernels)
+void preload_prim() { hipFuncAttributes at; (void)hipFuncGetAttributes(&at, reinterpret_cast<const void *>(&k_prim_touch)); (void)hipGetLastError(); }
+
 }  // namespace grb

@@ -645,3 +645,7 @@ GRB_EWISE(GrB_Vector_eWiseAdd_Monoid, GrB_Monoid, true)
 GRB_EWISE(GrB_Vector_eWiseMult_BinaryOp, GrB_BinaryOp, false)
 GRB_EWISE(GrB_Vector_eWiseMult_Monoid, GrB_Monoid, false)
 #undef GRB_EWISE
+
+namespace grb {
+void preload_vecops() { hipFuncAttributes at; (void)hipFuncGetAttributes(&at, reinterpret_cast<const void *>(&k_remove_element)); (void)hipGetLastError(); }
+}  // namespace grb

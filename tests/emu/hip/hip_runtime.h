@@ -53,6 +53,8 @@ inline hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t, int) { *v 
 inline hipError_t hipMallocAsync(void **p, size_t bytes, hipStream_t) { *p = malloc(bytes ? bytes : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 inline hipError_t hipFreeAsync(void *p, hipStream_t) { free(p); return hipSuccess; }
 inline hipError_t hipMemsetAsync(void *p, int v, size_t bytes, hipStream_t) { memset(p, v, bytes); return hipSuccess; }
+struct hipFuncAttributes { int numRegs; };
+inline hipError_t hipFuncGetAttributes(hipFuncAttributes *, const void *) { return hipSuccess; }
 inline hipError_t hipMemGetInfo(size_t *free_b, size_t *total_b) { *free_b = (size_t)1 << 30; *total_b = (size_t)4 << 30; return hipSuccess; }  // (the emulator: a small pool, so that its exhaustion is exercised too)
 inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t bytes, hipMemcpyKind, hipStream_t) { memmove(d, s, bytes); return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
