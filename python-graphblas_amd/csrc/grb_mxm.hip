@@ -1351,6 +1351,15 @@ static void run_bins(MxmArgs &a, const RowBins &rb)
     GRB_HIP(hipGetLastError());
 }
 
+// GrX_mxm_streamed multiplies row batches of A by the same B: the window offset table of B (19 ms to build at scale 22) is
+// built by the first batch that needs it and kept until the loop ends.
+struct WoffKeep {
+    bool on = false;
+    const void *Bp = nullptr;
+    int32_t *woff = nullptr;
+};
+static WoffKeep g_woff_keep;
+
 // T = A (+.x) B in the semiring's type; returns a fresh matrix (sorted rows)
 template <typename T>
 static GB_Matrix_opaque *spgemm(GB_Matrix_opaque *A, const void *Ax, GB_Matrix_opaque *B, const void *Bx, int st, int monoid,
@@ -1390,19 +1399,30 @@ static GB_Matrix_opaque *spgemm(GB_Matrix_opaque *A, const void *Ax, GB_Matrix_o
         const int64_t woff_entries = (int64_t)B->nrows * (n_win + 1);
         auto ensure_woff = [&]() {
             if (a.woff || (ctx().debug_flags & 256) || woff_entries * 4 > (8ll << 30)) return;
+            if (g_woff_keep.on && g_woff_keep.Bp == (const void *)B->d_ptr && g_woff_keep.woff) {  // (a row-batched product: B is the same in every batch)
+                a.woff = g_woff_keep.woff;
+                a.n_win = (int)n_win;
+                return;
+            }
             dev_free(woff.p);
             woff.p = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)woff_entries);
             hipLaunchKernelGGL(k_window_offsets, dim3((unsigned)ceil_div((int64_t)B->nrows, 256)), dim3(256), 0, ctx().stream,
                                (const int64_t *)B->d_ptr, (const int32_t *)B->d_col, (int64_t)B->nrows, (int)n_win, woff.p);
             a.woff = woff.p;
             a.n_win = (int)n_win;
+            if (g_woff_keep.on) {  // hand the table to the batch loop, which frees it at its end
+                g_woff_keep.Bp = (const void *)B->d_ptr;
+                g_woff_keep.woff = woff.release();
+            }
         };
         {
             RowBins rb(m);
             // rows beyond the LDS hash tables are walked as (row, window) units; with the unit kernels at hand the hash kernels
             // only keep the rows of up to max(4096, 32 per window) products (units of a handful of products do not pay)
             const bool units_ok = ctx().mxm_heavy_kernel == 1 && !(ctx().debug_flags & 256) && woff_entries * 4 <= (8ll << 30);
-            const int64_t sym_b3 = units_ok ? std::min<int64_t>(16384, std::max<int64_t>(ctx().mxm_unit_min_flops, 32 * n_win)) : 16384;
+            // (never above 4096: a row the hash kernels count must fit the numeric hash table, nnz <= flops <= 4096 -- or it falls to the
+            //  1024-thread window walk, a quarter of the scale-22 run while the limit was 32 x 256 windows = 8192)
+            const int64_t sym_b3 = units_ok ? std::min<int64_t>(4096, std::max<int64_t>(ctx().mxm_unit_min_flops, 32 * n_win)) : 16384;
             make_bins(rb, A->d_ptr, F.p, m, rownnz.p, 128, 1024, sym_b3);
             GRB_HIP(hipMemsetAsync(rownnz.p, 0, sizeof(int64_t) * (m + 1), ctx().stream));
             if (rb.count(4) && units_ok && rb.count(4) * (n_win + 1) * 4 <= (8ll << 30)) {
@@ -1787,6 +1807,15 @@ extern "C" GrB_Info GrX_mxm_streamed(const GrB_Semiring semiring, const GrB_Matr
         const int64_t per_entry = 4 + (int64_t)type_size(st);
         const int64_t max_flops = std::max<int64_t>(1, (int64_t)(budget_bytes / (uint64_t)per_entry));
         DevBuf<int64_t> cut(2);
+        struct KeepGuard {  // B's window offsets live from the first batch that builds them to the end of the loop
+            KeepGuard() { g_woff_keep = WoffKeep{}; g_woff_keep.on = true; }
+            ~KeepGuard()
+            {
+                (void)hipStreamSynchronize(ctx().stream);
+                dev_free(g_woff_keep.woff);
+                g_woff_keep = WoffKeep{};
+            }
+        } keep_guard;
         int64_t r0 = 0;
         while (r0 < m) {
             int64_t h[2];
