@@ -308,6 +308,7 @@ extern "C" GrB_Info GrX_option_set(const char *name, int64_t value)
     else if (n == "mxm_mask_mode") c.mxm_mask_mode = (int)value;
     else if (n == "mxm_heavy_kernel") c.mxm_heavy_kernel = (int)value;
     else if (n == "mxm_unit_min_flops") c.mxm_unit_min_flops = value;
+    else if (n == "mxm_masked_units_min_flops") c.mxm_masked_units_min_flops = value;
     else if (n == "mxm_unit_small") c.mxm_unit_small = (int)value;
     else if (n == "mxm_unit_dense") c.mxm_unit_dense = (int)value;
     else if (n == "mxm_unit_mid") c.mxm_unit_mid = (int)value;

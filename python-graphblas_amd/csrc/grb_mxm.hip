@@ -1496,7 +1496,7 @@ static GB_Matrix_opaque *spgemm(GB_Matrix_opaque *A, const void *Ax, GB_Matrix_o
 // Returns nullptr when the heavy-row path is unaffordable (offset table too large): the caller then takes the full product.
 template <typename T>
 static GB_Matrix_opaque *spgemm_masked(GB_Matrix_opaque *A, const void *Ax, GB_Matrix_opaque *B, const void *Bx, int st, int monoid,
-                                       int mult, GB_Matrix_opaque *Mask)
+                                       int mult, GB_Matrix_opaque *Mask, int64_t flops_total)
 {
     GB_Matrix_opaque *Tm = matrix_new(type_of_code(st), A->nrows, B->ncols);
     if (A->nvals == 0 || B->nvals == 0 || Mask->nvals == 0) return Tm;
@@ -1524,8 +1524,9 @@ static GB_Matrix_opaque *spgemm_masked(GB_Matrix_opaque *A, const void *Ax, GB_M
                            a.Mp, m, size.p);
         const int64_t n_win = ceil_div((int64_t)B->ncols, MM_WIN);
         const int64_t woff_entries = (int64_t)B->nrows * (n_win + 1), mwoff_entries = m * (n_win + 1);
+        // (small products: the classification's two host round trips cost more than the units save -- scale 12: 0.74 against 0.47 ms)
         const bool units_ok = ctx().mxm_heavy_kernel == 1 && !(ctx().debug_flags & 256) && woff_entries * 4 <= (8ll << 30) &&
-                              mwoff_entries * 4 <= (8ll << 30) && Mask->ncols == B->ncols;
+                              mwoff_entries * 4 <= (8ll << 30) && Mask->ncols == B->ncols && flops_total >= ctx().mxm_masked_units_min_flops;
         DevBuf<int32_t> urow(units_ok ? m : 0), mwoff(0);
         if (units_ok) {
             const int64_t nnzA = A->nvals;
@@ -1715,7 +1716,7 @@ static void mxm_core(GB_Matrix_opaque *C, GB_Matrix_opaque *Mask, const GB_Binar
     if (Mask && !f.comp && ctx().mxm_mask_mode != 0 && Mask->nvals > 0 && Mask->nvals < 0x7fffffffll * 8) {
         const int64_t flops = product_flops(Ae, Be);
         if (ctx().mxm_mask_mode == 2 || flops > 4 * (Mask->nvals + Ae->nvals)) {
-            GRB_DISPATCH_TYPE(st, T, { Tm = spgemm_masked<T>(Ae, Ax, Be, Bx, st, monoid, mult, Mask); })
+            GRB_DISPATCH_TYPE(st, T, { Tm = spgemm_masked<T>(Ae, Ax, Be, Bx, st, monoid, mult, Mask, flops); })
             if (Tm) {
                 ctx().stats.method = 4;
                 ctx().stats.flops = flops;

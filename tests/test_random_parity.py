@@ -290,6 +290,7 @@ def test_mxm_mask_driven(gb, seed):
     exp = O.mxm(oa, ob, sr, C=oc, mask=om, mask_struct=struct, accum=accum, replace=repl)
     try:
         _lib.lib.GrX_option_set(b"mxm_mask_mode", 2)
+        _lib.lib.GrX_option_set(b"mxm_masked_units_min_flops", 0 if seed % 2 else 64 << 20)  # (row, window) units / the row kernels
         A = gb.Matrix.from_coo(ar, ac, av, dtype=tname, nrows=m, ncols=k)
         B = gb.Matrix.from_coo(br, bc, bv, dtype=tname, nrows=k, ncols=n)
         C = gb.Matrix.from_coo(cr, cc, cv, dtype=tname, nrows=m, ncols=n) if use_c else gb.Matrix(tname, m, n)
@@ -308,6 +309,7 @@ def test_mxm_mask_driven(gb, seed):
             same_mat(D, exp2)
     finally:
         _lib.lib.GrX_option_set(b"mxm_mask_mode", 1)
+        _lib.lib.GrX_option_set(b"mxm_masked_units_min_flops", 64 << 20)
 
 
 @pytest.mark.parametrize("seed", range(6))
@@ -1140,7 +1142,13 @@ def test_mxm_masked_unit_classes(gb, sr, tname):
     B = gb.Matrix.from_coo(br, bc, bv, dtype=tname, nrows=k, ncols=n)
     M = gb.Matrix.from_coo(mr, mc, np.ones(mr.size, bool), dtype="BOOL", nrows=m, ncols=n)
     C = gb.Matrix(tname, m, n)
-    C(M.S) << A.mxm(B, getattr(gb.semiring, sr))
+    from graphblas_amd import _lib
+
+    try:
+        _lib.lib.GrX_option_set(b"mxm_masked_units_min_flops", 0)  # (small products keep the row kernels by default)
+        C(M.S) << A.mxm(B, getattr(gb.semiring, sr))
+    finally:
+        _lib.lib.GrX_option_set(b"mxm_masked_units_min_flops", 64 << 20)
     om = O.OMat.from_coo(mr, mc, np.ones(mr.size, bool), m, n, "BOOL")
     oc = O.mxm(O.OMat.from_coo(ar, ac, av, m, k, tname), O.OMat.from_coo(br, bc, bv, k, n, tname), sr, mask=om, mask_struct=True)
     cp, cj, cx = C.to_csr()
