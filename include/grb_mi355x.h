@@ -277,6 +277,10 @@ GrB_Info GrX_mxm_streamed(const GrB_Semiring semiring, const GrB_Matrix A, const
 /* Same shape, same pattern and values equal (rel_tol = abs_tol = 0) or close (|a - b| <= rel_tol |b| + abs_tol), compared on the
  * device in a common type (reference Matrix.isequal / isclose, core/matrix.py:373-467, do it with eWiseMult + reduce). */
 GrB_Info GrX_Matrix_isclose(bool *result, const GrB_Matrix A, const GrB_Matrix B, double rel_tol, double abs_tol);
+/* A copy with the values cast to `type`, made on the device (reference dup(dtype=...), core/matrix.py:469-497 and
+ * core/vector.py:392-420: a new object of the target type, then `rv << self`). */
+GrB_Info GrX_Matrix_dup_as(GrB_Matrix *C, const GrB_Type type, const GrB_Matrix A);
+GrB_Info GrX_Vector_dup_as(GrB_Vector *w, const GrB_Type type, const GrB_Vector u);
 /* Device bytes of the SpMV layouts cached with A so far (hot-coded columns, short part, long-row strips / items). */
 GrB_Info GrX_Matrix_cache_bytes(const GrB_Matrix A, uint64_t *bytes);
 /* Tuning / diagnostics knobs (also read from the environment at GrB_init as GRB_<NAME upper-case>):

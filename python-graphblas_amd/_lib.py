@@ -138,6 +138,8 @@ def _declare(L):
     L.GrX_last_stats.argtypes = [P(GrX_Stats)]
     L.GrX_Matrix_cache_bytes.argtypes = [c_void_p, P(c_u64)]
     L.GrX_Matrix_isclose.argtypes = [P(ctypes.c_bool), c_void_p, c_void_p, ctypes.c_double, ctypes.c_double]
+    L.GrX_Matrix_dup_as.argtypes = [P(c_void_p), c_void_p, c_void_p]
+    L.GrX_Vector_dup_as.argtypes = [P(c_void_p), c_void_p, c_void_p]
     L.GrX_mxm_streamed.argtypes = [c_void_p, c_void_p, c_void_p, c_u64, P(c_u64), P(c_u64), P(c_u64), P(c_u64)]
     L.GrX_version_string.restype = ctypes.c_char_p
 

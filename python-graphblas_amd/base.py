@@ -173,8 +173,24 @@ class BaseType:
         if isinstance(expr, Scalar) or _is_python_scalar(expr):
             # ``w(mask) << 5``: scalar assign over every index (reference core/base.py:352-372 -> Updater[...] << scalar)
             return self._assign_scalar_all(expr, mask=mask, accum=accum, replace=replace, opts=opts)
+        if self._grb_kind == "Vector" and type(expr) is type(self):
+            # ``w(mask, accum, replace) << u``: a copy under the write rule (reference core/base.py:373-399 applies the identity
+            # operator).  Here: first(u, u) over the union of u with itself -- one element-wise pass on the device.
+            from .operators import binary as _binary
+
+            expr = expr.ewise_add(expr, _binary.first)
         if self._grb_kind == "Matrix":
-            from .matrix import PowerCopy, PowerExpression, TransposedMatrix, _power
+            from .matrix import Matrix, PowerCopy, PowerExpression, TransposedMatrix, _power
+
+            if type(expr) is Matrix:
+                # ``C(mask, accum, replace) << A``: GrB_transpose with the input transposed back by the descriptor (T0)
+                complement = structure = False
+                if mask is not None:
+                    mask = _check_mask(mask, self)
+                    complement, structure = mask.complement, mask.structure
+                desc = descriptor_lookup(transpose_first=True, mask_complement=complement, mask_structure=structure,
+                                         output_replace=replace, **opts)
+                return call("GrB_transpose", [self, mask, accum, expr, desc])
 
             if isinstance(expr, TransposedMatrix):
                 # ``C(mask, accum, replace) << A.T`` -> GrB_transpose (reference core/base.py:401-411)

@@ -133,6 +133,22 @@ void preload_vecops();
 void preload_object();
 void preload_prim();
 
+template <typename T>
+struct DevPtr {  // owner of a device block that a callee allocated (freed unless released)
+    T *p = nullptr;
+    DevPtr() = default;
+    explicit DevPtr(T *q) : p(q) {}
+    DevPtr(const DevPtr &) = delete;
+    DevPtr &operator=(const DevPtr &) = delete;
+    ~DevPtr() { dev_free(p); }
+    T *release()
+    {
+        T *q = p;
+        p = nullptr;
+        return q;
+    }
+};
+
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 inline size_t bits_words64(uint64_t n) { return (size_t)((n + 63) / 64); }
 

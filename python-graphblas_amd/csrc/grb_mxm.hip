@@ -1419,7 +1419,8 @@ static GB_Matrix_opaque *spgemm(GB_Matrix_opaque *A, const void *Ax, GB_Matrix_o
             RowBins rb(m);
             // rows beyond the LDS hash tables are walked as (row, window) units; with the unit kernels at hand the hash kernels
             // only keep the rows of up to max(4096, 32 per window) products (units of a handful of products do not pay)
-            const bool units_ok = ctx().mxm_heavy_kernel == 1 && !(ctx().debug_flags & 256) && woff_entries * 4 <= (8ll << 30);
+            const bool units_ok = ctx().mxm_heavy_kernel == 1 && !(ctx().debug_flags & 256) && woff_entries * 4 <= (8ll << 30) &&
+                                  n_win < 65536;  // (a unit is (row << 16) | window)
             // (never above 4096: a row the hash kernels count must fit the numeric hash table, nnz <= flops <= 4096 -- or it falls to the
             //  1024-thread window walk, a quarter of the scale-22 run while the limit was 32 x 256 windows = 8192)
             const int64_t sym_b3 = units_ok ? std::min<int64_t>(4096, std::max<int64_t>(ctx().mxm_unit_min_flops, 32 * n_win)) : 16384;
@@ -1526,7 +1527,8 @@ static GB_Matrix_opaque *spgemm_masked(GB_Matrix_opaque *A, const void *Ax, GB_M
         const int64_t woff_entries = (int64_t)B->nrows * (n_win + 1), mwoff_entries = m * (n_win + 1);
         // (small products: the classification's two host round trips cost more than the units save -- scale 12: 0.74 against 0.47 ms)
         const bool units_ok = ctx().mxm_heavy_kernel == 1 && !(ctx().debug_flags & 256) && woff_entries * 4 <= (8ll << 30) &&
-                              mwoff_entries * 4 <= (8ll << 30) && Mask->ncols == B->ncols && flops_total >= ctx().mxm_masked_units_min_flops;
+                              mwoff_entries * 4 <= (8ll << 30) && n_win < 65536 && Mask->ncols == B->ncols &&
+                              flops_total >= ctx().mxm_masked_units_min_flops;
         DevBuf<int32_t> urow(units_ok ? m : 0), mwoff(0);
         if (units_ok) {
             const int64_t nnzA = A->nvals;

@@ -417,13 +417,10 @@ static void vector_build_typed(GB_Vector_opaque *w, const uint64_t *I, const voi
     bool dups = false;
     const int dup_op = dup ? canonical_op(w->type->code, dup->op) : -1;
     int64_t nu = sort_dedupe<T>(keys.p, perm.p, dX.p, n, std::max(1, ceil_log2_u64(w->n)), dup_op, &ok, &ov, &dups);
-    if (dups && !dup) {
-        dev_free(ok); dev_free(ov);
-        fail(GrB_INVALID_VALUE, "GrB_Vector_build: duplicate indices and no dup operator");
-    }
+    DevPtr<uint64_t> ok_own(ok);  // (released on every way out, a throwing launch included)
+    DevPtr<T> ov_own(ov);
+    if (dups && !dup) fail(GrB_INVALID_VALUE, "GrB_Vector_build: duplicate indices and no dup operator");
     LAUNCH((k_vec_scatter<T>), nu, ok, ov, nu, (T *)w->d_val, w->d_bits);
-    dev_free(ok);
-    dev_free(ov);
     w->nvals = nu;
 }
 
@@ -672,16 +669,17 @@ static void matrix_detect_iso(GB_Matrix_opaque *A)
     }
 }
 
-// Install sorted unique keys (row<<cshift|col) + values as the CSR of A.  Takes ownership of vals.
+// Install sorted unique keys (row<<cshift|col) + values as the CSR of A.  Takes the values out of `vals` once A owns them.
 template <typename T>
-static void matrix_install_from_keys(GB_Matrix_opaque *A, const uint64_t *keys, T *vals, int64_t nuniq, int cshift)
+static void matrix_install_from_keys(GB_Matrix_opaque *A, const uint64_t *keys, DevPtr<T> &vals, int64_t nuniq, int cshift)
 {
     matrix_release_storage(A);
+    A->owns = true;  // (what is attached below is released with A, whatever throws in between)
     A->d_ptr = (int64_t *)dev_alloc(sizeof(int64_t) * (A->nrows + 1));
     LAUNCH(k_rowptr_from_keys, (int64_t)A->nrows + 1, keys, nuniq, (int64_t)A->nrows, cshift, A->d_ptr);
     A->d_col = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)(nuniq ? nuniq : 1));
     LAUNCH(k_cols_from_keys, nuniq, keys, nuniq, cshift, A->d_col);
-    A->d_val = vals;
+    A->d_val = vals.release();
     A->nvals = nuniq;
     A->iso = false;
     A->owns = true;
@@ -709,12 +707,10 @@ static void matrix_build_device(GB_Matrix_opaque *A, const uint64_t *dI, const u
     bool dups = false;
     const int dup_op = dup ? canonical_op(A->type->code, dup->op) : -1;
     int64_t nu = sort_dedupe<T>(keys.p, perm.p, dX, n, key_bits, dup_op, &ok, &ov, &dups);
-    if (dups && !dup) {
-        dev_free(ok); dev_free(ov);
-        fail(GrB_INVALID_VALUE, std::string(who) + ": duplicate indices and no dup operator");
-    }
-    matrix_install_from_keys<T>(A, ok, ov, nu, cshift);
-    dev_free(ok);
+    DevPtr<uint64_t> ok_own(ok);
+    DevPtr<T> ov_own(ov);
+    if (dups && !dup) fail(GrB_INVALID_VALUE, std::string(who) + ": duplicate indices and no dup operator");
+    matrix_install_from_keys<T>(A, ok, ov_own, nu, cshift);
 }
 
 template <typename T>
@@ -764,14 +760,14 @@ static void matrix_extract_typed(GB_Matrix_opaque *A, uint64_t *I, uint64_t *J, 
         d2h(J, cols.p, sizeof(uint64_t) * nv);
     }
     if (X) {
-        T *vals = matrix_values_expanded<T>(A);
+        DevPtr<T> vals_own(matrix_values_expanded<T>(A));
+        T *vals = vals_own.p;
         if (x_type == A->type->code) d2h(X, vals, sizeof(T) * nv);
         else {
             DevBuf<char> c((size_t)nv * type_size(x_type));
             cast_array(x_type, c.p, A->type->code, vals, nv);
             d2h(X, c.p, (size_t)nv * type_size(x_type));
         }
-        dev_free(vals);
     }
 }
 
@@ -916,6 +912,17 @@ extern "C" GrB_Info GrB_Vector_dup(GrB_Vector *w, const GrB_Vector u)
     GRB_CATCH(nullptr)
 }
 
+extern "C" GrB_Info GrX_Vector_dup_as(GrB_Vector *w, const GrB_Type type, const GrB_Vector u)
+{
+    GRB_TRY
+    require_init();
+    if (!w) fail(GrB_NULL_POINTER, "GrX_Vector_dup_as: NULL output");
+    if (!type) fail(GrB_NULL_POINTER, "GrX_Vector_dup_as: NULL type");
+    check_vector(u, "u");
+    *w = vector_cast_copy(u, type->code);
+    GRB_CATCH(nullptr)
+}
+
 extern "C" GrB_Info GrB_Vector_free(GrB_Vector *v)
 {
     if (!v || !*v) return GrB_SUCCESS;
@@ -984,6 +991,19 @@ extern "C" GrB_Info GrB_Matrix_dup(GrB_Matrix *C, const GrB_Matrix A)
     if (!C) fail(GrB_NULL_POINTER, "GrB_Matrix_dup: NULL output");
     check_matrix(A, "A");
     *C = matrix_dup(A);
+    GRB_CATCH(nullptr)
+}
+
+// C = a copy of A with its values cast to `type` on the device (the reference's dup(dtype): core/matrix.py:469-497 builds the
+// new object and assigns `rv << self`, i.e. an identity apply with a typecast)
+extern "C" GrB_Info GrX_Matrix_dup_as(GrB_Matrix *C, const GrB_Type type, const GrB_Matrix A)
+{
+    GRB_TRY
+    require_init();
+    if (!C) fail(GrB_NULL_POINTER, "GrX_Matrix_dup_as: NULL output");
+    if (!type) fail(GrB_NULL_POINTER, "GrX_Matrix_dup_as: NULL type");
+    check_matrix(A, "A");
+    *C = matrix_cast_copy(A, type->code);
     GRB_CATCH(nullptr)
 }
 

@@ -173,14 +173,23 @@ class Matrix(BaseType):
     def to_csc(self):
         return self._to_csx(GrB_CSC_FORMAT)
 
-    def dup(self, dtype=None, *, name=None):
+    def dup(self, dtype=None, *, clear=False, mask=None, name=None):
+        """A copy; ``dtype``: with the values cast (on the device); ``clear``: same shape and dtype, no entries; ``mask``: only the
+        entries the mask lets through (reference core/matrix.py:469-497; tests/test_matrix.py:66-96)."""
+        dt = self.dtype if dtype is None else lookup_dtype(dtype)
+        if clear:
+            return Matrix(dt, self._nrows, self._ncols, name=name)
+        if mask is not None:
+            C = Matrix(dt, self._nrows, self._ncols, name=name)
+            C(mask=mask) << self
+            return C
         C = Matrix.__new__(Matrix)
-        C.dtype, C._nrows, C._ncols, C.name = self.dtype, self._nrows, self._ncols, name or f"M_{next(_name_counter)}"
+        C.dtype, C._nrows, C._ncols, C.name = dt, self._nrows, self._ncols, name or f"M_{next(_name_counter)}"
         C._handle = ctypes.c_void_p()
-        call_on(self, "GrB_Matrix_dup", [ctypes.byref(C._handle), self._handle])
-        if dtype is not None and lookup_dtype(dtype) is not self.dtype:
-            I, J, X = C.to_coo()
-            return Matrix.from_coo(I, J, X.astype(lookup_dtype(dtype).np_type), nrows=self._nrows, ncols=self._ncols, name=name)
+        if dt is self.dtype:
+            call_on(self, "GrB_Matrix_dup", [ctypes.byref(C._handle), self._handle])
+        else:  # the typecast copy is made on the device
+            call_on(self, "GrX_Matrix_dup_as", [ctypes.byref(C._handle), dt._carg, self._handle])
         return C
 
     def clear(self):

@@ -143,14 +143,23 @@ class Vector(BaseType):
         out[I.astype(np.int64)] = X
         return out
 
-    def dup(self, dtype=None, *, name=None):
+    def dup(self, dtype=None, *, clear=False, mask=None, name=None):
+        """A copy; ``dtype``: with the values cast (on the device); ``clear``: same size and dtype, no entries; ``mask``: only the
+        entries the mask lets through (reference core/vector.py:392-420; tests/test_vector.py:58-92)."""
+        dt = self.dtype if dtype is None else lookup_dtype(dtype)
+        if clear:
+            return Vector(dt, self._size, name=name)
+        if mask is not None:
+            w = Vector(dt, self._size, name=name)
+            w(mask=mask) << self
+            return w
         w = Vector.__new__(Vector)
-        w.dtype, w._size, w.name = self.dtype, self._size, name or f"v_{next(_name_counter)}"
+        w.dtype, w._size, w.name = dt, self._size, name or f"v_{next(_name_counter)}"
         w._handle = ctypes.c_void_p()
-        call_on(self, "GrB_Vector_dup", [ctypes.byref(w._handle), self._handle])
-        if dtype is not None and lookup_dtype(dtype) is not self.dtype:
-            I, X = w.to_coo()
-            return Vector.from_coo(I, X.astype(lookup_dtype(dtype).np_type), size=self._size, name=name)
+        if dt is self.dtype:
+            call_on(self, "GrB_Vector_dup", [ctypes.byref(w._handle), self._handle])
+        else:  # the typecast copy is made on the device
+            call_on(self, "GrX_Vector_dup_as", [ctypes.byref(w._handle), dt._carg, self._handle])
         return w
 
     def clear(self):

@@ -817,3 +817,47 @@ def test_matrix_isequal_isclose_on_device(gb, A):
     ones = gb.Matrix.from_coo(rows, cols, np.ones(rows.size, np.int64), nrows=7, ncols=7)  # stored as one value (iso)
     assert ones.isequal(gb.Matrix.from_coo(rows, cols, np.ones(rows.size), nrows=7, ncols=7))
     assert gb.Matrix(int, 3, 4).isequal(gb.Matrix(float, 3, 4))
+
+
+def test_dup_dtype_mask_clear(gb, A, v):
+    """dup with its extended arguments -- literals of graphblas/tests/test_matrix.py:66-96 and tests/test_vector.py:69-96; the
+    typecast copy is made in the library (GrX_Matrix_dup_as / GrX_Vector_dup_as), the masked one is `rv(mask) << self`."""
+    C = A.dup()
+    assert C is not A and C.dtype == A.dtype and C.nvals == A.nvals and C.nrows == A.nrows and C.ncols == A.ncols
+    keep = A.dup()
+    A.clear()  # (not the same backend object; Matrix element assignment is outside the path)
+    assert C.nvals == 12 and heq(C, keep)
+    A = keep
+    D = gb.Matrix.from_coo([0, 1], [0, 1], [0, 2.5], dtype="FP64")
+    assert heq(D.dup(dtype="INT64"), gb.Matrix.from_coo([0, 1], [0, 1], [0, 2], dtype="INT64"))
+    assert heq(D.dup(mask=D.V), gb.Matrix.from_coo([1], [1], [2.5], dtype="FP64"))
+    assert heq(D.dup(dtype="INT64", mask=D.V), gb.Matrix.from_coo([1], [1], [2], dtype="INT64"))
+    E = A.dup(clear=True)
+    assert E.dtype == A.dtype and E.nvals == 0 and E.shape == A.shape
+    E = A.dup("INT8", clear=True)
+    assert E.dtype.name == "INT8" and E.nvals == 0 and E.shape == A.shape
+    # vectors
+    u = v.dup()
+    assert u is not v and u.dtype == v.dtype and u.nvals == v.nvals and u.size == v.size
+    v[0] = 1000
+    assert u[0].new() != 1000
+    w = gb.Vector.from_coo([0, 1], [0, 2.5], dtype="FP64")
+    assert heq(w.dup(dtype="INT64"), gb.Vector.from_coo([0, 1], [0, 2], dtype="INT64"))
+    assert heq(w.dup(mask=w.V), gb.Vector.from_coo([1], [2.5], dtype="FP64"))
+    assert heq(w.dup(dtype="INT64", mask=w.V), gb.Vector.from_coo([1], [2], dtype="INT64"))
+    x = v.dup(clear=True)
+    assert x.dtype == v.dtype and x.nvals == 0 and x.size == v.size
+    x = v.dup("INT8", clear=True)
+    assert x.dtype.name == "INT8" and x.nvals == 0 and x.size == v.size
+    # a plain object on the right-hand side of an update: a copy under the write rule, with an accumulator too
+    y = gb.Vector.from_coo([0, 1, 3], [5, 6, 7], size=7)
+    y(gb.binary.plus) << v
+    assert heq(y, gb.Vector.from_coo([0, 1, 3, 4, 6], [1005, 7, 8, 2, 0], size=7))
+    F = gb.Matrix.from_coo([0, 3], [0, 0], [1, 10], nrows=7, ncols=7)
+    F(gb.binary.plus) << A
+    fr, fc, fv = F.to_coo()
+    ar, ac, av = A.to_coo()
+    exp = {(int(r), int(c)): int(x) for r, c, x in zip(ar, ac, av)}
+    exp[(0, 0)] = exp.get((0, 0), 0) + 1
+    exp[(3, 0)] = exp.get((3, 0), 0) + 10
+    assert {(int(r), int(c)): int(x) for r, c, x in zip(fr, fc, fv)} == exp
