@@ -553,6 +553,17 @@ __global__ __launch_bounds__(MM_WIN_BLOCK) void k_spgemm_win(const MxmArgs a, co
 #endif
 constexpr int MU_ILP = GRB_MU_ILP;  // products a lane has in flight
 constexpr int MU_SYMBOLIC = 0, MU_NUMERIC = 1, MU_MASKED = 2;  // what a unit kernel does
+// a unit of the numeric / masked pass as the classification writes it: everything the kernel needs to start on the entries of
+// A's row (one 32-byte load instead of the chain unit -> row -> slot -> offsets)
+struct alignas(16) UnitRec {
+    int64_t out;     // numeric: Tp[row] + the unit's offset inside its row;  masked: position of the unit's first mask entry
+    int64_t pbeg;    // the row of A: first entry ...
+    int32_t plen;    // ... and length
+    uint32_t row;
+    int32_t aux;     // numeric: the unit's bitmap in the pool or -1;  masked: mask entries inside the window
+    int32_t w;       // the window
+};
+static_assert(sizeof(UnitRec) == 32, "UnitRec is two 16-byte loads");
 constexpr int MU_POOLS = 1024;  // sub-pools of the bitmap pool
 constexpr int MU_SMALL = 512;  // entries of a unit a single wavefront accumulates
 
@@ -565,7 +576,7 @@ __device__ __forceinline__ void mw_sync()
 
 template <typename T, int MODE, int WPU, int CAP>
 __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const MxmArgs a, const uint32_t *rows, int64_t ridx0,
-                                                                          int64_t nrows_here, const uint64_t *units, int64_t nunits)
+                                                                          int64_t nrows_here, const UnitRec *units, int64_t nunits)
 {
     using W = typename Widen<T>::type;
     constexpr bool NUMERIC = MODE != MU_SYMBOLIC, MASKED = MODE == MU_MASKED;
@@ -577,34 +588,31 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const 
     __shared__ int s_wpre[NUMERIC ? UPB : 1][NUMERIC ? WORDS : 1];
     __shared__ int s_scan[WAVES][64];
     __shared__ int64_t s_qb[WAVES][64];
-    __shared__ int64_t s_pa[WAVES][64];
     __shared__ W s_acc[NUMERIC ? UPB : 1][NUMERIC ? CAP : 1];
     __shared__ unsigned long long s_hit[MASKED ? UPB : 1][MASKED ? (CAP + 63) / 64 : 1];  // (masked: which accumulators received a product)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int uib = WPU == 1 ? wave : 0, sub = WPU == 1 ? 0 : wave;  // unit inside the workgroup, wavefront inside the unit
     const int nwin = a.n_win;
     const int64_t unit = (int64_t)blockIdx.x * UPB + uib;
-    int64_t ridx = 0, row, out = 0;
+    int64_t ridx = 0, row, out = 0, pbeg, pend;
     int w, bslot = -1, mcnt = 0;
-    if constexpr (NUMERIC) {  // a unit of the class list: (row << 16) | window
+    if constexpr (NUMERIC) {  // a unit of the class list
         if (unit >= nunits) return;  // (uniform over the unit's threads)
-        const uint64_t e = units[unit];
-        row = (int64_t)(e >> 16);
-        w = (int)(e & 0xFFFFu);
-        const int64_t slot = a.wrow[row];
-        if constexpr (MASKED) {  // (wcnt = the window offsets of the mask rows: the unit's mask entries are Mj[out .. out + mcnt))
-            const int32_t *mw = a.wcnt + slot * (nwin + 1) + w;
-            out = a.Mp[row] + mw[0];
-            mcnt = mw[1] - mw[0];
-        } else {
-            out = a.Tp[row] + a.wcnt[slot * (nwin + 1) + w];
-            if (a.wbm) bslot = a.wbm[slot * nwin + w];
-        }
+        const UnitRec r = units[unit];
+        row = r.row;
+        w = r.w;
+        out = r.out;
+        pbeg = r.pbeg;
+        pend = pbeg + r.plen;
+        if constexpr (MASKED) mcnt = r.aux;  // (the unit's mask entries are Mj[out .. out + mcnt))
+        else bslot = r.aux;
     } else {  // every (row, window) of the rows [ridx0, ridx0 + nrows_here) of the bin
         if (unit >= nrows_here * nwin) return;
         ridx = ridx0 + unit / nwin;
         w = (int)(unit % nwin);
         row = rows[ridx];
+        pbeg = a.Ap[row];
+        pend = a.Ap[row + 1];
     }
     auto usync = [&]() {
         if constexpr (WPU == 1) mw_sync();
@@ -612,14 +620,30 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const 
     };
     unsigned long long *bits = s_bits[uib];
     int *wpre = s_wpre[NUMERIC ? uib : 0], *scan = s_scan[wave];
-    int64_t *sqb = s_qb[wave], *spa = s_pa[wave];
+    int64_t *sqb = s_qb[wave];
     W *acc = s_acc[NUMERIC ? uib : 0];
     const int monoid = a.monoid, mult = a.mult;
     const T *Ax = (const T *)a.Ax, *Bx = (const T *)a.Bx;
     const W ident = monoid_identity<T, W>(monoid);
-    const int64_t pbeg = a.Ap[row], pend = a.Ap[row + 1];
     const int c0 = w * MM_WIN;
     const int tiu = sub * 64 + lane;  // thread inside the unit
+    // the ranges of B inside the window for the first NB batches of the wavefront's entries of A: requested before anything
+    // else (two dependent round trips that overlap the bitmap load / clear and the accumulator fill), kept for every pass
+    int c_len[NB];
+    int64_t c_qb[NB];
+    auto fetch = [&](int64_t p, int &len, int64_t &qb) {
+        len = 0;
+        qb = 0;
+        if (p < pend) {
+            const int k = a.Aj[p];
+            const int32_t *o = a.woff + (int64_t)k * (nwin + 1) + w;
+            const int o0 = o[0], o1 = o[1];
+            qb = a.Bp[k] + o0;
+            len = o1 - o0;
+        }
+    };
+#pragma unroll
+    for (int b = 0; b < NB; b++) fetch(pbeg + sub + (int64_t)b * 64 * WPU + (int64_t)lane * WPU, c_len[b], c_qb[b]);
     if (bslot >= 0) {  // (numeric pass: the symbolic pass kept the unit's bitmap)
         for (int k = tiu; k < WORDS; k += 64 * WPU) bits[k] = a.bm_pool[(int64_t)bslot * WORDS + k];
     } else {
@@ -636,22 +660,12 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const 
     // every product of the row inside the window: d = load(p, q), then apply(d) -- MU_ILP products per lane at a time, their loads
     // issued before the first apply (the LDS atomics would otherwise serialise the global load latencies).  The wavefronts of
     // a unit take the entries of A 64 at a time.
-    int c_len[NB];
-    int64_t c_qb[NB];
-    auto visit = [&](auto first, auto &&load, auto &&apply) {
-        constexpr bool FIRST = decltype(first)::value;
-        auto fetch = [&](int64_t p, int &len, int64_t &qb) {
-            len = 0;
-            qb = 0;
-            if (p < pend) {
-                const int k = a.Aj[p];
-                const int32_t *o = a.woff + (int64_t)k * (nwin + 1) + w;
-                const int o0 = o[0], o1 = o[1];
-                qb = a.Bp[k] + o0;
-                len = o1 - o0;
-            }
-        };
-        auto process = [&](int64_t p, int len, int64_t qb) {
+    auto visit = [&](auto &&load, auto &&apply) {
+        // one batch: lane l holds the range [qb, qb + len) of B for the entry pc + l WPU of A; a wavefront scan of the lengths
+        // numbers the products, and the lanes take them round-robin (binary search of the product number in the scan).
+        // (A search-free dealing -- ranges of 16+ entries walked by the whole wavefront four at a time, shorter ones by their own
+        //  lane -- measured 20 % SLOWER, 275 against 225 ms at scale 20: fewer products in flight per round trip.)
+        auto process = [&](int64_t pc, int len, int64_t qb) {
             int incl = len;
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) {
@@ -662,7 +676,6 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const 
             if (total == 0) return;  // (wave-uniform)
             scan[lane] = incl - len;
             sqb[lane] = qb;
-            spa[lane] = p;
             mw_sync();
             for (int t0 = lane; t0 < total; t0 += 64 * MU_ILP) {
                 decltype(load((int64_t)0, (int64_t)0)) d[MU_ILP];
@@ -670,14 +683,11 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const 
                 for (int u = 0; u < MU_ILP; u++) {
                     const int t = t0 + 64 * u;
                     if (t < total) {
-                        int lo = 0, hi = 64;  // the last entry whose first product number is <= t
+                        int lo = 0;  // the last entry whose first product number is <= t (scan[0] = 0 <= t): six steps, three VALU each
 #pragma unroll
-                        for (int step = 0; step < 6; step++) {
-                            const int mid = (lo + hi) >> 1;
-                            if (scan[mid] <= t) lo = mid;
-                            else hi = mid;
-                        }
-                        d[u] = load(spa[lo], sqb[lo] + (t - scan[lo]));
+                        for (int s = 32; s > 0; s >>= 1)
+                            if (scan[lo + s] <= t) lo += s;
+                        d[u] = load(pc + (int64_t)lo * WPU, sqb[lo] + (t - scan[lo]));
                     }
                 }
 #pragma unroll
@@ -692,19 +702,18 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const 
 #pragma unroll
         for (int b = 0; b < NB; b++, pc += 64 * WPU) {
             if (pc >= pend) return;  // (wave-uniform)
-            if constexpr (FIRST) fetch(pc + (int64_t)lane * WPU, c_len[b], c_qb[b]);
-            process(pc + (int64_t)lane * WPU, c_len[b], c_qb[b]);
+            process(pc, c_len[b], c_qb[b]);
         }
         for (; pc < pend; pc += 64 * WPU) {
             int len;
             int64_t qb;
             fetch(pc + (int64_t)lane * WPU, len, qb);
-            process(pc + (int64_t)lane * WPU, len, qb);
+            process(pc, len, qb);
         }
     };
     // ---- pass A: which columns of the window does the row reach
     if (!MASKED && bslot < 0 && !(NUMERIC && MXM_ABL(a, 16)))
-        visit(std::true_type{}, [&](int64_t, int64_t q) { return a.Bj[q] - c0; }, [&](int j) { atomicOr(&bits[j >> 6], 1ull << (j & 63)); });
+        visit([&](int64_t, int64_t q) { return a.Bj[q] - c0; }, [&](int j) { atomicOr(&bits[j >> 6], 1ull << (j & 63)); });
     usync();
     // ---- counts: lane l looks at words 4 l .. 4 l + 3 (every wavefront of the unit computes the same numbers)
     unsigned long long mine[WPL];
@@ -776,10 +785,7 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const 
                     if constexpr (MASKED) atomicOr(&s_hit[uib][rank >> 6], 1ull << (rank & 63));
                 }
             };
-            if (!MXM_ABL(a, 8)) {
-                if ((MASKED || bslot >= 0) && r0 == 0) visit(std::true_type{}, load_b, apply_b);  // (no pass A ran: the ranges of B are fetched here)
-                else visit(std::false_type{}, load_b, apply_b);
-            }
+            if (!MXM_ABL(a, 8)) visit(load_b, apply_b);
             usync();
             if constexpr (MASKED) {  // per mask entry: hit or not, and the value
                 T *cv = (T *)a.cap_val;
@@ -820,7 +826,7 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const 
 constexpr int MU_DENSE = 4096;
 
 template <typename T>
-__global__ __launch_bounds__(MM_WIN_BLOCK) void k_spgemm_unit_dense(const MxmArgs a, const uint64_t *units)
+__global__ __launch_bounds__(MM_WIN_BLOCK) void k_spgemm_unit_dense(const MxmArgs a, const UnitRec *units)
 {
     using W = typename Widen<T>::type;
     __shared__ W s_acc[MM_WIN];
@@ -828,19 +834,16 @@ __global__ __launch_bounds__(MM_WIN_BLOCK) void k_spgemm_unit_dense(const MxmArg
     __shared__ int s_wave[MM_WIN_BLOCK / 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nwin = a.n_win;
-    const uint64_t e = units[blockIdx.x];
-    const int64_t row = (int64_t)(e >> 16);
-    const int w = (int)(e & 0xFFFFu);
-    const int64_t slot = a.wrow[row];
-    const int o0 = a.wcnt[slot * (nwin + 1) + w];
-    const int bslot = a.wbm ? a.wbm[slot * nwin + w] : -1;  // (the symbolic pass kept the bitmap: no atomics on it here)
+    const UnitRec r = units[blockIdx.x];
+    const int w = r.w;
+    const int bslot = r.aux;  // (the symbolic pass kept the bitmap: no atomics on it here)
     const int monoid = a.monoid, mult = a.mult;
     const T *Ax = (const T *)a.Ax, *Bx = (const T *)a.Bx;
     const W ident = monoid_identity<T, W>(monoid);
     for (int k = tid; k < MM_WIN; k += MM_WIN_BLOCK) s_acc[k] = ident;
     if (tid < MM_WIN / 64) s_bits[tid] = bslot >= 0 ? a.bm_pool[(int64_t)bslot * (MM_WIN / 64) + tid] : 0ull;
     __syncthreads();
-    const int64_t pbeg = a.Ap[row], pend = a.Ap[row + 1];
+    const int64_t pbeg = r.pbeg, pend = pbeg + r.plen;
     const int c0 = w * MM_WIN;
     for (int64_t pc = pbeg; pc < pend; pc += MM_WIN_BLOCK) {
         const int64_t p = pc + tid;
@@ -880,7 +883,7 @@ __global__ __launch_bounds__(MM_WIN_BLOCK) void k_spgemm_unit_dense(const MxmArg
     __syncthreads();
     int wave_off = 0;
     for (int x = 0; x < wv; x++) wave_off += s_wave[x];
-    int64_t o = a.Tp[row] + o0 + wave_off + (incl - c);
+    int64_t o = r.out + wave_off + (incl - c);
     T *Tx = (T *)a.Tx;
     while (b16) {
         const int t = __ffs(b16) - 1;
@@ -903,7 +906,8 @@ struct UnitLimits {
 
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_unit_classify(const int32_t *wcnt, const int32_t *wrow, int nwin, const uint32_t *rows, int64_t nrows_bin,
-                                                       unsigned long long *cursor, uint64_t *lists, UnitLimits L)
+                                                       unsigned long long *cursor, UnitRec *lists, UnitLimits L, const int64_t *Ap,
+                                                       const int64_t *base_ptr, const int32_t *wbm, int masked)
 {
     const int lane = threadIdx.x & 63;
     const int64_t ridx = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -927,7 +931,16 @@ __global__ __launch_bounds__(256) void k_unit_classify(const int32_t *wcnt, cons
             unsigned long long base = 0;
             if (lane == 0) base = atomicAdd(&cursor[c], (unsigned long long)__popcll(mk));
             base = __shfl(base, 0);
-            if (FILL && cls == c) lists[base + __popcll(mk & ((1ull << lane) - 1ull))] = ((uint64_t)row << 16) | (uint64_t)w;
+            if (FILL && cls == c) {
+                UnitRec r;
+                r.out = base_ptr[row] + wc[w];  // (base_ptr: the row pointers of T, or of the mask)
+                r.pbeg = Ap[row];
+                r.plen = (int32_t)(Ap[row + 1] - r.pbeg);
+                r.row = (uint32_t)row;
+                r.aux = masked ? cnt : (wbm ? wbm[(int64_t)slot * nwin + w] : -1);
+                r.w = w;
+                lists[base + __popcll(mk & ((1ull << lane) - 1ull))] = r;
+            }
         }
     }
 }
@@ -1260,33 +1273,35 @@ static void launch_unit_classes(MxmArgs &a, const uint32_t *rows, int64_t nrows)
     L.lim[1] = std::max(L.lim[0], ctx().mxm_unit_mid);
     L.lim[2] = MODE == MU_MASKED ? INT32_MAX : std::max(L.lim[1], ctx().mxm_unit_dense);
     hipLaunchKernelGGL((k_unit_classify<false>), dim3((unsigned)ceil_div(nrows, 4)), dim3(256), 0, ctx().stream, (const int32_t *)a.wcnt,
-                       (const int32_t *)a.wrow, a.n_win, rows, nrows, cur.p, (uint64_t *)nullptr, L);
+                       (const int32_t *)a.wrow, a.n_win, rows, nrows, cur.p, (UnitRec *)nullptr, L, a.Ap, (const int64_t *)nullptr,
+                       (const int32_t *)nullptr, 0);
     unsigned long long cnt[MU_NCLS], start[MU_NCLS + 1] = {0};
     d2h(cnt, cur.p, sizeof(cnt));
     for (int c = 0; c < MU_NCLS; c++) start[c + 1] = start[c] + cnt[c];
     if (getenv("GRB_MXM_TRACE"))
         fprintf(stderr, "[mxm] %s units: %lld rows x %d windows; by class %llu %llu %llu %llu\n", MODE == MU_MASKED ? "masked" : "numeric",
                 (long long)nrows, a.n_win, cnt[0], cnt[1], cnt[2], cnt[3]);
-    DevBuf<uint64_t> lists((size_t)start[MU_NCLS]);
+    DevBuf<UnitRec> lists((size_t)start[MU_NCLS]);
     h2d(cur.p, start, sizeof(unsigned long long) * MU_NCLS);
     hipLaunchKernelGGL((k_unit_classify<true>), dim3((unsigned)ceil_div(nrows, 4)), dim3(256), 0, ctx().stream, (const int32_t *)a.wcnt,
-                       (const int32_t *)a.wrow, a.n_win, rows, nrows, cur.p, lists.p, L);
+                       (const int32_t *)a.wrow, a.n_win, rows, nrows, cur.p, lists.p, L, a.Ap, MODE == MU_MASKED ? a.Mp : a.Tp,
+                       (const int32_t *)a.wbm, MODE == MU_MASKED ? 1 : 0);
     constexpr int64_t PER = 1ll << 21;
     auto per_class = [&](int c, auto &&launch) {
         for (int64_t u0 = 0; u0 < (int64_t)cnt[c]; u0 += PER)
             launch(lists.p + start[c] + u0, std::min<int64_t>(PER, (int64_t)cnt[c] - u0));
     };
-    per_class(0, [&](const uint64_t *u, int64_t nu) {
+    per_class(0, [&](const UnitRec *u, int64_t nu) {
         hipLaunchKernelGGL((k_spgemm_unit<T, MODE, 1, MU_SMALL>), dim3((unsigned)ceil_div(nu, 4)), dim3(256), 0, ctx().stream, a, rows, 0, 0, u, nu);
     });
-    per_class(1, [&](const uint64_t *u, int64_t nu) {
+    per_class(1, [&](const UnitRec *u, int64_t nu) {
         hipLaunchKernelGGL((k_spgemm_unit<T, MODE, 4, 1024>), dim3((unsigned)nu), dim3(256), 0, ctx().stream, a, rows, 0, 0, u, nu);
     });
-    per_class(2, [&](const uint64_t *u, int64_t nu) {
+    per_class(2, [&](const UnitRec *u, int64_t nu) {
         hipLaunchKernelGGL((k_spgemm_unit<T, MODE, GRB_MU_M2_WPU, 4096>), dim3((unsigned)nu), dim3(64 * GRB_MU_M2_WPU), 0, ctx().stream, a, rows, 0, 0, u, nu);
     });
     if constexpr (MODE == MU_NUMERIC)
-        per_class(3, [&](const uint64_t *u, int64_t nu) {
+        per_class(3, [&](const UnitRec *u, int64_t nu) {
             hipLaunchKernelGGL((k_spgemm_unit_dense<T>), dim3((unsigned)nu), dim3(MM_WIN_BLOCK), 0, ctx().stream, a, u);
         });
     ctx().stats.kernel_launches += 6;
@@ -1314,7 +1329,7 @@ static void run_bins(MxmArgs &a, const RowBins &rb)
             for (int64_t r0 = 0; r0 < rb.count(4); r0 += rows_per_launch) {
                 const int64_t nr = std::min(rows_per_launch, rb.count(4) - r0);
                 hipLaunchKernelGGL((k_spgemm_unit<T, MU_SYMBOLIC, 1, 1>), dim3((unsigned)ceil_div(nr * a.n_win, 4)), dim3(256), 0, ctx().stream, a, rb.ptr(4), r0,
-                                   nr, (const uint64_t *)nullptr, 0);
+                                   nr, (const UnitRec *)nullptr, 0);
                 ctx().stats.kernel_launches += 1;
             }
             hipLaunchKernelGGL(k_unit_prefix, dim3((unsigned)ceil_div(rb.count(4), 4)), dim3(256), 0, ctx().stream, a.wcnt, a.n_win, rb.ptr(4),
@@ -1420,7 +1435,7 @@ static GB_Matrix_opaque *spgemm(GB_Matrix_opaque *A, const void *Ax, GB_Matrix_o
             // rows beyond the LDS hash tables are walked as (row, window) units; with the unit kernels at hand the hash kernels
             // only keep the rows of up to max(4096, 32 per window) products (units of a handful of products do not pay)
             const bool units_ok = ctx().mxm_heavy_kernel == 1 && !(ctx().debug_flags & 256) && woff_entries * 4 <= (8ll << 30) &&
-                                  n_win < 65536;  // (a unit is (row << 16) | window)
+                                  n_win < 65536;
             // (never above 4096: a row the hash kernels count must fit the numeric hash table, nnz <= flops <= 4096 -- or it falls to the
             //  1024-thread window walk, a quarter of the scale-22 run while the limit was 32 x 256 windows = 8192)
             const int64_t sym_b3 = units_ok ? std::min<int64_t>(4096, std::max<int64_t>(ctx().mxm_unit_min_flops, 32 * n_win)) : 16384;
