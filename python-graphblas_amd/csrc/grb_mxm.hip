@@ -675,7 +675,7 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const 
             const int total = __shfl(incl, 63);
             if (total == 0) return;  // (wave-uniform)
             scan[lane] = incl - len;
-            sqb[lane] = qb;
+            sqb[lane] = qb - (incl - len);  // (product t of the batch is entry sqb[e] + t of B, e = the lane that brought it)
             mw_sync();
             for (int t0 = lane; t0 < total; t0 += 64 * MU_ILP) {
                 decltype(load((int64_t)0, (int64_t)0)) d[MU_ILP];
@@ -687,7 +687,7 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const 
 #pragma unroll
                         for (int s = 32; s > 0; s >>= 1)
                             if (scan[lo + s] <= t) lo += s;
-                        d[u] = load(pc + (int64_t)lo * WPU, sqb[lo] + (t - scan[lo]));
+                        d[u] = load(pc + (int64_t)lo * WPU, sqb[lo] + t);
                     }
                 }
 #pragma unroll
