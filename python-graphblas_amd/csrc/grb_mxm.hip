@@ -55,6 +55,8 @@ struct MxmArgs {
     // wrow[row] = the row's slot in wcnt (-1: the symbolic pass counted the row with a hash kernel)
     int32_t *wcnt;
     int32_t *wrow;
+    unsigned long long *class_count;         // symbolic pass: units per class of the numeric pass (device, MU_NCLS numbers)
+    const unsigned long long *class_known;   // numeric pass: the same on the host
     // bitmaps of the units the symbolic pass found beyond bm_min_cnt entries, kept for the numeric pass (which then skips its own
     // pass A): a pool of bm_cap bitmaps of MM_WIN bits handed out by an atomic cursor, wbm[slot * n_win + w] = the unit's
     // bitmap or -1 (small unit, or the pool ran out: the numeric pass recomputes)
@@ -948,8 +950,9 @@ __global__ __launch_bounds__(256) void k_unit_classify(const int32_t *wcnt, cons
 // the per-window counts of the rows of the symbolic unit pass -> offsets inside the row (exclusive scan in place, n_win + 1
 // numbers per row), the row's entry count, and the row -> slot map the numeric pass finds its units' offsets with.
 // One wavefront per row.
+// ... and, on the way, how many units each class of the numeric pass will hold (class_count[c]; k_unit_classify's counting pass)
 __global__ __launch_bounds__(256) void k_unit_prefix(int32_t *wcnt, int nwin, const uint32_t *rows, int64_t nrows_bin, int64_t *row_nnz,
-                                                     int32_t *wrow)
+                                                     int32_t *wrow, unsigned long long *class_count, UnitLimits L)
 {
     const int lane = threadIdx.x & 63;
     const int64_t ridx = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -958,6 +961,16 @@ __global__ __launch_bounds__(256) void k_unit_prefix(int32_t *wcnt, int nwin, co
     int carry = 0;
     for (int b = 0; b < nwin; b += 64) {
         const int v = b + lane < nwin ? wc[b + lane] : 0;
+        int cls = -1;
+        if (v > 0) {
+            cls = MU_NCLS - 1;
+            for (int c = MU_NCLS - 2; c >= 0; c--)
+                if (v <= L.lim[c]) cls = c;
+        }
+        for (int c = 0; c < MU_NCLS; c++) {
+            const unsigned long long mk = __ballot(cls == c);
+            if (mk != 0 && lane == 0) atomicAdd(&class_count[c], (unsigned long long)__popcll(mk));
+        }
         int incl = v;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -1264,19 +1277,30 @@ static void make_bins(RowBins &rb, const int64_t *Ap, const int64_t *F, int64_t 
 // the units of the rows `rows` (those with a slot: wrow[row] >= 0) by class, then one launch per class (and 2^21 units: a grid holds
 // fewer than 2^32 threads).  MODE = MU_NUMERIC: classes by the entry counts of the symbolic pass; MU_MASKED: by the number of mask
 // entries inside the window (a.wcnt = the window offsets of the mask rows), the densest class takes several passes.
-template <typename T, int MODE>
-static void launch_unit_classes(MxmArgs &a, const uint32_t *rows, int64_t nrows)
+static UnitLimits unit_limits(bool masked)
 {
-    DevBuf<unsigned long long> cur(8, true);
     UnitLimits L;
     L.lim[0] = std::min(MU_SMALL, ctx().mxm_unit_small);
     L.lim[1] = std::max(L.lim[0], ctx().mxm_unit_mid);
-    L.lim[2] = MODE == MU_MASKED ? INT32_MAX : std::max(L.lim[1], ctx().mxm_unit_dense);
-    hipLaunchKernelGGL((k_unit_classify<false>), dim3((unsigned)ceil_div(nrows, 4)), dim3(256), 0, ctx().stream, (const int32_t *)a.wcnt,
-                       (const int32_t *)a.wrow, a.n_win, rows, nrows, cur.p, (UnitRec *)nullptr, L, a.Ap, (const int64_t *)nullptr,
-                       (const int32_t *)nullptr, 0);
+    L.lim[2] = masked ? INT32_MAX : std::max(L.lim[1], ctx().mxm_unit_dense);
+    return L;
+}
+
+// (known: the class counts, when the symbolic pass already took them -- k_unit_prefix)
+template <typename T, int MODE>
+static void launch_unit_classes(MxmArgs &a, const uint32_t *rows, int64_t nrows, const unsigned long long *known = nullptr)
+{
+    DevBuf<unsigned long long> cur(8, true);
+    const UnitLimits L = unit_limits(MODE == MU_MASKED);
     unsigned long long cnt[MU_NCLS], start[MU_NCLS + 1] = {0};
-    d2h(cnt, cur.p, sizeof(cnt));
+    if (known) {
+        for (int c = 0; c < MU_NCLS; c++) cnt[c] = known[c];
+    } else {
+        hipLaunchKernelGGL((k_unit_classify<false>), dim3((unsigned)ceil_div(nrows, 4)), dim3(256), 0, ctx().stream, (const int32_t *)a.wcnt,
+                           (const int32_t *)a.wrow, a.n_win, rows, nrows, cur.p, (UnitRec *)nullptr, L, a.Ap, (const int64_t *)nullptr,
+                           (const int32_t *)nullptr, 0);
+        d2h(cnt, cur.p, sizeof(cnt));
+    }
     for (int c = 0; c < MU_NCLS; c++) start[c + 1] = start[c] + cnt[c];
     if (getenv("GRB_MXM_TRACE"))
         fprintf(stderr, "[mxm] %s units: %lld rows x %d windows; by class %llu %llu %llu %llu\n", MODE == MU_MASKED ? "masked" : "numeric",
@@ -1319,7 +1343,7 @@ static void run_bins(MxmArgs &a, const RowBins &rb)
     ctx().stats.kernel_launches += 3;
     if (rb.count(4) && a.woff && a.wrow && a.wcnt) {
         if constexpr (NUMERIC) {
-            launch_unit_classes<T, MU_NUMERIC>(a, rb.ptr(4), rb.count(4));
+            launch_unit_classes<T, MU_NUMERIC>(a, rb.ptr(4), rb.count(4), a.class_known);
             // rows of the bin the symbolic pass counted with a hash kernel (few products, but more entries than the numeric
             // hash table holds): the 1024-thread window walk
             hipLaunchKernelGGL((k_spgemm_win<T>), dim3((unsigned)rb.count(4)), dim3(MM_WIN_BLOCK), 0, ctx().stream, a, rb.ptr(4));
@@ -1333,7 +1357,7 @@ static void run_bins(MxmArgs &a, const RowBins &rb)
                 ctx().stats.kernel_launches += 1;
             }
             hipLaunchKernelGGL(k_unit_prefix, dim3((unsigned)ceil_div(rb.count(4), 4)), dim3(256), 0, ctx().stream, a.wcnt, a.n_win, rb.ptr(4),
-                               rb.count(4), a.row_nnz, a.wrow);
+                               rb.count(4), a.row_nnz, a.wrow, a.class_count, unit_limits(false));
             ctx().stats.kernel_launches += 1;
         }
     } else if (rb.count(4) && !NUMERIC && a.n <= (1 << 24) && !(ctx().debug_flags & 256)) {
@@ -1409,7 +1433,8 @@ static GB_Matrix_opaque *spgemm(GB_Matrix_opaque *A, const void *Ax, GB_Matrix_o
         a.row_nnz = rownnz.p;
         // column-window offsets of B's rows (heavy rows walk the windows in both passes): n_B x (windows + 1) int32, per call
         DevBuf<int32_t> woff(0), wcnt(0), wrow(0), wbm(0);
-        DevBuf<unsigned long long> bm_pool(0), bm_cur(16 * MU_POOLS);
+        DevBuf<unsigned long long> bm_pool(0), bm_cur(16 * MU_POOLS), class_cnt(8);
+        unsigned long long class_host[8] = {0};
         const int64_t n_win = ceil_div((int64_t)B->ncols, MM_WIN);
         const int64_t woff_entries = (int64_t)B->nrows * (n_win + 1);
         auto ensure_woff = [&]() {
@@ -1451,6 +1476,8 @@ static GB_Matrix_opaque *spgemm(GB_Matrix_opaque *A, const void *Ax, GB_Matrix_o
                     GRB_HIP(hipMemsetAsync(wrow.p, 0xFF, sizeof(int32_t) * (size_t)m, ctx().stream));
                     a.wcnt = wcnt.p;
                     a.wrow = wrow.p;
+                    GRB_HIP(hipMemsetAsync(class_cnt.p, 0, sizeof(unsigned long long) * 8, ctx().stream));
+                    a.class_count = class_cnt.p;
                     // the bitmap pool: as many bitmaps as the option allows and a quarter of the free memory holds
                     size_t free_b = 0, total_b = 0;
                     GRB_HIP(hipMemGetInfo(&free_b, &total_b));
@@ -1479,6 +1506,10 @@ static GB_Matrix_opaque *spgemm(GB_Matrix_opaque *A, const void *Ax, GB_Matrix_o
         prim_exclusive_sum_i64(rownnz.p, Tp, m + 1);
         int64_t nnzT = 0;
         d2h(&nnzT, Tp + m, sizeof(int64_t));
+        if (a.class_count) {  // (the symbolic pass walked units: their class counts come with the same synchronisation)
+            d2h(class_host, class_cnt.p, sizeof(unsigned long long) * MU_NCLS);
+            a.class_known = class_host;
+        }
         Tm->d_ptr = Tp;
         ctx().stats.out_nvals = nnzT;
         if (nnzT == 0) {
