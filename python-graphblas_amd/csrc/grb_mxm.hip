@@ -157,12 +157,10 @@ __device__ __forceinline__ void foreach_product(const MxmArgs &a, int64_t row, F
         s_fp_qb[tid] = qb;
         __syncthreads();
         for (int t = tid; t < total; t += BLOCK) {
-            int lo = 0, hi = BLOCK;
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (s_fp_scan[mid] <= t) lo = mid;
-                else hi = mid;
-            }
+            int lo = 0;  // the last entry whose first product number is <= t (BLOCK is a power of two; three VALU per step)
+#pragma unroll
+            for (int st = BLOCK / 2; st > 0; st >>= 1)
+                if (s_fp_scan[lo + st] <= t) lo += st;
             const int64_t q = s_fp_qb[lo] + (t - s_fp_scan[lo]);
             f(a.Bj[q], pc + lo, q);
         }
@@ -364,6 +362,17 @@ __global__ void k_window_offsets(const int64_t *Bp, const int32_t *Bj, int64_t n
     }
 }
 
+struct DealScratch {
+    int scan[MM_WIN_BLOCK + 1];
+    int64_t qb[MM_WIN_BLOCK];
+    int wsum[MM_WIN_BLOCK / 64];
+};
+__device__ __forceinline__ DealScratch &deal_scratch()
+{
+    __shared__ DealScratch sc;
+    return sc;
+}
+
 // Products A(row,k) * B(k,j) with j inside column window w, visited by the whole 1024-thread workgroup (every thread must
 // call).  The row's entries come 1024 at a time, one per thread: the thread fetches the range of B(k,:) inside the window
 // from the offset table; a workgroup scan of the range lengths numbers the products, and the threads take them round-robin
@@ -375,9 +384,12 @@ __global__ void k_window_offsets(const int64_t *Bp, const int32_t *Bj, int64_t n
 template <typename F>
 __device__ __forceinline__ void deal_products(int len, int64_t qb, F &&f)
 {
-    __shared__ int s_scan[MM_WIN_BLOCK + 1];
-    __shared__ int64_t s_qb[MM_WIN_BLOCK];
-    __shared__ int s_wsum[MM_WIN_BLOCK / 64];
+    // (one scratch area for every instantiation: a static __shared__ array inside a function template is allocated once per
+    //  instantiation, and the callers instantiate this one per semiring copy of their loops)
+    DealScratch &sc = deal_scratch();
+    int *s_scan = sc.scan;
+    int64_t *s_qb = sc.qb;
+    int *s_wsum = sc.wsum;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int incl = len;
 #pragma unroll
@@ -396,12 +408,10 @@ __device__ __forceinline__ void deal_products(int len, int64_t qb, F &&f)
     s_qb[tid] = qb;
     __syncthreads();
     for (int t = tid; t < total; t += MM_WIN_BLOCK) {
-        int lo = 0, hi = MM_WIN_BLOCK;  // the last entry whose first product number is <= t
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (s_scan[mid] <= t) lo = mid;
-            else hi = mid;
-        }
+        int lo = 0;  // the last entry whose first product number is <= t
+#pragma unroll
+        for (int st = MM_WIN_BLOCK / 2; st > 0; st >>= 1)
+            if (s_scan[lo + st] <= t) lo += st;
         f(lo, s_qb[lo] + (t - s_scan[lo]));
     }
     __syncthreads();
@@ -627,6 +637,12 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const 
     const int monoid = a.monoid, mult = a.mult;
     const T *Ax = (const T *)a.Ax, *Bx = (const T *)a.Bx;
     const W ident = monoid_identity<T, W>(monoid);
+    // (an iso operand stores one value: read once, not once per product)
+    T a_iso_val = (T)0, b_iso_val = (T)0;
+    if constexpr (NUMERIC) {
+        if (a.need_a && a.a_iso) a_iso_val = Ax[0];
+        if (a.need_b && a.b_iso) b_iso_val = Bx[0];
+    }
     const int c0 = w * MM_WIN;
     const int tiu = sub * 64 + lane;  // thread inside the unit
     // the ranges of B inside the window for the first NB batches of the wavefront's entries of A: requested before anything
@@ -772,22 +788,41 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const 
                 int j;
                 W v;
             };
-            auto load_b = [&](int64_t p, int64_t q) {
-                const T av = a.need_a ? Ax[a.a_iso ? 0 : p] : (T)0;
-                const T bv = a.need_b ? Bx[a.b_iso ? 0 : q] : (T)0;
-                return Prod{a.Bj[q] - c0, (W)apply_binop<T>(mult, av, bv)};
+            // One copy of the product loop per common semiring (MU / MO = the multiply / monoid opcodes as constants, -1 = the
+            // operands of the call): with the opcodes as run-time values every product step walked two trees of scalar compares
+            // and branches (9 600 lines of ISA for this kernel, SALU instructions = half the VALU count in the PMC pass).
+            auto pass_b = [&](auto mu_c, auto mo_c) {
+                constexpr int MU = decltype(mu_c)::value, MO = decltype(mo_c)::value;
+                const int mult_ = MU >= 0 ? MU : mult, monoid_ = MO >= 0 ? MO : monoid;
+                auto load_b = [&](int64_t p, int64_t q) {
+                    T av = (T)0, bv = (T)0;
+                    if constexpr (MU != OP_PAIR) {
+                        if (a.need_a) av = a.a_iso ? a_iso_val : Ax[p];
+                        if (a.need_b) bv = a.b_iso ? b_iso_val : Bx[q];
+                    }
+                    return Prod{a.Bj[q] - c0, (W)apply_binop<T>(mult_, av, bv)};
+                };
+                auto apply_b = [&](const Prod &d) {
+                    const unsigned long long word = bits[d.j >> 6];
+                    if (MASKED && !((word >> (d.j & 63)) & 1ull)) return;
+                    const int rank = wpre[d.j >> 6] + __popcll(word & ((1ull << (d.j & 63)) - 1ull)) - r0;
+                    if ((unsigned)rank < (unsigned)CAP && !MXM_ABL(a, 4)) {
+                        if (monoid_ == OP_ANY) acc[rank] = d.v;
+                        else atomic_combine<W>(&acc[rank], d.v, monoid_);
+                        if constexpr (MASKED) atomicOr(&s_hit[uib][rank >> 6], 1ull << (rank & 63));
+                    }
+                };
+                visit(load_b, apply_b);
             };
-            auto apply_b = [&](const Prod &d) {
-                const unsigned long long word = bits[d.j >> 6];
-                if (MASKED && !((word >> (d.j & 63)) & 1ull)) return;
-                const int rank = wpre[d.j >> 6] + __popcll(word & ((1ull << (d.j & 63)) - 1ull)) - r0;
-                if ((unsigned)rank < (unsigned)CAP && !MXM_ABL(a, 4)) {
-                    if (monoid == OP_ANY) acc[rank] = d.v;
-                    else atomic_combine<W>(&acc[rank], d.v, monoid);
-                    if constexpr (MASKED) atomicOr(&s_hit[uib][rank >> 6], 1ull << (rank & 63));
-                }
-            };
-            if (!MXM_ABL(a, 8)) visit(load_b, apply_b);
+            if (!MXM_ABL(a, 8)) {
+                using std::integral_constant;
+                if (mult == OP_TIMES && monoid == OP_PLUS) pass_b(integral_constant<int, OP_TIMES>{}, integral_constant<int, OP_PLUS>{});
+                else if (mult == OP_PLUS && monoid == OP_MIN) pass_b(integral_constant<int, OP_PLUS>{}, integral_constant<int, OP_MIN>{});
+                else if (mult == OP_PAIR && monoid == OP_PLUS) pass_b(integral_constant<int, OP_PAIR>{}, integral_constant<int, OP_PLUS>{});
+                else if (mult == OP_PAIR && monoid == OP_ANY) pass_b(integral_constant<int, OP_PAIR>{}, integral_constant<int, OP_ANY>{});
+                else if (mult == OP_LAND && monoid == OP_LOR) pass_b(integral_constant<int, OP_LAND>{}, integral_constant<int, OP_LOR>{});
+                else pass_b(integral_constant<int, -1>{}, integral_constant<int, -1>{});
+            }
             usync();
             if constexpr (MASKED) {  // per mask entry: hit or not, and the value
                 T *cv = (T *)a.cap_val;
@@ -847,27 +882,45 @@ __global__ __launch_bounds__(MM_WIN_BLOCK) void k_spgemm_unit_dense(const MxmArg
     __syncthreads();
     const int64_t pbeg = r.pbeg, pend = pbeg + r.plen;
     const int c0 = w * MM_WIN;
-    for (int64_t pc = pbeg; pc < pend; pc += MM_WIN_BLOCK) {
-        const int64_t p = pc + tid;
-        int len = 0;
-        int64_t qb = 0;
-        if (p < pend) {
-            const int k = a.Aj[p];
-            const int32_t *o = a.woff + (int64_t)k * (nwin + 1) + w;
-            const int b0 = o[0], b1 = o[1];
-            qb = a.Bp[k] + b0;
-            len = b1 - b0;
+    T a_iso_val = (T)0, b_iso_val = (T)0;  // (an iso operand stores one value: read once, not once per product)
+    if (a.need_a && a.a_iso) a_iso_val = Ax[0];
+    if (a.need_b && a.b_iso) b_iso_val = Bx[0];
+    // (one copy of the loop per common semiring: see k_spgemm_unit's pass B)
+    auto run = [&](auto mu_c, auto mo_c) {
+        constexpr int MU = decltype(mu_c)::value, MO = decltype(mo_c)::value;
+        const int mult_ = MU >= 0 ? MU : mult, monoid_ = MO >= 0 ? MO : monoid;
+        for (int64_t pc = pbeg; pc < pend; pc += MM_WIN_BLOCK) {
+            const int64_t p = pc + tid;
+            int len = 0;
+            int64_t qb = 0;
+            if (p < pend) {
+                const int k = a.Aj[p];
+                const int32_t *o = a.woff + (int64_t)k * (nwin + 1) + w;
+                const int b0 = o[0], b1 = o[1];
+                qb = a.Bp[k] + b0;
+                len = b1 - b0;
+            }
+            if (!MXM_ABL(a, 8)) deal_products(len, qb, [&](int e, int64_t q) {
+                const int j = a.Bj[q] - c0;
+                if (MXM_ABL(a, 4)) return;
+                T av = (T)0, bv = (T)0;
+                if constexpr (MU != OP_PAIR) {
+                    if (a.need_a) av = a.a_iso ? a_iso_val : Ax[pc + e];
+                    if (a.need_b) bv = a.b_iso ? b_iso_val : Bx[q];
+                }
+                const W prod = (W)apply_binop<T>(mult_, av, bv);
+                if (monoid_ == OP_ANY) s_acc[j] = prod;
+                else atomic_combine<W>(&s_acc[j], prod, monoid_);
+                if (bslot < 0) atomicOr(&s_bits[j >> 6], 1ull << (j & 63));
+            });
         }
-        if (!MXM_ABL(a, 8)) deal_products(len, qb, [&](int e, int64_t q) {
-            const int j = a.Bj[q] - c0;
-            if (MXM_ABL(a, 4)) return;
-            const T av = a.need_a ? Ax[a.a_iso ? 0 : pc + e] : (T)0;
-            const T bv = a.need_b ? Bx[a.b_iso ? 0 : q] : (T)0;
-            const W prod = (W)apply_binop<T>(mult, av, bv);
-            if (monoid == OP_ANY) s_acc[j] = prod;
-            else atomic_combine<W>(&s_acc[j], prod, monoid);
-            if (bslot < 0) atomicOr(&s_bits[j >> 6], 1ull << (j & 63));
-        });
+    };
+    {
+        using std::integral_constant;
+        if (mult == OP_TIMES && monoid == OP_PLUS) run(integral_constant<int, OP_TIMES>{}, integral_constant<int, OP_PLUS>{});
+        else if (mult == OP_PLUS && monoid == OP_MIN) run(integral_constant<int, OP_PLUS>{}, integral_constant<int, OP_MIN>{});
+        else if (mult == OP_PAIR && monoid == OP_PLUS) run(integral_constant<int, OP_PAIR>{}, integral_constant<int, OP_PLUS>{});
+        else run(integral_constant<int, -1>{}, integral_constant<int, -1>{});
     }
     __syncthreads();
     // emit: thread t takes 16 columns (a quarter of word t / 4)
