@@ -577,7 +577,10 @@ struct alignas(16) UnitRec {
 };
 static_assert(sizeof(UnitRec) == 32, "UnitRec is two 16-byte loads");
 constexpr int MU_POOLS = 1024;  // sub-pools of the bitmap pool
-constexpr int MU_SMALL = 512;  // entries of a unit a single wavefront accumulates
+#ifndef GRB_MU_SMALL
+#define GRB_MU_SMALL 512
+#endif
+constexpr int MU_SMALL = GRB_MU_SMALL;  // entries of a unit a single wavefront accumulates
 
 __device__ __forceinline__ void mw_sync()
 {
