@@ -5,6 +5,8 @@ go through torch.distributed (backend "nccl" = RCCL over xGMI on GPUs, "gloo" in
   ranks exchange their w slices into the next u -- an all-gather with per-rank sizes (``allgatherv_into``; equal blocks take
   the single-collective fast path ``allgather_into``).  Slices are 64-row aligned, so values AND bit-packed presence words
   land directly in the replicated vector's HBM image, with no staging copy.
+  When few entries change from one step to the next (the tail of an SSSP or BFS run), ``allgather_delta_into`` sends the changed
+  (index, value) pairs and presence words only and falls back to the dense exchange above a changed fraction.
 * **vxm (push) / mxv with T0**: rank r owns rows [cuts[r], cuts[r+1]) of A and the matching slice of u; its product is a
   PARTIAL result over all n columns; the partials are combined with the semiring's monoid by an all-reduce
   (``allreduce_monoid``: ncclMin / ncclMax / ncclSum on the values with absent entries set to the identity, bit-or on the
@@ -101,6 +103,68 @@ def allgatherv_into(u_full, w_local, cuts, *, device="cuda", values=True, presen
     if presence:
         dev.vector_modified(u_full)
     return [w for w in works if w is not None] if async_op else None
+
+
+def allgather_delta_into(u_full, w_local, cuts, *, device="cuda", dense_above=0.125):
+    """The same exchange as ``allgatherv_into`` when little changes between steps (late SSSP / BFS iterations): rank r compares
+    its new slice w_local with what u_full still holds for its rows (the previous iterate), and the ranks exchange only the
+    changed VALUES as (index, value) pairs and the changed PRESENCE WORDS as (word index, word) pairs -- three small collectives
+    (counts, padded indices, padded payloads) instead of n / N values per rank.  When any rank has more than ``dense_above`` of its
+    slice changed, every rank takes the dense exchange (the decision is made from the gathered counts, so it is the same
+    everywhere).  Returns the number of changed values over all ranks (-1: the dense exchange ran)."""
+    import torch
+    import torch.distributed as dist
+
+    from . import device as dev
+
+    rank, world = dist.get_rank(), dist.get_world_size()
+    u_vals, u_words = dev.vector_device_views(u_full, device)
+    w_vals, w_words = dev.vector_device_views(w_local, device)
+    lo, hi = cuts[rank], cuts[rank + 1]
+    rows = hi - lo
+    nw = (rows + 31) // 32
+    as_bits = {1: torch.uint8, 2: torch.int16, 4: torch.int32, 8: torch.int64}[u_vals.element_size()]
+    old_v, new_v = u_vals[lo:hi].view(as_bits), w_vals[:rows].view(as_bits)  # (bit patterns: NaN-safe, -0.0 != 0.0 is harmless)
+    old_w, new_w = u_words[lo // 32: lo // 32 + nw], w_words[:nw]
+    vi = torch.nonzero(old_v != new_v).flatten()
+    wi = torch.nonzero(old_w != new_w).flatten()
+    counts = torch.tensor([vi.numel(), wi.numel(), rows], dtype=torch.int64, device=u_vals.device)
+    all_counts = [torch.empty_like(counts) for _ in range(world)]
+    dist.all_gather(all_counts, counts)
+    all_counts = torch.stack(all_counts).cpu()
+    if bool(((all_counts[:, 0].double() > dense_above * all_counts[:, 2].double().clamp(min=1)) & (all_counts[:, 0] > 0)).any()):
+        allgatherv_into(u_full, w_local, cuts, device=device)
+        return -1
+    mv, mw = int(all_counts[:, 0].max()), int(all_counts[:, 1].max())
+    if mv:
+        send_i = torch.zeros(mv, dtype=torch.int64, device=u_vals.device)
+        send_x = torch.zeros(mv, dtype=as_bits, device=u_vals.device)
+        send_i[: vi.numel()] = vi + lo
+        send_x[: vi.numel()] = new_v[vi]
+        got_i = [torch.empty_like(send_i) for _ in range(world)]
+        got_x = [torch.empty_like(send_x) for _ in range(world)]
+        dist.all_gather(got_i, send_i)
+        dist.all_gather(got_x, send_x)
+        flat = u_vals.view(as_bits)
+        for r in range(world):
+            c = int(all_counts[r, 0])
+            if c:
+                flat[got_i[r][:c]] = got_x[r][:c]
+    if mw:
+        send_i = torch.zeros(mw, dtype=torch.int64, device=u_words.device)
+        send_x = torch.zeros(mw, dtype=u_words.dtype, device=u_words.device)
+        send_i[: wi.numel()] = wi + lo // 32
+        send_x[: wi.numel()] = new_w[wi]
+        got_i = [torch.empty_like(send_i) for _ in range(world)]
+        got_x = [torch.empty_like(send_x) for _ in range(world)]
+        dist.all_gather(got_i, send_i)
+        dist.all_gather(got_x, send_x)
+        for r in range(world):
+            c = int(all_counts[r, 1])
+            if c:
+                u_words[got_i[r][:c]] = got_x[r][:c]
+        dev.vector_modified(u_full)
+    return int(all_counts[:, 0].sum())
 
 
 _REDUCE_OF = {"min": "MIN", "max": "MAX", "plus": "SUM", "lor": "MAX", "land": "MIN", "any": "MAX"}
