@@ -10,7 +10,7 @@ dev = sys.argv[1] if len(sys.argv) > 1 else "gpu"
 lo, hi = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (100, 140)
 gb = bind(dev)
 names = ["test_mxv_random", "test_vxm_and_transposes_random", "test_hot_column_table", "test_push_direction",
-         "test_long_short_row_split", "test_mxm_random", "test_mxm_mask_driven", "test_vector_assign_reduce_random",
+         "test_long_short_row_split", "test_mxm_random", "test_mxm_mask_driven", "test_mxm_units_random", "test_vector_assign_reduce_random",
          "test_vector_ewise_random", "test_pair_over_full_operand", "test_sell_short_rows", "test_reductions_over_split_matrices",
          "test_mixed_types_unread_operands"]
 fails = 0

@@ -1106,6 +1106,101 @@ def test_mxm_unit_classes(gb, sr, tname, pool):
     assert np.diff(P.indptr)[2] > 4096 and deg[2] * 193 <= 16384
 
 
+@pytest.mark.parametrize("seed", range(20))
+def test_mxm_units_random(gb, seed, request=None):
+    """(row, column window) units on random shapes: the columns of B drawn from a skewed window distribution (units of every
+    class: one wavefront / four wavefronts with 1024 and 4096 accumulators / an accumulator per column, several windows, empty
+    windows), rows of A from a few to thousands of entries, every type and semiring of the random tests, iso and valued
+    operands; plain, with an accumulator into an existing C, under a structural / valued mask (full product + write rule, and
+    mask-driven with the units keyed by the mask row); random class limits and bitmap-pool sizes."""
+    from graphblas_amd import _lib
+
+    on_gpu = request is None or request.node.callspec.params["gb"] == "gpu"  # (scripts/stress_parity.py calls without a request)
+    rng = np.random.default_rng(9100 + seed)
+    tname = TYPES[seed % 7]
+    srs = semirings_for(tname)
+    sr = srs[int(rng.integers(len(srs)))]
+    nwin = int(rng.integers(1, 6))
+    n = int(rng.integers((nwin - 1) * 16384 + 1, nwin * 16384 + 1))
+    k = int(rng.integers(40, 400 if on_gpu else 120))
+    m = int(rng.integers(3, 40 if on_gpu else 10))
+    # rows of B: 20 .. 600 entries, windows drawn with skewed weights (some windows get nothing)
+    wts = rng.random(nwin) ** 3
+    wts[rng.random(nwin) < 0.25] = 0
+    if wts.sum() == 0:
+        wts[0] = 1
+    wts /= wts.sum()
+    br, bc = [], []
+    for r in range(k):
+        d = int(rng.integers(20, 600 if on_gpu else 200))
+        win = rng.choice(nwin, d, p=wts)
+        cols = np.unique(np.minimum(win * 16384 + rng.integers(0, 16384, d), n - 1))
+        br.append(np.full(cols.size, r))
+        bc.append(cols)
+    br, bc = np.concatenate(br), np.concatenate(bc)
+    deg = rng.integers(0, 12, m)
+    heavy = rng.random(m) < 0.5
+    deg[heavy] = rng.integers(max(1, k // 4), k + 1, int(heavy.sum()))
+    deg = np.minimum(deg, k)
+    ar = np.repeat(np.arange(m), deg)
+    ac = np.concatenate([np.sort(rng.choice(k, d, replace=False)) for d in deg]) if deg.sum() else np.zeros(0, np.int64)
+    iso = seed % 5 == 0
+    av = rand_vals(rng, ar.size, tname)
+    bv = rand_vals(rng, br.size, tname)
+    if iso and av.size and bv.size:
+        av[:] = av[0]
+        bv[:] = bv[0]
+    oa, ob = O.OMat.from_coo(ar, ac, av, m, k, tname), O.OMat.from_coo(br, bc, bv, k, n, tname)
+    mode = seed % 4  # 0 plain, 1 accumulate into C, 2 structural mask (mask-driven), 3 valued mask + replace (full product)
+    cr, cc, cv = rand_coo(rng, m, n, tname, long_rows=1)
+    mr = np.repeat(np.arange(m), rng.integers(0, 3000 if on_gpu else 600, m))
+    mc = rng.integers(0, n, mr.size)
+    key = np.unique(mr * n + mc)
+    mr, mc = key // n, key % n
+    mv = rng.integers(0, 2, mr.size).astype(np.int8)
+    oc = O.OMat.from_coo(cr, cc, cv, m, n, tname) if mode in (1, 3) else None
+    om = O.OMat.from_coo(mr, mc, mv, m, n, "INT8")
+    accum = "plus" if mode == 1 and tname != "BOOL" else None
+    if mode == 0 or mode == 1:
+        exp = O.mxm(oa, ob, sr, C=oc, accum=accum)
+    elif mode == 2:
+        exp = O.mxm(oa, ob, sr, mask=om, mask_struct=True)
+    else:
+        exp = O.mxm(oa, ob, sr, C=oc, mask=om, mask_struct=False, replace=True)
+    opts = dict(mxm_unit_small=int(rng.choice([64, 512])), mxm_unit_mid=int(rng.choice([300, 1024])),
+                mxm_unit_dense=int(rng.choice([1500, 4096])), mxm_bitmap_pool_cap=int(rng.choice([0, 2, (1 << 31) - 1])),
+                mxm_unit_min_flops=int(rng.choice([128, 1024])), mxm_masked_units_min_flops=0, mxm_mask_mode=2 if mode == 2 else 0)
+    try:
+        for name, val in opts.items():
+            _lib.lib.GrX_option_set(name.encode(), val)
+        A = gb.Matrix.from_coo(ar, ac, av, dtype=tname, nrows=m, ncols=k)
+        B = gb.Matrix.from_coo(br, bc, bv, dtype=tname, nrows=k, ncols=n)
+        C = gb.Matrix.from_coo(cr, cc, cv, dtype=tname, nrows=m, ncols=n) if mode in (1, 3) else gb.Matrix(tname, m, n)
+        M = gb.Matrix.from_coo(mr, mc, mv, dtype="INT8", nrows=m, ncols=n)
+        if mode == 0:
+            C << A.mxm(B, getattr(gb.semiring, sr))
+        elif mode == 1:
+            if accum:
+                C(accum=getattr(gb.binary, accum)) << A.mxm(B, getattr(gb.semiring, sr))
+            else:
+                C << A.mxm(B, getattr(gb.semiring, sr))
+                exp = O.mxm(oa, ob, sr)
+        elif mode == 2:
+            C(M.S) << A.mxm(B, getattr(gb.semiring, sr))
+        else:
+            C(M.V, replace=True) << A.mxm(B, getattr(gb.semiring, sr))
+        if sr.startswith("any_") and not sr.endswith("pair"):  # (any: one of the products, not a fixed one -- the pattern is checked)
+            I, J, _ = C.to_coo()
+            er, ec, _ = exp.to_coo()
+            assert I.tolist() == er.tolist() and J.tolist() == ec.tolist()
+        else:
+            same_mat(C, exp)
+    finally:
+        for name, val in dict(mxm_unit_small=512, mxm_unit_mid=1024, mxm_unit_dense=4096, mxm_bitmap_pool_cap=(1 << 31) - 1,
+                              mxm_unit_min_flops=1024, mxm_masked_units_min_flops=64 << 20, mxm_mask_mode=1).items():
+            _lib.lib.GrX_option_set(name.encode(), val)
+
+
 @pytest.mark.parametrize("sr,tname", [("plus_times", "INT64"), ("min_plus", "FP64"), ("any_pair", "BOOL"), ("plus_pair", "UINT16")])
 def test_mxm_masked_unit_classes(gb, sr, tname):
     """C<M.S> = A (+.x) B, mask-driven, with the heavy rows walked as (row, column window) units: the bitmap of a unit is the mask
