@@ -296,6 +296,8 @@ GrB_Info GrX_Matrix_cache_bytes(const GrB_Matrix A, uint64_t *bytes);
  *   "split_min_len" a row is "long" from this many entries (default 0 = 64 for the class strips, 256 for the item kernel)
  *   "lazy_layout"   1 (default): the cached SpMV layouts of a matrix with at least "lazy_min_nnz" (4 Mi) entries are built at its
  *                   second pull product; the first one runs on the CSR arrays as they are.  0: built at the first product.
+ *   "drop_hot_cols" 1 (default): the hot-coded copy of a matrix's whole column array is released once the long / short split has
+ *                   been built from it (the split's parts carry their own re-coded columns)
  *   "long_kernel"   layout / kernel of the long rows: 3 (default) class strips, items for BOOL matrices; 2 class strips (k_mxv_strip);
  *                   1 class-partitioned items (k_mxv_long_grp); 0 chunks straight from the CSR arrays (k_mxv_long)
  *   "long_classes"  column classes of the class strips: 8, 16 (default), 32 or 64 distinct LDS heads across the chip

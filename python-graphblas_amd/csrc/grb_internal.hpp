@@ -67,6 +67,7 @@ struct Context {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int64_t vec_pad_min_bytes = 1 << 20;  // vectors with at least this many bytes of values are allocated with the front pad
     int alloc_cache = 1;    // 1: freed device blocks are kept per size class and reused without calling the HIP allocator
+    int drop_hot_cols = 1;     // release the re-coded copy of the whole column array once the long / short split is built from it
     int mxm_heavy_kernel = 1;  // SpGEMM rows beyond the LDS hash: 1 = a wavefront per row over column windows (k_spgemm_wave), 0 = the
                             // 1024-thread kernels of round 1 (k_spgemm_sym_lds / k_spgemm_win)
     int mxm_unit_small = 512, mxm_unit_mid = 1024, mxm_unit_dense = 4096;  // entry counts of a unit up to which one wavefront / four wavefronts with compact
@@ -217,6 +218,7 @@ struct GB_Matrix_opaque {
     int32_t *d_hot_cols;  // K original column indices, hottest first
     int64_t hot_k;
     int hot_state;        // 0 = not analysed, 1 = enabled, -1 = not worth it
+    bool hot_cols_dropped = false;  // d_col_hot was released after the split was built from it (ensure_split)
     // long/short row split for the pull SpMV (grb_mxv.hip): rows with >= split_min_len entries are processed by a
     // lean wavefront-per-chunk kernel straight from this matrix's arrays; the remaining rows live in `short_part`
     // (same shape, long rows empty) and go through the merge-path kernel

@@ -336,6 +336,13 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
     A->split_hot = hot;
     A->split_kind = kind;
     A->split_state = 1;
+    // the short part and the strips / items carry their own re-coded columns: the re-coded copy of the whole array is only read
+    // again by a product that cannot take the split (a typecast of the values), which falls back to the plain arrays
+    if (hot && ctx().drop_hot_cols && nc > 0 && A->long_nnz > 0 && (kind == 1 || kind == 2) && A->d_col_hot) {
+        dev_free(A->d_col_hot);
+        A->d_col_hot = nullptr;
+        A->hot_cols_dropped = true;
+    }
 }
 
 // sliced-ELLPACK copy of the short part S of A (once per matrix; see grb_mxv_sell.inc)
@@ -510,6 +517,7 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
         launch_pull_ipt<T, MON, MUL, IPT>(S, b);  // S has no split of its own: takes the plain path below
         return;
     }
+    if (!a.col && a.nnz > 0) fail(GrB_PANIC, "pull SpMV: the plain path was reached with the re-coded columns released (internal error)");
     constexpr int TILE = PULL_BLOCK * IPT;
     a.dbg = ctx().debug_flags;
     ensure_tile_table(A, TILE);
@@ -703,7 +711,10 @@ static void mxv_core(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_Binar
     S->pull_calls++;
     if ((a.need_uval || !a.u_full) && !lazy) {
         ensure_hot(S, type_size(st));
-        if (S->hot_state == 1 && (uint64_t)(u->n + S->hot_k) * type_size(st) < 0xff000000ull) {
+        // (once the split is built from the re-coded columns, the re-coded copy of the WHOLE column array is released --
+        //  1.05 GB of the 3.7 GB of layouts at scale 24: a call that cannot take the split then runs on the plain arrays)
+        const bool split_usable = S->nvals && (S->type->code == st || !need_aval) && !by_rowlen;
+        if (S->hot_state == 1 && (!S->hot_cols_dropped || split_usable) && (uint64_t)(u->n + S->hot_k) * type_size(st) < 0xff000000ull) {
             const int k = (int)S->hot_k;  // multiple of 64
             const size_t vb = type_size(st);
             char *img_val;
@@ -754,6 +765,7 @@ static void mxv_core(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_Binar
     if (S->nvals && (S->type->code == st || !need_aval) && !by_rowlen && !lazy) {
         const bool hot = (a.col == S->d_col_hot);
         ensure_split(S, a.col, hot);
+        if (hot && S->hot_cols_dropped) a.col = S->d_col_hot;  // (released when the split was built: the tag of the re-coded columns is now nullptr)
         if (S->split_state == 1 && S->split_hot == hot) {
             a.long_rows = S->d_long_rows;
             a.chunk_slot = S->d_chunk_slot;
@@ -1030,7 +1042,8 @@ extern "C" GrB_Info GrX_Matrix_cache_bytes(const GrB_Matrix A, uint64_t *bytes)
     uint64_t b = 0;
     const uint64_t vs = A->type->size;
     if (A->d_tile_row) b += 8ull * (uint64_t)(A->n_tiles + 1);
-    if (A->d_col_hot) b += 4ull * (uint64_t)A->nvals + 4ull * (uint64_t)A->hot_k;
+    if (A->d_col_hot) b += 4ull * (uint64_t)A->nvals;
+    if (A->d_hot_cols) b += 4ull * (uint64_t)A->hot_k;
     if (A->split_state == 1) {
         const GB_Matrix_opaque *S = A->short_part;
         b += 8ull * (A->nrows + 1) + 4ull * (uint64_t)S->nvals + (S->iso ? vs : vs * (uint64_t)S->nvals);

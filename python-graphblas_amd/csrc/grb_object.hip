@@ -516,6 +516,7 @@ GB_Matrix_opaque *matrix_new(GrB_Type type, uint64_t nrows, uint64_t ncols)
     A->d_hot_cols = nullptr;
     A->hot_k = 0;
     A->hot_state = 0;
+    A->hot_cols_dropped = false;
     A->short_part = nullptr;
     A->d_long_bits = nullptr;
     A->d_long_rows = nullptr;
@@ -561,6 +562,7 @@ void matrix_invalidate_caches(GB_Matrix_opaque *A)
     A->d_hot_cols = nullptr;
     A->hot_k = 0;
     A->hot_state = 0;
+    A->hot_cols_dropped = false;
     if (A->short_part) matrix_free(A->short_part);
     A->short_part = nullptr;
     dev_free(A->d_long_bits);

@@ -511,6 +511,18 @@ def test_long_short_row_split(gb, seed):
         want = forced_long if forced_long != 3 else (1 if tname == "BOOL" else 2)
         assert st["method"] == 5 or (st["long_kernel"] == want and st["long_entries"] > 0)
         same_vec(w, exp)
+        # a product that needs A's values in another type cannot take the split (whose re-coded column copy of the whole matrix
+        # was released when the split was built): it runs on the plain arrays -- and the split serves the next same-typed call
+        other = "FP64" if tname not in ("FP64", "BOOL") else "INT32"
+        u2 = gb.Vector.from_coo(ui, uv.astype(O.NP_OF[other]), dtype=other, size=n)
+        sr2 = "plus_times" if tname != "BOOL" else "plus_plus"
+        got2 = A.mxv(u2, getattr(gb.semiring, sr2)).new()
+        exp2 = O.mxv(oa, O.OVec(n, ui, uv.astype(O.NP_OF[other]), other), sr2)
+        gi2, gv2 = got2.to_coo()
+        assert gi2.tolist() == exp2.idx.tolist() and np.allclose(gv2.astype(np.float64), exp2.vals.astype(np.float64), rtol=1e-6)
+        w3 = gb.Vector.from_coo(wi, wv, dtype=tname, size=m)
+        w3(~mk.V if comp else mk.V, accum=accum, replace=bool(seed & 2)) << A.mxv(u, getattr(gb.semiring, sr))
+        same_vec(w3, exp)
         x = gb.Vector.from_coo(xi, xv, dtype=tname, size=m)
         same_vec(x.vxm(A, getattr(gb.semiring, sr)).new(), exp_t)
         # square, w aliased with u
