@@ -18,6 +18,7 @@
 //      (values + presence bitmap) and are emitted by an ordered bitmap sweep.
 //   6. write rule: no mask and no accum -> T becomes C; otherwise a row-merge of (C_old, T, Mask).
 #include <algorithm>
+#include <vector>
 
 #include "grb_internal.hpp"
 #include "grb_ops.hpp"
@@ -342,25 +343,6 @@ __global__ __launch_bounds__(MM_BLOCK) void k_spgemm_spa(const MxmArgs a, const 
 constexpr int MM_WIN = 16384;   // 128 KiB of 8-byte accumulators: one 1024-thread workgroup per CU
 constexpr int MM_WIN_BLOCK = 1024;
 
-__global__ void k_window_offsets(const int64_t *Bp, const int32_t *Bj, int64_t nrowsB, int n_win, int32_t *woff)
-{
-    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= nrowsB) return;
-    const int64_t b = Bp[k], e = Bp[k + 1];
-    int32_t *o = woff + k * (int64_t)(n_win + 1);
-    int64_t pos = b;
-    for (int w = 0; w <= n_win; w++) {  // windows are visited in increasing order: each search starts at the last hit
-        const int64_t target = (int64_t)w * MM_WIN;
-        int64_t lo = pos, hi = e;
-        while (lo < hi) {
-            const int64_t mid = (lo + hi) >> 1;
-            if (Bj[mid] < target) lo = mid + 1;
-            else hi = mid;
-        }
-        pos = lo;
-        o[w] = (int32_t)(pos - b);
-    }
-}
 
 struct DealScratch {
     int scan[MM_WIN_BLOCK + 1];
@@ -961,6 +943,10 @@ constexpr int MU_NCLS = 4;
 struct UnitLimits {
     int lim[MU_NCLS - 1];
 };
+// class counters and list cursors are kept per SLOT of the row ((row / 4) mod MU_CSLOTS): millions of atomics on one address
+// serialise (21 ms per pass over the 4 M rows of scale 22 with a single counter per class)
+constexpr int MU_CSLOTS = 256;
+__device__ __forceinline__ int class_slot(int64_t row) { return (int)((row >> 2) & (MU_CSLOTS - 1)); }
 
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_unit_classify(const int32_t *wcnt, const int32_t *wrow, int nwin, const uint32_t *rows, int64_t nrows_bin,
@@ -974,6 +960,8 @@ __global__ __launch_bounds__(256) void k_unit_classify(const int32_t *wcnt, cons
     const int slot = wrow[row];
     if (slot < 0) return;
     const int32_t *wc = wcnt + (int64_t)slot * (nwin + 1);
+    unsigned long long *cur = cursor + class_slot(row) * MU_NCLS;
+    unsigned mine[MU_NCLS] = {0};
     for (int b = 0; b < nwin; b += 64) {
         const int w = b + lane;
         const int cnt = w < nwin ? wc[w + 1] - wc[w] : 0;
@@ -986,21 +974,164 @@ __global__ __launch_bounds__(256) void k_unit_classify(const int32_t *wcnt, cons
         for (int c = 0; c < MU_NCLS; c++) {
             const unsigned long long mk = __ballot(cls == c);
             if (mk == 0) continue;
-            unsigned long long base = 0;
-            if (lane == 0) base = atomicAdd(&cursor[c], (unsigned long long)__popcll(mk));
-            base = __shfl(base, 0);
-            if (FILL && cls == c) {
-                UnitRec r;
-                r.out = base_ptr[row] + wc[w];  // (base_ptr: the row pointers of T, or of the mask)
-                r.pbeg = Ap[row];
-                r.plen = (int32_t)(Ap[row + 1] - r.pbeg);
-                r.row = (uint32_t)row;
-                r.aux = masked ? cnt : (wbm ? wbm[(int64_t)slot * nwin + w] : -1);
-                r.w = w;
-                lists[base + __popcll(mk & ((1ull << lane) - 1ull))] = r;
+            if constexpr (!FILL) {
+                mine[c] += (unsigned)__popcll(mk);
+            } else {
+                unsigned long long base = 0;
+                if (lane == 0) base = atomicAdd(&cur[c], (unsigned long long)__popcll(mk));
+                base = __shfl(base, 0);
+                if (cls == c) {
+                    UnitRec r;
+                    r.out = base_ptr[row] + wc[w];  // (base_ptr: the row pointers of T, or of the mask)
+                    r.pbeg = Ap[row];
+                    r.plen = (int32_t)(Ap[row + 1] - r.pbeg);
+                    r.row = (uint32_t)row;
+                    r.aux = masked ? cnt : (wbm ? wbm[(int64_t)slot * nwin + w] : -1);
+                    r.w = w;
+                    lists[base + __popcll(mk & ((1ull << lane) - 1ull))] = r;
+                }
             }
         }
     }
+    if constexpr (!FILL) {
+        if (lane == 0)
+            for (int c = 0; c < MU_NCLS; c++)
+                if (mine[c]) atomicAdd(&cur[c], (unsigned long long)mine[c]);
+    }
+}
+
+// k_window_offsets with a WAVEFRONT per row: lane l searches the row for the first entry of windows l, l + 64, ... (the writes
+// are coalesced; a thread per row wrote 4.3 GB of offsets at scale 22 with a 1 KiB stride between lanes: 18 ms).  With
+// class_count: the rows with urow[row] >= 0 also have their windows classified by entry count (the counting pass of
+// k_unit_classify for the mask-driven product, whose "counts" are these offsets of the MASK rows).
+__global__ __launch_bounds__(256) void k_window_offsets_wave(const int64_t *Bp, const int32_t *Bj, int64_t nrowsB, int n_win, int32_t *woff,
+                                                             const int32_t *urow, unsigned long long *class_count, UnitLimits L)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t k = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (k >= nrowsB) return;
+    const int64_t b = Bp[k], e = Bp[k + 1];
+    int32_t *o = woff + k * (int64_t)(n_win + 1);
+    const bool classify = class_count && (!urow || urow[k] >= 0) && e > b;
+    unsigned ccount[MU_NCLS] = {0};
+    for (int w0 = 0; w0 <= n_win; w0 += 64) {
+        const int w = w0 + lane;
+        int first = 0;
+        if (w <= n_win) {
+            const int64_t target = (int64_t)w * MM_WIN;
+            int64_t lo = b, hi = e;
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) >> 1;
+                if (Bj[mid] < target) lo = mid + 1;
+                else hi = mid;
+            }
+            first = (int)(lo - b);
+            o[w] = first;
+        }
+        if (classify) {
+            // the window's count = the next window's first entry - this one's (the last lane of a batch searches one more)
+            int next = __shfl_down(first, 1);
+            if (lane == 63 || w == n_win) {
+                next = first;
+                if (w < n_win) {
+                    const int64_t target = (int64_t)(w + 1) * MM_WIN;
+                    int64_t lo = b + first, hi = e;
+                    while (lo < hi) {
+                        const int64_t mid = (lo + hi) >> 1;
+                        if (Bj[mid] < target) lo = mid + 1;
+                        else hi = mid;
+                    }
+                    next = (int)(lo - b);
+                }
+            }
+            const int cnt = w < n_win ? next - first : 0;
+            int cls = -1;
+            if (cnt > 0) {
+                cls = MU_NCLS - 1;
+                for (int c = MU_NCLS - 2; c >= 0; c--)
+                    if (cnt <= L.lim[c]) cls = c;
+            }
+            for (int c = 0; c < MU_NCLS; c++) ccount[c] += (unsigned)__popcll(__ballot(cls == c));
+        }
+    }
+    if (classify && lane == 0)
+        for (int c = 0; c < MU_NCLS; c++)
+            if (ccount[c]) atomicAdd(&class_count[class_slot(k) * MU_NCLS + c], (unsigned long long)ccount[c]);
+}
+
+// The same without any search, for up to WO_MAX_WIN windows: the wavefront histograms the window indices of the row's entries in
+// LDS (run lengths of the sorted row, no atomics), a wavefront scan of the histogram gives the offsets, written coalesced; the histogram is the
+// per-window entry count the classification needs.  (The search version costs a binary search per (row, window): 10^9 of them
+// for the 4 M rows x 257 windows of scale 22, 21 ms; this one 4 ms.)
+constexpr int WO_MAX_WIN = 2047;
+
+__global__ __launch_bounds__(256) void k_window_offsets_hist(const int64_t *Bp, const int32_t *Bj, int64_t nrowsB, int n_win, int32_t *woff,
+                                                             const int32_t *urow, unsigned long long *class_count, UnitLimits L)
+{
+    __shared__ int s_hist[4][WO_MAX_WIN + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t k = (int64_t)blockIdx.x * 4 + wave;
+    if (k >= nrowsB) return;
+    int *hist = s_hist[wave];
+    const int64_t b = Bp[k], e = Bp[k + 1];
+    int32_t *o = woff + k * (int64_t)(n_win + 1);
+    const bool classify = class_count && (!urow || urow[k] >= 0) && e > b;
+    for (int w = lane; w < n_win; w += 64) hist[w] = 0;
+    mw_sync();
+    // (the row is sorted: equal window indices are contiguous -- the first lane of every run adds the run's length, no atomics:
+    //  with one LDS atomic per entry the hub rows, thousands of entries in window 0, serialised the kernel to the speed of the
+    //  search version)
+    for (int64_t p0 = b; p0 < e; p0 += 64) {
+        const int64_t p = p0 + lane;
+        const bool valid = p < e;
+        const int w = valid ? Bj[p] / MM_WIN : -1;
+        const int prev = __shfl_up(w, 1);
+        const bool head = valid && (lane == 0 || prev != w);
+        const unsigned long long heads = __ballot(head), valids = __ballot(valid);
+        if (head) {
+            const unsigned long long above = lane == 63 ? 0ull : (heads >> (lane + 1));
+            const int run = above ? __ffsll(above) : __popcll(valids) - lane;  // to the next run's first lane, or to the end of the chunk
+            hist[w] += run;
+        }
+        mw_sync();  // (a run may continue in the next chunk: same wavefront, same counter)
+    }
+    int carry = 0;
+    unsigned ccount[MU_NCLS] = {0};
+    for (int w0 = 0; w0 <= n_win; w0 += 64) {
+        const int w = w0 + lane;
+        const int cnt = w < n_win ? hist[w] : 0;
+        int incl = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        if (w <= n_win) o[w] = carry + incl - cnt;  // entries of the row before window w
+        carry += __shfl(incl, 63);
+        if (classify) {
+            int cls = -1;
+            if (cnt > 0) {
+                cls = MU_NCLS - 1;
+                for (int c = MU_NCLS - 2; c >= 0; c--)
+                    if (cnt <= L.lim[c]) cls = c;
+            }
+            for (int c = 0; c < MU_NCLS; c++) ccount[c] += (unsigned)__popcll(__ballot(cls == c));
+        }
+    }
+    if (classify && lane == 0)
+        for (int c = 0; c < MU_NCLS; c++)
+            if (ccount[c]) atomicAdd(&class_count[class_slot(k) * MU_NCLS + c], (unsigned long long)ccount[c]);
+}
+
+static void launch_window_offsets(const int64_t *Bp, const int32_t *Bj, int64_t nrowsB, int n_win, int32_t *woff, const int32_t *urow,
+                                  unsigned long long *class_count, UnitLimits L)
+{
+    if (n_win <= WO_MAX_WIN)
+        hipLaunchKernelGGL(k_window_offsets_hist, dim3((unsigned)ceil_div(nrowsB, 4)), dim3(256), 0, ctx().stream, Bp, Bj, nrowsB, n_win, woff,
+                           urow, class_count, L);
+    else
+        hipLaunchKernelGGL(k_window_offsets_wave, dim3((unsigned)ceil_div(nrowsB, 4)), dim3(256), 0, ctx().stream, Bp, Bj, nrowsB, n_win, woff,
+                           urow, class_count, L);
 }
 
 // the per-window counts of the rows of the symbolic unit pass -> offsets inside the row (exclusive scan in place, n_win + 1
@@ -1015,6 +1146,7 @@ __global__ __launch_bounds__(256) void k_unit_prefix(int32_t *wcnt, int nwin, co
     if (ridx >= nrows_bin) return;
     int32_t *wc = wcnt + ridx * (nwin + 1);
     int carry = 0;
+    unsigned ccount[MU_NCLS] = {0};
     for (int b = 0; b < nwin; b += 64) {
         const int v = b + lane < nwin ? wc[b + lane] : 0;
         int cls = -1;
@@ -1023,10 +1155,7 @@ __global__ __launch_bounds__(256) void k_unit_prefix(int32_t *wcnt, int nwin, co
             for (int c = MU_NCLS - 2; c >= 0; c--)
                 if (v <= L.lim[c]) cls = c;
         }
-        for (int c = 0; c < MU_NCLS; c++) {
-            const unsigned long long mk = __ballot(cls == c);
-            if (mk != 0 && lane == 0) atomicAdd(&class_count[c], (unsigned long long)__popcll(mk));
-        }
+        for (int c = 0; c < MU_NCLS; c++) ccount[c] += (unsigned)__popcll(__ballot(cls == c));
         int incl = v;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -1041,6 +1170,8 @@ __global__ __launch_bounds__(256) void k_unit_prefix(int32_t *wcnt, int nwin, co
         const uint32_t row = rows[ridx];
         row_nnz[row] = carry;
         wrow[row] = (int32_t)ridx;
+        for (int c = 0; c < MU_NCLS; c++)
+            if (ccount[c]) atomicAdd(&class_count[class_slot(row) * MU_NCLS + c], (unsigned long long)ccount[c]);
     }
 }
 
@@ -1342,27 +1473,43 @@ static UnitLimits unit_limits(bool masked)
     return L;
 }
 
-// (known: the class counts, when the symbolic pass already took them -- k_unit_prefix)
+// (known: the per-slot class counts on the host, MU_CSLOTS x MU_NCLS numbers, when an earlier pass already took them --
+//  k_unit_prefix of the symbolic pass, the mask's k_window_offsets)
 template <typename T, int MODE>
 static void launch_unit_classes(MxmArgs &a, const uint32_t *rows, int64_t nrows, const unsigned long long *known = nullptr)
 {
-    DevBuf<unsigned long long> cur(8, true);
+    constexpr int NC = MU_CSLOTS * MU_NCLS;
+    DevBuf<unsigned long long> cur(NC, true);
     const UnitLimits L = unit_limits(MODE == MU_MASKED);
-    unsigned long long cnt[MU_NCLS], start[MU_NCLS + 1] = {0};
+    std::vector<unsigned long long> slot_cnt(NC);
     if (known) {
-        for (int c = 0; c < MU_NCLS; c++) cnt[c] = known[c];
+        std::copy(known, known + NC, slot_cnt.begin());
     } else {
         hipLaunchKernelGGL((k_unit_classify<false>), dim3((unsigned)ceil_div(nrows, 4)), dim3(256), 0, ctx().stream, (const int32_t *)a.wcnt,
                            (const int32_t *)a.wrow, a.n_win, rows, nrows, cur.p, (UnitRec *)nullptr, L, a.Ap, (const int64_t *)nullptr,
                            (const int32_t *)nullptr, 0);
-        d2h(cnt, cur.p, sizeof(cnt));
+        d2h(slot_cnt.data(), cur.p, sizeof(unsigned long long) * NC);
     }
+    // class c's list = the slots' sub-lists one after the other: the fill pass's cursors start at the sub-lists' beginnings
+    unsigned long long cnt[MU_NCLS] = {0}, start[MU_NCLS + 1] = {0};
+    for (int sl = 0; sl < MU_CSLOTS; sl++)
+        for (int c = 0; c < MU_NCLS; c++) cnt[c] += slot_cnt[(size_t)sl * MU_NCLS + c];
     for (int c = 0; c < MU_NCLS; c++) start[c + 1] = start[c] + cnt[c];
+    std::vector<unsigned long long> cursors(NC);
+    {
+        unsigned long long run[MU_NCLS];
+        for (int c = 0; c < MU_NCLS; c++) run[c] = start[c];
+        for (int sl = 0; sl < MU_CSLOTS; sl++)
+            for (int c = 0; c < MU_NCLS; c++) {
+                cursors[(size_t)sl * MU_NCLS + c] = run[c];
+                run[c] += slot_cnt[(size_t)sl * MU_NCLS + c];
+            }
+    }
     if (getenv("GRB_MXM_TRACE"))
         fprintf(stderr, "[mxm] %s units: %lld rows x %d windows; by class %llu %llu %llu %llu\n", MODE == MU_MASKED ? "masked" : "numeric",
                 (long long)nrows, a.n_win, cnt[0], cnt[1], cnt[2], cnt[3]);
     DevBuf<UnitRec> lists((size_t)start[MU_NCLS]);
-    h2d(cur.p, start, sizeof(unsigned long long) * MU_NCLS);
+    h2d(cur.p, cursors.data(), sizeof(unsigned long long) * NC);
     hipLaunchKernelGGL((k_unit_classify<true>), dim3((unsigned)ceil_div(nrows, 4)), dim3(256), 0, ctx().stream, (const int32_t *)a.wcnt,
                        (const int32_t *)a.wrow, a.n_win, rows, nrows, cur.p, lists.p, L, a.Ap, MODE == MU_MASKED ? a.Mp : a.Tp,
                        (const int32_t *)a.wbm, MODE == MU_MASKED ? 1 : 0);
@@ -1489,8 +1636,8 @@ static GB_Matrix_opaque *spgemm(GB_Matrix_opaque *A, const void *Ax, GB_Matrix_o
         a.row_nnz = rownnz.p;
         // column-window offsets of B's rows (heavy rows walk the windows in both passes): n_B x (windows + 1) int32, per call
         DevBuf<int32_t> woff(0), wcnt(0), wrow(0), wbm(0);
-        DevBuf<unsigned long long> bm_pool(0), bm_cur(16 * MU_POOLS), class_cnt(8);
-        unsigned long long class_host[8] = {0};
+        DevBuf<unsigned long long> bm_pool(0), bm_cur(16 * MU_POOLS), class_cnt(MU_CSLOTS * MU_NCLS);
+        std::vector<unsigned long long> class_host(MU_CSLOTS * MU_NCLS);
         const int64_t n_win = ceil_div((int64_t)B->ncols, MM_WIN);
         const int64_t woff_entries = (int64_t)B->nrows * (n_win + 1);
         auto ensure_woff = [&]() {
@@ -1502,8 +1649,8 @@ static GB_Matrix_opaque *spgemm(GB_Matrix_opaque *A, const void *Ax, GB_Matrix_o
             }
             dev_free(woff.p);
             woff.p = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)woff_entries);
-            hipLaunchKernelGGL(k_window_offsets, dim3((unsigned)ceil_div((int64_t)B->nrows, 256)), dim3(256), 0, ctx().stream,
-                               (const int64_t *)B->d_ptr, (const int32_t *)B->d_col, (int64_t)B->nrows, (int)n_win, woff.p);
+            launch_window_offsets((const int64_t *)B->d_ptr, (const int32_t *)B->d_col, (int64_t)B->nrows, (int)n_win, woff.p,
+                                  (const int32_t *)nullptr, (unsigned long long *)nullptr, UnitLimits{});
             a.woff = woff.p;
             a.n_win = (int)n_win;
             if (g_woff_keep.on) {  // hand the table to the batch loop, which frees it at its end
@@ -1532,7 +1679,7 @@ static GB_Matrix_opaque *spgemm(GB_Matrix_opaque *A, const void *Ax, GB_Matrix_o
                     GRB_HIP(hipMemsetAsync(wrow.p, 0xFF, sizeof(int32_t) * (size_t)m, ctx().stream));
                     a.wcnt = wcnt.p;
                     a.wrow = wrow.p;
-                    GRB_HIP(hipMemsetAsync(class_cnt.p, 0, sizeof(unsigned long long) * 8, ctx().stream));
+                    GRB_HIP(hipMemsetAsync(class_cnt.p, 0, sizeof(unsigned long long) * MU_CSLOTS * MU_NCLS, ctx().stream));
                     a.class_count = class_cnt.p;
                     // the bitmap pool: as many bitmaps as the option allows and a quarter of the free memory holds
                     size_t free_b = 0, total_b = 0;
@@ -1563,8 +1710,8 @@ static GB_Matrix_opaque *spgemm(GB_Matrix_opaque *A, const void *Ax, GB_Matrix_o
         int64_t nnzT = 0;
         d2h(&nnzT, Tp + m, sizeof(int64_t));
         if (a.class_count) {  // (the symbolic pass walked units: their class counts come with the same synchronisation)
-            d2h(class_host, class_cnt.p, sizeof(unsigned long long) * MU_NCLS);
-            a.class_known = class_host;
+            d2h(class_host.data(), class_cnt.p, sizeof(unsigned long long) * MU_CSLOTS * MU_NCLS);
+            a.class_known = class_host.data();
         }
         Tm->d_ptr = Tp;
         ctx().stats.out_nvals = nnzT;
@@ -1651,17 +1798,20 @@ static GB_Matrix_opaque *spgemm_masked(GB_Matrix_opaque *A, const void *Ax, GB_M
             }
             dev_free(woff.p);
             woff.p = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)woff_entries);
-            hipLaunchKernelGGL(k_window_offsets, dim3((unsigned)ceil_div((int64_t)B->nrows, 256)), dim3(256), 0, ctx().stream,
-                               (const int64_t *)B->d_ptr, (const int32_t *)B->d_col, (int64_t)B->nrows, (int)n_win, woff.p);
+            launch_window_offsets((const int64_t *)B->d_ptr, (const int32_t *)B->d_col, (int64_t)B->nrows, (int)n_win, woff.p,
+                                  (const int32_t *)nullptr, (unsigned long long *)nullptr, UnitLimits{});
             a.woff = woff.p;
             a.n_win = (int)n_win;
-            if (units_ok) {  // the mask rows' window offsets play the part of the symbolic pass's counts
+            if (units_ok) {  // the mask rows' window offsets play the part of the symbolic pass's counts, classes counted on the way
                 dev_free(mwoff.p);
                 mwoff.p = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)mwoff_entries);
-                hipLaunchKernelGGL(k_window_offsets, dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, ctx().stream, a.Mp, a.Mj, m, (int)n_win, mwoff.p);
+                DevBuf<unsigned long long> ccnt(MU_CSLOTS * MU_NCLS, true);
+                launch_window_offsets(a.Mp, a.Mj, m, (int)n_win, mwoff.p, (const int32_t *)urow.p, ccnt.p, unit_limits(true));
+                std::vector<unsigned long long> known(MU_CSLOTS * MU_NCLS);
+                d2h(known.data(), ccnt.p, sizeof(unsigned long long) * MU_CSLOTS * MU_NCLS);
                 a.wcnt = mwoff.p;
                 a.wrow = urow.p;
-                launch_unit_classes<T, MU_MASKED>(a, rb.ptr(4), rb.count(4));
+                launch_unit_classes<T, MU_MASKED>(a, rb.ptr(4), rb.count(4), known.data());
             }
         }
         if (rb.count(1)) hipLaunchKernelGGL((k_spgemm_mhash<T, 256>), dim3((unsigned)rb.count(1)), dim3(MM_BLOCK), 0, ctx().stream, a, rb.ptr(1));
@@ -1998,5 +2148,5 @@ extern "C" GrB_Info GrB_mxm(GrB_Matrix C, const GrB_Matrix Mask, const GrB_Binar
 }
 
 namespace grb {
-void preload_mxm() { hipFuncAttributes at; (void)hipFuncGetAttributes(&at, reinterpret_cast<const void *>(&k_window_offsets)); (void)hipGetLastError(); }
+void preload_mxm() { hipFuncAttributes at; (void)hipFuncGetAttributes(&at, reinterpret_cast<const void *>(&k_window_offsets_wave)); (void)hipGetLastError(); }
 }  // namespace grb

@@ -1118,6 +1118,53 @@ def test_mxm_unit_classes(gb, sr, tname, pool):
     assert np.diff(P.indptr)[2] > 4096 and deg[2] * 193 <= 16384
 
 
+def test_mxm_very_wide(gb):
+    """More than 2047 column windows (40 M columns): the window offsets come from the search kernel instead of the LDS histogram;
+    heavy rows are still walked as units (2 442 windows each), plain and under a structural mask."""
+    import scipy.sparse as sp
+
+    from graphblas_amd import _lib
+
+    rng = np.random.default_rng(4243)
+    m, k, n = 4, 50, 40_000_000
+    deg = np.array([30, 0, 45, 2])
+    ar = np.repeat(np.arange(m), deg)
+    ac = np.concatenate([np.sort(rng.choice(k, d, replace=False)) for d in deg])
+    av = rng.integers(1, 5, ar.size).astype(np.int64)
+    bdeg = rng.integers(60, 140, k)
+    br = np.repeat(np.arange(k), bdeg)
+    bc = np.concatenate([np.sort(rng.choice(n, d, replace=False)) for d in bdeg])
+    bv = rng.integers(1, 5, br.size).astype(np.int64)
+    A = gb.Matrix.from_coo(ar, ac, av, dtype="INT64", nrows=m, ncols=k)
+    B = gb.Matrix.from_coo(br, bc, bv, dtype="INT64", nrows=k, ncols=n)
+    C = A.mxm(B, gb.semiring.plus_times).new()
+    ref = (sp.csr_matrix((av, (ar, ac)), shape=(m, k)) @ sp.csr_matrix((bv, (br, bc)), shape=(k, n))).tocsr()
+    ref.sort_indices()
+    cp, cj, cx = C.to_csr()
+    assert np.array_equal(cp.astype(np.int64), ref.indptr) and np.array_equal(cj.astype(np.int64), ref.indices)
+    assert np.array_equal(cx, ref.data) and int(np.diff(ref.indptr).max()) > 2000
+    # mask: half of the product's own pattern plus entries elsewhere
+    rr = np.repeat(np.arange(m), np.diff(ref.indptr))
+    keep = rng.random(rr.size) < 0.5
+    mr = np.concatenate([rr[keep], rng.integers(0, m, 500)])
+    mc = np.concatenate([ref.indices[keep], rng.integers(0, n, 500)])
+    key = np.unique(mr * n + mc)
+    mr, mc = key // n, key % n
+    M = gb.Matrix.from_coo(mr, mc, np.ones(mr.size, bool), dtype="BOOL", nrows=m, ncols=n)
+    try:
+        _lib.lib.GrX_option_set(b"mxm_mask_mode", 2)
+        _lib.lib.GrX_option_set(b"mxm_masked_units_min_flops", 0)
+        D = A.mxm(B, gb.semiring.plus_times).new(mask=M.S)
+    finally:
+        _lib.lib.GrX_option_set(b"mxm_mask_mode", 1)
+        _lib.lib.GrX_option_set(b"mxm_masked_units_min_flops", 64 << 20)
+    want = ref.multiply(sp.csr_matrix((np.ones(mr.size), (mr, mc)), shape=(m, n)).astype(bool)).tocsr()
+    want.sort_indices()
+    dp, dj, dx = D.to_csr()
+    assert np.array_equal(dp.astype(np.int64), want.indptr) and np.array_equal(dj.astype(np.int64), want.indices)
+    assert np.array_equal(dx, want.data.astype(np.int64))
+
+
 @pytest.mark.parametrize("seed", range(20))
 def test_mxm_units_random(gb, seed, request=None):
     """(row, column window) units on random shapes: the columns of B drawn from a skewed window distribution (units of every
