@@ -309,7 +309,8 @@ GrB_Info GrX_Matrix_cache_bytes(const GrB_Matrix A, uint64_t *bytes);
  *                   0 never, 2 always
  *   "mxm_heavy_kernel"  SpGEMM rows beyond the LDS hash tables: 1 (default) (row, column window) work units (k_spgemm_unit),
  *                   0 the 1024-thread row kernels of round 1
- *   "mxm_unit_min_flops"  rows with more products than this (default 1024; and than 32 per column window) are walked as units
+ *   "mxm_unit_min_flops" / "mxm_unit_min_per_window"  rows with more products than this (1024) and than this many per column window
+ *                   (16), at most 4096, are walked as units
  *   "mxm_unit_small" / "mxm_unit_mid" / "mxm_unit_dense"  entry counts of a unit up to which one wavefront with 512 accumulators /
  *                   four wavefronts with 1024 / with 4096 accumulators take it (512, 1024, 4096); denser units get an
  *                   accumulator per column of the window

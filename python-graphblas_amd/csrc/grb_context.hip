@@ -205,6 +205,7 @@ extern "C" GrB_Info GrB_init(GrB_Mode mode)
     if (const char *e = getenv("GRB_MXM_HEAVY_KERNEL")) c.mxm_heavy_kernel = atoi(e);
     if (const char *e = getenv("GRB_DROP_HOT_COLS")) c.drop_hot_cols = atoi(e);
     if (const char *e = getenv("GRB_MXM_UNIT_MIN_FLOPS")) c.mxm_unit_min_flops = atoll(e);
+    if (const char *e = getenv("GRB_MXM_UNIT_MIN_PER_WINDOW")) c.mxm_unit_min_per_window = atoll(e);
     if (const char *e = getenv("GRB_MXM_UNIT_SMALL")) c.mxm_unit_small = atoi(e);
     if (const char *e = getenv("GRB_MXM_UNIT_DENSE")) c.mxm_unit_dense = atoi(e);
     if (const char *e = getenv("GRB_MXM_UNIT_MID")) c.mxm_unit_mid = atoi(e);
@@ -310,6 +311,7 @@ extern "C" GrB_Info GrX_option_set(const char *name, int64_t value)
     else if (n == "mxm_heavy_kernel") c.mxm_heavy_kernel = (int)value;
     else if (n == "drop_hot_cols") c.drop_hot_cols = (int)value;
     else if (n == "mxm_unit_min_flops") c.mxm_unit_min_flops = value;
+    else if (n == "mxm_unit_min_per_window") c.mxm_unit_min_per_window = value;
     else if (n == "mxm_masked_units_min_flops") c.mxm_masked_units_min_flops = value;
     else if (n == "mxm_unit_small") c.mxm_unit_small = (int)value;
     else if (n == "mxm_unit_dense") c.mxm_unit_dense = (int)value;

@@ -73,6 +73,7 @@ struct Context {
     int mxm_unit_small = 512, mxm_unit_mid = 1024, mxm_unit_dense = 4096;  // entry counts of a unit up to which one wavefront / four wavefronts with compact
                                                       // accumulators take it; denser units get an accumulator per column
     int64_t mxm_unit_min_flops = 1024;
+    int64_t mxm_unit_min_per_window = 16;  // ... and than this many per column window
     int64_t mxm_masked_units_min_flops = 64ll << 20;  // mask-driven products below this many multiplies keep the row kernels
     int64_t mxm_bitmap_pool_cap = INT32_MAX;  // ... and at most this many bitmaps (tests: a pool that runs out)
     int64_t mxm_bitmap_pool_mb = 16384;  // bitmaps of the denser units kept from the symbolic for the numeric pass: at most this much  // rows with more products than this (and than 32 per window) are walked as units

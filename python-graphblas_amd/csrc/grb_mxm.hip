@@ -1666,7 +1666,7 @@ static GB_Matrix_opaque *spgemm(GB_Matrix_opaque *A, const void *Ax, GB_Matrix_o
                                   n_win < 65536;
             // (never above 4096: a row the hash kernels count must fit the numeric hash table, nnz <= flops <= 4096 -- or it falls to the
             //  1024-thread window walk, a quarter of the scale-22 run while the limit was 32 x 256 windows = 8192)
-            const int64_t sym_b3 = units_ok ? std::min<int64_t>(4096, std::max<int64_t>(ctx().mxm_unit_min_flops, 32 * n_win)) : 16384;
+            const int64_t sym_b3 = units_ok ? std::min<int64_t>(4096, std::max<int64_t>(ctx().mxm_unit_min_flops, ctx().mxm_unit_min_per_window * n_win)) : 16384;
             make_bins(rb, A->d_ptr, F.p, m, rownnz.p, 128, 1024, sym_b3);
             GRB_HIP(hipMemsetAsync(rownnz.p, 0, sizeof(int64_t) * (m + 1), ctx().stream));
             if (rb.count(4) && units_ok && rb.count(4) * (n_win + 1) * 4 <= (8ll << 30)) {
@@ -1785,7 +1785,7 @@ static GB_Matrix_opaque *spgemm_masked(GB_Matrix_opaque *A, const void *Ax, GB_M
             hipLaunchKernelGGL(k_nnz_flops, dim3((unsigned)ceil_div(nnzA + 1, 256)), dim3(256), 0, ctx().stream, A->d_col, nnzA, B->d_ptr, F.p);
             prim_exclusive_sum_i64(F.p, F.p, nnzA + 1);
             hipLaunchKernelGGL(k_mask_unit_rows, dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, ctx().stream, (const int64_t *)A->d_ptr,
-                               (const int64_t *)F.p, a.Mp, m, std::max<int64_t>(ctx().mxm_unit_min_flops, 32 * n_win), urow.p);
+                               (const int64_t *)F.p, a.Mp, m, std::max<int64_t>(ctx().mxm_unit_min_flops, ctx().mxm_unit_min_per_window * n_win), urow.p);
             sync_stream();  // (F is freed at the end of this scope)
         }
         RowBins rb(m);
