@@ -681,17 +681,19 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const 
             sqb[lane] = qb - (incl - len);  // (product t of the batch is entry sqb[e] + t of B, e = the lane that brought it)
             mw_sync();
             for (int t0 = lane; t0 < total; t0 += 64 * MU_ILP) {
+                // MU_ILP products per lane: their searches interleave and their loads are issued back to back -- every product
+                // number is clamped into the batch instead of being guarded by a branch (a guarded load was waited for inside its
+                // branch: one memory round trip per product instead of one per MU_ILP), and `load` only loads: whatever depends on
+                // the loaded values happens in `apply`
                 decltype(load((int64_t)0, (int64_t)0)) d[MU_ILP];
 #pragma unroll
                 for (int u = 0; u < MU_ILP; u++) {
-                    const int t = t0 + 64 * u;
-                    if (t < total) {
-                        int lo = 0;  // the last entry whose first product number is <= t (scan[0] = 0 <= t): six steps, three VALU each
+                    const int t = t0 + 64 * u < total ? t0 + 64 * u : total - 1;
+                    int lo = 0;  // the last entry whose first product number is <= t (scan[0] = 0 <= t): six steps, three VALU each
 #pragma unroll
-                        for (int s = 32; s > 0; s >>= 1)
-                            if (scan[lo + s] <= t) lo += s;
-                        d[u] = load(pc + (int64_t)lo * WPU, sqb[lo] + t);
-                    }
+                    for (int s = 32; s > 0; s >>= 1)
+                        if (scan[lo + s] <= t) lo += s;
+                    d[u] = load(pc + (int64_t)lo * WPU, sqb[lo] + t);
                 }
 #pragma unroll
                 for (int u = 0; u < MU_ILP; u++)
@@ -716,7 +718,11 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const 
     };
     // ---- pass A: which columns of the window does the row reach
     if (!MASKED && bslot < 0 && !(NUMERIC && MXM_ABL(a, 16)))
-        visit([&](int64_t, int64_t q) { return a.Bj[q] - c0; }, [&](int j) { atomicOr(&bits[j >> 6], 1ull << (j & 63)); });
+        visit([&](int64_t, int64_t q) { return a.Bj[q]; },
+              [&](int jraw) {
+                  const int j = jraw - c0;
+                  atomicOr(&bits[j >> 6], 1ull << (j & 63));
+              });
     usync();
     // ---- counts: lane l looks at words 4 l .. 4 l + 3 (every wavefront of the unit computes the same numbers)
     unsigned long long mine[WPL];
@@ -769,9 +775,9 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const 
             if constexpr (MASKED)
                 for (int i = tiu; i < (CAP + 63) / 64; i += 64 * WPU) s_hit[uib][i] = 0ull;
             usync();
-            struct Prod {
+            struct Prod {  // what a product loads: the column of B's entry and the two values (the arithmetic waits until `apply`)
                 int j;
-                W v;
+                T av, bv;
             };
             // One copy of the product loop per common semiring (MU / MO = the multiply / monoid opcodes as constants, -1 = the
             // operands of the call): with the opcodes as run-time values every product step walked two trees of scalar compares
@@ -780,20 +786,25 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const 
                 constexpr int MU = decltype(mu_c)::value, MO = decltype(mo_c)::value;
                 const int mult_ = MU >= 0 ? MU : mult, monoid_ = MO >= 0 ? MO : monoid;
                 auto load_b = [&](int64_t p, int64_t q) {
-                    T av = (T)0, bv = (T)0;
+                    Prod r;
+                    r.j = a.Bj[q];
+                    r.av = (T)0;
+                    r.bv = (T)0;
                     if constexpr (MU != OP_PAIR) {
-                        if (a.need_a) av = a.a_iso ? a_iso_val : Ax[p];
-                        if (a.need_b) bv = a.b_iso ? b_iso_val : Bx[q];
+                        if (a.need_a) r.av = a.a_iso ? a_iso_val : Ax[p];
+                        if (a.need_b) r.bv = a.b_iso ? b_iso_val : Bx[q];
                     }
-                    return Prod{a.Bj[q] - c0, (W)apply_binop<T>(mult_, av, bv)};
+                    return r;
                 };
                 auto apply_b = [&](const Prod &d) {
-                    const unsigned long long word = bits[d.j >> 6];
-                    if (MASKED && !((word >> (d.j & 63)) & 1ull)) return;
-                    const int rank = wpre[d.j >> 6] + __popcll(word & ((1ull << (d.j & 63)) - 1ull)) - r0;
+                    const int j = d.j - c0;
+                    const unsigned long long word = bits[j >> 6];
+                    if (MASKED && !((word >> (j & 63)) & 1ull)) return;
+                    const int rank = wpre[j >> 6] + __popcll(word & ((1ull << (j & 63)) - 1ull)) - r0;
                     if ((unsigned)rank < (unsigned)CAP && !MXM_ABL(a, 4)) {
-                        if (monoid_ == OP_ANY) acc[rank] = d.v;
-                        else atomic_combine<W>(&acc[rank], d.v, monoid_);
+                        const W v = (W)apply_binop<T>(mult_, d.av, d.bv);
+                        if (monoid_ == OP_ANY) acc[rank] = v;
+                        else atomic_combine<W>(&acc[rank], v, monoid_);
                         if constexpr (MASKED) atomicOr(&s_hit[uib][rank >> 6], 1ull << (rank & 63));
                     }
                 };
