@@ -399,6 +399,51 @@ __device__ __forceinline__ void deal_products(int len, int64_t qb, F &&f)
     __syncthreads();
 }
 
+// the same with the products' loads and their use apart: d = load(e, q) for DP_ILP products of a thread back to back (product
+// numbers clamped into the batch instead of guarded: no branch holds a load's wait), then apply(d).  Every thread must call.
+constexpr int DP_ILP = 4;
+template <typename FL, typename FA>
+__device__ __forceinline__ void deal_products_2(int len, int64_t qb, FL &&load, FA &&apply)
+{
+    DealScratch &sc = deal_scratch();
+    int *s_scan = sc.scan;
+    int64_t *s_qb = sc.qb;
+    int *s_wsum = sc.wsum;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int incl = len;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) s_wsum[wv] = incl;
+    __syncthreads();
+    int wave_off = 0, total = 0;
+    for (int x = 0; x < MM_WIN_BLOCK / 64; x++) {
+        if (x < wv) wave_off += s_wsum[x];
+        total += s_wsum[x];
+    }
+    s_scan[tid] = wave_off + incl - len;
+    s_qb[tid] = qb - (wave_off + incl - len);  // (product t of the batch is entry s_qb[e] + t of B)
+    __syncthreads();
+    for (int t0 = tid; t0 < total; t0 += MM_WIN_BLOCK * DP_ILP) {
+        decltype(load(0, (int64_t)0)) d[DP_ILP];
+#pragma unroll
+        for (int u = 0; u < DP_ILP; u++) {
+            const int t = t0 + MM_WIN_BLOCK * u < total ? t0 + MM_WIN_BLOCK * u : total - 1;
+            int lo = 0;  // the last entry whose first product number is <= t
+#pragma unroll
+            for (int st = MM_WIN_BLOCK / 2; st > 0; st >>= 1)
+                if (s_scan[lo + st] <= t) lo += st;
+            d[u] = load(lo, s_qb[lo] + t);
+        }
+#pragma unroll
+        for (int u = 0; u < DP_ILP; u++)
+            if (t0 + MM_WIN_BLOCK * u < total) apply(d[u]);
+    }
+    __syncthreads();
+}
+
 // Walks the column windows of one row with a 1024-thread workgroup; body(w, visit) is called once per window (uniformly),
 // and visit(f) delivers the window's products to f(p, q) (p = position of A(row,k), q = position of B(k,j)).  The part of
 // B(k,:) inside window w is [woff[k][w], woff[k][w+1]).  Rows with at most 1024 entries (all but the hubs) keep one entry
@@ -634,16 +679,15 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const 
     // else (two dependent round trips that overlap the bitmap load / clear and the accumulator fill), kept for every pass
     int c_len[NB];
     int64_t c_qb[NB];
+    // (unguarded: an entry past the row's end re-reads the last one and brings length 0 -- a guarded chain of loads is waited
+    //  for inside its branch, and the NB chains below would run one after the other)
     auto fetch = [&](int64_t p, int &len, int64_t &qb) {
-        len = 0;
-        qb = 0;
-        if (p < pend) {
-            const int k = a.Aj[p];
-            const int32_t *o = a.woff + (int64_t)k * (nwin + 1) + w;
-            const int o0 = o[0], o1 = o[1];
-            qb = a.Bp[k] + o0;
-            len = o1 - o0;
-        }
+        const bool ok = p < pend;
+        const int k = a.Aj[ok ? p : pend - 1];
+        const int32_t *o = a.woff + (int64_t)k * (nwin + 1) + w;
+        const int o0 = o[0], o1 = o[1];
+        qb = a.Bp[k] + o0;
+        len = ok ? o1 - o0 : 0;
     };
 #pragma unroll
     for (int b = 0; b < NB; b++) fetch(pbeg + sub + (int64_t)b * 64 * WPU + (int64_t)lane * WPU, c_len[b], c_qb[b]);
@@ -896,19 +940,32 @@ __global__ __launch_bounds__(MM_WIN_BLOCK) void k_spgemm_unit_dense(const MxmArg
                 qb = a.Bp[k] + b0;
                 len = b1 - b0;
             }
-            if (!MXM_ABL(a, 8)) deal_products(len, qb, [&](int e, int64_t q) {
-                const int j = a.Bj[q] - c0;
-                if (MXM_ABL(a, 4)) return;
-                T av = (T)0, bv = (T)0;
-                if constexpr (MU != OP_PAIR) {
-                    if (a.need_a) av = a.a_iso ? a_iso_val : Ax[pc + e];
-                    if (a.need_b) bv = a.b_iso ? b_iso_val : Bx[q];
-                }
-                const W prod = (W)apply_binop<T>(mult_, av, bv);
-                if (monoid_ == OP_ANY) s_acc[j] = prod;
-                else atomic_combine<W>(&s_acc[j], prod, monoid_);
-                if (bslot < 0) atomicOr(&s_bits[j >> 6], 1ull << (j & 63));
-            });
+            struct Prod {
+                int j;
+                T av, bv;
+            };
+            if (!MXM_ABL(a, 8))
+                deal_products_2(
+                    len, qb,
+                    [&](int e, int64_t q) {
+                        Prod r;
+                        r.j = a.Bj[q];
+                        r.av = (T)0;
+                        r.bv = (T)0;
+                        if constexpr (MU != OP_PAIR) {
+                            if (a.need_a) r.av = a.a_iso ? a_iso_val : Ax[pc + e];
+                            if (a.need_b) r.bv = a.b_iso ? b_iso_val : Bx[q];
+                        }
+                        return r;
+                    },
+                    [&](const Prod &d) {
+                        if (MXM_ABL(a, 4)) return;
+                        const int j = d.j - c0;
+                        const W prod = (W)apply_binop<T>(mult_, d.av, d.bv);
+                        if (monoid_ == OP_ANY) s_acc[j] = prod;
+                        else atomic_combine<W>(&s_acc[j], prod, monoid_);
+                        if (bslot < 0) atomicOr(&s_bits[j >> 6], 1ull << (j & 63));
+                    });
         }
     };
     {
