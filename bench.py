@@ -369,7 +369,9 @@ def main_mxm(args, gb, torch, device, rank, world, dist, barrier):
         nnz_c, flops = float(st["out_nvals"]), float(st["flops"])
     ms = dt / args.steps * 1e3
     nnz_a = float(col_b.numel())
-    alg_bytes = nnz_a * 12 + flops * 12 + nnz_c * 12 + 3 * (n + 1) * 8  # SURVEY.md section 8d, I = 4, V = 8
+    # nnz(A) (I + V_A) + flops (I + V_B) + nnz(C) (I + V_C) + 3 (n + 1) P with I = 4, P = 8; the operands are iso
+    # (one stored value: V_A = V_B = 0), the product holds INT64 values (V_C = 8)
+    alg_bytes = nnz_a * 4 + flops * 4 + nnz_c * 12 + 3 * (n + 1) * 8
     achieved = alg_bytes / world / (ev_ms / args.steps * 1e-3) / 1e9
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
