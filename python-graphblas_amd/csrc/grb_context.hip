@@ -210,6 +210,7 @@ extern "C" GrB_Info GrB_init(GrB_Mode mode)
     if (const char *e = getenv("GRB_MXM_UNIT_DENSE")) c.mxm_unit_dense = atoi(e);
     if (const char *e = getenv("GRB_MXM_UNIT_MID")) c.mxm_unit_mid = atoi(e);
     if (const char *e = getenv("GRB_MXM_BITMAP_POOL_MB")) c.mxm_bitmap_pool_mb = atoll(e);
+    if (const char *e = getenv("GRB_MXM_BITMAP_MIN_CNT")) c.mxm_bitmap_min_cnt = atoi(e);
     if (const char *e = getenv("GRB_LONG_KERNEL")) c.long_kernel = atoi(e);
     if (const char *e = getenv("GRB_LONG_CLASSES")) c.long_classes = atoi(e);
     if (const char *e = getenv("GRB_SPLIT_MIN_LEN")) c.split_min_len = atoi(e);
@@ -317,6 +318,7 @@ extern "C" GrB_Info GrX_option_set(const char *name, int64_t value)
     else if (n == "mxm_unit_dense") c.mxm_unit_dense = (int)value;
     else if (n == "mxm_unit_mid") c.mxm_unit_mid = (int)value;
     else if (n == "mxm_bitmap_pool_mb") c.mxm_bitmap_pool_mb = value;
+    else if (n == "mxm_bitmap_min_cnt") c.mxm_bitmap_min_cnt = (int)value;
     else if (n == "mxm_bitmap_pool_cap") c.mxm_bitmap_pool_cap = value;
     else if (n == "vec_pad_min_bytes") c.vec_pad_min_bytes = value;
     else if (n == "alloc_cache") {

@@ -76,6 +76,7 @@ struct Context {
     int64_t mxm_unit_min_per_window = 16;  // ... and than this many per column window
     int64_t mxm_masked_units_min_flops = 64ll << 20;  // mask-driven products below this many multiplies keep the row kernels
     int64_t mxm_bitmap_pool_cap = INT32_MAX;  // ... and at most this many bitmaps (tests: a pool that runs out)
+    int mxm_bitmap_min_cnt = 512;  // units with more entries than this keep their bitmap
     int64_t mxm_bitmap_pool_mb = 16384;  // bitmaps of the denser units kept from the symbolic for the numeric pass: at most this much  // rows with more products than this (and than 32 per window) are walked as units
     int mxm_mask_mode = 1;  // mask-driven SpGEMM for non-complemented masks: 0 never, 1 when the full product costs more, 2 always
     int long_sub = 0;       // sub-ranges per class of the cold columns of the long rows (items of a class are walked sub-range by

@@ -1766,7 +1766,7 @@ static GB_Matrix_opaque *spgemm(GB_Matrix_opaque *A, const void *Ax, GB_Matrix_o
                         a.bm_cursor = bm_cur.p;
                         a.bm_pools = cap >= 64 * MU_POOLS ? MU_POOLS : 1;
                         a.bm_cap = cap / a.bm_pools;
-                        a.bm_min_cnt = std::min(MU_SMALL, ctx().mxm_unit_small);
+                        a.bm_min_cnt = ctx().mxm_bitmap_min_cnt;
                     }
                 }
             }
