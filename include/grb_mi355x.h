@@ -302,7 +302,8 @@ GrB_Info GrX_Matrix_cache_bytes(const GrB_Matrix A, uint64_t *bytes);
  *                   1 class-partitioned items (k_mxv_long_grp); 0 chunks straight from the CSR arrays (k_mxv_long)
  *   "long_classes"  column classes of the class strips: 8, 16 (default), 32 or 64 distinct LDS heads across the chip
  *   "short_kernel"  short rows of a split matrix: 1 (default) one wavefront per 64 rows, 0 merge-path tiles, 2 sliced ELLPACK
- *                   with a lane per row ("sell_sigma" rows per sort window; measured slower)
+ *                   with a lane per row ("sell_sigma" rows per sort window; measured slower), 3 persistent
+ *                   workgroups with an LDS head, 4 a lane per row folding products staged in LDS (both measured slower)
  *   "long_sub"      sub-ranges per class of the cold columns of the long rows (0 = sized from the operand image),
  *   "long_sub_min_len"  for rows from this many entries (0 = 512 per sub-range)
  *   "mxm_mask_mode" mask-driven SpGEMM for non-complemented masks: 1 (default) when the product costs clearly more than the mask,

@@ -502,7 +502,19 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
             ctx().stats.tiles = groups;
             return;
         }
-        if (ctx().short_kernel == 1 && S->nrows == A->nrows) {
+        if constexpr (sizeof(T) == 4 && !std::is_same<T, bool>::value) {
+            if (ctx().short_kernel == 4 && S->nrows == A->nrows && b.need_uval && b.u_full && b.need_aval) {
+                // short rows with a lane per row over entries staged in LDS (4-byte types, full operand whose values are read)
+                b.long_prefix = A->d_long_prefix;
+                hipLaunchKernelGGL((k_mxv_rows_lane<T, MON, MUL>), dim3((unsigned)ceil_div(ceil_div(b.m, 64), ROWS_BLOCK / 64)), dim3(ROWS_BLOCK),
+                                   0, ctx().stream, b);
+                GRB_HIP(hipGetLastError());
+                ctx().stats.kernel_launches += 1;
+                ctx().stats.tiles = ceil_div(b.m, 64);
+                return;
+            }
+        }
+        if ((ctx().short_kernel == 1 || ctx().short_kernel == 4) && S->nrows == A->nrows) {
             // short rows: one wavefront per 64 consecutive rows, which also applies the write rule of the long rows
             b.long_prefix = A->d_long_prefix;
             // (persistent variants -- static strides with the next group prefetched, or an LDS work counter per workgroup --

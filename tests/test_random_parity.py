@@ -490,7 +490,8 @@ def test_long_short_row_split(gb, seed):
         _lib.lib.GrX_option_set(b"push_mode", 0)
         # merge-path kernel / row-group kernel / sliced-ELLPACK kernel for the short rows
         # sliced ELLPACK / persistent row groups with an LDS head / merge path / row groups
-        _lib.lib.GrX_option_set(b"short_kernel", 2 if seed % 3 == 1 else (3 if seed % 3 == 2 else (0 if seed & 8 else 1)))
+        # (seeds 0, 6, 12: a lane per row over entries staged in LDS -- 4-byte types with a full operand; the rest falls back to row groups)
+        _lib.lib.GrX_option_set(b"short_kernel", 4 if seed % 6 == 0 else (2 if seed % 3 == 1 else (3 if seed % 3 == 2 else (0 if seed & 8 else 1))))
         _lib.lib.GrX_option_set(b"sell_sigma", [64, 128, 4096, 256][seed % 4])
         if seed & 4:
             _lib.lib.GrX_option_set(b"hot_min_cols", 8)
@@ -548,6 +549,73 @@ def test_long_short_row_split(gb, seed):
         _lib.lib.GrX_option_set(b"long_sub_min_len", 0)
         _lib.lib.GrX_option_set(b"long_kernel", DEFAULT_LONG_KERNEL)
         _lib.lib.GrX_option_set(b"long_classes", 16)
+
+
+@pytest.mark.parametrize("seed", range(18))
+def test_short_rows_lane_kernel(gb, seed):
+    """short_kernel = 4: a lane per row over the group's entries staged in LDS (4-byte types, a FULL operand whose values are
+    read).  Rows of 0 .. 70 entries around the long-row threshold, groups whose entries span several staging windows, long
+    rows in the same 64-row groups (their product comes from the long-row kernel), masks of every form, accumulators,
+    replace, iso matrices, with and without the hot-column table; semirings whose multiply ignores an operand fall back to
+    the row-group kernel under the same option."""
+    from graphblas_amd import _lib
+
+    rng = np.random.default_rng(3300 + seed)
+    tname = ["FP32", "INT32"][seed % 2]
+    sr = ["min_plus", "plus_times", "max_plus", "plus_plus", "min_second", "any_pair", "max_first", "plus_pair", "min_plus"][seed % 9]
+    m, n = int(rng.integers(70, 700)), int(rng.integers(300, 4000))
+    deg = rng.integers(0, 9, m)
+    deg[rng.random(m) < 0.25] = 0
+    thr = 24
+    for ln in (thr - 1, thr, thr + 1, 70, 300, 7, 23, 1):
+        deg[rng.integers(0, m)] = min(ln, n)
+    if seed % 3 == 0:  # a run of fat short rows: one group's entries span several staging windows of 256
+        s0 = int(rng.integers(0, m - 64))
+        deg[s0: s0 + 40] = thr - 1
+    rows = np.repeat(np.arange(m), deg)
+    cols = np.concatenate([rng.choice(n, d, replace=False) for d in deg])
+    vals = rand_vals(rng, rows.size, tname)
+    if seed % 5 == 0:
+        vals[:] = vals[0]  # iso
+    ui, uv = rand_vec(rng, n, 1.0, tname)
+    wi, wv = rand_vec(rng, m, 0.5, tname)
+    mi, mv = rand_vec(rng, m, 0.5, "BOOL")
+    accum = [None, "plus", "min", "second"][seed % 4]
+    comp, struct, repl = bool(seed & 1), bool(seed & 2), bool(seed & 4)
+    use_mask = seed % 7 != 3
+    oa = O.OMat.from_coo(rows, cols, vals, m, n, tname)
+    exp = O.mxv(oa, O.OVec(n, ui, uv, tname), sr, w=O.OVec(m, wi, wv, tname), mask=O.OVec(m, mi, mv, "BOOL") if use_mask else None,
+                mask_comp=comp and use_mask, mask_struct=struct and use_mask, accum=accum, replace=repl and use_mask)
+    try:
+        _lib.lib.GrX_option_set(b"split_min_nnz", 1)
+        _lib.lib.GrX_option_set(b"split_min_len", thr)
+        _lib.lib.GrX_option_set(b"push_mode", 0)
+        _lib.lib.GrX_option_set(b"short_kernel", 4)
+        if seed & 8:
+            _lib.lib.GrX_option_set(b"hot_min_cols", 8)
+            _lib.lib.GrX_option_set(b"hot_k", 64)
+        A = gb.Matrix.from_coo(rows, cols, vals, dtype=tname, nrows=m, ncols=n)
+        u = gb.Vector.from_coo(ui, uv, dtype=tname, size=n)
+        mk = gb.Vector.from_coo(mi, mv, dtype="BOOL", size=m)
+        for _ in range(2):  # (the second call runs on the cached layouts)
+            w = gb.Vector.from_coo(wi, wv, dtype=tname, size=m)
+            if use_mask:
+                msk = mk.S if struct else mk.V
+                w(~msk if comp else msk, accum=accum, replace=repl) << A.mxv(u, getattr(gb.semiring, sr))
+            else:
+                w(accum=accum) << A.mxv(u, getattr(gb.semiring, sr))
+            if sr.startswith("any_") and not sr.endswith("pair"):
+                gi, _ = w.to_coo()
+                assert gi.tolist() == exp.idx.tolist()
+            else:
+                same_vec(w, exp)
+    finally:
+        _lib.lib.GrX_option_set(b"split_min_nnz", 1 << 22)
+        _lib.lib.GrX_option_set(b"split_min_len", 0)
+        _lib.lib.GrX_option_set(b"push_mode", 1)
+        _lib.lib.GrX_option_set(b"short_kernel", DEFAULT_SHORT_KERNEL)
+        _lib.lib.GrX_option_set(b"hot_min_cols", 1 << 20)
+        _lib.lib.GrX_option_set(b"hot_k", 0)
 
 
 @pytest.mark.parametrize("seed", range(6))
