@@ -59,7 +59,10 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--streamed", action="store_true", help="mxm: run the unmasked product in row batches with the output streamed")
     p.add_argument("--stream-budget-gb", type=float, default=64.0, help="mxm --streamed: device bytes one batch's product may take")
-    p.add_argument("--extra", action="store_true", help="also run the secondary workloads (reported under 'extra')")
+    p.add_argument("--extra", action="store_true", help="(kept for old command lines: the secondary workloads now run by default)")
+    p.add_argument("--no-extra", action="store_true", help="headline workload only: skip the lines reported under 'extra'")
+    p.add_argument("--overlap-chunks", type=int, default=2,
+                   help="N > 1: row blocks per rank; the all-gather of block c overlaps the product of block c + 1 (1 = no overlap)")
     return p.parse_args()
 
 
@@ -71,112 +74,176 @@ def algorithmic_bytes_mxv(nnz_active, m, n, v_a, v_u, v_w, accum, mask):
 
 class MxvWorkload:
     """Holds the HBM-resident operands of one masked mxv and launches it through the C ABI directly
-    (ctypes call with pre-resolved handles: no per-step Python marshalling beyond one FFI call)."""
+    (ctypes call with pre-resolved handles: no per-step Python marshalling beyond one FFI call).
 
-    def __init__(self, gb, torch, scale, rank, world, semiring, visited_frac, seed=0, block=None):
-        from graphblas_amd import _lib, device, synthetic
+    With N > 1 ranks every rank owns ``chunks`` row blocks (sharded.chunk_blocks) and two replicas of u: a step is the product
+    of every block, each followed by the asynchronous all-gather of its w slices into the replica the NEXT step reads
+    (sharded.OverlappedMxv) -- the exchange of block c runs while block c + 1 is computed."""
+
+    def __init__(self, gb, torch, scale, rank, world, semiring, visited_frac, seed=0, block=None, chunks=1):
+        from graphblas_amd import _lib, device, sharded, synthetic
 
         self.gb, self.torch, self.rank, self.world = gb, torch, rank, world
         n = 1 << scale
         # (--block r/w: this process computes rank r's rows of a w-way run, alone: no exchange)
-        shard_rank, shard_world = block if block else (rank, world)
-        assert n % (64 * shard_world) == 0
-        rows = n // shard_world
-        lo, hi = shard_rank * rows, (shard_rank + 1) * rows
-        self.n, self.m, self.lo, self.hi = n, rows, lo, hi
-        self.block = block
-        indptr, col = synthetic.rmat_csr(scale, device="cuda", row_range=(lo, hi) if shard_world > 1 else None)
-        self.nnz_local = int(col.numel())
+        if block:
+            assert n % (64 * block[1]) == 0
+            rows = n // block[1]
+            ranges = [(block[0] * rows, (block[0] + 1) * rows)]
+        elif world > 1:
+            ranges = sharded.chunk_blocks(n, rank, world, chunks)
+        else:
+            ranges = [(0, n)]
+        self.ranges, self.n, self.block = ranges, n, block
+        self.lo, self.hi = ranges[0]
+        self.m = sum(hi - lo for lo, hi in ranges)
+        graphs = synthetic.rmat_csr(scale, device="cuda", row_ranges=ranges) if (block or world > 1) else [synthetic.rmat_csr(scale, device="cuda")]
         gen = torch.Generator(device="cuda")
         gen.manual_seed(4242 + seed)
         visited = torch.rand(n, generator=gen, device="cuda") < visited_frac
-        self.visited_local = visited[lo:hi].contiguous()
-        rowlen = indptr[1:] - indptr[:-1]
-        self.nnz_active_local = int(rowlen[~self.visited_local].sum().item())
         self.semiring = semiring
+        n_u = 2 if (world > 1 and not block) else 1
         if semiring == "min_plus":
-            vals = synthetic.edge_weights(col, scale)
-            self.A = device.matrix_from_device_csr(indptr, col, vals, rows, n, "FP32")
             dist = torch.randint(0, 1000, (n,), generator=gen, device="cuda").to(torch.float32)
             self._dist = dist
-            self._vals = vals
-            self.u = device.vector_from_device(dist)
-            self.w = device.vector_from_device(dist[lo:hi].contiguous())
+            self.us = [device.vector_from_device(dist) for _ in range(n_u)]
             self.sr = gb.semiring.min_plus["FP32"]
             self.accum = gb.binary.min["FP32"]
             self.dtype_name, self.v_a, self.v_u, self.v_w = "f32", 4, 4, 4
         else:  # lor_land on an iso-True BOOL matrix: one BFS level step  q<~visited.S, replace> = A lor.land q
-            one = torch.ones(1, dtype=torch.bool, device="cuda")
-            self.A = device.matrix_from_device_csr(indptr, col, one, rows, n, "BOOL", iso=True)
             frontier = torch.rand(n, generator=gen, device="cuda") < 0.3
             self._frontier = frontier
-            self.u = device.vector_from_device(torch.ones(n, dtype=torch.bool, device="cuda"), present=frontier)
-            self.w = device.vector_from_device(torch.ones(rows, dtype=torch.bool, device="cuda"),
-                                               present=frontier[lo:hi].contiguous())
+            self.us = [device.vector_from_device(torch.ones(n, dtype=torch.bool, device="cuda"), present=frontier) for _ in range(n_u)]
             self.sr = gb.semiring.lor_land["BOOL"]
             self.accum = None
             self.dtype_name, self.v_a, self.v_u, self.v_w = "bool", 0, 1, 1
-        self.mask = device.vector_from_device(torch.ones(rows, dtype=torch.bool, device="cuda"), present=self.visited_local)
-        self._keep = (indptr, col)
+        self.u = self.us[0]
+        self.As, self.ws, self.masks, self.visited_c, self._keeps, self._valss = [], [], [], [], [], []
+        self.nnz_local = self.nnz_active_local = 0
+        for (lo, hi), (indptr, col) in zip(ranges, graphs):
+            rows = hi - lo
+            vis_c = visited[lo:hi].contiguous()
+            rowlen = indptr[1:] - indptr[:-1]
+            self.nnz_local += int(col.numel())
+            self.nnz_active_local += int(rowlen[~vis_c].sum().item())
+            if semiring == "min_plus":
+                # (a sharded run never materialises the whole graph: every block draws its weights from the same stream, so the
+                #  N-rank runs relax other weights than the single-GPU run; each run is checked against ITS OWN operands)
+                vals = synthetic.edge_weights(col, scale)
+                self.As.append(device.matrix_from_device_csr(indptr, col, vals, rows, n, "FP32"))
+                self.ws.append(device.vector_from_device(self._dist[lo:hi].contiguous()))
+                self._valss.append(vals)
+            else:
+                one = torch.ones(1, dtype=torch.bool, device="cuda")
+                self.As.append(device.matrix_from_device_csr(indptr, col, one, rows, n, "BOOL", iso=True))
+                self.ws.append(device.vector_from_device(torch.ones(rows, dtype=torch.bool, device="cuda"),
+                                                         present=self._frontier[lo:hi].contiguous()))
+                self._valss.append(None)
+            self.masks.append(device.vector_from_device(torch.ones(rows, dtype=torch.bool, device="cuda"), present=vis_c))
+            self.visited_c.append(vis_c)
+            self._keeps.append((indptr, col))
+        # (single block: the names the CPU baseline and the single-GPU check use)
+        self.A, self.w, self.mask, self.visited_local, self._keep, self._vals = (self.As[0], self.ws[0], self.masks[0], self.visited_c[0],
+                                                                                 self._keeps[0], self._valss[0])
         desc_name = "GrB_DESC_SC" if semiring == "min_plus" else "GrB_DESC_RSC"
         L = _lib.lib
         self._call = L.GrB_mxv
         self._args = (self.w._carg, self.mask._carg, self.accum._carg if self.accum else None, self.sr._carg,
                       self.A._carg, self.u._carg, ctypes.c_void_p(_lib.handle(desc_name)))
-        if world > 1:
-            self.u_vals, _ = device.vector_device_views(self.u)
-            self.w_vals, _ = device.vector_device_views(self.w)
-            # The collective normally lands directly in the replicated vector's HBM image (library memory from the
-            # stream-ordered HIP pool).  Should the RCCL build refuse those buffers, stage through torch-owned tensors.
-            self._staged = False
-            try:
-                torch.distributed.all_gather_into_tensor(self.u_vals, self.u_vals[lo:hi].clone())
-                torch.cuda.synchronize()
-            except RuntimeError:
-                self._staged = True
-                self._gather_buf = torch.empty_like(self.u_vals)
-                self._send_buf = torch.empty_like(self.w_vals)
+        self.ov = None
+        if n_u == 2:
+            # the BFS step's output is not full: its presence words travel with the values
+            self.ov = sharded.OverlappedMxv(self.As, self.ws, self.masks, self.us, self.sr, accum=self.accum, desc_name=desc_name,
+                                            presence=(semiring != "min_plus"))
+            self.ov.probe_exchange()
+            torch.cuda.synchronize()
 
     def step(self):
+        if self.ov is not None:
+            return self.ov.step()
         rc = self._call(*self._args)
         if rc != 0:
             raise RuntimeError(f"GrB_mxv failed with GrB_Info {rc}")
-        if self.world > 1 and self.semiring == "min_plus":
-            # next u = all ranks' w slices (u and w stay full, so only values travel; 4 B * n/N per rank)
-            if self._staged:
-                self._send_buf.copy_(self.w_vals)
-                self.torch.distributed.all_gather_into_tensor(self._gather_buf, self._send_buf)
-                self.u_vals.copy_(self._gather_buf)
-            else:
-                self.torch.distributed.all_gather_into_tensor(self.u_vals, self.w_vals)
 
-    def verify(self):
-        """Check the output of the timed calls against a torch segment reduction of the same products (single GPU: u is fixed,
-        so K steps of  w<mask> = min(w, A min.+ u)  leave what one step leaves; the BFS step has no accumulator at all).
-        min_plus over integer-valued fp32 operands is exact, so the comparison is bit for bit."""
+    # ---- checks --------------------------------------------------------------------------------------------------------------
+    def _bits(self, words, m):
         import numpy as np
 
+        return self.torch.from_numpy(np.unpackbits(words.cpu().numpy().view(np.uint8), bitorder="little")[:m].astype(bool)).cuda()
+
+    def _expected_block(self, c, u_vals, u_has, w_vals_before, w_has_before):
+        """torch evaluation of one step on block c from the given operand images: (expected presence, expected values)."""
+        torch = self.torch
+        indptr, col = self._keeps[c]
+        lo, hi = self.ranges[c]
+        m = hi - lo
+        rows = torch.repeat_interleave(torch.arange(m, device="cuda"), indptr[1:] - indptr[:-1])
+        active = ~self.visited_c[c]
+        if self.semiring == "min_plus":
+            cand = self._valss[c] + u_vals[col.long()]
+            ref = torch.full((m,), float("inf"), device="cuda").scatter_reduce(0, rows, cand, "amin")
+            del cand
+            return w_has_before, torch.where(active, torch.minimum(w_vals_before, ref), w_vals_before)
+        hit = torch.zeros(m, dtype=torch.bool, device="cuda")
+        sel = u_has[col.long()] & u_vals[col.long()]
+        hit.index_put_((rows[sel],), torch.tensor(True, device="cuda"))
+        return hit & active, None
+
+    def verify(self):
+        """Check the output of the timed calls against a torch segment reduction of the same products.  Single GPU: u is fixed,
+        so K steps of  w<mask> = min(w, A min.+ u)  leave what one step leaves; the BFS step has no accumulator at all.  N ranks:
+        u changes with every step, so ONE MORE step is run from a snapshot of the operands and every rank checks (a) its blocks of
+        that step against torch, (b) that the replica the next step reads holds exactly the ranks' slices (its own rows equal its
+        w, and a checksum of the whole replica is the same on every rank); the flags are combined with a MIN all-reduce.
+        min_plus over integer-valued fp32 operands is exact, so every comparison is bit for bit."""
         from graphblas_amd import device
 
         torch = self.torch
-        if self.world > 1:
-            return None
-        indptr, col = self._keep
-        n, m = self.n, self.m
-        rows = torch.repeat_interleave(torch.arange(m, device="cuda"), indptr[1:] - indptr[:-1])
-        active = ~self.visited_local
-        wv, wb = device.vector_device_views(self.w)
-        got_has = torch.from_numpy(np.unpackbits(wb.cpu().numpy().view(np.uint8), bitorder="little")[:m].astype(bool)).cuda()
-        if self.semiring == "min_plus":
-            cand = self._vals + self._dist[col.long()]
-            ref = torch.full((m,), float("inf"), device="cuda").scatter_reduce(0, rows, cand, "amin")
-            del cand
-            exp = torch.where(active, torch.minimum(self._dist[self.lo:self.hi], ref), self._dist[self.lo:self.hi])
-            return bool(got_has.all().item()) and bool(torch.equal(wv, exp))
-        hit = torch.zeros(m, dtype=torch.bool, device="cuda")
-        hit.index_put_((rows[self._frontier[col.long()]],), torch.tensor(True, device="cuda"))
-        exp_has = hit & active
-        return bool(torch.equal(got_has, exp_has)) and bool(wv[exp_has].all().item())
+        if self.ov is None:
+            wv, wb = device.vector_device_views(self.w)
+            got_has = self._bits(wb, self.m)
+            if self.semiring == "min_plus":
+                d0 = self._dist[self.lo:self.hi]
+                exp_has, exp = self._expected_block(0, self._dist, None, d0, torch.ones(self.m, dtype=torch.bool, device="cuda"))
+                return bool(got_has.all().item()) and bool(torch.equal(wv, exp))
+            exp_has, _ = self._expected_block(0, torch.ones(self.n, dtype=torch.bool, device="cuda"), self._frontier, None, None)
+            return bool(torch.equal(got_has, exp_has)) and bool(wv[exp_has].all().item())
+        import torch.distributed as dist
+
+        ov = self.ov
+        src = ov.current_u()
+        uv, ub = device.vector_device_views(src)
+        u_vals, u_has = uv.clone(), self._bits(ub, self.n)
+        before = []
+        for c in range(ov.chunks):
+            wv, wb = device.vector_device_views(self.ws[c])
+            before.append((wv.clone(), self._bits(wb, self.ranges[c][1] - self.ranges[c][0])))
+        ov.step()
+        torch.cuda.synchronize()
+        ok = True
+        nv, nb = device.vector_device_views(ov.current_u())
+        n_has = self._bits(nb, self.n)
+        for c in range(ov.chunks):
+            lo, hi = self.ranges[c]
+            wv, wb = device.vector_device_views(self.ws[c])
+            got_has = self._bits(wb, hi - lo)
+            exp_has, exp = self._expected_block(c, u_vals, u_has, *before[c])
+            if self.semiring == "min_plus":
+                ok = ok and bool(got_has.all().item()) and bool(torch.equal(wv, exp)) and bool(torch.equal(nv[lo:hi], wv))
+            else:
+                ok = ok and bool(torch.equal(got_has, exp_has)) and bool(wv[exp_has].all().item())
+                ok = ok and bool(torch.equal(n_has[lo:hi], got_has)) and bool(nv[lo:hi][got_has].all().item())
+        # the replica every rank will read next must be the same everywhere: two order-independent checksums
+        img = nv.view(torch.int32).to(torch.int64) if self.semiring == "min_plus" else (nv.to(torch.int64) & n_has.to(torch.int64))
+        idx = torch.arange(1, self.n + 1, device="cuda", dtype=torch.int64)
+        sums = torch.stack([img.sum(), (img * idx).sum(), n_has.to(torch.int64).sum()])
+        hi_, lo_ = sums.clone(), sums.clone()
+        dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
+        ok = ok and bool(torch.equal(hi_, lo_))
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(flag.item())
 
     def bytes_per_step(self):
         return algorithmic_bytes_mxv(self.nnz_active_local, self.m, self.n, self.v_a, self.v_u, self.v_w,
@@ -298,13 +365,73 @@ def cpu_baseline_mxv(wl, torch, reps_budget_s=20.0):
                       "C oracle (oracle/grb_oracle.c, OpenMP) -- a CPU restatement, not SuiteSparse"}
 
 
-def main_mxm(args, gb, torch, device, rank, world, dist, barrier):
+def verify_mxm(torch, device, gb, L, sr, A, B, ip_a, col_a, ip_b, col_b, n, masked, C, st, stream_out, budget, seed=5):
+    """Independent checks of the SpGEMM line (operands are matrices of ones, INT64 plus_times):
+      * the multiply count the symbolic pass reports = sum over the entries (i, k) of A of nnz(B(k, :)), computed by torch from the
+        row pointers;
+      * unmasked: sum of the values of C = that count (every multiply adds 1 somewhere), nnz(C) = the last row pointer, and, on
+        a seeded sample of rows, the row's columns and values equal torch.unique(with counts) over the gathered rows of B
+        (sorted, so the order inside the row is checked too); masked: the same rows restricted to the mask row's columns;
+      * streamed (no C leaves the library): its checksum = the multiply count, and the same pipeline on a small row block equals
+        the materialised product of that block, which is checked as above."""
+    rowlen_b = ip_b[1:] - ip_b[:-1]
+    flops_expected = int(rowlen_b[col_a.long()].sum().item())
+    ok = int(st["flops"]) == flops_expected
+    m = int(ip_a.numel()) - 1
+
+    def check_rows(Cmat, ip_x, col_x, rows_total, mask_rows):
+        cp, cj, cx, _iso = device.matrix_device_views(Cmat)
+        good = int(cp[-1].item()) == int(cj.numel())
+        g = torch.Generator(device="cpu")
+        g.manual_seed(seed)
+        lens = (ip_x[1:] - ip_x[:-1]).cpu()
+        cand = torch.nonzero(lens > 0).flatten()
+        pick = cand[torch.randperm(cand.numel(), generator=g)[:24]].tolist() if cand.numel() else []
+        for i in pick:
+            ks = col_x[int(ip_x[i]): int(ip_x[i + 1])].long()
+            starts, lens_k = ip_b[ks], ip_b[ks + 1] - ip_b[ks]
+            offs = torch.cumsum(lens_k, 0) - lens_k
+            total = int(lens_k.sum().item())
+            pos = torch.arange(total, device="cuda") + (starts - offs).repeat_interleave(lens_k)  # every entry of every selected row of B
+            cols, cnt = torch.unique(col_b[pos], return_counts=True)
+            if mask_rows:
+                keep = torch.isin(cols, ks.to(cols.dtype))
+                cols, cnt = cols[keep], cnt[keep]
+            r0, r1 = int(cp[i].item()), int(cp[i + 1].item())
+            good = good and r1 - r0 == int(cols.numel()) and bool(torch.equal(cj[r0:r1], cols.to(torch.int32))) \
+                and bool(torch.equal(cx[r0:r1], cnt.to(torch.int64)))
+        return good, cx
+
+    if C is not None:
+        good, cx = check_rows(C, ip_a, col_a, m, masked)
+        ok = ok and good and int(st["out_nvals"]) == int(cx.numel())
+        if not masked:
+            ok = ok and int(cx.sum().item()) == flops_expected
+    else:
+        ok = ok and stream_out.get("checksum") == flops_expected
+        # the streamed pipeline on a row block against the materialised (and independently checked) product of the same block
+        rows_blk = min(m, 2048)
+        e1 = int(ip_a[rows_blk].item())
+        one = torch.ones(1, dtype=torch.int64, device="cuda")
+        ip_k, col_k = ip_a[: rows_blk + 1].contiguous(), col_a[:e1].contiguous()
+        Ablk = device.matrix_from_device_csr(ip_k, col_k, one, rows_blk, n, "INT64", iso=True)
+        Cblk = gb.Matrix("INT64", rows_blk, n)
+        ok = ok and L.GrB_mxm(Cblk._carg, None, None, sr._carg, Ablk._carg, B._carg, None) == 0
+        good, cx = check_rows(Cblk, ip_k, col_k, rows_blk, False)
+        nv, cs, fl, nb = (ctypes.c_uint64(0) for _ in range(4))
+        ok = ok and good and L.GrX_mxm_streamed(sr._carg, Ablk._carg, B._carg, ctypes.c_uint64(max(budget >> 8, 1 << 26)), ctypes.byref(nv),
+                                                ctypes.byref(cs), ctypes.byref(fl), ctypes.byref(nb)) == 0
+        ok = ok and int(nv.value) == int(cx.numel()) and int(cs.value) == int(cx.sum().item()) == int(fl.value)
+    return bool(ok)
+
+
+def run_mxm(args, gb, torch, device, rank, world, dist, barrier, *, scale, workload, steps, warmup, want_cpu=True):
     """configs[3]: C = A (+.x) A, plus_times INT64 on R-MAT (ones), rows of A sharded over the ranks, B = A
-    replicated; no collective in the timed loop (the product stays row-sharded).  value = nnz(C) / s."""
+    replicated; no collective in the timed loop (the product stays row-sharded).  value = nnz(C) / s.  Returns the line."""
     from graphblas_amd import _lib, sharded, synthetic
 
-    n = 1 << args.scale
-    ip_b, col_b = synthetic.rmat_csr(args.scale, device="cuda")
+    n = 1 << scale
+    ip_b, col_b = synthetic.rmat_csr(scale, device="cuda")
     # rows of A cut so that every rank carries the same number of multiplies (not the same number of rows): no collective
     # constrains the block sizes here
     if world > 1:
@@ -319,17 +446,18 @@ def main_mxm(args, gb, torch, device, rank, world, dist, barrier):
         col_a = col_b[ip_b[lo]: ip_b[hi]].contiguous()
         A = device.matrix_from_device_csr(ip_a, col_a, one, hi - lo, n, "INT64", iso=True)
     else:
-        A = B
+        A, ip_a, col_a = B, ip_b, col_b
     sr = gb.semiring.plus_times["INT64"]
     L = _lib.lib
 
-    masked = args.workload == "mxm_plus_times_masked"  # triangle-count style: C<A.S> = A (+.x) A
+    masked = workload == "mxm_plus_times_masked"  # triangle-count style: C<A.S> = A (+.x) A
     desc_s = ctypes.c_void_p(_lib.handle("GrB_DESC_S"))
     # the unmasked product of scale >= 21 does not fit one GPU (scale 22: 900 GB): it runs in row batches whose products fit
     # `budget`, every batch through the full symbolic + numeric pipeline; count and checksum leave the batch (GrX_mxm_streamed)
-    streamed = (not masked) and (args.streamed or args.scale >= 21)  # (the same pipeline at every rank count: comparable lines)
+    streamed = (not masked) and (args.streamed or scale >= 21)  # (the same pipeline at every rank count: comparable lines)
     budget = int(args.stream_budget_gb * (1 << 30))
     stream_out = {}
+    keep = {}
 
     def step():
         if streamed:
@@ -340,6 +468,7 @@ def main_mxm(args, gb, torch, device, rank, world, dist, barrier):
                 raise RuntimeError(f"GrX_mxm_streamed failed with GrB_Info {rc}")
             stream_out.update(batches=int(nb.value), checksum=int(cs.value))
             return device.last_stats()
+        keep.pop("C", None)  # (the previous product is released before the next one is allocated)
         C = gb.Matrix("INT64", hi - lo, n)
         if masked:
             rc = L.GrB_mxm(C._carg, A._carg, None, sr._carg, A._carg, B._carg, desc_s)
@@ -348,50 +477,60 @@ def main_mxm(args, gb, torch, device, rank, world, dist, barrier):
         if rc != 0:
             raise RuntimeError(f"GrB_mxm failed with GrB_Info {rc}")
         st = device.last_stats()
+        keep["C"] = C
         return st
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         st = step()
     barrier()
     t0 = time.perf_counter()
     device.timer_start()
-    for _ in range(args.steps):
+    for _ in range(steps):
         st = step()
     ev_ms = device.timer_stop()
     barrier()
     dt = time.perf_counter() - t0
-    t = torch.tensor([dt, float(st["out_nvals"]), float(st["flops"]), ev_ms], dtype=torch.float64, device="cuda")
+    verified = verify_mxm(torch, device, gb, L, sr, A, B, ip_a, col_a, ip_b, col_b, n, masked, keep.get("C"), st, stream_out, budget)
+    keep.clear()
+    t = torch.tensor([dt, float(st["out_nvals"]), float(st["flops"]), ev_ms, 1.0 if verified else 0.0], dtype=torch.float64, device="cuda")
     if dist is not None:
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        dt, nnz_c, flops, ev_ms = tmax[0].item(), tsum[1].item(), tsum[2].item(), tmax[3].item()
+        tmin = t.clone(); dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+        dt, nnz_c, flops, ev_ms, verified = tmax[0].item(), tsum[1].item(), tsum[2].item(), tmax[3].item(), bool(tmin[4].item())
     else:
         nnz_c, flops = float(st["out_nvals"]), float(st["flops"])
-    ms = dt / args.steps * 1e3
+    ms = dt / steps * 1e3
     nnz_a = float(col_b.numel())
     # nnz(A) (I + V_A) + flops (I + V_B) + nnz(C) (I + V_C) + 3 (n + 1) P with I = 4, P = 8; the operands are iso
     # (one stored value: V_A = V_B = 0), the product holds INT64 values (V_C = 8)
     alg_bytes = nnz_a * 4 + flops * 4 + nnz_c * 12 + 3 * (n + 1) * 8
-    achieved = alg_bytes / world / (ev_ms / args.steps * 1e-3) / 1e9
+    achieved = alg_bytes / world / (ev_ms / steps * 1e-3) / 1e9
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and want_cpu and not args.no_cpu_baseline:
         try:
             cpu = cpu_baseline_mxm(ip_b, col_b, n, flops, masked)
         except Exception as e:  # the baseline must never take the bench line down
             cpu = {"value": None, "unit": "nnz(C)/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
+    return {
+        "metric": "SpGEMM nnz-out/s on R-MAT scale-%d" % scale, "value": nnz_c / (ms * 1e-3), "unit": "nnz(C)/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": ms, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "int64", "data": "synthetic", "verified": verified,
+        "config": {"workload": f"rmat{scale} {workload}: " + ("C<A.S> = A (+.x) A (mask-driven)" if masked else "C = A (+.x) A")
+                   + ", INT64 ones" + (f"; row batches under {args.stream_budget_gb:g} GiB, output streamed (count + checksum)" if streamed else ""),
+                   "nnz_A": nnz_a, "flops": flops, "nnz_C": nnz_c, "parallelism": f"row-shard x{world} (flop-balanced cuts), B replicated", **stream_out},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None if streamed else measured_traffic(workload, scale),
+                     "kernel": "k_spgemm_mhash / k_spgemm_mwin" if masked else "k_spgemm_unit (symbolic + numeric classes) / k_spgemm_unit_dense / k_spgemm_hash",
+                     "kernel_ms_hip_events": ev_ms / steps, "algorithmic_bytes_per_launch": alg_bytes / world},
+        "cpu_baseline": cpu, "stats": st}
+
+
+def main_mxm(args, gb, torch, device, rank, world, dist, barrier):
+    line = run_mxm(args, gb, torch, device, rank, world, dist, barrier, scale=args.scale, workload=args.workload, steps=args.steps,
+                   warmup=args.warmup, want_cpu=(world == 1))
     if rank == 0:
-        print(json.dumps({
-            "metric": "SpGEMM nnz-out/s on R-MAT scale-%d" % args.scale, "value": nnz_c / (ms * 1e-3), "unit": "nnz(C)/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
-            "config": {"workload": f"rmat{args.scale} {args.workload}: " + ("C<A.S> = A (+.x) A (mask-driven)" if masked else "C = A (+.x) A")
-                       + ", INT64 ones" + (f"; row batches under {args.stream_budget_gb:g} GiB, output streamed (count + checksum)" if streamed else ""),
-                       "nnz_A": nnz_a, "flops": flops, "nnz_C": nnz_c, "parallelism": f"row-shard x{world} (flop-balanced cuts), B replicated", **stream_out},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None if streamed else measured_traffic(args.workload, args.scale),
-                         "kernel": "k_spgemm_mhash / k_spgemm_mwin" if masked else "k_spgemm_unit (symbolic + numeric classes) / k_spgemm_unit_dense / k_spgemm_hash",
-                         "kernel_ms_hip_events": ev_ms / args.steps, "algorithmic_bytes_per_launch": alg_bytes / world},
-            "cpu_baseline": cpu, "stats": st}))
+        print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()
 
@@ -580,10 +719,34 @@ def main_sssp(args, gb, torch, device, rank, world):
         "roofline": None, "cpu_baseline": None}))
 
 
+def respawn_under_launcher(args):
+    """`python bench.py --gpus N` started without a launcher (no WORLD_SIZE in the environment): start N ranks of this very
+    command under torch.distributed.run on this node -- or fail cleanly when the node has fewer than N GPUs."""
+    import socket
+
+    import torch
+
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} needs {args.gpus} visible GPUs on this node, found {have}; "
+                         "not falling back to fewer ranks (the line would claim a rank count it did not run)\n")
+        sys.exit(2)
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.execv(sys.executable, cmd)
+
+
 def main():
     args = parse()
     if args.workload == "kron26":  # configs[4]: Kronecker scale-26 min_plus mxv fp32 (8 GPUs; one rank's block with --block r/8)
         args.workload, args.scale = "mxv_min_plus", 26
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.block:
+        respawn_under_launcher(args)
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
@@ -592,7 +755,11 @@ def main():
     block = None
     if args.block and world == 1:
         block = tuple(int(x) for x in args.block.split("/"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1 and not block:
+            sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE=1: start it without a launcher (it spawns its own ranks) or with "
+                             f"torch.distributed.run --nproc-per-node {args.gpus}\n")
+            sys.exit(2)
         args.gpus = world
     torch.cuda.set_device(local_rank)
     dist = None
@@ -600,6 +767,9 @@ def main():
         import torch.distributed as dist
 
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        seen = torch.ones(1, device="cuda")
+        dist.all_reduce(seen)  # every rank adds one: the ranks really see each other over RCCL
+        assert int(seen.item()) == world == dist.get_world_size(), (seen.item(), world)
     import graphblas_amd as gb
     from graphblas_amd import _lib as _lib_mod
     from graphblas_amd import device
@@ -611,10 +781,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run(workload):
+    def run(workload, scale, steps, warmup):
         sr = {"mxv_min_plus_masked": "min_plus", "mxv_lor_land_masked": "lor_land", "mxv_min_plus": "min_plus"}[workload]
         visited = 0.0 if workload == "mxv_min_plus" else args.visited
-        wl = MxvWorkload(gb, torch, args.scale, rank, world, sr, visited, block=block)
+        wl = MxvWorkload(gb, torch, scale, rank, world, sr, visited, block=block, chunks=max(1, args.overlap_chunks))
         # The first product of a matrix runs on its CSR arrays as they are; the second builds the cached layouts (hot-column coding,
         # long / short split, class strips).  Both are part of the warm-up and are timed apart (wall clock around a synchronised call).
         def timed_call():
@@ -626,14 +796,17 @@ def main():
 
         first_call_ms = timed_call()
         second_call_ms = timed_call()
-        cache_bytes = ctypes.c_uint64(0)
-        _lib_mod.lib.GrX_Matrix_cache_bytes(wl.A._carg, ctypes.byref(cache_bytes))
-        for _ in range(max(args.warmup - 2, 0)):
+        cache_bytes = 0
+        for A in wl.As:
+            cb = ctypes.c_uint64(0)
+            _lib_mod.lib.GrX_Matrix_cache_bytes(A._carg, ctypes.byref(cb))
+            cache_bytes += int(cb.value)
+        for _ in range(max(warmup - 2, 0)):
             wl.step()
         barrier()
         t0 = time.perf_counter()
         device.timer_start()
-        for _ in range(args.steps):
+        for _ in range(steps):
             wl.step()
         ev_ms = device.timer_stop()
         barrier()
@@ -647,44 +820,41 @@ def main():
             dt, edges, ev_ms = tmax[0].item(), tsum[1].item(), tmax[2].item()
         else:
             edges = float(wl.nnz_active_local)
-        ms_per_step = dt / args.steps * 1e3
-        kernel_ms = ev_ms / args.steps
+        ms_per_step = dt / steps * 1e3
+        kernel_ms = ev_ms / steps
         achieved = wl.bytes_per_step() / (kernel_ms * 1e-3) / 1e9
+        stats = device.last_stats()
         verified = wl.verify()
         res = {
             "verified": verified,
             "first_call_ms": first_call_ms,
             "layout_build_call_ms": second_call_ms,
-            "preprocess_bytes": int(cache_bytes.value),
-            "matrix_bytes": int(wl.nnz_local * (4 + wl.v_a) + (wl.m + 1) * 8),
+            "preprocess_bytes": cache_bytes,
+            "matrix_bytes": int(wl.nnz_local * (4 + wl.v_a) + (wl.m + len(wl.As)) * 8),
             "value": edges / (ms_per_step * 1e-3) / 1e9,
             "ms_per_step": ms_per_step,
             "dtype": wl.dtype_name,
             "edges_per_step": edges,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy_peak_6290": achieved / 6290.0,
-                         "traffic": measured_traffic(workload, args.scale) if world == 1 else None,
-                         "kernel": "one GrB_mxv call: k_mxv_strip (k_mxv_long_grp for BOOL matrices) + k_mxv_rows (+ k_x_image, k_long_init); k_mxv_pull + k_mxv_seams below the split threshold",
+                         "traffic": measured_traffic(workload, scale) if (world == 1 and not block) else None,
+                         "kernel": MXV_KERNELS_NOTE,
                          "kernel_ms_hip_events": kernel_ms, "algorithmic_bytes_per_launch": wl.bytes_per_step()},
-            "stats": device.last_stats(),
+            "stats": stats,
         }
+        if world > 1:
+            res["roofline"]["note"] = ("per rank: this rank's algorithmic bytes over the HIP-event time of its step on the library's stream "
+                                       "(products + waits for the exchanges), max over ranks")
+            res["exchange"] = {"chunks_per_rank": wl.ov.chunks, "replicas_of_u": 2, "staged_through_torch_buffers": wl.ov.staged,
+                               "presence_words_travel": wl.ov.presence, "collective": "all_gather_into_tensor per chunk, async_op"}
         if res["roofline"]["traffic"]:
             # the PMC traffic (L2 misses x 128 B, measured in separate profiled runs of this workload) over this run's kernel time
             res["roofline"]["traffic_GBps"] = res["roofline"]["traffic"] / (kernel_ms * 1e-3) / 1e9
         return wl, res
 
-    if args.workload == "uniform_fp64":
-        return main_uniform(args, gb, torch, device, rank, world)
-    if args.workload == "bfs":
-        return main_bfs(args, gb, torch, device, rank, world)
-    if args.workload == "sssp":
-        return main_sssp(args, gb, torch, device, rank, world)
-    if args.workload in ("mxm_plus_times", "mxm_plus_times_masked"):
-        return main_mxm(args, gb, torch, device, rank, world, dist, barrier)
-    wl, res = run(args.workload)
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    def cpu_line(wl):
         ss_lib, ss_note = probe_suitesparse()
+        cpu = None
         if ss_lib is not None and wl.semiring == "min_plus":
             try:
                 cpu = cpu_baseline_suitesparse(ss_lib, wl, torch)
@@ -696,14 +866,50 @@ def main():
             except Exception as e:  # the baseline must never take the bench line down
                 cpu = {"value": None, "unit": "GTEPS", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
         cpu["suitesparse_probe"] = ss_note
+        return cpu
+
+    if args.workload == "uniform_fp64":
+        return main_uniform(args, gb, torch, device, rank, world)
+    if args.workload == "bfs":
+        return main_bfs(args, gb, torch, device, rank, world)
+    if args.workload == "sssp":
+        return main_sssp(args, gb, torch, device, rank, world)
+    if args.workload in ("mxm_plus_times", "mxm_plus_times_masked"):
+        return main_mxm(args, gb, torch, device, rank, world, dist, barrier)
+    wl, res = run(args.workload, args.scale, args.steps, args.warmup)
+    cpu = cpu_line(wl) if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
+    # ---- the rest of the BASELINE metric, in the same line under `extra`: the BFS level step (configs[2]) and SpGEMM A (+.x) A
+    #      at scale 20 (one GPU: the materialised product) and scale 22 (configs[3]; row batches on one GPU, row-sharded on N) ----
     extra = []
-    if args.extra and world == 1:
+    default_line = args.workload == "mxv_min_plus_masked" and args.scale == 24 and not block
+    if default_line and not args.no_extra:
         del wl
-        for name in ("mxv_lor_land_masked", "mxv_min_plus"):
-            if name == args.workload:
-                continue
-            _, r = run(name)
-            extra.append({"workload": name, **{k: r[k] for k in ("value", "ms_per_step", "dtype", "roofline", "verified")}})
+
+        def freed():
+            import gc
+
+            gc.collect()
+            device.trim_memory()
+            torch.cuda.empty_cache()
+
+        freed()
+        wl2, r = run("mxv_lor_land_masked", 24, args.steps, args.warmup)
+        c2 = cpu_line(wl2) if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
+        extra.append({"workload": "rmat24 mxv_lor_land_masked: q<~visited.S, replace> = A lor.land q, iso BOOL, frontier density 0.3 (configs[2])",
+                      **{k: r[k] for k in ("value", "ms_per_step", "dtype", "roofline", "verified")}, "unit": "GTEPS", "cpu_baseline": c2})
+        del wl2
+        freed()
+        for scale, steps, warmup in ((20, 3, 1), (22, 2, 1)):
+            if scale == 20 and world > 1:
+                continue  # (the sharded runs carry the scale-22 product, the size the north star quotes for 1 -> 8 GPUs)
+            try:
+                line = run_mxm(args, gb, torch, device, rank, world, dist, barrier, scale=scale, workload="mxm_plus_times", steps=steps,
+                               warmup=warmup, want_cpu=(world == 1))
+            except Exception as e:  # an extra line must never take the headline down
+                line = {"error": repr(e)}
+            extra.append({"workload": f"rmat{scale} mxm_plus_times (configs[3]" + (")" if scale == 22 else " at scale 20: fits one GPU as an object)"),
+                          **{k: line[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "verified", "config", "roofline", "cpu_baseline", "error") if k in line}})
+            freed()
     if rank == 0:
         out = {
             "metric": "GTEPS (mxv) on R-MAT scale-%d" % args.scale,
@@ -723,21 +929,28 @@ def main():
                        if args.workload == "mxv_min_plus_masked" else f"rmat{args.scale} {args.workload}",
                        "edges_counted_per_step": res["edges_per_step"],
                        "parallelism": (f"rank {block[0]} of a {block[1]}-way row shard, compute only" if block else
-                                       f"row-shard x{world}" + (" + RCCL all-gather of w" if world > 1 else ""))},
+                                       f"row-shard x{world}" + (f" ({res['exchange']['chunks_per_rank']} row blocks per rank) + RCCL all-gather of the w slices into "
+                                                                "the other replica of u, overlapped with the next block's product" if world > 1 else ""))},
             "verified": res["verified"],
             "first_call_ms": res["first_call_ms"],
             "layout_build_call_ms": res["layout_build_call_ms"],
             "preprocess_bytes": res["preprocess_bytes"],
             "matrix_bytes": res["matrix_bytes"],
-            "roofline": res["roofline"] if world == 1 else {**res["roofline"], "note": "per-rank max over ranks"},
+            "roofline": res["roofline"],
             "cpu_baseline": cpu,
             "stats": res["stats"],
         }
+        if "exchange" in res:
+            out["exchange"] = res["exchange"]
         if extra:
             out["extra"] = extra
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+MXV_KERNELS_NOTE = ("one GrB_mxv call: k_mxv_strip (k_mxv_long_grp for BOOL matrices) + k_mxv_rows (+ k_x_image, k_long_init); "
+                    "k_mxv_pull + k_mxv_seams below the split threshold")
 
 
 if __name__ == "__main__":

@@ -250,6 +250,9 @@ GrB_Info GrX_Matrix_cache_transpose(GrB_Matrix A);
 /* Launch on this hipStream_t (default: the null stream, which orders with torch's default stream). */
 GrB_Info GrX_set_stream(void *hip_stream);
 GrB_Info GrX_synchronize(void);
+/* Return the device memory the library caches (its size-class block cache and the stream-ordered HIP pool behind it) to the
+ * driver: for a process that shares the GPU with another allocator (torch) between two phases with different footprints. */
+GrB_Info GrX_trim_memory(void);
 /* HIP-event stopwatch on the library's stream. */
 GrB_Info GrX_timer_start(void);
 GrB_Info GrX_timer_stop(float *elapsed_ms);
@@ -274,7 +277,8 @@ GrB_Info GrX_last_stats(GrX_Stats *stats);
  * have the semiring's type.  Replaces nothing in the reference: GrB_mxm (graphblas/core/matrix.py:2264-2331) materialises C. */
 GrB_Info GrX_mxm_streamed(const GrB_Semiring semiring, const GrB_Matrix A, const GrB_Matrix B, uint64_t budget_bytes,
                           uint64_t *nvals, uint64_t *checksum, uint64_t *flops, uint64_t *batches);
-/* Same shape, same pattern and values equal (rel_tol = abs_tol = 0) or close (|a - b| <= rel_tol |b| + abs_tol), compared on the
+/* Same shape, same pattern and values equal (rel_tol = abs_tol = 0) or close (|a - b| <= max(rel_tol max(|a|, |b|), abs_tol), the
+ * reference's _isclose, core/operator/binary.py:329), compared on the
  * device in a common type (reference Matrix.isequal / isclose, core/matrix.py:373-467, do it with eWiseMult + reduce). */
 GrB_Info GrX_Matrix_isclose(bool *result, const GrB_Matrix A, const GrB_Matrix B, double rel_tol, double abs_tol);
 /* A copy with the values cast to `type`, made on the device (reference dup(dtype=...), core/matrix.py:469-497 and

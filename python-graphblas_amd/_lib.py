@@ -133,6 +133,7 @@ def _declare(L):
     L.GrX_option_set.argtypes = [ctypes.c_char_p, ctypes.c_int64]
     L.GrX_set_stream.argtypes = [c_void_p]
     L.GrX_synchronize.argtypes = []
+    L.GrX_trim_memory.argtypes = []
     L.GrX_timer_start.argtypes = []
     L.GrX_timer_stop.argtypes = [P(ctypes.c_float)]
     L.GrX_last_stats.argtypes = [P(GrX_Stats)]

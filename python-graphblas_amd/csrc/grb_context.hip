@@ -2,6 +2,7 @@
 // Counterpart of the reference's `initialize(blocking=..., memory_manager="numpy")` call at
 // graphblas/__init__.py:170-173 (there: SuiteSparse GrB_init on the host; here: a gfx950 device is
 // mandatory -- there is no CPU fallback).
+#include <algorithm>
 #include <cstdlib>
 #include <mutex>
 #include <unordered_map>
@@ -194,28 +195,19 @@ extern "C" GrB_Info GrB_init(GrB_Mode mode)
         preload_prim();
     }
     if (const char *e = getenv("GRB_DEBUG_FLAGS")) c.debug_flags = atoi(e) & DEBUG_FLAGS_MASK;
-    if (const char *e = getenv("GRB_PULL_IPT")) c.tune_pull_ipt = atoi(e);
-    if (const char *e = getenv("GRB_HOT_MIN_COLS")) c.hot_min_cols = atoll(e);
-    if (const char *e = getenv("GRB_HOT_K")) c.hot_k = atoll(e);
-    if (const char *e = getenv("GRB_PUSH_MODE")) c.push_mode = atoi(e);
-    if (const char *e = getenv("GRB_ALLOC_CACHE")) c.alloc_cache = atoi(e);
-    if (const char *e = getenv("GRB_SHORT_KERNEL")) c.short_kernel = atoi(e);
-    if (const char *e = getenv("GRB_SELL_SIGMA")) c.sell_sigma = atoi(e);
-    if (const char *e = getenv("GRB_LAZY_LAYOUT")) c.lazy_layout = atoi(e);
-    if (const char *e = getenv("GRB_MXM_HEAVY_KERNEL")) c.mxm_heavy_kernel = atoi(e);
-    if (const char *e = getenv("GRB_DROP_HOT_COLS")) c.drop_hot_cols = atoi(e);
-    if (const char *e = getenv("GRB_MXM_UNIT_MIN_FLOPS")) c.mxm_unit_min_flops = atoll(e);
-    if (const char *e = getenv("GRB_MXM_UNIT_MIN_PER_WINDOW")) c.mxm_unit_min_per_window = atoll(e);
-    if (const char *e = getenv("GRB_MXM_UNIT_SMALL")) c.mxm_unit_small = atoi(e);
-    if (const char *e = getenv("GRB_MXM_UNIT_DENSE")) c.mxm_unit_dense = atoi(e);
-    if (const char *e = getenv("GRB_MXM_UNIT_MID")) c.mxm_unit_mid = atoi(e);
-    if (const char *e = getenv("GRB_MXM_BITMAP_POOL_MB")) c.mxm_bitmap_pool_mb = atoll(e);
-    if (const char *e = getenv("GRB_MXM_BITMAP_MIN_CNT")) c.mxm_bitmap_min_cnt = atoi(e);
-    if (const char *e = getenv("GRB_LONG_KERNEL")) c.long_kernel = atoi(e);
-    if (const char *e = getenv("GRB_LONG_CLASSES")) c.long_classes = atoi(e);
-    if (const char *e = getenv("GRB_SPLIT_MIN_LEN")) c.split_min_len = atoi(e);
-    if (const char *e = getenv("GRB_LONG_SUB")) c.long_sub = atoi(e);
-    if (const char *e = getenv("GRB_LONG_SUB_MIN_LEN")) c.long_sub_min_len = atoi(e);
+    // tuning knobs from the environment go through the same validation as GrX_option_set (an invalid value is ignored)
+    static const struct { const char *env, *opt; } knobs[] = {
+        {"GRB_PULL_IPT", "pull_ipt"}, {"GRB_HOT_MIN_COLS", "hot_min_cols"}, {"GRB_HOT_K", "hot_k"}, {"GRB_PUSH_MODE", "push_mode"},
+        {"GRB_ALLOC_CACHE", "alloc_cache"}, {"GRB_SHORT_KERNEL", "short_kernel"}, {"GRB_SELL_SIGMA", "sell_sigma"},
+        {"GRB_LAZY_LAYOUT", "lazy_layout"}, {"GRB_MXM_HEAVY_KERNEL", "mxm_heavy_kernel"}, {"GRB_DROP_HOT_COLS", "drop_hot_cols"},
+        {"GRB_MXM_UNIT_MIN_FLOPS", "mxm_unit_min_flops"}, {"GRB_MXM_UNIT_MIN_PER_WINDOW", "mxm_unit_min_per_window"},
+        {"GRB_MXM_UNIT_SMALL", "mxm_unit_small"}, {"GRB_MXM_UNIT_DENSE", "mxm_unit_dense"}, {"GRB_MXM_UNIT_MID", "mxm_unit_mid"},
+        {"GRB_MXM_BITMAP_POOL_MB", "mxm_bitmap_pool_mb"}, {"GRB_MXM_BITMAP_MIN_CNT", "mxm_bitmap_min_cnt"},
+        {"GRB_LONG_KERNEL", "long_kernel"}, {"GRB_LONG_CLASSES", "long_classes"}, {"GRB_SPLIT_MIN_LEN", "split_min_len"},
+        {"GRB_LONG_SUB", "long_sub"}, {"GRB_LONG_SUB_MIN_LEN", "long_sub_min_len"},
+    };
+    for (const auto &k : knobs)
+        if (const char *e = getenv(k.env)) (void)GrX_option_set(k.opt, atoll(e));
     c.initialized = true;
     return GrB_SUCCESS;
 }
@@ -259,6 +251,20 @@ extern "C" GrB_Info GrX_synchronize(void)
     GRB_CATCH(nullptr)
 }
 
+extern "C" GrB_Info GrX_trim_memory(void)
+{
+    GRB_TRY
+    require_init();
+    sync_stream();
+    dev_cache_release();
+    sync_stream();
+    int dev = 0;
+    hipMemPool_t pool;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) (void)hipMemPoolTrimTo(pool, 0);
+    (void)hipGetLastError();
+    GRB_CATCH(nullptr)
+}
+
 extern "C" GrB_Info GrX_timer_start(void)
 {
     GRB_TRY
@@ -299,14 +305,14 @@ extern "C" GrB_Info GrX_option_set(const char *name, int64_t value)
     else if (n == "hot_k") c.hot_k = value;
     else if (n == "push_mode") c.push_mode = (int)value;
     else if (n == "split_min_nnz") c.split_min_nnz = value;
-    else if (n == "split_min_len") c.split_min_len = (int)value;
+    else if (n == "split_min_len") c.split_min_len = (int)std::max<int64_t>(0, std::min<int64_t>(value, 1 << 30));
     else if (n == "short_kernel") c.short_kernel = (int)value;
     else if (n == "lazy_layout") c.lazy_layout = (int)value;
     else if (n == "lazy_min_nnz") c.lazy_min_nnz = value;
     else if (n == "long_kernel") c.long_kernel = (int)value;
     else if (n == "long_classes") c.long_classes = (value == 16 || value == 32 || value == 64) ? (int)value : 8;
     else if (n == "sell_sigma") c.sell_sigma = (int)value;
-    else if (n == "long_sub") c.long_sub = (int)value;
+    else if (n == "long_sub") c.long_sub = (int)std::max<int64_t>(0, std::min<int64_t>(value, 16));
     else if (n == "long_sub_min_len") c.long_sub_min_len = (int)value;
     else if (n == "mxm_mask_mode") c.mxm_mask_mode = (int)value;
     else if (n == "mxm_heavy_kernel") c.mxm_heavy_kernel = (int)value;
@@ -314,9 +320,10 @@ extern "C" GrB_Info GrX_option_set(const char *name, int64_t value)
     else if (n == "mxm_unit_min_flops") c.mxm_unit_min_flops = value;
     else if (n == "mxm_unit_min_per_window") c.mxm_unit_min_per_window = value;
     else if (n == "mxm_masked_units_min_flops") c.mxm_masked_units_min_flops = value;
-    else if (n == "mxm_unit_small") c.mxm_unit_small = (int)value;
-    else if (n == "mxm_unit_dense") c.mxm_unit_dense = (int)value;
-    else if (n == "mxm_unit_mid") c.mxm_unit_mid = (int)value;
+    else if (n == "mxm_unit_small" || n == "mxm_unit_dense" || n == "mxm_unit_mid") {  // class limits of the SpGEMM units: entry counts
+        if (value < 1 || value > (1 << 30)) return GrB_INVALID_VALUE;
+        (n == "mxm_unit_small" ? c.mxm_unit_small : n == "mxm_unit_dense" ? c.mxm_unit_dense : c.mxm_unit_mid) = (int)value;
+    }
     else if (n == "mxm_bitmap_pool_mb") c.mxm_bitmap_pool_mb = value;
     else if (n == "mxm_bitmap_min_cnt") c.mxm_bitmap_min_cnt = (int)value;
     else if (n == "mxm_bitmap_pool_cap") c.mxm_bitmap_pool_cap = value;

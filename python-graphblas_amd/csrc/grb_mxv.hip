@@ -87,6 +87,23 @@ static void ensure_hot(GB_Matrix_opaque *A, size_t value_bytes)
     A->hot_state = 1;
 }
 
+// The re-coded copy of the whole column array is released once the split is built from it (ensure_split); a later rebuild of the
+// split in the hot coding (another long-row kernel or class count was selected) needs it again: re-code from the hot-column list.
+static void restore_hot_cols(GB_Matrix_opaque *A)
+{
+    if (A->d_col_hot || A->hot_state != 1 || !A->d_hot_cols) return;
+    const int64_t n = (int64_t)A->ncols, nnz = A->nvals;
+    DevBuf<int32_t> rank(n);
+    GRB_HIP(hipMemsetAsync(rank.p, 0xff, sizeof(int32_t) * (size_t)n, ctx().stream));
+    hipLaunchKernelGGL(k_hot_rank_scatter, dim3((unsigned)ceil_div(A->hot_k, 256)), dim3(256), 0, ctx().stream, (const int32_t *)A->d_hot_cols,
+                       A->hot_k, rank.p);
+    A->d_col_hot = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)(nnz ? nnz : 1));
+    hipLaunchKernelGGL(k_hot_recode, dim3((unsigned)ceil_div(nnz, 256)), dim3(256), 0, ctx().stream, A->d_col, nnz, (const int32_t *)rank.p,
+                       (int)A->hot_k, A->d_col_hot);
+    sync_stream();  // (rank is released at the end of this scope)
+    A->hot_cols_dropped = false;
+}
+
 template <typename T> struct PullIPT { static constexpr int value = sizeof(T) >= 8 ? 4 : 8; };
 
 static void ensure_tile_table(GB_Matrix_opaque *A, int tile_items)
@@ -147,6 +164,11 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
         A->d_long_bits = nullptr; A->d_long_rows = nullptr; A->d_chunk_slot = nullptr; A->d_chunk_start = nullptr; A->d_chunk_len = nullptr;
     }
     A->split_state = -1;
+    if (hot && A->hot_cols_dropped) {  // (a rebuild in the hot coding after the re-coded columns were released)
+        restore_hot_cols(A);
+        col_src = A->d_col_hot;
+    }
+    if (!col_src) fail(GrB_PANIC, "pull SpMV: the split cannot be built without a column source (internal error)");
     const int64_t m = (int64_t)A->nrows, nnz = A->nvals;
     if (nnz < ctx().split_min_nnz || m == 0 || (ctx().debug_flags & 128)) return;
     const int min_len = ctx().split_min_len > 0 ? ctx().split_min_len : (kind == 2 ? 64 : 256);  // (measured optima, scripts/gpu_r02_nc.sh)
@@ -775,8 +797,22 @@ static void mxv_core(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_Binar
     }
     // long/short row split (large matrices whose long rows hold a good share of the entries)
     if (S->nvals && (S->type->code == st || !need_aval) && !by_rowlen && !lazy) {
-        const bool hot = (a.col == S->d_col_hot);
-        ensure_split(S, a.col, hot);
+        bool hot = (a.col == S->d_col_hot);
+        // An existing split is never rebuilt because a call comes with the other column coding (mixing row reductions and
+        // products on one matrix used to rebuild the layouts -- tens of milliseconds at scale 24 -- at every call, and a
+        // rebuild after the re-coded columns were released read a null column array): a call that reads no column at all (a
+        // full operand whose values the multiply ignores: the row reductions) takes the split as it is; a call that gathers
+        // with the original column indices while the split holds table codes runs on the plain arrays.  Only a split in the
+        // original coding is replaced when a call can use the hot table.
+        const bool reads_cols = a.need_uval || !a.u_full;
+        if (S->split_state == 1 && S->split_hot != hot && !reads_cols) {
+            hot = S->split_hot;
+            a.col = hot ? S->d_col_hot : S->d_col;
+        } else if (S->split_state == 1 && S->split_hot && !hot) {
+            // (plain path below: a.col is the original column array, which use_split does not match)
+        } else {
+            ensure_split(S, a.col, hot);
+        }
         if (hot && S->hot_cols_dropped) a.col = S->d_col_hot;  // (released when the split was built: the tag of the re-coded columns is now nullptr)
         if (S->split_state == 1 && S->split_hot == hot) {
             a.long_rows = S->d_long_rows;

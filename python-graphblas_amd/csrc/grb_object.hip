@@ -1091,7 +1091,7 @@ extern "C" GrB_Info GrB_Matrix_exportHint(GrB_Format *format, const GrB_Matrix A
 }
 
 // ---- device-side comparison (reference Matrix.isequal / isclose, core/matrix.py:373-467: same shape, same pattern, values equal /
-//      within rel_tol * |b| + abs_tol after a cast to a common type) -- nothing travels to the host but the verdict ----------------
+//      within max(rel_tol * max(|a|, |b|), abs_tol) after a cast to a common type) -- nothing travels to the host but the verdict ----------------
 template <typename T>
 __global__ void k_mat_compare(const int64_t *Ap, const int64_t *Bp, int64_t m1, const int32_t *Aj, const int32_t *Bj, const T *Ax, int a_iso,
                               const T *Bx, int b_iso, int64_t nnz, double rel_tol, double abs_tol, int *differ)
@@ -1105,8 +1105,10 @@ __global__ void k_mat_compare(const int64_t *Ap, const int64_t *Bp, int64_t m1, 
         if (rel_tol == 0.0 && abs_tol == 0.0) bad = bad || !(x == y);
         else {
             const double dx = (double)x, dy = (double)y;
-            const double d = dx > dy ? dx - dy : dy - dx, ay = dy < 0 ? -dy : dy;
-            bad = bad || !(d <= rel_tol * ay + abs_tol || dx == dy);
+            // the reference's _isclose (core/operator/binary.py:329): x == y or |x - y| <= max(rel_tol * max(|x|, |y|), abs_tol)
+            const double d = dx > dy ? dx - dy : dy - dx, ax = dx < 0 ? -dx : dx, ay = dy < 0 ? -dy : dy;
+            const double rt = rel_tol * (ax > ay ? ax : ay);
+            bad = bad || !(dx == dy || d <= (rt > abs_tol ? rt : abs_tol));
         }
     }
     if (__ballot(bad) && (threadIdx.x & 63) == 0) *differ = 1;
@@ -1128,9 +1130,13 @@ extern "C" GrB_Info GrX_Matrix_isclose(bool *result, const GrB_Matrix A, const G
     // values in a common type: the wider of the two (FP64 when they differ in kind)
     int ct = A->type->code;
     if (B->type->code != ct) ct = (A->type->code >= TC_FP32 || B->type->code >= TC_FP32) ? TC_FP64 : (A->type->size >= B->type->size ? A->type->code : B->type->code);
-    GB_Matrix_opaque *Ac = ct == A->type->code ? nullptr : matrix_cast_copy(A, ct);
-    GB_Matrix_opaque *Bc = ct == B->type->code ? nullptr : matrix_cast_copy(B, ct);
-    const GB_Matrix_opaque *X = Ac ? Ac : A, *Y = Bc ? Bc : B;
+    struct Owned {  // (typecast copies are released on every way out, also when a launch or the read-back throws)
+        GB_Matrix_opaque *p = nullptr;
+        ~Owned() { if (p) matrix_free(p); }
+    } Ac, Bc;
+    if (ct != A->type->code) Ac.p = matrix_cast_copy(A, ct);
+    if (ct != B->type->code) Bc.p = matrix_cast_copy(B, ct);
+    const GB_Matrix_opaque *X = Ac.p ? Ac.p : A, *Y = Bc.p ? Bc.p : B;
     DevBuf<int> differ(1, true);
     const int64_t threads = std::max<int64_t>((int64_t)A->nrows + 1, A->nvals);
     GRB_DISPATCH_TYPE(ct, T, {
@@ -1139,8 +1145,6 @@ extern "C" GrB_Info GrX_Matrix_isclose(bool *result, const GrB_Matrix A, const G
     })
     int h = 0;
     d2h(&h, differ.p, sizeof(int));
-    if (Ac) matrix_free(Ac);
-    if (Bc) matrix_free(Bc);
     *result = h == 0;
     GRB_CATCH(errp(A))
 }

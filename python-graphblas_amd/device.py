@@ -93,6 +93,27 @@ def vector_device_views(v, device="cuda"):
     return vals, words
 
 
+def matrix_device_views(A):
+    """(indptr int64[nrows+1], col int32[nvals], values[nvals] or [1] when iso, iso) torch CUDA tensors ALIASING A's CSR in HBM
+    (valid until A is modified or freed) -- for checks that stay on the device."""
+    import torch
+
+    dp, dj, dx = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+    nv, iso = ctypes.c_uint64(), ctypes.c_int()
+    call_on(A, "GrX_Matrix_export_CSR_device", [ctypes.byref(dp), ctypes.byref(dj), ctypes.byref(dx), ctypes.byref(nv), ctypes.byref(iso), A._handle])
+    nnz = int(nv.value)
+    indptr = torch.as_tensor(_CudaView(dp.value, (A._nrows + 1,), "<i8"), device="cuda")
+    col = torch.as_tensor(_CudaView(dj.value, (max(nnz, 1),), "<i4"), device="cuda")[:nnz]
+    nx = 1 if iso.value else nnz
+    vals = torch.as_tensor(_CudaView(dx.value, (max(nx, 1),), np.dtype(A.dtype.np_type).str), device="cuda")[:nx]
+    return indptr, col, vals, bool(iso.value)
+
+
+def trim_memory():
+    """Hand the library's cached device memory back to the driver (between bench phases with different footprints)."""
+    call_on(None, "GrX_trim_memory", [])
+
+
 def synchronize():
     call_on(None, "GrX_synchronize", [])
 

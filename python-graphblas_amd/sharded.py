@@ -29,6 +29,17 @@ def row_block(n, rank, world):
     return rank * rows, (rank + 1) * rows
 
 
+def chunk_blocks(n, rank, world, chunks):
+    """Row blocks of ``rank`` when every rank owns ``chunks`` blocks instead of one: block c = rows
+    [c * n / chunks + rank * h, ... + h) with h = n / (chunks * world), 64-row aligned.  The slices of chunk c of all ranks are
+    contiguous in u, in rank order: ONE all-gather per chunk lands them in place, and the exchange of chunk c can run while
+    chunk c + 1 is being computed (``OverlappedMxv``)."""
+    if n % (64 * world * chunks):
+        raise ValueError("n must be a multiple of 64 * world_size * chunks")
+    h = n // (world * chunks)
+    return [(c * (n // chunks) + rank * h, c * (n // chunks) + (rank + 1) * h) for c in range(chunks)]
+
+
 def balanced_cuts(weight_prefix, world, align=64):
     """Row cuts [c_0 = 0, c_1, ..., c_world = m] such that every block carries about the same weight.
 
@@ -167,6 +178,127 @@ def allgather_delta_into(u_full, w_local, cuts, *, device="cuda", dense_above=0.
     return int(all_counts[:, 0].sum())
 
 
+def _gather_async(dist, out, part):
+    """all-gather `part` of every rank into `out` (rank order), asynchronously; returns the work handle."""
+    try:
+        return dist.all_gather_into_tensor(out, part, async_op=True)
+    except (RuntimeError, NotImplementedError):  # backends without the flat variant
+        return dist.all_gather(list(out.chunk(dist.get_world_size())), part, async_op=True)
+
+
+class OverlappedMxv:
+    """The row-sharded pull step  w<mask> = accum(w, A (+.x) u)  followed by the exchange of the w slices into the next u, with
+    the exchange OVERLAPPED with compute (reference call graphblas/core/matrix.py:2203-2262).
+
+    Every rank owns ``chunks`` row blocks (``chunk_blocks``) with their own matrix, output and mask objects, and there are TWO
+    replicas of u: step k reads replica k % 2 and the slices land in replica (k + 1) % 2, so nothing a product still reads is
+    overwritten.  Per step: product of chunk 0 -> its all-gather is issued asynchronously (on the GPU: RCCL's own stream, ordered
+    behind the product by an event) -> product of chunk 1 runs meanwhile -> ... -> wait for all exchanges.  With one chunk this
+    is the plain step (product, then all-gather).  Values always travel; presence words only when ``presence`` (an output that
+    is not full: the BFS step -- min_plus relaxations with a full u keep u and w full).
+
+    The products go straight to the C ABI (``GrB_mxv`` with pre-resolved handles).  ``device="cpu"``: the gloo tests over the
+    emulator build, where the vectors' images live in host memory."""
+
+    def __init__(self, A_blocks, w_blocks, mask_blocks, u_pair, semiring, *, accum=None, desc_name=None, presence=False,
+                 device="cuda"):
+        import ctypes
+
+        import torch.distributed as dist
+
+        from . import _lib
+        from . import device as dev
+
+        self.dist, self.dev, self.device = dist, dev, device
+        self.chunks = len(A_blocks)
+        self.A, self.w, self.mask, self.u = list(A_blocks), list(w_blocks), list(mask_blocks), list(u_pair)
+        self.presence = presence
+        self.k = 0
+        self.staged = False
+        n = self.u[0]._size
+        world = dist.get_world_size()
+        if n % (64 * world * self.chunks):
+            raise ValueError("n must be a multiple of 64 * world_size * chunks")
+        self.n, self.world, self.h = n, world, n // (world * self.chunks)
+        desc = ctypes.c_void_p(_lib.handle(desc_name)) if desc_name else None
+        self._call = _lib.lib.GrB_mxv
+        self._args = [[(self.w[c]._carg, self.mask[c]._carg if self.mask[c] is not None else None, accum._carg if accum is not None else None,
+                        semiring._carg, self.A[c]._carg, self.u[r]._carg, desc) for c in range(self.chunks)] for r in range(2)]
+        self._views()
+
+    def _views(self):
+        as_u8 = lambda t: t.view(self._torch().uint8) if t.dtype == self._torch().bool else t
+        self.u_vals, self.u_words, self.w_vals, self.w_words = [], [], [], []
+        for r in range(2):
+            v, b = self.dev.vector_device_views(self.u[r], self.device)
+            self.u_vals.append(as_u8(v))
+            self.u_words.append(b)
+        for c in range(self.chunks):
+            v, b = self.dev.vector_device_views(self.w[c], self.device)
+            self.w_vals.append(as_u8(v))
+            self.w_words.append(b)
+
+    @staticmethod
+    def _torch():
+        import torch
+
+        return torch
+
+    def current_u(self):
+        """The replica the NEXT step reads."""
+        return self.u[self.k & 1]
+
+    def _exchange(self, c, dst):
+        n_c, h = self.n // self.chunks, self.h
+        out_v = self.u_vals[dst][c * n_c: (c + 1) * n_c]
+        part_v = self.w_vals[c][:h]
+        works = []
+        if self.staged:
+            torch = self._torch()
+            send = part_v.clone()
+            recv = torch.empty(n_c, dtype=send.dtype, device=send.device)
+            self.dist.all_gather_into_tensor(recv, send)
+            out_v.copy_(recv)
+        else:
+            works.append(_gather_async(self.dist, out_v, part_v))
+        if self.presence:
+            out_b = self.u_words[dst][c * n_c // 32: (c + 1) * n_c // 32]
+            part_b = self.w_words[c][: h // 32]
+            if self.staged:
+                torch = self._torch()
+                send = part_b.clone()
+                recv = torch.empty(n_c // 32, dtype=send.dtype, device=send.device)
+                self.dist.all_gather_into_tensor(recv, send)
+                out_b.copy_(recv)
+            else:
+                works.append(_gather_async(self.dist, out_b, part_b))
+        return works
+
+    def probe_exchange(self):
+        """One untimed exchange of what the vectors hold now, to find out whether the collective accepts the library's own device
+        memory (stream-ordered HIP pool); should it refuse, the exchanges are staged through torch-owned tensors from then on."""
+        try:
+            for wk in self._exchange(0, self.k & 1 ^ 1):
+                wk.wait()
+        except RuntimeError:
+            self.staged = True
+            self._exchange(0, self.k & 1 ^ 1)
+
+    def step(self):
+        src, dst = self.k & 1, (self.k + 1) & 1
+        works = []
+        for c in range(self.chunks):
+            rc = self._call(*self._args[src][c])
+            if rc != 0:
+                raise RuntimeError(f"GrB_mxv failed with GrB_Info {rc}")
+            works += self._exchange(c, dst)
+        for wk in works:
+            wk.wait()
+        if self.presence:
+            self.dev.vector_modified(self.u[dst])
+        self.k += 1
+
+
 _REDUCE_OF = {"min": "MIN", "max": "MAX", "plus": "SUM", "lor": "MAX", "land": "MIN", "any": "MAX"}
 
 
@@ -187,6 +319,11 @@ def allreduce_monoid(t, monoid_name, identity, *, device="cuda"):
     shifts = torch.arange(32, device=words.device, dtype=torch.int32)
     present = ((words.view(-1, 1) >> shifts) & 1).to(torch.bool).view(-1)[:n]
     as_num = vals.view(torch.uint8) if vals.dtype == torch.bool else vals
+    if monoid_name == "any":
+        # ANY has no identity: a rank without the entry must never win the MAX, so it contributes the smallest value of the
+        # type (then the result is one of the ranks' products whatever their signs -- any of them is a valid ANY)
+        identity = (-float("inf") if as_num.dtype.is_floating_point else
+                    (0 if as_num.dtype == torch.uint8 else torch.iinfo(as_num.dtype).min))
     ident = torch.as_tensor(identity, dtype=as_num.dtype, device=as_num.device)
     as_num.copy_(torch.where(present, as_num, ident))
     dist.all_reduce(as_num, op=getattr(dist.ReduceOp, _REDUCE_OF[monoid_name]))

@@ -10,11 +10,13 @@ import numpy as np
 
 
 def rmat_csr(scale, edge_factor=16, *, seed=None, device="cuda", abcd=(0.57, 0.19, 0.19, 0.05), row_range=None,
-             chunk_edges=1 << 27):
+             row_ranges=None, chunk_edges=1 << 27):
     """Returns (indptr int64[n_rows+1], col int32[nnz]) torch tensors on ``device``; sorted, deduped.
 
     ``row_range=(lo, hi)`` keeps only rows lo..hi-1 (1-D row sharding: every rank draws the same
     edge stream from the same seed and keeps its block), re-based so that row lo becomes row 0.
+    ``row_ranges=[(lo, hi), ...]`` does the same for several blocks from ONE pass over the edge stream
+    and returns a list of (indptr, col) pairs (a rank that owns several row blocks: sharded.OverlappedMxv).
     """
     import torch
 
@@ -25,8 +27,9 @@ def rmat_csr(scale, edge_factor=16, *, seed=None, device="cuda", abcd=(0.57, 0.1
     gen.manual_seed(1000 + seed)
     perm = torch.randperm(n, generator=gen, device=device)
     a, b, c, _ = abcd
-    lo, hi = row_range if row_range is not None else (0, n)
-    keys = []
+    ranges = list(row_ranges) if row_ranges is not None else [row_range if row_range is not None else (0, n)]
+    whole = row_ranges is None and row_range is None
+    keys = [[] for _ in ranges]
     done = 0
     while done < n_edges:
         m = min(chunk_edges, n_edges - done)
@@ -40,21 +43,26 @@ def rmat_csr(scale, edge_factor=16, *, seed=None, device="cuda", abcd=(0.57, 0.1
             dst = (dst << 1) | dst_bit
         src = perm[src]
         dst = perm[dst]
-        if row_range is not None:
-            keep = (src >= lo) & (src < hi)
-            src, dst = src[keep], dst[keep]
-        keys.append(torch.unique((src - lo) * n + dst))
+        for k, (lo, hi) in enumerate(ranges):
+            if whole:
+                keys[k].append(torch.unique(src * n + dst))
+            else:
+                keep = (src >= lo) & (src < hi)
+                keys[k].append(torch.unique((src[keep] - lo) * n + dst[keep]))
         del src, dst
         done += m
-    key = torch.unique(torch.cat(keys)) if len(keys) > 1 else keys[0]
-    del keys
-    rows = hi - lo
-    row = torch.div(key, n, rounding_mode="floor")
-    col = (key - row * n).to(torch.int32)
-    counts = torch.bincount(row, minlength=rows)
-    indptr = torch.zeros(rows + 1, dtype=torch.int64, device=device)
-    indptr[1:] = torch.cumsum(counts, 0)
-    return indptr, col
+    out = []
+    for k, (lo, hi) in enumerate(ranges):
+        key = torch.unique(torch.cat(keys[k])) if len(keys[k]) > 1 else keys[k][0]
+        keys[k] = None
+        rows = hi - lo
+        row = torch.div(key, n, rounding_mode="floor")
+        col = (key - row * n).to(torch.int32)
+        counts = torch.bincount(row, minlength=rows)
+        indptr = torch.zeros(rows + 1, dtype=torch.int64, device=device)
+        indptr[1:] = torch.cumsum(counts, 0)
+        out.append((indptr, col))
+    return out if row_ranges is not None else out[0]
 
 
 def edge_weights(col, seed, dtype=None, device=None):

@@ -61,6 +61,7 @@ inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t bytes, hipMemcpy
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 inline hipError_t hipDeviceGetDefaultMemPool(hipMemPool_t *p, int) { *p = nullptr; return hipSuccess; }
 inline hipError_t hipMemPoolSetAttribute(hipMemPool_t, hipMemPoolAttr, void *) { return hipSuccess; }
+inline hipError_t hipMemPoolTrimTo(hipMemPool_t, size_t) { return hipSuccess; }
 inline hipError_t hipEventCreate(hipEvent_t *e) { *e = (hipEvent_t)malloc(8); return hipSuccess; }
 inline hipError_t hipEventDestroy(hipEvent_t e) { free(e); return hipSuccess; }
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t);

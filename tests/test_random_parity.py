@@ -551,6 +551,67 @@ def test_long_short_row_split(gb, seed):
         _lib.lib.GrX_option_set(b"long_classes", 16)
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_split_survives_mixed_calls_and_option_changes(gb, seed):
+    """A product builds the hot-coded split and releases the re-coded column copy; then a row reduction (a call that reads no
+    column), the same product again, a product that gathers with the ORIGINAL column indices (a typecast of the values cannot take
+    the split), and a change of the class count (a rebuild in the hot coding, which needs the re-coded columns back): none of
+    them may rebuild from a released array, and the reduction must not throw the hot-coded split away."""
+    from graphblas_amd import _lib, device
+
+    rng = np.random.default_rng(4400 + seed)
+    tname = ["FP32", "INT64", "FP64", "INT32"][seed]
+    m, n = int(rng.integers(80, 300)), int(rng.integers(2100, 4000))
+    deg = rng.integers(0, 6, m)
+    for ln in (9, 64, 65, 513, 2049):
+        deg[rng.integers(0, m)] = ln
+    # skewed columns (the hot-column table is only built for those): most entries land in a twentieth of the columns
+    hot = rng.permutation(n)[: n // 20]
+    rows = np.repeat(np.arange(m), deg)
+    cols = np.where(rng.random(rows.size) < 0.8, hot[rng.integers(0, hot.size, rows.size)], rng.integers(0, n, rows.size))
+    key = np.unique(rows * n + cols)
+    rows, cols = key // n, key % n
+    deg = np.bincount(rows, minlength=m)
+    vals = rand_vals(rng, rows.size, tname)
+    ui, uv = rand_vec(rng, n, [1.0, 0.5][seed & 1], tname)
+    oa, ou = O.OMat.from_coo(rows, cols, vals, m, n, tname), O.OVec(n, ui, uv, tname)
+    exp = O.mxv(oa, ou, "min_plus")
+    try:
+        for name, val in ((b"split_min_nnz", 1), (b"split_min_len", 8), (b"push_mode", 0), (b"hot_min_cols", 8), (b"hot_k", 64),
+                          (b"long_kernel", 2), (b"long_classes", 16), (b"vec_pad_min_bytes", 0)):
+            _lib.lib.GrX_option_set(name, val)
+        A = gb.Matrix.from_coo(rows, cols, vals, dtype=tname, nrows=m, ncols=n)
+        u = gb.Vector.from_coo(ui, uv, dtype=tname, size=n)
+        same_vec(A.mxv(u, gb.semiring.min_plus).new(), exp)
+        st = device.last_stats()
+        assert st["hot_k"] > 0 and st["long_kernel"] == 2 and st["long_entries"] > 0
+        red = A.reduce_rowwise(gb.monoid.plus).new()
+        assert device.last_stats()["long_kernel"] == 2  # (took the hot-coded split as it is)
+        ri, rv = red.to_coo()
+        want = np.zeros(m, vals.dtype)
+        np.add.at(want, rows, vals)
+        assert ri.tolist() == np.flatnonzero(deg).tolist() and rv.tolist() == want[deg > 0].tolist()
+        same_vec(A.mxv(u, gb.semiring.min_plus).new(), exp)
+        assert device.last_stats()["long_kernel"] == 2
+        other = "FP64" if tname != "FP64" else "INT32"
+        u2 = gb.Vector.from_coo(ui, uv.astype(O.NP_OF[other]), dtype=other, size=n)
+        g2 = A.mxv(u2, gb.semiring.plus_times).new()
+        e2 = O.mxv(oa, O.OVec(n, ui, uv.astype(O.NP_OF[other]), other), "plus_times")
+        gi2, gv2 = g2.to_coo()
+        assert gi2.tolist() == e2.idx.tolist() and np.allclose(gv2.astype(np.float64), e2.vals.astype(np.float64), rtol=1e-6)
+        for ncls, kernel in ((32, 2), (32, 1), (16, 2)):
+            _lib.lib.GrX_option_set(b"long_classes", ncls)
+            _lib.lib.GrX_option_set(b"long_kernel", kernel)
+            same_vec(A.mxv(u, gb.semiring.min_plus).new(), exp)
+            assert device.last_stats()["long_kernel"] == kernel
+            red2 = A.reduce_rowwise(gb.monoid.plus).new()
+            assert red2.isequal(red)
+    finally:
+        for name, val in ((b"split_min_nnz", 1 << 22), (b"split_min_len", 0), (b"push_mode", 1), (b"hot_min_cols", 1 << 20), (b"hot_k", 0),
+                          (b"long_kernel", DEFAULT_LONG_KERNEL), (b"long_classes", 16), (b"vec_pad_min_bytes", 1 << 20)):
+            _lib.lib.GrX_option_set(name, val)
+
+
 @pytest.mark.parametrize("seed", range(18))
 def test_short_rows_lane_kernel(gb, seed):
     """short_kernel = 4: a lane per row over the group's entries staged in LDS (4-byte types, a FULL operand whose values are

@@ -376,3 +376,125 @@ def test_row_sharded_mxm_flop_balanced():
         assert res[r][2] == blk.indptr.tolist() and res[r][3] == blk.indices.tolist() and res[r][4] == blk.data.tolist()
         blkm = refm[lo:hi]
         assert res[r][5] == blkm.indptr.tolist() and res[r][6] == blkm.indices.tolist() and res[r][7] == blkm.data.tolist()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the overlapped step bench.py --gpus N runs (sharded.OverlappedMxv): every rank owns `chunks` row blocks, two replicas of u,
+# the all-gather of block c is issued asynchronously while block c + 1 is computed
+# ---------------------------------------------------------------------------------------------------------------------
+def _overlap_worker(rank, world, port, q, scale, iters, chunks, kind):
+    gb, dist = _init(rank, world, port)
+    import torch
+
+    from graphblas_amd import device, sharded, synthetic
+
+    n = 1 << scale
+    ranges = sharded.chunk_blocks(n, rank, world, chunks)
+    graphs = synthetic.rmat_csr(scale, device="cpu", row_ranges=ranges)
+    full_ip, full_col = synthetic.rmat_csr(scale, device="cpu")
+    wts_full = synthetic.edge_weights(full_col, scale)
+    g = torch.Generator().manual_seed(11)
+    dist0 = torch.randint(0, 1000, (n,), generator=g).to(torch.float32).numpy()
+    frontier = (torch.rand(n, generator=g) < 0.3).numpy()
+    visited = (torch.rand(n, generator=g) < 0.5).numpy()
+    As, ws, masks = [], [], []
+    for (lo, hi), (ip, col) in zip(ranges, graphs):
+        assert torch.equal(col, full_col[full_ip[lo]: full_ip[hi]])
+        vloc = np.flatnonzero(visited[lo:hi])
+        masks.append(gb.Vector.from_coo(vloc, np.ones(vloc.size, bool), dtype="BOOL", size=hi - lo))
+        if kind == "min_plus":
+            As.append(device.matrix_from_device_csr(ip, col, wts_full[full_ip[lo]: full_ip[hi]].contiguous(), hi - lo, n, "FP32", copy=True))
+            ws.append(gb.Vector.from_coo(np.arange(hi - lo), dist0[lo:hi], dtype="FP32", size=hi - lo))
+        else:
+            As.append(device.matrix_from_device_csr(ip, col, torch.ones(1, dtype=torch.bool), hi - lo, n, "BOOL", copy=True, iso=True))
+            floc = np.flatnonzero(frontier[lo:hi])
+            ws.append(gb.Vector.from_coo(floc, np.ones(floc.size, bool), dtype="BOOL", size=hi - lo))
+    if kind == "min_plus":
+        us = [gb.Vector.from_coo(np.arange(n), dist0, dtype="FP32", size=n) for _ in range(2)]
+        ov = sharded.OverlappedMxv(As, ws, masks, us, gb.semiring.min_plus["FP32"], accum=gb.binary.min["FP32"], desc_name="GrB_DESC_SC",
+                                   presence=False, device="cpu")
+    else:
+        fi = np.flatnonzero(frontier)
+        us = [gb.Vector.from_coo(fi, np.ones(fi.size, bool), dtype="BOOL", size=n) for _ in range(2)]
+        ov = sharded.OverlappedMxv(As, ws, masks, us, gb.semiring.lor_land["BOOL"], desc_name="GrB_DESC_RSC", presence=True, device="cpu")
+    ov.probe_exchange()
+    for _ in range(iters):
+        ov.step()
+    ui, uv = ov.current_u().to_coo()
+    q.put((rank, (ui.tolist(), uv.tolist(), ranges, ov.staged)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind,chunks,world", [("min_plus", 2, 2), ("lor_land", 2, 2), ("min_plus", 1, 2), ("lor_land", 4, 2)])
+def test_overlapped_sharded_step(kind, chunks, world):
+    """The step of `bench.py --gpus N`: `chunks` row blocks per rank, asynchronous all-gather of every block's slices into the
+    other replica of u while the next block is computed.  Three steps of the masked min_plus relaxation (values travel) and of the
+    BFS level step (values and presence words travel) equal the single-process oracle on every rank."""
+    import torch
+
+    from graphblas_amd import synthetic
+    from oracle import grb_oracle as O
+
+    scale, iters = 10, 3
+    res = _spawn(_overlap_worker, world, (scale, iters, chunks, kind))
+    n = 1 << scale
+    ip, col = synthetic.rmat_csr(scale, device="cpu")
+    g = torch.Generator().manual_seed(11)
+    dist0 = torch.randint(0, 1000, (n,), generator=g).to(torch.float32).numpy()
+    frontier = (torch.rand(n, generator=g) < 0.3).numpy()
+    visited = (torch.rand(n, generator=g) < 0.5).numpy()
+    ovis = O.OVec(n, np.flatnonzero(visited), np.ones(int(visited.sum()), bool), "BOOL")
+    if kind == "min_plus":
+        oa = O.OMat(n, n, ip.numpy(), col.numpy().astype(np.int64), synthetic.edge_weights(col, scale).numpy(), "FP32")
+        ou = O.OVec(n, np.arange(n), dist0, "FP32")
+        for _ in range(iters):
+            ou = O.mxv(oa, ou, "min_plus", w=ou, mask=ovis, mask_comp=True, mask_struct=True, accum="min")
+    else:
+        oa = O.OMat(n, n, ip.numpy(), col.numpy().astype(np.int64), np.ones(col.numel(), bool), "BOOL")
+        fi = np.flatnonzero(frontier)
+        ou = O.OVec(n, fi, np.ones(fi.size, bool), "BOOL")
+        for _ in range(iters):
+            ou = O.mxv(oa, ou, "lor_land", w=ou, mask=ovis, mask_comp=True, mask_struct=True, replace=True)
+        assert ou.idx.size > 0
+    blocks = sorted(b for r in range(world) for b in res[r][2])
+    assert blocks[0][0] == 0 and blocks[-1][1] == n and all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))  # the blocks tile the rows
+    for r in range(world):
+        assert res[r][0] == ou.idx.tolist() and res[r][1] == ou.vals.tolist()
+        assert res[r][3] is False
+
+
+def _any_worker(rank, world, port, q):
+    gb, dist = _init(rank, world, port)
+    from graphblas_amd import sharded
+
+    n = 192
+    # rank 0 has entries at 0..63 (negative), rank 1 at 32..127 (negative): 32..63 on both, 128.. on none
+    lo, hi = (0, 64) if rank == 0 else (32, 128)
+    idx = np.arange(lo, hi)
+    vals = (-(idx + 1) * (rank + 2)).astype(np.int64)
+    t = gb.Vector.from_coo(idx, vals, dtype="INT64", size=n)
+    sharded.allreduce_monoid(t, "any", 0, device="cpu")
+    gi, gv = t.to_coo()
+    tf = gb.Vector.from_coo(idx, vals.astype(np.float32), dtype="FP32", size=n)
+    sharded.allreduce_monoid(tf, "any", 0, device="cpu")
+    fi, fv = tf.to_coo()
+    q.put((rank, (gi.tolist(), gv.tolist(), fi.tolist(), fv.tolist())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_any_monoid_allreduce_with_negative_values():
+    """ANY has no identity: a rank that lacks an entry must not contribute a value.  With negative products the result of the
+    all-reduce has to be one of the ranks' values (it used to be 0 = the filler of the absent side)."""
+    res = _spawn(_any_worker, 2, ())
+    for r in range(2):
+        gi, gv, fi, fv = res[r]
+        assert gi == list(range(128)) == fi
+        for i, v, f in zip(gi, gv, fv):
+            cands = set()
+            if i < 64:
+                cands.add(-(i + 1) * 2)
+            if i >= 32:
+                cands.add(-(i + 1) * 3)
+            assert v in cands and int(f) in cands and v < 0
