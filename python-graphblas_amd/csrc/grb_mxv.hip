@@ -422,7 +422,8 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
                            a.col == (A->split_hot ? A->d_col_hot : A->d_col) && a.n_chunks > 0;
     if (use_split) {
         GB_Matrix_opaque *S = A->short_part;
-        DevBuf<W> tl_val(a.n_long);
+        // (ablation build GRB_STRIP_ABL & 32: one scratch slot per lane of every chunk)
+        DevBuf<W> tl_val((GRB_STRIP_ABL & 32) ? std::max<int64_t>(a.n_long, (A->strip_cb[A->strip_ncls > 0 ? A->strip_ncls : 0] + 1) * 64) : a.n_long);
         DevBuf<unsigned char> tl_has(a.n_long);
         const bool by_strip = A->split_kind == 2 && A->long_nnz > 0 && A->strip_nseg > 0;
         ctx().stats.long_entries = A->nvals - S->nvals;

@@ -22,7 +22,7 @@ build)
 run)
   cd "$ROOT"
   one() {
-    GRB_SPLIT_MIN_LEN=${GRB_SPLIT_MIN_LEN:-256} python bench.py --steps 30 --no-cpu-baseline --extra 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$1', round(d['ms_per_step'],4), [(e['workload'], round(e['ms_per_step'],4)) for e in d['extra']])"
+    python bench.py --steps 30 --no-cpu-baseline --no-extra ${VARIANT_BENCH_ARGS:-} 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$1', round(d['ms_per_step'],4), 'verified', d['verified'])"
   }
   unset GRB_MI355X_LIB; one default
   for lib in build/variants/*/libgrb_mi355x.so; do

@@ -38,9 +38,10 @@ def _graph(gb, scale, kind):
 
 
 @pytest.mark.parametrize("scale,kind,sr", [(16, "FP32", "min_plus"), (17, "BOOL", "lor_land"), (16, "INT64", "plus_times"),
-                                           (16, "FP32", "plus_times"), (16, "BOOL", "any_pair")])
+                                           (16, "FP32", "plus_times"), (16, "BOOL", "any_pair"), (20, "FP32", "min_plus")])
 def test_rmat_vs_oracle(gb, scale, kind, sr):
-    """configs[1]-style graphs at oracle-friendly sizes: bit-exact against the CPU oracle."""
+    """configs[1]-style graphs at oracle-friendly sizes -- and configs[1] itself (R-MAT scale 20, FP32 min_plus: 16 M entries, the
+    oracle takes a second per call) -- bit-exact against the CPU oracle."""
     import torch
 
     from graphblas_amd import device
@@ -463,3 +464,125 @@ def test_scale24_headline_calls(gb):
         nv, nb = device.vector_device_views(nxt)
         got = bits(nb)
         assert torch.equal(got, hit & ~visited) and bool(nv[got].all())
+
+
+@pytest.mark.gpu
+def test_kron26_rank_block(gb):
+    """configs[4] (Kronecker scale 26, min_plus FP32, 8 GPUs): rank 0's row block of the 8-way run -- 8 388 608 x 67 108 864,
+    ~134 M entries, generated from the same edge stream every rank draws -- against the CPU oracle, bit for bit: the first call on
+    the plain CSR arrays, the second on the cached layouts (hot-column table over a 256 MiB operand, class strips), unmasked as
+    `bench.py --workload kron26` runs it and under a complemented structural mask; then the BFS step of the same block."""
+    import torch
+
+    from graphblas_amd import device, synthetic
+    from oracle import grb_oracle as O
+
+    scale, world, rank = 26, 8, 0
+    n = 1 << scale
+    rows = n // world
+    lo, hi = rank * rows, (rank + 1) * rows
+    ip_b, col_b = synthetic.rmat_csr(scale, device="cuda", row_range=(lo, hi))
+    assert ip_b.numel() == rows + 1 and 100_000_000 < col_b.numel() < 180_000_000
+    val_b = synthetic.edge_weights(col_b, scale)
+    B = device.matrix_from_device_csr(ip_b, col_b, val_b, rows, n, "FP32")
+    rng = np.random.default_rng(scale)
+    uv = rng.integers(0, 1000, n).astype(np.float32)
+    vb = np.flatnonzero(rng.random(rows) < 0.5)
+    u = device.vector_from_device(torch.from_numpy(uv).cuda())
+    vis_b = gb.Vector.from_coo(vb, np.ones(vb.size, bool), dtype="BOOL", size=rows)
+    ob = O.OMat(rows, n, ip_b.cpu().numpy(), col_b.cpu().numpy().astype(np.int64), val_b.cpu().numpy(), "FP32")
+    ou = O.OVec(n, np.arange(n), uv, "FP32")
+    ow = O.OVec(rows, np.arange(rows), uv[lo:hi], "FP32")
+    exp_plain = O.mxv(ob, ou, "min_plus", w=ow, accum="min")
+    exp_masked = O.mxv(ob, ou, "min_plus", w=ow, mask=O.OVec(rows, vb, np.ones(vb.size, bool), "BOOL"), mask_comp=True, mask_struct=True,
+                       accum="min")
+    for call in range(2):
+        w_b = device.vector_from_device(torch.from_numpy(uv[lo:hi].copy()).cuda())
+        w_b(accum="min") << B.mxv(u, gb.semiring.min_plus)
+        st = device.last_stats()
+        assert (st["hot_k"] > 0) == (call == 1) and (st["long_kernel"] == 2) == (call == 1)
+        wv, _ = device.vector_device_views(w_b)
+        assert np.array_equal(wv.cpu().numpy(), exp_plain.vals)
+    w_b = device.vector_from_device(torch.from_numpy(uv[lo:hi].copy()).cuda())
+    w_b(~vis_b.S, accum="min") << B.mxv(u, gb.semiring.min_plus)
+    wv, _ = device.vector_device_views(w_b)
+    assert np.array_equal(wv.cpu().numpy(), exp_masked.vals) and w_b.nvals == rows
+    del B, w_b
+    one = torch.ones(1, dtype=torch.bool, device="cuda")
+    Bb = device.matrix_from_device_csr(ip_b, col_b, one, rows, n, "BOOL", iso=True)
+    qi = np.flatnonzero(rng.random(n) < 0.3)
+    q = gb.Vector.from_coo(qi, np.ones(qi.size, bool), dtype="BOOL", size=n)
+    for call in range(2):
+        nxt = gb.Vector("BOOL", size=rows)
+        nxt(~vis_b.S, replace=True) << Bb.mxv(q, gb.semiring.lor_land)
+    obb = O.OMat(rows, n, ob.indptr, ob.indices, np.ones(col_b.numel(), bool), "BOOL")
+    expb = O.mxv(obb, O.OVec(n, qi, np.ones(qi.size, bool), "BOOL"), "lor_land", mask=O.OVec(rows, vb, np.ones(vb.size, bool), "BOOL"),
+                 mask_comp=True, mask_struct=True, replace=True)
+    bi, bv = nxt.to_coo()
+    assert np.array_equal(bi.astype(np.int64), expb.idx) and np.array_equal(bv, expb.vals)
+
+
+@pytest.mark.gpu
+def test_mxm_scale16_vs_scipy_on_the_host(gb):
+    """SpGEMM at a size where the (row, column window) unit kernels, the dense units and the hash kernels all run (R-MAT scale 16:
+    0.96 M entries, 0.4 G multiplies, 165 M entries in C), against scipy's csr @ csr computed on the host -- an implementation that
+    shares nothing with this library; INT64 ones, so the comparison is bit for bit over the whole CSR."""
+    sp = pytest.importorskip("scipy.sparse")
+    import torch
+
+    from graphblas_amd import device, synthetic
+
+    scale = 16
+    n = 1 << scale
+    indptr, col = synthetic.rmat_csr(scale, device="cuda")
+    A = device.matrix_from_device_csr(indptr, col, torch.ones(1, dtype=torch.int64, device="cuda"), n, n, "INT64", iso=True)
+    ip, cj = indptr.cpu().numpy(), col.cpu().numpy()
+    S = sp.csr_matrix((np.ones(cj.size, np.int64), cj, ip), shape=(n, n))
+    ref = (S @ S).tocsr()
+    ref.sort_indices()
+    C = A.mxm(A, gb.semiring.plus_times).new()
+    st = device.last_stats()
+    assert st["out_nvals"] == ref.nnz and st["flops"] == int(np.diff(ip)[cj].sum())
+    cp, cjd, cx, _ = device.matrix_device_views(C)
+    assert np.array_equal(cp.cpu().numpy(), ref.indptr)
+    assert np.array_equal(cjd.cpu().numpy(), ref.indices)
+    assert np.array_equal(cx.cpu().numpy(), ref.data)
+    # under the complemented structural mask (the reference pins C<~M.S> at tests/test_matrix.py:359-366 on its 7 x 7 literal)
+    M = A.mxm(A, gb.semiring.plus_times).new(mask=~A.S)
+    pat = sp.csr_matrix((np.ones(cj.size, np.int64), cj, ip), shape=(n, n))
+    inside = ref.multiply(pat).tocsr()  # product restricted to A's pattern (values kept)
+    diff = (ref - inside).tocsr()
+    diff.eliminate_zeros()  # (the product's values are >= 1, so a zero here is exactly an entry inside the pattern)
+    diff.sort_indices()
+    mp, mj, mx, _ = device.matrix_device_views(M)
+    assert np.array_equal(mp.cpu().numpy(), diff.indptr) and np.array_equal(mj.cpu().numpy(), diff.indices)
+    assert np.array_equal(mx.cpu().numpy(), diff.data)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scale,workload", [(18, "mxm_plus_times"), (20, "mxm_plus_times"), (22, "mxm_plus_times"), (22, "mxm_plus_times_masked")])
+def test_mxm_bench_sizes_with_independent_checks(gb, scale, workload):
+    """The SpGEMM lines bench.py prints (scale 20: the materialised product, 9.7 G entries; scale 22: row batches with the output
+    streamed; scale 22 under the structural mask A), each with the checks of bench.verify_mxm: the multiply count against the row
+    pointers, sum of the values = multiply count, nnz(C) = last row pointer, sampled rows (columns, order and values) against
+    torch.unique over the gathered rows of B, and for the streamed pipeline a row block against its materialised product."""
+    import argparse
+
+    import torch
+
+    import bench
+    from graphblas_amd import device
+
+    args = argparse.Namespace(streamed=False, stream_budget_gb=64.0, no_cpu_baseline=True)
+    line = bench.run_mxm(args, gb, torch, device, 0, 1, None, torch.cuda.synchronize, scale=scale, workload=workload, steps=1, warmup=0,
+                         want_cpu=False)
+    assert line["verified"] is True
+    cfg = line["config"]
+    assert cfg["flops"] > 10 * cfg["nnz_A"] and cfg["nnz_C"] > 0
+    if workload == "mxm_plus_times":
+        assert cfg["nnz_C"] > 50 * cfg["nnz_A"]
+        if scale >= 21:
+            assert cfg["batches"] > 1 and cfg["checksum"] == cfg["flops"]
+    else:
+        assert cfg["nnz_C"] <= cfg["nnz_A"]
+    device.trim_memory()
