@@ -201,6 +201,12 @@ class MxvWorkload:
         torch = self.torch
         if self.ov is None:
             wv, wb = device.vector_device_views(self.w)
+            if self.semiring == "min_plus":
+                # (after the warm-up w is at the fixed point of the relaxation: a call that computed nothing would leave it right.
+                #  Reset w to its initial values and run the call once more, on the layouts the timed calls ran on.)
+                wv.copy_(self._dist[self.lo:self.hi])
+                self.step()
+                torch.cuda.synchronize()
             got_has = self._bits(wb, self.m)
             if self.semiring == "min_plus":
                 d0 = self._dist[self.lo:self.hi]
@@ -213,6 +219,12 @@ class MxvWorkload:
         ov = self.ov
         src = ov.current_u()
         uv, ub = device.vector_device_views(src)
+        if self.semiring == "min_plus":
+            # (the relaxation has converged during the timed steps: start the checked step from the initial operands again)
+            uv.copy_(self._dist)
+            for c in range(ov.chunks):
+                lo, hi = self.ranges[c]
+                device.vector_device_views(self.ws[c])[0].copy_(self._dist[lo:hi])
         u_vals, u_has = uv.clone(), self._bits(ub, self.n)
         before = []
         for c in range(ov.chunks):

@@ -250,6 +250,15 @@ struct GB_Matrix_opaque {
     int64_t strip_cb[65] = {0};
     int strip_ncls = 8;
     int64_t strip_nseg = 0;
+    // ... or as HOT / COLD strips (long_kernel = 4, split kind 3; grb_mxv_strip.inc): the entries whose column code is LDS-resident in
+    // its class live in d_hrec -- per lane of 8 entries one record [8 LDS slots as u16 (u32 for BOOL) | 8 values] -- in chunks
+    // [strip_cb[c], strip_cb[c+1]) of the hot classes; all other entries (gathered from the operand image) in d_lcol / d_lval as
+    // strips of `strip_cold_ncls` contiguous column ranges, chunks [cold_cb[c], cold_cb[c+1]) in the same chunk numbering
+    // (d_lcol[0] is the first entry of chunk cold_cb[0]); d_sstart / d_sslot cover both
+    char *d_hrec = nullptr;
+    int hrec_bytes = 0;                // bytes of one lane record
+    int strip_cold_ncls = 0;
+    int64_t cold_cb[9] = {0};
     int split_kind = 0;                // value of the long_kernel option the split was built for
     int pull_calls = 0;                // pull products run on this matrix since its layouts were last dropped
     // the short rows once more in sliced-ELLPACK form (k_mxv_sell; built on first use when short_kernel = 2)
@@ -260,6 +269,15 @@ struct GB_Matrix_opaque {
     void *d_sell_val;
     int64_t sell_slices, sell_slots;
     int sell_state;           // 0 = not built, 1 = built
+    // ... or as tagged row groups (k_mxv_rows_tag; short_kernel = 5): per group of 64 rows its entries contiguous, padded to a
+    // multiple of 4, one byte per entry naming its row inside the group (64 = padding)
+    int32_t *d_tg_off = nullptr;       // per group (+1): first entry / 4
+    int32_t *d_tg_col = nullptr;
+    void *d_tg_val = nullptr;          // nullptr for iso matrices
+    unsigned char *d_tg_tag = nullptr;
+    uint64_t *d_tg_nonempty = nullptr; // per group: bit l = short row 64 g + l has an entry
+    int64_t tg_units = 0;
+    int tg_state = 0;
     int64_t n_long, n_chunks;
     int split_state;          // 0 = not analysed, 1 = enabled, -1 = not worth it
     bool split_hot;           // short_part's columns are hot-coded

@@ -36,6 +36,7 @@ namespace grb {
 #include "grb_mxv_long.inc"
 #include "grb_mxv_strip.inc"
 #include "grb_mxv_rows.inc"
+#include "grb_mxv_rows_tag.inc"
 #include "grb_mxv_sell.inc"
 #include "grb_mxv_split_build.inc"
 #include "grb_mxv_write.inc"
@@ -53,7 +54,7 @@ static void ensure_hot(GB_Matrix_opaque *A, size_t value_bytes)
     if (n < ctx().hot_min_cols || nnz == 0 || n + (int64_t)(1 << 22) > 0x7fffffff) return;
     int64_t k = ctx().hot_k > 0 ? ctx().hot_k : (int64_t)((2u << 20) / (value_bytes ? value_bytes : 1));
     // (the class strips keep the hottest codes of every class in LDS: the table has to hold at least those)
-    if (ctx().hot_k <= 0 && value_bytes > 1 && (ctx().long_kernel == 2 || ctx().long_kernel == 3)) {
+    if (ctx().hot_k <= 0 && value_bytes > 1 && ctx().long_kernel >= 2) {
         const int ncls = (ctx().long_classes == 16 || ctx().long_classes == 32 || ctx().long_classes == 64) ? ctx().long_classes : 8;
         k = std::max<int64_t>(k, long_lds_codes((int)value_bytes, false, LONG_LDS_WORDS) / 8 * ncls);
     }
@@ -148,16 +149,24 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
     const int ncls_opt = (ctx().long_classes == 16 || ctx().long_classes == 32 || ctx().long_classes == 64) ? ctx().long_classes : 8;
     // which long-row kernel this matrix is laid out for: option 3 (default) = class strips, except for BOOL matrices -- their
     // products are terminal monoids (the BFS step), where the item kernel's per-row early exit wins
-    const int kind = ctx().long_kernel == 3 ? (A->type->code == TC_BOOL ? 1 : 2) : ctx().long_kernel;
-    if (A->split_state != 0 && (A->split_state < 0 || (A->split_hot == hot && A->split_kind == kind && (A->split_kind != 2 || A->strip_nseg == 0 || A->strip_ncls == ncls_opt)))) return;
+    // (5: the same by type with the hot / cold strips -- 4 -- for non-BOOL matrices)
+    const int lk = ctx().long_kernel;
+    const int kind = lk == 3 ? (A->type->code == TC_BOOL ? 1 : 2) : (lk == 5 ? (A->type->code == TC_BOOL ? 1 : 4) : lk);
+    if (A->split_state != 0 && (A->split_state < 0 || (A->split_hot == hot && A->split_kind == kind && ((A->split_kind != 2 && A->split_kind != 4) || A->strip_nseg == 0 || A->strip_ncls == ncls_opt)))) return;
     if (A->split_state == 1) {  // built against the other column coding (or for another long-row kernel): rebuild
         matrix_free(A->short_part);
         A->short_part = nullptr;
         dev_free(A->d_long_bits); dev_free(A->d_long_rows); dev_free(A->d_chunk_slot); dev_free(A->d_chunk_start); dev_free(A->d_chunk_len); dev_free(A->d_long_prefix);
         dev_free(A->d_lcol); dev_free(A->d_lval); dev_free(A->d_it_start); dev_free(A->d_it_len); dev_free(A->d_it_slot);
         dev_free(A->d_item_begin);
-        dev_free(A->d_sstart); dev_free(A->d_sslot);
-        A->d_sstart = nullptr; A->d_sslot = nullptr; A->strip_nseg = 0;
+        // (layouts derived from the short part go with it)
+        dev_free(A->d_sell_perm); dev_free(A->d_sell_off); dev_free(A->d_sell_order); dev_free(A->d_sell_col); dev_free(A->d_sell_val);
+        A->d_sell_perm = nullptr; A->d_sell_off = nullptr; A->d_sell_order = nullptr; A->d_sell_col = nullptr; A->d_sell_val = nullptr;
+        A->sell_state = 0;
+        dev_free(A->d_tg_off); dev_free(A->d_tg_col); dev_free(A->d_tg_val); dev_free(A->d_tg_tag); dev_free(A->d_tg_nonempty);
+        A->d_tg_off = nullptr; A->d_tg_col = nullptr; A->d_tg_val = nullptr; A->d_tg_tag = nullptr; A->d_tg_nonempty = nullptr; A->tg_state = 0;
+        dev_free(A->d_sstart); dev_free(A->d_sslot); dev_free(A->d_hrec);
+        A->d_sstart = nullptr; A->d_sslot = nullptr; A->d_hrec = nullptr; A->strip_nseg = 0;
         A->d_lcol = nullptr; A->d_lval = nullptr; A->d_it_start = nullptr; A->d_it_len = nullptr; A->d_it_slot = nullptr;
         A->d_item_begin = nullptr; A->long_nnz = 0; A->n_items = 0;
         A->d_long_prefix = nullptr;
@@ -171,7 +180,7 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
     if (!col_src) fail(GrB_PANIC, "pull SpMV: the split cannot be built without a column source (internal error)");
     const int64_t m = (int64_t)A->nrows, nnz = A->nvals;
     if (nnz < ctx().split_min_nnz || m == 0 || (ctx().debug_flags & 128)) return;
-    const int min_len = ctx().split_min_len > 0 ? ctx().split_min_len : (kind == 2 ? 64 : 256);  // (measured optima, scripts/gpu_r02_nc.sh)
+    const int min_len = ctx().split_min_len > 0 ? ctx().split_min_len : ((kind == 2 || kind == 4) ? 64 : 256);  // (measured optima, scripts/gpu_r02_nc.sh)
     DevBuf<uint64_t> lbits(bits_words64((uint64_t)m));
     DevBuf<int64_t> slen(m + 1), lflag(m + 1), nchunk(m + 1);
     hipLaunchKernelGGL(k_split_classify, dim3((unsigned)ceil_div((int64_t)bits_words64((uint64_t)m) * 64 + 1, 256)), dim3(256), 0,
@@ -212,32 +221,50 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
             // sub-ranges per class: sized so that one sub-range of the operand image is ~2 MiB (half an XCD's L2; BOOL images are
             // bit-packed and fit as they are); measured on R-MAT scale 24 fp32: 4 sub-ranges -3 % per call, and rows need ~512
             // entries per sub-range or their items get too small (sub 8 from 2048 entries: +3 %)
-            const int ncls = (kind == 2 && (ctx().long_classes == 16 || ctx().long_classes == 32 || ctx().long_classes == 64))
+            const bool strips = kind == 2 || kind == 4;
+            const int ncls = (strips && (ctx().long_classes == 16 || ctx().long_classes == 32 || ctx().long_classes == 64))
                                  ? ctx().long_classes : 8;
+            // hot / cold strips: the codes that are LDS-resident in their class, and the contiguous column ranges of the others
+            const int COLD_CLS = 8;
+            const int64_t lds_lim4 = std::min<int64_t>(hot ? A->hot_k : 0, long_lds_codes((int)A->type->size, A->type->code == TC_BOOL, LONG_LDS_WORDS) / 8 * ncls);
+            const int64_t codes_total = (int64_t)A->ncols + (hot ? A->hot_k : 0);
+            // (kind 4: `sub` = sub-ranges per COLD class -- 8 cold classes whatever the number of hot ones)
+            const int range_cls = kind == 4 ? COLD_CLS : ncls;
             unsigned sub = 1;
             if (ctx().long_sub > 0) sub = (unsigned)std::min(16, ctx().long_sub);
             else if (A->type->code != TC_BOOL)
-                while (sub < 16 && (int64_t)A->ncols * (int64_t)A->type->size > (int64_t)sub * ncls * (3ll << 20)) sub *= 2;
+                while (sub < 16 && (int64_t)A->ncols * (int64_t)A->type->size > (int64_t)sub * range_cls * (3ll << 20)) sub *= 2;
             const int64_t sub_min_len = ctx().long_sub_min_len > 0 ? ctx().long_sub_min_len : 512 * (int64_t)sub;
             const int64_t nv = (int64_t)ncls * (int64_t)sub * nl;
             int bits = 1;
             while (((int64_t)1 << bits) < nv) bits++;
             DevBuf<uint64_t> keys(nnz_long), keys2(nnz_long);
             DevBuf<uint32_t> idx(nnz_long), idx2(nnz_long);
+            if (kind == 4)
+                hipLaunchKernelGGL(k_long_keys, dim3((unsigned)nl), dim3(256), 0, ctx().stream, (const int64_t *)A->d_ptr,
+                                   (const int64_t *)S->d_ptr, (const int32_t *)A->d_long_rows, col_src, nl, keys.p, idx.p,
+                                   (unsigned)lds_lim4, (unsigned)std::max<int64_t>(1, ceil_div(codes_total - lds_lim4, (int64_t)COLD_CLS * (int64_t)sub)),
+                                   sub, sub_min_len, (unsigned)ncls, 2);
+            else
             hipLaunchKernelGGL(k_long_keys, dim3((unsigned)nl), dim3(256), 0, ctx().stream, (const int64_t *)A->d_ptr,
                                (const int64_t *)S->d_ptr, (const int32_t *)A->d_long_rows, col_src, nl, keys.p, idx.p,
                                (unsigned)(hot ? A->hot_k : 0), (unsigned)std::max<int64_t>(1, ceil_div((int64_t)A->ncols, (int64_t)ncls * (int64_t)sub)),
                                sub, sub_min_len, (unsigned)ncls, kind == 2 ? 1 : 0);
-            if (kind == 2) {
+            // (virtual classes: kind 2 ncls * sub; kind 4 ncls hot classes + COLD_CLS cold ranges, with `sub` = 1 in the segment tables)
+            const int nvc = kind == 4 ? ncls + COLD_CLS : ncls;                       // classes (chunk ranges)
+            const int nvirt = kind == 4 ? ncls + COLD_CLS * (int)sub : ncls * (int)sub;  // virtual classes (sort keys)
+            const int hot_cls = kind == 4 ? ncls : 0;
+            if (strips) {
                 int vbits = 1;
-                while ((1 << vbits) < ncls * (int)sub) vbits++;
+                while ((1 << vbits) < nvirt) vbits++;
                 prim_sort_pairs_u64_u32_bits(keys.p, keys2.p, idx.p, idx2.p, nnz_long, 32, 32 + vbits);
             } else {
                 prim_sort_pairs_u64_u32(keys.p, keys2.p, idx.p, idx2.p, nnz_long, bits);
             }
-            if (kind == 2) {
+            if (strips) {
                 // flat class strips (grb_mxv_strip.inc): segments = runs of equal keys; every segment padded to a multiple of 8
-                // entries, every class to whole chunks of 512
+                // entries, every class to whole chunks of 512.  Kind 4: classes 0 .. ncls - 1 are the hot strips (lane records in
+                // d_hrec), classes ncls .. ncls + COLD_CLS - 1 the cold strips (d_lcol / d_lval), one chunk numbering over both
                 const int64_t nblk = ceil_div(nnz_long, STRIP_CH);
                 DevBuf<int64_t> blk(nblk + 1);
                 hipLaunchKernelGGL(k_strip_count, dim3((unsigned)nblk), dim3(STRIP_CH), 0, ctx().stream, (const uint64_t *)keys2.p, nnz_long, blk.p);
@@ -251,55 +278,84 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
                 hipLaunchKernelGGL(k_strip_plen, dim3((unsigned)ceil_div(nseg + 1, 256)), dim3(256), 0, ctx().stream, (const int64_t *)seg_first.p,
                                    nseg, off.p);
                 prim_exclusive_sum_i64(off.p, off.p, nseg + 1);
-                DevBuf<int64_t> sc(65), raw(65), cshift(64);
+                constexpr int MAXC = 64 + 8;
+                DevBuf<int64_t> sc(MAXC + 1), raw(MAXC + 1), cshift(MAXC);
                 hipLaunchKernelGGL(k_strip_class_bounds, dim3(1), dim3(128), 0, ctx().stream, (const uint64_t *)keys2.p, (const int64_t *)seg_first.p,
-                                   nseg, nl, sub, (const int64_t *)off.p, sc.p, raw.p, ncls);
-                int64_t h_raw[65], h_shift[64], h_cb[65];
-                d2h(h_raw, raw.p, sizeof(int64_t) * (size_t)(ncls + 1));
+                                   nseg, nl, sub, (const int64_t *)off.p, sc.p, raw.p, nvc, hot_cls);
+                int64_t h_raw[MAXC + 1], h_shift[MAXC], h_cb[MAXC + 1];
+                d2h(h_raw, raw.p, sizeof(int64_t) * (size_t)(nvc + 1));
                 int64_t base = 0;
-                for (int c = 0; c < ncls; c++) {
+                for (int c = 0; c < nvc; c++) {
                     h_cb[c] = base / STRIP_CH;
                     h_shift[c] = base - h_raw[c];
                     base += ceil_div(h_raw[c + 1] - h_raw[c], STRIP_CH) * STRIP_CH;
                 }
-                h_cb[ncls] = base / STRIP_CH;
+                h_cb[nvc] = base / STRIP_CH;
                 const int64_t padded = base, nch = padded / STRIP_CH;
-                h2d(cshift.p, h_shift, sizeof(int64_t) * (size_t)ncls);
-                A->cls_lds_lim = (int)std::min<int64_t>(hot ? A->hot_k : 0,
-                                                        long_lds_codes((int)A->type->size, A->type->code == TC_BOOL, LONG_LDS_WORDS) / 8 * ncls);
+                h2d(cshift.p, h_shift, sizeof(int64_t) * (size_t)nvc);
+                A->cls_lds_lim = (int)lds_lim4;
+                const int64_t hot_chunks = kind == 4 ? h_cb[ncls] : 0;                 // chunks of the hot strips
+                const int64_t flat_entries = kind == 4 ? padded - hot_chunks * STRIP_CH : padded;  // entries held by d_lcol / d_lval
+                const int code_bytes = A->type->code == TC_BOOL ? 32 : 16;
+                const int val_bytes = A->iso ? 0 : (int)std::max<size_t>(16, 8 * A->type->size);
                 if (padded > 0 && padded < 0x7fffffff0ll) {
-                    A->d_lcol = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)padded);
-                    A->d_lval = A->iso ? nullptr : dev_alloc(A->type->size * (size_t)padded);
+                    A->d_lcol = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)std::max<int64_t>(flat_entries, 1));
+                    A->d_lval = A->iso ? nullptr : dev_alloc(A->type->size * (size_t)std::max<int64_t>(flat_entries, 1));
                     A->d_sstart = (unsigned long long *)dev_alloc(sizeof(unsigned long long) * (size_t)nch);
                     A->d_sslot = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)(padded / 8));
                     GRB_HIP(hipMemsetAsync(A->d_sslot, 0xff, sizeof(int32_t) * (size_t)(padded / 8), ctx().stream));
-                    GRB_HIP(hipMemsetAsync(A->d_lcol, 0xff, sizeof(int32_t) * (size_t)padded, ctx().stream));
-                    if (A->d_lval) GRB_HIP(hipMemsetAsync(A->d_lval, 0, A->type->size * (size_t)padded, ctx().stream));
+                    GRB_HIP(hipMemsetAsync(A->d_lcol, 0xff, sizeof(int32_t) * (size_t)std::max<int64_t>(flat_entries, 1), ctx().stream));
+                    if (A->d_lval) GRB_HIP(hipMemsetAsync(A->d_lval, 0, A->type->size * (size_t)std::max<int64_t>(flat_entries, 1), ctx().stream));
                     GRB_HIP(hipMemsetAsync(A->d_sstart, 0, sizeof(unsigned long long) * (size_t)nch, ctx().stream));
+                    A->hrec_bytes = 0;
+                    if (kind == 4) {
+                        A->hrec_bytes = code_bytes + val_bytes;
+                        const size_t hbytes = (size_t)std::max<int64_t>(hot_chunks, 1) * 64 * (size_t)A->hrec_bytes;
+                        A->d_hrec = (char *)dev_alloc(hbytes);
+                        if (A->type->code == TC_BOOL) GRB_HIP(hipMemsetAsync(A->d_hrec, 0xff, hbytes, ctx().stream));  // (code -1 = padding)
+                        else {
+                            const int64_t n_rec = std::max<int64_t>(hot_chunks, 1) * 64;
+                            GRB_DISPATCH_TYPE(A->type->code, T, {
+                                hipLaunchKernelGGL((k_hrec_init<T>), dim3((unsigned)ceil_div(n_rec, 256)), dim3(256), 0, ctx().stream, A->d_hrec, n_rec,
+                                                   A->hrec_bytes, hot_pad_code<T>(LONG_LDS_WORDS));
+                            })
+                        }
+                    }
                     GRB_DISPATCH_TYPE(A->type->code, T, {
                         hipLaunchKernelGGL((k_strip_place<T>), dim3((unsigned)nblk), dim3(STRIP_CH), 0, ctx().stream, (const uint64_t *)keys2.p,
                                            (const uint32_t *)idx2.p, nnz_long, (const int64_t *)blk.p, (const int64_t *)seg_first.p,
                                            (const int64_t *)off.p, (const int64_t *)cshift.p, nl, sub, col_src, (const T *)A->d_val,
-                                           A->iso ? 1 : 0, A->cls_lds_lim, ncls, A->d_lcol, (T *)A->d_lval, A->d_sstart, A->d_sslot);
+                                           A->iso ? 1 : 0, A->cls_lds_lim, ncls, A->d_lcol, (T *)A->d_lval, A->d_sstart, A->d_sslot,
+                                           A->d_hrec, A->hrec_bytes, hot_chunks * STRIP_CH, hot_cls);
                     })
                     {
-                        int64_t h_end[64];
-                        for (int c = 0; c < ncls; c++) h_end[c] = h_cb[c + 1] * STRIP_CH;
-                        DevBuf<int64_t> cend(64);
-                        h2d(cend.p, h_end, sizeof(int64_t) * (size_t)ncls);
-                        hipLaunchKernelGGL(k_strip_pad_starts, dim3(1), dim3(64), 0, ctx().stream, (const int64_t *)sc.p, (const int64_t *)off.p,
-                                           (const int64_t *)cshift.p, (const int64_t *)cend.p, ncls, A->d_sstart);
+                        int64_t h_end[MAXC];
+                        for (int c = 0; c < nvc; c++) h_end[c] = h_cb[c + 1] * STRIP_CH;
+                        DevBuf<int64_t> cend(MAXC);
+                        h2d(cend.p, h_end, sizeof(int64_t) * (size_t)nvc);
+                        hipLaunchKernelGGL(k_strip_pad_starts, dim3(1), dim3(128), 0, ctx().stream, (const int64_t *)sc.p, (const int64_t *)off.p,
+                                           (const int64_t *)cshift.p, (const int64_t *)cend.p, nvc, A->d_sstart);
                         sync_stream();
                     }
                     for (int c = 0; c <= ncls; c++) A->strip_cb[c] = h_cb[c];
+                    if (getenv("GRB_PRINT_STRIPS")) {  // (diagnostic: chunks per class -- a persistent class with more chunks than the others sets the kernel's time)
+                        fprintf(stderr, "[strips kind %d] %d classes, chunks per class:", kind, nvc);
+                        for (int c = 0; c < nvc; c++) fprintf(stderr, " %lld", (long long)(h_cb[c + 1] - h_cb[c]));
+                        fprintf(stderr, "  segments %lld\n", (long long)nseg);
+                    }
+                    A->strip_cold_ncls = 0;
+                    if (kind == 4) {
+                        A->strip_cold_ncls = COLD_CLS;
+                        for (int c = 0; c <= COLD_CLS; c++) A->cold_cb[c] = h_cb[ncls + c];
+                    }
                     A->strip_ncls = ncls;
                     A->strip_nseg = nseg;
                     A->long_nnz = nnz_long;
                     sync_stream();  // (the temporaries above are released at the end of this scope)
                 }
             }
-            DevBuf<int64_t> vptr(kind == 2 ? 0 : nv + 1), icnt(kind == 2 ? 0 : nv + 1);
-            if (kind != 2) {
+            DevBuf<int64_t> vptr(strips ? 0 : nv + 1), icnt(strips ? 0 : nv + 1);
+            if (!strips) {
             hipLaunchKernelGGL(k_long_vptr, dim3((unsigned)ceil_div(nv + 1, 256)), dim3(256), 0, ctx().stream,
                                (const uint64_t *)keys2.p, nnz_long, nv, vptr.p);
             hipLaunchKernelGGL(k_long_item_count, dim3((unsigned)ceil_div(nv + 1, 256)), dim3(256), 0, ctx().stream,
@@ -360,7 +416,7 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
     A->split_state = 1;
     // the short part and the strips / items carry their own re-coded columns: the re-coded copy of the whole array is only read
     // again by a product that cannot take the split (a typecast of the values), which falls back to the plain arrays
-    if (hot && ctx().drop_hot_cols && nc > 0 && A->long_nnz > 0 && (kind == 1 || kind == 2) && A->d_col_hot) {
+    if (hot && ctx().drop_hot_cols && nc > 0 && A->long_nnz > 0 && (kind == 1 || kind == 2 || kind == 4) && A->d_col_hot) {
         dev_free(A->d_col_hot);
         A->d_col_hot = nullptr;
         A->hot_cols_dropped = true;
@@ -412,6 +468,40 @@ static void ensure_sell(GB_Matrix_opaque *A)
     A->sell_state = 1;
 }
 
+// tagged row groups of the short part S of A (once per matrix; see grb_mxv_rows_tag.inc)
+static void ensure_tagged(GB_Matrix_opaque *A)
+{
+    if (A->tg_state == 1) return;
+    GB_Matrix_opaque *S = A->short_part;
+    const int64_t m = (int64_t)S->nrows, ngroups = ceil_div(m, 64);
+    const int64_t *sptr = matrix_rowptr(S);
+    DevBuf<int64_t> cnt(ngroups + 1);
+    A->d_tg_nonempty = (uint64_t *)dev_alloc(sizeof(uint64_t) * (size_t)std::max<int64_t>(ngroups, 1));
+    hipLaunchKernelGGL(k_tag_count, dim3((unsigned)ceil_div((ngroups + 1) * 64, 256)), dim3(256), 0, ctx().stream, sptr, m, ngroups, cnt.p,
+                       A->d_tg_nonempty);
+    prim_exclusive_sum_i64(cnt.p, cnt.p, ngroups + 1);
+    int64_t units = 0;
+    d2h(&units, cnt.p + ngroups, 8);
+    if (units >= 0x7ffffff0ll) fail(GrB_NOT_IMPLEMENTED, "tagged row groups: too many entries for 32-bit group offsets");
+    A->d_tg_off = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)(ngroups + 1));
+    hipLaunchKernelGGL(k_tag_off32, dim3((unsigned)ceil_div(ngroups + 1, 256)), dim3(256), 0, ctx().stream, (const int64_t *)cnt.p, ngroups + 1,
+                       A->d_tg_off);
+    const size_t ents = (size_t)std::max<int64_t>(units, 1) * TAG_EPL;
+    A->d_tg_col = (int32_t *)dev_alloc(sizeof(int32_t) * ents);
+    A->d_tg_val = S->iso ? nullptr : dev_alloc(S->type->size * ents);
+    A->d_tg_tag = (unsigned char *)dev_alloc(ents);
+    GRB_HIP(hipMemsetAsync(A->d_tg_col, 0xff, sizeof(int32_t) * ents, ctx().stream));
+    if (A->d_tg_val) GRB_HIP(hipMemsetAsync(A->d_tg_val, 0, S->type->size * ents, ctx().stream));
+    GRB_HIP(hipMemsetAsync(A->d_tg_tag, 0x40, ents, ctx().stream));
+    GRB_DISPATCH_TYPE(S->type->code, T, {
+        hipLaunchKernelGGL((k_tag_fill<T>), dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, ctx().stream, sptr, (const int32_t *)S->d_col,
+                           (const T *)S->d_val, S->iso ? 1 : 0, m, (const int64_t *)cnt.p, A->d_tg_col, (T *)A->d_tg_val, A->d_tg_tag);
+    })
+    sync_stream();  // (cnt is released at the end of this scope)
+    A->tg_units = units;
+    A->tg_state = 1;
+}
+
 template <typename T, int MON, int MUL, int IPT>
 static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
 {
@@ -425,16 +515,24 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
         // (ablation build GRB_STRIP_ABL & 32: one scratch slot per lane of every chunk)
         DevBuf<W> tl_val((GRB_STRIP_ABL & 32) ? std::max<int64_t>(a.n_long, (A->strip_cb[A->strip_ncls > 0 ? A->strip_ncls : 0] + 1) * 64) : a.n_long);
         DevBuf<unsigned char> tl_has(a.n_long);
-        const bool by_strip = A->split_kind == 2 && A->long_nnz > 0 && A->strip_nseg > 0;
+        const bool by_strip = (A->split_kind == 2 || A->split_kind == 4) && A->long_nnz > 0 && A->strip_nseg > 0;
         ctx().stats.long_entries = A->nvals - S->nvals;
         ctx().stats.long_segments = by_strip ? A->strip_nseg : 0;
         const bool by_class = A->split_kind == 1 && A->long_nnz > 0 && A->n_items > 0;
-        ctx().stats.long_kernel = by_strip ? 2 : (by_class ? 1 : 0);
+        ctx().stats.long_kernel = by_strip ? A->split_kind : (by_class ? 1 : 0);
         DevBuf<uint32_t> long_act((size_t)ceil_div(a.n_long, 64) * 2);
         a.long_act = long_act.p;
+        // the fast kernel of the hot strips (k_mxv_hstrip): a specialised semiring over a full operand whose values are read
+        bool hot_fast = false;
+        // (not for iso matrices: their padding entries would carry the one stored value instead of 0, and value (+) padding word must
+        //  be the identity -- INT64_MAX + v wraps)
+        if constexpr (MON >= 0) hot_fast = hstrip_fast_semiring<T>(MON, MUL) && A->split_kind == 4 && by_strip && a.u_full && a.need_uval && a.need_aval && !a.a_iso;
+        DevBuf<unsigned char> long_act8(hot_fast && a.has_mask ? (size_t)a.n_long : 1);
+        a.long_act8 = long_act8.p;
         hipLaunchKernelGGL((k_long_init<W>), dim3((unsigned)ceil_div(a.n_long, 256)), dim3(256), 0, ctx().stream, tl_val.p, tl_has.p,
                            a.n_long, monoid_identity<T, W>(a.monoid), a.long_rows, a.m_bits, a.has_mask, a.m_comp, long_act.p,
-                           ((by_class || by_strip) && a.u_full) ? 1 : 0, (by_strip && acc_is_ordered<W>(a.monoid)) ? 1 : 0);
+                           ((by_class || by_strip) && a.u_full) ? 1 : 0, (by_strip && acc_is_ordered<W>(a.monoid)) ? 1 : 0,
+                           (hot_fast && a.has_mask) ? long_act8.p : nullptr);
         a.tl_ord = (by_strip && acc_is_ordered<W>(a.monoid)) ? 1 : 0;
         a.long_has_known = ((by_class || by_strip) && a.u_full) ? 1 : 0;
         a.tl_val = tl_val.p;
@@ -454,6 +552,47 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
             for (int c = 0; c <= A->strip_ncls; c++) a.strip_cb[c] = A->strip_cb[c];
             a.strip_ncls = A->strip_ncls;
             const int64_t G = std::max<int64_t>(A->strip_ncls, (int64_t)(ctx().num_cus / A->strip_ncls) * A->strip_ncls);
+            if (A->split_kind == 4) {
+                // hot strips (lane records, LDS gathers only), then the cold strips (image gathers) with a token LDS array
+                a.hrec = A->d_hrec;
+                a.hrec_bytes = A->hrec_bytes;
+                if (A->strip_cb[A->strip_ncls] > 0) {
+                    bool launched = false;
+                    if constexpr (MON >= 0) {
+                        if constexpr (hstrip_fast_semiring<T>(MON, MUL)) {
+                            if (hot_fast) {
+                                hipLaunchKernelGGL((k_mxv_hstrip<T, MON, MUL, LONG_LDS_WORDS>), dim3((unsigned)G), dim3(LONG_BLOCK), 0, ctx().stream, a);
+                                launched = true;
+                            }
+                        }
+                    }
+                    if (!launched)
+                        hipLaunchKernelGGL((k_mxv_strip<T, MON, MUL, LONG_LDS_WORDS, 1>), dim3((unsigned)G), dim3(LONG_BLOCK), 0, ctx().stream, a);
+                }
+                const int cc = A->strip_cold_ncls;
+                if (cc > 0 && A->cold_cb[cc] > A->cold_cb[0]) {
+                    PullArgs c2 = a;
+                    for (int c = 0; c <= cc; c++) c2.strip_cb[c] = A->cold_cb[c];
+                    c2.strip_ncls = cc;
+                    c2.cls_lds_lim = 0;
+                    c2.lcol = A->d_lcol - A->cold_cb[0] * STRIP_CH;  // (the kernel addresses entries by their global chunk number)
+                    c2.lval = A->d_lval ? (const char *)A->d_lval - (size_t)A->cold_cb[0] * STRIP_CH * sizeof(T) : nullptr;
+                    bool launched = false;
+                    if constexpr (MON >= 0) {
+                        if constexpr (hstrip_fast_semiring<T>(MON, MUL)) {
+                            if (hot_fast) {  // (two workgroups per CU: the lean kernel fits 8 wavefronts per SIMD)
+                                const int64_t Gf = std::max<int64_t>(cc, (int64_t)(ctx().num_cus * 2 / cc) * cc);
+                                hipLaunchKernelGGL((k_mxv_cstrip<T, MON, MUL>), dim3((unsigned)Gf), dim3(LONG_BLOCK), 0, ctx().stream, c2);
+                                launched = true;
+                            }
+                        }
+                    }
+                    const int64_t Gc = std::max<int64_t>(cc, (int64_t)(ctx().num_cus * COLD_WGS_PER_CU / cc) * cc);
+                    if (!launched)
+                        hipLaunchKernelGGL((k_mxv_strip<T, MON, MUL, COLD_LDS_WORDS, 0>), dim3((unsigned)Gc), dim3(LONG_BLOCK), 0, ctx().stream, c2);
+                    ctx().stats.kernel_launches += 1;
+                }
+            } else
             hipLaunchKernelGGL((k_mxv_strip<T, MON, MUL, LONG_LDS_WORDS>), dim3((unsigned)G), dim3(LONG_BLOCK), 0, ctx().stream, a);
         } else if (by_class) {
             a.lcol = A->d_lcol;
@@ -514,6 +653,22 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
             ctx().stats.tiles = A->sell_slots;  // (slots incl. padding; the short part holds S->nvals entries)
             return;
         }
+        if (ctx().short_kernel == 5 && S->nrows == A->nrows && S->nvals < 0x1ffffffffll) {
+            // short rows as tagged row groups: the row of every entry is stored with it (no marks, no scan, no segmented fold)
+            ensure_tagged(A);
+            b.long_prefix = A->d_long_prefix;
+            b.tg_off = A->d_tg_off;
+            b.tg_col = A->d_tg_col;
+            b.tg_val = A->d_tg_val;
+            b.tg_tag = A->d_tg_tag;
+            b.tg_nonempty = A->d_tg_nonempty;
+            hipLaunchKernelGGL((k_mxv_rows_tag<T, MON, MUL>), dim3((unsigned)ceil_div(ceil_div(b.m, 64), (ROWS_BLOCK / 64) * TAG_K)), dim3(ROWS_BLOCK), 0,
+                               ctx().stream, b);
+            GRB_HIP(hipGetLastError());
+            ctx().stats.kernel_launches += 1;
+            ctx().stats.tiles = ceil_div(b.m, 64);
+            return;
+        }
         if (ctx().short_kernel == 3 && S->nrows == A->nrows) {
             // short rows from persistent workgroups that keep the head of the operand image in LDS
             b.long_prefix = A->d_long_prefix;
@@ -537,7 +692,7 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
                 return;
             }
         }
-        if ((ctx().short_kernel == 1 || ctx().short_kernel == 4) && S->nrows == A->nrows) {
+        if ((ctx().short_kernel == 1 || ctx().short_kernel == 4 || ctx().short_kernel == 5) && S->nrows == A->nrows) {
             // short rows: one wavefront per 64 consecutive rows, which also applies the write rule of the long rows
             b.long_prefix = A->d_long_prefix;
             // (persistent variants -- static strides with the next group prefetched, or an LDS work counter per workgroup --
@@ -828,7 +983,7 @@ static void mxv_core(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_Binar
     DevBuf<uint64_t> valbits(0);
     // (u not full: presence and value share one word per 16 codes, one gather per entry instead of two -- every pull kernel
     //  but the chunk kernel of the long rows reads that form)
-    const bool chunk_kernel = S->split_state == 1 && !((S->split_kind == 1 || S->split_kind == 2) && S->long_nnz > 0);
+    const bool chunk_kernel = S->split_state == 1 && !((S->split_kind == 1 || S->split_kind == 2 || S->split_kind == 4) && S->long_nnz > 0);
     if (st == TC_BOOL && a.need_uval && !a.u_full && !chunk_kernel && !(ctx().debug_flags & 2048)) {
         const int64_t len = a.x_len;
         dev_free(valbits.p);
@@ -1097,7 +1252,13 @@ extern "C" GrB_Info GrX_Matrix_cache_bytes(const GrB_Matrix A, uint64_t *bytes)
         const GB_Matrix_opaque *S = A->short_part;
         b += 8ull * (A->nrows + 1) + 4ull * (uint64_t)S->nvals + (S->iso ? vs : vs * (uint64_t)S->nvals);
         b += bits_words64(A->nrows) * 8 + 4ull * (uint64_t)A->n_long + 4ull * bits_words64(A->nrows) + 16ull * (uint64_t)A->n_chunks;
-        if (A->split_kind == 2 && A->strip_nseg > 0) {
+        if (A->tg_state == 1) b += (uint64_t)A->tg_units * TAG_EPL * (5 + (A->d_tg_val ? vs : 0)) + 12ull * ((A->nrows + 63) / 64);
+        if (A->split_kind == 4 && A->strip_nseg > 0) {
+            const uint64_t hot_lanes = (uint64_t)A->strip_cb[A->strip_ncls] * 64;
+            const uint64_t cold = (uint64_t)(A->cold_cb[A->strip_cold_ncls] - A->cold_cb[0]) * STRIP_CH;
+            const uint64_t padded = hot_lanes * 8 + cold;
+            b += hot_lanes * (uint64_t)A->hrec_bytes + cold * 4 + (A->d_lval ? cold * vs : 0) + padded / 2 + padded / STRIP_CH * 8;
+        } else if (A->split_kind == 2 && A->strip_nseg > 0) {
             const uint64_t padded = (uint64_t)A->strip_cb[A->strip_ncls] * STRIP_CH;
             b += padded * 4 + (A->d_lval ? padded * vs : 0) + padded / 2 + padded / STRIP_CH * 8;
         } else if (A->n_items > 0) {

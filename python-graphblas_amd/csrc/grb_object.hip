@@ -579,10 +579,15 @@ void matrix_invalidate_caches(GB_Matrix_opaque *A)
     dev_free(A->d_item_begin);
     dev_free(A->d_sstart);
     dev_free(A->d_sslot);
+    dev_free(A->d_hrec);
     A->d_sstart = nullptr;
     A->d_sslot = nullptr;
+    A->d_hrec = nullptr;
     A->strip_nseg = 0;
     A->pull_calls = 0;
+    dev_free(A->d_tg_off); dev_free(A->d_tg_col); dev_free(A->d_tg_val); dev_free(A->d_tg_tag); dev_free(A->d_tg_nonempty);
+    A->d_tg_off = nullptr; A->d_tg_col = nullptr; A->d_tg_val = nullptr; A->d_tg_tag = nullptr; A->d_tg_nonempty = nullptr;
+    A->tg_state = 0;
     dev_free(A->d_sell_perm);
     dev_free(A->d_sell_off);
     dev_free(A->d_sell_order);

@@ -491,7 +491,8 @@ def test_long_short_row_split(gb, seed):
         # merge-path kernel / row-group kernel / sliced-ELLPACK kernel for the short rows
         # sliced ELLPACK / persistent row groups with an LDS head / merge path / row groups
         # (seeds 0, 6, 12: a lane per row over entries staged in LDS -- 4-byte types with a full operand; the rest falls back to row groups)
-        _lib.lib.GrX_option_set(b"short_kernel", 4 if seed % 6 == 0 else (2 if seed % 3 == 1 else (3 if seed % 3 == 2 else (0 if seed & 8 else 1))))
+        # (5: tagged row groups -- the row of every entry stored with it)
+        _lib.lib.GrX_option_set(b"short_kernel", [4, 2, 3, 5, 2, 5, 4, 5, 3, 0, 5, 3, 4, 5, 5, 1][seed])
         _lib.lib.GrX_option_set(b"sell_sigma", [64, 128, 4096, 256][seed % 4])
         if seed & 4:
             _lib.lib.GrX_option_set(b"hot_min_cols", 8)
@@ -499,7 +500,8 @@ def test_long_short_row_split(gb, seed):
         _lib.lib.GrX_option_set(b"long_sub", 1 + seed % 5)
         _lib.lib.GrX_option_set(b"long_sub_min_len", 64 if seed & 1 else 8)
         # long rows: by matrix type (strips, items for BOOL) / strips for every type incl. BOOL / items for every type
-        forced_long = [DEFAULT_LONG_KERNEL, 2, 1, DEFAULT_LONG_KERNEL, 2][seed % 5]
+        # ... / hot + cold strips for every type / by type with the hot + cold strips
+        forced_long = [DEFAULT_LONG_KERNEL, 2, 1, 4, 5][seed % 5]
         _lib.lib.GrX_option_set(b"long_kernel", forced_long)
         _lib.lib.GrX_option_set(b"long_classes", [16, 8, 32, 16, 64][seed % 5])
         A = gb.Matrix.from_coo(rows, cols, vals, dtype=tname, nrows=m, ncols=n)
@@ -509,7 +511,7 @@ def test_long_short_row_split(gb, seed):
         w(~mk.V if comp else mk.V, accum=accum, replace=bool(seed & 2)) << A.mxv(u, getattr(gb.semiring, sr))
         st = device.last_stats()  # init + long rows + short rows (with the write rule of every row); PAIR over a full u reads no rows
         assert st["kernel_launches"] >= 3 or st["method"] == 5
-        want = forced_long if forced_long != 3 else (1 if tname == "BOOL" else 2)
+        want = {3: 1 if tname == "BOOL" else 2, 5: 1 if tname == "BOOL" else 4}.get(forced_long, forced_long)
         assert st["method"] == 5 or (st["long_kernel"] == want and st["long_entries"] > 0)
         same_vec(w, exp)
         # a product that needs A's values in another type cannot take the split (whose re-coded column copy of the whole matrix
@@ -549,6 +551,77 @@ def test_long_short_row_split(gb, seed):
         _lib.lib.GrX_option_set(b"long_sub_min_len", 0)
         _lib.lib.GrX_option_set(b"long_kernel", DEFAULT_LONG_KERNEL)
         _lib.lib.GrX_option_set(b"long_classes", 16)
+
+
+@pytest.mark.parametrize("seed", range(21))
+def test_hot_cold_strips(gb, seed):
+    """long_kernel = 4: the long rows as HOT strips (entries whose column code is LDS-resident in its class: lane records of 8
+    16-bit LDS slots + 8 values, 32-bit slots for BOOL) plus COLD strips (image gathers, 8 contiguous column ranges).  Skewed
+    columns so that both parts carry entries, every type, table sizes from a few lines to everything, 8 .. 64 classes, full and
+    sparse operands (the presence lookups of resident codes go to the image), masks that switch long rows off, accumulators,
+    replace, iso matrices, vxm over the transpose -- against the oracle."""
+    from graphblas_amd import _lib, device
+
+    rng = np.random.default_rng(8800 + seed)
+    tname = TYPES[seed % 7]
+    sr = semirings_for(tname)[(seed // 7) % 4]
+    m, n = int(rng.integers(60, 400)), int(rng.integers(2100, 5000))
+    deg = rng.integers(0, 6, m)
+    deg[rng.random(m) < 0.3] = 0
+    for ln in (8, 9, 15, 16, 17, 63, 64, 65, 511, 513, 1030, int(rng.integers(1500, 2000))):
+        deg[rng.integers(0, m)] = ln
+    hot = rng.permutation(n)[: n // 10]
+    rows = np.repeat(np.arange(m), deg)
+    cols = np.where(rng.random(rows.size) < 0.75, hot[rng.integers(0, hot.size, rows.size)], rng.integers(0, n, rows.size))
+    key = np.unique(rows * n + cols)
+    rows, cols = key // n, key % n
+    iso = seed % 5 == 4
+    vals = np.full(rows.size, rand_vals(rng, 1, tname)[0]) if iso else rand_vals(rng, rows.size, tname)
+    ui, uv = rand_vec(rng, n, [1.0, 0.5, 0.05][seed % 3], tname)
+    wi, wv = rand_vec(rng, m, 0.5, tname)
+    mi, mv = rand_vec(rng, m, 0.5, "BOOL")
+    accum = [None, "plus", "min"][seed % 3] if tname != "BOOL" else [None, "lor", "land"][seed % 3]
+    comp, repl = bool(seed & 1), bool(seed & 2)
+    oa = O.OMat.from_coo(rows, cols, vals, m, n, tname)
+    exp = O.mxv(oa, O.OVec(n, ui, uv, tname), sr, w=O.OVec(m, wi, wv, tname), mask=O.OVec(m, mi, mv, "BOOL"),
+                mask_comp=comp, accum=accum, replace=repl)
+    exp_plain = O.mxv(oa, O.OVec(n, ui, uv, tname), sr)
+    xi, xv = rand_vec(rng, m, 0.6, tname)
+    exp_t = O.vxm(O.OVec(m, xi, xv, tname), oa, sr)
+    try:
+        for name, val in ((b"split_min_nnz", 1), (b"split_min_len", 8), (b"push_mode", 0), (b"hot_min_cols", 8),
+                          (b"hot_k", [64, 256, 2048, 1 << 20][seed % 4]), (b"long_kernel", 4), (b"long_classes", [16, 8, 32, 64][(seed // 2) % 4]),
+                          (b"short_kernel", 5 if seed % 3 else DEFAULT_SHORT_KERNEL),
+                          (b"vec_pad_min_bytes", 0 if seed % 2 else 1 << 20)):
+            _lib.lib.GrX_option_set(name, val)
+        A = gb.Matrix.from_coo(rows, cols, vals, dtype=tname, nrows=m, ncols=n)
+        u = gb.Vector.from_coo(ui, uv, dtype=tname, size=n)
+        w = gb.Vector.from_coo(wi, wv, dtype=tname, size=m)
+        mk = gb.Vector.from_coo(mi, mv, dtype="BOOL", size=m)
+        w(~mk.V if comp else mk.V, accum=accum, replace=repl) << A.mxv(u, getattr(gb.semiring, sr))
+        st = device.last_stats()
+        # (a 64-entry table covers too few references to be built: those seeds run the cold strips alone)
+        assert st["method"] == 5 or (st["long_kernel"] == 4 and st["long_entries"] > 0 and (st["hot_k"] > 0 or seed % 4 == 0)), st
+        same_vec(w, exp)
+        same_vec(A.mxv(u, getattr(gb.semiring, sr)).new(), exp_plain)
+        x = gb.Vector.from_coo(xi, xv, dtype=tname, size=m)
+        same_vec(x.vxm(A, getattr(gb.semiring, sr)).new(), exp_t)
+        if tname != "BOOL":
+            # a FULL operand under the semirings the fast hot-strip kernel takes for 4- and 8-byte types (k_mxv_hstrip: padding by an
+            # absorbing LDS word, scalar scan masks, byte mask probes), with and without a mask that switches long rows off
+            fv = rand_vals(rng, n, tname)
+            uf, ouf = gb.Vector.from_coo(np.arange(n), fv, dtype=tname, size=n), O.OVec(n, np.arange(n), fv, tname)
+            for sr2 in ("min_plus", "max_plus", "plus_times"):
+                same_vec(A.mxv(uf, getattr(gb.semiring, sr2)).new(), O.mxv(oa, ouf, sr2))
+                w2 = gb.Vector.from_coo(wi, wv, dtype=tname, size=m)
+                w2(~mk.S if comp else mk.S, accum=accum, replace=repl) << A.mxv(uf, getattr(gb.semiring, sr2))
+                same_vec(w2, O.mxv(oa, ouf, sr2, w=O.OVec(m, wi, wv, tname), mask=O.OVec(m, mi, mv, "BOOL"), mask_comp=comp, mask_struct=True,
+                                   accum=accum, replace=repl))
+    finally:
+        for name, val in ((b"split_min_nnz", 1 << 22), (b"split_min_len", 0), (b"push_mode", 1), (b"hot_min_cols", 1 << 20), (b"hot_k", 0),
+                          (b"long_kernel", DEFAULT_LONG_KERNEL), (b"long_classes", 16), (b"vec_pad_min_bytes", 1 << 20),
+                          (b"short_kernel", DEFAULT_SHORT_KERNEL)):
+            _lib.lib.GrX_option_set(name, val)
 
 
 @pytest.mark.parametrize("seed", range(4))
@@ -599,7 +672,7 @@ def test_split_survives_mixed_calls_and_option_changes(gb, seed):
         e2 = O.mxv(oa, O.OVec(n, ui, uv.astype(O.NP_OF[other]), other), "plus_times")
         gi2, gv2 = g2.to_coo()
         assert gi2.tolist() == e2.idx.tolist() and np.allclose(gv2.astype(np.float64), e2.vals.astype(np.float64), rtol=1e-6)
-        for ncls, kernel in ((32, 2), (32, 1), (16, 2)):
+        for ncls, kernel in ((32, 2), (32, 1), (16, 4), (64, 4), (16, 2)):
             _lib.lib.GrX_option_set(b"long_classes", ncls)
             _lib.lib.GrX_option_set(b"long_kernel", kernel)
             same_vec(A.mxv(u, gb.semiring.min_plus).new(), exp)
@@ -712,7 +785,7 @@ def test_long_rows_many_chunks(gb, seed, request):
         _lib.lib.GrX_option_set(b"split_min_nnz", 1)
         _lib.lib.GrX_option_set(b"split_min_len", 2)
         _lib.lib.GrX_option_set(b"push_mode", 0)
-        _lib.lib.GrX_option_set(b"long_kernel", 0 if seed in (1, 5) else (1 if seed == 2 else 2))  # chunk kernel / item kernel / class strips
+        _lib.lib.GrX_option_set(b"long_kernel", [2, 0, 1, 4, 4, 0][seed])  # class strips / chunk kernel / item kernel / hot + cold strips
         _lib.lib.GrX_option_set(b"long_sub", [2, 1, 4, 3, 16, 1][seed])  # sub-ranges per class of the cold columns
         _lib.lib.GrX_option_set(b"long_sub_min_len", [2, 2, 600, 1025, 2, 2][seed])
         A = gb.Matrix.from_coo(rows, cols, vals, dtype=tname, nrows=m, ncols=n)
@@ -925,6 +998,11 @@ def test_long_rows_terminal_monoids(gb, seed):
     try:
         _lib.lib.GrX_option_set(b"split_min_nnz", 1)
         _lib.lib.GrX_option_set(b"push_mode", 0)
+        # (the item kernel BOOL matrices get by default / the hot + cold strips / the class strips: each has its own early exit)
+        _lib.lib.GrX_option_set(b"long_kernel", [DEFAULT_LONG_KERNEL, 4, 2, DEFAULT_LONG_KERNEL, 4, DEFAULT_LONG_KERNEL][seed])
+        if seed in (1, 4):
+            _lib.lib.GrX_option_set(b"hot_min_cols", 8)
+            _lib.lib.GrX_option_set(b"hot_k", 4096)
         A = gb.Matrix.from_coo(rows, cols, vals, dtype="BOOL", nrows=m, ncols=n)
         u = gb.Vector.from_coo(ui, uv, dtype="BOOL", size=n)
         mk = gb.Vector.from_coo(mi, mv, dtype="BOOL", size=m)
@@ -938,6 +1016,9 @@ def test_long_rows_terminal_monoids(gb, seed):
         _lib.lib.GrX_option_set(b"debug_flags", 0)
         _lib.lib.GrX_option_set(b"split_min_nnz", 1 << 22)
         _lib.lib.GrX_option_set(b"push_mode", 1)
+        _lib.lib.GrX_option_set(b"long_kernel", DEFAULT_LONG_KERNEL)
+        _lib.lib.GrX_option_set(b"hot_min_cols", 1 << 20)
+        _lib.lib.GrX_option_set(b"hot_k", 0)
 
 
 @pytest.mark.parametrize("seed", range(8))
