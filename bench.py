@@ -961,7 +961,7 @@ def main():
         dist.destroy_process_group()
 
 
-MXV_KERNELS_NOTE = ("one GrB_mxv call: k_mxv_strip (k_mxv_long_grp for BOOL matrices) + k_mxv_rows (+ k_x_image, k_long_init); "
+MXV_KERNELS_NOTE = ("one GrB_mxv call: k_mxv_hstrip + k_mxv_cstrip (k_mxv_long_grp for BOOL matrices) + k_mxv_rows_tag (+ k_x_image, k_long_init); "
                     "k_mxv_pull + k_mxv_seams below the split threshold")
 
 

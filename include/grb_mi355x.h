@@ -108,7 +108,7 @@ GrB_Info GrB_Matrix_exportSize(GrB_Index *Ap_len, GrB_Index *Ai_len, GrB_Index *
                                const GrB_Matrix A);
 GrB_Info GrB_Matrix_exportHint(GrB_Format *format, const GrB_Matrix A);
 GrB_Info GrB_transpose(GrB_Matrix C, const GrB_Matrix Mask, const GrB_BinaryOp accum, const GrB_Matrix A,
-                       const GrB_Descriptor desc); /* Mask/accum must be NULL (only the plain transpose is on the path) */
+                       const GrB_Descriptor desc); /* C<Mask, replace> = accum(C, A') (or A with T0), through the matrix write rule of GrB_mxm */
 
 /* ---- Vector ------------------------------------------------------------------------------- */
 GrB_Info GrB_Vector_new(GrB_Vector *v, GrB_Type type, GrB_Index n);
@@ -267,7 +267,7 @@ typedef struct {
     int64_t hot_k;            /* mxv/vxm: entries of the hot-column table used by the call (0 = none) */
     int64_t long_entries;     /* mxv/vxm over a split matrix: entries held by the long rows (0 = no split) */
     int64_t long_segments;    /* ... as class strips: (class, sub-range, row) segments = atomics of an unmasked call */
-    int32_t long_kernel;      /* ... long-row kernel that ran: 0 chunks, 1 class items, 2 class strips; -1 = no split */
+    int32_t long_kernel;      /* ... long-row kernel that ran: 0 chunks, 1 class items, 2 mixed class strips, 4 hot / cold strips; -1 = no split */
     int32_t reserved_;
 } GrX_Stats;
 GrB_Info GrX_last_stats(GrX_Stats *stats);
@@ -302,10 +302,14 @@ GrB_Info GrX_Matrix_cache_bytes(const GrB_Matrix A, uint64_t *bytes);
  *                   second pull product; the first one runs on the CSR arrays as they are.  0: built at the first product.
  *   "drop_hot_cols" 1 (default): the hot-coded copy of a matrix's whole column array is released once the long / short split has
  *                   been built from it (the split's parts carry their own re-coded columns)
- *   "long_kernel"   layout / kernel of the long rows: 3 (default) class strips, items for BOOL matrices; 2 class strips (k_mxv_strip);
- *                   1 class-partitioned items (k_mxv_long_grp); 0 chunks straight from the CSR arrays (k_mxv_long)
+ *   "long_kernel"   layout / kernel of the long rows: 5 (default) hot / cold strips, items for BOOL matrices; 4 hot / cold strips for
+ *                   every type (entries whose column is LDS-resident in its class as 16-bit lane records, k_mxv_hstrip; the others as
+ *                   strips of contiguous column ranges, k_mxv_cstrip; operands the lean kernels do not take: k_mxv_strip); 3 mixed class
+ *                   strips, items for BOOL matrices; 2 mixed class strips (k_mxv_strip); 1 class-partitioned items (k_mxv_long_grp);
+ *                   0 chunks straight from the CSR arrays (k_mxv_long)
  *   "long_classes"  column classes of the class strips: 8, 16 (default), 32 or 64 distinct LDS heads across the chip
- *   "short_kernel"  short rows of a split matrix: 1 (default) one wavefront per 64 rows, 0 merge-path tiles, 2 sliced ELLPACK
+ *   "short_kernel"  short rows of a split matrix: 5 (default) tagged row groups (the row of every entry stored with it, k_mxv_rows_tag),
+ *                   1 one wavefront per 64 rows with row marks and a segmented fold (k_mxv_rows), 0 merge-path tiles, 2 sliced ELLPACK
  *                   with a lane per row ("sell_sigma" rows per sort window; measured slower), 3 persistent
  *                   workgroups with an LDS head, 4 a lane per row folding products staged in LDS (both measured slower)
  *   "long_sub"      sub-ranges per class of the cold columns of the long rows (0 = sized from the operand image),

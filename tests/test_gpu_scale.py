@@ -445,7 +445,7 @@ def test_scale24_headline_calls(gb):
             w(~vis.S, accum=gb.binary.min) << A.mxv(u, gb.semiring.min_plus)
             st = device.last_stats()
             if call == 1:
-                assert st["long_kernel"] == 2 and st["long_entries"] > 100_000_000 and st["hot_k"] > 0
+                assert st["long_kernel"] == 4 and st["long_entries"] > 100_000_000 and st["hot_k"] > 0
             else:
                 assert st["long_kernel"] == -1 and st["hot_k"] == 0
             wv, wb = device.vector_device_views(w)
@@ -500,7 +500,7 @@ def test_kron26_rank_block(gb):
         w_b = device.vector_from_device(torch.from_numpy(uv[lo:hi].copy()).cuda())
         w_b(accum="min") << B.mxv(u, gb.semiring.min_plus)
         st = device.last_stats()
-        assert (st["hot_k"] > 0) == (call == 1) and (st["long_kernel"] == 2) == (call == 1)
+        assert (st["hot_k"] > 0) == (call == 1) and (st["long_kernel"] == 4) == (call == 1)
         wv, _ = device.vector_device_views(w_b)
         assert np.array_equal(wv.cpu().numpy(), exp_plain.vals)
     w_b = device.vector_from_device(torch.from_numpy(uv[lo:hi].copy()).cuda())

@@ -14,8 +14,8 @@ from tests.backend import DEVICES, bind
 TYPES = ["INT64", "FP32", "BOOL", "FP64", "INT8", "UINT16", "INT32"]
 import os
 
-DEFAULT_SHORT_KERNEL = int(os.environ.get("GRB_SHORT_KERNEL", "1"))
-DEFAULT_LONG_KERNEL = int(os.environ.get("GRB_LONG_KERNEL", "3"))  # what tests restore after forcing a long-row kernel
+DEFAULT_SHORT_KERNEL = int(os.environ.get("GRB_SHORT_KERNEL", "5"))
+DEFAULT_LONG_KERNEL = int(os.environ.get("GRB_LONG_KERNEL", "5"))  # what tests restore after forcing a long-row kernel
 
 
 @pytest.fixture(params=DEVICES)
@@ -501,7 +501,7 @@ def test_long_short_row_split(gb, seed):
         _lib.lib.GrX_option_set(b"long_sub_min_len", 64 if seed & 1 else 8)
         # long rows: by matrix type (strips, items for BOOL) / strips for every type incl. BOOL / items for every type
         # ... / hot + cold strips for every type / by type with the hot + cold strips
-        forced_long = [DEFAULT_LONG_KERNEL, 2, 1, 4, 5][seed % 5]
+        forced_long = [DEFAULT_LONG_KERNEL, 2, 1, 4, 3][seed % 5]
         _lib.lib.GrX_option_set(b"long_kernel", forced_long)
         _lib.lib.GrX_option_set(b"long_classes", [16, 8, 32, 16, 64][seed % 5])
         A = gb.Matrix.from_coo(rows, cols, vals, dtype=tname, nrows=m, ncols=n)
