@@ -61,6 +61,11 @@ def parse():
     p.add_argument("--stream-budget-gb", type=float, default=64.0, help="mxm --streamed: device bytes one batch's product may take")
     p.add_argument("--extra", action="store_true", help="(kept for old command lines: the secondary workloads now run by default)")
     p.add_argument("--no-extra", action="store_true", help="headline workload only: skip the lines reported under 'extra'")
+    p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                   help="N > 1: torch.distributed backend (nccl = RCCL; gloo only to rehearse the N-rank code path on a box with fewer GPUs)")
+    p.add_argument("--share-gpus", action="store_true",
+                   help="N > 1 rehearsal: ranks beyond the visible GPUs share devices (rank r on GPU r %% device_count; needs --backend gloo: "
+                        "RCCL refuses two ranks on one device); the line is marked as a rehearsal and is no measurement")
     p.add_argument("--overlap-chunks", type=int, default=2,
                    help="N > 1: row blocks per rank; the all-gather of block c overlaps the product of block c + 1 (1 = no overlap)")
     return p.parse_args()
@@ -739,7 +744,7 @@ def respawn_under_launcher(args):
     import torch
 
     have = torch.cuda.device_count() if torch.cuda.is_available() else 0
-    if have < args.gpus:
+    if have < args.gpus and not (args.share_gpus and have >= 1):
         sys.stderr.write(f"bench.py: --gpus {args.gpus} needs {args.gpus} visible GPUs on this node, found {have}; "
                          "not falling back to fewer ranks (the line would claim a rank count it did not run)\n")
         sys.exit(2)
@@ -773,12 +778,20 @@ def main():
                              f"torch.distributed.run --nproc-per-node {args.gpus}\n")
             sys.exit(2)
         args.gpus = world
+    if args.share_gpus:
+        if args.backend != "gloo":
+            sys.stderr.write("bench.py: --share-gpus needs --backend gloo (RCCL refuses two ranks on one device)\n")
+            sys.exit(2)
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
         seen = torch.ones(1, device="cuda")
         dist.all_reduce(seen)  # every rank adds one: the ranks really see each other over RCCL
         assert int(seen.item()) == world == dist.get_world_size(), (seen.item(), world)
@@ -954,6 +967,9 @@ def main():
         }
         if "exchange" in res:
             out["exchange"] = res["exchange"]
+        if args.share_gpus or args.backend != "nccl":
+            out["rehearsal"] = (f"backend {args.backend}" + (", ranks share GPUs" if args.share_gpus else "") +
+                                ": the N-rank code path was exercised; the numbers are NOT a multi-GPU measurement")
         if extra:
             out["extra"] = extra
         print(json.dumps(out))

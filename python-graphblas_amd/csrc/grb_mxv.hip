@@ -243,13 +243,13 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
             if (kind == 4)
                 hipLaunchKernelGGL(k_long_keys, dim3((unsigned)nl), dim3(256), 0, ctx().stream, (const int64_t *)A->d_ptr,
                                    (const int64_t *)S->d_ptr, (const int32_t *)A->d_long_rows, col_src, nl, keys.p, idx.p,
-                                   (unsigned)lds_lim4, (unsigned)std::max<int64_t>(1, ceil_div(codes_total - lds_lim4, (int64_t)COLD_CLS * (int64_t)sub)),
-                                   sub, sub_min_len, (unsigned)ncls, 2);
+                                   (unsigned)lds_lim4, (unsigned)std::max<int64_t>(1, ceil_div(codes_total - std::max<int64_t>(lds_lim4, hot ? A->hot_k : 0), (int64_t)COLD_CLS * (int64_t)sub)),
+                                   sub, sub_min_len, (unsigned)ncls, 2, (unsigned)(hot ? A->hot_k : 0));
             else
             hipLaunchKernelGGL(k_long_keys, dim3((unsigned)nl), dim3(256), 0, ctx().stream, (const int64_t *)A->d_ptr,
                                (const int64_t *)S->d_ptr, (const int32_t *)A->d_long_rows, col_src, nl, keys.p, idx.p,
                                (unsigned)(hot ? A->hot_k : 0), (unsigned)std::max<int64_t>(1, ceil_div((int64_t)A->ncols, (int64_t)ncls * (int64_t)sub)),
-                               sub, sub_min_len, (unsigned)ncls, kind == 2 ? 1 : 0);
+                               sub, sub_min_len, (unsigned)ncls, kind == 2 ? 1 : 0, 0u);
             // (virtual classes: kind 2 ncls * sub; kind 4 ncls hot classes + COLD_CLS cold ranges, with `sub` = 1 in the segment tables)
             const int nvc = kind == 4 ? ncls + COLD_CLS : ncls;                       // classes (chunk ranges)
             const int nvirt = kind == 4 ? ncls + COLD_CLS * (int)sub : ncls * (int)sub;  // virtual classes (sort keys)

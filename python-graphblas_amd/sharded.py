@@ -215,6 +215,9 @@ class OverlappedMxv:
         self.presence = presence
         self.k = 0
         self.staged = False
+        # (gloo moves CPU tensors only: device images are exchanged through host copies -- the rehearsal mode of bench.py on a box with
+        #  fewer GPUs than ranks; RCCL takes the device images as they are)
+        self.host_staged = device != "cpu" and dist.get_backend() == "gloo"
         n = self.u[0]._size
         world = dist.get_world_size()
         if n % (64 * world * self.chunks):
@@ -253,6 +256,17 @@ class OverlappedMxv:
         out_v = self.u_vals[dst][c * n_c: (c + 1) * n_c]
         part_v = self.w_vals[c][:h]
         works = []
+        if self.host_staged:
+            torch = self._torch()
+            pairs = [(out_v, part_v)]
+            if self.presence:
+                pairs.append((self.u_words[dst][c * n_c // 32: (c + 1) * n_c // 32], self.w_words[c][: h // 32]))
+            for out_t, part_t in pairs:
+                send = part_t.cpu()
+                recv = torch.empty(out_t.numel(), dtype=send.dtype)
+                _gather(self.dist, recv, send)
+                out_t.copy_(recv)
+            return works
         if self.staged:
             torch = self._torch()
             send = part_v.clone()
