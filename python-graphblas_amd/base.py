@@ -113,6 +113,18 @@ def _check_mask(mask, output=None):
 
 
 # ---- collections' common base ----------------------------------------------------------------------------
+def _output_param_kind(item):
+    """What a positional output parameter is: a mask (a Mask view or a collection used as one), the ``replace`` marker, or an
+    accumulator (an operator, or its name); anything else is rejected with the reference's message."""
+    if item is _replace_singleton:
+        return "replace"
+    if isinstance(item, (Mask, BaseType)):
+        return "mask"
+    if isinstance(item, (str, TypedOp)) or hasattr(item, "opclass"):
+        return "accum"
+    raise TypeError(f"Invalid item found in output params: {type(item)}")
+
+
 class BaseType:
     _grb_kind = None
     _is_transposed = False
@@ -126,37 +138,26 @@ class BaseType:
         return ValueMask(self)
 
     def __call__(self, *args, mask=None, accum=None, replace=False, **opts):
-        """Parse ``(mask, accum, replace)`` in any order (reference core/base.py:192-263)."""
-        mask_arg = accum_arg = None
-        for arg in args:
-            if isinstance(arg, (Mask, BaseType)):
-                if mask_arg is not None:
-                    raise TypeError("Got multiple values for argument 'mask'")
-                mask_arg = arg
-            elif arg is _replace_singleton:
+        """The output parameters of an update, ``w(mask, accum, replace) << expr``: positional and keyword spellings in any order
+        (behaviour pinned by the reference's tests, tests/test_vector.py:350-368, tests/test_matrix.py:373-374; counterpart of
+        core/base.py:192-263)."""
+        given = {"mask": [mask] if mask is not None else [], "accum": [accum] if accum is not None else []}
+        for item in args:
+            kind = _output_param_kind(item)
+            if kind == "replace":
                 replace = True
             else:
-                if accum_arg is not None:
-                    raise TypeError("Got multiple values for argument 'accum'")
-                if not isinstance(arg, (str, TypedOp)) and not hasattr(arg, "opclass"):
-                    raise TypeError(f"Invalid item found in output params: {type(arg)}")
-                accum_arg = arg
-        if mask_arg is not None and mask is not None:
-            raise TypeError("Got multiple values for argument 'mask'")
-        if mask_arg is not None:
-            mask = mask_arg
-        if mask is None:
-            if replace:
-                raise TypeError("'replace' argument may only be True if a mask is provided")
-        else:
-            mask = _check_mask(mask)
-        if accum_arg is not None:
-            if accum is not None:
-                raise TypeError("Got multiple values for argument 'accum'")
-            accum = accum_arg
-        if accum is not None:
-            accum = get_typed_op(accum, self.dtype, kind="binary")
-            if accum.opclass == "Monoid":
+                given[kind].append(item)
+        for name, found in given.items():
+            if len(found) > 1:
+                raise TypeError(f"Got multiple values for argument '{name}'")
+        mask = _check_mask(given["mask"][0]) if given["mask"] else None
+        if mask is None and replace:
+            raise TypeError("'replace' argument may only be True if a mask is provided")
+        accum = None
+        if given["accum"]:
+            accum = get_typed_op(given["accum"][0], self.dtype, kind="binary")
+            if accum.opclass == "Monoid":  # (a monoid given as the accumulator means its binary operator)
                 accum = accum.binaryop
         return Updater(self, mask=mask, accum=accum, replace=replace, opts=opts)
 

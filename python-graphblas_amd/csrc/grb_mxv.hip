@@ -37,7 +37,9 @@ namespace grb {
 #include "grb_mxv_strip.inc"
 #include "grb_mxv_rows.inc"
 #include "grb_mxv_rows_tag.inc"
+#ifdef GRB_EXPERIMENTAL_KERNELS  // the short-row kernels that were measured slower: `make experimental`
 #include "grb_mxv_sell.inc"
+#endif
 #include "grb_mxv_split_build.inc"
 #include "grb_mxv_write.inc"
 #include "grb_mxv_push.inc"
@@ -423,6 +425,7 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
     }
 }
 
+#ifdef GRB_EXPERIMENTAL_KERNELS
 // sliced-ELLPACK copy of the short part S of A (once per matrix; see grb_mxv_sell.inc)
 static void ensure_sell(GB_Matrix_opaque *A)
 {
@@ -467,6 +470,8 @@ static void ensure_sell(GB_Matrix_opaque *A)
     A->sell_slots = slots;
     A->sell_state = 1;
 }
+
+#endif
 
 // tagged row groups of the short part S of A (once per matrix; see grb_mxv_rows_tag.inc)
 static void ensure_tagged(GB_Matrix_opaque *A)
@@ -634,6 +639,23 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
         b.long_bits = A->d_long_bits;
         b.n_chunks = 0;
         b.n_long_epi = a.n_long;
+        if (ctx().short_kernel == 5 && S->nrows == A->nrows && S->nvals < 0x1ffffffffll) {
+            // short rows as tagged row groups: the row of every entry is stored with it (no marks, no scan, no segmented fold)
+            ensure_tagged(A);
+            b.long_prefix = A->d_long_prefix;
+            b.tg_off = A->d_tg_off;
+            b.tg_col = A->d_tg_col;
+            b.tg_val = A->d_tg_val;
+            b.tg_tag = A->d_tg_tag;
+            b.tg_nonempty = A->d_tg_nonempty;
+            hipLaunchKernelGGL((k_mxv_rows_tag<T, MON, MUL>), dim3((unsigned)ceil_div(ceil_div(b.m, 64), (ROWS_BLOCK / 64) * TAG_K)), dim3(ROWS_BLOCK), 0,
+                               ctx().stream, b);
+            GRB_HIP(hipGetLastError());
+            ctx().stats.kernel_launches += 1;
+            ctx().stats.tiles = ceil_div(b.m, 64);
+            return;
+        }
+#ifdef GRB_EXPERIMENTAL_KERNELS
         if (ctx().short_kernel == 2 && S->nrows == A->nrows && A->nrows < 0x7fffffffll) {
             // short rows in sliced-ELLPACK form: a lane per row, which also applies the write rule of the long rows
             ensure_sell(A);
@@ -651,22 +673,6 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
             GRB_HIP(hipGetLastError());
             ctx().stats.kernel_launches += 1;
             ctx().stats.tiles = A->sell_slots;  // (slots incl. padding; the short part holds S->nvals entries)
-            return;
-        }
-        if (ctx().short_kernel == 5 && S->nrows == A->nrows && S->nvals < 0x1ffffffffll) {
-            // short rows as tagged row groups: the row of every entry is stored with it (no marks, no scan, no segmented fold)
-            ensure_tagged(A);
-            b.long_prefix = A->d_long_prefix;
-            b.tg_off = A->d_tg_off;
-            b.tg_col = A->d_tg_col;
-            b.tg_val = A->d_tg_val;
-            b.tg_tag = A->d_tg_tag;
-            b.tg_nonempty = A->d_tg_nonempty;
-            hipLaunchKernelGGL((k_mxv_rows_tag<T, MON, MUL>), dim3((unsigned)ceil_div(ceil_div(b.m, 64), (ROWS_BLOCK / 64) * TAG_K)), dim3(ROWS_BLOCK), 0,
-                               ctx().stream, b);
-            GRB_HIP(hipGetLastError());
-            ctx().stats.kernel_launches += 1;
-            ctx().stats.tiles = ceil_div(b.m, 64);
             return;
         }
         if (ctx().short_kernel == 3 && S->nrows == A->nrows) {
@@ -692,7 +698,8 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
                 return;
             }
         }
-        if ((ctx().short_kernel == 1 || ctx().short_kernel == 4 || ctx().short_kernel == 5) && S->nrows == A->nrows) {
+#endif
+        if (ctx().short_kernel != 0 && S->nrows == A->nrows) {  // (also what the experimental kernels fall back to in a build without them)
             // short rows: one wavefront per 64 consecutive rows, which also applies the write rule of the long rows
             b.long_prefix = A->d_long_prefix;
             // (persistent variants -- static strides with the next group prefetched, or an LDS work counter per workgroup --
