@@ -259,8 +259,14 @@ struct GB_Matrix_opaque {
     // (d_lcol[0] is the first entry of chunk cold_cb[0]); d_sstart / d_sslot cover both
     char *d_hrec = nullptr;
     int hrec_bytes = 0;                // bytes of one lane record
-    int strip_cold_ncls = 0;
-    int64_t cold_cb[9] = {0};
+    // ... the cold entries as tagged tiles (k_mxv_ctile, grb_mxv_ctile.inc): sorted by (column range, long row), tile t = (range
+    // t / ct_nsb, rows [8192 (t % ct_nsb), ...)) holds entries [tiles[t].u0 * 4, ... + 4 n_units): column code, value, 16-bit row in the tile
+    int32_t *d_ct_col = nullptr;
+    void *d_ct_val = nullptr;          // nullptr for iso matrices
+    uint16_t *d_ct_loc = nullptr;
+    void *d_ct_tiles = nullptr;        // CTile[ct_ncr * ct_nsb]
+    int ct_nsb = 0, ct_ncr = 0;
+    int64_t ct_units = 0;
     int split_kind = 0;                // value of the long_kernel option the split was built for
     int pull_calls = 0;                // pull products run on this matrix since its layouts were last dropped
     // the short rows once more in sliced-ELLPACK form (k_mxv_sell; built on first use when short_kernel = 2)

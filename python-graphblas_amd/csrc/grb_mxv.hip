@@ -37,6 +37,7 @@ namespace grb {
 #include "grb_mxv_strip.inc"
 #include "grb_mxv_rows.inc"
 #include "grb_mxv_rows_tag.inc"
+#include "grb_mxv_ctile.inc"
 #ifdef GRB_EXPERIMENTAL_KERNELS  // the short-row kernels that were measured slower: `make experimental`
 #include "grb_mxv_sell.inc"
 #endif
@@ -169,6 +170,8 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
         A->d_tg_off = nullptr; A->d_tg_col = nullptr; A->d_tg_val = nullptr; A->d_tg_tag = nullptr; A->d_tg_nonempty = nullptr; A->tg_state = 0;
         dev_free(A->d_sstart); dev_free(A->d_sslot); dev_free(A->d_hrec);
         A->d_sstart = nullptr; A->d_sslot = nullptr; A->d_hrec = nullptr; A->strip_nseg = 0;
+        dev_free(A->d_ct_col); dev_free(A->d_ct_val); dev_free(A->d_ct_loc); dev_free(A->d_ct_tiles);
+        A->d_ct_col = nullptr; A->d_ct_val = nullptr; A->d_ct_loc = nullptr; A->d_ct_tiles = nullptr; A->ct_units = 0;
         A->d_lcol = nullptr; A->d_lval = nullptr; A->d_it_start = nullptr; A->d_it_len = nullptr; A->d_it_slot = nullptr;
         A->d_item_begin = nullptr; A->long_nnz = 0; A->n_items = 0;
         A->d_long_prefix = nullptr;
@@ -230,13 +233,15 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
             const int COLD_CLS = 8;
             const int64_t lds_lim4 = std::min<int64_t>(hot ? A->hot_k : 0, long_lds_codes((int)A->type->size, A->type->code == TC_BOOL, LONG_LDS_WORDS) / 8 * ncls);
             const int64_t codes_total = (int64_t)A->ncols + (hot ? A->hot_k : 0);
-            // (kind 4: `sub` = sub-ranges per COLD class -- 8 cold classes whatever the number of hot ones)
+            // (kind 4: the cold entries go to tagged tiles of 8 * `sub` column ranges of ~3 MiB of the operand image each, every row cut)
             const int range_cls = kind == 4 ? COLD_CLS : ncls;
             unsigned sub = 1;
-            if (ctx().long_sub > 0) sub = (unsigned)std::min(16, ctx().long_sub);
-            else if (A->type->code != TC_BOOL)
-                while (sub < 16 && (int64_t)A->ncols * (int64_t)A->type->size > (int64_t)sub * range_cls * (3ll << 20)) sub *= 2;
-            const int64_t sub_min_len = ctx().long_sub_min_len > 0 ? ctx().long_sub_min_len : 512 * (int64_t)sub;
+            if (ctx().long_sub > 0) sub = (unsigned)std::min(kind == 4 ? 8 : 16, ctx().long_sub);
+            else if (A->type->code != TC_BOOL || kind == 4) {
+                const int64_t image_bytes = A->type->code == TC_BOOL ? (int64_t)A->ncols / 8 : (int64_t)A->ncols * (int64_t)A->type->size;
+                while (sub < (kind == 4 ? 8u : 16u) && image_bytes > (int64_t)sub * range_cls * (3ll << 20)) sub *= 2;
+            }
+            const int64_t sub_min_len = kind == 4 ? 0 : (ctx().long_sub_min_len > 0 ? ctx().long_sub_min_len : 512 * (int64_t)sub);
             const int64_t nv = (int64_t)ncls * (int64_t)sub * nl;
             int bits = 1;
             while (((int64_t)1 << bits) < nv) bits++;
@@ -253,9 +258,11 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
                                (unsigned)(hot ? A->hot_k : 0), (unsigned)std::max<int64_t>(1, ceil_div((int64_t)A->ncols, (int64_t)ncls * (int64_t)sub)),
                                sub, sub_min_len, (unsigned)ncls, kind == 2 ? 1 : 0, 0u);
             // (virtual classes: kind 2 ncls * sub; kind 4 ncls hot classes + COLD_CLS cold ranges, with `sub` = 1 in the segment tables)
-            const int nvc = kind == 4 ? ncls + COLD_CLS : ncls;                       // classes (chunk ranges)
+            const int nvc = ncls;                                                       // classes of the strips (chunk ranges)
             const int nvirt = kind == 4 ? ncls + COLD_CLS * (int)sub : ncls * (int)sub;  // virtual classes (sort keys)
-            const int hot_cls = kind == 4 ? ncls : 0;
+            const int n_cr = COLD_CLS * (int)sub;                                       // kind 4: column ranges of the cold tiles
+            const int hot_cls = 0;
+            const unsigned strip_sub = kind == 4 ? 1u : sub;                            // virtual classes per strip class
             if (strips) {
                 int vbits = 1;
                 while ((1 << vbits) < nvirt) vbits++;
@@ -263,19 +270,38 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
             } else {
                 prim_sort_pairs_u64_u32(keys.p, keys2.p, idx.p, idx2.p, nnz_long, bits);
             }
-            if (strips) {
+            // kind 4: the sorted entries are [hot: virtual classes 0 .. ncls - 1 | cold: column ranges ncls .. ncls + n_cr - 1]; the hot
+            // part becomes strips (lane records), the cold part tagged tiles (grb_mxv_ctile.inc)
+            const int n_sb = (int)ceil_div(nl, (int64_t)CT_SLOTS);
+            const int64_t n_tiles = kind == 4 ? (int64_t)n_cr * n_sb : 0;
+            std::vector<int64_t> h_first((size_t)n_tiles + 1, 0);
+            DevBuf<int64_t> tile_first(n_tiles + 1);
+            int64_t n_strip = nnz_long;
+            if (kind == 4) {
+                hipLaunchKernelGGL(k_ctile_first, dim3((unsigned)ceil_div(n_tiles + 1, 256)), dim3(256), 0, ctx().stream, (const uint64_t *)keys2.p, nnz_long,
+                                   n_tiles, n_sb, (unsigned)ncls, tile_first.p);
+                d2h(h_first.data(), tile_first.p, sizeof(int64_t) * (size_t)(n_tiles + 1));
+                n_strip = h_first[0];
+            }
+            if (kind == 4) {
+                A->long_nnz = nnz_long;
+                A->strip_ncls = ncls;
+                A->strip_nseg = 0;
+                A->cls_lds_lim = (int)lds_lim4;
+                for (int c = 0; c <= ncls; c++) A->strip_cb[c] = 0;
+            }
+            if (strips && n_strip > 0) {
                 // flat class strips (grb_mxv_strip.inc): segments = runs of equal keys; every segment padded to a multiple of 8
-                // entries, every class to whole chunks of 512.  Kind 4: classes 0 .. ncls - 1 are the hot strips (lane records in
-                // d_hrec), classes ncls .. ncls + COLD_CLS - 1 the cold strips (d_lcol / d_lval), one chunk numbering over both
-                const int64_t nblk = ceil_div(nnz_long, STRIP_CH);
+                // entries, every class to whole chunks of 512.  Kind 4: the hot entries only, as lane records in d_hrec
+                const int64_t nblk = ceil_div(n_strip, STRIP_CH);
                 DevBuf<int64_t> blk(nblk + 1);
-                hipLaunchKernelGGL(k_strip_count, dim3((unsigned)nblk), dim3(STRIP_CH), 0, ctx().stream, (const uint64_t *)keys2.p, nnz_long, blk.p);
+                hipLaunchKernelGGL(k_strip_count, dim3((unsigned)nblk), dim3(STRIP_CH), 0, ctx().stream, (const uint64_t *)keys2.p, n_strip, blk.p);
                 prim_exclusive_sum_i64(blk.p, blk.p, nblk + 1);
                 int64_t nseg = 0;
                 d2h(&nseg, blk.p + nblk, 8);
                 if (nseg >= 0x7ffffff0ll) fail(GrB_NOT_IMPLEMENTED, "class strips: too many segments for 32-bit numbering");
                 DevBuf<int64_t> seg_first(nseg + 1), off(nseg + 1);
-                hipLaunchKernelGGL(k_strip_seg_fill, dim3((unsigned)nblk), dim3(STRIP_CH), 0, ctx().stream, (const uint64_t *)keys2.p, nnz_long,
+                hipLaunchKernelGGL(k_strip_seg_fill, dim3((unsigned)nblk), dim3(STRIP_CH), 0, ctx().stream, (const uint64_t *)keys2.p, n_strip,
                                    (const int64_t *)blk.p, seg_first.p);
                 hipLaunchKernelGGL(k_strip_plen, dim3((unsigned)ceil_div(nseg + 1, 256)), dim3(256), 0, ctx().stream, (const int64_t *)seg_first.p,
                                    nseg, off.p);
@@ -283,7 +309,7 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
                 constexpr int MAXC = 64 + 8;
                 DevBuf<int64_t> sc(MAXC + 1), raw(MAXC + 1), cshift(MAXC);
                 hipLaunchKernelGGL(k_strip_class_bounds, dim3(1), dim3(128), 0, ctx().stream, (const uint64_t *)keys2.p, (const int64_t *)seg_first.p,
-                                   nseg, nl, sub, (const int64_t *)off.p, sc.p, raw.p, nvc, hot_cls);
+                                   nseg, nl, strip_sub, (const int64_t *)off.p, sc.p, raw.p, nvc, hot_cls);
                 int64_t h_raw[MAXC + 1], h_shift[MAXC], h_cb[MAXC + 1];
                 d2h(h_raw, raw.p, sizeof(int64_t) * (size_t)(nvc + 1));
                 int64_t base = 0;
@@ -296,8 +322,8 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
                 const int64_t padded = base, nch = padded / STRIP_CH;
                 h2d(cshift.p, h_shift, sizeof(int64_t) * (size_t)nvc);
                 A->cls_lds_lim = (int)lds_lim4;
-                const int64_t hot_chunks = kind == 4 ? h_cb[ncls] : 0;                 // chunks of the hot strips
-                const int64_t flat_entries = kind == 4 ? padded - hot_chunks * STRIP_CH : padded;  // entries held by d_lcol / d_lval
+                const int64_t hot_chunks = kind == 4 ? h_cb[ncls] : 0;   // chunks of the hot strips (kind 4: all of them)
+                const int64_t flat_entries = kind == 4 ? 0 : padded;     // entries held by d_lcol / d_lval
                 const int code_bytes = A->type->code == TC_BOOL ? 32 : 16;
                 const int val_bytes = A->iso ? 0 : (int)std::max<size_t>(16, 8 * A->type->size);
                 if (padded > 0 && padded < 0x7fffffff0ll) {
@@ -325,8 +351,8 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
                     }
                     GRB_DISPATCH_TYPE(A->type->code, T, {
                         hipLaunchKernelGGL((k_strip_place<T>), dim3((unsigned)nblk), dim3(STRIP_CH), 0, ctx().stream, (const uint64_t *)keys2.p,
-                                           (const uint32_t *)idx2.p, nnz_long, (const int64_t *)blk.p, (const int64_t *)seg_first.p,
-                                           (const int64_t *)off.p, (const int64_t *)cshift.p, nl, sub, col_src, (const T *)A->d_val,
+                                           (const uint32_t *)idx2.p, n_strip, (const int64_t *)blk.p, (const int64_t *)seg_first.p,
+                                           (const int64_t *)off.p, (const int64_t *)cshift.p, nl, strip_sub, col_src, (const T *)A->d_val,
                                            A->iso ? 1 : 0, A->cls_lds_lim, ncls, A->d_lcol, (T *)A->d_lval, A->d_sstart, A->d_sslot,
                                            A->d_hrec, A->hrec_bytes, hot_chunks * STRIP_CH, hot_cls);
                     })
@@ -345,16 +371,42 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
                         for (int c = 0; c < nvc; c++) fprintf(stderr, " %lld", (long long)(h_cb[c + 1] - h_cb[c]));
                         fprintf(stderr, "  segments %lld\n", (long long)nseg);
                     }
-                    A->strip_cold_ncls = 0;
-                    if (kind == 4) {
-                        A->strip_cold_ncls = COLD_CLS;
-                        for (int c = 0; c <= COLD_CLS; c++) A->cold_cb[c] = h_cb[ncls + c];
-                    }
                     A->strip_ncls = ncls;
                     A->strip_nseg = nseg;
                     A->long_nnz = nnz_long;
                     sync_stream();  // (the temporaries above are released at the end of this scope)
                 }
+            }
+            if (kind == 4 && nnz_long > n_strip) {
+                // the cold entries as tagged tiles: per tile its entries padded to a multiple of 4, in (column range, row) order
+                std::vector<CTile> h_tiles((size_t)n_tiles);
+                int64_t units = 0;
+                for (int64_t t = 0; t < n_tiles; t++) {
+                    const int64_t cnt = h_first[t + 1] - h_first[t];
+                    h_tiles[t].u0 = units;
+                    h_tiles[t].n_units = (int32_t)ceil_div(cnt, (int64_t)CT_EPL);
+                    h_tiles[t].base = (int32_t)((t % n_sb) * (int64_t)CT_SLOTS);
+                    units += h_tiles[t].n_units;
+                }
+                const size_t ents = (size_t)std::max<int64_t>(units, 1) * CT_EPL;
+                A->d_ct_tiles = dev_alloc(sizeof(CTile) * (size_t)n_tiles);
+                h2d(A->d_ct_tiles, h_tiles.data(), sizeof(CTile) * (size_t)n_tiles);
+                A->d_ct_col = (int32_t *)dev_alloc(sizeof(int32_t) * ents);
+                A->d_ct_val = A->iso ? nullptr : dev_alloc(A->type->size * ents);
+                A->d_ct_loc = (uint16_t *)dev_alloc(sizeof(uint16_t) * ents);
+                GRB_HIP(hipMemsetAsync(A->d_ct_col, 0xff, sizeof(int32_t) * ents, ctx().stream));
+                if (A->d_ct_val) GRB_HIP(hipMemsetAsync(A->d_ct_val, 0, A->type->size * ents, ctx().stream));
+                GRB_HIP(hipMemsetAsync(A->d_ct_loc, 0, sizeof(uint16_t) * ents, ctx().stream));
+                const int64_t n_cold = nnz_long - n_strip;
+                GRB_DISPATCH_TYPE(A->type->code, T, {
+                    hipLaunchKernelGGL((k_ctile_place<T>), dim3((unsigned)ceil_div(n_cold, 256)), dim3(256), 0, ctx().stream, (const uint64_t *)keys2.p,
+                                       (const uint32_t *)idx2.p, n_strip, nnz_long, (const int64_t *)tile_first.p, (const CTile *)A->d_ct_tiles, n_sb,
+                                       (unsigned)ncls, col_src, (const T *)A->d_val, A->iso ? 1 : 0, A->d_ct_col, (T *)A->d_ct_val, A->d_ct_loc);
+                })
+                A->ct_nsb = n_sb;
+                A->ct_ncr = n_cr;
+                A->ct_units = units;
+                sync_stream();
             }
             DevBuf<int64_t> vptr(strips ? 0 : nv + 1), icnt(strips ? 0 : nv + 1);
             if (!strips) {
@@ -520,7 +572,7 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
         // (ablation build GRB_STRIP_ABL & 32: one scratch slot per lane of every chunk)
         DevBuf<W> tl_val((GRB_STRIP_ABL & 32) ? std::max<int64_t>(a.n_long, (A->strip_cb[A->strip_ncls > 0 ? A->strip_ncls : 0] + 1) * 64) : a.n_long);
         DevBuf<unsigned char> tl_has(a.n_long);
-        const bool by_strip = (A->split_kind == 2 || A->split_kind == 4) && A->long_nnz > 0 && A->strip_nseg > 0;
+        const bool by_strip = (A->split_kind == 2 || A->split_kind == 4) && A->long_nnz > 0 && (A->strip_nseg > 0 || A->ct_units > 0);
         ctx().stats.long_entries = A->nvals - S->nvals;
         ctx().stats.long_segments = by_strip ? A->strip_nseg : 0;
         const bool by_class = A->split_kind == 1 && A->long_nnz > 0 && A->n_items > 0;
@@ -574,27 +626,15 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
                     if (!launched)
                         hipLaunchKernelGGL((k_mxv_strip<T, MON, MUL, LONG_LDS_WORDS, 1>), dim3((unsigned)G), dim3(LONG_BLOCK), 0, ctx().stream, a);
                 }
-                const int cc = A->strip_cold_ncls;
-                if (cc > 0 && A->cold_cb[cc] > A->cold_cb[0]) {
-                    PullArgs c2 = a;
-                    for (int c = 0; c <= cc; c++) c2.strip_cb[c] = A->cold_cb[c];
-                    c2.strip_ncls = cc;
-                    c2.cls_lds_lim = 0;
-                    c2.lcol = A->d_lcol - A->cold_cb[0] * STRIP_CH;  // (the kernel addresses entries by their global chunk number)
-                    c2.lval = A->d_lval ? (const char *)A->d_lval - (size_t)A->cold_cb[0] * STRIP_CH * sizeof(T) : nullptr;
-                    bool launched = false;
-                    if constexpr (MON >= 0) {
-                        if constexpr (hstrip_fast_semiring<T>(MON, MUL)) {
-                            if (hot_fast) {  // (two workgroups per CU: the lean kernel fits 8 wavefronts per SIMD)
-                                const int64_t Gf = std::max<int64_t>(cc, (int64_t)(ctx().num_cus * 2 / cc) * cc);
-                                hipLaunchKernelGGL((k_mxv_cstrip<T, MON, MUL>), dim3((unsigned)Gf), dim3(LONG_BLOCK), 0, ctx().stream, c2);
-                                launched = true;
-                            }
-                        }
-                    }
-                    const int64_t Gc = std::max<int64_t>(cc, (int64_t)(ctx().num_cus * COLD_WGS_PER_CU / cc) * cc);
-                    if (!launched)
-                        hipLaunchKernelGGL((k_mxv_strip<T, MON, MUL, COLD_LDS_WORDS, 0>), dim3((unsigned)Gc), dim3(LONG_BLOCK), 0, ctx().stream, c2);
+                if (A->ct_units > 0) {  // the cold entries: tagged tiles, column range by column range per XCD
+                    a.ct_col = A->d_ct_col;
+                    a.ct_val = A->d_ct_val;
+                    a.ct_loc = A->d_ct_loc;
+                    a.ct_tiles = (const CTile *)A->d_ct_tiles;
+                    a.ct_nsb = A->ct_nsb;
+                    a.ct_ncr = A->ct_ncr;
+                    const int64_t Gt = std::max<int64_t>(8, (int64_t)(ctx().num_cus * CT_WGS_PER_CU / 8) * 8);
+                    hipLaunchKernelGGL((k_mxv_ctile<T, MON, MUL>), dim3((unsigned)Gt), dim3(CT_BLOCK), 0, ctx().stream, a);
                     ctx().stats.kernel_launches += 1;
                 }
             } else
@@ -1260,11 +1300,10 @@ extern "C" GrB_Info GrX_Matrix_cache_bytes(const GrB_Matrix A, uint64_t *bytes)
         b += 8ull * (A->nrows + 1) + 4ull * (uint64_t)S->nvals + (S->iso ? vs : vs * (uint64_t)S->nvals);
         b += bits_words64(A->nrows) * 8 + 4ull * (uint64_t)A->n_long + 4ull * bits_words64(A->nrows) + 16ull * (uint64_t)A->n_chunks;
         if (A->tg_state == 1) b += (uint64_t)A->tg_units * TAG_EPL * (5 + (A->d_tg_val ? vs : 0)) + 12ull * ((A->nrows + 63) / 64);
-        if (A->split_kind == 4 && A->strip_nseg > 0) {
+        if (A->split_kind == 4 && (A->strip_nseg > 0 || A->ct_units > 0)) {
             const uint64_t hot_lanes = (uint64_t)A->strip_cb[A->strip_ncls] * 64;
-            const uint64_t cold = (uint64_t)(A->cold_cb[A->strip_cold_ncls] - A->cold_cb[0]) * STRIP_CH;
-            const uint64_t padded = hot_lanes * 8 + cold;
-            b += hot_lanes * (uint64_t)A->hrec_bytes + cold * 4 + (A->d_lval ? cold * vs : 0) + padded / 2 + padded / STRIP_CH * 8;
+            const uint64_t cold = (uint64_t)A->ct_units * CT_EPL;
+            b += hot_lanes * (uint64_t)A->hrec_bytes + hot_lanes * 4 + hot_lanes / 8 + cold * (6 + (A->d_ct_val ? vs : 0)) + 16ull * (uint64_t)(A->ct_nsb * A->ct_ncr);
         } else if (A->split_kind == 2 && A->strip_nseg > 0) {
             const uint64_t padded = (uint64_t)A->strip_cb[A->strip_ncls] * STRIP_CH;
             b += padded * 4 + (A->d_lval ? padded * vs : 0) + padded / 2 + padded / STRIP_CH * 8;

@@ -625,6 +625,52 @@ def test_hot_cold_strips(gb, seed):
 
 
 @pytest.mark.parametrize("seed", range(4))
+def test_cold_tiles_many_long_rows(gb, seed):
+    """The cold entries of a hot / cold layout as tagged tiles (k_mxv_ctile) with MORE long rows than one tile holds (8192): the
+    threshold at 2 entries makes every non-empty row long, so tiles of several row blocks and column ranges carry entries; a small
+    hot table keeps most entries cold.  Full and sparse operands, masks, an accumulator -- against the oracle."""
+    from graphblas_amd import _lib, device
+
+    rng = np.random.default_rng(9900 + seed)
+    tname = ["FP32", "INT64", "BOOL", "FP64"][seed]
+    sr = {"FP32": "min_plus", "INT64": "plus_times", "BOOL": "lor_land", "FP64": "max_plus"}[tname]
+    m, n = 21000, 3000
+    deg = rng.integers(2, 5, m)
+    deg[rng.random(m) < 0.1] = 0
+    hot = rng.permutation(n)[: n // 10]
+    rows = np.repeat(np.arange(m), deg)
+    cols = np.where(rng.random(rows.size) < 0.5, hot[rng.integers(0, hot.size, rows.size)], rng.integers(0, n, rows.size))
+    key = np.unique(rows * n + cols)
+    rows, cols = key // n, key % n
+    vals = rand_vals(rng, rows.size, tname)
+    ui, uv = rand_vec(rng, n, [1.0, 0.5][seed & 1], tname)
+    wi, wv = rand_vec(rng, m, 0.5, tname)
+    mi, mv = rand_vec(rng, m, 0.5, "BOOL")
+    accum = None if tname == "BOOL" else "min"
+    oa = O.OMat.from_coo(rows, cols, vals, m, n, tname)
+    exp = O.mxv(oa, O.OVec(n, ui, uv, tname), sr, w=O.OVec(m, wi, wv, tname), mask=O.OVec(m, mi, mv, "BOOL"), mask_comp=True,
+                mask_struct=True, accum=accum)
+    exp_plain = O.mxv(oa, O.OVec(n, ui, uv, tname), sr)
+    try:
+        for name, val in ((b"split_min_nnz", 1), (b"split_min_len", 2), (b"push_mode", 0), (b"hot_min_cols", 8), (b"hot_k", 128),
+                          (b"long_kernel", 4), (b"long_sub", 1 + seed), (b"vec_pad_min_bytes", 0)):
+            _lib.lib.GrX_option_set(name, val)
+        A = gb.Matrix.from_coo(rows, cols, vals, dtype=tname, nrows=m, ncols=n)
+        u = gb.Vector.from_coo(ui, uv, dtype=tname, size=n)
+        w = gb.Vector.from_coo(wi, wv, dtype=tname, size=m)
+        mk = gb.Vector.from_coo(mi, mv, dtype="BOOL", size=m)
+        w(~mk.S, accum=accum) << A.mxv(u, getattr(gb.semiring, sr))
+        st = device.last_stats()
+        assert st["long_kernel"] == 4 and st["long_entries"] > 30000, st
+        same_vec(w, exp)
+        same_vec(A.mxv(u, getattr(gb.semiring, sr)).new(), exp_plain)
+    finally:
+        for name, val in ((b"split_min_nnz", 1 << 22), (b"split_min_len", 0), (b"push_mode", 1), (b"hot_min_cols", 1 << 20), (b"hot_k", 0),
+                          (b"long_kernel", DEFAULT_LONG_KERNEL), (b"long_sub", 0), (b"vec_pad_min_bytes", 1 << 20)):
+            _lib.lib.GrX_option_set(name, val)
+
+
+@pytest.mark.parametrize("seed", range(4))
 def test_split_survives_mixed_calls_and_option_changes(gb, seed):
     """A product builds the hot-coded split and releases the re-coded column copy; then a row reduction (a call that reads no
     column), the same product again, a product that gathers with the ORIGINAL column indices (a typecast of the values cannot take
