@@ -286,6 +286,7 @@ struct GB_Matrix_opaque {
     uint64_t *d_tg_nonempty = nullptr; // per group: bit l = short row 64 g + l has an entry
     int64_t tg_units = 0;
     int tg_state = 0;
+    bool short_tagged_only = false;    // the short part keeps its row pointers only: its entries live in the tagged row groups
     int64_t n_long, n_chunks;
     int split_state;          // 0 = not analysed, 1 = enabled, -1 = not worth it
     bool split_hot;           // short_part's columns are hot-coded

@@ -147,6 +147,7 @@ static void report_phase_times(const long long *d_times, int64_t n_tiles)
 
 // Analyse (once) whether the rows split usefully into long and short ones and build the two parts.
 // `col_src` is the column array the kernels will index (hot-coded or original).
+static void ensure_tagged(GB_Matrix_opaque *A);
 static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
 {
     const int ncls_opt = (ctx().long_classes == 16 || ctx().long_classes == 32 || ctx().long_classes == 64) ? ctx().long_classes : 8;
@@ -155,7 +156,11 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
     // (5: the same by type with the hot / cold strips -- 4 -- for non-BOOL matrices)
     const int lk = ctx().long_kernel;
     const int kind = lk == 3 ? (A->type->code == TC_BOOL ? 1 : 2) : (lk == 5 ? (A->type->code == TC_BOOL ? 1 : 4) : lk);
-    if (A->split_state != 0 && (A->split_state < 0 || (A->split_hot == hot && A->split_kind == kind && ((A->split_kind != 2 && A->split_kind != 4) || A->strip_nseg == 0 || A->strip_ncls == ncls_opt)))) return;
+    // (the short part holds its entries either as CSR arrays or, for the tagged row groups, in that layout alone: another short-row
+    //  kernel than the one the split was built for rebuilds it)
+    const bool want_tagged_only = ctx().short_kernel == 5;
+    if (A->split_state != 0 && (A->split_state < 0 || (A->split_hot == hot && A->split_kind == kind && A->short_tagged_only == want_tagged_only &&
+                                                       ((A->split_kind != 2 && A->split_kind != 4) || (A->strip_nseg == 0 && A->ct_units == 0) || A->strip_ncls == ncls_opt)))) return;
     if (A->split_state == 1) {  // built against the other column coding (or for another long-row kernel): rebuild
         matrix_free(A->short_part);
         A->short_part = nullptr;
@@ -468,6 +473,19 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
     A->split_hot = hot;
     A->split_kind = kind;
     A->split_state = 1;
+    A->short_tagged_only = false;
+    if (want_tagged_only && S->nrows == A->nrows && S->nvals < 0x1ffffffffll) {
+        // the tagged row groups are the only form of the short rows' entries the kernels read: the CSR copy they were built from is
+        // released (0.42 GB of the cached layouts at scale 24); the row pointers stay (row lengths, accounting)
+        ensure_tagged(A);
+        dev_free(S->d_col);
+        S->d_col = nullptr;
+        if (!S->iso) {
+            dev_free(S->d_val);
+            S->d_val = nullptr;
+        }
+        A->short_tagged_only = true;
+    }
     // the short part and the strips / items carry their own re-coded columns: the re-coded copy of the whole array is only read
     // again by a product that cannot take the split (a typecast of the values), which falls back to the plain arrays
     if (hot && ctx().drop_hot_cols && nc > 0 && A->long_nnz > 0 && (kind == 1 || kind == 2 || kind == 4) && A->d_col_hot) {
@@ -529,6 +547,7 @@ static void ensure_sell(GB_Matrix_opaque *A)
 static void ensure_tagged(GB_Matrix_opaque *A)
 {
     if (A->tg_state == 1) return;
+    if (!A->short_part->d_col && A->short_part->nvals > 0) fail(GrB_PANIC, "tagged row groups: the short part's CSR arrays were released (internal error)");
     GB_Matrix_opaque *S = A->short_part;
     const int64_t m = (int64_t)S->nrows, ngroups = ceil_div(m, 64);
     const int64_t *sptr = matrix_rowptr(S);
@@ -679,7 +698,7 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
         b.long_bits = A->d_long_bits;
         b.n_chunks = 0;
         b.n_long_epi = a.n_long;
-        if (ctx().short_kernel == 5 && S->nrows == A->nrows && S->nvals < 0x1ffffffffll) {
+        if ((ctx().short_kernel == 5 || A->short_tagged_only) && S->nrows == A->nrows && S->nvals < 0x1ffffffffll) {
             // short rows as tagged row groups: the row of every entry is stored with it (no marks, no scan, no segmented fold)
             ensure_tagged(A);
             b.long_prefix = A->d_long_prefix;
@@ -1297,7 +1316,7 @@ extern "C" GrB_Info GrX_Matrix_cache_bytes(const GrB_Matrix A, uint64_t *bytes)
     if (A->d_hot_cols) b += 4ull * (uint64_t)A->hot_k;
     if (A->split_state == 1) {
         const GB_Matrix_opaque *S = A->short_part;
-        b += 8ull * (A->nrows + 1) + 4ull * (uint64_t)S->nvals + (S->iso ? vs : vs * (uint64_t)S->nvals);
+        b += 8ull * (A->nrows + 1) + (A->short_tagged_only ? 0 : 4ull * (uint64_t)S->nvals + (S->iso ? vs : vs * (uint64_t)S->nvals));
         b += bits_words64(A->nrows) * 8 + 4ull * (uint64_t)A->n_long + 4ull * bits_words64(A->nrows) + 16ull * (uint64_t)A->n_chunks;
         if (A->tg_state == 1) b += (uint64_t)A->tg_units * TAG_EPL * (5 + (A->d_tg_val ? vs : 0)) + 12ull * ((A->nrows + 63) / 64);
         if (A->split_kind == 4 && (A->strip_nseg > 0 || A->ct_units > 0)) {
