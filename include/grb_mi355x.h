@@ -302,13 +302,15 @@ GrB_Info GrX_Matrix_cache_bytes(const GrB_Matrix A, uint64_t *bytes);
  *                   second pull product; the first one runs on the CSR arrays as they are.  0: built at the first product.
  *   "drop_hot_cols" 1 (default): the hot-coded copy of a matrix's whole column array is released once the long / short split has
  *                   been built from it (the split's parts carry their own re-coded columns)
- *   "long_kernel"   layout / kernel of the long rows: 5 (default) hot / cold strips, items for BOOL matrices; 4 hot / cold strips for
- *                   every type (entries whose column is LDS-resident in its class as 16-bit lane records, k_mxv_hstrip; the others as
- *                   strips of contiguous column ranges, k_mxv_cstrip; operands the lean kernels do not take: k_mxv_strip); 3 mixed class
+ *   "long_kernel"   layout / kernel of the long rows: 5 (default) by type and size -- items for BOOL matrices, hot strips + cold tiles
+ *                   from "lean_min_nnz" (48 Mi) entries, mixed class strips below; 4 hot strips + cold tiles for every matrix (entries
+ *                   whose column is LDS-resident in its class as 16-bit lane records, k_mxv_hstrip; the others as tagged tiles of
+ *                   ~2 MiB column ranges, k_mxv_ctile; operands the lean hot kernel does not take: k_mxv_strip); 3 mixed class
  *                   strips, items for BOOL matrices; 2 mixed class strips (k_mxv_strip); 1 class-partitioned items (k_mxv_long_grp);
  *                   0 chunks straight from the CSR arrays (k_mxv_long)
  *   "long_classes"  column classes of the class strips: 8, 16 (default), 32 or 64 distinct LDS heads across the chip
- *   "short_kernel"  short rows of a split matrix: 5 (default) tagged row groups (the row of every entry stored with it, k_mxv_rows_tag),
+ *   "short_kernel"  short rows of a split matrix: 6 (default) by size -- 5 from "lean_min_nnz" entries, 1 below; 5 tagged row groups (the
+ *                   row of every entry stored with it, k_mxv_rows_tag),
  *                   1 one wavefront per 64 rows with row marks and a segmented fold (k_mxv_rows), 0 merge-path tiles, 2 sliced ELLPACK
  *                   with a lane per row ("sell_sigma" rows per sort window; measured slower), 3 persistent
  *                   workgroups with an LDS head, 4 a lane per row folding products staged in LDS (both measured slower)

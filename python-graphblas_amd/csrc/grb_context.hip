@@ -204,7 +204,7 @@ extern "C" GrB_Info GrB_init(GrB_Mode mode)
         {"GRB_MXM_UNIT_SMALL", "mxm_unit_small"}, {"GRB_MXM_UNIT_DENSE", "mxm_unit_dense"}, {"GRB_MXM_UNIT_MID", "mxm_unit_mid"},
         {"GRB_MXM_BITMAP_POOL_MB", "mxm_bitmap_pool_mb"}, {"GRB_MXM_BITMAP_MIN_CNT", "mxm_bitmap_min_cnt"},
         {"GRB_LONG_KERNEL", "long_kernel"}, {"GRB_LONG_CLASSES", "long_classes"}, {"GRB_SPLIT_MIN_LEN", "split_min_len"},
-        {"GRB_LONG_SUB", "long_sub"}, {"GRB_LONG_SUB_MIN_LEN", "long_sub_min_len"},
+        {"GRB_LONG_SUB", "long_sub"}, {"GRB_LONG_SUB_MIN_LEN", "long_sub_min_len"}, {"GRB_LEAN_MIN_NNZ", "lean_min_nnz"},
     };
     for (const auto &k : knobs)
         if (const char *e = getenv(k.env)) (void)GrX_option_set(k.opt, atoll(e));
@@ -309,6 +309,7 @@ extern "C" GrB_Info GrX_option_set(const char *name, int64_t value)
     else if (n == "short_kernel") c.short_kernel = (int)value;
     else if (n == "lazy_layout") c.lazy_layout = (int)value;
     else if (n == "lazy_min_nnz") c.lazy_min_nnz = value;
+    else if (n == "lean_min_nnz") c.lean_min_nnz = value < 0 ? 0 : value;
     else if (n == "long_kernel") c.long_kernel = (int)value;
     else if (n == "long_classes") c.long_classes = (value == 16 || value == 32 || value == 64) ? (int)value : 8;
     else if (n == "sell_sigma") c.sell_sigma = (int)value;

@@ -82,11 +82,15 @@ struct Context {
     int long_sub = 0;       // sub-ranges per class of the cold columns of the long rows (items of a class are walked sub-range by
                             // sub-range); 0 = sized from the operand image (~2 MiB per sub-range)
     int long_sub_min_len = 0;  // ... for rows with at least this many entries (0 = 512 per sub-range)
-    int long_kernel = 5;    // long rows: 5 = by matrix type (hot / cold strips; items for BOOL), 4 = hot / cold strips (k_mxv_hstrip / k_mxv_cstrip,
-                            // generic: k_mxv_strip), 3 = by type with the mixed class strips, 2 = mixed class strips (k_mxv_strip),
-                            // 1 = class-partitioned items (k_mxv_long_grp), 0 = chunk kernel (k_mxv_long)
-    int short_kernel = 5;   // short rows of a split matrix: 5 = tagged row groups (k_mxv_rows_tag), 1 = row-group kernel (k_mxv_rows), 0 = merge-path
-                            // kernel, 2 = sliced ELLPACK (k_mxv_sell), 3 = persistent row groups with an LDS head, 4 = a lane per row
+    int long_kernel = 5;    // long rows: 5 = by matrix type and size (items for BOOL; hot / cold strips from lean_min_nnz entries, mixed class
+                            // strips below), 4 = hot strips + cold tiles (k_mxv_hstrip / k_mxv_ctile, generic: k_mxv_strip), 3 = by type with
+                            // the mixed class strips, 2 = mixed class strips (k_mxv_strip), 1 = class-partitioned items (k_mxv_long_grp),
+                            // 0 = chunk kernel (k_mxv_long)
+    int short_kernel = 6;   // short rows of a split matrix: 6 = by size (tagged row groups from lean_min_nnz entries, row groups below), 5 = tagged
+                            // row groups (k_mxv_rows_tag), 1 = row-group kernel (k_mxv_rows), 0 = merge-path kernel, 2 = sliced ELLPACK
+                            // (k_mxv_sell), 3 = persistent row groups with an LDS head, 4 = a lane per row
+    int64_t lean_min_nnz = 48ll << 20;  // the round-3 layouts pay from about this many entries (measured: one rank's block of an 8-way
+                            // scale-24 run -- 33 M entries -- 0.130 ms on the round-2 layouts against 0.144, scale 22 -- 67 M -- 0.203 against 0.190)
     int sell_sigma = 4096;  // rows per sort window of the sliced-ELLPACK form
     GrX_Stats stats{};
     int debug_flags = 0;    // GRB_DEBUG: kernel ablation switches (benchmark diagnostics only)

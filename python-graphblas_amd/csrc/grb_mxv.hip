@@ -148,6 +148,12 @@ static void report_phase_times(const long long *d_times, int64_t n_tiles)
 // Analyse (once) whether the rows split usefully into long and short ones and build the two parts.
 // `col_src` is the column array the kernels will index (hot-coded or original).
 static void ensure_tagged(GB_Matrix_opaque *A);
+// the short-row kernel of a matrix: option 6 (default) = tagged row groups for large matrices, the row-group kernel below
+static int short_kernel_for(const GB_Matrix_opaque *A)
+{
+    const int sk = ctx().short_kernel;
+    return sk == 6 ? (A->nvals >= ctx().lean_min_nnz ? 5 : 1) : sk;
+}
 static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
 {
     const int ncls_opt = (ctx().long_classes == 16 || ctx().long_classes == 32 || ctx().long_classes == 64) ? ctx().long_classes : 8;
@@ -155,10 +161,11 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
     // products are terminal monoids (the BFS step), where the item kernel's per-row early exit wins
     // (5: the same by type with the hot / cold strips -- 4 -- for non-BOOL matrices)
     const int lk = ctx().long_kernel;
-    const int kind = lk == 3 ? (A->type->code == TC_BOOL ? 1 : 2) : (lk == 5 ? (A->type->code == TC_BOOL ? 1 : 4) : lk);
+    const bool big = A->nvals >= ctx().lean_min_nnz;  // (the hot / cold strips and the tagged row groups pay from ~50 M entries)
+    const int kind = lk == 3 ? (A->type->code == TC_BOOL ? 1 : 2) : (lk == 5 ? (A->type->code == TC_BOOL ? 1 : (big ? 4 : 2)) : lk);
     // (the short part holds its entries either as CSR arrays or, for the tagged row groups, in that layout alone: another short-row
     //  kernel than the one the split was built for rebuilds it)
-    const bool want_tagged_only = ctx().short_kernel == 5;
+    const bool want_tagged_only = short_kernel_for(A) == 5;
     if (A->split_state != 0 && (A->split_state < 0 || (A->split_hot == hot && A->split_kind == kind && A->short_tagged_only == want_tagged_only &&
                                                        ((A->split_kind != 2 && A->split_kind != 4) || (A->strip_nseg == 0 && A->ct_units == 0) || A->strip_ncls == ncls_opt)))) return;
     if (A->split_state == 1) {  // built against the other column coding (or for another long-row kernel): rebuild
@@ -698,7 +705,8 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
         b.long_bits = A->d_long_bits;
         b.n_chunks = 0;
         b.n_long_epi = a.n_long;
-        if ((ctx().short_kernel == 5 || A->short_tagged_only) && S->nrows == A->nrows && S->nvals < 0x1ffffffffll) {
+        const int sk = short_kernel_for(A);
+        if ((sk == 5 || A->short_tagged_only) && S->nrows == A->nrows && S->nvals < 0x1ffffffffll) {
             // short rows as tagged row groups: the row of every entry is stored with it (no marks, no scan, no segmented fold)
             ensure_tagged(A);
             b.long_prefix = A->d_long_prefix;
@@ -715,7 +723,7 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
             return;
         }
 #ifdef GRB_EXPERIMENTAL_KERNELS
-        if (ctx().short_kernel == 2 && S->nrows == A->nrows && A->nrows < 0x7fffffffll) {
+        if (sk == 2 && S->nrows == A->nrows && A->nrows < 0x7fffffffll) {
             // short rows in sliced-ELLPACK form: a lane per row, which also applies the write rule of the long rows
             ensure_sell(A);
             b.long_prefix = A->d_long_prefix;
@@ -734,7 +742,7 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
             ctx().stats.tiles = A->sell_slots;  // (slots incl. padding; the short part holds S->nvals entries)
             return;
         }
-        if (ctx().short_kernel == 3 && S->nrows == A->nrows) {
+        if (sk == 3 && S->nrows == A->nrows) {
             // short rows from persistent workgroups that keep the head of the operand image in LDS
             b.long_prefix = A->d_long_prefix;
             const int64_t groups = ceil_div(b.m, 64);
@@ -746,7 +754,7 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
             return;
         }
         if constexpr (sizeof(T) == 4 && !std::is_same<T, bool>::value) {
-            if (ctx().short_kernel == 4 && S->nrows == A->nrows && b.need_uval && b.u_full && b.need_aval) {
+            if (sk == 4 && S->nrows == A->nrows && b.need_uval && b.u_full && b.need_aval) {
                 // short rows with a lane per row over entries staged in LDS (4-byte types, full operand whose values are read)
                 b.long_prefix = A->d_long_prefix;
                 hipLaunchKernelGGL((k_mxv_rows_lane<T, MON, MUL>), dim3((unsigned)ceil_div(ceil_div(b.m, 64), ROWS_BLOCK / 64)), dim3(ROWS_BLOCK),
@@ -758,7 +766,7 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
             }
         }
 #endif
-        if (ctx().short_kernel != 0 && S->nrows == A->nrows) {  // (also what the experimental kernels fall back to in a build without them)
+        if (sk != 0 && S->nrows == A->nrows) {  // (also what the experimental kernels fall back to in a build without them)
             // short rows: one wavefront per 64 consecutive rows, which also applies the write rule of the long rows
             b.long_prefix = A->d_long_prefix;
             // (persistent variants -- static strides with the next group prefetched, or an LDS work counter per workgroup --

@@ -14,7 +14,7 @@ from tests.backend import DEVICES, bind
 TYPES = ["INT64", "FP32", "BOOL", "FP64", "INT8", "UINT16", "INT32"]
 import os
 
-DEFAULT_SHORT_KERNEL = int(os.environ.get("GRB_SHORT_KERNEL", "5"))
+DEFAULT_SHORT_KERNEL = int(os.environ.get("GRB_SHORT_KERNEL", "6"))
 DEFAULT_LONG_KERNEL = int(os.environ.get("GRB_LONG_KERNEL", "5"))  # what tests restore after forcing a long-row kernel
 
 
@@ -511,7 +511,8 @@ def test_long_short_row_split(gb, seed):
         w(~mk.V if comp else mk.V, accum=accum, replace=bool(seed & 2)) << A.mxv(u, getattr(gb.semiring, sr))
         st = device.last_stats()  # init + long rows + short rows (with the write rule of every row); PAIR over a full u reads no rows
         assert st["kernel_launches"] >= 3 or st["method"] == 5
-        want = {3: 1 if tname == "BOOL" else 2, 5: 1 if tname == "BOOL" else 4}.get(forced_long, forced_long)
+        # (5 = by type and size: a matrix this small gets the mixed class strips; the hot / cold strips start at lean_min_nnz entries)
+        want = {3: 1 if tname == "BOOL" else 2, 5: 1 if tname == "BOOL" else 2}.get(forced_long, forced_long)
         assert st["method"] == 5 or (st["long_kernel"] == want and st["long_entries"] > 0)
         same_vec(w, exp)
         # a product that needs A's values in another type cannot take the split (whose re-coded column copy of the whole matrix
