@@ -44,6 +44,24 @@ def measured_traffic(workload, scale):
     return best["traffic_bytes_per_launch"] if best else None
 
 
+def measured_traffic_band(workload, scale):
+    """[uncorrected, FETCH_SIZE-doubled] bytes per launch of the same profile: the corrected figure alone over-counts the gather share
+    (the doubling is calibrated for 16-byte streaming reads only) -- the truth lies inside the band."""
+    import glob
+
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_traffic*.json"))):
+        try:
+            rec = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if rec.get("workload") == workload and rec.get("scale") == scale:
+            best = rec
+    if not best:
+        return None
+    return best.get("traffic_band_bytes") or [best.get("traffic_bytes_per_launch_uncorrected"), best.get("traffic_bytes_per_launch")]
+
+
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
@@ -873,6 +891,7 @@ def main():
             res["exchange"] = {"chunks_per_rank": wl.ov.chunks, "replicas_of_u": 2, "staged_through_torch_buffers": wl.ov.staged,
                                "presence_words_travel": wl.ov.presence, "collective": "all_gather_into_tensor per chunk, async_op"}
         if res["roofline"]["traffic"]:
+            res["roofline"]["traffic_band"] = measured_traffic_band(workload, scale)
             # the PMC traffic (L2 misses x 128 B, measured in separate profiled runs of this workload) over this run's kernel time
             res["roofline"]["traffic_GBps"] = res["roofline"]["traffic"] / (kernel_ms * 1e-3) / 1e9
         return wl, res
