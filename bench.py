@@ -70,7 +70,8 @@ def parse():
     p.add_argument("--scale", type=int, default=24)
     p.add_argument("--visited", type=float, default=0.5, help="fraction of rows masked out (visited)")
     p.add_argument("--workload", default="mxv_min_plus_masked",
-                   choices=["mxv_min_plus_masked", "mxv_lor_land_masked", "mxv_min_plus", "mxm_plus_times", "mxm_plus_times_masked", "bfs", "sssp",
+                   choices=["mxv_min_plus_masked", "mxv_lor_land_masked", "mxv_min_plus", "mxm_plus_times", "mxm_plus_times_masked",
+                            "mxm_plus_times_cmask", "bfs", "sssp",
                             "uniform_fp64", "kron26"])
     p.add_argument("--block", default=None, metavar="R/W",
                    help="single GPU: run rank R's row block of a W-way sharded run (the compute part of one rank's step; no exchange)")
@@ -400,6 +401,11 @@ def cpu_baseline_mxv(wl, torch, reps_budget_s=20.0):
                       "C oracle (oracle/grb_oracle.c, OpenMP) -- a CPU restatement, not SuiteSparse"}
 
 
+def _desc_s():
+    from graphblas_amd import _lib
+    return _lib.handle("GrB_DESC_S")
+
+
 def verify_mxm(torch, device, gb, L, sr, A, B, ip_a, col_a, ip_b, col_b, n, masked, C, st, stream_out, budget, seed=5):
     """Independent checks of the SpGEMM line (operands are matrices of ones, INT64 plus_times):
       * the multiply count the symbolic pass reports = sum over the entries (i, k) of A of nnz(B(k, :)), computed by torch from the
@@ -431,6 +437,8 @@ def verify_mxm(torch, device, gb, L, sr, A, B, ip_a, col_a, ip_b, col_b, n, mask
             cols, cnt = torch.unique(col_b[pos], return_counts=True)
             if mask_rows:
                 keep = torch.isin(cols, ks.to(cols.dtype))
+                if mask_rows == "comp":
+                    keep = ~keep
                 cols, cnt = cols[keep], cnt[keep]
             r0, r1 = int(cp[i].item()), int(cp[i + 1].item())
             good = good and r1 - r0 == int(cols.numel()) and bool(torch.equal(cj[r0:r1], cols.to(torch.int32))) \
@@ -439,9 +447,20 @@ def verify_mxm(torch, device, gb, L, sr, A, B, ip_a, col_a, ip_b, col_b, n, mask
 
     if C is not None:
         good, cx = check_rows(C, ip_a, col_a, m, masked)
-        ok = ok and good and int(st["out_nvals"]) == int(cx.numel())
+        # (stats.out_nvals counts the product the kernels wrote: C itself, except when a complemented mask was left to the write rule)
+        ok = ok and good and (int(st["out_nvals"]) == int(cx.numel()) or (masked == "comp" and int(st["method"]) == 3))
         if not masked:
             ok = ok and int(cx.sum().item()) == flops_expected
+        elif masked == "comp":
+            # C<!A.S> and C<A.S> split the full product: their value sums add up to the multiply count (the mask-driven product
+            # is another code path -- k_spgemm_mhash / k_spgemm_mwin / masked units -- and has its own checks above when it is the line)
+            total_c = int(cx.sum().item())
+            Cm = gb.Matrix("INT64", m, n)
+            if L.GrB_mxm(Cm._carg, A._carg, None, sr._carg, A._carg, B._carg, ctypes.c_void_p(_desc_s())) == 0 and Cm.nvals > 0:
+                good_m, cxm = check_rows(Cm, ip_a, col_a, m, True)
+                ok = ok and good_m and total_c + int(cxm.sum().item()) == flops_expected
+            else:
+                ok = False
     else:
         ok = ok and stream_out.get("checksum") == flops_expected
         # the streamed pipeline on a row block against the materialised (and independently checked) product of the same block
@@ -485,8 +504,9 @@ def run_mxm(args, gb, torch, device, rank, world, dist, barrier, *, scale, workl
     sr = gb.semiring.plus_times["INT64"]
     L = _lib.lib
 
-    masked = workload == "mxm_plus_times_masked"  # triangle-count style: C<A.S> = A (+.x) A
-    desc_s = ctypes.c_void_p(_lib.handle("GrB_DESC_S"))
+    # triangle-count style: C<A.S> = A (+.x) A;  "comp": the two-hop pairs that are not neighbours, C<!A.S> = A (+.x) A
+    masked = {"mxm_plus_times_masked": True, "mxm_plus_times_cmask": "comp"}.get(workload, False)
+    desc_s = ctypes.c_void_p(_lib.handle("GrB_DESC_SC" if masked == "comp" else "GrB_DESC_S"))
     # the unmasked product of scale >= 21 does not fit one GPU (scale 22: 900 GB): it runs in row batches whose products fit
     # `budget`, every batch through the full symbolic + numeric pipeline; count and checksum leave the batch (GrX_mxm_streamed)
     streamed = (not masked) and (args.streamed or scale >= 21)  # (the same pipeline at every rank count: comparable lines)
@@ -551,12 +571,13 @@ def run_mxm(args, gb, torch, device, rank, world, dist, barrier, *, scale, workl
         "metric": "SpGEMM nnz-out/s on R-MAT scale-%d" % scale, "value": nnz_c / (ms * 1e-3), "unit": "nnz(C)/s",
         "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": ms, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "int64", "data": "synthetic", "verified": verified,
-        "config": {"workload": f"rmat{scale} {workload}: " + ("C<A.S> = A (+.x) A (mask-driven)" if masked else "C = A (+.x) A")
+        "config": {"workload": f"rmat{scale} {workload}: " + ("C<!A.S> = A (+.x) A (complemented mask fused into the product)" if masked == "comp"
+                                                            else "C<A.S> = A (+.x) A (mask-driven)" if masked else "C = A (+.x) A")
                    + ", INT64 ones" + (f"; row batches under {args.stream_budget_gb:g} GiB, output streamed (count + checksum)" if streamed else ""),
                    "nnz_A": nnz_a, "flops": flops, "nnz_C": nnz_c, "parallelism": f"row-shard x{world} (flop-balanced cuts), B replicated", **stream_out},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None if streamed else measured_traffic(workload, scale),
-                     "kernel": "k_spgemm_mhash / k_spgemm_mwin" if masked else "k_spgemm_unit (symbolic + numeric classes) / k_spgemm_unit_dense / k_spgemm_hash",
+                     "kernel": "k_spgemm_mhash / k_spgemm_mwin" if masked is True else "k_spgemm_unit (symbolic + numeric classes) / k_spgemm_unit_dense / k_spgemm_hash",
                      "kernel_ms_hip_events": ev_ms / steps, "algorithmic_bytes_per_launch": alg_bytes / world},
         "cpu_baseline": cpu, "stats": st}
 
@@ -588,7 +609,8 @@ def cpu_baseline_mxm(indptr, col, n, flops_total, masked, target_flops=1.5e9):
     oa = O.OMat(rows, n, ip[: rows + 1].copy(), cj[:e1].copy(), ones[:e1].copy(), "INT64")
     O.use_all_threads()
     t0 = time.perf_counter()
-    T = O.mxm(oa, ob, "plus_times", mask=oa if masked else None, mask_struct=masked) if masked else O.mxm_product(oa, ob, "plus_times")
+    T = (O.mxm(oa, ob, "plus_times", mask=oa, mask_struct=True, mask_comp=masked == "comp") if masked
+         else O.mxm_product(oa, ob, "plus_times"))
     dt = time.perf_counter() - t0
     nnz_c = int(T.indices.size) if hasattr(T, "indices") else int(T[1].size)
     return {"value": nnz_c / dt, "unit": "nnz(C)/s", "cores": O.num_threads(), "kind": "port",
@@ -918,7 +940,7 @@ def main():
         return main_bfs(args, gb, torch, device, rank, world)
     if args.workload == "sssp":
         return main_sssp(args, gb, torch, device, rank, world)
-    if args.workload in ("mxm_plus_times", "mxm_plus_times_masked"):
+    if args.workload in ("mxm_plus_times", "mxm_plus_times_masked", "mxm_plus_times_cmask"):
         return main_mxm(args, gb, torch, device, rank, world, dist, barrier)
     wl, res = run(args.workload, args.scale, args.steps, args.warmup)
     cpu = cpu_line(wl) if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None

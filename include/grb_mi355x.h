@@ -262,7 +262,7 @@ typedef struct {
     int64_t tiles;            /* merge-path tiles (mxv/vxm) or row bins (mxm) */
     int64_t flops;            /* mxm: sum_k nnz(A(:,k)) nnz(B(k,:)) from the symbolic pass; mxv: nnz(A) */
     int64_t out_nvals;        /* mxm: nnz(T); mxv: -1 (not counted) */
-    int32_t method;           /* 1 pull SpMV, 2 push (SpMSpV), 3 hash SpGEMM, 4 mask-driven SpGEMM, 5 mxv by row length (PAIR, full operand), 6 empty operand: write rule only */
+    int32_t method;           /* 1 pull SpMV, 2 push (SpMSpV), 3 hash SpGEMM, 4 mask-driven SpGEMM, 5 mxv by row length (PAIR, full operand), 6 empty operand: write rule only, 7 SpGEMM with the complemented mask fused into the product */
     int32_t fused_epilogue;   /* 1 if mask/accum/replace were applied inside the product kernel */
     int64_t hot_k;            /* mxv/vxm: entries of the hot-column table used by the call (0 = none) */
     int64_t long_entries;     /* mxv/vxm over a split matrix: entries held by the long rows (0 = no split) */
@@ -317,7 +317,8 @@ GrB_Info GrX_Matrix_cache_bytes(const GrB_Matrix A, uint64_t *bytes);
  *   "long_sub"      sub-ranges per class of the cold columns of the long rows (0 = sized from the operand image),
  *   "long_sub_min_len"  for rows from this many entries (0 = 512 per sub-range)
  *   "mxm_mask_mode" mask-driven SpGEMM for non-complemented masks: 1 (default) when the product costs clearly more than the mask,
- *                   0 never, 2 always
+ *                   0 never, 2 always;  complemented masks: fused into the product (the forbidden positions never enter it)
+ *                   unless 0 (full product, then the write rule)
  *   "mxm_heavy_kernel"  SpGEMM rows beyond the LDS hash tables: 1 (default) (row, column window) work units (k_spgemm_unit),
  *                   0 the 1024-thread row kernels of round 1
  *   "mxm_unit_min_flops" / "mxm_unit_min_per_window"  rows with more products than this (1024) and than this many per column window

@@ -205,6 +205,7 @@ extern "C" GrB_Info GrB_init(GrB_Mode mode)
         {"GRB_MXM_BITMAP_POOL_MB", "mxm_bitmap_pool_mb"}, {"GRB_MXM_BITMAP_MIN_CNT", "mxm_bitmap_min_cnt"},
         {"GRB_LONG_KERNEL", "long_kernel"}, {"GRB_LONG_CLASSES", "long_classes"}, {"GRB_SPLIT_MIN_LEN", "split_min_len"},
         {"GRB_LONG_SUB", "long_sub"}, {"GRB_LONG_SUB_MIN_LEN", "long_sub_min_len"}, {"GRB_LEAN_MIN_NNZ", "lean_min_nnz"},
+        {"GRB_MXM_MASK_MODE", "mxm_mask_mode"},
     };
     for (const auto &k : knobs)
         if (const char *e = getenv(k.env)) (void)GrX_option_set(k.opt, atoll(e));

@@ -73,7 +73,17 @@ struct MxmArgs {
     const int32_t *Mj;
     void *cap_val;           // per mask entry: the product's value ...
     unsigned char *cap_hit;  // ... and whether any product hit it
+    // complemented mask fused into the product (C<!M>): the pattern of the mask entries that forbid a position (structural: all of
+    // them, valued: the true ones), sorted rows; T never holds a forbidden position, and the symbolic counts are those of T
+    // without them.  cm_woff = the window offsets of the forbidden rows (m x (n_win + 1), as woff for B) for the unit kernels.
+    const int64_t *CMp;
+    const int32_t *CMj;
+    const int32_t *cm_woff;
 };
+
+// the hash kernels keep a forbidden column as the key -(j + 2): it occupies its slot (probing stays consistent), a product that
+// finds it is dropped, and the compaction (keys >= 0) never sees it
+__device__ __forceinline__ int forbidden_key(int j) { return -(j + 2); }
 
 __device__ __forceinline__ unsigned hash_col(int c, int table_mask) { return ((unsigned)c * 2654435761u) & (unsigned)table_mask; }
 
@@ -94,13 +104,16 @@ __device__ __forceinline__ int bin_of(int64_t x, int64_t b1, int64_t b2, int64_t
 
 // size[i] = F[Ap[i+1]] - F[Ap[i]]  (F == nullptr: size[i] is already in `size`);  key = bin, payload = row
 // (wrow: rows with a slot in the unit tables -- wrow[i] >= 0 -- go to bin 4 whatever their size)
+// (extra_ptr: row pointers whose row lengths count towards the bin of a non-empty row -- the forbidden columns of a fused
+//  complemented mask sit in the hash tables beside the row's own)
 __global__ void k_row_bins(const int64_t *Ap, const int64_t *F, int64_t m, int64_t *size, int64_t b1, int64_t b2,
-                           int64_t b3, uint64_t *binkey, uint32_t *rowid, const int32_t *wrow)
+                           int64_t b3, uint64_t *binkey, uint32_t *rowid, const int32_t *wrow, const int64_t *extra_ptr)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
     int64_t s = F ? F[Ap[i + 1]] - F[Ap[i]] : size[i];
     if (F) size[i] = s;
+    if (extra_ptr && s > 0) s += extra_ptr[i + 1] - extra_ptr[i];
     binkey[i] = (wrow && wrow[i] >= 0 && s > 0) ? 4ull : (uint64_t)bin_of(s, b1, b2, b3);
     rowid[i] = (uint32_t)i;
 }
@@ -191,17 +204,28 @@ __global__ __launch_bounds__(MM_BLOCK) void k_spgemm_hash(const MxmArgs a, const
     }
     if (tid == 0) s_cnt = 0;
     __syncthreads();
+    if (a.CMp) {  // fused complemented mask: the forbidden columns take their slots first
+        const int64_t mhi = a.CMp[row + 1];
+        for (int64_t p = a.CMp[row] + tid; p < mhi; p += MM_BLOCK) {
+            const int j = a.CMj[p];
+            unsigned h = hash_col(j, TABLE - 1);
+            while (atomicCAS(&s_key[h], -1, forbidden_key(j)) != -1) h = (h + 1) & (TABLE - 1);
+        }
+        __syncthreads();
+    }
 
     int my_new = 0;
     foreach_product(a, row, [&](int j, int64_t p, int64_t q) {
         unsigned h = hash_col(j, TABLE - 1);
+        bool dropped = false;
         while (true) {
             const int old = atomicCAS(&s_key[h], -1, j);
             if (old == -1) { my_new++; break; }
             if (old == j) break;
+            if (old == forbidden_key(j)) { dropped = true; break; }
             h = (h + 1) & (TABLE - 1);
         }
-        if (NUMERIC) {
+        if (NUMERIC && !dropped) {
             const T av = a.need_a ? Ax[a.a_iso ? 0 : p] : (T)0;
             const T bv = a.need_b ? Bx[a.b_iso ? 0 : q] : (T)0;
             const W prod = (W)apply_binop<T>(mult, av, bv);
@@ -528,6 +552,17 @@ __global__ __launch_bounds__(MM_WIN_BLOCK) void k_spgemm_win(const MxmArgs a, co
             atomicOr(&s_bits[j >> 6], 1ull << (j & 63));
         });
         __syncthreads();
+        if (a.CMp) {  // fused complemented mask: forbidden columns give their accumulators back and are not emitted
+            const int32_t *mo = a.cm_woff + row * (a.n_win + 1) + w;
+            const int m0 = mo[0], m1 = mo[1];
+            const int64_t mb = a.CMp[row];
+            for (int i = m0 + tid; i < m1; i += MM_WIN_BLOCK) {
+                const int j = a.CMj[mb + i] - c0;
+                atomicAnd(&s_bits[j >> 6], ~(1ull << (j & 63)));
+                s_acc[j] = ident;
+            }
+            __syncthreads();
+        }
         // ordered sweep of the window's presence words (MM_WIN/64 = 256 words: threads 0..255 take one each)
         unsigned long long b = (tid < MM_WIN / 64) ? s_bits[tid] : 0ull;
         const int c = __popcll(b);
@@ -768,6 +803,21 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const 
                   atomicOr(&bits[j >> 6], 1ull << (j & 63));
               });
     usync();
+    // fused complemented mask: the forbidden columns inside the window leave the bitmap (a bitmap kept by the symbolic pass
+    // is already without them); pass B drops the products that find their column's bit clear
+    const bool cmask = !MASKED && a.CMp != nullptr;
+    if (cmask && bslot < 0) {
+        const int32_t *mo = a.cm_woff + (int64_t)row * (nwin + 1) + w;
+        const int m0 = mo[0], m1 = mo[1];
+        if (m1 > m0) {
+            const int64_t mb = a.CMp[row];
+            for (int i = m0 + tiu; i < m1; i += 64 * WPU) {
+                const int j = a.CMj[mb + i] - c0;
+                atomicAnd(&bits[j >> 6], ~(1ull << (j & 63)));
+            }
+        }
+        usync();
+    }
     // ---- counts: lane l looks at words 4 l .. 4 l + 3 (every wavefront of the unit computes the same numbers)
     unsigned long long mine[WPL];
     int c = 0;
@@ -843,7 +893,7 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const 
                 auto apply_b = [&](const Prod &d) {
                     const int j = d.j - c0;
                     const unsigned long long word = bits[j >> 6];
-                    if (MASKED && !((word >> (j & 63)) & 1ull)) return;
+                    if ((MASKED || cmask) && !((word >> (j & 63)) & 1ull)) return;
                     const int rank = wpre[j >> 6] + __popcll(word & ((1ull << (j & 63)) - 1ull)) - r0;
                     if ((unsigned)rank < (unsigned)CAP && !MXM_ABL(a, 4)) {
                         const W v = (W)apply_binop<T>(mult_, d.av, d.bv);
@@ -976,6 +1026,16 @@ __global__ __launch_bounds__(MM_WIN_BLOCK) void k_spgemm_unit_dense(const MxmArg
         else run(integral_constant<int, -1>{}, integral_constant<int, -1>{});
     }
     __syncthreads();
+    if (a.CMp && bslot < 0) {  // fused complemented mask: forbidden columns are not emitted (the kept bitmaps are already without them)
+        const int32_t *mo = a.cm_woff + (int64_t)r.row * (nwin + 1) + w;
+        const int m0 = mo[0], m1 = mo[1];
+        const int64_t mb = a.CMp[r.row];
+        for (int i = m0 + tid; i < m1; i += MM_WIN_BLOCK) {
+            const int j = a.CMj[mb + i] - c0;
+            atomicAnd(&s_bits[j >> 6], ~(1ull << (j & 63)));
+        }
+        __syncthreads();
+    }
     // emit: thread t takes 16 columns (a quarter of word t / 4)
     const unsigned long long word = s_bits[tid >> 2];
     const int q4 = tid & 3;
@@ -1516,12 +1576,12 @@ struct RowBins {
 
 // stable sort of rows by bin(size): rows inside a bin stay in increasing order
 static void make_bins(RowBins &rb, const int64_t *Ap, const int64_t *F, int64_t m, int64_t *size, int64_t b1, int64_t b2,
-                      int64_t b3, const int32_t *wrow = nullptr)
+                      int64_t b3, const int32_t *wrow = nullptr, const int64_t *extra_ptr = nullptr)
 {
     DevBuf<uint64_t> key(m), key2(m);
     DevBuf<uint32_t> rid(m);
     hipLaunchKernelGGL(k_row_bins, dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, ctx().stream, Ap, F, m, size, b1, b2, b3,
-                       key.p, rid.p, wrow);
+                       key.p, rid.p, wrow, extra_ptr);
     prim_sort_pairs_u64_u32(key.p, key2.p, rid.p, rb.rows.p, m, 3);
     DevBuf<int64_t> bs(6);
     hipLaunchKernelGGL(k_bin_starts, dim3(1), dim3(64), 0, ctx().stream, key2.p, m, bs.p);
@@ -1671,10 +1731,18 @@ struct WoffKeep {
 static WoffKeep g_woff_keep;
 
 // T = A (+.x) B in the semiring's type; returns a fresh matrix (sorted rows)
+// forbidden: the pattern of a complemented mask to fuse (positions T must not hold), *fused tells whether it was honoured --
+// the fused path needs the window offset tables (hash / unit / window kernels only); when it is not taken T is the full product
+// and the caller's write rule applies the mask.
+struct ForbiddenPattern {
+    const int64_t *p = nullptr;
+    const int32_t *j = nullptr;
+};
 template <typename T>
 static GB_Matrix_opaque *spgemm(GB_Matrix_opaque *A, const void *Ax, GB_Matrix_opaque *B, const void *Bx, int st, int monoid,
-                                int mult)
+                                int mult, const ForbiddenPattern *forbidden = nullptr, bool *fused = nullptr)
 {
+    if (fused) *fused = false;
     GB_Matrix_opaque *Tm = matrix_new(type_of_code(st), A->nrows, B->ncols);
     if (A->nvals == 0 || B->nvals == 0) return Tm;
     try {
@@ -1708,6 +1776,9 @@ static GB_Matrix_opaque *spgemm(GB_Matrix_opaque *A, const void *Ax, GB_Matrix_o
         std::vector<unsigned long long> class_host(MU_CSLOTS * MU_NCLS);
         const int64_t n_win = ceil_div((int64_t)B->ncols, MM_WIN);
         const int64_t woff_entries = (int64_t)B->nrows * (n_win + 1);
+        DevBuf<int32_t> cm_woff(0);
+        bool fuse = forbidden && forbidden->p && !(ctx().debug_flags & 256) && ctx().mxm_heavy_kernel == 1 && n_win < 65536 &&
+                    woff_entries * 4 <= (8ll << 30) && m * (n_win + 1) * 4 <= (8ll << 30);
         auto ensure_woff = [&]() {
             if (a.woff || (ctx().debug_flags & 256) || woff_entries * 4 > (8ll << 30)) return;
             if (g_woff_keep.on && g_woff_keep.Bp == (const void *)B->d_ptr && g_woff_keep.woff) {  // (a row-batched product: B is the same in every batch)
@@ -1735,7 +1806,7 @@ static GB_Matrix_opaque *spgemm(GB_Matrix_opaque *A, const void *Ax, GB_Matrix_o
             // (never above 4096: a row the hash kernels count must fit the numeric hash table, nnz <= flops <= 4096 -- or it falls to the
             //  1024-thread window walk, a quarter of the scale-22 run while the limit was 32 x 256 windows = 8192)
             const int64_t sym_b3 = units_ok ? std::min<int64_t>(4096, std::max<int64_t>(ctx().mxm_unit_min_flops, ctx().mxm_unit_min_per_window * n_win)) : 16384;
-            make_bins(rb, A->d_ptr, F.p, m, rownnz.p, 128, 1024, sym_b3);
+            make_bins(rb, A->d_ptr, F.p, m, rownnz.p, 128, 1024, sym_b3, nullptr, fuse ? forbidden->p : nullptr);
             GRB_HIP(hipMemsetAsync(rownnz.p, 0, sizeof(int64_t) * (m + 1), ctx().stream));
             if (rb.count(4) && units_ok && rb.count(4) * (n_win + 1) * 4 <= (8ll << 30)) {
                 ensure_woff();
@@ -1770,6 +1841,19 @@ static GB_Matrix_opaque *spgemm(GB_Matrix_opaque *A, const void *Ax, GB_Matrix_o
                     }
                 }
             }
+            // the fused complemented mask: every kernel this product will run must know it (the dense-accumulator fall-backs do not)
+            fuse = fuse && (rb.count(4) == 0 || (a.woff && a.wrow && a.wcnt));
+            if (fuse) {
+                dev_free(cm_woff.p);
+                cm_woff.p = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)(m * (n_win + 1)));
+                launch_window_offsets(forbidden->p, forbidden->j, m, (int)n_win, cm_woff.p, (const int32_t *)nullptr,
+                                      (unsigned long long *)nullptr, UnitLimits{});
+                a.CMp = forbidden->p;
+                a.CMj = forbidden->j;
+                a.cm_woff = cm_woff.p;
+                a.n_win = (int)n_win;
+                if (fused) *fused = true;
+            }
             run_bins<T, false>(a, rb);
         }
         // 4. row pointers of T (counts stay in rownnz for the numeric binning)
@@ -1798,7 +1882,7 @@ static GB_Matrix_opaque *spgemm(GB_Matrix_opaque *A, const void *Ax, GB_Matrix_o
         //    offset table (n_B x (windows+1) int32) is affordable, else dense accumulators in HBM
         {
             RowBins rb(m);
-            make_bins(rb, A->d_ptr, nullptr, m, rownnz.p, 128, 1024, 4096, a.wrow);
+            make_bins(rb, A->d_ptr, nullptr, m, rownnz.p, 128, 1024, 4096, a.wrow, fuse ? forbidden->p : nullptr);
             if (rb.count(4)) ensure_woff();
             run_bins<T, true>(a, rb);
             sync_stream();  // woff is released at the end of this scope
@@ -1913,6 +1997,52 @@ static GB_Matrix_opaque *spgemm_masked(GB_Matrix_opaque *A, const void *Ax, GB_M
         throw;
     }
     return Tm;
+}
+
+// ---- the forbidden pattern of a VALUED complemented mask: its true entries, compacted (a structural mask forbids its whole
+//      pattern, no copy) ------------------------------------------------------------------------------------------------------
+template <typename TM>
+__global__ void k_mask_truth(const TM *Mx, int m_iso, int64_t n, int64_t *flag)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) flag[p] = Mx[m_iso ? 0 : p] != (TM)0 ? 1 : 0;
+    else if (p == n) flag[p] = 0;
+}
+__global__ void k_true_cols(const int64_t *pos, const int32_t *Mj, int64_t n, int32_t *out)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n && pos[p + 1] != pos[p]) out[pos[p]] = Mj[p];
+}
+static void true_pattern(GB_Matrix_opaque *Mask, DevBuf<int64_t> &ptr, DevBuf<int32_t> &col)
+{
+    const int64_t n = Mask->nvals, m = (int64_t)Mask->nrows;
+    DevBuf<int64_t> pos(n + 1);
+    const dim3 grid((unsigned)ceil_div(n + 1, 256)), block(256);
+    const int iso = Mask->iso ? 1 : 0;
+    switch (type_size(Mask->type->code)) {
+    case 1: hipLaunchKernelGGL((k_mask_truth<uint8_t>), grid, block, 0, ctx().stream, (const uint8_t *)Mask->d_val, iso, n, pos.p); break;
+    case 2: hipLaunchKernelGGL((k_mask_truth<uint16_t>), grid, block, 0, ctx().stream, (const uint16_t *)Mask->d_val, iso, n, pos.p); break;
+    case 4:
+        if (Mask->type->code == TC_FP32) hipLaunchKernelGGL((k_mask_truth<float>), grid, block, 0, ctx().stream, (const float *)Mask->d_val, iso, n, pos.p);
+        else hipLaunchKernelGGL((k_mask_truth<uint32_t>), grid, block, 0, ctx().stream, (const uint32_t *)Mask->d_val, iso, n, pos.p);
+        break;
+    default:
+        if (Mask->type->code == TC_FP64) hipLaunchKernelGGL((k_mask_truth<double>), grid, block, 0, ctx().stream, (const double *)Mask->d_val, iso, n, pos.p);
+        else hipLaunchKernelGGL((k_mask_truth<uint64_t>), grid, block, 0, ctx().stream, (const uint64_t *)Mask->d_val, iso, n, pos.p);
+        break;
+    }
+    prim_exclusive_sum_i64(pos.p, pos.p, n + 1);
+    int64_t n_true = 0;
+    d2h(&n_true, pos.p + n, sizeof(int64_t));
+    dev_free(ptr.p);
+    ptr.p = (int64_t *)dev_alloc(sizeof(int64_t) * (size_t)(m + 1));
+    hipLaunchKernelGGL(k_cap_rowptr, dim3((unsigned)ceil_div(m + 1, 256)), dim3(256), 0, ctx().stream, matrix_rowptr(Mask),
+                       (const int64_t *)pos.p, m, ptr.p);
+    dev_free(col.p);
+    col.p = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)std::max<int64_t>(1, n_true));
+    hipLaunchKernelGGL(k_true_cols, grid, block, 0, ctx().stream, (const int64_t *)pos.p, (const int32_t *)Mask->d_col, n, col.p);
+    ctx().stats.kernel_launches += 3;
+    sync_stream();  // (pos is released at the end of this scope)
 }
 
 // flops of A (+.x) B = sum over the entries A(i,k) of nnz(B(k,:))
@@ -2045,6 +2175,24 @@ static void mxm_core(GB_Matrix_opaque *C, GB_Matrix_opaque *Mask, const GB_Binar
             }
         }
     }
+    // A complemented mask is fused into the product: the positions it forbids never enter T (they would only be dropped by the
+    // write rule, after a second pass over all of T)
+    bool fused = false;
+    DevBuf<int64_t> fp_ptr(0);
+    DevBuf<int32_t> fp_col(0);
+    if (!Tm && Mask && f.comp && ctx().mxm_mask_mode != 0 && Mask->nvals > 0) {
+        ForbiddenPattern fp;
+        if (f.structure) {
+            fp.p = matrix_rowptr(Mask);
+            fp.j = Mask->d_col;
+        } else {
+            true_pattern(Mask, fp_ptr, fp_col);
+            fp.p = fp_ptr.p;
+            fp.j = fp_col.p;
+        }
+        GRB_DISPATCH_TYPE(st, T, { Tm = spgemm<T>(Ae, Ax, Be, Bx, st, monoid, mult, &fp, &fused); })
+        if (fused) ctx().stats.method = 7;
+    }
     if (!Tm) GRB_DISPATCH_TYPE(st, T, { Tm = spgemm<T>(Ae, Ax, Be, Bx, st, monoid, mult); })
     try {
         // T in the output type
@@ -2057,7 +2205,10 @@ static void mxm_core(GB_Matrix_opaque *C, GB_Matrix_opaque *Mask, const GB_Binar
         Tm->type = C->type;
         // a mask-driven product lies inside the mask's pattern: under a structural mask, with nothing to accumulate into and
         // nothing of C to keep (C empty, or replace), the write rule is C = T
+        // (the same for a fused complemented mask, valued or structural: T holds no forbidden position, and what C held at the
+        //  forbidden ones is either nothing or deleted by replace)
         if (ctx().stats.method == 4 && !accum && f.structure && !f.comp && (C->nvals == 0 || f.replace)) take_storage(C, Tm);
+        else if (fused && !accum && (C->nvals == 0 || f.replace)) take_storage(C, Tm);
         else matrix_apply_write_rule(C, Mask, accum, Tm, f.replace, f.comp, f.structure);
     } catch (...) {
         matrix_free(Tm);

@@ -549,6 +549,7 @@ def test_mxm_scale16_vs_scipy_on_the_host(gb):
     assert np.array_equal(cx.cpu().numpy(), ref.data)
     # under the complemented structural mask (the reference pins C<~M.S> at tests/test_matrix.py:359-366 on its 7 x 7 literal)
     M = A.mxm(A, gb.semiring.plus_times).new(mask=~A.S)
+    assert device.last_stats()["method"] == 7  # the complemented mask was fused into the product (no second pass over T)
     pat = sp.csr_matrix((np.ones(cj.size, np.int64), cj, ip), shape=(n, n))
     inside = ref.multiply(pat).tocsr()  # product restricted to A's pattern (values kept)
     diff = (ref - inside).tocsr()
@@ -560,10 +561,12 @@ def test_mxm_scale16_vs_scipy_on_the_host(gb):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("scale,workload", [(18, "mxm_plus_times"), (20, "mxm_plus_times"), (22, "mxm_plus_times"), (22, "mxm_plus_times_masked")])
+@pytest.mark.parametrize("scale,workload", [(18, "mxm_plus_times"), (20, "mxm_plus_times"), (22, "mxm_plus_times"), (22, "mxm_plus_times_masked"),
+                                            (18, "mxm_plus_times_cmask"), (20, "mxm_plus_times_cmask")])
 def test_mxm_bench_sizes_with_independent_checks(gb, scale, workload):
     """The SpGEMM lines bench.py prints (scale 20: the materialised product, 9.7 G entries; scale 22: row batches with the output
-    streamed; scale 22 under the structural mask A), each with the checks of bench.verify_mxm: the multiply count against the row
+    streamed; scale 22 under the structural mask A; scale 18 / 20 under the complemented structural mask A, fused into the product),
+    each with the checks of bench.verify_mxm: the multiply count against the row
     pointers, sum of the values = multiply count, nnz(C) = last row pointer, sampled rows (columns, order and values) against
     torch.unique over the gathered rows of B, and for the streamed pipeline a row block against its materialised product."""
     import argparse
@@ -583,6 +586,8 @@ def test_mxm_bench_sizes_with_independent_checks(gb, scale, workload):
         assert cfg["nnz_C"] > 50 * cfg["nnz_A"]
         if scale >= 21:
             assert cfg["batches"] > 1 and cfg["checksum"] == cfg["flops"]
+    elif workload == "mxm_plus_times_cmask":
+        assert line["stats"]["method"] == 7 and cfg["nnz_C"] > 50 * cfg["nnz_A"]
     else:
         assert cfg["nnz_C"] <= cfg["nnz_A"]
     device.trim_memory()

@@ -1518,6 +1518,97 @@ def test_mxm_units_random(gb, seed, request=None):
             _lib.lib.GrX_option_set(name.encode(), val)
 
 
+@pytest.mark.parametrize("seed", range(28))
+def test_mxm_complemented_mask_fused(gb, seed, request=None):
+    """C<!M> = A (+.x) B with the complemented mask fused into the product (the forbidden positions never enter T): rows of
+    every size class -- LDS hash tables (forbidden columns pre-inserted), (row, column window) units of every class with and
+    without kept bitmaps, the dense unit, the 1024-thread window walk --, structural and valued masks whose entries cover a large
+    part of the product's pattern (and positions outside it, and whole rows of it), with / without an old C, accumulators,
+    replace.  Checked against the oracle, and against the unfused path (full product + write rule) of the library itself."""
+    from graphblas_amd import _lib, device
+
+    on_gpu = request is None or request.node.callspec.params["gb"] == "gpu"
+    rng = np.random.default_rng(9900 + seed)
+    tname = TYPES[seed % 7]
+    srs = semirings_for(tname)
+    sr = srs[int(rng.integers(len(srs)))]
+    small = seed % 4 == 3  # hash-table rows only
+    nwin = 1 if small else int(rng.integers(1, 5))
+    n = int(rng.integers(20, 400)) if small else int(rng.integers((nwin - 1) * 16384 + 1, nwin * 16384 + 1))
+    k = int(rng.integers(5, 80)) if small else int(rng.integers(40, 300 if on_gpu else 100))
+    m = int(rng.integers(3, 60)) if small else int(rng.integers(3, 30 if on_gpu else 9))
+    wts = rng.random(nwin) ** 2
+    wts /= wts.sum()
+    br, bc = [], []
+    for r in range(k):
+        d = int(rng.integers(1, 30)) if small else int(rng.integers(20, 500 if on_gpu else 160))
+        win = rng.choice(nwin, d, p=wts)
+        cols = np.unique(np.minimum(win * 16384 + rng.integers(0, min(n, 16384), d), n - 1))
+        br.append(np.full(cols.size, r))
+        bc.append(cols)
+    br, bc = np.concatenate(br), np.concatenate(bc)
+    deg = rng.integers(0, 12, m)
+    heavy = rng.random(m) < (0.2 if small else 0.6)
+    deg[heavy] = rng.integers(max(1, k // 4), k + 1, int(heavy.sum()))
+    deg = np.minimum(deg, k)
+    ar = np.repeat(np.arange(m), deg)
+    ac = np.concatenate([np.sort(rng.choice(k, d, replace=False)) for d in deg]) if deg.sum() else np.zeros(0, np.int64)
+    av, bv = rand_vals(rng, ar.size, tname), rand_vals(rng, br.size, tname)
+    if seed % 5 == 0 and av.size and bv.size:
+        av[:] = av[0]
+        bv[:] = bv[0]
+    oa, ob = O.OMat.from_coo(ar, ac, av, m, k, tname), O.OMat.from_coo(br, bc, bv, k, n, tname)
+    # the mask: a fraction of the product's own pattern (per row: none / some / most / all of it) + positions outside it
+    tr, tc, _ = O.mxm(oa, ob, "any_pair" if tname == "BOOL" else sr).to_coo()
+    tr, tc = np.asarray(tr, np.int64), np.asarray(tc, np.int64)
+    frac = rng.choice([0.0, 0.1, 0.6, 1.0], m)
+    keep = rng.random(tr.size) < frac[tr] if tr.size else np.zeros(0, bool)
+    xr = rng.integers(0, m, 50 if small else 400)
+    xc = rng.integers(0, n, xr.size)
+    key = np.unique(np.concatenate([tr[keep] * n + tc[keep], xr * n + xc]))
+    mr, mc = key // n, key % n
+    mv = rng.integers(0, 2, mr.size).astype(np.int8)
+    struct, repl = bool(seed & 1), bool(seed & 2)
+    accum = [None, "plus", "second", None][seed % 4] if seed % 3 == 0 and tname != "BOOL" else None
+    use_c = accum is not None or bool(rng.integers(2))
+    cr, cc, cv = rand_coo(rng, m, n, tname, long_rows=1)
+    oc = O.OMat.from_coo(cr, cc, cv, m, n, tname) if use_c else None
+    om = O.OMat.from_coo(mr, mc, mv, m, n, "INT8")
+    exp = O.mxm(oa, ob, sr, C=oc, mask=om, mask_comp=True, mask_struct=struct, accum=accum, replace=repl)
+    opts = dict(mxm_unit_small=int(rng.choice([64, 512])), mxm_unit_mid=int(rng.choice([300, 1024])),
+                mxm_unit_dense=int(rng.choice([1500, 4096])), mxm_bitmap_pool_cap=int(rng.choice([0, 2, (1 << 31) - 1])),
+                mxm_unit_min_flops=int(rng.choice([128, 1024, 1 << 30])))  # (2^30: no units -- the window walk takes the heavy rows)
+    any_values = sr.startswith("any_") and not sr.endswith("pair")
+    try:
+        for name, val in opts.items():
+            _lib.lib.GrX_option_set(name.encode(), val)
+        A = gb.Matrix.from_coo(ar, ac, av, dtype=tname, nrows=m, ncols=k)
+        B = gb.Matrix.from_coo(br, bc, bv, dtype=tname, nrows=k, ncols=n)
+        M = gb.Matrix.from_coo(mr, mc, mv, dtype="INT8", nrows=m, ncols=n)
+        got = []
+        for mask_mode in (1, 0):  # fused, then the full product + write rule
+            _lib.lib.GrX_option_set(b"mxm_mask_mode", mask_mode)
+            C = gb.Matrix.from_coo(cr, cc, cv, dtype=tname, nrows=m, ncols=n) if use_c else gb.Matrix(tname, m, n)
+            kw = dict(mask=~(M.S if struct else M.V), replace=repl)
+            if accum:
+                kw["accum"] = getattr(gb.binary, accum)
+            C(**kw) << A.mxm(B, getattr(gb.semiring, sr))
+            if ar.size and br.size and mr.size:
+                assert device.last_stats()["method"] == (7 if mask_mode == 1 else 3)
+            got.append(C)
+        for C in got:
+            if any_values:  # (any: one of the products, not a fixed one -- the pattern is checked)
+                I, J, _ = C.to_coo()
+                er, ec, _ = exp.to_coo()
+                assert I.tolist() == er.tolist() and J.tolist() == ec.tolist()
+            else:
+                same_mat(C, exp)
+    finally:
+        for name, val in dict(mxm_unit_small=512, mxm_unit_mid=1024, mxm_unit_dense=4096, mxm_bitmap_pool_cap=(1 << 31) - 1,
+                              mxm_unit_min_flops=1024, mxm_mask_mode=1).items():
+            _lib.lib.GrX_option_set(name.encode(), val)
+
+
 @pytest.mark.parametrize("sr,tname", [("plus_times", "INT64"), ("min_plus", "FP64"), ("any_pair", "BOOL"), ("plus_pair", "UINT16")])
 def test_mxm_masked_unit_classes(gb, sr, tname):
     """C<M.S> = A (+.x) B, mask-driven, with the heavy rows walked as (row, column window) units: the bitmap of a unit is the mask
