@@ -319,6 +319,8 @@ GrB_Info GrX_Matrix_cache_bytes(const GrB_Matrix A, uint64_t *bytes);
  *   "mxm_mask_mode" mask-driven SpGEMM for non-complemented masks: 1 (default) when the product costs clearly more than the mask,
  *                   0 never, 2 always;  complemented masks: fused into the product (the forbidden positions never enter it)
  *                   unless 0 (full product, then the write rule)
+ *   "mat_write_kernel"  the write rule C<M,replace> = accum(C, T) of matrix results: 1 (default) a wavefront per row, long rows
+ *                   cut into column pieces; 0 a thread per row (rounds 1-2: 1.6 s on a 9.7 G-entry T)
  *   "mxm_heavy_kernel"  SpGEMM rows beyond the LDS hash tables: 1 (default) (row, column window) work units (k_spgemm_unit),
  *                   0 the 1024-thread row kernels of round 1
  *   "mxm_unit_min_flops" / "mxm_unit_min_per_window"  rows with more products than this (1024) and than this many per column window

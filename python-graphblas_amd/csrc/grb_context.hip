@@ -205,7 +205,7 @@ extern "C" GrB_Info GrB_init(GrB_Mode mode)
         {"GRB_MXM_BITMAP_POOL_MB", "mxm_bitmap_pool_mb"}, {"GRB_MXM_BITMAP_MIN_CNT", "mxm_bitmap_min_cnt"},
         {"GRB_LONG_KERNEL", "long_kernel"}, {"GRB_LONG_CLASSES", "long_classes"}, {"GRB_SPLIT_MIN_LEN", "split_min_len"},
         {"GRB_LONG_SUB", "long_sub"}, {"GRB_LONG_SUB_MIN_LEN", "long_sub_min_len"}, {"GRB_LEAN_MIN_NNZ", "lean_min_nnz"},
-        {"GRB_MXM_MASK_MODE", "mxm_mask_mode"},
+        {"GRB_MXM_MASK_MODE", "mxm_mask_mode"}, {"GRB_MAT_WRITE_KERNEL", "mat_write_kernel"},
     };
     for (const auto &k : knobs)
         if (const char *e = getenv(k.env)) (void)GrX_option_set(k.opt, atoll(e));
@@ -317,6 +317,10 @@ extern "C" GrB_Info GrX_option_set(const char *name, int64_t value)
     else if (n == "long_sub") c.long_sub = (int)std::max<int64_t>(0, std::min<int64_t>(value, 16));
     else if (n == "long_sub_min_len") c.long_sub_min_len = (int)value;
     else if (n == "mxm_mask_mode") c.mxm_mask_mode = (int)value;
+    else if (n == "mat_write_kernel") {
+        if (value != 0 && value != 1) return GrB_INVALID_VALUE;
+        c.mat_write_kernel = (int)value;
+    }
     else if (n == "mxm_heavy_kernel") c.mxm_heavy_kernel = (int)value;
     else if (n == "drop_hot_cols") c.drop_hot_cols = (int)value;
     else if (n == "mxm_unit_min_flops") c.mxm_unit_min_flops = value;

@@ -78,6 +78,7 @@ struct Context {
     int64_t mxm_bitmap_pool_cap = INT32_MAX;  // ... and at most this many bitmaps (tests: a pool that runs out)
     int mxm_bitmap_min_cnt = 512;  // units with more entries than this keep their bitmap
     int64_t mxm_bitmap_pool_mb = 16384;  // bitmaps of the denser units kept from the symbolic for the numeric pass: at most this much  // rows with more products than this (and than 32 per window) are walked as units
+    int mat_write_kernel = 1;  // the write rule of matrix results: 1 a wavefront per row / column piece, 0 a thread per row (rounds 1-2)
     int mxm_mask_mode = 1;  // mask-driven SpGEMM for non-complemented masks: 0 never, 1 when the full product costs more, 2 always;
                             // complemented masks are fused into the product unless 0
     int long_sub = 0;       // sub-ranges per class of the cold columns of the long rows (items of a class are walked sub-range by

@@ -1563,6 +1563,8 @@ __global__ void k_mat_write(int64_t m, const int64_t *Cp, const int32_t *Cj, con
     if (!FILL) Ncount[i] = cnt;
 }
 
+#include "grb_mxm_write.inc"
+
 // ---------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------
@@ -2084,6 +2086,54 @@ void matrix_apply_write_rule(GB_Matrix_opaque *C, GB_Matrix_opaque *Mask, const 
         const int acc_op = accum ? canonical_op(C->type->code, accum->op) : -1;
         const int64_t *Mp = Mask ? matrix_rowptr(Mask) : nullptr;
         GB_Matrix_opaque *N = matrix_new(C->type, C->nrows, C->ncols);
+        if (ctx().mat_write_kernel == 1) {  // a wavefront per row / per column piece of a long row (grb_mxm_write.inc)
+            try {
+                WriteArgs wa{};
+                wa.m = m;
+                wa.Cp = (const int64_t *)C->d_ptr; wa.Cj = (const int32_t *)C->d_col; wa.Cx = C->d_val; wa.c_iso = C->iso ? 1 : 0;
+                wa.Tp = Tp; wa.Tj = (const int32_t *)Tm->d_col; wa.Tx = Tm->d_val;
+                wa.Mp = Mp; wa.Mj = Mask ? (const int32_t *)Mask->d_col : nullptr; wa.Mx = Mask ? (const void *)Mask->d_val : nullptr;
+                wa.m_type = Mask ? Mask->type->code : 0; wa.m_iso = Mask && Mask->iso ? 1 : 0; wa.has_mask = Mask ? 1 : 0;
+                wa.m_struct = f.structure ? 1 : 0; wa.m_comp = f.comp ? 1 : 0; wa.accum = acc_op; wa.replace = f.replace ? 1 : 0;
+                const int64_t ncols = (int64_t)C->ncols;
+                const int pieces = (int)std::min<int64_t>(WR_MAX_PIECES, std::max<int64_t>(1, ceil_div(ncols, (int64_t)16384)));
+                wa.piece_cols = (int)std::min<int64_t>(0x7fffffff, ceil_div(ncols, (int64_t)pieces));
+                DevBuf<int64_t> ubase(m + 1);
+                hipLaunchKernelGGL(k_write_units_per_row, dim3((unsigned)ceil_div(m + 1, 256)), dim3(256), 0, ctx().stream, wa.Cp, Tp, m, pieces, ubase.p);
+                prim_exclusive_sum_i64(ubase.p, ubase.p, m + 1);
+                int64_t n_units = 0, nnzN = 0;
+                d2h(&n_units, ubase.p + m, sizeof(int64_t));
+                if (n_units > 0) {
+                    DevBuf<int32_t> urow(n_units);
+                    hipLaunchKernelGGL(k_write_unit_rows, dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, ctx().stream, (const int64_t *)ubase.p, m, urow.p);
+                    DevBuf<int64_t> uoff(n_units + 1, true);
+                    wa.ubase = ubase.p; wa.urow = urow.p; wa.n_units = n_units; wa.ucount = uoff.p;
+                    const dim3 grid((unsigned)ceil_div(n_units, 4)), block(256);
+                    GRB_DISPATCH_TYPE(C->type->code, TW, { hipLaunchKernelGGL((k_mat_write_wave<TW, false>), grid, block, 0, ctx().stream, wa); })
+                    prim_exclusive_sum_i64(uoff.p, uoff.p, n_units + 1);
+                    d2h(&nnzN, uoff.p + n_units, sizeof(int64_t));
+                    if (nnzN) {
+                        N->d_ptr = (int64_t *)dev_alloc(sizeof(int64_t) * (m + 1));
+                        hipLaunchKernelGGL(k_write_rowptr, dim3((unsigned)ceil_div(m + 1, 256)), dim3(256), 0, ctx().stream, (const int64_t *)ubase.p,
+                                           (const int64_t *)uoff.p, m, N->d_ptr);
+                        N->d_col = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)nnzN);
+                        N->d_val = dev_alloc(C->type->size * (size_t)nnzN);
+                        wa.uoff = uoff.p; wa.Nj = N->d_col; wa.Nx = N->d_val;
+                        GRB_DISPATCH_TYPE(C->type->code, TW, { hipLaunchKernelGGL((k_mat_write_wave<TW, true>), grid, block, 0, ctx().stream, wa); })
+                    }
+                    ctx().stats.kernel_launches += 5;
+                    sync_stream();  // (the unit tables are released at the end of this scope)
+                }
+                N->nvals = nnzN;
+                GRB_HIP(hipGetLastError());
+                take_storage(C, N);
+            } catch (...) {
+                matrix_free(N);
+                throw;
+            }
+            matrix_free(N);
+            return;
+        }
         try {
             DevBuf<int64_t> cnt(m + 1, true);
             int64_t *Np = (int64_t *)dev_alloc(sizeof(int64_t) * (m + 1));

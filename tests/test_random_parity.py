@@ -1609,6 +1609,64 @@ def test_mxm_complemented_mask_fused(gb, seed, request=None):
             _lib.lib.GrX_option_set(name.encode(), val)
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_matrix_write_rule_wavefront_merge(gb, seed):
+    """The write rule C<M, replace> = accum(C, T) of matrix results (k_mat_write_wave): rows of C_old, T and M of every length
+    against each other -- empty, a few entries, several 64-entry chunks, rows cut into column pieces (more than 8192 entries on
+    more than 16384 columns), a full row --, the mask denser than C_old and T (the merge step bounded by the mask chunk), false
+    mask values, complement, replace, accumulators, iso C_old.  T is given exactly (A = identity, so T = B), the result is
+    checked against the oracle and against the thread-per-row kernel of rounds 1-2."""
+    from graphblas_amd import _lib
+
+    rng = np.random.default_rng(7700 + seed)
+    tname = ["INT64", "FP64", "INT8", "BOOL", "FP32", "UINT16"][seed % 6]
+    sr = "lor_land" if tname == "BOOL" else "plus_times"
+    m = 7
+    n = int(rng.integers(300, 3000)) if seed % 4 == 3 else int(rng.integers(17000, 70000))
+    shapes = [0, 3, 70, min(n, 200), min(n, 9000), min(n, 20000), n]
+
+    def rows_with(lengths, vals_type):
+        lengths = rng.permutation(lengths)
+        r = np.concatenate([np.full(ln, i) for i, ln in enumerate(lengths)]).astype(np.int64)
+        c = np.concatenate([np.sort(rng.choice(n, ln, replace=False)) for ln in lengths]).astype(np.int64)
+        return r, c, rand_vals(rng, r.size, vals_type)
+
+    br, bc, bv = rows_with(shapes, tname)
+    cr, cc, cv = rows_with(shapes, tname)
+    mr, mc, mv = rows_with([0, 1, 40, min(n, 500), min(n, 15000), min(n, 30000), n], "INT8")
+    if seed % 5 == 1 and cv.size:
+        cv[:] = cv[0]
+    eye = np.arange(m)
+    one = np.ones(m, dtype=bv.dtype)
+    oa, ob = O.OMat.from_coo(eye, eye, one, m, m, tname), O.OMat.from_coo(br, bc, bv, m, n, tname)
+    oc, om = O.OMat.from_coo(cr, cc, cv, m, n, tname), O.OMat.from_coo(mr, mc, mv, m, n, "INT8")
+    mask_kind = seed % 3  # 0 none, 1 structural, 2 valued
+    comp, repl = bool(seed & 1) and mask_kind > 0, bool(seed & 2) and mask_kind > 0
+    accum = [None, "plus", "second", "min"][seed % 4] if tname != "BOOL" else [None, "lor"][seed % 2]
+    if mask_kind == 0 and accum is None:
+        accum = "lor" if tname == "BOOL" else "plus"  # (no mask and no accum: C = T, no write rule at all)
+    exp = O.mxm(oa, ob, sr, C=oc, mask=om if mask_kind else None, mask_comp=comp, mask_struct=mask_kind == 1, accum=accum, replace=repl)
+    A = gb.Matrix.from_coo(eye, eye, one, dtype=tname, nrows=m, ncols=m)
+    B = gb.Matrix.from_coo(br, bc, bv, dtype=tname, nrows=m, ncols=n)
+    M = gb.Matrix.from_coo(mr, mc, mv, dtype="INT8", nrows=m, ncols=n)
+    try:
+        _lib.lib.GrX_option_set(b"mxm_mask_mode", 0)  # (the full product, then the write rule -- the kernel under test)
+        for kernel in (1, 0):
+            _lib.lib.GrX_option_set(b"mat_write_kernel", kernel)
+            C = gb.Matrix.from_coo(cr, cc, cv, dtype=tname, nrows=m, ncols=n)
+            kw = {}
+            if mask_kind:
+                mm = M.S if mask_kind == 1 else M.V
+                kw = dict(mask=~mm if comp else mm, replace=repl)
+            if accum:
+                kw["accum"] = getattr(gb.binary, accum)
+            C(**kw) << A.mxm(B, getattr(gb.semiring, sr))
+            same_mat(C, exp)
+    finally:
+        _lib.lib.GrX_option_set(b"mxm_mask_mode", 1)
+        _lib.lib.GrX_option_set(b"mat_write_kernel", 1)
+
+
 @pytest.mark.parametrize("sr,tname", [("plus_times", "INT64"), ("min_plus", "FP64"), ("any_pair", "BOOL"), ("plus_pair", "UINT16")])
 def test_mxm_masked_unit_classes(gb, sr, tname):
     """C<M.S> = A (+.x) B, mask-driven, with the heavy rows walked as (row, column window) units: the bitmap of a unit is the mask
