@@ -755,7 +755,7 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const 
                 if (lane >= off) incl += t;
             }
             const int total = __shfl(incl, 63);
-            if (total == 0) return;  // (wave-uniform)
+            if (total == 0 || MXM_ABL(a, 128)) return;  // (wave-uniform; timing switch 128: no products at all)
             scan[lane] = incl - len;
             sqb[lane] = qb - (incl - len);  // (product t of the batch is entry sqb[e] + t of B, e = the lane that brought it)
             mw_sync();
@@ -797,11 +797,16 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const 
     };
     // ---- pass A: which columns of the window does the row reach
     if (!MASKED && bslot < 0 && !(NUMERIC && MXM_ABL(a, 16)))
-        visit([&](int64_t, int64_t q) { return a.Bj[q]; },
+        visit([&](int64_t, int64_t q) { return MXM_ABL(a, 256) ? c0 + (int)((q * 37) & (MM_WIN - 1)) : a.Bj[q]; },  // (256: no load of B)
               [&](int jraw) {
+                  if (MXM_ABL(a, 64)) return;  // (64: no bitmap atomics)
                   const int j = jraw - c0;
-                  atomicOr(&bits[j >> 6], 1ull << (j & 63));
+                  unsigned *wp = (unsigned *)bits + (j >> 5);  // (32-bit words: one shift, no 64-bit mask to build)
+                  const unsigned bit = 1u << (j & 31);
+                  atomicOr(wp, bit);
               });
+    // (the clamped duplicates of a trip's last products stay guarded although setting a bit twice changes nothing: unguarded, up to
+    //  255 lanes hit the same bitmap word and the LDS atomics serialise -- symbolic pass 34.6 -> 41.5 ms)
     usync();
     // fused complemented mask: the forbidden columns inside the window leave the bitmap (a bitmap kept by the symbolic pass
     // is already without them); pass B drops the products that find their column's bit clear
@@ -1759,7 +1764,7 @@ static GB_Matrix_opaque *spgemm(GB_Matrix_opaque *A, const void *Ax, GB_Matrix_o
         a.need_a = !(mult == OP_PAIR || mult == OP_SECOND);
         a.need_b = !(mult == OP_PAIR || mult == OP_FIRST || mult == OP_ANY);
 #ifdef GRB_ABLATE
-        a.abl = (ctx().debug_flags >> 20) & 0xFF;
+        a.abl = (ctx().debug_flags >> 20) & 0x7FF;
 #endif
         // 1. flops per stored entry of A, scanned
         DevBuf<int64_t> F(nnzA + 1);
