@@ -965,15 +965,16 @@ def main():
                       **{k: r[k] for k in ("value", "ms_per_step", "dtype", "roofline", "verified")}, "unit": "GTEPS", "cpu_baseline": c2})
         del wl2
         freed()
-        for scale, steps, warmup in ((20, 3, 1), (22, 2, 1)):
+        for scale, steps, warmup, wk in ((20, 3, 1, "mxm_plus_times"), (20, 2, 1, "mxm_plus_times_cmask"), (22, 2, 1, "mxm_plus_times")):
             if scale == 20 and world > 1:
                 continue  # (the sharded runs carry the scale-22 product, the size the north star quotes for 1 -> 8 GPUs)
             try:
-                line = run_mxm(args, gb, torch, device, rank, world, dist, barrier, scale=scale, workload="mxm_plus_times", steps=steps,
-                               warmup=warmup, want_cpu=(world == 1))
+                line = run_mxm(args, gb, torch, device, rank, world, dist, barrier, scale=scale, workload=wk, steps=steps,
+                               warmup=warmup, want_cpu=(world == 1 and wk == "mxm_plus_times"))
             except Exception as e:  # an extra line must never take the headline down
                 line = {"error": repr(e)}
-            extra.append({"workload": f"rmat{scale} mxm_plus_times (configs[3]" + (")" if scale == 22 else " at scale 20: fits one GPU as an object)"),
+            extra.append({"workload": f"rmat{scale} {wk} (configs[3]" + (")" if scale == 22 else " at scale 20: fits one GPU as an object"
+                                                                          + (", under the complemented structural mask ~A.S" if wk.endswith("cmask") else "") + ")"),
                           **{k: line[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "verified", "config", "roofline", "cpu_baseline", "error") if k in line}})
             freed()
     if rank == 0:
