@@ -21,7 +21,12 @@ def bind(dev):
     if _bound is None:
         if dev == "emu":
             if not os.environ.get("GRB_EMU_PREBUILT"):  # (worker processes of a multi-rank test reuse the parent's build)
-                subprocess.check_call([os.path.join(ROOT, "tests", "emu", "build_emu.sh")], stdout=subprocess.DEVNULL)
+                import fcntl
+
+                # (pytest-xdist workers start together: one of them rebuilds a stale library, the others wait instead of loading it half-linked)
+                with open(os.path.join(ROOT, "tests", "emu", ".build.lock"), "w") as lock:
+                    fcntl.flock(lock, fcntl.LOCK_EX)
+                    subprocess.check_call([os.path.join(ROOT, "tests", "emu", "build_emu.sh")], stdout=subprocess.DEVNULL)
             gb.init(lib_path=EMU_SO)
         else:
             gb.init()
