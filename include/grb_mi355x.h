@@ -323,6 +323,8 @@ GrB_Info GrX_Matrix_cache_bytes(const GrB_Matrix A, uint64_t *bytes);
  *                   cut into column pieces; 0 a thread per row (rounds 1-2: 1.6 s on a 9.7 G-entry T)
  *   "mxm_heavy_kernel"  SpGEMM rows beyond the LDS hash tables: 1 (default) (row, column window) work units (k_spgemm_unit),
  *                   0 the 1024-thread row kernels of round 1
+ *   "mxm_sym_windows"  consecutive column windows of a row one symbolic unit walks (rows of up to 128 entries of A; default 8,
+ *                   1 = one window per unit as in round 2, at most 64)
  *   "mxm_unit_min_flops" / "mxm_unit_min_per_window"  rows with more products than this (1024) and than this many per column window
  *                   (16), at most 4096, are walked as units
  *   "mxm_unit_small" / "mxm_unit_mid" / "mxm_unit_dense"  entry counts of a unit up to which one wavefront with 512 accumulators /

@@ -205,7 +205,7 @@ extern "C" GrB_Info GrB_init(GrB_Mode mode)
         {"GRB_MXM_BITMAP_POOL_MB", "mxm_bitmap_pool_mb"}, {"GRB_MXM_BITMAP_MIN_CNT", "mxm_bitmap_min_cnt"},
         {"GRB_LONG_KERNEL", "long_kernel"}, {"GRB_LONG_CLASSES", "long_classes"}, {"GRB_SPLIT_MIN_LEN", "split_min_len"},
         {"GRB_LONG_SUB", "long_sub"}, {"GRB_LONG_SUB_MIN_LEN", "long_sub_min_len"}, {"GRB_LEAN_MIN_NNZ", "lean_min_nnz"},
-        {"GRB_MXM_MASK_MODE", "mxm_mask_mode"}, {"GRB_MAT_WRITE_KERNEL", "mat_write_kernel"},
+        {"GRB_MXM_MASK_MODE", "mxm_mask_mode"}, {"GRB_MAT_WRITE_KERNEL", "mat_write_kernel"}, {"GRB_MXM_SYM_WINDOWS", "mxm_sym_windows"},
     };
     for (const auto &k : knobs)
         if (const char *e = getenv(k.env)) (void)GrX_option_set(k.opt, atoll(e));
@@ -329,6 +329,10 @@ extern "C" GrB_Info GrX_option_set(const char *name, int64_t value)
     else if (n == "mxm_unit_small" || n == "mxm_unit_dense" || n == "mxm_unit_mid") {  // class limits of the SpGEMM units: entry counts
         if (value < 1 || value > (1 << 30)) return GrB_INVALID_VALUE;
         (n == "mxm_unit_small" ? c.mxm_unit_small : n == "mxm_unit_dense" ? c.mxm_unit_dense : c.mxm_unit_mid) = (int)value;
+    }
+    else if (n == "mxm_sym_windows") {
+        if (value < 1 || value > 64) return GrB_INVALID_VALUE;
+        c.mxm_sym_windows = value;
     }
     else if (n == "mxm_bitmap_pool_mb") c.mxm_bitmap_pool_mb = value;
     else if (n == "mxm_bitmap_min_cnt") c.mxm_bitmap_min_cnt = (int)value;

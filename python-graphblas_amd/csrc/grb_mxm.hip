@@ -67,6 +67,11 @@ struct MxmArgs {
     int bm_pools;    // (a power of two)
     int32_t *wbm;
     int bm_min_cnt;
+    // symbolic units: sym_wg consecutive windows of a row per unit (the prologue -- row, row bounds, entries of A, row pointers of B --
+    // once per group); rows with more than sym_plen_max entries of A are skipped by such a launch (0: none is) -- their units would
+    // run their windows' thousands of batches one after the other -- and walked one window per unit from the list sym_list
+    int sym_wg, sym_plen_max;
+    const int32_t *sym_list;  // positions (in `rows`) of the rows of a list launch, or nullptr: positions ridx0 ...
     int abl;  // -DGRB_ABLATE builds: timing switches of the unit kernels (bits 20.. of debug_flags); results are wrong on purpose
     // mask-driven product (T restricted to the pattern of a non-complemented mask): results land in the mask's own layout
     const int64_t *Mp;
@@ -625,6 +630,7 @@ __global__ __launch_bounds__(MM_WIN_BLOCK) void k_spgemm_win(const MxmArgs a, co
 #ifndef GRB_MU_M2_WPU
 #define GRB_MU_M2_WPU 4
 #endif
+constexpr int MU_SYM_PLEN = 128;  // rows of A up to this long (the batches a wavefront keeps in registers) may share a symbolic unit between windows
 constexpr int MU_ILP = GRB_MU_ILP;  // products a lane has in flight
 constexpr int MU_SYMBOLIC = 0, MU_NUMERIC = 1, MU_MASKED = 2;  // what a unit kernel does
 // a unit of the numeric / masked pass as the classification writes it: everything the kernel needs to start on the entries of
@@ -672,7 +678,7 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const 
     const int nwin = a.n_win;
     const int64_t unit = (int64_t)blockIdx.x * UPB + uib;
     int64_t ridx = 0, row, out = 0, pbeg, pend;
-    int w, bslot = -1, mcnt = 0;
+    int w, w_end = 0, bslot = -1, mcnt = 0;
     if constexpr (NUMERIC) {  // a unit of the class list
         if (unit >= nunits) return;  // (uniform over the unit's threads)
         const UnitRec r = units[unit];
@@ -684,12 +690,16 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const 
         if constexpr (MASKED) mcnt = r.aux;  // (the unit's mask entries are Mj[out .. out + mcnt))
         else bslot = r.aux;
     } else {  // every (row, window) of the rows [ridx0, ridx0 + nrows_here) of the bin
-        if (unit >= nrows_here * nwin) return;
-        ridx = ridx0 + unit / nwin;
-        w = (int)(unit % nwin);
+        const int wg = a.sym_wg, ngrp = (nwin + wg - 1) / wg;
+        if (unit >= nrows_here * ngrp) return;
+        ridx = ridx0 + unit / ngrp;
+        if (a.sym_list) ridx = a.sym_list[ridx];
+        w = (int)(unit % ngrp) * wg;
+        w_end = w + wg < nwin ? w + wg : nwin;
         row = rows[ridx];
         pbeg = a.Ap[row];
         pend = a.Ap[row + 1];
+        if (a.sym_plen_max > 0 && pend - pbeg > a.sym_plen_max) return;  // (a row of the list launch)
     }
     auto usync = [&]() {
         if constexpr (WPU == 1) mw_sync();
@@ -708,8 +718,9 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const 
         if (a.need_a && a.a_iso) a_iso_val = Ax[0];
         if (a.need_b && a.b_iso) b_iso_val = Bx[0];
     }
-    const int c0 = w * MM_WIN;
     const int tiu = sub * 64 + lane;  // thread inside the unit
+    for (;;) {  // (the windows of a symbolic unit; numeric and masked units: once)
+    const int c0 = w * MM_WIN;
     // the ranges of B inside the window for the first NB batches of the wavefront's entries of A: requested before anything
     // else (two dependent round trips that overlap the bitmap load / clear and the accumulator fill), kept for every pass
     int c_len[NB];
@@ -950,6 +961,12 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const 
             pre += __popcll(mine[x]);
         }
     }
+    if constexpr (NUMERIC) break;
+    else {
+        if (++w >= w_end) break;
+        usync();  // (the next window clears the bitmap this one was counted from)
+    }
+    }  // for (;;)
 }
 
 // a DENSE unit (more than MU_DENSE of the window's MM_WIN columns): compact accumulators would take several passes over the
@@ -1265,6 +1282,15 @@ static void launch_window_offsets(const int64_t *Bp, const int32_t *Bj, int64_t 
     else
         hipLaunchKernelGGL(k_window_offsets_wave, dim3((unsigned)ceil_div(nrowsB, 4)), dim3(256), 0, ctx().stream, Bp, Bj, nrowsB, n_win, woff,
                            urow, class_count, L);
+}
+
+// positions (in the bin's row list) of the rows with more than plen_max entries of A, in no particular order
+__global__ void k_sym_long_rows(const uint32_t *rows, int64_t nrows_bin, const int64_t *Ap, int plen_max, unsigned long long *cursor, int32_t *list)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nrows_bin) return;
+    const int64_t row = rows[i];
+    if (Ap[row + 1] - Ap[row] > plen_max) list[atomicAdd(cursor, 1ull)] = (int32_t)i;
 }
 
 // the per-window counts of the rows of the symbolic unit pass -> offsets inside the row (exclusive scan in place, n_win + 1
@@ -1687,12 +1713,39 @@ static void run_bins(MxmArgs &a, const RowBins &rb)
             hipLaunchKernelGGL((k_spgemm_win<T>), dim3((unsigned)rb.count(4)), dim3(MM_WIN_BLOCK), 0, ctx().stream, a, rb.ptr(4));
             ctx().stats.kernel_launches += 1;
         } else {
-            const int64_t rows_per_launch = std::max<int64_t>(1, (1ll << 22) / a.n_win);
-            for (int64_t r0 = 0; r0 < rb.count(4); r0 += rows_per_launch) {
-                const int64_t nr = std::min(rows_per_launch, rb.count(4) - r0);
-                hipLaunchKernelGGL((k_spgemm_unit<T, MU_SYMBOLIC, 1, 1>), dim3((unsigned)ceil_div(nr * a.n_win, 4)), dim3(256), 0, ctx().stream, a, rb.ptr(4), r0,
-                                   nr, (const UnitRec *)nullptr, 0);
-                ctx().stats.kernel_launches += 1;
+            // rows with at most MU_SYM_PLEN entries of A (94 % of the unit rows of an R-MAT product): MU_SYM_WG windows per unit;
+            // the others from a list, one window per unit
+            const int wg = (int)std::max<int64_t>(1, std::min<int64_t>(ctx().mxm_sym_windows, a.n_win));
+            DevBuf<int32_t> long_list(wg > 1 ? rb.count(4) : 0);
+            int64_t n_long_rows = 0;
+            if (wg > 1) {
+                DevBuf<unsigned long long> cur(1, true);
+                hipLaunchKernelGGL(k_sym_long_rows, dim3((unsigned)ceil_div(rb.count(4), 256)), dim3(256), 0, ctx().stream, rb.ptr(4), rb.count(4), a.Ap,
+                                   MU_SYM_PLEN, cur.p, long_list.p);
+                unsigned long long got = 0;
+                d2h(&got, cur.p, sizeof(got));
+                n_long_rows = (int64_t)got;
+            }
+            auto launch_sym = [&](int64_t nrows_total, int wg_here, int plen_max, const int32_t *list) {
+                MxmArgs as = a;
+                as.sym_wg = wg_here;
+                as.sym_plen_max = plen_max;
+                as.sym_list = list;
+                const int64_t ngrp = ceil_div((int64_t)a.n_win, (int64_t)wg_here);
+                const int64_t rows_per_launch = std::max<int64_t>(1, (1ll << 22) / ngrp);
+                for (int64_t r0 = 0; r0 < nrows_total; r0 += rows_per_launch) {
+                    const int64_t nr = std::min(rows_per_launch, nrows_total - r0);
+                    hipLaunchKernelGGL((k_spgemm_unit<T, MU_SYMBOLIC, 1, 1>), dim3((unsigned)ceil_div(nr * ngrp, 4)), dim3(256), 0, ctx().stream, as, rb.ptr(4), r0,
+                                       nr, (const UnitRec *)nullptr, 0);
+                    ctx().stats.kernel_launches += 1;
+                }
+            };
+            if (wg > 1) {
+                launch_sym(rb.count(4), wg, MU_SYM_PLEN, nullptr);
+                if (n_long_rows) launch_sym(n_long_rows, 1, 0, long_list.p);
+                sync_stream();  // (the list is released at the end of this scope)
+            } else {
+                launch_sym(rb.count(4), 1, 0, nullptr);
             }
             hipLaunchKernelGGL(k_unit_prefix, dim3((unsigned)ceil_div(rb.count(4), 4)), dim3(256), 0, ctx().stream, a.wcnt, a.n_win, rb.ptr(4),
                                rb.count(4), a.row_nnz, a.wrow, a.class_count, unit_limits(false));

@@ -1486,7 +1486,8 @@ def test_mxm_units_random(gb, seed, request=None):
         exp = O.mxm(oa, ob, sr, C=oc, mask=om, mask_struct=False, replace=True)
     opts = dict(mxm_unit_small=int(rng.choice([64, 512])), mxm_unit_mid=int(rng.choice([300, 1024])),
                 mxm_unit_dense=int(rng.choice([1500, 4096])), mxm_bitmap_pool_cap=int(rng.choice([0, 2, (1 << 31) - 1])),
-                mxm_unit_min_flops=int(rng.choice([128, 1024])), mxm_masked_units_min_flops=0, mxm_mask_mode=2 if mode == 2 else 0)
+                mxm_unit_min_flops=int(rng.choice([128, 1024])), mxm_masked_units_min_flops=0, mxm_mask_mode=2 if mode == 2 else 0,
+                mxm_sym_windows=int(rng.choice([1, 2, 4, 64])))
     try:
         for name, val in opts.items():
             _lib.lib.GrX_option_set(name.encode(), val)
@@ -1514,7 +1515,7 @@ def test_mxm_units_random(gb, seed, request=None):
             same_mat(C, exp)
     finally:
         for name, val in dict(mxm_unit_small=512, mxm_unit_mid=1024, mxm_unit_dense=4096, mxm_bitmap_pool_cap=(1 << 31) - 1,
-                              mxm_unit_min_flops=1024, mxm_masked_units_min_flops=64 << 20, mxm_mask_mode=1).items():
+                              mxm_unit_min_flops=1024, mxm_masked_units_min_flops=64 << 20, mxm_mask_mode=1, mxm_sym_windows=8).items():
             _lib.lib.GrX_option_set(name.encode(), val)
 
 
@@ -1577,7 +1578,8 @@ def test_mxm_complemented_mask_fused(gb, seed, request=None):
     exp = O.mxm(oa, ob, sr, C=oc, mask=om, mask_comp=True, mask_struct=struct, accum=accum, replace=repl)
     opts = dict(mxm_unit_small=int(rng.choice([64, 512])), mxm_unit_mid=int(rng.choice([300, 1024])),
                 mxm_unit_dense=int(rng.choice([1500, 4096])), mxm_bitmap_pool_cap=int(rng.choice([0, 2, (1 << 31) - 1])),
-                mxm_unit_min_flops=int(rng.choice([128, 1024, 1 << 30])))  # (2^30: no units -- the window walk takes the heavy rows)
+                mxm_unit_min_flops=int(rng.choice([128, 1024, 1 << 30])),  # (2^30: no units -- the window walk takes the heavy rows)
+                mxm_sym_windows=int(rng.choice([1, 3, 4, 64])))
     any_values = sr.startswith("any_") and not sr.endswith("pair")
     try:
         for name, val in opts.items():
@@ -1605,7 +1607,7 @@ def test_mxm_complemented_mask_fused(gb, seed, request=None):
                 same_mat(C, exp)
     finally:
         for name, val in dict(mxm_unit_small=512, mxm_unit_mid=1024, mxm_unit_dense=4096, mxm_bitmap_pool_cap=(1 << 31) - 1,
-                              mxm_unit_min_flops=1024, mxm_mask_mode=1).items():
+                              mxm_unit_min_flops=1024, mxm_mask_mode=1, mxm_sym_windows=8).items():
             _lib.lib.GrX_option_set(name.encode(), val)
 
 
