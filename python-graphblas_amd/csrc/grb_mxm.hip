@@ -90,6 +90,20 @@ struct MxmArgs {
 // finds it is dropped, and the compaction (keys >= 0) never sees it
 __device__ __forceinline__ int forbidden_key(int j) { return -(j + 2); }
 
+// inclusive sum over the 64 lanes of a wavefront in the vector ALU (DPP row shifts inside the rows of 16 lanes, then the two row
+// broadcasts): six add instructions -- the __shfl_up form is six ds_bpermute round trips through the LDS pipeline, a dependent
+// chain of ~600 cycles in kernels whose time is the length of that chain
+__device__ __forceinline__ int wave_inclusive_sum(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
 __device__ __forceinline__ unsigned hash_col(int c, int table_mask) { return ((unsigned)c * 2654435761u) & (unsigned)table_mask; }
 
 // ---- step 1 helpers ---------------------------------------------------------------------------------------
@@ -159,12 +173,7 @@ __device__ __forceinline__ void foreach_product(const MxmArgs &a, int64_t row, F
             qb = a.Bp[k];
             len = (int)(a.Bp[k + 1] - qb);
         }
-        int incl = len;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int t = __shfl_up(incl, off);
-            if (lane >= off) incl += t;
-        }
+        int incl = wave_inclusive_sum(len);
         if (lane == 63) s_fp_wave[wv] = incl;
         __syncthreads();
         int wave_off = 0, total = 0;
@@ -331,11 +340,7 @@ __global__ __launch_bounds__(MM_BLOCK) void k_spgemm_spa(const MxmArgs a, const 
             unsigned long long b = (w < a.spa_words) ? bits[w] : 0ull;
             const int c = __popcll(b);
             // workgroup exclusive scan of c: wave scan by shuffles, then the 4 wave totals through LDS
-            int incl = c;
-            for (int off = 1; off < 64; off <<= 1) {
-                const int t = __shfl_up(incl, off);
-                if (lane >= off) incl += t;
-            }
+            int incl = wave_inclusive_sum(c);
             if (lane == 63) s_wave[wv] = incl;
             __syncthreads();
             int wave_off = 0;
@@ -402,12 +407,7 @@ __device__ __forceinline__ void deal_products(int len, int64_t qb, F &&f)
     int64_t *s_qb = sc.qb;
     int *s_wsum = sc.wsum;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    int incl = len;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int t = __shfl_up(incl, off);
-        if (lane >= off) incl += t;
-    }
+    int incl = wave_inclusive_sum(len);
     if (lane == 63) s_wsum[wv] = incl;
     __syncthreads();
     int wave_off = 0, total = 0;
@@ -439,12 +439,7 @@ __device__ __forceinline__ void deal_products_2(int len, int64_t qb, FL &&load, 
     int64_t *s_qb = sc.qb;
     int *s_wsum = sc.wsum;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    int incl = len;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int t = __shfl_up(incl, off);
-        if (lane >= off) incl += t;
-    }
+    int incl = wave_inclusive_sum(len);
     if (lane == 63) s_wsum[wv] = incl;
     __syncthreads();
     int wave_off = 0, total = 0;
@@ -571,12 +566,7 @@ __global__ __launch_bounds__(MM_WIN_BLOCK) void k_spgemm_win(const MxmArgs a, co
         // ordered sweep of the window's presence words (MM_WIN/64 = 256 words: threads 0..255 take one each)
         unsigned long long b = (tid < MM_WIN / 64) ? s_bits[tid] : 0ull;
         const int c = __popcll(b);
-        int incl = c;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int t = __shfl_up(incl, off);
-            if (lane >= off) incl += t;
-        }
+        int incl = wave_inclusive_sum(c);
         if (lane == 63) s_wave[wv] = incl;
         __syncthreads();
         int wave_off = 0, total = 0;
@@ -759,13 +749,8 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const 
         // (A search-free dealing -- ranges of 16+ entries walked by the whole wavefront four at a time, shorter ones by their own
         //  lane -- measured 20 % SLOWER, 275 against 225 ms at scale 20: fewer products in flight per round trip.)
         auto process = [&](int64_t pc, int len, int64_t qb) {
-            int incl = len;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const int t = __shfl_up(incl, off);
-                if (lane >= off) incl += t;
-            }
-            const int total = __shfl(incl, 63);
+            const int incl = wave_inclusive_sum(len);
+            const int total = __builtin_amdgcn_readlane(incl, 63);
             if (total == 0 || MXM_ABL(a, 128)) return;  // (wave-uniform; timing switch 128: no products at all)
             scan[lane] = incl - len;
             sqb[lane] = qb - (incl - len);  // (product t of the batch is entry sqb[e] + t of B, e = the lane that brought it)
@@ -842,13 +827,8 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const 
         mine[x] = bits[lane * WPL + x];
         c += __popcll(mine[x]);
     }
-    int incl = c;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int t = __shfl_up(incl, off);
-        if (lane >= off) incl += t;
-    }
-    const int cnt = __shfl(incl, 63);
+    const int incl = wave_inclusive_sum(c);
+    const int cnt = __builtin_amdgcn_readlane(incl, 63);
     if constexpr (!NUMERIC) {
         if (lane == 0) a.wcnt[ridx * (nwin + 1) + w] = cnt;
         if (a.wbm) {
@@ -1063,12 +1043,7 @@ __global__ __launch_bounds__(MM_WIN_BLOCK) void k_spgemm_unit_dense(const MxmArg
     const int q4 = tid & 3;
     unsigned b16 = (unsigned)(word >> (16 * q4)) & 0xFFFFu;
     const int c = __popc(b16);
-    int incl = c;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int t = __shfl_up(incl, off);
-        if (lane >= off) incl += t;
-    }
+    int incl = wave_inclusive_sum(c);
     if (lane == 63) s_wave[wv] = incl;
     __syncthreads();
     int wave_off = 0;
@@ -1250,14 +1225,9 @@ __global__ __launch_bounds__(256) void k_window_offsets_hist(const int64_t *Bp, 
     for (int w0 = 0; w0 <= n_win; w0 += 64) {
         const int w = w0 + lane;
         const int cnt = w < n_win ? hist[w] : 0;
-        int incl = cnt;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int t = __shfl_up(incl, off);
-            if (lane >= off) incl += t;
-        }
+        int incl = wave_inclusive_sum(cnt);
         if (w <= n_win) o[w] = carry + incl - cnt;  // entries of the row before window w
-        carry += __shfl(incl, 63);
+        carry += __builtin_amdgcn_readlane(incl, 63);
         if (classify) {
             int cls = -1;
             if (cnt > 0) {
@@ -1315,14 +1285,9 @@ __global__ __launch_bounds__(256) void k_unit_prefix(int32_t *wcnt, int nwin, co
                 if (v <= L.lim[c]) cls = c;
         }
         for (int c = 0; c < MU_NCLS; c++) ccount[c] += (unsigned)__popcll(__ballot(cls == c));
-        int incl = v;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int t = __shfl_up(incl, off);
-            if (lane >= off) incl += t;
-        }
+        int incl = wave_inclusive_sum(v);
         if (b + lane < nwin) wc[b + lane] = carry + incl - v;
-        carry += __shfl(incl, 63);
+        carry += __builtin_amdgcn_readlane(incl, 63);
     }
     if (lane == 0) {
         wc[nwin] = carry;

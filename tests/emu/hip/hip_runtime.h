@@ -116,6 +116,37 @@ inline void __builtin_amdgcn_s_waitcnt(int) {}
 inline void __builtin_amdgcn_fence(int, const char *) {}
 inline void __builtin_amdgcn_wave_barrier() { emu::wave_exchange(0, -1, false, nullptr); }  // fibers of the wavefront rendezvous
 inline int __builtin_amdgcn_readfirstlane(int v) { return v; }  // callers pass wave-uniform values
+inline int __builtin_amdgcn_readlane(int v, int src_lane)  // (every lane of the wavefront calls, with the same lane number)
+{
+    uint64_t bits = 0;
+    memcpy(&bits, &v, sizeof(int));
+    const uint64_t r = emu::wave_exchange(bits, src_lane, false, nullptr);
+    int got;
+    memcpy(&got, &r, sizeof(int));
+    return got;
+}
+// DPP data movement inside a wavefront, the controls the kernels use: row_shr:n (0x110 + n: from lane - n of the same row of 16
+// lanes), row_bcast:15 (0x142: lane 15 of the previous row) and row_bcast:31 (0x143: lane 31, rows 2 and 3); a lane whose row is
+// not in row_mask, or whose source does not exist, keeps `old`
+inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int, bool)
+{
+    const int l = emu::lane_id(), row = l >> 4;
+    int from = -1;
+    if (ctrl >= 0x111 && ctrl <= 0x11f) {
+        const int n = ctrl - 0x110;
+        if ((l & 15) >= n) from = l - n;
+    } else if (ctrl == 0x142) {
+        if (row >= 1) from = row * 16 - 1;
+    } else if (ctrl == 0x143) {
+        if (row >= 2) from = 31;
+    }
+    uint64_t bits = 0;
+    memcpy(&bits, &src, sizeof(int));
+    const uint64_t r = emu::wave_exchange(bits, from >= 0 ? from : l, false, nullptr);  // (every lane takes part in the exchange)
+    int got;
+    memcpy(&got, &r, sizeof(int));
+    return (from >= 0 && ((row_mask >> row) & 1)) ? got : old;
+}
 // raw buffer loads: out-of-range offsets return 0 (per dword), like the hardware range check with stride 0
 struct __amdgpu_buffer_rsrc_t { const char *base; unsigned n; };
 inline __amdgpu_buffer_rsrc_t __builtin_amdgcn_make_buffer_rsrc(void *p, short, int n, int) { return {(const char *)p, (unsigned)n}; }
