@@ -104,6 +104,10 @@ __device__ __forceinline__ int wave_inclusive_sum(int v)
     return v;
 }
 
+// a load through a pointer that went through LDS: the compiler no longer knows it points to global memory and emits FLAT loads
+// (counted on both memory counters, waited for together with the LDS operations) -- say so
+__device__ __forceinline__ int load_global_i32(const int32_t *p) { return *(const __attribute__((address_space(1))) int32_t *)p; }
+
 __device__ __forceinline__ unsigned hash_col(int c, int table_mask) { return ((unsigned)c * 2654435761u) & (unsigned)table_mask; }
 
 // ---- step 1 helpers ---------------------------------------------------------------------------------------
@@ -620,6 +624,10 @@ __global__ __launch_bounds__(MM_WIN_BLOCK) void k_spgemm_win(const MxmArgs a, co
 #ifndef GRB_MU_M2_WPU
 #define GRB_MU_M2_WPU 4
 #endif
+#ifndef GRB_MU_SEG
+#define GRB_MU_SEG 2048
+#endif
+constexpr int MU_SEG = GRB_MU_SEG;  // products per segment of the rank dealing (a multiple of 64 MU_ILP, at most 4096)
 constexpr int MU_SYM_PLEN = 128;  // rows of A up to this long (the batches a wavefront keeps in registers) may share a symbolic unit between windows
 constexpr int MU_ILP = GRB_MU_ILP;  // products a lane has in flight
 constexpr int MU_SYMBOLIC = 0, MU_NUMERIC = 1, MU_MASKED = 2;  // what a unit kernel does
@@ -659,8 +667,15 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const 
     constexpr int NB = 2;  // batches of entries of A a wavefront keeps (range of B inside the window) from pass A for pass B
     __shared__ unsigned long long s_bits[UPB][WORDS];
     __shared__ int s_wpre[NUMERIC ? UPB : 1][NUMERIC ? WORDS : 1];
-    __shared__ int s_scan[WAVES][64];
-    __shared__ int64_t s_qb[WAVES][64];
+    // how a wavefront finds the entry of A a product belongs to: by rank in a bitmap of first product numbers, or -- the numeric
+    // one-wavefront class, measured 3 ms faster with it -- by binary search in the scan of the range lengths (round 2)
+    constexpr bool SEARCH_DEAL = NUMERIC && WPU == 1;
+    __shared__ unsigned long long s_recm[WAVES][SEARCH_DEAL ? 1 : MU_SEG / 64];
+    __shared__ short s_recb[WAVES][SEARCH_DEAL ? 1 : MU_SEG / 64];
+    __shared__ const int32_t *s_cptr[WAVES][SEARCH_DEAL ? 1 : 64];
+    __shared__ unsigned char s_clane[WAVES][SEARCH_DEAL ? 1 : 64];
+    __shared__ int s_scan[WAVES][SEARCH_DEAL ? 64 : 1];
+    __shared__ int64_t s_qb[WAVES][SEARCH_DEAL ? 64 : 1];
     __shared__ W s_acc[NUMERIC ? UPB : 1][NUMERIC ? CAP : 1];
     __shared__ unsigned long long s_hit[MASKED ? UPB : 1][MASKED ? (CAP + 63) / 64 : 1];  // (masked: which accumulators received a product)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -696,8 +711,13 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const 
         else __syncthreads();
     };
     unsigned long long *bits = s_bits[uib];
-    int *wpre = s_wpre[NUMERIC ? uib : 0], *scan = s_scan[wave];
+    int *wpre = s_wpre[NUMERIC ? uib : 0];
+    unsigned long long *recm = s_recm[wave];
+    short *recb = s_recb[wave];
+    int *scan = s_scan[wave];
     int64_t *sqb = s_qb[wave];
+    const int32_t **cptr = s_cptr[wave];
+    unsigned char *clane = s_clane[wave];
     W *acc = s_acc[NUMERIC ? uib : 0];
     const int monoid = a.monoid, mult = a.mult;
     const T *Ax = (const T *)a.Ax, *Bx = (const T *)a.Bx;
@@ -743,38 +763,97 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const 
     // every product of the row inside the window: d = load(p, q), then apply(d) -- MU_ILP products per lane at a time, their loads
     // issued before the first apply (the LDS atomics would otherwise serialise the global load latencies).  The wavefronts of
     // a unit take the entries of A 64 at a time.
+    const unsigned long long lane_le = (2ull << lane) - 1ull;  // bits 0 .. lane
+    int64_t pc_of_batch = 0;  // the entry of A lane 0 holds in the batch being dealt (for `load`: entry of A = this + lane WPU)
     auto visit = [&](auto &&load, auto &&apply) {
         // one batch: lane l holds the range [qb, qb + len) of B for the entry pc + l WPU of A; a wavefront scan of the lengths
         // numbers the products, and the lanes take them round-robin (binary search of the product number in the scan).
         // (A search-free dealing -- ranges of 16+ entries walked by the whole wavefront four at a time, shorter ones by their own
         //  lane -- measured 20 % SLOWER, 275 against 225 ms at scale 20: fewer products in flight per round trip.)
         auto process = [&](int64_t pc, int len, int64_t qb) {
+            constexpr int ILP = MU_ILP;
+            static_assert(MU_SEG % (64 * ILP) == 0 && MU_SEG / 64 <= 64 && (MU_SEG & (MU_SEG - 1)) == 0, "segments hold whole trips, one word per lane");
             const int incl = wave_inclusive_sum(len);
-            const int total = __builtin_amdgcn_readlane(incl, 63);
-            if (total == 0 || MXM_ABL(a, 128)) return;  // (wave-uniform; timing switch 128: no products at all)
-            scan[lane] = incl - len;
-            sqb[lane] = qb - (incl - len);  // (product t of the batch is entry sqb[e] + t of B, e = the lane that brought it)
-            mw_sync();
-            for (int t0 = lane; t0 < total; t0 += 64 * MU_ILP) {
-                // MU_ILP products per lane: their searches interleave and their loads are issued back to back -- every product
-                // number is clamped into the batch instead of being guarded by a branch (a guarded load was waited for inside its
-                // branch: one memory round trip per product instead of one per MU_ILP), and `load` only loads: whatever depends on
-                // the loaded values happens in `apply`
-                decltype(load((int64_t)0, (int64_t)0)) d[MU_ILP];
+            const int total = __builtin_amdgcn_readlane(incl, 63);  // (uniform: loop bounds stay scalar)
+            if (total == 0 || MXM_ABL(a, 128)) return;  // (timing switch 128: no products at all)
+            const int start = incl - len;  // the number of the entry's first product
+            pc_of_batch = pc;
+            if constexpr (SEARCH_DEAL) {
+                scan[lane] = start;
+                sqb[lane] = qb - start;  // (product t of the batch is entry sqb[e] + t of B, e = the lane that brought it)
+                mw_sync();
+                for (int t0 = lane; t0 < total; t0 += 64 * ILP) {
+                    // ILP products per lane: their searches interleave and their loads are issued back to back -- every product number
+                    // is clamped into the batch instead of being guarded by a branch (a guarded load is waited for inside its branch)
+                    decltype(load((const int32_t *)nullptr, 0u, 0)) d[ILP];
 #pragma unroll
-                for (int u = 0; u < MU_ILP; u++) {
-                    const int t = t0 + 64 * u < total ? t0 + 64 * u : total - 1;
-                    int lo = 0;  // the last entry whose first product number is <= t (scan[0] = 0 <= t): six steps, three VALU each
+                    for (int u = 0; u < ILP; u++) {
+                        const int t = t0 + 64 * u < total ? t0 + 64 * u : total - 1;
+                        int lo = 0;  // the last entry whose first product number is <= t (scan[0] = 0 <= t): six steps, three VALU each
 #pragma unroll
-                    for (int s = 32; s > 0; s >>= 1)
-                        if (scan[lo + s] <= t) lo += s;
-                    d[u] = load(pc + (int64_t)lo * WPU, sqb[lo] + t);
+                        for (int st = 32; st > 0; st >>= 1)
+                            if (scan[lo + st] <= t) lo += st;
+                        d[u] = load(a.Bj + sqb[lo], (unsigned)t, lo);
+                    }
+#pragma unroll
+                    for (int u = 0; u < ILP; u++)
+                        if (t0 + 64 * u < total) apply(d[u]);
                 }
-#pragma unroll
-                for (int u = 0; u < MU_ILP; u++)
-                    if (t0 + 64 * u < total) apply(d[u]);
+                mw_sync();
+                return;
             }
-            mw_sync();
+            // The owner of a product by RANK in a bitmap of the entries' first product numbers (the trick the unit's columns are
+            // ranked with).  Round 2 searched the product number in the scan: six dependent LDS reads and 18 vector instructions
+            // per product -- and the instruction counters of round 3 (profiles/r03/pmc_mxm_issue.txt) show what the units are
+            // bound by: ONE instruction of any kind per SIMD and 4 cycles (23.5 G instructions x 4 / (1024 SIMDs x 2.4 GHz) = 38 ms
+            // for a 37.8 ms symbolic pass), so the product loop is written for instruction count.  Per batch the non-empty entries
+            // are compacted (cptr[c] = where product 0 of the batch would sit in B's column array if the entry's range started
+            // there, clane[c] = the entry's lane); per segment of MU_SEG products every non-empty entry sets the bit of its first
+            // product number (one LDS atomic per ENTRY), a scan of the words' popcounts gives every word the rank of the last
+            // entry that starts before it; lane l of group g then takes product 64 g + l, which belongs to entry
+            // rec[g].b + popcount(rec[g].m up to bit l) of the compacted list: one 16-byte LDS read with an immediate offset, two
+            // ANDs, two popcounts, one pointer read, one 64-bit shift-add.
+            const unsigned long long have = __ballot(len > 0);
+            if (len > 0) {
+                const int c = __popcll(have & (lane_le >> 1));
+                cptr[c] = a.Bj + (qb - start);
+                clane[c] = (unsigned char)lane;
+            }
+            for (int seg0 = 0; seg0 < total; seg0 += MU_SEG) {
+                const int seg_n = total - seg0 < MU_SEG ? total - seg0 : MU_SEG;  // products of the segment
+                if (lane < MU_SEG / 64) recm[lane] = 0ull;
+                mw_sync();
+                const int rel = start - seg0;
+                if (len > 0 && rel >= 0 && rel < MU_SEG) atomicOr(&recm[rel >> 6], 1ull << (rel & 63));
+                mw_sync();
+                const int c = lane < MU_SEG / 64 ? __popcll(recm[lane]) : 0;
+                const int ci = wave_inclusive_sum(c);
+                const int before = __popcll(__ballot(len > 0 && rel < 0));  // entries that start before the segment
+                // (words past the segment's last group hold no bit and the rank of the batch's last entry: a group number needs no clamp)
+                if (lane < MU_SEG / 64) recb[lane] = (short)(before + ci - c - 1);
+                mw_sync();
+                // ILP groups per trip, their loads issued back to back: a product number past the batch is clamped to the last
+                // product instead of being guarded by a branch (a guarded load is waited for inside its branch); `load` only loads,
+                // whatever depends on the loaded values happens in `apply`, which is guarded.
+                const int g_n = (seg_n + 63) >> 6;
+                const unsigned long long *rpm = recm;
+                const short *rpb = recb;
+                unsigned t = (unsigned)(seg0 + lane);
+                const unsigned t_last = (unsigned)(total - 1);
+                for (int g0 = 0; g0 < g_n; g0 += ILP, rpm += ILP, rpb += ILP, t += 64 * ILP) {
+                    decltype(load((const int32_t *)nullptr, 0u, 0)) d[ILP];
+#pragma unroll
+                    for (int u = 0; u < ILP; u++) {
+                        const int rank = (int)rpb[u] + __popcll(rpm[u] & lane_le);
+                        const unsigned tu = t + 64u * u < t_last ? t + 64u * u : t_last;
+                        d[u] = load(cptr[rank], tu, rank);
+                    }
+#pragma unroll
+                    for (int u = 0; u < ILP; u++)
+                        if (t + 64u * u <= t_last) apply(d[u]);
+                }
+                mw_sync();
+            }
         };
         // wavefront s of the unit takes the entries s, s + WPU, s + 2 WPU, ... of the row (64 of them per batch): dealt in
         // blocks of 64, the first wavefront would own the smallest k -- on a graph numbered by degree, the hub rows of B
@@ -793,7 +872,7 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const 
     };
     // ---- pass A: which columns of the window does the row reach
     if (!MASKED && bslot < 0 && !(NUMERIC && MXM_ABL(a, 16)))
-        visit([&](int64_t, int64_t q) { return MXM_ABL(a, 256) ? c0 + (int)((q * 37) & (MM_WIN - 1)) : a.Bj[q]; },  // (256: no load of B)
+        visit([&](const int32_t *from, unsigned t, int) { return MXM_ABL(a, 256) ? c0 + (int)((t * 37u) & (MM_WIN - 1)) : load_global_i32(from + t); },  // (256: no load of B)
               [&](int jraw) {
                   if (MXM_ABL(a, 64)) return;  // (64: no bitmap atomics)
                   const int j = jraw - c0;
@@ -875,14 +954,14 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const 
             auto pass_b = [&](auto mu_c, auto mo_c) {
                 constexpr int MU = decltype(mu_c)::value, MO = decltype(mo_c)::value;
                 const int mult_ = MU >= 0 ? MU : mult, monoid_ = MO >= 0 ? MO : monoid;
-                auto load_b = [&](int64_t p, int64_t q) {
+                auto load_b = [&](const int32_t *from, unsigned t, int rank) {
                     Prod r;
-                    r.j = a.Bj[q];
+                    r.j = load_global_i32(from + t);
                     r.av = (T)0;
                     r.bv = (T)0;
                     if constexpr (MU != OP_PAIR) {
-                        if (a.need_a) r.av = a.a_iso ? a_iso_val : Ax[p];
-                        if (a.need_b) r.bv = a.b_iso ? b_iso_val : Bx[q];
+                        if (a.need_a) r.av = a.a_iso ? a_iso_val : Ax[pc_of_batch + (int64_t)(SEARCH_DEAL ? rank : (int)clane[rank]) * WPU];  // (search: the rank is the lane)
+                        if (a.need_b) r.bv = a.b_iso ? b_iso_val : Bx[(from - a.Bj) + (int64_t)t];
                     }
                     return r;
                 };
