@@ -126,7 +126,8 @@ inline int __builtin_amdgcn_readlane(int v, int src_lane)  // (every lane of the
     return got;
 }
 // DPP data movement inside a wavefront, the controls the kernels use: row_shr:n (0x110 + n: from lane - n of the same row of 16
-// lanes), row_bcast:15 (0x142: lane 15 of the previous row) and row_bcast:31 (0x143: lane 31, rows 2 and 3); a lane whose row is
+// lanes), wave_shr:1 (0x138: from lane - 1, across the rows), row_bcast:15 (0x142: lane 15 of the previous row) and row_bcast:31
+// (0x143: lane 31, rows 2 and 3); a lane whose row is
 // not in row_mask, or whose source does not exist, keeps `old`
 inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int, bool)
 {
@@ -135,6 +136,8 @@ inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask,
     if (ctrl >= 0x111 && ctrl <= 0x11f) {
         const int n = ctrl - 0x110;
         if ((l & 15) >= n) from = l - n;
+    } else if (ctrl == 0x138) {  // wave_shr:1
+        if (l >= 1) from = l - 1;
     } else if (ctrl == 0x142) {
         if (row >= 1) from = row * 16 - 1;
     } else if (ctrl == 0x143) {
