@@ -1004,20 +1004,40 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const 
         if constexpr (MASKED) return;
         // ---- columns, in order: the wavefronts of the unit share the (lane, word) pairs -- every wavefront holds all of them
         constexpr int LSPLIT = WPU > WPL ? WPU / WPL : 1;  // wavefronts per word index
+        // A lane turns its words into column numbers one bit at a time; written straight to T every store instruction of the
+        // wavefront touched 64 different cache lines (each lane its own run).  The numbers go through LDS instead -- the
+        // accumulators are free by now -- and leave as consecutive dwords: 256 bytes per store instruction.  (A unit with more
+        // columns than accumulators -- class limits set by hand -- keeps the direct stores.)
+        const bool staged = cnt <= CAP * (int)(sizeof(W) / sizeof(int));
+        int *cols = (int *)acc;
         int pre = incl - c;
 #pragma unroll
         for (int x = 0; x < WPL; x++) {
             unsigned long long b = mine[x];
             const bool take = WPU == 1 || (WPU <= WPL ? (x % WPU == sub) : (x == sub % WPL && lane % LSPLIT == sub / WPL));
             if (take && !MXM_ABL(a, 1)) {
-                int64_t o = out + pre;
-                while (b) {
-                    const int t = __ffsll(b) - 1;
-                    b &= b - 1;
-                    a.Tj[o++] = c0 + (lane * WPL + x) * 64 + t;
+                const int cbase = c0 + (lane * WPL + x) * 64;
+                if (staged) {
+                    int o = pre;
+                    while (b) {
+                        const int t = __ffsll(b) - 1;
+                        b &= b - 1;
+                        cols[o++] = cbase + t;
+                    }
+                } else {
+                    int64_t o = out + pre;
+                    while (b) {
+                        const int t = __ffsll(b) - 1;
+                        b &= b - 1;
+                        a.Tj[o++] = cbase + t;
+                    }
                 }
             }
             pre += __popcll(mine[x]);
+        }
+        if (staged && !MXM_ABL(a, 1)) {
+            usync();
+            for (int i = tiu; i < cnt; i += 64 * WPU) a.Tj[out + i] = cols[i];
         }
     }
     if constexpr (NUMERIC) break;
