@@ -1520,7 +1520,7 @@ def test_mxm_units_random(gb, seed, request=None):
 
 
 @pytest.mark.parametrize("seed", range(28))
-def test_mxm_complemented_mask_fused(gb, seed, request=None):
+def test_mxm_complemented_mask_fused(gb, seed, request):
     """C<!M> = A (+.x) B with the complemented mask fused into the product (the forbidden positions never enter T): rows of
     every size class -- LDS hash tables (forbidden columns pre-inserted), (row, column window) units of every class with and
     without kept bitmaps, the dense unit, the 1024-thread window walk --, structural and valued masks whose entries cover a large
@@ -1528,7 +1528,7 @@ def test_mxm_complemented_mask_fused(gb, seed, request=None):
     replace.  Checked against the oracle, and against the unfused path (full product + write rule) of the library itself."""
     from graphblas_amd import _lib, device
 
-    on_gpu = request is None or request.node.callspec.params["gb"] == "gpu"
+    on_gpu = request.node.callspec.params["gb"] == "gpu"
     if not on_gpu and seed >= 20:
         pytest.skip("the emulator tier runs the first 20 cases (a few seconds each); the GPU tier runs all")
     rng = np.random.default_rng(9900 + seed)
