@@ -231,6 +231,8 @@ class MxvWorkload:
                 wv.copy_(self._dist[self.lo:self.hi])
                 self.step()
                 torch.cuda.synchronize()
+                # (the call may keep w in the matrix's vertex order between calls: the views are fetched again -- that brings it back)
+                wv, wb = device.vector_device_views(self.w)
             got_has = self._bits(wb, self.m)
             if self.semiring == "min_plus":
                 d0 = self._dist[self.lo:self.hi]

@@ -240,8 +240,13 @@ GrB_Info GrX_Matrix_export_CSR_device(const int64_t **d_Ap, const int32_t **d_Aj
  * (bit i of 32-bit word i>>5), NULL meaning "all n entries present".  Always copies. */
 GrB_Info GrX_Vector_import_dense_device(GrB_Vector *v, GrB_Type type, GrB_Index n, const void *d_val,
                                         const uint32_t *d_present);
-/* Borrow the device image of v (valid until v is modified or freed). *d_present has ceil(n/64)*2 words. */
+/* Borrow the device image of v (the pointers stay valid until v is resized, cleared or freed). *d_present has ceil(n/64)*2 words.
+ * The image is in natural index order when the call returns; a later product with a large square matrix may leave v in that
+ * matrix's vertex order (section "vertex order" below): export again after such a call, or pin the vector. */
 GrB_Info GrX_Vector_export_dense_device(const void **d_val, const uint32_t **d_present, const GrB_Vector v);
+/* pinned != 0: v is never left in another than the natural index order (its image is aliased outside the library for longer than
+ * one call: RCCL buffers, torch views); products that involve it run on the natural-order layouts. */
+GrB_Info GrX_Vector_pin_natural(GrB_Vector v, int pinned);
 /* Tell the library that the caller wrote into the image returned by GrX_Vector_export_dense_device
  * (e.g. an RCCL all-gather landed there): the cached entry count is dropped. */
 GrB_Info GrX_Vector_modified(GrB_Vector v);
@@ -268,7 +273,8 @@ typedef struct {
     int64_t long_entries;     /* mxv/vxm over a split matrix: entries held by the long rows (0 = no split) */
     int64_t long_segments;    /* ... as class strips: (class, sub-range, row) segments = atomics of an unmasked call */
     int32_t long_kernel;      /* ... long-row kernel that ran: 0 chunks, 1 class items, 2 mixed class strips, 4 hot / cold strips; -1 = no split */
-    int32_t reserved_;
+    int32_t reorders;         /* vectors this call converted between vertex orders (0 in the steady state of a loop) */
+    int64_t ordered;          /* 1: the product ran on the matrix's popularity-ordered layouts with operands kept in that order */
 } GrX_Stats;
 GrB_Info GrX_last_stats(GrX_Stats *stats);
 /* T = A (+.x) B in row batches of A whose products fit `budget_bytes` of device memory; every batch runs the full two-pass
@@ -296,6 +302,11 @@ GrB_Info GrX_Matrix_cache_bytes(const GrB_Matrix A, uint64_t *bytes);
  *   "pull_ipt"      merge items per thread of the pull SpMV (0 = default)
  *   "hot_min_cols"  matrices with at least this many columns get a hot-column table for the pull SpMV
  *   "hot_k"         entries of that table (0 = sized to ~2 MiB of x values)
+ *   "order_mode"    1 (default): square matrices with at least "order_min_nnz" (48 Mi) entries get their pull layouts in a vertex
+ *                   order of their own -- vertices by falling column count -- and the vectors they are multiplied with are KEPT in
+ *                   that order between calls (converted on first use, converted back by every entry point that is not element-wise:
+ *                   build / extractTuples / export / indexed assign and extract / a product with another matrix); results are the
+ *                   ones of the natural order, element for element.  0: never.  GrX_Stats.ordered / .reorders report it per call.
  *   "split_min_nnz" matrices with at least this many entries get the long/short row split of the pull SpMV
  *   "split_min_len" a row is "long" from this many entries (default 0 = 64 for the class strips, 256 for the item kernel)
  *   "lazy_layout"   1 (default): the cached SpMV layouts of a matrix with at least "lazy_min_nnz" (4 Mi) entries are built at its

@@ -32,7 +32,7 @@ class GrX_Stats(ctypes.Structure):
     _fields_ = [("kernel_launches", ctypes.c_int64), ("tiles", ctypes.c_int64), ("flops", ctypes.c_int64),
                 ("out_nvals", ctypes.c_int64), ("method", ctypes.c_int32), ("fused_epilogue", ctypes.c_int32),
                 ("hot_k", ctypes.c_int64), ("long_entries", ctypes.c_int64), ("long_segments", ctypes.c_int64),
-                ("long_kernel", ctypes.c_int32), ("reserved_", ctypes.c_int32)]
+                ("long_kernel", ctypes.c_int32), ("reorders", ctypes.c_int32), ("ordered", ctypes.c_int64)]
 
 
 def load(path: str | None = None):
@@ -128,6 +128,7 @@ def _declare(L):
     L.GrX_Vector_import_dense_device.argtypes = [P(c_void_p), c_void_p, c_u64, c_void_p, c_void_p]
     L.GrX_Vector_export_dense_device.argtypes = [P(c_void_p), P(c_void_p), c_void_p]
     L.GrX_Vector_modified.argtypes = [c_void_p]
+    L.GrX_Vector_pin_natural.argtypes = [c_void_p, ctypes.c_int]
     L.GrB_Vector_assign.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_u64, c_void_p]
     L.GrB_Vector_extract.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_u64, c_void_p]
     L.GrX_option_set.argtypes = [ctypes.c_char_p, ctypes.c_int64]

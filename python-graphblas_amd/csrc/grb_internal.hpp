@@ -106,6 +106,10 @@ struct Context {
     int lazy_layout = 1;             // 1: the SpMV layouts of a large matrix are built at its SECOND pull product, not its first
     int64_t lazy_min_nnz = 1 << 22;  // ... for matrices with at least this many entries (smaller ones build at once)
     int push_mode = 1;               // 0 never push, 1 push when u has < n/64 entries, 2 always push (tests)
+    int order_mode = 1;              // 1: large square matrices get popularity-ordered pull layouts and keep their operands in that order
+                                     // (grb_mxv_order.inc); 0: never
+    int64_t order_min_nnz = 48ll << 20;  // ... from this many entries (the layouts that profit are the ones of lean_min_nnz)
+    int64_t reorder_count = 0;       // vectors converted between vertex orders so far (cumulative)
 };
 Context &ctx();
 void require_init();
@@ -193,6 +197,19 @@ struct GB_Descriptor_opaque {
     bool builtin;
 };
 
+// A vertex order: the permutation a large square matrix's pull layouts are built in -- vertices by falling
+// column count, so that a 128-byte line of an operand holds 32 columns of about the same popularity and the hot columns are the
+// first K positions -- shared, by reference count, with the vectors that are kept in that order between calls.  Position p of an
+// ordered vector holds the element with natural index d_inv[p]; d_rank is the inverse map.
+struct GB_Perm {
+    int64_t refs = 1;
+    uint64_t n = 0;
+    int32_t *d_rank = nullptr;  // natural index -> position
+    int32_t *d_inv = nullptr;   // position -> natural index
+    int64_t n_live_rows = 0;    // positions >= this hold vertices whose ROW of the matrix the order was built from is empty
+    int64_t n_live_cols = 0;    // positions >= this hold vertices that (by the sampled histogram) no entry of that matrix refers to
+};
+
 constexpr size_t VEC_VAL_PAD = (size_t)8 << 20;    // the default hot-column table is 2 MiB of values ...
 constexpr size_t VEC_BITS_PAD = (size_t)256 << 10;  // ... and at most 2 Mi presence bits (1-byte types)
 
@@ -205,6 +222,11 @@ struct GB_Vector_opaque {
     bool padded;       // the allocations start VEC_VAL_PAD / VEC_BITS_PAD bytes before d_val / d_bits: the pull SpMV
                        // writes its hot-column table there, so that [table | values] is one image without a copy
     int64_t nvals;     // -1 = unknown (counted on demand)
+    GB_Perm *order = nullptr;  // nullptr: natural order; else the elements are stored in this vertex order (a reference is held).
+                               // Every entry point takes vectors in natural order (check_vector converts) except the ones that are
+                               // order-aware: mxv / vxm on the matrix the order belongs to, the element-wise operations, reduce, dup,
+                               // element access.  An ordered vector without entries is converted for free.
+    bool pinned = false;       // never leave this vector in another than the natural order (its HBM image is aliased outside the library)
     std::string err;
 };
 
@@ -294,6 +316,19 @@ struct GB_Matrix_opaque {
     int64_t tg_units = 0;
     int tg_state = 0;
     bool short_tagged_only = false;    // the short part keeps its row pointers only: its entries live in the tagged row groups
+    // ---- vertex order (round 4; grb_mxv_order.inc): a large square matrix is laid out a second time as ord = P A P' for a permutation P
+    //      by falling column count (perm); the pull kernels run on `ord` with operands kept in that order.  `ord` is a matrix object of its
+    //      own whose column indices ARE the hot codes (hot_identity): the first hot_k positions are the hot table, no image is built
+    GB_Perm *perm = nullptr;           // the order of this matrix's vertex space (shared with its transpose and with vectors)
+    GB_Matrix_opaque *ord = nullptr;   // the matrix in that order (owned): layouts only -- its CSR arrays are released once they are built
+    GB_Matrix_opaque *tr_of = nullptr; // this matrix is the cached transpose of tr_of (not owned)
+    int ord_state = 0;                 // 0 = not analysed, 1 = `ord` is built, -1 = not worth it / not possible
+    uint64_t ord_sig = 0;              // the layout options `ord` was built under
+    bool hot_identity = false;         // (an `ord` twin) d_col_hot aliases d_col: codes are positions; codes >= hot_k are not offset by hot_k
+    int32_t *d_cold_bounds = nullptr;  // (an `ord` twin) first code of every column range of the cold tiles (ct_ncr + 1 values)
+    int32_t *d_ct_order = nullptr;     // (cold tiles) tile numbers in the order the XCDs walk them: XCD x takes d_ct_order[ct_xoff[x] .. ct_xoff[x + 1])
+    int64_t ct_xoff[9] = {0};
+    int64_t ct_ntiles = 0;
     int64_t n_long, n_chunks;
     int split_state;          // 0 = not analysed, 1 = enabled, -1 = not worth it
     bool split_hot;           // short_part's columns are hot-coded
@@ -304,11 +339,19 @@ namespace grb {
 
 GrB_Type type_of_code(int code);
 
-inline void check_vector(const GB_Vector_opaque *v, const char *what)
+void vector_set_order(GB_Vector_opaque *v, GB_Perm *order);     // converts v (in place: its device pointers stay) into `order` (nullptr = natural)
+// validity only: for the entry points that work in whatever vertex order the vector is stored in
+inline void check_vector_any(const GB_Vector_opaque *v, const char *what)
 {
     if (!v) fail(GrB_NULL_POINTER, std::string(what) + " is NULL");
     if (v->magic != MAGIC_VECTOR)
         fail(v->magic == MAGIC_FREED ? GrB_UNINITIALIZED_OBJECT : GrB_INVALID_OBJECT, std::string(what) + " is not a valid GrB_Vector");
+}
+// ... and the default: the vector is brought back to the natural order first
+inline void check_vector(const GB_Vector_opaque *v, const char *what)
+{
+    check_vector_any(v, what);
+    if (v->order) vector_set_order(const_cast<GB_Vector_opaque *>(v), nullptr);
 }
 inline void check_matrix(const GB_Matrix_opaque *A, const char *what)
 {
@@ -321,6 +364,12 @@ inline std::string *errp(GB_Vector_opaque *v) { return (v && v->magic == MAGIC_V
 inline std::string *errp(GB_Matrix_opaque *A) { return (A && A->magic == MAGIC_MATRIX) ? &A->err : nullptr; }
 
 // ---- object services implemented in grb_object.hip --------------------------------------------------
+void perm_retain(GB_Perm *p);
+void perm_release(GB_Perm *p);                                  // frees the maps with the last reference
+// one order for the operands of an element-wise operation: the first order found on a vector that holds entries (natural if one of them
+// is pinned); every vector is converted to it (vectors without entries for free)
+GB_Perm *vectors_common_order(GB_Vector_opaque *const *vs, int count);
+uint64_t vector_position(GB_Vector_opaque *v, uint64_t i);      // where element i of v is stored (i itself in natural order)
 void vector_ensure_storage(GB_Vector_opaque *v);               // allocate zeroed values+bits if absent
 void vector_release_storage(GB_Vector_opaque *v);              // free buffers, nvals = 0
 void vector_alloc_pair(const GB_Vector_opaque *v, bool padded, bool zero_val, void **val, uint64_t **bits);  // presence zeroed

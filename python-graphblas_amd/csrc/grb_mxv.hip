@@ -45,16 +45,14 @@ namespace grb {
 #include "grb_mxv_write.inc"
 #include "grb_mxv_push.inc"
 #include "grb_mxv_hot.inc"
+#include "grb_mxv_order.inc"
 
 // ---------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------
-static void ensure_hot(GB_Matrix_opaque *A, size_t value_bytes)
+// entries of the hot-column table of a matrix with n columns whose operands have value_bytes per element (0: no table)
+static int64_t hot_table_size(int64_t n, size_t value_bytes)
 {
-    if (A->hot_state != 0) return;
-    A->hot_state = -1;
-    const int64_t n = (int64_t)A->ncols, nnz = A->nvals;
-    if (n < ctx().hot_min_cols || nnz == 0 || n + (int64_t)(1 << 22) > 0x7fffffff) return;
     int64_t k = ctx().hot_k > 0 ? ctx().hot_k : (int64_t)((2u << 20) / (value_bytes ? value_bytes : 1));
     // (the class strips keep the hottest codes of every class in LDS: the table has to hold at least those)
     if (ctx().hot_k <= 0 && value_bytes > 1 && ctx().long_kernel >= 2) {
@@ -63,6 +61,16 @@ static void ensure_hot(GB_Matrix_opaque *A, size_t value_bytes)
     }
     k = std::min<int64_t>(k, n / 4);
     k &= ~(int64_t)63;
+    return k < 64 ? 0 : k;
+}
+
+static void ensure_hot(GB_Matrix_opaque *A, size_t value_bytes)
+{
+    if (A->hot_state != 0) return;
+    A->hot_state = -1;
+    const int64_t n = (int64_t)A->ncols, nnz = A->nvals;
+    if (n < ctx().hot_min_cols || nnz == 0 || n + (int64_t)(1 << 22) > 0x7fffffff) return;
+    const int64_t k = hot_table_size(n, value_bytes);
     if (k < 64) return;
     DevBuf<unsigned int> cnt(n, true);
     const int hstride = nnz >= ((int64_t)1 << 26) ? 8 : 1;
@@ -95,6 +103,7 @@ static void ensure_hot(GB_Matrix_opaque *A, size_t value_bytes)
 // split in the hot coding (another long-row kernel or class count was selected) needs it again: re-code from the hot-column list.
 static void restore_hot_cols(GB_Matrix_opaque *A)
 {
+    if (A->hot_identity) fail(GrB_PANIC, "pull SpMV: an ordered layout cannot be rebuilt in place (internal error)");
     if (A->d_col_hot || A->hot_state != 1 || !A->d_hot_cols) return;
     const int64_t n = (int64_t)A->ncols, nnz = A->nvals;
     DevBuf<int32_t> rank(n);
@@ -182,8 +191,8 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
         A->d_tg_off = nullptr; A->d_tg_col = nullptr; A->d_tg_val = nullptr; A->d_tg_tag = nullptr; A->d_tg_nonempty = nullptr; A->tg_state = 0;
         dev_free(A->d_sstart); dev_free(A->d_sslot); dev_free(A->d_hrec);
         A->d_sstart = nullptr; A->d_sslot = nullptr; A->d_hrec = nullptr; A->strip_nseg = 0;
-        dev_free(A->d_ct_col); dev_free(A->d_ct_val); dev_free(A->d_ct_loc); dev_free(A->d_ct_tiles);
-        A->d_ct_col = nullptr; A->d_ct_val = nullptr; A->d_ct_loc = nullptr; A->d_ct_tiles = nullptr; A->ct_units = 0;
+        dev_free(A->d_ct_col); dev_free(A->d_ct_val); dev_free(A->d_ct_loc); dev_free(A->d_ct_tiles); dev_free(A->d_ct_order);
+        A->d_ct_col = nullptr; A->d_ct_val = nullptr; A->d_ct_loc = nullptr; A->d_ct_tiles = nullptr; A->d_ct_order = nullptr; A->ct_units = 0; A->ct_ntiles = 0;
         A->d_lcol = nullptr; A->d_lval = nullptr; A->d_it_start = nullptr; A->d_it_len = nullptr; A->d_it_slot = nullptr;
         A->d_item_begin = nullptr; A->long_nnz = 0; A->n_items = 0;
         A->d_long_prefix = nullptr;
@@ -244,7 +253,7 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
             // hot / cold strips: the codes that are LDS-resident in their class, and the contiguous column ranges of the others
             const int COLD_CLS = 8;
             const int64_t lds_lim4 = std::min<int64_t>(hot ? A->hot_k : 0, long_lds_codes((int)A->type->size, A->type->code == TC_BOOL, LONG_LDS_WORDS) / 8 * ncls);
-            const int64_t codes_total = (int64_t)A->ncols + (hot ? A->hot_k : 0);
+            const int64_t codes_total = (int64_t)A->ncols + ((hot && !A->hot_identity) ? A->hot_k : 0);
             // (kind 4: the cold entries go to tagged tiles of 8 * `sub` column ranges of ~3 MiB of the operand image each, every row cut)
             const int range_cls = kind == 4 ? COLD_CLS : ncls;
             unsigned sub = 1;
@@ -259,20 +268,23 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
             while (((int64_t)1 << bits) < nv) bits++;
             DevBuf<uint64_t> keys(nnz_long), keys2(nnz_long);
             DevBuf<uint32_t> idx(nnz_long), idx2(nnz_long);
+            // (a matrix in its popularity order carries its own column ranges: about equal reference counts, at most ~2 MiB of operand)
+            const bool own_ranges = kind == 4 && A->hot_identity && A->d_cold_bounds && A->ct_ncr > 0;
             if (kind == 4)
                 hipLaunchKernelGGL(k_long_keys, dim3((unsigned)nl), dim3(256), 0, ctx().stream, (const int64_t *)A->d_ptr,
                                    (const int64_t *)S->d_ptr, (const int32_t *)A->d_long_rows, col_src, nl, keys.p, idx.p,
                                    (unsigned)lds_lim4, (unsigned)std::max<int64_t>(1, ceil_div(codes_total - std::max<int64_t>(lds_lim4, hot ? A->hot_k : 0), (int64_t)COLD_CLS * (int64_t)sub)),
-                                   sub, sub_min_len, (unsigned)ncls, 2, (unsigned)(hot ? A->hot_k : 0));
+                                   sub, sub_min_len, (unsigned)ncls, 2, (unsigned)(hot ? A->hot_k : 0),
+                                   own_ranges ? (const int32_t *)A->d_cold_bounds : (const int32_t *)nullptr, own_ranges ? A->ct_ncr + 1 : 0);
             else
             hipLaunchKernelGGL(k_long_keys, dim3((unsigned)nl), dim3(256), 0, ctx().stream, (const int64_t *)A->d_ptr,
                                (const int64_t *)S->d_ptr, (const int32_t *)A->d_long_rows, col_src, nl, keys.p, idx.p,
                                (unsigned)(hot ? A->hot_k : 0), (unsigned)std::max<int64_t>(1, ceil_div((int64_t)A->ncols, (int64_t)ncls * (int64_t)sub)),
-                               sub, sub_min_len, (unsigned)ncls, kind == 2 ? 1 : 0, 0u);
+                               sub, sub_min_len, (unsigned)ncls, kind == 2 ? 1 : 0, 0u, (const int32_t *)nullptr, 0);
             // (virtual classes: kind 2 ncls * sub; kind 4 ncls hot classes + COLD_CLS cold ranges, with `sub` = 1 in the segment tables)
             const int nvc = ncls;                                                       // classes of the strips (chunk ranges)
-            const int nvirt = kind == 4 ? ncls + COLD_CLS * (int)sub : ncls * (int)sub;  // virtual classes (sort keys)
-            const int n_cr = COLD_CLS * (int)sub;                                       // kind 4: column ranges of the cold tiles
+            const int n_cr = own_ranges ? A->ct_ncr : COLD_CLS * (int)sub;             // kind 4: column ranges of the cold tiles
+            const int nvirt = kind == 4 ? ncls + n_cr : ncls * (int)sub;                // virtual classes (sort keys)
             const int hot_cls = 0;
             const unsigned strip_sub = kind == 4 ? 1u : sub;                            // virtual classes per strip class
             if (strips) {
@@ -390,19 +402,68 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
                 }
             }
             if (kind == 4 && nnz_long > n_strip) {
-                // the cold entries as tagged tiles: per tile its entries padded to a multiple of 4, in (column range, row) order
-                std::vector<CTile> h_tiles((size_t)n_tiles);
+                // the cold entries as tagged tiles: a (column range, slot block) pair is one tile, or several when it holds more than
+                // CT_MAX_ENTRIES entries (the hub rows: the sorted run is cut into equal pieces -- a piece still lies inside the
+                // pair's 4096 slots); per tile its entries padded to a multiple of 4, in (column range, row) order
+                std::vector<CTile> h_tiles;
+                std::vector<int64_t> h_efirst;
+                std::vector<int> tile_range;
+                std::vector<int64_t> range_cnt((size_t)n_cr, 0);
                 int64_t units = 0;
                 for (int64_t t = 0; t < n_tiles; t++) {
                     const int64_t cnt = h_first[t + 1] - h_first[t];
-                    h_tiles[t].u0 = units;
-                    h_tiles[t].n_units = (int32_t)ceil_div(cnt, (int64_t)CT_EPL);
-                    h_tiles[t].base = (int32_t)((t % n_sb) * (int64_t)CT_SLOTS);
-                    units += h_tiles[t].n_units;
+                    if (cnt == 0) continue;
+                    const int64_t pieces = ceil_div(cnt, CT_MAX_ENTRIES), per = ceil_div(cnt, pieces);
+                    for (int64_t q = 0; q < pieces; q++) {
+                        const int64_t e0 = h_first[t] + q * per, e1 = std::min<int64_t>(h_first[t] + (q + 1) * per, h_first[t + 1]);
+                        CTile ct;
+                        ct.u0 = units;
+                        ct.n_units = (int32_t)ceil_div(e1 - e0, (int64_t)CT_EPL);
+                        ct.base = (int32_t)((t % n_sb) * (int64_t)CT_SLOTS);
+                        units += ct.n_units;
+                        h_tiles.push_back(ct);
+                        h_efirst.push_back(e0);
+                        tile_range.push_back((int)(t / n_sb));
+                    }
+                    range_cnt[(size_t)(t / n_sb)] += cnt;
                 }
+                const int64_t nt = (int64_t)h_tiles.size();
+                h_efirst.push_back(nnz_long);
+                // column ranges to XCDs: round-robin (the natural order's equal-width ranges), or -- ranges of a popularity order,
+                // whose counts differ -- the largest remaining range to the XCD with the least work; an XCD walks its ranges one after
+                // the other, so its 32 CUs gather from ONE range at a time and it stays in their L2
+                std::vector<int> range_xcd((size_t)n_cr);
+                if (own_ranges) {
+                    std::vector<int> by_cnt((size_t)n_cr);
+                    for (int r = 0; r < n_cr; r++) by_cnt[(size_t)r] = r;
+                    std::stable_sort(by_cnt.begin(), by_cnt.end(), [&](int x, int y) { return range_cnt[(size_t)x] > range_cnt[(size_t)y]; });
+                    int64_t load[8] = {0};
+                    for (int r : by_cnt) {
+                        int best = 0;
+                        for (int x = 1; x < 8; x++)
+                            if (load[x] < load[best]) best = x;
+                        range_xcd[(size_t)r] = best;
+                        load[best] += range_cnt[(size_t)r];
+                    }
+                } else {
+                    for (int r = 0; r < n_cr; r++) range_xcd[(size_t)r] = r % 8;
+                }
+                std::vector<int32_t> h_order;
+                h_order.reserve((size_t)nt);
+                for (int x = 0; x < 8; x++) {
+                    A->ct_xoff[x] = (int64_t)h_order.size();
+                    for (int64_t t = 0; t < nt; t++)
+                        if (range_xcd[(size_t)tile_range[(size_t)t]] == x) h_order.push_back((int32_t)t);
+                }
+                A->ct_xoff[8] = (int64_t)h_order.size();
                 const size_t ents = (size_t)std::max<int64_t>(units, 1) * CT_EPL;
-                A->d_ct_tiles = dev_alloc(sizeof(CTile) * (size_t)n_tiles);
-                h2d(A->d_ct_tiles, h_tiles.data(), sizeof(CTile) * (size_t)n_tiles);
+                A->d_ct_tiles = dev_alloc(sizeof(CTile) * (size_t)std::max<int64_t>(nt, 1));
+                h2d(A->d_ct_tiles, h_tiles.data(), sizeof(CTile) * (size_t)nt);
+                dev_free(A->d_ct_order);
+                A->d_ct_order = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)std::max<int64_t>(nt, 1));
+                h2d(A->d_ct_order, h_order.data(), sizeof(int32_t) * (size_t)nt);
+                DevBuf<int64_t> efirst(nt + 1);
+                h2d(efirst.p, h_efirst.data(), sizeof(int64_t) * (size_t)(nt + 1));
                 A->d_ct_col = (int32_t *)dev_alloc(sizeof(int32_t) * ents);
                 A->d_ct_val = A->iso ? nullptr : dev_alloc(A->type->size * ents);
                 A->d_ct_loc = (uint16_t *)dev_alloc(sizeof(uint16_t) * ents);
@@ -412,12 +473,18 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
                 const int64_t n_cold = nnz_long - n_strip;
                 GRB_DISPATCH_TYPE(A->type->code, T, {
                     hipLaunchKernelGGL((k_ctile_place<T>), dim3((unsigned)ceil_div(n_cold, 256)), dim3(256), 0, ctx().stream, (const uint64_t *)keys2.p,
-                                       (const uint32_t *)idx2.p, n_strip, nnz_long, (const int64_t *)tile_first.p, (const CTile *)A->d_ct_tiles, n_sb,
-                                       (unsigned)ncls, col_src, (const T *)A->d_val, A->iso ? 1 : 0, A->d_ct_col, (T *)A->d_ct_val, A->d_ct_loc);
+                                       (const uint32_t *)idx2.p, n_strip, nnz_long, (const int64_t *)efirst.p, nt, (const CTile *)A->d_ct_tiles,
+                                       col_src, (const T *)A->d_val, A->iso ? 1 : 0, A->d_ct_col, (T *)A->d_ct_val, A->d_ct_loc);
                 })
                 A->ct_nsb = n_sb;
                 A->ct_ncr = n_cr;
+                A->ct_ntiles = nt;
                 A->ct_units = units;
+                if (getenv("GRB_PRINT_STRIPS")) {
+                    fprintf(stderr, "[cold tiles] %d column ranges, %lld tiles, entries per range:", n_cr, (long long)nt);
+                    for (int r = 0; r < n_cr; r++) fprintf(stderr, " %lld(x%d)", (long long)range_cnt[(size_t)r], range_xcd[(size_t)r]);
+                    fprintf(stderr, "\n");
+                }
                 sync_stream();
             }
             DevBuf<int64_t> vptr(strips ? 0 : nv + 1), icnt(strips ? 0 : nv + 1);
@@ -498,8 +565,183 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
     if (hot && ctx().drop_hot_cols && nc > 0 && A->long_nnz > 0 && (kind == 1 || kind == 2 || kind == 4) && A->d_col_hot) {
         dev_free(A->d_col_hot);
         A->d_col_hot = nullptr;
+        if (A->hot_identity) A->d_col = nullptr;  // (the same array)
         A->hot_cols_dropped = true;
     }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// popularity-ordered layouts (grb_mxv_order.inc)
+// ---------------------------------------------------------------------------------------------------
+// the layout options an ordered twin depends on: a change rebuilds it from the matrix (its own CSR arrays are gone by then)
+static uint64_t order_signature()
+{
+    const Context &c = ctx();
+    uint64_t h = 1469598103934665603ull;
+    const int64_t v[] = {c.long_kernel, c.short_kernel, c.long_classes, c.split_min_len, c.long_sub, c.long_sub_min_len, c.lean_min_nnz,
+                         c.split_min_nnz, c.hot_k, c.drop_hot_cols};
+    for (int64_t x : v) h = (h ^ (uint64_t)x) * 1099511628211ull;
+    return h;
+}
+
+// The vertex order of S's space: its own, or the one its transpose partner already has (both directions of a square matrix share
+// one order, so a vector never has to change between A and A').  Built from S: vertices by falling column count (sampled like the
+// hot table's histogram), ties by falling row length; the first HOT_MIX ranks are dealt over the lines of the hot table.
+static GB_Perm *ensure_perm(GB_Matrix_opaque *S, int64_t k_hot, DevBuf<unsigned int> &poscnt)
+{
+    const int64_t n = (int64_t)S->ncols, nnz = S->nvals;
+    GB_Matrix_opaque *partner = S->tr ? S->tr : S->tr_of;
+    const bool adopt = !S->perm && partner && partner->perm;
+    if (adopt) {
+        S->perm = partner->perm;
+        perm_retain(S->perm);
+    }
+    // (the reference counts by position steer the column ranges of the cold tiles: needed with an adopted order as well)
+    DevBuf<unsigned int> cnt(n, true);
+    const int hstride = nnz >= ((int64_t)1 << 26) ? 8 : 1;
+    hipLaunchKernelGGL(k_hot_hist, dim3((unsigned)ceil_div(nnz, 256 * hstride)), dim3(256), 0, ctx().stream, S->d_col, nnz, cnt.p, hstride);
+    if (S->perm) {
+        hipLaunchKernelGGL(k_order_poscnt, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx().stream, (const unsigned int *)cnt.p,
+                           (const int32_t *)S->perm->d_inv, n, poscnt.p);
+        sync_stream();
+        return S->perm;
+    }
+    DevBuf<uint64_t> keys(n), keys2(n);
+    DevBuf<uint32_t> ids(n), ids2(n);
+    hipLaunchKernelGGL(k_order_keys, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx().stream, (const unsigned int *)cnt.p, matrix_rowptr(S), n, keys.p, ids.p);
+    prim_sort_pairs_u64_u32(keys.p, keys2.p, ids.p, ids2.p, n, 40);
+    GB_Perm *P = new GB_Perm();
+    P->n = (uint64_t)n;
+    try {
+        P->d_rank = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)n);
+        P->d_inv = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)n);
+        DevBuf<unsigned long long> live(2, true);
+        hipLaunchKernelGGL(k_order_place, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx().stream, (const uint32_t *)ids2.p, (const uint64_t *)keys2.p, n, k_hot,
+                           P->d_rank, P->d_inv, poscnt.p, live.p);
+        unsigned long long h_live[2] = {0, 0};
+        d2h(h_live, live.p, sizeof(h_live));
+        P->n_live_rows = (int64_t)h_live[0];
+        P->n_live_cols = (int64_t)h_live[1];
+    } catch (...) {
+        perm_release(P);
+        throw;
+    }
+    S->perm = P;
+    if (partner && !partner->perm) {
+        partner->perm = P;
+        perm_retain(P);
+    }
+    return P;
+}
+
+// ord = P S P' with its pull layouts; S->ord_state = 1, or -1 when the matrix does not take them (no skew: the split declines)
+static void ensure_ordered(GB_Matrix_opaque *S)
+{
+    const uint64_t sig = order_signature();
+    if (S->ord_state == 1 && S->ord && S->ord_sig == sig) return;
+    if (S->ord_state == -1 && S->ord_sig == sig) return;
+    if (S->ord) {  // (built under other layout options)
+        matrix_free(S->ord);
+        S->ord = nullptr;
+    }
+    S->ord_state = -1;
+    S->ord_sig = sig;
+    const int64_t n = (int64_t)S->ncols, nnz = S->nvals;
+    if (n + (int64_t)(1 << 22) > 0x7fffffff || nnz >= 0xf0000000ll) return;
+    const size_t vb = S->type->size;
+    const int64_t k_hot = hot_table_size(n, vb);
+    if (k_hot < 64 || n < ctx().hot_min_cols) return;
+    DevBuf<unsigned int> poscnt(n);
+    GB_Perm *P = ensure_perm(S, k_hot, poscnt);
+    GB_Matrix_opaque *R = matrix_new(S->type, S->nrows, S->ncols);
+    try {
+        // ---- the matrix in the new order: row p = row d_inv[p] of S with its columns renamed by d_rank (unsorted inside a row: no
+        //      layout below needs them sorted)
+        DevBuf<int64_t> len(n + 1);
+        hipLaunchKernelGGL(k_twin_lengths, dim3((unsigned)ceil_div(n + 1, 256)), dim3(256), 0, ctx().stream, matrix_rowptr(S), (const int32_t *)P->d_inv, n, len.p);
+        R->d_ptr = (int64_t *)dev_alloc(sizeof(int64_t) * (size_t)(n + 1));
+        prim_exclusive_sum_i64(len.p, R->d_ptr, n + 1);
+        R->d_col = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)nnz);
+        R->d_val = dev_alloc(vb * (size_t)(S->iso ? 1 : nnz));
+        R->iso = S->iso;
+        R->nvals = nnz;
+        if (S->iso) d2d(R->d_val, S->d_val, vb);
+        DevBuf<unsigned long long> span(1, true);
+        hipLaunchKernelGGL(k_twin_huge_span, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx().stream, (const int64_t *)R->d_ptr, n, span.p);
+        unsigned long long h_span = 0;
+        d2h(&h_span, span.p, sizeof(h_span));
+        GRB_DISPATCH_TYPE(S->type->code, T, {
+            hipLaunchKernelGGL((k_twin_rows<T>), dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx().stream, matrix_rowptr(S), (const int32_t *)S->d_col,
+                               (const T *)S->d_val, S->iso ? 1 : 0, (const int32_t *)P->d_inv, (const int32_t *)P->d_rank, n, (const int64_t *)R->d_ptr,
+                               R->d_col, (T *)R->d_val);
+            if (h_span > 0)
+                hipLaunchKernelGGL((k_twin_huge<T>), dim3((unsigned)h_span), dim3(256), 0, ctx().stream, matrix_rowptr(S), (const int32_t *)S->d_col,
+                                   (const T *)S->d_val, S->iso ? 1 : 0, (const int32_t *)P->d_inv, (const int32_t *)P->d_rank, (const int64_t *)R->d_ptr,
+                                   R->d_col, (T *)R->d_val);
+        })
+        // ---- its column codes ARE the hot codes: positions below k_hot are the table, the operand is the image
+        R->hot_state = 1;
+        R->hot_k = k_hot;
+        R->hot_identity = true;
+        R->d_col_hot = R->d_col;
+        // ---- column ranges of the cold tiles: behind the LDS-resident codes, about equal reference counts, at most ~2 MiB of operand
+        {
+            const int ncls = (ctx().long_classes == 16 || ctx().long_classes == 32 || ctx().long_classes == 64) ? ctx().long_classes : 8;
+            const int64_t lim = std::min<int64_t>(k_hot, long_lds_codes((int)vb, S->type->code == TC_BOOL, LONG_LDS_WORDS) / 8 * ncls);
+            const int g = 4096;
+            const int64_t nblk = ceil_div(std::max<int64_t>(n - lim, 1), g);
+            DevBuf<int64_t> blk(nblk);
+            hipLaunchKernelGGL(k_order_coarse, dim3((unsigned)ceil_div(nblk, 4)), dim3(256), 0, ctx().stream, (const unsigned int *)poscnt.p, n, lim, g, nblk, blk.p);
+            std::vector<int64_t> h_blk((size_t)nblk);
+            d2h(h_blk.data(), blk.p, sizeof(int64_t) * (size_t)nblk);
+            int64_t total = 0;
+            for (int64_t b = 0; b < nblk; b++) total += h_blk[(size_t)b];
+            const int R_TARGET = 32, R_MAX = 48;
+            const int64_t cap_codes = std::max<int64_t>(g, ((int64_t)2 << 20) / (int64_t)std::max<size_t>(vb, 1)), target = std::max<int64_t>(1, total / R_TARGET);
+            std::vector<int32_t> bounds;
+            bounds.push_back((int32_t)lim);
+            int64_t acc = 0, width = 0;
+            for (int64_t b = 0; b < nblk; b++) {
+                acc += h_blk[(size_t)b];
+                width += g;
+                const int64_t end = std::min<int64_t>(lim + (b + 1) * g, n);
+                const bool last_ref = (lim + (b + 1) * g >= P->n_live_cols);  // (behind it: columns nobody counted a reference to)
+                if ((int)bounds.size() < R_MAX && end < n && (acc >= target || width >= cap_codes || (last_ref && acc > 0))) {
+                    bounds.push_back((int32_t)end);
+                    acc = 0;
+                    width = 0;
+                }
+            }
+            bounds.push_back((int32_t)n);
+            R->ct_ncr = (int)bounds.size() - 1;
+            R->d_cold_bounds = (int32_t *)dev_alloc(sizeof(int32_t) * bounds.size());
+            h2d(R->d_cold_bounds, bounds.data(), sizeof(int32_t) * bounds.size());
+        }
+        sync_stream();
+        // ---- the layouts (hot strips, cold tiles, tagged row groups) in that order
+        ensure_split(R, R->d_col_hot, true);
+        const bool usable = R->split_state == 1 && R->split_kind == 4 && R->long_nnz > 0 && (R->strip_nseg > 0 || R->ct_units > 0) && R->short_tagged_only;
+        if (!usable) {
+            matrix_free(R);
+            return;
+        }
+        // (nothing reads the CSR arrays of the twin again: the layouts carry their own columns and values)
+        if (R->d_col) {
+            dev_free(R->d_col);
+            R->d_col = nullptr;
+            R->d_col_hot = nullptr;
+            R->hot_cols_dropped = true;
+        }
+        if (!R->iso) {
+            dev_free(R->d_val);
+            R->d_val = nullptr;
+        }
+    } catch (...) {
+        matrix_free(R);
+        throw;
+    }
+    S->ord = R;
+    S->ord_state = 1;
 }
 
 #ifdef GRB_EXPERIMENTAL_KERNELS
@@ -657,8 +899,8 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
                     a.ct_val = A->d_ct_val;
                     a.ct_loc = A->d_ct_loc;
                     a.ct_tiles = (const CTile *)A->d_ct_tiles;
-                    a.ct_nsb = A->ct_nsb;
-                    a.ct_ncr = A->ct_ncr;
+                    a.ct_order = A->d_ct_order;
+                    for (int x = 0; x <= 8; x++) a.ct_xoff[x] = A->ct_xoff[x];
                     const int64_t Gt = std::max<int64_t>(8, (int64_t)(ctx().num_cus * CT_WGS_PER_CU / 8) * 8);
                     hipLaunchKernelGGL((k_mxv_ctile<T, MON, MUL>), dim3((unsigned)Gt), dim3(CT_BLOCK), 0, ctx().stream, a);
                     ctx().stats.kernel_launches += 1;
@@ -973,7 +1215,12 @@ static void mxv_core(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_Binar
     // scale 24) are built when the matrix comes back for a second product
     const bool lazy = ctx().lazy_layout && S->nvals >= ctx().lazy_min_nnz && S->pull_calls == 0 && S->hot_state == 0 && S->split_state == 0;
     S->pull_calls++;
-    if ((a.need_uval || !a.u_full) && !lazy) {
+    if (S->hot_identity) {
+        // a matrix in its popularity order (grb_mxv_order.inc): the column codes are positions of the operand itself -- the first hot_k of
+        // them are the hot table, nothing is gathered per call
+        a.col = S->d_col_hot;
+        ctx().stats.hot_k = S->hot_k;
+    } else if ((a.need_uval || !a.u_full) && !lazy) {
         ensure_hot(S, type_size(st));
         // (once the split is built from the re-coded columns, the re-coded copy of the WHOLE column array is released --
         //  1.05 GB of the 3.7 GB of layouts at scale 24: a call that cannot take the split then runs on the plain arrays)
@@ -1258,6 +1505,66 @@ static bool want_push(GB_Vector_opaque *u, GB_Matrix_opaque *P_or_null)
     return nv * 64 < (int64_t)u->n;  // fewer than n/64 entries
 }
 
+// the push direction walks the rows of a matrix in natural order: its operands come back to it first
+static bool push_natural(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_BinaryOp_opaque *accum, const GB_Semiring_opaque *sr,
+                         GB_Matrix_opaque *P, GB_Vector_opaque *u, bool flip, DescFlags f)
+{
+    vector_set_order(u, nullptr);
+    vector_set_order(w, nullptr);
+    if (mask) vector_set_order(mask, nullptr);
+    return push_core(w, mask, accum, sr, P, u, flip, f);
+}
+
+// One product  w<mask> = accum(w, S (+.x) u): on the popularity-ordered twin of S with the operands kept in its vertex order when the
+// matrix has (or now gets) one and the call can use it, otherwise on S with the operands in natural order.
+// (`u_token`: u stands for "present everywhere, values never read" -- the row reductions -- and has no storage to convert)
+static void mxv_any_order(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_BinaryOp_opaque *accum, const GB_Semiring_opaque *sr,
+                          GB_Matrix_opaque *S, GB_Vector_opaque *u, bool flip, DescFlags f, bool u_token = false)
+{
+    const int64_t reorders0 = ctx().reorder_count;
+    GB_Vector_opaque *vs[3] = {w, u_token ? nullptr : u, mask};
+    bool ordered = false;
+    const bool shapes_ok = S->ncols == u->n && w->n == S->nrows && (!mask || mask->n == w->n) && !(!mask && f.comp) && w->n > 0;
+    if (shapes_ok && (S->nvals == 0 || u->nvals == 0 || !u->d_val)) {
+        // only the write rule runs (element-wise): any order the operands share will do
+        GB_Vector_opaque *ws[2] = {w, mask};
+        (void)vectors_common_order(ws, 2);
+        mxv_core(w, mask, accum, sr, S, u, flip, f);
+        ctx().stats.reorders = (int32_t)(ctx().reorder_count - reorders0);
+        return;
+    }
+    if (shapes_ok && ctx().order_mode && S->nrows == S->ncols && S->nvals >= ctx().order_min_nnz && S->type->code != TC_BOOL &&
+        sr->type == S->type->code && !w->pinned && !u->pinned && !(mask && mask->pinned) && S->d_col) {
+        int mult = canonical_op(sr->type, sr->mult);
+        if (flip) mult = flip_op(mult);
+        const bool by_rowlen = mult == OP_PAIR && u->nvals == (int64_t)u->n && !(ctx().debug_flags & 65536);
+        // (the first product of a large matrix runs on its arrays as they are -- lazy layouts, section 4.1.6 -- and counts itself)
+        const bool first = ctx().lazy_layout && S->nvals >= ctx().lazy_min_nnz && S->pull_calls == 0 && S->ord_state == 0;
+        if (!by_rowlen && !first) {
+            ensure_ordered(S);
+            ordered = S->ord_state == 1;
+        }
+    }
+    if (ordered) {
+        GB_Perm *P = S->perm;
+        // an output that keeps nothing of its old content needs no conversion: it is emptied and takes the order
+        const bool w_dead = !accum && (!mask || f.replace) && w != u && w != mask;
+        if (w_dead && w->order != P && w->d_val) {
+            GRB_HIP(hipMemsetAsync(w->d_bits, 0, bits_words64(w->n) * 8, ctx().stream));
+            w->nvals = 0;
+        }
+        for (GB_Vector_opaque *v : vs)
+            if (v) vector_set_order(v, P);
+        mxv_core(w, mask, accum, sr, S->ord, u, flip, f);
+        ctx().stats.ordered = 1;
+    } else {
+        for (GB_Vector_opaque *v : vs)
+            if (v) vector_set_order(v, nullptr);
+        mxv_core(w, mask, accum, sr, S, u, flip, f);
+    }
+    ctx().stats.reorders = (int32_t)(ctx().reorder_count - reorders0);
+}
+
 }  // namespace grb
 
 using namespace grb;
@@ -1267,20 +1574,20 @@ extern "C" GrB_Info GrB_mxv(GrB_Vector w, const GrB_Vector mask, const GrB_Binar
 {
     GRB_TRY
     require_init();
-    check_vector(w, "w");
-    if (mask) check_vector(mask, "mask");
+    check_vector_any(w, "w");
+    if (mask) check_vector_any(mask, "mask");
     check_matrix(A, "A");
-    check_vector(u, "u");
+    check_vector_any(u, "u");
     if (!semiring) fail(GrB_NULL_POINTER, "semiring is NULL");
     DescFlags f = flags_of(desc);
     // pull over S = A (or A' with T0); push needs the matrix whose ROWS are indexed like u: S' -- only when cached
     GB_Matrix_opaque *P = f.t0 ? A : A->tr;
     const bool dims_ok = (f.t0 ? A->nrows : A->ncols) == u->n && (f.t0 ? A->ncols : A->nrows) == w->n && (!mask || mask->n == w->n);
     if (dims_ok && (!accum || (accum->type == w->type->code && !op_is_comparison(accum->op))) && !(!mask && f.comp) && w->n > 0 && want_push(u, P) &&
-        push_core(w, mask, accum, semiring, P, u, /*flip=*/true, f)) {
+        push_natural(w, mask, accum, semiring, P, u, /*flip=*/true, f)) {
     } else {
         GB_Matrix_opaque *S = f.t0 ? matrix_transpose_cached(A) : A;
-        mxv_core(w, mask, accum, semiring, S, u, /*flip=*/false, f);
+        mxv_any_order(w, mask, accum, semiring, S, u, /*flip=*/false, f);
     }
     GRB_CATCH(errp(w))
 }
@@ -1290,10 +1597,10 @@ extern "C" GrB_Info GrB_vxm(GrB_Vector w, const GrB_Vector mask, const GrB_Binar
 {
     GRB_TRY
     require_init();
-    check_vector(w, "w");
-    if (mask) check_vector(mask, "mask");
+    check_vector_any(w, "w");
+    if (mask) check_vector_any(mask, "mask");
     check_matrix(A, "A");
-    check_vector(u, "u");
+    check_vector_any(u, "u");
     if (!semiring) fail(GrB_NULL_POINTER, "semiring is NULL");
     DescFlags f = flags_of(desc);
     // w' = u' A  <=>  w = A' u with the multiply operands swapped; desc T1 transposes A
@@ -1301,10 +1608,10 @@ extern "C" GrB_Info GrB_vxm(GrB_Vector w, const GrB_Vector mask, const GrB_Binar
     GB_Matrix_opaque *P = f.t1 ? A->tr : A;
     const bool dims_ok = (f.t1 ? A->ncols : A->nrows) == u->n && (f.t1 ? A->nrows : A->ncols) == w->n && (!mask || mask->n == w->n);
     if (dims_ok && (!accum || (accum->type == w->type->code && !op_is_comparison(accum->op))) && !(!mask && f.comp) && w->n > 0 && want_push(u, P) &&
-        push_core(w, mask, accum, semiring, P, u, /*flip=*/false, f)) {
+        push_natural(w, mask, accum, semiring, P, u, /*flip=*/false, f)) {
     } else {
         GB_Matrix_opaque *S = f.t1 ? A : matrix_transpose_cached(A);
-        mxv_core(w, mask, accum, semiring, S, u, /*flip=*/true, f);
+        mxv_any_order(w, mask, accum, semiring, S, u, /*flip=*/true, f);
     }
     GRB_CATCH(errp(w))
 }
@@ -1330,7 +1637,7 @@ extern "C" GrB_Info GrX_Matrix_cache_bytes(const GrB_Matrix A, uint64_t *bytes)
         if (A->split_kind == 4 && (A->strip_nseg > 0 || A->ct_units > 0)) {
             const uint64_t hot_lanes = (uint64_t)A->strip_cb[A->strip_ncls] * 64;
             const uint64_t cold = (uint64_t)A->ct_units * CT_EPL;
-            b += hot_lanes * (uint64_t)A->hrec_bytes + hot_lanes * 4 + hot_lanes / 8 + cold * (6 + (A->d_ct_val ? vs : 0)) + 16ull * (uint64_t)(A->ct_nsb * A->ct_ncr);
+            b += hot_lanes * (uint64_t)A->hrec_bytes + hot_lanes * 4 + hot_lanes / 8 + cold * (6 + (A->d_ct_val ? vs : 0)) + 20ull * (uint64_t)A->ct_ntiles;
         } else if (A->split_kind == 2 && A->strip_nseg > 0) {
             const uint64_t padded = (uint64_t)A->strip_cb[A->strip_ncls] * STRIP_CH;
             b += padded * 4 + (A->d_lval ? padded * vs : 0) + padded / 2 + padded / STRIP_CH * 8;
@@ -1338,6 +1645,11 @@ extern "C" GrB_Info GrX_Matrix_cache_bytes(const GrB_Matrix A, uint64_t *bytes)
             const uint64_t padded = (uint64_t)A->long_nnz + 4ull * (uint64_t)A->n_items;
             b += padded * 4 + (A->d_lval ? padded * vs : 0) + 16ull * (uint64_t)A->n_items;
         }
+    }
+    if (A->ord) {  // the popularity-ordered twin: its layouts, its row pointers, the two maps of the order
+        uint64_t tb = 0;
+        (void)GrX_Matrix_cache_bytes(A->ord, &tb);
+        b += tb + 8ull * (A->nrows + 1) + 8ull * A->nrows;
     }
     *bytes = b;
     GRB_CATCH(errp(A))
@@ -1351,8 +1663,8 @@ extern "C" GrB_Info GrB_Matrix_reduce_Monoid(GrB_Vector w, const GrB_Vector mask
 {
     GRB_TRY
     require_init();
-    check_vector(w, "w");
-    if (mask) check_vector(mask, "mask");
+    check_vector_any(w, "w");
+    if (mask) check_vector_any(mask, "mask");
     check_matrix(A, "A");
     if (!monoid) fail(GrB_NULL_POINTER, "monoid is NULL");
     DescFlags f = flags_of(desc);
@@ -1365,7 +1677,7 @@ extern "C" GrB_Info GrB_Matrix_reduce_Monoid(GrB_Vector w, const GrB_Vector mask
     ones->d_bits = (uint64_t *)dev_alloc(16);
     ones->nvals = (int64_t)S->ncols;
     try {
-        mxv_core(w, mask, accum, &sr, S, ones, /*flip=*/false, f);
+        mxv_any_order(w, mask, accum, &sr, S, ones, /*flip=*/false, f, /*u_token=*/true);
     } catch (...) {
         vector_free(ones);
         throw;

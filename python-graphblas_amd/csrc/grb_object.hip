@@ -298,6 +298,94 @@ void vector_release_storage(GB_Vector_opaque *v)
     v->d_val = nullptr;
     v->d_bits = nullptr;
     v->nvals = 0;
+    if (v->order) {  // (a vector without entries is in every order)
+        perm_release(v->order);
+        v->order = nullptr;
+    }
+}
+
+// ---- vertex orders (GB_Perm, grb_internal.hpp) ------------------------------------------------------------------------------
+void perm_retain(GB_Perm *p)
+{
+    if (p) p->refs++;
+}
+void perm_release(GB_Perm *p)
+{
+    if (!p || --p->refs > 0) return;
+    dev_free(p->d_rank);
+    dev_free(p->d_inv);
+    delete p;
+}
+
+// new[t] = old[src_of[t]] for values and presence bits (the presence word of 64 consecutive targets by one ballot)
+template <typename T>
+__global__ void k_vec_permute(int64_t n, const int32_t *src_of, const T *old_val, const uint64_t *old_bits, T *new_val, uint64_t *new_bits)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool has = false;
+    if (t < n) {
+        const int64_t s = src_of[t];
+        has = (old_bits[s >> 6] >> (s & 63)) & 1ull;
+        new_val[t] = old_val[s];
+    }
+    const unsigned long long b = __ballot(has);
+    if ((threadIdx.x & 63) == 0 && t < ((n + 63) & ~(int64_t)63)) new_bits[t >> 6] = b;
+}
+
+// In place: the vector keeps its device pointers (they may be aliased outside the library: GrX_Vector_export_dense_device).
+void vector_set_order(GB_Vector_opaque *v, GB_Perm *order)
+{
+    if (v->order == order) return;
+    if (order && order->n != v->n) fail(GrB_PANIC, "vector order: size mismatch (internal error)");
+    const bool has_entries = v->d_val && v->nvals != 0 && v->n > 0;
+    if (has_entries && v->order && order) vector_set_order(v, nullptr);  // (between two orders: through the natural one)
+    if (has_entries) {
+        // into an order: position p takes the element d_inv[p]; back: element i comes from position d_rank[i]
+        const int32_t *src_of = order ? order->d_inv : v->order->d_rank;
+        const int64_t n = (int64_t)v->n;
+        const size_t vb = (size_t)n * v->type->size, bb = bits_words64(v->n) * 8;
+        DevBuf<char> tv(vb);
+        DevBuf<uint64_t> tb(bits_words64(v->n));
+        const int64_t threads = (int64_t)bits_words64(v->n) * 64;
+        switch (v->type->size) {
+        case 1: LAUNCH((k_vec_permute<uint8_t>), threads, n, src_of, (const uint8_t *)v->d_val, (const uint64_t *)v->d_bits, (uint8_t *)tv.p, tb.p); break;
+        case 2: LAUNCH((k_vec_permute<uint16_t>), threads, n, src_of, (const uint16_t *)v->d_val, (const uint64_t *)v->d_bits, (uint16_t *)tv.p, tb.p); break;
+        case 4: LAUNCH((k_vec_permute<uint32_t>), threads, n, src_of, (const uint32_t *)v->d_val, (const uint64_t *)v->d_bits, (uint32_t *)tv.p, tb.p); break;
+        default: LAUNCH((k_vec_permute<uint64_t>), threads, n, src_of, (const uint64_t *)v->d_val, (const uint64_t *)v->d_bits, (uint64_t *)tv.p, tb.p); break;
+        }
+        d2d(v->d_val, tv.p, vb);
+        d2d(v->d_bits, tb.p, bb);
+        ctx().reorder_count += 1;
+    }
+    perm_retain(order);
+    perm_release(v->order);
+    v->order = order;
+}
+
+GB_Perm *vectors_common_order(GB_Vector_opaque *const *vs, int count)
+{
+    GB_Perm *target = nullptr;
+    bool pinned = false;
+    for (int i = 0; i < count; i++) {
+        GB_Vector_opaque *v = vs[i];
+        if (!v) continue;
+        pinned = pinned || v->pinned;
+        if (!target && v->order && v->d_val && v->nvals != 0) target = v->order;
+    }
+    if (pinned) target = nullptr;
+    if (target) perm_retain(target);  // (converting the last vector that holds it must not free it)
+    for (int i = 0; i < count; i++)
+        if (vs[i]) vector_set_order(vs[i], target);
+    if (target) perm_release(target);  // (still referenced by the vectors, unless all of them were empty)
+    return target;
+}
+
+uint64_t vector_position(GB_Vector_opaque *v, uint64_t i)
+{
+    if (!v->order) return i;
+    int32_t p = 0;
+    d2h(&p, v->order->d_rank + i, sizeof(p));
+    return (uint64_t)p;
 }
 
 void vector_free(GB_Vector_opaque *v)
@@ -339,6 +427,8 @@ GB_Vector_opaque *vector_cast_copy(GB_Vector_opaque *v, int type)
         cast_array(type, w->d_val, v->type->code, v->d_val, (int64_t)v->n);
         d2d(w->d_bits, v->d_bits, bits_words64(v->n) * 8);
         w->nvals = v->nvals;
+        perm_retain(v->order);  // (a copy is element-wise: it is in the order of its source)
+        w->order = v->order;
     }
     return w;
 }
@@ -552,6 +642,16 @@ void matrix_invalidate_caches(GB_Matrix_opaque *A)
         matrix_free(A->tr);
         A->tr = nullptr;
     }
+    if (A->ord) {
+        matrix_free(A->ord);
+        A->ord = nullptr;
+    }
+    perm_release(A->perm);  // (vectors in this order keep it alive until they are converted)
+    A->perm = nullptr;
+    A->ord_state = 0;
+    dev_free(A->d_cold_bounds); dev_free(A->d_ct_order);
+    A->d_cold_bounds = nullptr; A->d_ct_order = nullptr; A->ct_ntiles = 0;
+    if (A->hot_identity) A->d_col_hot = nullptr;  // (an alias of d_col)
     dev_free(A->d_tile_row);
     A->d_tile_row = nullptr;
     A->n_tiles = 0;
@@ -814,6 +914,7 @@ GB_Matrix_opaque *matrix_transpose_cached(GB_Matrix_opaque *A)
 {
     if (!A->tr) {
         GRB_DISPATCH_TYPE(A->type->code, T, { A->tr = matrix_transpose_new<T>(A); })
+        A->tr->tr_of = A;
     }
     return A->tr;
 }
@@ -916,7 +1017,7 @@ extern "C" GrB_Info GrB_Vector_dup(GrB_Vector *w, const GrB_Vector u)
     GRB_TRY
     require_init();
     if (!w) fail(GrB_NULL_POINTER, "GrB_Vector_dup: NULL output");
-    check_vector(u, "u");
+    check_vector_any(u, "u");
     *w = vector_cast_copy(u, u->type->code);
     GRB_CATCH(nullptr)
 }
@@ -927,7 +1028,7 @@ extern "C" GrB_Info GrX_Vector_dup_as(GrB_Vector *w, const GrB_Type type, const 
     require_init();
     if (!w) fail(GrB_NULL_POINTER, "GrX_Vector_dup_as: NULL output");
     if (!type) fail(GrB_NULL_POINTER, "GrX_Vector_dup_as: NULL type");
-    check_vector(u, "u");
+    check_vector_any(u, "u");
     *w = vector_cast_copy(u, type->code);
     GRB_CATCH(nullptr)
 }
@@ -943,7 +1044,7 @@ extern "C" GrB_Info GrB_Vector_free(GrB_Vector *v)
 extern "C" GrB_Info GrB_Vector_clear(GrB_Vector v)
 {
     GRB_TRY
-    check_vector(v, "v");
+    check_vector_any(v, "v");
     vector_release_storage(v);
     GRB_CATCH(errp(v))
 }
@@ -952,7 +1053,7 @@ extern "C" GrB_Info GrB_Vector_size(GrB_Index *n, const GrB_Vector v)
 {
     GRB_TRY
     if (!n) fail(GrB_NULL_POINTER, "n is NULL");
-    check_vector(v, "v");
+    check_vector_any(v, "v");
     *n = v->n;
     GRB_CATCH(nullptr)
 }
@@ -961,7 +1062,7 @@ extern "C" GrB_Info GrB_Vector_nvals(GrB_Index *nvals, const GrB_Vector v)
 {
     GRB_TRY
     if (!nvals) fail(GrB_NULL_POINTER, "nvals is NULL");
-    check_vector(v, "v");
+    check_vector_any(v, "v");
     *nvals = (GrB_Index)vector_nvals(v);
     GRB_CATCH(errp(v))
 }
@@ -969,7 +1070,7 @@ extern "C" GrB_Info GrB_Vector_nvals(GrB_Index *nvals, const GrB_Vector v)
 extern "C" GrB_Info GrB_Vector_wait(GrB_Vector v, GrB_WaitMode)
 {
     GRB_TRY
-    check_vector(v, "v");
+    check_vector_any(v, "v");
     sync_stream();
     GRB_CATCH(errp(v))
 }
@@ -1367,6 +1468,15 @@ extern "C" GrB_Info GrX_Vector_export_dense_device(const void **d_val, const uin
     vector_ensure_storage(v);
     if (d_val) *d_val = v->d_val;
     if (d_present) *d_present = (const uint32_t *)v->d_bits;
+    GRB_CATCH(errp(v))
+}
+
+extern "C" GrB_Info GrX_Vector_pin_natural(GrB_Vector v, int pinned)
+{
+    GRB_TRY
+    require_init();
+    check_vector(v, "v");  // (natural from now on)
+    v->pinned = pinned != 0;
     GRB_CATCH(errp(v))
 }
 

@@ -153,6 +153,7 @@ static void set_element(GB_Vector_opaque *w, T x, uint64_t i)
 {
     if (i >= w->n) fail(GrB_INVALID_INDEX, "setElement: index " + std::to_string(i) + " is outside a vector of size " + std::to_string(w->n));
     vector_ensure_storage(w);
+    i = vector_position(w, i);  // (a vector kept in a matrix's vertex order: where element i lives)
     GRB_DISPATCH_TYPE(w->type->code, TW, {
         hipLaunchKernelGGL((k_set_element<TW>), dim3(1), dim3(64), 0, ctx().stream, (TW *)w->d_val, w->d_bits, (int64_t)i,
                            cast_value<TW, T>(x));
@@ -167,6 +168,7 @@ static GrB_Info extract_element(T *x, GB_Vector_opaque *u, uint64_t i)
     if (!x) fail(GrB_NULL_POINTER, "extractElement: output pointer is NULL");
     if (i >= u->n) fail(GrB_INVALID_INDEX, "extractElement: index " + std::to_string(i) + " is outside a vector of size " + std::to_string(u->n));
     if (!u->d_val) return GrB_NO_VALUE;
+    i = vector_position(u, i);
     uint64_t word = 0;
     d2h(&word, u->d_bits + (i >> 6), sizeof(word));
     if (!((word >> (i & 63)) & 1ull)) return GrB_NO_VALUE;
@@ -189,6 +191,10 @@ static void assign_all(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_Bin
         return;
     }
     if (w->n == 0) return;
+    {   // element-wise: any vertex order will do, as long as it is the same for w and the mask
+        GB_Vector_opaque *vs[2] = {w, mask};
+        (void)vectors_common_order(vs, 2);
+    }
     vector_ensure_storage(w);
     DevBuf<uint64_t> mbits(mask ? bits_words64(w->n) : 1);
     if (mask) vector_mask_bits(mask, f.structure, mbits.p);  // (a snapshot: the mask may be w itself)
@@ -293,6 +299,10 @@ static void ewise_core(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_Bin
         return;
     }
     if (w->n == 0) return;
+    {   // element-wise: any vertex order will do, as long as all four vectors are in it
+        GB_Vector_opaque *vs[4] = {w, u, v, mask};
+        (void)vectors_common_order(vs, 4);
+    }
     const int64_t n = (int64_t)w->n;
     const bool cmp = op_is_comparison(op_in);
     const int op = cmp ? op_in : canonical_op(ot, op_in);
@@ -569,9 +579,10 @@ extern "C" GrB_Info GrB_Vector_removeElement(GrB_Vector w, GrB_Index i)
 {
     GRB_TRY
     require_init();
-    check_vector(w, "w");
+    check_vector_any(w, "w");
     if (i >= w->n) fail(GrB_INVALID_INDEX, "removeElement: index " + std::to_string(i) + " is outside a vector of size " + std::to_string(w->n));
     if (w->d_val) {
+        i = vector_position(w, i);
         hipLaunchKernelGGL(k_remove_element, dim3(1), dim3(64), 0, ctx().stream, w->d_bits, (int64_t)i);
         w->nvals = -1;
         if (ctx().blocking) sync_stream();
@@ -584,7 +595,7 @@ extern "C" GrB_Info GrB_Vector_removeElement(GrB_Vector w, GrB_Index i)
     {                                                                                                                                   \
         GRB_TRY                                                                                                                         \
         require_init();                                                                                                                 \
-        check_vector(w, "w");                                                                                                           \
+        check_vector_any(w, "w");                                                                                                       \
         set_element<ctype>(w, x, i);                                                                                                    \
         GRB_CATCH(errp(w))                                                                                                              \
     }                                                                                                                                   \
@@ -592,7 +603,7 @@ extern "C" GrB_Info GrB_Vector_removeElement(GrB_Vector w, GrB_Index i)
     {                                                                                                                                   \
         GRB_TRY                                                                                                                         \
         require_init();                                                                                                                 \
-        check_vector(u, "u");                                                                                                           \
+        check_vector_any(u, "u");                                                                                                       \
         return extract_element<ctype>(x, u, i);                                                                                         \
         GRB_CATCH(errp(u))                                                                                                              \
     }                                                                                                                                   \
@@ -601,9 +612,11 @@ extern "C" GrB_Info GrB_Vector_removeElement(GrB_Vector w, GrB_Index i)
     {                                                                                                                                   \
         GRB_TRY                                                                                                                         \
         require_init();                                                                                                                 \
-        check_vector(w, "w");                                                                                                           \
-        if (mask) check_vector(mask, "mask");                                                                                           \
+        check_vector_any(w, "w");                                                                                                       \
+        if (mask) check_vector_any(mask, "mask");                                                                                       \
         if (indices != GrB_ALL) {                                                                                                       \
+            check_vector(w, "w");                                                                                                       \
+            if (mask) check_vector(mask, "mask");                                                                                       \
             GRB_DISPATCH_TYPE(w->type->code, TW_, {                                                                                     \
                 const TW_ xs = cast_value<TW_, ctype>(x);                                                                               \
                 assign_indexed(w, mask, accum, nullptr, &xs, indices, nindices, desc);                                                  \
@@ -618,7 +631,7 @@ extern "C" GrB_Info GrB_Vector_removeElement(GrB_Vector w, GrB_Index i)
     {                                                                                                                                   \
         GRB_TRY                                                                                                                         \
         require_init();                                                                                                                 \
-        check_vector(u, "u");                                                                                                           \
+        check_vector_any(u, "u");  /* (a reduction does not care where the elements are) */                                            \
         (void)desc;                                                                                                                     \
         reduce_to<ctype>(val, accum, monoid, u);                                                                                        \
         GRB_CATCH(errp(u))                                                                                                              \
@@ -632,10 +645,10 @@ GRB_FOR_EACH_TYPE(GRB_VECOPS_TYPED)
     {                                                                                                                          \
         GRB_TRY                                                                                                                \
         require_init();                                                                                                        \
-        check_vector(w, "w");                                                                                                  \
-        if (mask) check_vector(mask, "mask");                                                                                  \
-        check_vector(u, "u");                                                                                                  \
-        check_vector(v, "v");                                                                                                  \
+        check_vector_any(w, "w");                                                                                              \
+        if (mask) check_vector_any(mask, "mask");                                                                              \
+        check_vector_any(u, "u");                                                                                              \
+        check_vector_any(v, "v");                                                                                              \
         if (!op) fail(GrB_NULL_POINTER, "eWise: operator is NULL");                                                            \
         ewise_core(w, mask, accum, op->op, op->type, u, v, desc, IS_ADD);                                                      \
         GRB_CATCH(errp(w))                                                                                                     \

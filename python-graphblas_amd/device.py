@@ -71,12 +71,21 @@ class _CudaView:
         self.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (ptr, False), "version": 2}
 
 
-def vector_device_views(v, device="cuda"):
-    """(values, presence_words) torch tensors ALIASING the vector's HBM image (valid until the vector
-    is modified by a call that reallocates it, or freed).  ``device="cpu"`` is for the CPU test tier,
-    where the emulator build keeps the image in host memory."""
+def vector_pin_natural(v, pinned=True):
+    """Keep ``v`` in natural index order for good: its HBM image is aliased outside the library for longer than one call (collective
+    buffers).  Products that involve a pinned vector run on the natural-order layouts of their matrix."""
+    call_on(v, "GrX_Vector_pin_natural", [v._handle, 1 if pinned else 0])
+
+
+def vector_device_views(v, device="cuda", *, pin=False):
+    """(values, presence_words) torch tensors ALIASING the vector's HBM image (valid until the vector is resized, cleared or
+    freed).  The image is in natural index order when this returns; a later product with a large square matrix may leave the
+    vector in that matrix's vertex order -- fetch the views again after such a call, or pass ``pin=True`` to hold the vector in
+    natural order for good.  ``device="cpu"`` is for the CPU test tier, where the emulator build keeps the image in host memory."""
     import torch
 
+    if pin:
+        vector_pin_natural(v)
     dv, db = ctypes.c_void_p(), ctypes.c_void_p()
     call_on(v, "GrX_Vector_export_dense_device", [ctypes.byref(dv), ctypes.byref(db), v._handle])
     n = v._size

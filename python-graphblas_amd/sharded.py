@@ -76,8 +76,8 @@ def allgather_into(u_full, w_local, *, device="cuda", values=True, presence=True
 
     from . import device as dev
 
-    u_vals, u_words = dev.vector_device_views(u_full, device)
-    w_vals, w_words = dev.vector_device_views(w_local, device)
+    u_vals, u_words = dev.vector_device_views(u_full, device, pin=True)
+    w_vals, w_words = dev.vector_device_views(w_local, device, pin=True)
     if values:
         _gather(dist, u_vals, w_vals)
     if presence:
@@ -94,8 +94,8 @@ def allgatherv_into(u_full, w_local, cuts, *, device="cuda", values=True, presen
     from . import device as dev
 
     rank, world = dist.get_rank(), dist.get_world_size()
-    u_vals, u_words = dev.vector_device_views(u_full, device)
-    w_vals, w_words = dev.vector_device_views(w_local, device)
+    u_vals, u_words = dev.vector_device_views(u_full, device, pin=True)
+    w_vals, w_words = dev.vector_device_views(w_local, device, pin=True)
     lo, hi = cuts[rank], cuts[rank + 1]
     if hi > lo:
         if values:
@@ -129,8 +129,8 @@ def allgather_delta_into(u_full, w_local, cuts, *, device="cuda", dense_above=0.
     from . import device as dev
 
     rank, world = dist.get_rank(), dist.get_world_size()
-    u_vals, u_words = dev.vector_device_views(u_full, device)
-    w_vals, w_words = dev.vector_device_views(w_local, device)
+    u_vals, u_words = dev.vector_device_views(u_full, device, pin=True)
+    w_vals, w_words = dev.vector_device_views(w_local, device, pin=True)
     lo, hi = cuts[rank], cuts[rank + 1]
     rows = hi - lo
     nw = (rows + 31) // 32
@@ -233,11 +233,11 @@ class OverlappedMxv:
         as_u8 = lambda t: t.view(self._torch().uint8) if t.dtype == self._torch().bool else t
         self.u_vals, self.u_words, self.w_vals, self.w_words = [], [], [], []
         for r in range(2):
-            v, b = self.dev.vector_device_views(self.u[r], self.device)
+            v, b = self.dev.vector_device_views(self.u[r], self.device, pin=True)
             self.u_vals.append(as_u8(v))
             self.u_words.append(b)
         for c in range(self.chunks):
-            v, b = self.dev.vector_device_views(self.w[c], self.device)
+            v, b = self.dev.vector_device_views(self.w[c], self.device, pin=True)
             self.w_vals.append(as_u8(v))
             self.w_words.append(b)
 
@@ -328,7 +328,7 @@ def allreduce_monoid(t, monoid_name, identity, *, device="cuda"):
 
     if monoid_name not in _REDUCE_OF:
         raise NotImplementedError(f"no collective operator for the monoid {monoid_name!r} (times / lxor / lxnor need a gather + local fold)")
-    vals, words = dev.vector_device_views(t, device)
+    vals, words = dev.vector_device_views(t, device, pin=True)
     n = vals.numel()
     shifts = torch.arange(32, device=words.device, dtype=torch.int32)
     present = ((words.view(-1, 1) >> shifts) & 1).to(torch.bool).view(-1)[:n]

@@ -1,0 +1,224 @@
+"""Popularity-ordered layouts (python-graphblas_amd/csrc/grb_mxv_order.inc): a large square matrix is laid out a second time in a
+vertex order of its own and the vectors of its space are KEPT in that order between calls.  The order is a storage format: every
+result must be the one of the natural order, element for element -- checked here against the oracle with the size thresholds lowered
+so that small graphs take the path the scale-24 bench graph takes (GPU tier: the HIP kernels; CPU tier: the same sources under the
+wave64 emulator).
+
+Covers: the masked / accumulated product, the plain product, vxm over the transpose (which shares the order), products that cannot
+take the ordered layouts in between (another type, the row-length path), operands converted on first use and reused, every way a
+vector leaves the library (to_coo, element access, reduce, isequal, device views), element-wise operations between ordered and
+natural vectors, scalar assignment under a mask, the SSSP loop of the reference's primer and a level BFS written with the
+reference's calls."""
+import numpy as np
+import pytest
+
+from oracle import grb_oracle as O
+from tests.backend import DEVICES, bind
+from tests.test_random_parity import rand_vals, rand_vec, same_vec
+
+ORDER_OPTS = ((b"order_min_nnz", 1), (b"lean_min_nnz", 1), (b"split_min_nnz", 1), (b"split_min_len", 8), (b"push_mode", 0), (b"hot_min_cols", 8),
+              (b"lazy_layout", 0), (b"vec_pad_min_bytes", 0))
+RESTORE = ((b"order_min_nnz", 48 << 20), (b"lean_min_nnz", 48 << 20), (b"split_min_nnz", 1 << 22), (b"split_min_len", 0), (b"push_mode", 1),
+           (b"hot_min_cols", 1 << 20), (b"hot_k", 0), (b"lazy_layout", 1), (b"vec_pad_min_bytes", 1 << 20), (b"long_classes", 16), (b"order_mode", 1))
+
+
+@pytest.fixture(params=DEVICES)
+def gb(request):
+    return bind(request.param)
+
+
+def skewed_square(rng, n, tname, hub_rows=6):
+    """A square power-law-ish graph: most references go to a tenth of the columns, a few rows are long, many are empty."""
+    deg = rng.integers(0, 7, n)
+    deg[rng.random(n) < 0.4] = 0
+    for ln in (8, 9, 17, 63, 64, 65, 300, 513, int(rng.integers(700, n // 2))) + tuple(int(x) for x in rng.integers(100, 600, hub_rows + n // 150)):
+        deg[rng.integers(0, n)] = ln  # (the long rows must hold a good share of the entries, or the split declines)
+    hot = rng.permutation(n)[: n // 10]
+    rows = np.repeat(np.arange(n), deg)
+    cols = np.where(rng.random(rows.size) < 0.7, hot[rng.integers(0, hot.size, rows.size)], rng.integers(0, n, rows.size))
+    key = np.unique(rows * n + cols)
+    rows, cols = key // n, key % n
+    return rows, cols, rand_vals(rng, rows.size, tname)
+
+
+def set_opts(opts):
+    from graphblas_amd import _lib
+
+    for name, val in opts:
+        assert _lib.lib.GrX_option_set(name, val) == 0, name
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_ordered_product_matches_the_oracle(gb, seed):
+    from graphblas_amd import device
+
+    rng = np.random.default_rng(4100 + seed)
+    tname = ["FP32", "INT64", "FP64", "INT32", "UINT16", "INT8"][seed % 6]
+    sr = ["min_plus", "plus_times", "max_plus", "any_pair", "min_second", "plus_plus"][(seed // 2) % 6]
+    n = int(rng.integers(2200, 5200))
+    rows, cols, vals = skewed_square(rng, n, tname)
+    iso = seed % 5 == 3
+    if iso:
+        vals = np.full(rows.size, vals[0])
+    ui, uv = rand_vec(rng, n, [1.0, 0.5, 0.05][seed % 3], tname)
+    wi, wv = rand_vec(rng, n, 0.5, tname)
+    mi, mv = rand_vec(rng, n, 0.5, "BOOL")
+    accum = [None, "plus", "min"][seed % 3]
+    comp, repl, struct = bool(seed & 1), bool(seed & 2), bool(seed & 4)
+    oa = O.OMat.from_coo(rows, cols, vals, n, n, tname)
+    ou, ow, om = O.OVec(n, ui, uv, tname), O.OVec(n, wi, wv, tname), O.OVec(n, mi, mv, "BOOL")
+    exp = O.mxv(oa, ou, sr, w=ow, mask=om, mask_comp=comp, mask_struct=struct, accum=accum, replace=repl)
+    try:
+        set_opts(ORDER_OPTS + ((b"hot_k", [64, 256, 1 << 20][seed % 3]), (b"long_classes", [16, 8, 32][seed % 3])))
+        A = gb.Matrix.from_coo(rows, cols, vals, dtype=tname, nrows=n, ncols=n)
+        u = gb.Vector.from_coo(ui, uv, dtype=tname, size=n)
+        w = gb.Vector.from_coo(wi, wv, dtype=tname, size=n)
+        mk = gb.Vector.from_coo(mi, mv, dtype="BOOL", size=n)
+        m_arg = (mk.S if struct else mk.V)
+        w(~m_arg if comp else m_arg, accum=accum, replace=repl) << A.mxv(u, getattr(gb.semiring, sr))
+        st = device.last_stats()
+        by_rowlen = sr in ("any_pair",) and len(ui) == n
+        assert by_rowlen or (st["ordered"] == 1 and st["long_kernel"] == 4 and st["reorders"] >= 1), st
+        same_vec(w, exp)  # (to_coo brings w back to the natural order)
+        # the same call again: the operands that stayed in the library are still in the matrix's order
+        w2 = gb.Vector.from_coo(wi, wv, dtype=tname, size=n)
+        w2(~m_arg if comp else m_arg, accum=accum, replace=repl) << A.mxv(u, getattr(gb.semiring, sr))
+        st = device.last_stats()
+        # (only the fresh w2 -- and not even that when nothing of it survives the call: no accumulator and replace)
+        assert by_rowlen or (st["ordered"] == 1 and st["reorders"] == (0 if accum is None and repl else 1)), st
+        same_vec(w2, exp)
+        # plain product into a new vector, vxm over the transpose (same order), a product in another type (natural path)
+        same_vec(A.mxv(u, getattr(gb.semiring, sr)).new(), O.mxv(oa, ou, sr))
+        xi, xv = rand_vec(rng, n, 0.6, tname)
+        x = gb.Vector.from_coo(xi, xv, dtype=tname, size=n)
+        same_vec(x.vxm(A, getattr(gb.semiring, sr)).new(), O.vxm(O.OVec(n, xi, xv, tname), oa, sr))
+        same_vec(A.T.mxv(x, getattr(gb.semiring, sr)).new(), O.mxv(oa, O.OVec(n, xi, xv, tname), sr, transpose_a=True))
+        if tname != "FP64":  # (a semiring of another type than the matrix: typecast copies, natural order)
+            same_vec(A.mxv(u, gb.semiring.plus_times["FP64"]).new(),
+                     O.mxv(O.OMat.from_coo(rows, cols, vals.astype(np.float64), n, n, "FP64"), O.OVec(n, ui, uv.astype(np.float64), "FP64"), "plus_times"))
+            assert device.last_stats()["ordered"] == 0
+        # the operand itself is unchanged by all of this
+        same_vec(u, ou)
+        same_vec(mk, om)
+    finally:
+        set_opts(RESTORE)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_ordered_vectors_through_every_exit(gb, seed):
+    """A vector that the library keeps in a matrix's order must look like any other vector from outside."""
+    from graphblas_amd import device
+
+    rng = np.random.default_rng(4300 + seed)
+    tname = ["FP32", "INT64", "FP64", "INT32"][seed]
+    n = int(rng.integers(2100, 3000))
+    rows, cols, vals = skewed_square(rng, n, tname)
+    oa = O.OMat.from_coo(rows, cols, vals, n, n, tname)
+    ui, uv = rand_vec(rng, n, 0.7, tname)
+    ou = O.OVec(n, ui, uv, tname)
+    try:
+        set_opts(ORDER_OPTS + ((b"hot_k", 256),))
+        A = gb.Matrix.from_coo(rows, cols, vals, dtype=tname, nrows=n, ncols=n)
+        u = gb.Vector.from_coo(ui, uv, dtype=tname, size=n)
+        w = A.mxv(u, gb.semiring.min_plus).new()
+        assert device.last_stats()["ordered"] == 1
+        exp = O.mxv(oa, ou, "min_plus")
+        dense = np.zeros(n, O.NP_OF[tname])
+        dense[exp.idx] = exp.vals
+        has = np.zeros(n, bool)
+        has[exp.idx] = True
+        # element access on the ordered vector (no conversion: the position is looked up)
+        for i in list(exp.idx[:3]) + ([int(np.flatnonzero(~has)[0])] if (~has).any() else []):
+            got = w[int(i)].value
+            assert (got is None and not has[i]) or got == dense[i], (i, got)
+        assert w.nvals == exp.idx.size
+        # reduce, dup, isequal, element-wise with a NATURAL vector, scalar assignment under the ordered vector as a mask
+        assert w.reduce(gb.monoid.min).new().value == (exp.vals.min() if exp.idx.size else None)
+        d = w.dup()
+        assert d.isequal(w)
+        same_vec(d, exp)
+        yi, yv = rand_vec(rng, n, 0.5, tname)
+        y = gb.Vector.from_coo(yi, yv, dtype=tname, size=n)
+        w2 = A.mxv(u, gb.semiring.min_plus).new()  # ordered again
+        z = w2.ewise_add(y, gb.binary.plus).new()
+        oz = O.OVec(n, *ewise_np(exp, O.OVec(n, yi, yv, tname), n, tname, add=True), tname)
+        same_vec(z, oz)
+        z2 = w2.ewise_mult(y, gb.binary.min).new()
+        same_vec(z2, O.OVec(n, *ewise_np(exp, O.OVec(n, yi, yv, tname), n, tname, add=False), tname))
+        t = gb.Vector(tname, size=n)
+        t(mask=w2.S) << 7
+        ti, tv = t.to_coo()
+        assert ti.tolist() == exp.idx.tolist() and set(tv.tolist()) <= {7}
+        # setElement / removeElement on the ordered vector, then the whole content
+        w3 = A.mxv(u, gb.semiring.min_plus).new()
+        w3[5] = 3
+        del w3[int(exp.idx[0])]
+        dense2, has2 = dense.copy(), has.copy()
+        dense2[5], has2[5] = 3, True
+        has2[exp.idx[0]] = False
+        gi, gv = w3.to_coo()
+        assert gi.tolist() == np.flatnonzero(has2).tolist() and gv.tolist() == dense2[has2].tolist()
+        # a product with an ordered OUTPUT that is then an INPUT (the loop case): w4 = A min.+ (A min.+ u)
+        w4 = A.mxv(w2, gb.semiring.min_plus).new()
+        st = device.last_stats()
+        assert st["ordered"] == 1 and st["reorders"] == 0, st
+        same_vec(w4, O.mxv(oa, exp, "min_plus"))
+        # the HBM image handed out to torch / RCCL is the natural one
+        vals_t, words_t = device.vector_device_views(w2, "cuda" if _on_gpu() else "cpu")
+        words = np.asarray(words_t.cpu()).view(np.uint32)
+        bits = np.unpackbits(words.view(np.uint8), bitorder="little")[:n].astype(bool)
+        assert bits.tolist() == has.tolist()
+        assert np.asarray(vals_t.cpu())[has].tolist() == dense[has].tolist()
+    finally:
+        set_opts(RESTORE)
+
+
+def _on_gpu():
+    from tests import backend
+
+    return backend._bound == "gpu"
+
+
+def ewise_np(a, b, n, tname, add):
+    da, db = np.zeros(n, O.NP_OF[tname]), np.zeros(n, O.NP_OF[tname])
+    ha, hb = np.zeros(n, bool), np.zeros(n, bool)
+    da[a.idx], ha[a.idx] = a.vals, True
+    db[b.idx], hb[b.idx] = b.vals, True
+    if add:
+        out = np.where(ha & hb, da + db, np.where(ha, da, db))
+        has = ha | hb
+    else:
+        out = np.minimum(da, db)
+        has = ha & hb
+    return np.flatnonzero(has), out[has].astype(O.NP_OF[tname])
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_sssp_and_bfs_loops_stay_ordered(gb, seed):
+    """The reference's traversal loops (docs/getting_started/primer.rst:236-246, notebooks Example B.1) on an ordered matrix: after the first
+    sweep no vector is converted again, and the results are the oracle's."""
+    from graphblas_amd import device
+
+    rng = np.random.default_rng(4500 + seed)
+    n = int(rng.integers(2100, 2600))
+    rows, cols, vals = skewed_square(rng, n, "FP32")
+    oa = O.OMat.from_coo(rows, cols, vals, n, n, "FP32")
+    src = int(rows[np.argmax(np.bincount(rows, minlength=n)[rows])])
+    try:
+        set_opts(ORDER_OPTS + ((b"hot_k", 256),))
+        G = gb.Matrix.from_coo(rows, cols, vals, dtype="FP32", nrows=n, ncols=n)
+        v = gb.Vector("FP32", size=n)
+        v[src] = 0
+        ov = O.OVec(n, np.array([src]), np.array([0], np.float32), "FP32")
+        conversions = []
+        for it in range(n):
+            w = v.dup()
+            v(gb.binary.min) << v.vxm(G, gb.semiring.min_plus)
+            conversions.append(device.last_stats()["reorders"])
+            ov = O.vxm(ov, oa, "min_plus", w=ov, accum="min")
+            if v.isequal(w):
+                break
+        same_vec(v, ov)
+        assert it >= 2 and sum(conversions[1:]) == 0, conversions  # (the first sweep converts v; after that everything stays)
+    finally:
+        set_opts(RESTORE)
