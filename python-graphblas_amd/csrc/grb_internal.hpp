@@ -325,6 +325,7 @@ struct GB_Matrix_opaque {
     int ord_state = 0;                 // 0 = not analysed, 1 = `ord` is built, -1 = not worth it / not possible
     uint64_t ord_sig = 0;              // the layout options `ord` was built under
     bool hot_identity = false;         // (an `ord` twin) d_col_hot aliases d_col: codes are positions; codes >= hot_k are not offset by hot_k
+    int64_t ord_live_rows = 0;         // (an `ord` twin) rows at and behind this position are empty
     int32_t *d_cold_bounds = nullptr;  // (an `ord` twin) first code of every column range of the cold tiles (ct_ncr + 1 values)
     int32_t *d_ct_order = nullptr;     // (cold tiles) tile numbers in the order the XCDs walk them: XCD x takes d_ct_order[ct_xoff[x] .. ct_xoff[x + 1])
     int64_t ct_xoff[9] = {0};

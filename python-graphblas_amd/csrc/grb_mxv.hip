@@ -296,14 +296,15 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
             }
             // kind 4: the sorted entries are [hot: virtual classes 0 .. ncls - 1 | cold: column ranges ncls .. ncls + n_cr - 1]; the hot
             // part becomes strips (lane records), the cold part tagged tiles (grb_mxv_ctile.inc)
-            const int n_sb = (int)ceil_div(nl, (int64_t)CT_SLOTS);
+            const int ct_slots = A->type->size > 4 ? CT_SLOTS / 2 : CT_SLOTS;  // (CtSlots<W>: 8-byte accumulators take half the slots)
+            const int n_sb = (int)ceil_div(nl, (int64_t)ct_slots);
             const int64_t n_tiles = kind == 4 ? (int64_t)n_cr * n_sb : 0;
             std::vector<int64_t> h_first((size_t)n_tiles + 1, 0);
             DevBuf<int64_t> tile_first(n_tiles + 1);
             int64_t n_strip = nnz_long;
             if (kind == 4) {
                 hipLaunchKernelGGL(k_ctile_first, dim3((unsigned)ceil_div(n_tiles + 1, 256)), dim3(256), 0, ctx().stream, (const uint64_t *)keys2.p, nnz_long,
-                                   n_tiles, n_sb, (unsigned)ncls, tile_first.p);
+                                   n_tiles, n_sb, (unsigned)ncls, tile_first.p, ct_slots);
                 d2h(h_first.data(), tile_first.p, sizeof(int64_t) * (size_t)(n_tiles + 1));
                 n_strip = h_first[0];
             }
@@ -419,7 +420,7 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
                         CTile ct;
                         ct.u0 = units;
                         ct.n_units = (int32_t)ceil_div(e1 - e0, (int64_t)CT_EPL);
-                        ct.base = (int32_t)((t % n_sb) * (int64_t)CT_SLOTS);
+                        ct.base = (int32_t)((t % n_sb) * (int64_t)ct_slots);
                         units += ct.n_units;
                         h_tiles.push_back(ct);
                         h_efirst.push_back(e0);
@@ -471,11 +472,22 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
                 if (A->d_ct_val) GRB_HIP(hipMemsetAsync(A->d_ct_val, 0, A->type->size * ents, ctx().stream));
                 GRB_HIP(hipMemsetAsync(A->d_ct_loc, 0, sizeof(uint16_t) * ents, ctx().stream));
                 const int64_t n_cold = nnz_long - n_strip;
-                GRB_DISPATCH_TYPE(A->type->code, T, {
-                    hipLaunchKernelGGL((k_ctile_place<T>), dim3((unsigned)ceil_div(n_cold, 256)), dim3(256), 0, ctx().stream, (const uint64_t *)keys2.p,
-                                       (const uint32_t *)idx2.p, n_strip, nnz_long, (const int64_t *)efirst.p, nt, (const CTile *)A->d_ct_tiles,
-                                       col_src, (const T *)A->d_val, A->iso ? 1 : 0, A->d_ct_col, (T *)A->d_ct_val, A->d_ct_loc);
-                })
+                {
+                    // inside a tile the entries go by column code: neighbouring lanes gather from the same lines (grb_mxv_ctile.inc)
+                    DevBuf<uint64_t> key2(n_cold), key2s(n_cold);
+                    DevBuf<uint32_t> pay(n_cold), pays(n_cold);
+                    hipLaunchKernelGGL(k_ctile_keys2, dim3((unsigned)ceil_div(n_cold, 256)), dim3(256), 0, ctx().stream, (const uint32_t *)idx2.p, n_strip, n_cold,
+                                       (const int64_t *)efirst.p, nt, col_src, key2.p, pay.p);
+                    int tbits = 1;
+                    while (((int64_t)1 << tbits) < nt) tbits++;
+                    prim_sort_pairs_u64_u32(key2.p, key2s.p, pay.p, pays.p, n_cold, 32 + tbits);
+                    GRB_DISPATCH_TYPE(A->type->code, T, {
+                        hipLaunchKernelGGL((k_ctile_place<T>), dim3((unsigned)ceil_div(n_cold, 256)), dim3(256), 0, ctx().stream, (const uint64_t *)keys2.p,
+                                           (const uint32_t *)idx2.p, n_strip, n_cold, (const uint64_t *)key2s.p, (const uint32_t *)pays.p, (const int64_t *)efirst.p,
+                                           (const CTile *)A->d_ct_tiles, (const T *)A->d_val, A->iso ? 1 : 0, A->d_ct_col, (T *)A->d_ct_val, A->d_ct_loc);
+                    })
+                    sync_stream();
+                }
                 A->ct_nsb = n_sb;
                 A->ct_ncr = n_cr;
                 A->ct_ntiles = nt;
@@ -679,6 +691,13 @@ static void ensure_ordered(GB_Matrix_opaque *S)
                                    (const T *)S->d_val, S->iso ? 1 : 0, (const int32_t *)P->d_inv, (const int32_t *)P->d_rank, (const int64_t *)R->d_ptr,
                                    R->d_col, (T *)R->d_val);
         })
+        {
+            DevBuf<unsigned long long> last(1, true);
+            hipLaunchKernelGGL(k_twin_live_rows, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx().stream, (const int64_t *)R->d_ptr, n, last.p);
+            unsigned long long h_last = 0;
+            d2h(&h_last, last.p, sizeof(h_last));
+            R->ord_live_rows = (int64_t)h_last;
+        }
         // ---- its column codes ARE the hot codes: positions below k_hot are the table, the operand is the image
         R->hot_state = 1;
         R->hot_k = k_hot;
@@ -696,8 +715,9 @@ static void ensure_ordered(GB_Matrix_opaque *S)
             d2h(h_blk.data(), blk.p, sizeof(int64_t) * (size_t)nblk);
             int64_t total = 0;
             for (int64_t b = 0; b < nblk; b++) total += h_blk[(size_t)b];
-            const int R_TARGET = 32, R_MAX = 48;
-            const int64_t cap_codes = std::max<int64_t>(g, ((int64_t)2 << 20) / (int64_t)std::max<size_t>(vb, 1)), target = std::max<int64_t>(1, total / R_TARGET);
+            const int R_TARGET = getenv("GRB_ORD_RANGES") ? std::max(1, std::min(48, atoi(getenv("GRB_ORD_RANGES")))) : 32, R_MAX = 48;
+            const int64_t cap_bytes = getenv("GRB_ORD_RANGE_KB") ? (int64_t)atoi(getenv("GRB_ORD_RANGE_KB")) << 10 : (int64_t)2 << 20;
+            const int64_t cap_codes = std::max<int64_t>(g, cap_bytes / (int64_t)std::max<size_t>(vb, 1)), target = std::max<int64_t>(1, total / R_TARGET);
             std::vector<int32_t> bounds;
             bounds.push_back((int32_t)lim);
             int64_t acc = 0, width = 0;
@@ -720,7 +740,9 @@ static void ensure_ordered(GB_Matrix_opaque *S)
         sync_stream();
         // ---- the layouts (hot strips, cold tiles, tagged row groups) in that order
         ensure_split(R, R->d_col_hot, true);
-        const bool usable = R->split_state == 1 && R->split_kind == 4 && R->long_nnz > 0 && (R->strip_nseg > 0 || R->ct_units > 0) && R->short_tagged_only;
+        // (hot strips + cold tiles, or -- BOOL matrices -- class items; the short rows as tagged row groups either way)
+        const bool usable = R->split_state == 1 && R->long_nnz > 0 && R->short_tagged_only &&
+                            ((R->split_kind == 4 && (R->strip_nseg > 0 || R->ct_units > 0)) || (R->split_kind == 1 && R->n_items > 0));
         if (!usable) {
             matrix_free(R);
             return;
@@ -957,7 +979,25 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
             b.tg_val = A->d_tg_val;
             b.tg_tag = A->d_tg_tag;
             b.tg_nonempty = A->d_tg_nonempty;
-            hipLaunchKernelGGL((k_mxv_rows_tag<T, MON, MUL>), dim3((unsigned)ceil_div(ceil_div(b.m, 64), (ROWS_BLOCK / 64) * TAG_K)), dim3(ROWS_BLOCK), 0,
+            int64_t groups = ceil_div(b.m, 64);
+            b.tg_groups = 0;
+            b.tg_stride = 0;
+            if (A->hot_identity && !b.fresh) {
+                // a matrix in its popularity order: rows sorted by falling weight, the empty ones at the end
+                const int64_t live_groups = std::max<int64_t>(1, ceil_div(A->ord_live_rows, 64));
+                if (live_groups < groups) {
+                    if (!(b.accum >= 0 && !b.replace)) {
+                        const int64_t tail = groups - live_groups;
+                        hipLaunchKernelGGL(k_rows_tail, dim3((unsigned)ceil_div(tail, 256)), dim3(256), 0, ctx().stream, b, live_groups);
+                        ctx().stats.kernel_launches += 1;
+                    }
+                    groups = live_groups;
+                    b.tg_groups = live_groups;
+                }
+                b.tg_stride = ceil_div(groups, TAG_K);
+                if (b.tg_groups == 0) b.tg_groups = groups;
+            }
+            hipLaunchKernelGGL((k_mxv_rows_tag<T, MON, MUL>), dim3((unsigned)ceil_div(ceil_div(groups, TAG_K), ROWS_BLOCK / 64)), dim3(ROWS_BLOCK), 0,
                                ctx().stream, b);
             GRB_HIP(hipGetLastError());
             ctx().stats.kernel_launches += 1;
@@ -1533,7 +1573,7 @@ static void mxv_any_order(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_
         ctx().stats.reorders = (int32_t)(ctx().reorder_count - reorders0);
         return;
     }
-    if (shapes_ok && ctx().order_mode && S->nrows == S->ncols && S->nvals >= ctx().order_min_nnz && S->type->code != TC_BOOL &&
+    if (shapes_ok && ctx().order_mode && S->nrows == S->ncols && S->nvals >= ctx().order_min_nnz &&
         sr->type == S->type->code && !w->pinned && !u->pinned && !(mask && mask->pinned) && S->d_col) {
         int mult = canonical_op(sr->type, sr->mult);
         if (flip) mult = flip_op(mult);
