@@ -85,6 +85,10 @@ def parse():
     p.add_argument("--share-gpus", action="store_true",
                    help="N > 1 rehearsal: ranks beyond the visible GPUs share devices (rank r on GPU r %% device_count; needs --backend gloo: "
                         "RCCL refuses two ranks on one device); the line is marked as a rehearsal and is no measurement")
+    p.add_argument("--force-dist", action="store_true",
+                   help="with ONE rank: initialise torch.distributed all the same and take the N-rank code path (sharded.OverlappedMxv with two "
+                        "replicas of u, all_gather_into_tensor on the library's memory, the sharded SpGEMM extra) -- a one-rank RCCL world "
+                        "proves on a single-GPU box that RCCL accepts the library's buffers; the numbers are no multi-GPU measurement")
     p.add_argument("--overlap-chunks", type=int, default=2,
                    help="N > 1: row blocks per rank; the all-gather of block c overlaps the product of block c + 1 (1 = no overlap)")
     return p.parse_args()
@@ -104,29 +108,30 @@ class MxvWorkload:
     of every block, each followed by the asynchronous all-gather of its w slices into the replica the NEXT step reads
     (sharded.OverlappedMxv) -- the exchange of block c runs while block c + 1 is computed."""
 
-    def __init__(self, gb, torch, scale, rank, world, semiring, visited_frac, seed=0, block=None, chunks=1):
+    def __init__(self, gb, torch, scale, rank, world, semiring, visited_frac, seed=0, block=None, chunks=1, force_dist=False):
         from graphblas_amd import _lib, device, sharded, synthetic
 
         self.gb, self.torch, self.rank, self.world = gb, torch, rank, world
+        sharded_path = (world > 1 or force_dist) and not block  # (--force-dist: the N-rank code path with one rank)
         n = 1 << scale
         # (--block r/w: this process computes rank r's rows of a w-way run, alone: no exchange)
         if block:
             assert n % (64 * block[1]) == 0
             rows = n // block[1]
             ranges = [(block[0] * rows, (block[0] + 1) * rows)]
-        elif world > 1:
+        elif sharded_path:
             ranges = sharded.chunk_blocks(n, rank, world, chunks)
         else:
             ranges = [(0, n)]
         self.ranges, self.n, self.block = ranges, n, block
         self.lo, self.hi = ranges[0]
         self.m = sum(hi - lo for lo, hi in ranges)
-        graphs = synthetic.rmat_csr(scale, device="cuda", row_ranges=ranges) if (block or world > 1) else [synthetic.rmat_csr(scale, device="cuda")]
+        graphs = synthetic.rmat_csr(scale, device="cuda", row_ranges=ranges) if (block or sharded_path) else [synthetic.rmat_csr(scale, device="cuda")]
         gen = torch.Generator(device="cuda")
         gen.manual_seed(4242 + seed)
         visited = torch.rand(n, generator=gen, device="cuda") < visited_frac
         self.semiring = semiring
-        n_u = 2 if (world > 1 and not block) else 1
+        n_u = 2 if sharded_path else 1
         if semiring == "min_plus":
             dist = torch.randint(0, 1000, (n,), generator=gen, device="cuda").to(torch.float32)
             self._dist = dist
@@ -490,14 +495,15 @@ def run_mxm(args, gb, torch, device, rank, world, dist, barrier, *, scale, workl
     ip_b, col_b = synthetic.rmat_csr(scale, device="cuda")
     # rows of A cut so that every rank carries the same number of multiplies (not the same number of rows): no collective
     # constrains the block sizes here
-    if world > 1:
+    sharded_path = world > 1 or args.force_dist  # (--force-dist: the flop-balanced cuts and the row view of A with one rank)
+    if sharded_path:
         cuts = sharded.balanced_cuts(sharded.flops_prefix(ip_b, col_b, ip_b[1:] - ip_b[:-1]), world)
         lo, hi = cuts[rank], cuts[rank + 1]
     else:
         lo, hi = 0, n
     one = torch.ones(1, dtype=torch.int64, device="cuda")
     B = device.matrix_from_device_csr(ip_b, col_b, one, n, n, "INT64", iso=True)
-    if world > 1:
+    if sharded_path:
         ip_a = (ip_b[lo: hi + 1] - ip_b[lo]).contiguous()
         col_a = col_b[ip_b[lo]: ip_b[hi]].contiguous()
         A = device.matrix_from_device_csr(ip_a, col_a, one, hi - lo, n, "INT64", iso=True)
@@ -588,7 +594,7 @@ def main_mxm(args, gb, torch, device, rank, world, dist, barrier):
     line = run_mxm(args, gb, torch, device, rank, world, dist, barrier, scale=args.scale, workload=args.workload, steps=args.steps,
                    warmup=args.warmup, want_cpu=(world == 1))
     if rank == 0:
-        print(json.dumps(line))
+        emit(line)
     if dist is not None:
         dist.destroy_process_group()
 
@@ -666,7 +672,7 @@ def main_uniform(args, gb, torch, device, rank, world):
     nnz = int(r.size)
     alg = algorithmic_bytes_mxv(nnz, n, n, 8, 8, 8, accum=False, mask=False)
     kernel_ms = ev_ms / args.steps
-    print(json.dumps({
+    emit(({
         "metric": "GTEPS (mxv) on uniform 4096x4096 1% FP64", "value": nnz / dt / 1e9, "unit": "GTEPS", "n_gpus": 1, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic", "verified": verified,
@@ -722,7 +728,7 @@ def main_bfs(args, gb, torch, device, rank, world):
     idx, _lev = v.to_coo()
     visited = torch.from_numpy(idx.astype("int64")).cuda()
     edges = int(deg[visited].sum().item())
-    print(json.dumps({
+    emit(({
         "metric": "GTEPS (BFS traversal) on R-MAT scale-%d" % args.scale, "value": edges / dt / 1e9, "unit": "GTEPS", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "bool", "data": "synthetic",
@@ -769,13 +775,36 @@ def main_sssp(args, gb, torch, device, rank, world):
     idx, _d = v.to_coo()
     reached = torch.from_numpy(idx.astype("int64")).cuda()
     edges = int(deg[reached].sum().item())
-    print(json.dumps({
+    emit(({
         "metric": "GTEPS (SSSP) on R-MAT scale-%d" % args.scale, "value": edges / dt / 1e9, "unit": "GTEPS", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"rmat{args.scale} sssp: Bellman-Ford by vxm(min_plus) with accum min until isequal, whole loop through the C ABI",
                    "iterations": its, "reached_vertices": int(idx.size), "edges_counted_per_step": edges},
         "roofline": None, "cpu_baseline": None}))
+
+
+_REAL_STDOUT = None
+
+
+def claim_stdout():
+    """The driver reads ONE JSON line from stdout.  Libraries loaded later write there too (RCCL prints its version banner to the C
+    stdout when a communicator comes up): file descriptor 1 is pointed at stderr for the rest of the run and the line goes out through a
+    private copy of the original descriptor."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(line):
+    data = (json.dumps(line) + "\n").encode()
+    if _REAL_STDOUT is None:
+        sys.stdout.write(data.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_REAL_STDOUT, data)
 
 
 def respawn_under_launcher(args):
@@ -806,6 +835,7 @@ def main():
         args.workload, args.scale = "mxv_min_plus", 26
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.block:
         respawn_under_launcher(args)
+    claim_stdout()
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
@@ -827,8 +857,20 @@ def main():
         local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
+
+        if world == 1:  # (--force-dist without a launcher: a one-rank world on this process)
+            import socket
+
+            sock = socket.socket()
+            sock.bind(("127.0.0.1", 0))
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(sock.getsockname()[1]))
+            sock.close()
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -851,7 +893,7 @@ def main():
     def run(workload, scale, steps, warmup):
         sr = {"mxv_min_plus_masked": "min_plus", "mxv_lor_land_masked": "lor_land", "mxv_min_plus": "min_plus"}[workload]
         visited = 0.0 if workload == "mxv_min_plus" else args.visited
-        wl = MxvWorkload(gb, torch, scale, rank, world, sr, visited, block=block, chunks=max(1, args.overlap_chunks))
+        wl = MxvWorkload(gb, torch, scale, rank, world, sr, visited, block=block, chunks=max(1, args.overlap_chunks), force_dist=args.force_dist)
         # The first product of a matrix runs on its CSR arrays as they are; the second builds the cached layouts (hot-column coding,
         # long / short split, class strips).  Both are part of the warm-up and are timed apart (wall clock around a synchronised call).
         def timed_call():
@@ -904,12 +946,12 @@ def main():
             "edges_per_step": edges,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy_peak_6290": achieved / 6290.0,
-                         "traffic": measured_traffic(workload, scale) if (world == 1 and not block) else None,
+                         "traffic": measured_traffic(workload, scale) if (world == 1 and not block and wl.ov is None) else None,
                          "kernel": MXV_KERNELS_NOTE,
                          "kernel_ms_hip_events": kernel_ms, "algorithmic_bytes_per_launch": wl.bytes_per_step()},
             "stats": stats,
         }
-        if world > 1:
+        if wl.ov is not None:
             res["roofline"]["note"] = ("per rank: this rank's algorithmic bytes over the HIP-event time of its step on the library's stream "
                                        "(products + waits for the exchanges), max over ranks")
             res["exchange"] = {"chunks_per_rank": wl.ov.chunks, "replicas_of_u": 2, "staged_through_torch_buffers": wl.ov.staged,
@@ -945,7 +987,7 @@ def main():
     if args.workload in ("mxm_plus_times", "mxm_plus_times_masked", "mxm_plus_times_cmask"):
         return main_mxm(args, gb, torch, device, rank, world, dist, barrier)
     wl, res = run(args.workload, args.scale, args.steps, args.warmup)
-    cpu = cpu_line(wl) if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
+    cpu = cpu_line(wl) if (rank == 0 and world == 1 and not args.no_cpu_baseline and not args.force_dist) else None
     # ---- the rest of the BASELINE metric, in the same line under `extra`: the BFS level step (configs[2]) and SpGEMM A (+.x) A
     #      at scale 20 (one GPU: the materialised product) and scale 22 (configs[3]; row batches on one GPU, row-sharded on N) ----
     extra = []
@@ -962,13 +1004,13 @@ def main():
 
         freed()
         wl2, r = run("mxv_lor_land_masked", 24, args.steps, args.warmup)
-        c2 = cpu_line(wl2) if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
+        c2 = cpu_line(wl2) if (rank == 0 and world == 1 and not args.no_cpu_baseline and not args.force_dist) else None
         extra.append({"workload": "rmat24 mxv_lor_land_masked: q<~visited.S, replace> = A lor.land q, iso BOOL, frontier density 0.3 (configs[2])",
                       **{k: r[k] for k in ("value", "ms_per_step", "dtype", "roofline", "verified")}, "unit": "GTEPS", "cpu_baseline": c2})
         del wl2
         freed()
         for scale, steps, warmup, wk in ((20, 3, 1, "mxm_plus_times"), (20, 2, 1, "mxm_plus_times_cmask"), (22, 2, 1, "mxm_plus_times")):
-            if scale == 20 and world > 1:
+            if scale == 20 and (world > 1 or args.force_dist):
                 continue  # (the sharded runs carry the scale-22 product, the size the north star quotes for 1 -> 8 GPUs)
             try:
                 line = run_mxm(args, gb, torch, device, rank, world, dist, barrier, scale=scale, workload=wk, steps=steps,
@@ -999,7 +1041,7 @@ def main():
                        "edges_counted_per_step": res["edges_per_step"],
                        "parallelism": (f"rank {block[0]} of a {block[1]}-way row shard, compute only" if block else
                                        f"row-shard x{world}" + (f" ({res['exchange']['chunks_per_rank']} row blocks per rank) + RCCL all-gather of the w slices into "
-                                                                "the other replica of u, overlapped with the next block's product" if world > 1 else ""))},
+                                                                "the other replica of u, overlapped with the next block's product" if "exchange" in res else ""))},
             "verified": res["verified"],
             "first_call_ms": res["first_call_ms"],
             "layout_build_call_ms": res["layout_build_call_ms"],
@@ -1011,18 +1053,21 @@ def main():
         }
         if "exchange" in res:
             out["exchange"] = res["exchange"]
-        if args.share_gpus or args.backend != "nccl":
+        if args.share_gpus or args.backend != "nccl" or (args.force_dist and world == 1):
             out["rehearsal"] = (f"backend {args.backend}" + (", ranks share GPUs" if args.share_gpus else "") +
+                                (", ONE rank with --force-dist (a one-rank world: RCCL initialised, the collectives ran on the library's buffers)"
+                                 if args.force_dist and world == 1 else "") +
                                 ": the N-rank code path was exercised; the numbers are NOT a multi-GPU measurement")
         if extra:
             out["extra"] = extra
-        print(json.dumps(out))
+        emit(out)
     if dist is not None:
         dist.destroy_process_group()
 
 
-MXV_KERNELS_NOTE = ("one GrB_mxv call: k_mxv_hstrip + k_mxv_cstrip (k_mxv_long_grp for BOOL matrices) + k_mxv_rows_tag (+ k_x_image, k_long_init); "
-                    "k_mxv_pull + k_mxv_seams below the split threshold")
+MXV_KERNELS_NOTE = ("one GrB_mxv call: k_long_init + k_mxv_hstrip + k_mxv_ctile (k_long_compact_* + k_mxv_long_grp for BOOL matrices) + k_mxv_rows_tag "
+                    "(+ k_rows_tail when the write rule touches the empty tail) on the matrix's popularity-ordered layouts -- no per-call operand image; "
+                    "k_x_image in front of them on the natural-order layouts (order_mode 0, row blocks of a sharded run); k_mxv_pull + k_mxv_seams below the split threshold")
 
 
 if __name__ == "__main__":

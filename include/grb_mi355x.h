@@ -291,6 +291,10 @@ GrB_Info GrX_Matrix_isclose(bool *result, const GrB_Matrix A, const GrB_Matrix B
  * core/vector.py:392-420: a new object of the target type, then `rv << self`). */
 GrB_Info GrX_Matrix_dup_as(GrB_Matrix *C, const GrB_Type type, const GrB_Matrix A);
 GrB_Info GrX_Vector_dup_as(GrB_Vector *w, const GrB_Type type, const GrB_Vector u);
+/* Write the monoid's identity into the VALUE image of v wherever v holds no entry (for ANY, which has no identity: the smallest value of
+ * the type); the presence words stay.  The image can then be all-reduced as it is: the monoid all-reduce of the row-sharded vxm
+ * (sharded.allreduce_monoid; reference call graphblas/core/vector.py:1309-1378 run on N ranks). */
+GrB_Info GrX_Vector_fill_absent(GrB_Vector v, const GrB_Monoid monoid);
 /* Device bytes of the SpMV layouts cached with A so far (hot-coded columns, short part, long-row strips / items). */
 GrB_Info GrX_Matrix_cache_bytes(const GrB_Matrix A, uint64_t *bytes);
 /* Tuning / diagnostics knobs (also read from the environment at GrB_init as GRB_<NAME upper-case>):

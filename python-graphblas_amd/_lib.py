@@ -129,6 +129,7 @@ def _declare(L):
     L.GrX_Vector_export_dense_device.argtypes = [P(c_void_p), P(c_void_p), c_void_p]
     L.GrX_Vector_modified.argtypes = [c_void_p]
     L.GrX_Vector_pin_natural.argtypes = [c_void_p, ctypes.c_int]
+    L.GrX_Vector_fill_absent.argtypes = [c_void_p, c_void_p]
     L.GrB_Vector_assign.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_u64, c_void_p]
     L.GrB_Vector_extract.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_u64, c_void_p]
     L.GrX_option_set.argtypes = [ctypes.c_char_p, ctypes.c_int64]

@@ -57,6 +57,14 @@ __global__ void k_assign_all(int64_t n, T *val, uint64_t *bits, const uint64_t *
     if (lane == 0 && g < nwords) bits[g] = b;
 }
 
+// val[i] = ident wherever bit i is clear (the partial product of a rank before the monoid all-reduce, sharded.allreduce_monoid)
+template <typename T>
+__global__ void k_fill_absent(T *val, const uint64_t *bits, int64_t n, T ident)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && !((bits[i >> 6] >> (i & 63)) & 1ull)) val[i] = ident;
+}
+
 template <typename W>
 __global__ void k_fill_one(W *p, W v)
 {
@@ -573,6 +581,28 @@ extern "C" GrB_Info GrB_Vector_extract(GrB_Vector w, const GrB_Vector mask, cons
         extract_indexed(w, mask, accum, u, indices, nindices, desc);
     }
     GRB_CATCH(errp(w))
+}
+
+// Write the monoid's identity into the positions of v that hold no entry (ANY, which has none: the smallest value of the type, so
+// that a rank without the entry never wins a MAX) -- the values image can then go through an all-reduce as it is.  The presence words
+// are untouched: v still holds the same entries.
+extern "C" GrB_Info GrX_Vector_fill_absent(GrB_Vector v, const GrB_Monoid monoid)
+{
+    GRB_TRY
+    require_init();
+    check_vector(v, "v");
+    if (!monoid) fail(GrB_NULL_POINTER, "monoid is NULL");
+    if (monoid->type != v->type->code) fail(GrB_DOMAIN_MISMATCH, "GrX_Vector_fill_absent: the monoid's type must be the vector's");
+    if (v->n == 0) return GrB_SUCCESS;
+    vector_ensure_storage(v);
+    const int op = canonical_op(monoid->type, monoid->op);
+    GRB_DISPATCH_TYPE(v->type->code, T, {
+        const T ident = op == OP_ANY ? (std::is_same<T, bool>::value ? (T)0 : type_lowest<T>()) : (T)monoid_identity<T, T>(op);
+        hipLaunchKernelGGL((k_fill_absent<T>), dim3((unsigned)ceil_div((int64_t)v->n, 256)), dim3(256), 0, ctx().stream, (T *)v->d_val,
+                           (const uint64_t *)v->d_bits, (int64_t)v->n, ident);
+    })
+    if (ctx().blocking) sync_stream();
+    GRB_CATCH(errp(v))
 }
 
 extern "C" GrB_Info GrB_Vector_removeElement(GrB_Vector w, GrB_Index i)

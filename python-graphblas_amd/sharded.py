@@ -316,32 +316,40 @@ class OverlappedMxv:
 _REDUCE_OF = {"min": "MIN", "max": "MAX", "plus": "SUM", "lor": "MAX", "land": "MIN", "any": "MAX"}
 
 
-def allreduce_monoid(t, monoid_name, identity, *, device="cuda"):
-    """Combine the ranks' PARTIAL products t (same size on every rank) with the monoid, in place: entries a rank does not have
-    are set to the monoid's identity, the values are all-reduced with the matching collective operator (ncclMin / ncclMax /
-    ncclSum; lor = max and land = min on 0/1), the presence words with a bit-or.  Returns nothing; t then holds the full product
-    on every rank."""
+def allreduce_monoid(t, monoid_name, identity=None, *, device="cuda"):
+    """Combine the ranks' PARTIAL products t (same size on every rank) with the monoid, in place: the library writes the monoid's
+    identity under the entries a rank does not have (GrX_Vector_fill_absent: one pass over the vector, no n-element temporaries; for
+    ANY, which has no identity, the smallest value of the type, so that a rank without the entry never wins the MAX), the value image
+    is all-reduced with the matching collective operator (ncclMin / ncclMax / ncclSum; lor = max and land = min on 0/1), the
+    presence words with a bit-or.  Returns nothing; t then holds the full product on every rank.  (``identity`` is kept for old
+    callers: the library derives it from the monoid.)"""
     import torch
     import torch.distributed as dist
 
+    from . import _lib, operators
     from . import device as dev
+    from .base import call_on
 
     if monoid_name not in _REDUCE_OF:
         raise NotImplementedError(f"no collective operator for the monoid {monoid_name!r} (times / lxor / lxnor need a gather + local fold)")
+    mon = getattr(operators.monoid, monoid_name)[t.dtype]
     vals, words = dev.vector_device_views(t, device, pin=True)
-    n = vals.numel()
-    shifts = torch.arange(32, device=words.device, dtype=torch.int32)
-    present = ((words.view(-1, 1) >> shifts) & 1).to(torch.bool).view(-1)[:n]
+    call_on(t, "GrX_Vector_fill_absent", [t._handle, mon._carg])
     as_num = vals.view(torch.uint8) if vals.dtype == torch.bool else vals
-    if monoid_name == "any":
-        # ANY has no identity: a rank without the entry must never win the MAX, so it contributes the smallest value of the
-        # type (then the result is one of the ranks' products whatever their signs -- any of them is a valid ANY)
-        identity = (-float("inf") if as_num.dtype.is_floating_point else
-                    (0 if as_num.dtype == torch.uint8 else torch.iinfo(as_num.dtype).min))
-    ident = torch.as_tensor(identity, dtype=as_num.dtype, device=as_num.device)
-    as_num.copy_(torch.where(present, as_num, ident))
     dist.all_reduce(as_num, op=getattr(dist.ReduceOp, _REDUCE_OF[monoid_name]))
-    dist.all_reduce(words, op=dist.ReduceOp.BOR)
+    # presence: the bit-or of the ranks' words.  RCCL / NCCL have no bitwise reduction (ProcessGroupNCCL refuses ReduceOp.BOR -- found
+    # by the first run on RCCL, profiles/r04/rccl_one_rank.txt): the packed words of all ranks are gathered (n / 8 bytes per rank) and
+    # folded locally
+    world = dist.get_world_size()
+    if dist.get_backend() == "nccl" or world == 1:
+        gathered = torch.empty(world * words.numel(), dtype=words.dtype, device=words.device)
+        _gather(dist, gathered, words.contiguous())
+        acc = gathered[: words.numel()].clone()
+        for r in range(1, world):
+            acc |= gathered[r * words.numel(): (r + 1) * words.numel()]
+        words.copy_(acc)
+    else:
+        dist.all_reduce(words, op=dist.ReduceOp.BOR)
     dev.vector_modified(t)
 
 

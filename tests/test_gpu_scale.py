@@ -591,3 +591,32 @@ def test_mxm_bench_sizes_with_independent_checks(gb, scale, workload):
     else:
         assert cfg["nnz_C"] <= cfg["nnz_A"]
     device.trim_memory()
+
+
+@pytest.mark.gpu
+def test_rccl_one_rank_world():
+    """RCCL runs on the library's own device memory: a one-rank `nccl` world in a process of its own (tests/nccl_one_rank.py) drives the
+    overlapped all-gather step (values, values + presence words), the probe exchange and the monoid all-reduce of the row-sharded vxm,
+    each checked against the same product without the exchange; then bench.py's N-rank path with one rank (--force-dist): the masked
+    relaxation through sharded.OverlappedMxv and the row-sharded SpGEMM, both `verified`."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "nccl_one_rank.py")], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])  # (RCCL prints its banner to stdout as well)
+    assert out["backend"] == "nccl" and out["ok"], out
+    for args in (["--scale", "20", "--steps", "3", "--warmup", "3", "--no-extra", "--no-cpu-baseline"],
+                 ["--workload", "mxm_plus_times", "--scale", "17", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"]):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force-dist", "--backend", "nccl"] + args, capture_output=True, text=True,
+                           timeout=900, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        assert len(r.stdout.strip().splitlines()) == 1, r.stdout[-2000:]  # (bench.py keeps stdout to its one JSON line)
+        line = json.loads(r.stdout)
+        assert line["verified"] is True, line
+        if "exchange" in line:
+            assert line["exchange"]["collective"].startswith("all_gather_into_tensor") and "rehearsal" in line
