@@ -252,6 +252,8 @@ GrB_Info GrX_Vector_pin_natural(GrB_Vector v, int pinned);
 GrB_Info GrX_Vector_modified(GrB_Vector v);
 /* Build and cache the transpose now (otherwise built lazily on the first T0/vxm use). */
 GrB_Info GrX_Matrix_cache_transpose(GrB_Matrix A);
+/* The hipStream_t the library launches on (NULL: the null stream). */
+GrB_Info GrX_get_stream(void **hip_stream);
 /* Launch on this hipStream_t (default: the null stream, which orders with torch's default stream). */
 GrB_Info GrX_set_stream(void *hip_stream);
 GrB_Info GrX_synchronize(void);
@@ -326,9 +328,8 @@ GrB_Info GrX_Matrix_cache_bytes(const GrB_Matrix A, uint64_t *bytes);
  *   "long_classes"  column classes of the class strips: 8, 16 (default), 32 or 64 distinct LDS heads across the chip
  *   "short_kernel"  short rows of a split matrix: 6 (default) by size -- 5 from "lean_min_nnz" entries, 1 below; 5 tagged row groups (the
  *                   row of every entry stored with it, k_mxv_rows_tag),
- *                   1 one wavefront per 64 rows with row marks and a segmented fold (k_mxv_rows), 0 merge-path tiles, 2 sliced ELLPACK
- *                   with a lane per row ("sell_sigma" rows per sort window; measured slower), 3 persistent
- *                   workgroups with an LDS head, 4 a lane per row folding products staged in LDS (both measured slower)
+ *                   1 one wavefront per 64 rows with row marks and a segmented fold (k_mxv_rows), 0 merge-path tiles.  (2 / 3 / 4 were
+ *                   three alternatives measured slower in rounds 1-2 -- DESIGN.md section 4.1.3 -- and are GrB_INVALID_VALUE now.)
  *   "long_sub"      sub-ranges per class of the cold columns of the long rows (0 = sized from the operand image),
  *   "long_sub_min_len"  for rows from this many entries (0 = 512 per sub-range)
  *   "mxm_mask_mode" mask-driven SpGEMM for non-complemented masks: 1 (default) when the product costs clearly more than the mask,

@@ -130,6 +130,7 @@ def _declare(L):
     L.GrX_Vector_modified.argtypes = [c_void_p]
     L.GrX_Vector_pin_natural.argtypes = [c_void_p, ctypes.c_int]
     L.GrX_Vector_fill_absent.argtypes = [c_void_p, c_void_p]
+    L.GrX_get_stream.argtypes = [P(c_void_p)]
     L.GrB_Vector_assign.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_u64, c_void_p]
     L.GrB_Vector_extract.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_u64, c_void_p]
     L.GrX_option_set.argtypes = [ctypes.c_char_p, ctypes.c_int64]

@@ -198,7 +198,7 @@ extern "C" GrB_Info GrB_init(GrB_Mode mode)
     // tuning knobs from the environment go through the same validation as GrX_option_set (an invalid value is ignored)
     static const struct { const char *env, *opt; } knobs[] = {
         {"GRB_PULL_IPT", "pull_ipt"}, {"GRB_HOT_MIN_COLS", "hot_min_cols"}, {"GRB_HOT_K", "hot_k"}, {"GRB_PUSH_MODE", "push_mode"},
-        {"GRB_ALLOC_CACHE", "alloc_cache"}, {"GRB_SHORT_KERNEL", "short_kernel"}, {"GRB_SELL_SIGMA", "sell_sigma"},
+        {"GRB_ALLOC_CACHE", "alloc_cache"}, {"GRB_SHORT_KERNEL", "short_kernel"},
         {"GRB_LAZY_LAYOUT", "lazy_layout"}, {"GRB_MXM_HEAVY_KERNEL", "mxm_heavy_kernel"}, {"GRB_DROP_HOT_COLS", "drop_hot_cols"},
         {"GRB_MXM_UNIT_MIN_FLOPS", "mxm_unit_min_flops"}, {"GRB_MXM_UNIT_MIN_PER_WINDOW", "mxm_unit_min_per_window"},
         {"GRB_MXM_UNIT_SMALL", "mxm_unit_small"}, {"GRB_MXM_UNIT_DENSE", "mxm_unit_dense"}, {"GRB_MXM_UNIT_MID", "mxm_unit_mid"},
@@ -244,6 +244,15 @@ extern "C" GrB_Info GrX_set_stream(void *hip_stream)
     dev_cache_release();  // cached blocks were last used on the old stream
     sync_stream();
     ctx().stream = static_cast<hipStream_t>(hip_stream);
+    GRB_CATCH(nullptr)
+}
+
+extern "C" GrB_Info GrX_get_stream(void **hip_stream)
+{
+    GRB_TRY
+    require_init();
+    if (!hip_stream) fail(GrB_NULL_POINTER, "hip_stream is NULL");
+    *hip_stream = (void *)ctx().stream;
     GRB_CATCH(nullptr)
 }
 
@@ -310,13 +319,16 @@ extern "C" GrB_Info GrX_option_set(const char *name, int64_t value)
     else if (n == "push_mode") c.push_mode = (int)value;
     else if (n == "split_min_nnz") c.split_min_nnz = value;
     else if (n == "split_min_len") c.split_min_len = (int)std::max<int64_t>(0, std::min<int64_t>(value, 1 << 30));
-    else if (n == "short_kernel") c.short_kernel = (int)value;
+    else if (n == "short_kernel") {
+        // (2 = sliced ELLPACK, 3 = persistent row groups with an LDS head, 4 = a lane per row: measured slower in rounds 1-2, removed)
+        if (value < 0 || value > 6 || value == 2 || value == 3 || value == 4) return GrB_INVALID_VALUE;
+        c.short_kernel = (int)value;
+    }
     else if (n == "lazy_layout") c.lazy_layout = (int)value;
     else if (n == "lazy_min_nnz") c.lazy_min_nnz = value;
     else if (n == "lean_min_nnz") c.lean_min_nnz = value < 0 ? 0 : value;
     else if (n == "long_kernel") c.long_kernel = (int)value;
     else if (n == "long_classes") c.long_classes = (value == 16 || value == 32 || value == 64) ? (int)value : 8;
-    else if (n == "sell_sigma") c.sell_sigma = (int)value;
     else if (n == "long_sub") c.long_sub = (int)std::max<int64_t>(0, std::min<int64_t>(value, 16));
     else if (n == "long_sub_min_len") c.long_sub_min_len = (int)value;
     else if (n == "mxm_mask_mode") c.mxm_mask_mode = (int)value;

@@ -90,11 +90,11 @@ struct Context {
                             // the mixed class strips, 2 = mixed class strips (k_mxv_strip), 1 = class-partitioned items (k_mxv_long_grp),
                             // 0 = chunk kernel (k_mxv_long)
     int short_kernel = 6;   // short rows of a split matrix: 6 = by size (tagged row groups from lean_min_nnz entries, row groups below), 5 = tagged
-                            // row groups (k_mxv_rows_tag), 1 = row-group kernel (k_mxv_rows), 0 = merge-path kernel, 2 = sliced ELLPACK
-                            // (k_mxv_sell), 3 = persistent row groups with an LDS head, 4 = a lane per row
+                            // row groups (k_mxv_rows_tag), 1 = row-group kernel (k_mxv_rows), 0 = merge-path kernel.  (2 / 3 / 4 -- sliced
+                            // ELLPACK, persistent row groups with an LDS head, a lane per row -- were measured slower in rounds 1-2 and are
+                            // gone from the tree: DESIGN.md section 4.1.3 keeps their numbers)
     int64_t lean_min_nnz = 48ll << 20;  // the round-3 layouts pay from about this many entries (measured: one rank's block of an 8-way
                             // scale-24 run -- 33 M entries -- 0.130 ms on the round-2 layouts against 0.144, scale 22 -- 67 M -- 0.203 against 0.190)
-    int sell_sigma = 4096;  // rows per sort window of the sliced-ELLPACK form
     GrX_Stats stats{};
     int debug_flags = 0;    // GRB_DEBUG: kernel ablation switches (benchmark diagnostics only)
     int tune_pull_ipt = 0;  // GRB_PULL_IPT: merge items per thread of the pull SpMV (0 = default)
@@ -298,15 +298,7 @@ struct GB_Matrix_opaque {
     int64_t ct_units = 0;
     int split_kind = 0;                // value of the long_kernel option the split was built for
     int pull_calls = 0;                // pull products run on this matrix since its layouts were last dropped
-    // the short rows once more in sliced-ELLPACK form (k_mxv_sell; built on first use when short_kernel = 2)
-    int32_t *d_sell_perm;
-    int64_t *d_sell_off;
-    uint32_t *d_sell_order;   // slices by falling length (launch order)
-    int32_t *d_sell_col;
-    void *d_sell_val;
-    int64_t sell_slices, sell_slots;
-    int sell_state;           // 0 = not built, 1 = built
-    // ... or as tagged row groups (k_mxv_rows_tag; short_kernel = 5): per group of 64 rows its entries contiguous, padded to a
+    // the short rows as tagged row groups (k_mxv_rows_tag; short_kernel = 5): per group of 64 rows its entries contiguous, padded to a
     // multiple of 4, one byte per entry naming its row inside the group (64 = padding)
     int32_t *d_tg_off = nullptr;       // per group (+1): first entry / 4
     int32_t *d_tg_col = nullptr;

@@ -38,9 +38,6 @@ namespace grb {
 #include "grb_mxv_rows.inc"
 #include "grb_mxv_rows_tag.inc"
 #include "grb_mxv_ctile.inc"
-#ifdef GRB_EXPERIMENTAL_KERNELS  // the short-row kernels that were measured slower: `make experimental`
-#include "grb_mxv_sell.inc"
-#endif
 #include "grb_mxv_split_build.inc"
 #include "grb_mxv_write.inc"
 #include "grb_mxv_push.inc"
@@ -174,7 +171,9 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
     const int kind = lk == 3 ? (A->type->code == TC_BOOL ? 1 : 2) : (lk == 5 ? (A->type->code == TC_BOOL ? 1 : (big ? 4 : 2)) : lk);
     // (the short part holds its entries either as CSR arrays or, for the tagged row groups, in that layout alone: another short-row
     //  kernel than the one the split was built for rebuilds it)
-    const bool want_tagged_only = short_kernel_for(A) == 5;
+    // (the tagged groups number their units with 31 bits and their entries with 33: beyond that the short part keeps its CSR arrays
+    //  and the row-group kernel -- the same guard as where short_tagged_only is set, or the split would be rebuilt at every call)
+    const bool want_tagged_only = short_kernel_for(A) == 5 && A->nvals < 0x1ffffffffll;
     if (A->split_state != 0 && (A->split_state < 0 || (A->split_hot == hot && A->split_kind == kind && A->short_tagged_only == want_tagged_only &&
                                                        ((A->split_kind != 2 && A->split_kind != 4) || (A->strip_nseg == 0 && A->ct_units == 0) || A->strip_ncls == ncls_opt)))) return;
     if (A->split_state == 1) {  // built against the other column coding (or for another long-row kernel): rebuild
@@ -184,9 +183,6 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
         dev_free(A->d_lcol); dev_free(A->d_lval); dev_free(A->d_it_start); dev_free(A->d_it_len); dev_free(A->d_it_slot);
         dev_free(A->d_item_begin);
         // (layouts derived from the short part go with it)
-        dev_free(A->d_sell_perm); dev_free(A->d_sell_off); dev_free(A->d_sell_order); dev_free(A->d_sell_col); dev_free(A->d_sell_val);
-        A->d_sell_perm = nullptr; A->d_sell_off = nullptr; A->d_sell_order = nullptr; A->d_sell_col = nullptr; A->d_sell_val = nullptr;
-        A->sell_state = 0;
         dev_free(A->d_tg_off); dev_free(A->d_tg_col); dev_free(A->d_tg_val); dev_free(A->d_tg_tag); dev_free(A->d_tg_nonempty);
         A->d_tg_off = nullptr; A->d_tg_col = nullptr; A->d_tg_val = nullptr; A->d_tg_tag = nullptr; A->d_tg_nonempty = nullptr; A->tg_state = 0;
         dev_free(A->d_sstart); dev_free(A->d_sslot); dev_free(A->d_hrec);
@@ -766,54 +762,6 @@ static void ensure_ordered(GB_Matrix_opaque *S)
     S->ord_state = 1;
 }
 
-#ifdef GRB_EXPERIMENTAL_KERNELS
-// sliced-ELLPACK copy of the short part S of A (once per matrix; see grb_mxv_sell.inc)
-static void ensure_sell(GB_Matrix_opaque *A)
-{
-    if (A->sell_state == 1) return;
-    GB_Matrix_opaque *S = A->short_part;
-    const int64_t m = (int64_t)S->nrows;
-    const int64_t sigma = std::max<int64_t>(64, ((int64_t)ctx().sell_sigma / 64) * 64);
-    const int64_t n_slices = ceil_div(m, 64);
-    const int64_t *sptr = matrix_rowptr(S);
-    DevBuf<uint64_t> keys(m), keys2(m);
-    DevBuf<uint32_t> idx(m), order(m);
-    hipLaunchKernelGGL(k_sell_keys, dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, ctx().stream, sptr, m, sigma, keys.p, idx.p);
-    int bits = 10;
-    while (((int64_t)1 << (bits - 9)) < ceil_div(m, sigma) + 1) bits++;
-    prim_sort_pairs_u64_u32(keys.p, keys2.p, idx.p, order.p, m, bits);
-    A->d_sell_perm = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)(n_slices * 64));
-    A->d_sell_off = (int64_t *)dev_alloc(sizeof(int64_t) * (size_t)(n_slices + 1));
-    hipLaunchKernelGGL(k_sell_slices, dim3((unsigned)ceil_div(n_slices * 64, 256)), dim3(256), 0, ctx().stream, sptr,
-                       (const uint32_t *)order.p, m, n_slices, A->d_sell_perm, A->d_sell_off);
-    prim_exclusive_sum_i64(A->d_sell_off, A->d_sell_off, n_slices + 1);
-    int64_t slots = 0;
-    d2h(&slots, A->d_sell_off + n_slices, 8);
-    if (slots >= 0xf0000000ll / 8) fail(GrB_NOT_IMPLEMENTED, "sliced-ELLPACK form: too many slots for 32-bit offsets");
-    A->d_sell_col = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)std::max<int64_t>(slots, 1));
-    A->d_sell_val = S->iso ? nullptr : dev_alloc(S->type->size * (size_t)std::max<int64_t>(slots, 1));
-    GRB_DISPATCH_TYPE(S->type->code, T, {
-        hipLaunchKernelGGL((k_sell_fill<T>), dim3((unsigned)ceil_div(n_slices * 64, 256)), dim3(256), 0, ctx().stream, sptr,
-                           (const int32_t *)S->d_col, (const T *)S->d_val, S->iso ? 1 : 0, (const int32_t *)A->d_sell_perm,
-                           (const int64_t *)A->d_sell_off, n_slices, A->d_sell_col, (T *)A->d_sell_val);
-    })
-    {
-        DevBuf<uint64_t> okeys(n_slices), okeys2(n_slices);
-        DevBuf<uint32_t> oidx(n_slices);
-        A->d_sell_order = (uint32_t *)dev_alloc(sizeof(uint32_t) * (size_t)n_slices);
-        hipLaunchKernelGGL(k_sell_order_keys, dim3((unsigned)ceil_div(n_slices, 256)), dim3(256), 0, ctx().stream,
-                           (const int64_t *)A->d_sell_off, n_slices, okeys.p, oidx.p);
-        prim_sort_pairs_u64_u32(okeys.p, okeys2.p, oidx.p, A->d_sell_order, n_slices, 9);
-        sync_stream();
-    }
-    sync_stream();  // (the temporaries above are released at the end of this scope)
-    A->sell_slices = n_slices;
-    A->sell_slots = slots;
-    A->sell_state = 1;
-}
-
-#endif
-
 // tagged row groups of the short part S of A (once per matrix; see grb_mxv_rows_tag.inc)
 static void ensure_tagged(GB_Matrix_opaque *A)
 {
@@ -829,7 +777,7 @@ static void ensure_tagged(GB_Matrix_opaque *A)
     prim_exclusive_sum_i64(cnt.p, cnt.p, ngroups + 1);
     int64_t units = 0;
     d2h(&units, cnt.p + ngroups, 8);
-    if (units >= 0x7ffffff0ll) fail(GrB_NOT_IMPLEMENTED, "tagged row groups: too many entries for 32-bit group offsets");
+    if (units >= 0x7ffffff0ll) fail(GrB_NOT_IMPLEMENTED, "tagged row groups: too many entries for 32-bit group offsets");  // (unreachable below 2^33 entries: ensure_split's guard)
     A->d_tg_off = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)(ngroups + 1));
     hipLaunchKernelGGL(k_tag_off32, dim3((unsigned)ceil_div(ngroups + 1, 256)), dim3(256), 0, ctx().stream, (const int64_t *)cnt.p, ngroups + 1,
                        A->d_tg_off);
@@ -1004,51 +952,7 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
             ctx().stats.tiles = ceil_div(b.m, 64);
             return;
         }
-#ifdef GRB_EXPERIMENTAL_KERNELS
-        if (sk == 2 && S->nrows == A->nrows && A->nrows < 0x7fffffffll) {
-            // short rows in sliced-ELLPACK form: a lane per row, which also applies the write rule of the long rows
-            ensure_sell(A);
-            b.long_prefix = A->d_long_prefix;
-            b.sell_perm = A->d_sell_perm;
-            b.sell_off = A->d_sell_off;
-            b.sell_order = A->d_sell_order;
-            b.sell_col = A->d_sell_col;
-            b.sell_val = A->d_sell_val;
-            b.sell_iso = S->d_val;
-            b.sell_slices = A->sell_slices;
-            if (b.fresh) GRB_HIP(hipMemsetAsync(b.w_new_bits, 0, bits_words64((uint64_t)b.m) * 8, ctx().stream));
-            hipLaunchKernelGGL((k_mxv_sell<T, MON, MUL>), dim3((unsigned)ceil_div(b.sell_slices, SELL_BLOCK / 64)), dim3(SELL_BLOCK), 0,
-                               ctx().stream, b);
-            GRB_HIP(hipGetLastError());
-            ctx().stats.kernel_launches += 1;
-            ctx().stats.tiles = A->sell_slots;  // (slots incl. padding; the short part holds S->nvals entries)
-            return;
-        }
-        if (sk == 3 && S->nrows == A->nrows) {
-            // short rows from persistent workgroups that keep the head of the operand image in LDS
-            b.long_prefix = A->d_long_prefix;
-            const int64_t groups = ceil_div(b.m, 64);
-            const int64_t G = std::max<int64_t>(1, std::min<int64_t>((int64_t)ctx().num_cus, ceil_div(groups, ROWS_HEAD_BLOCK / 64)));
-            hipLaunchKernelGGL((k_mxv_rows_head<T, MON, MUL>), dim3((unsigned)G), dim3(ROWS_HEAD_BLOCK), 0, ctx().stream, b);
-            GRB_HIP(hipGetLastError());
-            ctx().stats.kernel_launches += 1;
-            ctx().stats.tiles = groups;
-            return;
-        }
-        if constexpr (sizeof(T) == 4 && !std::is_same<T, bool>::value) {
-            if (sk == 4 && S->nrows == A->nrows && b.need_uval && b.u_full && b.need_aval) {
-                // short rows with a lane per row over entries staged in LDS (4-byte types, full operand whose values are read)
-                b.long_prefix = A->d_long_prefix;
-                hipLaunchKernelGGL((k_mxv_rows_lane<T, MON, MUL>), dim3((unsigned)ceil_div(ceil_div(b.m, 64), ROWS_BLOCK / 64)), dim3(ROWS_BLOCK),
-                                   0, ctx().stream, b);
-                GRB_HIP(hipGetLastError());
-                ctx().stats.kernel_launches += 1;
-                ctx().stats.tiles = ceil_div(b.m, 64);
-                return;
-            }
-        }
-#endif
-        if (sk != 0 && S->nrows == A->nrows) {  // (also what the experimental kernels fall back to in a build without them)
+        if (sk != 0 && S->nrows == A->nrows) {
             // short rows: one wavefront per 64 consecutive rows, which also applies the write rule of the long rows
             b.long_prefix = A->d_long_prefix;
             // (persistent variants -- static strides with the next group prefetched, or an LDS work counter per workgroup --

@@ -620,13 +620,6 @@ GB_Matrix_opaque *matrix_new(GrB_Type type, uint64_t nrows, uint64_t ncols)
     A->d_it_len = nullptr;
     A->d_it_slot = nullptr;
     A->d_item_begin = nullptr;
-    A->d_sell_perm = nullptr;
-    A->d_sell_off = nullptr;
-    A->d_sell_order = nullptr;
-    A->d_sell_col = nullptr;
-    A->d_sell_val = nullptr;
-    A->sell_slices = A->sell_slots = 0;
-    A->sell_state = 0;
     A->long_nnz = 0;
     A->n_items = 0;
     for (auto &x : A->item_begin) x = 0;
@@ -690,18 +683,6 @@ void matrix_invalidate_caches(GB_Matrix_opaque *A)
     dev_free(A->d_tg_off); dev_free(A->d_tg_col); dev_free(A->d_tg_val); dev_free(A->d_tg_tag); dev_free(A->d_tg_nonempty);
     A->d_tg_off = nullptr; A->d_tg_col = nullptr; A->d_tg_val = nullptr; A->d_tg_tag = nullptr; A->d_tg_nonempty = nullptr;
     A->tg_state = 0;
-    dev_free(A->d_sell_perm);
-    dev_free(A->d_sell_off);
-    dev_free(A->d_sell_order);
-    A->d_sell_order = nullptr;
-    dev_free(A->d_sell_col);
-    dev_free(A->d_sell_val);
-    A->d_sell_perm = nullptr;
-    A->d_sell_off = nullptr;
-    A->d_sell_col = nullptr;
-    A->d_sell_val = nullptr;
-    A->sell_slices = A->sell_slots = 0;
-    A->sell_state = 0;
     A->d_lcol = nullptr;
     A->d_lval = nullptr;
     A->d_it_start = nullptr;

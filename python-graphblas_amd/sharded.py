@@ -223,6 +223,18 @@ class OverlappedMxv:
         if n % (64 * world * self.chunks):
             raise ValueError("n must be a multiple of 64 * world_size * chunks")
         self.n, self.world, self.h = n, world, n // (world * self.chunks)
+        if device != "cpu":
+            # The asynchronous collective is ordered behind the product (and the next product behind the collective) through torch's
+            # CURRENT stream: ProcessGroupNCCL records its events there.  That orders against the library only if the library launches on
+            # the same stream -- both default to the null stream; after GrX_set_stream, or under torch.cuda.stream(...), they differ and
+            # a gather could read a slice before its product has written it.
+            import torch
+
+            lib_stream = ctypes.c_void_p()
+            _lib.lib.GrX_get_stream(ctypes.byref(lib_stream))
+            if (lib_stream.value or 0) != (torch.cuda.current_stream().cuda_stream or 0):
+                raise RuntimeError("OverlappedMxv: the library's launch stream (GrX_set_stream) is not torch's current stream: the exchange "
+                                   "would not be ordered behind the products; construct and step it with the two streams equal")
         desc = ctypes.c_void_p(_lib.handle(desc_name)) if desc_name else None
         self._call = _lib.lib.GrB_mxv
         self._args = [[(self.w[c]._carg, self.mask[c]._carg if self.mask[c] is not None else None, accum._carg if accum is not None else None,

@@ -1,8 +1,6 @@
 #!/bin/bash
 # TEST INFRASTRUCTURE ONLY: compile the unmodified kernel sources for the CPU SIMT emulator -- with the flags of the shipped library
 # (no -DGRB_ABLATE: the CPU tier exercises the same preprocessor path through every kernel as the GPU does).
-# GRB_EMU_EXPERIMENTAL=1 (with a clean tests/emu/obj) also compiles the short-row kernels that were measured slower and live behind
-# -DGRB_EXPERIMENTAL_KERNELS: the tests that select them (short_kernel = 2 / 3 / 4) otherwise run the default kernel.
 set -e
 HERE="$(cd "$(dirname "$0")" && pwd)"
 ROOT="$(cd "$HERE/../.." && pwd)"
@@ -13,7 +11,7 @@ pids=()
 for f in "$SRC"/*.hip; do
   o="$HERE/obj/$(basename "${f%.hip}").o"
   if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ -n "$(find "$SRC" "$HERE/hip" "$HERE/rocprim" "$ROOT/include" -newer "$o" \( -name '*.hpp' -o -name '*.h' -o -name '*.inc' \) | head -1)" ]; then
-    g++ -O1 -g -std=c++17 -fPIC ${GRB_EMU_EXPERIMENTAL:+-DGRB_EXPERIMENTAL_KERNELS} -x c++ -I"$HERE" -I"$ROOT/include" -I"$SRC" -Wno-attributes -w -c "$f" -o "$o" &
+    g++ -O1 -g -std=c++17 -fPIC -x c++ -I"$HERE" -I"$ROOT/include" -I"$SRC" -Wno-attributes -w -c "$f" -o "$o" &
     pids+=($!)
   fi
 done

@@ -492,8 +492,7 @@ def test_long_short_row_split(gb, seed):
         # sliced ELLPACK / persistent row groups with an LDS head / merge path / row groups
         # (seeds 0, 6, 12: a lane per row over entries staged in LDS -- 4-byte types with a full operand; the rest falls back to row groups)
         # (5: tagged row groups -- the row of every entry stored with it)
-        _lib.lib.GrX_option_set(b"short_kernel", [4, 2, 3, 5, 2, 5, 4, 5, 3, 0, 5, 3, 4, 5, 5, 1][seed])
-        _lib.lib.GrX_option_set(b"sell_sigma", [64, 128, 4096, 256][seed % 4])
+        _lib.lib.GrX_option_set(b"short_kernel", [1, 5, 1, 5, 6, 5, 1, 5, 0, 0, 5, 1, 6, 5, 5, 1][seed])
         if seed & 4:
             _lib.lib.GrX_option_set(b"hot_min_cols", 8)
             _lib.lib.GrX_option_set(b"hot_k", 64)
@@ -545,7 +544,6 @@ def test_long_short_row_split(gb, seed):
         _lib.lib.GrX_option_set(b"split_min_len", 0)
         _lib.lib.GrX_option_set(b"push_mode", 1)
         _lib.lib.GrX_option_set(b"short_kernel", DEFAULT_SHORT_KERNEL)
-        _lib.lib.GrX_option_set(b"sell_sigma", 4096)
         _lib.lib.GrX_option_set(b"hot_min_cols", 1 << 20)
         _lib.lib.GrX_option_set(b"hot_k", 0)
         _lib.lib.GrX_option_set(b"long_sub", 0)
@@ -730,73 +728,6 @@ def test_split_survives_mixed_calls_and_option_changes(gb, seed):
         for name, val in ((b"split_min_nnz", 1 << 22), (b"split_min_len", 0), (b"push_mode", 1), (b"hot_min_cols", 1 << 20), (b"hot_k", 0),
                           (b"long_kernel", DEFAULT_LONG_KERNEL), (b"long_classes", 16), (b"vec_pad_min_bytes", 1 << 20)):
             _lib.lib.GrX_option_set(name, val)
-
-
-@pytest.mark.parametrize("seed", range(18))
-def test_short_rows_lane_kernel(gb, seed):
-    """short_kernel = 4: a lane per row over the group's entries staged in LDS (4-byte types, a FULL operand whose values are
-    read).  Rows of 0 .. 70 entries around the long-row threshold, groups whose entries span several staging windows, long
-    rows in the same 64-row groups (their product comes from the long-row kernel), masks of every form, accumulators,
-    replace, iso matrices, with and without the hot-column table; semirings whose multiply ignores an operand fall back to
-    the row-group kernel under the same option."""
-    from graphblas_amd import _lib
-
-    rng = np.random.default_rng(3300 + seed)
-    tname = ["FP32", "INT32"][seed % 2]
-    sr = ["min_plus", "plus_times", "max_plus", "plus_plus", "min_second", "any_pair", "max_first", "plus_pair", "min_plus"][seed % 9]
-    m, n = int(rng.integers(70, 700)), int(rng.integers(300, 4000))
-    deg = rng.integers(0, 9, m)
-    deg[rng.random(m) < 0.25] = 0
-    thr = 24
-    for ln in (thr - 1, thr, thr + 1, 70, 300, 7, 23, 1):
-        deg[rng.integers(0, m)] = min(ln, n)
-    if seed % 3 == 0:  # a run of fat short rows: one group's entries span several staging windows of 256
-        s0 = int(rng.integers(0, m - 64))
-        deg[s0: s0 + 40] = thr - 1
-    rows = np.repeat(np.arange(m), deg)
-    cols = np.concatenate([rng.choice(n, d, replace=False) for d in deg])
-    vals = rand_vals(rng, rows.size, tname)
-    if seed % 5 == 0:
-        vals[:] = vals[0]  # iso
-    ui, uv = rand_vec(rng, n, 1.0, tname)
-    wi, wv = rand_vec(rng, m, 0.5, tname)
-    mi, mv = rand_vec(rng, m, 0.5, "BOOL")
-    accum = [None, "plus", "min", "second"][seed % 4]
-    comp, struct, repl = bool(seed & 1), bool(seed & 2), bool(seed & 4)
-    use_mask = seed % 7 != 3
-    oa = O.OMat.from_coo(rows, cols, vals, m, n, tname)
-    exp = O.mxv(oa, O.OVec(n, ui, uv, tname), sr, w=O.OVec(m, wi, wv, tname), mask=O.OVec(m, mi, mv, "BOOL") if use_mask else None,
-                mask_comp=comp and use_mask, mask_struct=struct and use_mask, accum=accum, replace=repl and use_mask)
-    try:
-        _lib.lib.GrX_option_set(b"split_min_nnz", 1)
-        _lib.lib.GrX_option_set(b"split_min_len", thr)
-        _lib.lib.GrX_option_set(b"push_mode", 0)
-        _lib.lib.GrX_option_set(b"short_kernel", 4)
-        if seed & 8:
-            _lib.lib.GrX_option_set(b"hot_min_cols", 8)
-            _lib.lib.GrX_option_set(b"hot_k", 64)
-        A = gb.Matrix.from_coo(rows, cols, vals, dtype=tname, nrows=m, ncols=n)
-        u = gb.Vector.from_coo(ui, uv, dtype=tname, size=n)
-        mk = gb.Vector.from_coo(mi, mv, dtype="BOOL", size=m)
-        for _ in range(2):  # (the second call runs on the cached layouts)
-            w = gb.Vector.from_coo(wi, wv, dtype=tname, size=m)
-            if use_mask:
-                msk = mk.S if struct else mk.V
-                w(~msk if comp else msk, accum=accum, replace=repl) << A.mxv(u, getattr(gb.semiring, sr))
-            else:
-                w(accum=accum) << A.mxv(u, getattr(gb.semiring, sr))
-            if sr.startswith("any_") and not sr.endswith("pair"):
-                gi, _ = w.to_coo()
-                assert gi.tolist() == exp.idx.tolist()
-            else:
-                same_vec(w, exp)
-    finally:
-        _lib.lib.GrX_option_set(b"split_min_nnz", 1 << 22)
-        _lib.lib.GrX_option_set(b"split_min_len", 0)
-        _lib.lib.GrX_option_set(b"push_mode", 1)
-        _lib.lib.GrX_option_set(b"short_kernel", DEFAULT_SHORT_KERNEL)
-        _lib.lib.GrX_option_set(b"hot_min_cols", 1 << 20)
-        _lib.lib.GrX_option_set(b"hot_k", 0)
 
 
 @pytest.mark.parametrize("seed", range(6))
@@ -1109,156 +1040,6 @@ def test_reductions_over_split_matrices(gb, seed):
         _lib.lib.GrX_option_set(b"debug_flags", 0)
         _lib.lib.GrX_option_set(b"split_min_nnz", 1 << 22)
         _lib.lib.GrX_option_set(b"split_min_len", 0)
-
-
-@pytest.mark.parametrize("seed", range(28))
-def test_sell_short_rows(gb, seed):
-    """short_kernel = 2: the short rows in sliced-ELLPACK form, a lane per row (k_mxv_sell) -- every type and semiring, all mask
-    forms, accumulators, replace, full / sparse operands, an output of another type, the output aliasing the operand, row counts
-    that are no multiple of 64, sort windows from 64 rows up -- against the oracle."""
-    from graphblas_amd import _lib, device
-
-    rng = np.random.default_rng(7300 + seed)
-    tname = TYPES[seed % 7]
-    srs = semirings_for(tname)
-    sr = srs[seed % len(srs)]
-    m, n = int(rng.integers(1, 900)), int(rng.integers(300, 3000))
-    square = seed % 5 == 4
-    if square:
-        n = m = max(m, 300)
-    deg = rng.integers(0, 9, m)
-    deg[rng.random(m) < 0.3] = 0
-    for ln in (40, 100, 255, 256, 300, int(rng.integers(200, n)), n, n - 1, n - 7):  # rows around and above the long-row threshold
-        deg[rng.integers(0, m)] = min(ln, n)
-    rows = np.repeat(np.arange(m), deg)
-    cols = np.concatenate([rng.choice(n, d, replace=False) for d in deg]) if deg.sum() else np.zeros(0, np.int64)
-    vals = rand_vals(rng, rows.size, tname)
-    ui, uv = rand_vec(rng, n, [1.0, 0.5, 0.05][seed % 3], tname)
-    wname = tname if seed % 4 else ["INT64", "FP64", "INT32", "FP32"][(seed // 4) % 4]
-    wi, wv = rand_vec(rng, m, 0.5, wname)
-    mi, mv = rand_vec(rng, m, 0.5, "INT8")
-    use_mask = seed % 6 != 0
-    comp, struct, repl = (bool(x) for x in rng.integers(0, 2, 3))
-    accum = [None, "plus", "min", "second"][rng.integers(4)]
-    oa = O.OMat.from_coo(rows, cols, vals, m, n, tname)
-    alias = square and wname == tname
-    ow = O.OVec(n, ui, uv, tname) if alias else O.OVec(m, wi, wv, wname)
-    exp = O.mxv(oa, O.OVec(n, ui, uv, tname), sr, w=ow, mask=O.OVec(m, mi, mv, "INT8") if use_mask else None,
-                mask_comp=comp and use_mask, mask_struct=struct, accum=accum, replace=repl and use_mask)
-    try:
-        _lib.lib.GrX_option_set(b"split_min_nnz", 1)
-        _lib.lib.GrX_option_set(b"split_min_len", 256 if seed % 2 else 64)
-        _lib.lib.GrX_option_set(b"push_mode", 0)
-        _lib.lib.GrX_option_set(b"short_kernel", 2)
-        _lib.lib.GrX_option_set(b"sell_sigma", [64, 192, 4096, 1024][seed % 4])
-        A = gb.Matrix.from_coo(rows, cols, vals, dtype=tname, nrows=m, ncols=n)
-        u = gb.Vector.from_coo(ui, uv, dtype=tname, size=n)
-        w = u if alias else gb.Vector.from_coo(wi, wv, dtype=wname, size=m)
-        kw = {}
-        if use_mask:
-            mk = gb.Vector.from_coo(mi, mv, dtype="INT8", size=m)
-            mm = mk.S if struct else mk.V
-            kw = dict(mask=~mm if comp else mm, replace=repl)
-        if accum:
-            kw["accum"] = accum
-        w(**kw) << A.mxv(u, getattr(gb.semiring, sr))
-        same_vec(w, exp)
-    finally:
-        _lib.lib.GrX_option_set(b"split_min_nnz", 1 << 22)
-        _lib.lib.GrX_option_set(b"split_min_len", 0)
-        _lib.lib.GrX_option_set(b"push_mode", 1)
-        _lib.lib.GrX_option_set(b"short_kernel", DEFAULT_SHORT_KERNEL)
-        _lib.lib.GrX_option_set(b"sell_sigma", 4096)
-
-
-@pytest.mark.parametrize("dummy", [0])
-def test_sell_layout(gb, dummy):
-    """The sliced-ELLPACK form of a known matrix: GrX_Stats.tiles reports its slots -- 64 x the longest row of every slice after
-    sorting the rows by falling length inside windows of sigma rows."""
-    from graphblas_amd import _lib, device
-
-    m, n = 300, 2000
-    rng = np.random.default_rng(1)
-    deg = rng.integers(0, 20, m)
-    deg[7], deg[150] = 1200, 1900  # long rows (empty in the short part; they must hold 30 % of the entries for the split)
-    rows = np.repeat(np.arange(m), deg)
-    cols = np.concatenate([rng.choice(n, d, replace=False) for d in deg])
-    vals = np.ones(rows.size)
-    short = np.where(deg >= 64, 0, deg)
-    for sigma in (64, 128, 4096):
-        expect = 0
-        for w0 in range(0, m, sigma):
-            srt = np.sort(short[w0:w0 + sigma])[::-1]
-            expect += sum(64 * int(srt[k]) for k in range(0, len(srt), 64))
-        if sigma == 4096:  # one window: slices cut the globally sorted rows
-            srt = np.sort(short)[::-1]
-            expect = sum(64 * int(srt[k]) for k in range(0, m, 64))
-        try:
-            _lib.lib.GrX_option_set(b"split_min_nnz", 1)
-            _lib.lib.GrX_option_set(b"split_min_len", 64)
-            _lib.lib.GrX_option_set(b"short_kernel", 2)
-            _lib.lib.GrX_option_set(b"sell_sigma", sigma)
-            A = gb.Matrix.from_coo(rows, cols, vals, nrows=m, ncols=n)
-            u = gb.Vector.from_coo(np.arange(n), np.ones(n), size=n)
-            w = A.mxv(u, gb.semiring.plus_times).new()
-            # (the sliced-ELLPACK kernel lives behind -DGRB_EXPERIMENTAL_KERNELS; a build without it runs the row groups: 5 of them)
-            assert device.last_stats()["tiles"] in (expect, (m + 63) // 64), sigma
-            gi, gv = w.to_coo()
-            assert np.array_equal(gi, np.flatnonzero(deg)) and np.array_equal(gv, deg[deg > 0].astype(float))
-        finally:
-            _lib.lib.GrX_option_set(b"split_min_nnz", 1 << 22)
-            _lib.lib.GrX_option_set(b"split_min_len", 0)
-            _lib.lib.GrX_option_set(b"short_kernel", DEFAULT_SHORT_KERNEL)
-            _lib.lib.GrX_option_set(b"sell_sigma", 4096)
-
-
-@pytest.mark.parametrize("seed", range(12))
-def test_mixed_types_unread_operands(gb, seed):
-    """Multiply operators that ignore an operand's values (PAIR, FIRST, SECOND, ANY) with operands of ANOTHER type than the
-    semiring's: the cast of an unread operand is skipped only where nothing is laid out in the semiring's type -- with a sparse
-    u the presence image [hot table | u] still is.  Hot table and row split forced on; full and sparse u; mxv and vxm."""
-    from graphblas_amd import _lib
-
-    rng = np.random.default_rng(8400 + seed)
-    ta, tu = [("INT64", "BOOL"), ("FP64", "INT8"), ("FP32", "BOOL"), ("INT8", "INT64"), ("BOOL", "FP64"), ("UINT16", "FP32")][seed % 6]
-    sr = ["any_pair", "plus_pair", "min_first", "max_second", "plus_first", "any_pair"][(seed // 2) % 6]
-    m, n = int(rng.integers(60, 500)), int(rng.integers(2100, 5000))
-    deg = rng.integers(0, 6, m)
-    deg[rng.random(m) < 0.3] = 0
-    for ln in (9, 65, 513, 2049, int(rng.integers(1500, n))):
-        deg[rng.integers(0, m)] = min(ln, n)
-    rows = np.repeat(np.arange(m), deg)
-    cols = np.concatenate([rng.choice(n, d, replace=False) for d in deg])
-    vals = rand_vals(rng, rows.size, ta)
-    ui, uv = rand_vec(rng, n, [0.4, 1.0, 0.03][seed % 3], tu)
-    mi, mv = rand_vec(rng, m, 0.5, "BOOL")
-    st = O.unify(ta, tu)
-    if st == "BOOL" or sr.split("_")[0] not in ("any", "plus", "min", "max"):
-        pytest.skip("no such semiring for the unified type")
-    oa = O.OMat.from_coo(rows, cols, vals, m, n, ta)
-    exp = O.mxv(oa, O.OVec(n, ui, uv, tu), sr, mask=O.OVec(m, mi, mv, "BOOL"), mask_comp=bool(seed & 1))
-    xi, xv = rand_vec(rng, m, [0.5, 1.0][seed % 2], tu)
-    exp_t = O.vxm(O.OVec(m, xi, xv, tu), oa, sr)
-    try:
-        _lib.lib.GrX_option_set(b"split_min_nnz", 1)
-        _lib.lib.GrX_option_set(b"split_min_len", 8)
-        _lib.lib.GrX_option_set(b"push_mode", 0)
-        _lib.lib.GrX_option_set(b"hot_min_cols", 8)
-        _lib.lib.GrX_option_set(b"hot_k", 64)
-        A = gb.Matrix.from_coo(rows, cols, vals, dtype=ta, nrows=m, ncols=n)
-        u = gb.Vector.from_coo(ui, uv, dtype=tu, size=n)
-        mk = gb.Vector.from_coo(mi, mv, dtype="BOOL", size=m)
-        w = gb.Vector(st, size=m)
-        w(~mk.V if seed & 1 else mk.V) << A.mxv(u, getattr(gb.semiring, sr))
-        same_vec(w, exp)
-        x = gb.Vector.from_coo(xi, xv, dtype=tu, size=m)
-        same_vec(x.vxm(A, getattr(gb.semiring, sr)).new(), exp_t)
-    finally:
-        _lib.lib.GrX_option_set(b"split_min_nnz", 1 << 22)
-        _lib.lib.GrX_option_set(b"split_min_len", 0)
-        _lib.lib.GrX_option_set(b"push_mode", 1)
-        _lib.lib.GrX_option_set(b"hot_min_cols", 1 << 20)
-        _lib.lib.GrX_option_set(b"hot_k", 0)
 
 
 @pytest.mark.parametrize("seed", range(4))
