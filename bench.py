@@ -686,6 +686,56 @@ def main_uniform(args, gb, torch, device, rank, world):
                                    f"scipy.sparse csr @ x on one core: {t_scipy * 1e3:.3f} ms; not SuiteSparse"}}))
 
 
+def cpu_baseline_loop(kind, scale=20):
+    """The CPU column of the traversal lines: the same loop with the C oracle's mat-vec (OpenMP, all host cores) on the R-MAT graph of
+    the same generator at scale 20 (a bounded sample: the scale-24 loop would take minutes on the host), from the largest-degree
+    vertex.  value = Graph500-style TEPS of that run."""
+    import numpy as np
+    import torch
+
+    from graphblas_amd import synthetic
+    from oracle import grb_oracle as O
+
+    n = 1 << scale
+    ip, col = synthetic.rmat_csr(scale, device="cuda" if torch.cuda.is_available() else "cpu")
+    vals = synthetic.edge_weights(col, scale).cpu().numpy() if kind == "sssp" else None
+    ip, col = ip.cpu().numpy(), col.cpu().numpy().astype(np.int64)
+    deg = np.diff(ip)
+    src = int(np.argmax(deg))
+    O.use_all_threads()
+    if kind == "sssp":
+        At = O.OMat(n, n, ip, col, vals, "FP32").transpose()  # (v @ G pulls over G')
+        t0 = time.perf_counter()
+        v = O.OVec(n, np.array([src]), np.array([0], np.float32), "FP32")
+        its = 0
+        while True:
+            its += 1
+            nv = O.mxv(At, v, "min_plus", w=v, accum="min")
+            same = nv.idx.size == v.idx.size and np.array_equal(nv.idx, v.idx) and np.array_equal(nv.vals, v.vals)
+            v = nv
+            if same:
+                break
+        dt = time.perf_counter() - t0
+        reached = v.idx
+    else:
+        At = O.OMat(n, n, ip, col, np.ones(col.size, bool), "BOOL").transpose()
+        t0 = time.perf_counter()
+        q = O.OVec(n, np.array([src]), np.array([True]), "BOOL")
+        seen = np.zeros(n, bool)
+        its = 0
+        while q.idx.size:
+            its += 1
+            seen[q.idx] = True
+            vis = O.OVec(n, np.flatnonzero(seen), np.ones(int(seen.sum()), bool), "BOOL")
+            q = O.mxv(At, q, "lor_land", w=q, mask=vis, mask_comp=True, mask_struct=True, replace=True)
+        dt = time.perf_counter() - t0
+        reached = np.flatnonzero(seen)
+    edges = int(deg[reached].sum())
+    return {"value": edges / dt / 1e9, "unit": "GTEPS", "cores": O.num_threads(), "kind": "port",
+            "sample": f"the same loop on the scale-{scale} graph of the same generator ({its} sweeps, {dt * 1e3:.0f} ms, {edges} edges counted) with the C "
+                      "oracle's mat-vec (oracle/grb_oracle.c, OpenMP) -- a CPU restatement, not SuiteSparse"}
+
+
 def main_bfs(args, gb, torch, device, rank, world):
     """A whole level-synchronous BFS on the device (notebooks/Example B.1 -- Level BFS.ipynb): per level one masked scalar
     assign (levels), one vxm over lor_land with the complemented structural mask + replace (push for thin frontiers, pull
@@ -725,16 +775,48 @@ def main_bfs(args, gb, torch, device, rank, world):
         v, depth = traverse()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
+    # one more traversal, instrumented (not timed): per level the direction the library took and the SURVEY 8d bytes of that direction
+    #   push: products x I + frontier x (I + 2 P) + reached x 1 B;  pull: entries of the unvisited rows x I (estimated from the share of
+    #   unvisited VERTICES) + (n + 1) P + the frontier / visited / output bit vectors
+    nnz_all = int(col.numel())
+    alg_bytes, levels_log = 0.0, []
+    vv = gb.Vector("INT32", n)
+    qq = gb.Vector(bool, n)
+    qq[src] << True
+    dd = 0
+    while True:
+        dd += 1
+        f_nv, seen_before = qq.nvals, vv.nvals
+        vv[:](mask=qq.V) << dd
+        qq(~vv.S, replace=True) << qq.vxm(A, gb.semiring.lor_land)
+        st = device.last_stats()
+        if st["method"] == 2:
+            b = st["flops"] * 4 + f_nv * 20 + qq.nvals
+        else:
+            b = nnz_all * 4 * (1.0 - (seen_before + f_nv) / n) + (n + 1) * 8 + 3 * n / 8
+        alg_bytes += b
+        levels_log.append({"level": dd, "frontier": int(f_nv), "direction": "push" if st["method"] == 2 else "pull", "bytes": b})
+        if qq.nvals == 0:
+            break
     idx, _lev = v.to_coo()
     visited = torch.from_numpy(idx.astype("int64")).cuda()
     edges = int(deg[visited].sum().item())
+    cpu = None
+    if not args.no_cpu_baseline:
+        try:
+            cpu = cpu_baseline_loop("bfs")
+        except Exception as e:
+            cpu = {"value": None, "unit": "GTEPS", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
     emit(({
         "metric": "GTEPS (BFS traversal) on R-MAT scale-%d" % args.scale, "value": edges / dt / 1e9, "unit": "GTEPS", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "bool", "data": "synthetic",
         "config": {"workload": f"rmat{args.scale} bfs: level BFS from the largest-degree vertex, whole loop through the C ABI",
-                   "levels": depth, "visited_vertices": int(idx.size), "edges_counted_per_step": edges},
-        "roofline": None, "cpu_baseline": None}))
+                   "levels": depth, "visited_vertices": int(idx.size), "edges_counted_per_step": edges, "per_level": levels_log},
+        "roofline": {"bound": "hbm", "achieved": alg_bytes / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_bytes / dt / 1e9 / HBM_PEAK_GBS,
+                     "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
+                     "note": "whole traversal (wall clock incl. the host's per-level reads) over the sum of the levels' SURVEY 8d bytes in the direction taken"},
+        "cpu_baseline": cpu}))
 
 
 def main_sssp(args, gb, torch, device, rank, world):
@@ -772,16 +854,42 @@ def main_sssp(args, gb, torch, device, rank, world):
         v, its = solve()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
+    # instrumented solve (not timed): bytes per sweep in the direction taken -- pull: all entries x (I + V) + (n + 1) P + the vectors (u, w
+    # read and written); push: products x (I + V) + frontier x (I + V + 2 P) + touched outputs
+    nnz_all = int(col.numel())
+    alg_bytes, sweeps_log = 0.0, []
+    vv = gb.Vector("FP32", n)
+    vv[src] << 0.0
+    while True:
+        f_nv = vv.nvals
+        ww = vv.dup()
+        vv(gb.op.min) << gb.semiring.min_plus(vv @ G)
+        st = device.last_stats()
+        b = (st["flops"] * 8 + f_nv * 24 + vv.nvals * 8) if st["method"] == 2 else (nnz_all * 8 + (n + 1) * 8 + 3 * n * 4)
+        alg_bytes += b + 2 * n * 4 * 2  # (+ the copy and the comparison of the fixed-point test)
+        sweeps_log.append({"frontier": int(f_nv), "direction": "push" if st["method"] == 2 else "pull", "ordered": int(st["ordered"])})
+        if vv.isequal(ww):
+            break
     idx, _d = v.to_coo()
     reached = torch.from_numpy(idx.astype("int64")).cuda()
     edges = int(deg[reached].sum().item())
+    cpu = None
+    if not args.no_cpu_baseline:
+        try:
+            cpu = cpu_baseline_loop("sssp")
+        except Exception as e:
+            cpu = {"value": None, "unit": "GTEPS", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
     emit(({
         "metric": "GTEPS (SSSP) on R-MAT scale-%d" % args.scale, "value": edges / dt / 1e9, "unit": "GTEPS", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"rmat{args.scale} sssp: Bellman-Ford by vxm(min_plus) with accum min until isequal, whole loop through the C ABI",
-                   "iterations": its, "reached_vertices": int(idx.size), "edges_counted_per_step": edges},
-        "roofline": None, "cpu_baseline": None}))
+                   "iterations": its, "ms_per_iteration": dt * 1e3 / its, "reached_vertices": int(idx.size), "edges_counted_per_step": edges,
+                   "per_sweep": sweeps_log},
+        "roofline": {"bound": "hbm", "achieved": alg_bytes / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_bytes / dt / 1e9 / HBM_PEAK_GBS,
+                     "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
+                     "note": "whole loop (wall clock incl. the host's fixed-point reads) over the sum of the sweeps' SURVEY 8d bytes in the direction taken"},
+        "cpu_baseline": cpu}))
 
 
 _REAL_STDOUT = None

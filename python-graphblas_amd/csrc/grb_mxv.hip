@@ -1400,7 +1400,7 @@ static bool push_core(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_Bina
         prim_exclusive_sum_i64(pre.p, pre.p, fcount + 1);
         d2h(&work, pre.p + fcount, sizeof(int64_t));
     }
-    if (ctx().push_mode == 1 && work * 12 > P->nvals) return false;
+    if (ctx().push_mode == 1 && work * 128 > P->nvals) return false;
     const int wt = widened_type_code(st);
     const size_t wbytes = type_size(wt);
     // dense accumulator of the product (semiring type, widened) + presence
@@ -1449,6 +1449,109 @@ static bool want_push(GB_Vector_opaque *u, GB_Matrix_opaque *P_or_null)
     return nv * 64 < (int64_t)u->n;  // fewer than n/64 entries
 }
 
+// The push direction for a THIN frontier (grb_mxv_push.inc, second half): returns 1 when the product was computed, 0 when the pull
+// direction should run (u has too many entries, or its rows hold too many: decided from ONE host read), -1 when this path does not
+// apply (typecasts, a frontier beyond the queue) and the dense push path should be tried.
+static int push_thin(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_BinaryOp_opaque *accum, const GB_Semiring_opaque *sr,
+                     GB_Matrix_opaque *P, GB_Vector_opaque *u, bool flip, DescFlags f)
+{
+    const int st = sr->type;
+    const int monoid = canonical_op(st, sr->monoid);
+    int mult = canonical_op(st, sr->mult);
+    if (flip) mult = flip_op(mult);  // the kernel evaluates mult(u_k, P_kj)
+    const int need_a = !(mult == OP_PAIR || mult == OP_FIRST || mult == OP_ANY);
+    const int need_u = !(mult == OP_PAIR || mult == OP_SECOND);
+    if ((need_a && P->type->code != st) || (need_u && u->type->code != st) || w->type->code != st) return -1;
+    if (u->n > 0xffffffffull || w->n > 0x7fffffffull || !u->d_val) return -1;
+    const int64_t n_in = (int64_t)u->n, n_out = (int64_t)w->n;
+    if (ctx().push_mode == 1 && u->nvals >= 0 && u->nvals * 64 >= n_in) return 0;
+    // the operands in one order: natural, or the vertex order they already share (a square matrix's: the maps translate)
+    GB_Vector_opaque *vs[3] = {u, w, mask};
+    GB_Perm *ord = (u->n == w->n) ? vectors_common_order(vs, 3) : nullptr;
+    if (u->n != w->n)
+        for (GB_Vector_opaque *v : vs)
+            if (v) vector_set_order(v, nullptr);
+    ctx().stats = GrX_Stats{};
+    ctx().stats.method = 2;
+    ctx().stats.out_nvals = -1;
+    ctx().stats.long_kernel = -1;
+    PushThin a{};
+    a.u_bits = u->d_bits;
+    a.n_in = n_in;
+    a.n_out = n_out;
+    a.in_map = ord ? ord->d_inv : nullptr;
+    a.out_map = ord ? ord->d_rank : nullptr;
+    a.rowptr = matrix_rowptr(P);
+    a.col = P->d_col;
+    a.aval = P->d_val;
+    a.a_iso = P->iso ? 1 : 0;
+    a.u_val = u->d_val;
+    a.monoid = monoid;
+    a.mult = mult;
+    a.need_a = need_a;
+    a.need_u = need_u;
+    a.f_cap = std::max<int64_t>(n_in / 64 + 64, (int64_t)1 << 16);
+    a.c_cap = a.f_cap + P->nvals / PUSH_Q + 64;
+    DevBuf<uint32_t> f_list(a.f_cap);
+    DevBuf<uint64_t> chunks(a.c_cap);
+    DevBuf<unsigned long long> counters(4, true);
+    a.f_list = f_list.p;
+    a.chunks = chunks.p;
+    a.counters = counters.p;
+    hipLaunchKernelGGL(k_push_frontier, dim3((unsigned)ceil_div((int64_t)bits_words64(u->n), 256)), dim3(256), 0, ctx().stream, a);
+    unsigned long long h[3] = {0, 0, 0};
+    d2h(h, counters.p, sizeof(h));
+    const int64_t fcount = (int64_t)h[0], work = (int64_t)h[1], n_chunks = (int64_t)h[2];
+    u->nvals = fcount;
+    ctx().stats.flops = work;
+    ctx().stats.kernel_launches = 1;
+    if (fcount == 0) return 0;  // (nothing to push: the pull entry applies the write rule alone)
+    // (direction: a masked pull over the ordered layouts costs 0.3-0.75 ms at scale 24 whatever the frontier, the push passes ~0.3 ms per
+    //  million products: profiles/r04/push_pull_grid*.jsonl -- the frontier of density 1e-2, 2.7 M products, is pulled, 1e-4 pushed)
+    if (ctx().push_mode == 1 && (fcount * 64 >= n_in || work * 128 > P->nvals)) return 0;
+    if (fcount > a.f_cap || n_chunks > a.c_cap) return -1;
+    if (ctx().push_mode == 1 && work * 8 > n_out) return -1;  // (the dense accumulator pays from here)
+    // ---- mask bits (a mask that aliases w is snapshotted) ----
+    DevBuf<uint64_t> mbits_tmp(0);
+    if (mask) {
+        if (f.structure && mask->d_val && mask != w) a.m_bits = mask->d_bits;
+        else {
+            dev_free(mbits_tmp.p);
+            mbits_tmp.p = (uint64_t *)dev_alloc(bits_words64(mask->n) * 8);
+            vector_mask_bits(mask, f.structure, mbits_tmp.p);
+            a.m_bits = mbits_tmp.p;
+        }
+    }
+    a.has_mask = mask ? 1 : 0;
+    a.m_comp = f.comp ? 1 : 0;
+    vector_ensure_storage(w);
+    const size_t wbytes = type_size(widened_type_code(st));
+    DevBuf<char> t_val((size_t)n_out * wbytes);  // (never filled: only positions a product marks are read)
+    DevBuf<unsigned long long> done(bits_words64((uint64_t)n_out), true);
+    a.t_val = t_val.p;
+    a.done_bits = done.p;
+    a.w_val = w->d_val;
+    a.w_bits = (unsigned long long *)w->d_bits;
+    a.accum = accum ? canonical_op(st, accum->op) : -1;
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(n_chunks, 4), (int64_t)ctx().num_cus * 8));
+    GRB_DISPATCH_TYPE(st, T, {
+        if (n_chunks > 0) {
+            hipLaunchKernelGGL((k_push_pass<T, 0>), dim3(grid), dim3(256), 0, ctx().stream, a, n_chunks);
+            hipLaunchKernelGGL((k_push_pass<T, 1>), dim3(grid), dim3(256), 0, ctx().stream, a, n_chunks);
+        }
+        // what the rule deletes from w goes first (u was read above: w may alias it) ...
+        if (!(accum && !f.replace))
+            hipLaunchKernelGGL(k_push_words, dim3((unsigned)ceil_div((int64_t)bits_words64(w->n), 256)), dim3(256), 0, ctx().stream,
+                               (unsigned long long *)w->d_bits, a.m_bits, a.has_mask, a.m_comp, a.accum, f.replace ? 1 : 0, (int64_t)bits_words64(w->n));
+        // ... then the products are applied
+        if (n_chunks > 0) hipLaunchKernelGGL((k_push_pass<T, 2>), dim3(grid), dim3(256), 0, ctx().stream, a, n_chunks);
+    })
+    ctx().stats.kernel_launches += 4;
+    w->nvals = -1;
+    if (ctx().blocking) sync_stream();
+    return 1;
+}
+
 // the push direction walks the rows of a matrix in natural order: its operands come back to it first
 static bool push_natural(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_BinaryOp_opaque *accum, const GB_Semiring_opaque *sr,
                          GB_Matrix_opaque *P, GB_Vector_opaque *u, bool flip, DescFlags f)
@@ -1457,6 +1560,17 @@ static bool push_natural(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_B
     vector_set_order(w, nullptr);
     if (mask) vector_set_order(mask, nullptr);
     return push_core(w, mask, accum, sr, P, u, flip, f);
+}
+
+// the push direction, thin path first; false: the pull direction runs
+static bool push_any(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_BinaryOp_opaque *accum, const GB_Semiring_opaque *sr,
+                     GB_Matrix_opaque *P, GB_Vector_opaque *u, bool flip, DescFlags f)
+{
+    if (!P || ctx().push_mode == 0 || u->nvals == 0 || P->nvals == 0 || !u->d_val) return false;
+    const int thin = push_thin(w, mask, accum, sr, P, u, flip, f);
+    if (thin >= 0) return thin == 1;
+    if (!want_push(u, P)) return false;
+    return push_natural(w, mask, accum, sr, P, u, flip, f);
 }
 
 // One product  w<mask> = accum(w, S (+.x) u): on the popularity-ordered twin of S with the operands kept in its vertex order when the
@@ -1527,8 +1641,7 @@ extern "C" GrB_Info GrB_mxv(GrB_Vector w, const GrB_Vector mask, const GrB_Binar
     // pull over S = A (or A' with T0); push needs the matrix whose ROWS are indexed like u: S' -- only when cached
     GB_Matrix_opaque *P = f.t0 ? A : A->tr;
     const bool dims_ok = (f.t0 ? A->nrows : A->ncols) == u->n && (f.t0 ? A->ncols : A->nrows) == w->n && (!mask || mask->n == w->n);
-    if (dims_ok && (!accum || (accum->type == w->type->code && !op_is_comparison(accum->op))) && !(!mask && f.comp) && w->n > 0 && want_push(u, P) &&
-        push_natural(w, mask, accum, semiring, P, u, /*flip=*/true, f)) {
+    if (dims_ok && (!accum || (accum->type == w->type->code && !op_is_comparison(accum->op))) && !(!mask && f.comp) && w->n > 0 && push_any(w, mask, accum, semiring, P, u, /*flip=*/true, f)) {
     } else {
         GB_Matrix_opaque *S = f.t0 ? matrix_transpose_cached(A) : A;
         mxv_any_order(w, mask, accum, semiring, S, u, /*flip=*/false, f);
@@ -1551,8 +1664,7 @@ extern "C" GrB_Info GrB_vxm(GrB_Vector w, const GrB_Vector mask, const GrB_Binar
     // push walks the rows of P = A (or A' with T1, when cached) selected by u; pull gathers over S = P'
     GB_Matrix_opaque *P = f.t1 ? A->tr : A;
     const bool dims_ok = (f.t1 ? A->ncols : A->nrows) == u->n && (f.t1 ? A->nrows : A->ncols) == w->n && (!mask || mask->n == w->n);
-    if (dims_ok && (!accum || (accum->type == w->type->code && !op_is_comparison(accum->op))) && !(!mask && f.comp) && w->n > 0 && want_push(u, P) &&
-        push_natural(w, mask, accum, semiring, P, u, /*flip=*/false, f)) {
+    if (dims_ok && (!accum || (accum->type == w->type->code && !op_is_comparison(accum->op))) && !(!mask && f.comp) && w->n > 0 && push_any(w, mask, accum, semiring, P, u, /*flip=*/false, f)) {
     } else {
         GB_Matrix_opaque *S = f.t1 ? A : matrix_transpose_cached(A);
         mxv_any_order(w, mask, accum, semiring, S, u, /*flip=*/true, f);

@@ -1,42 +1,99 @@
 #!/usr/bin/env python3
-"""GPU measurement: one BFS-style level step  q<~visited.S, replace> = q lor.land A  at several frontier
-densities, pull (merge-path SpMV over the cached transpose) vs push (SpMSpV over A's rows)."""
+"""GPU measurement (SURVEY.md section 8d grids): one BFS level step  q<~visited.S, replace> = q lor.land A  on R-MAT at frontier densities x
+visited densities, the pull direction (over the cached transpose) against the push direction (SpMSpV over A's rows; thin path of round 4),
+plus the frontier of THREE vertices and the scale-20 SSSP step with a sparse u (density 1e-3).  One JSON line per point.
+    python scripts/push_vs_pull.py [scale]"""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 import graphblas_amd as gb
 from graphblas_amd import _lib, device, synthetic
-scale = int(sys.argv[1]) if len(sys.argv) > 1 else 22
+scale = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 gb.init()
-n = 1 << scale
-indptr, col = synthetic.rmat_csr(scale, device="cuda")
-one = torch.ones(1, dtype=torch.bool, device="cuda")
-A = device.matrix_from_device_csr(indptr, col, one, n, n, "BOOL", iso=True)
-device.cache_transpose(A)
-gen = torch.Generator(device="cuda"); gen.manual_seed(1)
-visited = device.vector_from_device(torch.ones(n, dtype=torch.bool, device="cuda"), present=torch.rand(n, generator=gen, device="cuda") < 0.3)
 L = _lib.lib
-sr = gb.semiring.lor_land["BOOL"]
-desc = _lib.handle("GrB_DESC_RSC")
-for dens in (1e-6, 1e-5, 1e-4, 1e-3, 1e-2, 1e-1):
+
+
+def time_call(fn, reps=5):
+    outs = []
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        device.timer_start()
+        fn()
+        outs.append(device.timer_stop())
+    return min(outs)
+
+
+def bfs_grid(scale):
+    n = 1 << scale
+    indptr, col = synthetic.rmat_csr(scale, device="cuda")
+    A = device.matrix_from_device_csr(indptr, col, torch.ones(1, dtype=torch.bool, device="cuda"), n, n, "BOOL", iso=True)
+    device.cache_transpose(A)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(1)
+    sr, desc = gb.semiring.lor_land["BOOL"], _lib.handle("GrB_DESC_RSC")
+    points = [(3.0 / n, 0.0)] + [(fd, vd) for fd in (1e-4, 1e-2, 0.3) for vd in (0.0, 0.5, 0.9)]
+    for fd, vd in points:
+        visited = device.vector_from_device(torch.ones(n, dtype=torch.bool, device="cuda"), present=torch.rand(n, generator=gen, device="cuda") < vd)
+        present = torch.rand(n, generator=gen, device="cuda") < fd
+        if fd * n < 10:
+            present = torch.zeros(n, dtype=torch.bool, device="cuda")
+            present[torch.randint(0, n, (3,), generator=gen, device="cuda")] = True
+        q = device.vector_from_device(torch.ones(n, dtype=torch.bool, device="cuda"), present=present)
+        res = {}
+        for mode, name in ((0, "pull"), (2, "push"), (1, "auto")):
+            L.GrX_option_set(b"push_mode", mode)
+            keep = {}
+
+            def call():
+                keep["w"] = w = gb.Vector("BOOL", n)
+                assert L.GrB_vxm(w._carg, visited._carg, None, sr._carg, q._carg, A._carg, desc) == 0
+
+            for _ in range(3):
+                call()  # (layouts; operands settle in their order)
+            res[name + "_ms"] = time_call(call)
+            res[name + "_nvals"] = keep["w"].nvals
+            st = device.last_stats()
+            res[name + "_method"] = st["method"]
+            if name == "push":
+                res["work"] = st["flops"]
+        assert res["pull_nvals"] == res["push_nvals"] == res["auto_nvals"], res
+        print(json.dumps({"workload": "bfs_level_step lor_land", "scale": scale, "frontier_density": fd, "visited_density": vd,
+                          "frontier_nvals": int(present.sum().item()), **res}), flush=True)
+    L.GrX_option_set(b"push_mode", 1)
+
+
+def sssp_sparse_u(scale=20, dens=1e-3):
+    n = 1 << scale
+    indptr, col = synthetic.rmat_csr(scale, device="cuda")
+    A = device.matrix_from_device_csr(indptr, col, synthetic.edge_weights(col, scale), n, n, "FP32")
+    device.cache_transpose(A)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(2)
+    d = torch.randint(0, 1000, (n,), generator=gen, device="cuda").to(torch.float32)
     present = torch.rand(n, generator=gen, device="cuda") < dens
-    q = device.vector_from_device(torch.ones(n, dtype=torch.bool, device="cuda"), present=present)
+    u = device.vector_from_device(d, present=present)
+    sr, acc = gb.semiring.min_plus["FP32"], gb.binary.min["FP32"]
     res = {}
-    for mode, name in ((0, "pull"), (2, "push")):
+    for mode, name in ((0, "pull"), (2, "push"), (1, "auto")):
         L.GrX_option_set(b"push_mode", mode)
-        outs = []
-        for rep in range(4):
-            w = gb.Vector("BOOL", n)
-            torch.cuda.synchronize()
-            device.timer_start()
-            rc = L.GrB_vxm(w._carg, visited._carg, None, sr._carg, q._carg, A._carg, desc)
-            ms = device.timer_stop()
-            assert rc == 0
-            outs.append(ms)
-        res[name] = min(outs)
-        res[name + "_nvals"] = w.nvals
+        keep = {}
+
+        def call():
+            keep["w"] = w = device.vector_from_device(d)
+            assert L.GrB_mxv(w._carg, None, acc._carg, sr._carg, A._carg, u._carg, None) == 0
+
+        for _ in range(3):
+            call()
+        res[name + "_ms"] = time_call(call)
         res[name + "_method"] = device.last_stats()["method"]
-    assert res["pull_nvals"] == res["push_nvals"]
-    print(json.dumps({"scale": scale, "frontier_density": dens, "frontier_nvals": int(present.sum().item()), **res}), flush=True)
-L.GrX_option_set(b"push_mode", 1)
+        res[name + "_sum"] = float(keep["w"].reduce(gb.monoid.plus).new().value)
+    assert res["pull_sum"] == res["push_sum"] == res["auto_sum"], res
+    print(json.dumps({"workload": "sssp_step w(min) << A min.+ u, sparse u", "scale": scale, "u_density": dens, "u_nvals": int(present.sum().item()), **res}), flush=True)
+    L.GrX_option_set(b"push_mode", 1)
+
+
+if scale != 24:
+    bfs_grid(scale)
+else:
+    bfs_grid(22)
+    sssp_sparse_u(20)
+    bfs_grid(24)

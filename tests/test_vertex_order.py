@@ -193,10 +193,11 @@ def ewise_np(a, b, n, tname, add):
     return np.flatnonzero(has), out[has].astype(O.NP_OF[tname])
 
 
-@pytest.mark.parametrize("seed", range(3))
+@pytest.mark.parametrize("seed", range(6))
 def test_sssp_and_bfs_loops_stay_ordered(gb, seed):
     """The reference's traversal loops (docs/getting_started/primer.rst:236-246, notebooks Example B.1) on an ordered matrix: after the first
-    sweep no vector is converted again, and the results are the oracle's."""
+    sweep no vector is converted again -- also when thin frontiers take the push direction, whose kernels translate positions through the
+    order's maps (seeds 3-5: even sweeps forced to push, odd ones to pull) -- and the results are the oracle's."""
     from graphblas_amd import device
 
     rng = np.random.default_rng(4500 + seed)
@@ -204,21 +205,55 @@ def test_sssp_and_bfs_loops_stay_ordered(gb, seed):
     rows, cols, vals = skewed_square(rng, n, "FP32")
     oa = O.OMat.from_coo(rows, cols, vals, n, n, "FP32")
     src = int(rows[np.argmax(np.bincount(rows, minlength=n)[rows])])
+    push = seed >= 3
     try:
-        set_opts(ORDER_OPTS + ((b"hot_k", 256),))
+        set_opts(ORDER_OPTS + ((b"hot_k", 256), (b"push_mode", 1 if push else 0)))
         G = gb.Matrix.from_coo(rows, cols, vals, dtype="FP32", nrows=n, ncols=n)
+        # ---- SSSP (Bellman-Ford sweeps until nothing changes)
         v = gb.Vector("FP32", size=n)
         v[src] = 0
         ov = O.OVec(n, np.array([src]), np.array([0], np.float32), "FP32")
-        conversions = []
+        conversions, methods = [], []
         for it in range(n):
+            if push:  # (even sweeps pushed, odd ones pulled: the operands change direction without changing order)
+                set_opts(((b"push_mode", 2 if it % 2 == 0 else 0),))
             w = v.dup()
             v(gb.binary.min) << v.vxm(G, gb.semiring.min_plus)
-            conversions.append(device.last_stats()["reorders"])
+            st = device.last_stats()
+            conversions.append(st["reorders"])
+            methods.append(st["method"])
             ov = O.vxm(ov, oa, "min_plus", w=ov, accum="min")
             if v.isequal(w):
                 break
         same_vec(v, ov)
-        assert it >= 2 and sum(conversions[1:]) == 0, conversions  # (the first sweep converts v; after that everything stays)
+        first_pull = methods.index(1)
+        assert it >= 2 and sum(conversions[first_pull + 1:]) == 0, (conversions, methods)  # (the first pull converts v; after that everything stays)
+        if push:
+            assert methods[0] == 2 and methods[1] == 1 and methods[2] == 2, methods
+        # ---- level BFS: levels[:](mask=q.V) << level; q(~levels.S, replace) << q.vxm(G, lor_land) -- on the BOOL view of the graph
+        Gb = gb.Matrix.from_coo(rows, cols, np.ones(rows.size, bool), dtype="BOOL", nrows=n, ncols=n)
+        ob = O.OMat.from_coo(rows, cols, np.ones(rows.size, bool), n, n, "BOOL")
+        q = gb.Vector("BOOL", size=n)
+        q[src] = True
+        levels = gb.Vector("INT64", size=n)
+        oq = O.OVec(n, np.array([src]), np.array([True]), "BOOL")
+        olev_i, olev_v = [], []
+        conv = []
+        for level in range(n):
+            if q.nvals == 0:
+                break
+            if push:
+                set_opts(((b"push_mode", 2 if level % 2 == 0 else 0),))
+            levels(mask=q.V)[:] << level
+            olev_i += oq.idx.tolist()
+            olev_v += [level] * oq.idx.size
+            q(~levels.S, replace=True) << q.vxm(Gb, gb.semiring.lor_land)
+            conv.append((device.last_stats()["method"], device.last_stats()["reorders"]))
+            seen = O.OVec(n, np.array(sorted(olev_i)), np.ones(len(olev_i), bool), "BOOL")
+            oq = O.vxm(oq, ob, "lor_land", w=oq, mask=seen, mask_comp=True, mask_struct=True, replace=True)
+        li, lv = levels.to_coo()
+        order = np.argsort(olev_i)
+        assert li.tolist() == np.asarray(olev_i)[order].tolist() and lv.tolist() == np.asarray(olev_v)[order].tolist()
+        assert level >= 2, conv
     finally:
         set_opts(RESTORE)
