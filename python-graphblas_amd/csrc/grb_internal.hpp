@@ -226,6 +226,7 @@ struct GB_Vector_opaque {
                                // Every entry point takes vectors in natural order (check_vector converts) except the ones that are
                                // order-aware: mxv / vxm on the matrix the order belongs to, the element-wise operations, reduce, dup,
                                // element access.  An ordered vector without entries is converted for free.
+    bool exported = false;     // its device pointers were handed out (GrX_Vector_export_dense_device): conversions keep them (copy back)
     bool pinned = false;       // never leave this vector in another than the natural order (its HBM image is aliased outside the library)
     std::string err;
 };

@@ -1465,6 +1465,9 @@ static int push_thin(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_Binar
     if (u->n > 0xffffffffull || w->n > 0x7fffffffull || !u->d_val) return -1;
     const int64_t n_in = (int64_t)u->n, n_out = (int64_t)w->n;
     if (ctx().push_mode == 1 && u->nvals >= 0 && u->nvals * 64 >= n_in) return 0;
+    // (a frontier vertex has at least the mean degree: with this many of them the products pass the direction threshold below for sure --
+    //  no attempt, no host read)
+    if (ctx().push_mode == 1 && u->nvals >= 0 && n_in > 0 && (double)u->nvals * ((double)P->nvals / (double)n_in) * 128.0 > (double)P->nvals) return 0;
     // the operands in one order: natural, or the vertex order they already share (a square matrix's: the maps translate)
     GB_Vector_opaque *vs[3] = {u, w, mask};
     GB_Perm *ord = (u->n == w->n) ? vectors_common_order(vs, 3) : nullptr;

@@ -332,7 +332,23 @@ __global__ void k_vec_permute(int64_t n, const int32_t *src_of, const T *old_val
     if ((threadIdx.x & 63) == 0 && t < ((n + 63) & ~(int64_t)63)) new_bits[t >> 6] = b;
 }
 
-// In place: the vector keeps its device pointers (they may be aliased outside the library: GrX_Vector_export_dense_device).
+// new[dst_of[s]] = old[s] for the PRESENT positions s only (new_bits zeroed by the caller): a thread per presence word of the old image
+template <typename T>
+__global__ void k_vec_permute_sparse(int64_t n, const int32_t *dst_of, const T *old_val, const uint64_t *old_bits, T *new_val, unsigned long long *new_bits)
+{
+    const int64_t wd = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (wd >= ((n + 63) >> 6)) return;
+    for (uint64_t bits = old_bits[wd]; bits; bits &= bits - 1) {
+        const int64_t s = (wd << 6) + (__ffsll((long long)bits) - 1);
+        const int64_t t = dst_of[s];
+        new_val[t] = old_val[s];
+        atomicOr(&new_bits[t >> 6], 1ull << (t & 63));
+    }
+}
+
+// A vector whose device pointers were handed out keeps them (converted into a temporary, copied back); any other vector swaps to a
+// fresh pair.  Few entries (known count below n / 16, e.g. the frontier and level vectors of the first BFS levels): only the present
+// entries move -- a pass over the presence words and a scatter -- instead of a gather over all n positions.
 void vector_set_order(GB_Vector_opaque *v, GB_Perm *order)
 {
     if (v->order == order) return;
@@ -340,21 +356,48 @@ void vector_set_order(GB_Vector_opaque *v, GB_Perm *order)
     const bool has_entries = v->d_val && v->nvals != 0 && v->n > 0;
     if (has_entries && v->order && order) vector_set_order(v, nullptr);  // (between two orders: through the natural one)
     if (has_entries) {
-        // into an order: position p takes the element d_inv[p]; back: element i comes from position d_rank[i]
-        const int32_t *src_of = order ? order->d_inv : v->order->d_rank;
         const int64_t n = (int64_t)v->n;
         const size_t vb = (size_t)n * v->type->size, bb = bits_words64(v->n) * 8;
-        DevBuf<char> tv(vb);
-        DevBuf<uint64_t> tb(bits_words64(v->n));
-        const int64_t threads = (int64_t)bits_words64(v->n) * 64;
-        switch (v->type->size) {
-        case 1: LAUNCH((k_vec_permute<uint8_t>), threads, n, src_of, (const uint8_t *)v->d_val, (const uint64_t *)v->d_bits, (uint8_t *)tv.p, tb.p); break;
-        case 2: LAUNCH((k_vec_permute<uint16_t>), threads, n, src_of, (const uint16_t *)v->d_val, (const uint64_t *)v->d_bits, (uint16_t *)tv.p, tb.p); break;
-        case 4: LAUNCH((k_vec_permute<uint32_t>), threads, n, src_of, (const uint32_t *)v->d_val, (const uint64_t *)v->d_bits, (uint32_t *)tv.p, tb.p); break;
-        default: LAUNCH((k_vec_permute<uint64_t>), threads, n, src_of, (const uint64_t *)v->d_val, (const uint64_t *)v->d_bits, (uint64_t *)tv.p, tb.p); break;
+        if (n >= (1 << 16) && v->nvals < 0) (void)vector_nvals(v);  // (one host read decides between the two forms)
+        const bool sparse = v->nvals >= 0 && v->nvals * 16 < n;
+        void *nval = nullptr;
+        uint64_t *nbits = nullptr;
+        vector_alloc_pair(v, v->padded, false, &nval, &nbits);  // (presence zeroed)
+        try {
+            if (sparse) {
+                // forward maps: into an order, element i goes to position d_rank[i]; back, position p goes to element d_inv[p]
+                const int32_t *dst_of = order ? order->d_rank : v->order->d_inv;
+                const int64_t threads = (int64_t)bits_words64(v->n);
+                switch (v->type->size) {
+                case 1: LAUNCH((k_vec_permute_sparse<uint8_t>), threads, n, dst_of, (const uint8_t *)v->d_val, (const uint64_t *)v->d_bits, (uint8_t *)nval, (unsigned long long *)nbits); break;
+                case 2: LAUNCH((k_vec_permute_sparse<uint16_t>), threads, n, dst_of, (const uint16_t *)v->d_val, (const uint64_t *)v->d_bits, (uint16_t *)nval, (unsigned long long *)nbits); break;
+                case 4: LAUNCH((k_vec_permute_sparse<uint32_t>), threads, n, dst_of, (const uint32_t *)v->d_val, (const uint64_t *)v->d_bits, (uint32_t *)nval, (unsigned long long *)nbits); break;
+                default: LAUNCH((k_vec_permute_sparse<uint64_t>), threads, n, dst_of, (const uint64_t *)v->d_val, (const uint64_t *)v->d_bits, (uint64_t *)nval, (unsigned long long *)nbits); break;
+                }
+            } else {
+                // inverse maps: into an order, position p takes the element d_inv[p]; back, element i comes from position d_rank[i]
+                const int32_t *src_of = order ? order->d_inv : v->order->d_rank;
+                const int64_t threads = (int64_t)bits_words64(v->n) * 64;
+                switch (v->type->size) {
+                case 1: LAUNCH((k_vec_permute<uint8_t>), threads, n, src_of, (const uint8_t *)v->d_val, (const uint64_t *)v->d_bits, (uint8_t *)nval, nbits); break;
+                case 2: LAUNCH((k_vec_permute<uint16_t>), threads, n, src_of, (const uint16_t *)v->d_val, (const uint64_t *)v->d_bits, (uint16_t *)nval, nbits); break;
+                case 4: LAUNCH((k_vec_permute<uint32_t>), threads, n, src_of, (const uint32_t *)v->d_val, (const uint64_t *)v->d_bits, (uint32_t *)nval, nbits); break;
+                default: LAUNCH((k_vec_permute<uint64_t>), threads, n, src_of, (const uint64_t *)v->d_val, (const uint64_t *)v->d_bits, (uint64_t *)nval, nbits); break;
+                }
+            }
+        } catch (...) {
+            vector_free_pair(v->padded, nval, nbits);
+            throw;
         }
-        d2d(v->d_val, tv.p, vb);
-        d2d(v->d_bits, tb.p, bb);
+        if (v->exported) {
+            d2d(v->d_val, nval, vb);
+            d2d(v->d_bits, nbits, bb);
+            vector_free_pair(v->padded, nval, nbits);
+        } else {
+            vector_free_pair(v->padded, v->d_val, v->d_bits);
+            v->d_val = nval;
+            v->d_bits = nbits;
+        }
         ctx().reorder_count += 1;
     }
     perm_retain(order);
@@ -1447,6 +1490,7 @@ extern "C" GrB_Info GrX_Vector_export_dense_device(const void **d_val, const uin
     require_init();
     check_vector(v, "v");
     vector_ensure_storage(v);
+    v->exported = true;  // (from now on conversions between vertex orders keep these pointers)
     if (d_val) *d_val = v->d_val;
     if (d_present) *d_present = (const uint32_t *)v->d_bits;
     GRB_CATCH(errp(v))
