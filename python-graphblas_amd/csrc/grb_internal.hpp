@@ -106,6 +106,7 @@ struct Context {
     int lazy_layout = 1;             // 1: the SpMV layouts of a large matrix are built at its SECOND pull product, not its first
     int64_t lazy_min_nnz = 1 << 22;  // ... for matrices with at least this many entries (smaller ones build at once)
     int push_mode = 1;               // 0 never push, 1 push when u has < n/64 entries, 2 always push (tests)
+    int value_dict = 1;              // 1: hot-strip records carry 1-byte value codes when the matrix has at most 256 distinct values
     int order_mode = 1;              // 1: large square matrices get popularity-ordered pull layouts and keep their operands in that order
                                      // (grb_mxv_order.inc); 0: never
     int64_t order_min_nnz = 48ll << 20;  // ... from this many entries (the layouts that profit are the ones of lean_min_nnz)
@@ -289,6 +290,11 @@ struct GB_Matrix_opaque {
     // (d_lcol[0] is the first entry of chunk cold_cb[0]); d_sstart / d_sslot cover both
     char *d_hrec = nullptr;
     int hrec_bytes = 0;                // bytes of one lane record
+    // ... with the values DICTIONARY-CODED when the matrix holds at most 256 distinct ones (4-byte types; grb_mxv_vdict.inc): a lane
+    // record is [8 LDS slots as u16 | 8 value codes as u8] = 24 bytes, the kernels look the values up (LDS / L1) -- exact, whatever the
+    // values are, and half the bytes of the stream the hot strips are bound by
+    void *d_vdict = nullptr;           // 256 values of the matrix type (unused codes: 0)
+    int vdict_n = 0;                   // distinct values found (0: no dictionary)
     // ... the cold entries as tagged tiles (k_mxv_ctile, grb_mxv_ctile.inc): sorted by (column range, long row), tile t = (range
     // t / ct_nsb, rows [8192 (t % ct_nsb), ...)) holds entries [tiles[t].u0 * 4, ... + 4 n_units): column code, value, 16-bit row in the tile
     int32_t *d_ct_col = nullptr;

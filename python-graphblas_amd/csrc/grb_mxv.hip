@@ -34,6 +34,7 @@ namespace grb {
 #include "grb_mxv_common.inc"
 #include "grb_mxv_pull.inc"
 #include "grb_mxv_long.inc"
+#include "grb_mxv_vdict.inc"
 #include "grb_mxv_strip.inc"
 #include "grb_mxv_rows.inc"
 #include "grb_mxv_rows_tag.inc"
@@ -346,7 +347,46 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
                 const int64_t hot_chunks = kind == 4 ? h_cb[ncls] : 0;   // chunks of the hot strips (kind 4: all of them)
                 const int64_t flat_entries = kind == 4 ? 0 : padded;     // entries held by d_lcol / d_lval
                 const int code_bytes = A->type->code == TC_BOOL ? 32 : 16;
-                const int val_bytes = A->iso ? 0 : (int)std::max<size_t>(16, 8 * A->type->size);
+                // value dictionary (grb_mxv_vdict.inc): at most 256 distinct finite values of a 4-byte type -> one-byte codes in the records
+                DevBuf<unsigned long long> vd_table(VDICT_SLOTS, true);
+                DevBuf<unsigned char> vd_codes(VDICT_SLOTS, true);
+                bool use_dict = false;
+                dev_free(A->d_vdict);
+                A->d_vdict = nullptr;
+                A->vdict_n = 0;
+                if (kind == 4 && ctx().value_dict && !A->iso && A->type->size == 4 && A->type->code != TC_BOOL) {
+                    DevBuf<unsigned int> vd_count(1, true);
+                    hipLaunchKernelGGL(k_vdict_collect, dim3((unsigned)std::min<int64_t>(ceil_div(nnz, 256), (int64_t)ctx().num_cus * 16)), dim3(256), 0, ctx().stream,
+                                       (const uint32_t *)A->d_val, nnz, vd_table.p, vd_count.p);
+                    unsigned int h_count = 0;
+                    d2h(&h_count, vd_count.p, sizeof(h_count));
+                    if (h_count >= 1 && h_count <= 256) {
+                        std::vector<unsigned long long> h_table(VDICT_SLOTS);
+                        d2h(h_table.data(), vd_table.p, sizeof(unsigned long long) * VDICT_SLOTS);
+                        std::vector<uint32_t> dict(256, 0u);
+                        std::vector<unsigned char> h_codes(VDICT_SLOTS, 0);
+                        int next = 0;
+                        bool finite = true;
+                        for (int sl = 0; sl < VDICT_SLOTS; sl++) {
+                            if (!h_table[(size_t)sl]) continue;
+                            const uint32_t bits = (uint32_t)h_table[(size_t)sl];
+                            if (A->type->code == TC_FP32 && ((bits >> 23) & 0xffu) == 0xffu) finite = false;  // (inf / NaN: the padding trick of the fast kernel needs finite values)
+                            if (next < 256) {
+                                dict[(size_t)next] = bits;
+                                h_codes[(size_t)sl] = (unsigned char)next;
+                            }
+                            next++;
+                        }
+                        if (finite && next == (int)h_count) {
+                            A->d_vdict = dev_alloc(256 * sizeof(uint32_t));
+                            h2d(A->d_vdict, dict.data(), 256 * sizeof(uint32_t));
+                            h2d(vd_codes.p, h_codes.data(), VDICT_SLOTS);
+                            A->vdict_n = next;
+                            use_dict = true;
+                        }
+                    }
+                }
+                const int val_bytes = A->iso ? 0 : (use_dict ? 8 : (int)std::max<size_t>(16, 8 * A->type->size));
                 if (padded > 0 && padded < 0x7fffffff0ll) {
                     A->d_lcol = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)std::max<int64_t>(flat_entries, 1));
                     A->d_lval = A->iso ? nullptr : dev_alloc(A->type->size * (size_t)std::max<int64_t>(flat_entries, 1));
@@ -375,7 +415,9 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
                                            (const uint32_t *)idx2.p, n_strip, (const int64_t *)blk.p, (const int64_t *)seg_first.p,
                                            (const int64_t *)off.p, (const int64_t *)cshift.p, nl, strip_sub, col_src, (const T *)A->d_val,
                                            A->iso ? 1 : 0, A->cls_lds_lim, ncls, A->d_lcol, (T *)A->d_lval, A->d_sstart, A->d_sslot,
-                                           A->d_hrec, A->hrec_bytes, hot_chunks * STRIP_CH, hot_cls);
+                                           A->d_hrec, A->hrec_bytes, hot_chunks * STRIP_CH, hot_cls,
+                                           use_dict ? (const unsigned long long *)vd_table.p : (const unsigned long long *)nullptr,
+                                           use_dict ? (const unsigned char *)vd_codes.p : (const unsigned char *)nullptr);
                     })
                     {
                         int64_t h_end[MAXC];
@@ -851,12 +893,22 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
                 // hot strips (lane records, LDS gathers only), then the cold strips (image gathers) with a token LDS array
                 a.hrec = A->d_hrec;
                 a.hrec_bytes = A->hrec_bytes;
+                a.vdict = A->vdict_n > 0 ? A->d_vdict : nullptr;
+                ctx().stats.value_dict = A->vdict_n;
                 if (A->strip_cb[A->strip_ncls] > 0) {
                     bool launched = false;
                     if constexpr (MON >= 0) {
                         if constexpr (hstrip_fast_semiring<T>(MON, MUL)) {
                             if (hot_fast) {
-                                hipLaunchKernelGGL((k_mxv_hstrip<T, MON, MUL, LONG_LDS_WORDS>), dim3((unsigned)G), dim3(LONG_BLOCK), 0, ctx().stream, a);
+                                bool dict_launched = false;
+                                if constexpr (sizeof(T) == 4) {
+                                    if (a.vdict) {
+                                        hipLaunchKernelGGL((k_mxv_hstrip<T, MON, MUL, LONG_LDS_WORDS, true>), dim3((unsigned)G), dim3(LONG_BLOCK), 0, ctx().stream, a);
+                                        dict_launched = true;
+                                    }
+                                }
+                                if (!dict_launched)
+                                    hipLaunchKernelGGL((k_mxv_hstrip<T, MON, MUL, LONG_LDS_WORDS>), dim3((unsigned)G), dim3(LONG_BLOCK), 0, ctx().stream, a);
                                 launched = true;
                             }
                         }

@@ -85,8 +85,11 @@ def sssp_sparse_u(scale=20, dens=1e-3):
             call()
         res[name + "_ms"] = time_call(call)
         res[name + "_method"] = device.last_stats()["method"]
-        res[name + "_sum"] = float(keep["w"].reduce(gb.monoid.plus).new().value)
-    assert res["pull_sum"] == res["push_sum"] == res["auto_sum"], res
+        # (compared entry for entry with the pull result: a float sum over a million values depends on the order they are stored in)
+        if name == "pull":
+            ref = keep["w"]
+        else:
+            assert keep["w"].isequal(ref), (name, res)
     print(json.dumps({"workload": "sssp_step w(min) << A min.+ u, sparse u", "scale": scale, "u_density": dens, "u_nvals": int(present.sum().item()), **res}), flush=True)
     L.GrX_option_set(b"push_mode", 1)
 

@@ -257,3 +257,39 @@ def test_sssp_and_bfs_loops_stay_ordered(gb, seed):
         assert level >= 2, conv
     finally:
         set_opts(RESTORE)
+
+
+@pytest.mark.parametrize("case", ["256_values", "257_values", "with_inf", "dict_off"])
+def test_value_dictionary_boundaries(gb, case):
+    """Hot-strip records carry one-byte value codes when a 4-byte matrix holds at most 256 distinct finite values (grb_mxv_vdict.inc):
+    exactly 256 (coded), 257 (not coded), an infinite value among few (not coded: the fast kernel's padding needs finite values), and
+    the option switched off -- the same results either way, against the oracle, through the fast kernel (full operand) and the generic one
+    (sparse operand), ordered layouts."""
+    from graphblas_amd import device
+
+    rng = np.random.default_rng(77)
+    n = 3000
+    rows, cols, _ = skewed_square(rng, n, "FP32")
+    k = {"256_values": 256, "257_values": 257, "with_inf": 9, "dict_off": 9}[case]
+    pool = (np.arange(1, k + 1) * 0.5).astype(np.float32)
+    if case == "with_inf":
+        pool[3] = np.inf
+    vals = pool[rng.integers(0, k, rows.size)]
+    vals[:k] = pool  # (every value of the pool occurs)
+    oa = O.OMat.from_coo(rows, cols, vals, n, n, "FP32")
+    try:
+        set_opts(ORDER_OPTS + ((b"hot_k", 1 << 20), (b"value_dict", 0 if case == "dict_off" else 1)))
+        A = gb.Matrix.from_coo(rows, cols, vals, dtype="FP32", nrows=n, ncols=n)
+        for dens in (1.0, 0.4):
+            ui, uv = rand_vec(rng, n, dens, "FP32")
+            u = gb.Vector.from_coo(ui, uv, dtype="FP32", size=n)
+            for sr in ("min_plus", "plus_times", "max_plus"):
+                got = A.mxv(u, getattr(gb.semiring, sr)).new()
+                st = device.last_stats()
+                assert st["ordered"] == 1 and st["value_dict"] == (256 if case == "256_values" else 0), st
+                exp = O.mxv(oa, O.OVec(n, ui, uv, "FP32"), sr)
+                gi, gv = got.to_coo()
+                assert gi.tolist() == exp.idx.tolist()
+                np.testing.assert_array_equal(gv, exp.vals)
+    finally:
+        set_opts(RESTORE + ((b"value_dict", 1),))
