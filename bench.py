@@ -495,7 +495,7 @@ def run_mxm(args, gb, torch, device, rank, world, dist, barrier, *, scale, workl
     ip_b, col_b = synthetic.rmat_csr(scale, device="cuda")
     # rows of A cut so that every rank carries the same number of multiplies (not the same number of rows): no collective
     # constrains the block sizes here
-    sharded_path = world > 1 or args.force_dist  # (--force-dist: the flop-balanced cuts and the row view of A with one rank)
+    sharded_path = world > 1 or getattr(args, "force_dist", False)  # (--force-dist: the flop-balanced cuts and the row view of A with one rank)
     if sharded_path:
         cuts = sharded.balanced_cuts(sharded.flops_prefix(ip_b, col_b, ip_b[1:] - ip_b[:-1]), world)
         lo, hi = cuts[rank], cuts[rank + 1]

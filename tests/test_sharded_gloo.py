@@ -378,6 +378,56 @@ def test_row_sharded_mxm_flop_balanced():
         assert res[r][5] == blkm.indptr.tolist() and res[r][6] == blkm.indices.tolist() and res[r][7] == blkm.data.tolist()
 
 
+def _mxm_streamed_worker(rank, world, port, q, scale, budget):
+    """What bench.py's sharded scale-22 line does per rank: GrX_mxm_streamed over the rank's flop-balanced row block in row batches
+    under a byte budget (small here: several batches), then the ranks' entry counts, checksums and multiply counts are summed."""
+    import ctypes
+
+    gb, dist = _init(rank, world, port)
+    import torch
+
+    from graphblas_amd import _lib, device, sharded, synthetic
+
+    n = 1 << scale
+    ip, col = synthetic.rmat_csr(scale, device="cpu")
+    one = torch.ones(1, dtype=torch.int64)
+    B = device.matrix_from_device_csr(ip, col, one, n, n, "INT64", copy=True, iso=True)
+    cuts = sharded.balanced_cuts(sharded.flops_prefix(ip, col, ip[1:] - ip[:-1]), world)
+    lo, hi = cuts[rank], cuts[rank + 1]
+    e0, e1 = int(ip[lo]), int(ip[hi])
+    A = device.matrix_from_device_csr((ip[lo:hi + 1] - ip[lo]).contiguous(), col[e0:e1].contiguous(), one, hi - lo, n, "INT64", copy=True, iso=True)
+    nv, cs, fl, nb = (ctypes.c_uint64(0) for _ in range(4))
+    rc = _lib.lib.GrX_mxm_streamed(gb.semiring.plus_times["INT64"]._carg, A._carg, B._carg, ctypes.c_uint64(budget), ctypes.byref(nv), ctypes.byref(cs),
+                                   ctypes.byref(fl), ctypes.byref(nb))
+    assert rc == 0
+    t = torch.tensor([nv.value, cs.value, fl.value], dtype=torch.int64)
+    dist.all_reduce(t)  # (the only exchange of the sharded product: three counters)
+    q.put((rank, (t.tolist(), int(nb.value), int(nv.value))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_row_sharded_mxm_streamed_counts():
+    """The sharded form of the scale-22 SpGEMM line (the product streamed in row batches per rank, only counters leave): summed over
+    the ranks, the entry count is nnz(A A), the checksum and the multiply count are the number of multiplies -- against scipy; every
+    rank really ran several batches."""
+    import scipy.sparse as sp
+
+    from graphblas_amd import synthetic
+
+    scale, world = 8, 2
+    res = _spawn(_mxm_streamed_worker, world, (scale, 1 << 16))
+    n = 1 << scale
+    ip, col = synthetic.rmat_csr(scale, device="cpu")
+    S = sp.csr_matrix((np.ones(col.numel(), np.int64), col.numpy(), ip.numpy()), shape=(n, n))
+    ref = (S @ S).tocsr()
+    flops = int(np.diff(ip.numpy())[col.numpy()].sum())
+    for r in range(world):
+        assert res[r][0] == [ref.nnz, flops, flops], (res[r], ref.nnz, flops)
+        assert res[r][1] >= 2  # (batches)
+    assert sum(res[r][2] for r in range(world)) == ref.nnz
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # the overlapped step bench.py --gpus N runs (sharded.OverlappedMxv): every rank owns `chunks` row blocks, two replicas of u,
 # the all-gather of block c is issued asynchronously while block c + 1 is computed
