@@ -295,6 +295,9 @@ struct GB_Matrix_opaque {
     // values are, and half the bytes of the stream the hot strips are bound by
     void *d_vdict = nullptr;           // 256 values of the matrix type (unused codes: 0)
     int vdict_n = 0;                   // distinct values found (0: no dictionary)
+    unsigned long long *d_vd_table = nullptr;  // the hash table value -> slot the codes were assigned from (build time: placement kernels)
+    unsigned char *d_vd_codes = nullptr;       // code of every slot
+    // (the cold tiles and the tagged row groups of such a matrix carry the one-byte codes too: d_ct_val / d_tg_val are then byte arrays)
     // ... the cold entries as tagged tiles (k_mxv_ctile, grb_mxv_ctile.inc): sorted by (column range, long row), tile t = (range
     // t / ct_nsb, rows [8192 (t % ct_nsb), ...)) holds entries [tiles[t].u0 * 4, ... + 4 n_units): column code, value, 16-bit row in the tile
     int32_t *d_ct_col = nullptr;

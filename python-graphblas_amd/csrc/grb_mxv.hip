@@ -152,6 +152,47 @@ static void report_phase_times(const long long *d_times, int64_t n_tiles)
             sum[5] / n_tiles, sum[6] / n_tiles, tmax - tmin);
 }
 
+// value dictionary of a matrix (grb_mxv_vdict.inc): at most 256 distinct finite values of a 4-byte type -> one-byte codes in the lane
+// records of the hot strips, the cold tiles and the tagged row groups.  Sets A->vdict_n (0: none).
+static void ensure_vdict(GB_Matrix_opaque *A, bool wanted)
+{
+    dev_free(A->d_vdict); dev_free(A->d_vd_table); dev_free(A->d_vd_codes);
+    A->d_vdict = nullptr; A->d_vd_table = nullptr; A->d_vd_codes = nullptr;
+    A->vdict_n = 0;
+    const int64_t nnz = A->nvals;
+    if (!wanted || !ctx().value_dict || A->iso || A->type->size != 4 || A->type->code == TC_BOOL || nnz == 0) return;
+    DevBuf<unsigned long long> vd_table(VDICT_SLOTS, true);
+    DevBuf<unsigned int> vd_count(1, true);
+    hipLaunchKernelGGL(k_vdict_collect, dim3((unsigned)std::min<int64_t>(ceil_div(nnz, 256), (int64_t)ctx().num_cus * 16)), dim3(256), 0, ctx().stream,
+                       (const uint32_t *)A->d_val, nnz, vd_table.p, vd_count.p);
+    unsigned int h_count = 0;
+    d2h(&h_count, vd_count.p, sizeof(h_count));
+    if (h_count < 1 || h_count > 256) return;
+    std::vector<unsigned long long> h_table(VDICT_SLOTS);
+    d2h(h_table.data(), vd_table.p, sizeof(unsigned long long) * VDICT_SLOTS);
+    std::vector<uint32_t> dict(256, 0u);
+    std::vector<unsigned char> h_codes(VDICT_SLOTS, 0);
+    int next = 0;
+    for (int sl = 0; sl < VDICT_SLOTS; sl++) {
+        if (!h_table[(size_t)sl]) continue;
+        const uint32_t bits = (uint32_t)h_table[(size_t)sl];
+        if (A->type->code == TC_FP32 && ((bits >> 23) & 0xffu) == 0xffu) return;  // (inf / NaN: the padding trick of the fast kernel needs finite values)
+        if (next < 256) {
+            dict[(size_t)next] = bits;
+            h_codes[(size_t)sl] = (unsigned char)next;
+        }
+        next++;
+    }
+    if (next != (int)h_count) return;
+    A->d_vdict = dev_alloc(256 * sizeof(uint32_t));
+    h2d(A->d_vdict, dict.data(), 256 * sizeof(uint32_t));
+    A->d_vd_table = (unsigned long long *)dev_alloc(sizeof(unsigned long long) * VDICT_SLOTS);
+    h2d(A->d_vd_table, h_table.data(), sizeof(unsigned long long) * VDICT_SLOTS);
+    A->d_vd_codes = (unsigned char *)dev_alloc(VDICT_SLOTS);
+    h2d(A->d_vd_codes, h_codes.data(), VDICT_SLOTS);
+    A->vdict_n = next;
+}
+
 // Analyse (once) whether the rows split usefully into long and short ones and build the two parts.
 // `col_src` is the column array the kernels will index (hot-coded or original).
 static void ensure_tagged(GB_Matrix_opaque *A);
@@ -216,6 +257,7 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
     d2h(&nl, lflag.p + m, 8);
     d2h(&nc, nchunk.p + m, 8);
     if (nl == 0 || (double)(nnz - nnz_short) < 0.3 * (double)nnz) return;  // too few entries in long rows to pay off
+    ensure_vdict(A, kind == 4);
     GB_Matrix_opaque *S = matrix_new(A->type, A->nrows, A->ncols);
     try {
         S->d_ptr = slen.release();
@@ -347,45 +389,7 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
                 const int64_t hot_chunks = kind == 4 ? h_cb[ncls] : 0;   // chunks of the hot strips (kind 4: all of them)
                 const int64_t flat_entries = kind == 4 ? 0 : padded;     // entries held by d_lcol / d_lval
                 const int code_bytes = A->type->code == TC_BOOL ? 32 : 16;
-                // value dictionary (grb_mxv_vdict.inc): at most 256 distinct finite values of a 4-byte type -> one-byte codes in the records
-                DevBuf<unsigned long long> vd_table(VDICT_SLOTS, true);
-                DevBuf<unsigned char> vd_codes(VDICT_SLOTS, true);
-                bool use_dict = false;
-                dev_free(A->d_vdict);
-                A->d_vdict = nullptr;
-                A->vdict_n = 0;
-                if (kind == 4 && ctx().value_dict && !A->iso && A->type->size == 4 && A->type->code != TC_BOOL) {
-                    DevBuf<unsigned int> vd_count(1, true);
-                    hipLaunchKernelGGL(k_vdict_collect, dim3((unsigned)std::min<int64_t>(ceil_div(nnz, 256), (int64_t)ctx().num_cus * 16)), dim3(256), 0, ctx().stream,
-                                       (const uint32_t *)A->d_val, nnz, vd_table.p, vd_count.p);
-                    unsigned int h_count = 0;
-                    d2h(&h_count, vd_count.p, sizeof(h_count));
-                    if (h_count >= 1 && h_count <= 256) {
-                        std::vector<unsigned long long> h_table(VDICT_SLOTS);
-                        d2h(h_table.data(), vd_table.p, sizeof(unsigned long long) * VDICT_SLOTS);
-                        std::vector<uint32_t> dict(256, 0u);
-                        std::vector<unsigned char> h_codes(VDICT_SLOTS, 0);
-                        int next = 0;
-                        bool finite = true;
-                        for (int sl = 0; sl < VDICT_SLOTS; sl++) {
-                            if (!h_table[(size_t)sl]) continue;
-                            const uint32_t bits = (uint32_t)h_table[(size_t)sl];
-                            if (A->type->code == TC_FP32 && ((bits >> 23) & 0xffu) == 0xffu) finite = false;  // (inf / NaN: the padding trick of the fast kernel needs finite values)
-                            if (next < 256) {
-                                dict[(size_t)next] = bits;
-                                h_codes[(size_t)sl] = (unsigned char)next;
-                            }
-                            next++;
-                        }
-                        if (finite && next == (int)h_count) {
-                            A->d_vdict = dev_alloc(256 * sizeof(uint32_t));
-                            h2d(A->d_vdict, dict.data(), 256 * sizeof(uint32_t));
-                            h2d(vd_codes.p, h_codes.data(), VDICT_SLOTS);
-                            A->vdict_n = next;
-                            use_dict = true;
-                        }
-                    }
-                }
+                const bool use_dict = A->vdict_n > 0;
                 const int val_bytes = A->iso ? 0 : (use_dict ? 8 : (int)std::max<size_t>(16, 8 * A->type->size));
                 if (padded > 0 && padded < 0x7fffffff0ll) {
                     A->d_lcol = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)std::max<int64_t>(flat_entries, 1));
@@ -416,8 +420,8 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
                                            (const int64_t *)off.p, (const int64_t *)cshift.p, nl, strip_sub, col_src, (const T *)A->d_val,
                                            A->iso ? 1 : 0, A->cls_lds_lim, ncls, A->d_lcol, (T *)A->d_lval, A->d_sstart, A->d_sslot,
                                            A->d_hrec, A->hrec_bytes, hot_chunks * STRIP_CH, hot_cls,
-                                           use_dict ? (const unsigned long long *)vd_table.p : (const unsigned long long *)nullptr,
-                                           use_dict ? (const unsigned char *)vd_codes.p : (const unsigned char *)nullptr);
+                                           use_dict ? (const unsigned long long *)A->d_vd_table : (const unsigned long long *)nullptr,
+                                           use_dict ? (const unsigned char *)A->d_vd_codes : (const unsigned char *)nullptr);
                     })
                     {
                         int64_t h_end[MAXC];
@@ -440,6 +444,10 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
                     sync_stream();  // (the temporaries above are released at the end of this scope)
                 }
             }
+            // (measured, profiles/r04/value_dict.txt: one-byte codes make the tagged row groups 5 % faster -- 9 -> 6 bytes per entry of a
+            //  kernel that streams them all -- and the cold tiles 7 % SLOWER: their stream is a third of their time, the code load + LDS
+            //  lookup per entry costs more than the bytes it saves.  The tiles keep full values.)
+            const bool use_dict_all = false;
             if (kind == 4 && nnz_long > n_strip) {
                 // the cold entries as tagged tiles: a (column range, slot block) pair is one tile, or several when it holds more than
                 // CT_MAX_ENTRIES entries (the hub rows: the sorted run is cut into equal pieces -- a piece still lies inside the
@@ -504,10 +512,11 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
                 DevBuf<int64_t> efirst(nt + 1);
                 h2d(efirst.p, h_efirst.data(), sizeof(int64_t) * (size_t)(nt + 1));
                 A->d_ct_col = (int32_t *)dev_alloc(sizeof(int32_t) * ents);
-                A->d_ct_val = A->iso ? nullptr : dev_alloc(A->type->size * ents);
+                const size_t ct_vb = use_dict_all ? 1 : A->type->size;  // (dictionary-coded matrices: one byte per value)
+                A->d_ct_val = A->iso ? nullptr : dev_alloc(ct_vb * ents);
                 A->d_ct_loc = (uint16_t *)dev_alloc(sizeof(uint16_t) * ents);
                 GRB_HIP(hipMemsetAsync(A->d_ct_col, 0xff, sizeof(int32_t) * ents, ctx().stream));
-                if (A->d_ct_val) GRB_HIP(hipMemsetAsync(A->d_ct_val, 0, A->type->size * ents, ctx().stream));
+                if (A->d_ct_val) GRB_HIP(hipMemsetAsync(A->d_ct_val, 0, ct_vb * ents, ctx().stream));
                 GRB_HIP(hipMemsetAsync(A->d_ct_loc, 0, sizeof(uint16_t) * ents, ctx().stream));
                 const int64_t n_cold = nnz_long - n_strip;
                 {
@@ -522,7 +531,9 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
                     GRB_DISPATCH_TYPE(A->type->code, T, {
                         hipLaunchKernelGGL((k_ctile_place<T>), dim3((unsigned)ceil_div(n_cold, 256)), dim3(256), 0, ctx().stream, (const uint64_t *)keys2.p,
                                            (const uint32_t *)idx2.p, n_strip, n_cold, (const uint64_t *)key2s.p, (const uint32_t *)pays.p, (const int64_t *)efirst.p,
-                                           (const CTile *)A->d_ct_tiles, (const T *)A->d_val, A->iso ? 1 : 0, A->d_ct_col, (T *)A->d_ct_val, A->d_ct_loc);
+                                           (const CTile *)A->d_ct_tiles, (const T *)A->d_val, A->iso ? 1 : 0, A->d_ct_col, (T *)A->d_ct_val, A->d_ct_loc,
+                                           use_dict_all ? (const unsigned long long *)A->d_vd_table : (const unsigned long long *)nullptr,
+                                           use_dict_all ? (const unsigned char *)A->d_vd_codes : (const unsigned char *)nullptr);
                     })
                     sync_stream();
                 }
@@ -825,14 +836,18 @@ static void ensure_tagged(GB_Matrix_opaque *A)
                        A->d_tg_off);
     const size_t ents = (size_t)std::max<int64_t>(units, 1) * TAG_EPL;
     A->d_tg_col = (int32_t *)dev_alloc(sizeof(int32_t) * ents);
-    A->d_tg_val = S->iso ? nullptr : dev_alloc(S->type->size * ents);
+    const bool dict = A->vdict_n > 0;  // (dictionary-coded matrices: one byte per value)
+    const size_t tg_vb = dict ? 1 : S->type->size;
+    A->d_tg_val = S->iso ? nullptr : dev_alloc(tg_vb * ents);
     A->d_tg_tag = (unsigned char *)dev_alloc(ents);
     GRB_HIP(hipMemsetAsync(A->d_tg_col, 0xff, sizeof(int32_t) * ents, ctx().stream));
-    if (A->d_tg_val) GRB_HIP(hipMemsetAsync(A->d_tg_val, 0, S->type->size * ents, ctx().stream));
+    if (A->d_tg_val) GRB_HIP(hipMemsetAsync(A->d_tg_val, 0, tg_vb * ents, ctx().stream));
     GRB_HIP(hipMemsetAsync(A->d_tg_tag, 0x40, ents, ctx().stream));
     GRB_DISPATCH_TYPE(S->type->code, T, {
         hipLaunchKernelGGL((k_tag_fill<T>), dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, ctx().stream, sptr, (const int32_t *)S->d_col,
-                           (const T *)S->d_val, S->iso ? 1 : 0, m, (const int64_t *)cnt.p, A->d_tg_col, (T *)A->d_tg_val, A->d_tg_tag);
+                           (const T *)S->d_val, S->iso ? 1 : 0, m, (const int64_t *)cnt.p, A->d_tg_col, (T *)A->d_tg_val, A->d_tg_tag,
+                           dict ? (const unsigned long long *)A->d_vd_table : (const unsigned long long *)nullptr,
+                           dict ? (const unsigned char *)A->d_vd_codes : (const unsigned char *)nullptr);
     })
     sync_stream();  // (cnt is released at the end of this scope)
     A->tg_units = units;
@@ -919,6 +934,7 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
                 if (A->ct_units > 0) {  // the cold entries: tagged tiles, column range by column range per XCD
                     a.ct_col = A->d_ct_col;
                     a.ct_val = A->d_ct_val;
+                    a.ct_dict = 0;  // (set with use_dict_all in ensure_split: the tiles keep full values)
                     a.ct_loc = A->d_ct_loc;
                     a.ct_tiles = (const CTile *)A->d_ct_tiles;
                     a.ct_order = A->d_ct_order;
@@ -977,6 +993,7 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
             b.tg_off = A->d_tg_off;
             b.tg_col = A->d_tg_col;
             b.tg_val = A->d_tg_val;
+            b.vdict = A->vdict_n > 0 ? A->d_vdict : nullptr;
             b.tg_tag = A->d_tg_tag;
             b.tg_nonempty = A->d_tg_nonempty;
             int64_t groups = ceil_div(b.m, 64);
@@ -1744,7 +1761,7 @@ extern "C" GrB_Info GrX_Matrix_cache_bytes(const GrB_Matrix A, uint64_t *bytes)
         const GB_Matrix_opaque *S = A->short_part;
         b += 8ull * (A->nrows + 1) + (A->short_tagged_only ? 0 : 4ull * (uint64_t)S->nvals + (S->iso ? vs : vs * (uint64_t)S->nvals));
         b += bits_words64(A->nrows) * 8 + 4ull * (uint64_t)A->n_long + 4ull * bits_words64(A->nrows) + 16ull * (uint64_t)A->n_chunks;
-        if (A->tg_state == 1) b += (uint64_t)A->tg_units * TAG_EPL * (5 + (A->d_tg_val ? vs : 0)) + 12ull * ((A->nrows + 63) / 64);
+        if (A->tg_state == 1) b += (uint64_t)A->tg_units * TAG_EPL * (5 + (A->d_tg_val ? (A->vdict_n > 0 ? 1 : vs) : 0)) + 12ull * ((A->nrows + 63) / 64);
         if (A->split_kind == 4 && (A->strip_nseg > 0 || A->ct_units > 0)) {
             const uint64_t hot_lanes = (uint64_t)A->strip_cb[A->strip_ncls] * 64;
             const uint64_t cold = (uint64_t)A->ct_units * CT_EPL;

@@ -716,8 +716,8 @@ void matrix_invalidate_caches(GB_Matrix_opaque *A)
     dev_free(A->d_sstart);
     dev_free(A->d_sslot);
     dev_free(A->d_hrec);
-    dev_free(A->d_vdict);
-    A->d_vdict = nullptr;
+    dev_free(A->d_vdict); dev_free(A->d_vd_table); dev_free(A->d_vd_codes);
+    A->d_vdict = nullptr; A->d_vd_table = nullptr; A->d_vd_codes = nullptr;
     A->vdict_n = 0;
     dev_free(A->d_ct_col); dev_free(A->d_ct_val); dev_free(A->d_ct_loc); dev_free(A->d_ct_tiles);
     A->d_ct_col = nullptr; A->d_ct_val = nullptr; A->d_ct_loc = nullptr; A->d_ct_tiles = nullptr; A->ct_units = 0;
