@@ -106,6 +106,7 @@ struct Context {
     int lazy_layout = 1;             // 1: the SpMV layouts of a large matrix are built at its SECOND pull product, not its first
     int64_t lazy_min_nnz = 1 << 22;  // ... for matrices with at least this many entries (smaller ones build at once)
     int push_mode = 1;               // 0 never push, 1 push when u has < n/64 entries, 2 always push (tests)
+    int hub_min_len = 1024;          // rows of an ordered matrix from this many entries are dealt to 64 column classes (0: no hub level)
     int value_dict = 1;              // 1: hot-strip records carry 1-byte value codes when the matrix has at most 256 distinct values
     int order_mode = 1;              // 1: large square matrices get popularity-ordered pull layouts and keep their operands in that order
                                      // (grb_mxv_order.inc); 0: never
@@ -280,8 +281,17 @@ struct GB_Matrix_opaque {
     // [strip_cb[c], strip_cb[c+1]) of 512 entries, sorted by (sub-range, row); segments start at multiples of 8 entries
     unsigned long long *d_sstart = nullptr;  // per chunk: bit l = a segment starts at lane l's 8 entries
     int32_t *d_sslot = nullptr;        // per lane (8 entries): accumulator slot (index into d_long_rows), -1 = padding
-    int64_t strip_cb[65] = {0};
+    int64_t strip_cb[161] = {0};        // (+ the hub level's classes behind the first strip_ncls, see hub_ncls)
     int strip_ncls = 8;
+    // ... a matrix in its popularity order deals the entries of its HUB rows (>= hub_min_len entries) to hub_ncls = 64 classes instead of
+    // 16: four times the LDS-resident codes (2.5 Mi: 95 % of the references of an R-MAT graph instead of 81 %) at segments that are still
+    // long enough for the 8-entry lane records.  Their strips are the classes [strip_ncls, strip_ncls + hub_ncls) of strip_cb, run by a
+    // second launch of the strip kernel
+    int hub_ncls = 0;                  // 0: no hub level
+    int hub_lds_lim = 0;               // codes below it are LDS-resident in the hub level's classes
+    int32_t *d_wg_tab = nullptr;       // workgroup table of the one-launch form of k_mxv_hstrip over both levels (PullArgs::wg_tab), wg_tab_g workgroups
+    int64_t *d_strip_cb = nullptr;     // device copy of strip_cb
+    int wg_tab_g = 0;
     int64_t strip_nseg = 0;
     // ... or as HOT / COLD strips (long_kernel = 4, split kind 3; grb_mxv_strip.inc): the entries whose column code is LDS-resident in
     // its class live in d_hrec -- per lane of 8 entries one record [8 LDS slots as u16 (u32 for BOOL) | 8 values] -- in chunks

@@ -228,7 +228,7 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
         dev_free(A->d_tg_off); dev_free(A->d_tg_col); dev_free(A->d_tg_val); dev_free(A->d_tg_tag); dev_free(A->d_tg_nonempty);
         A->d_tg_off = nullptr; A->d_tg_col = nullptr; A->d_tg_val = nullptr; A->d_tg_tag = nullptr; A->d_tg_nonempty = nullptr; A->tg_state = 0;
         dev_free(A->d_sstart); dev_free(A->d_sslot); dev_free(A->d_hrec);
-        A->d_sstart = nullptr; A->d_sslot = nullptr; A->d_hrec = nullptr; A->strip_nseg = 0;
+        A->d_sstart = nullptr; A->d_sslot = nullptr; A->d_hrec = nullptr; A->strip_nseg = 0; A->hub_ncls = 0;
         dev_free(A->d_ct_col); dev_free(A->d_ct_val); dev_free(A->d_ct_loc); dev_free(A->d_ct_tiles); dev_free(A->d_ct_order);
         A->d_ct_col = nullptr; A->d_ct_val = nullptr; A->d_ct_loc = nullptr; A->d_ct_tiles = nullptr; A->d_ct_order = nullptr; A->ct_units = 0; A->ct_ntiles = 0;
         A->d_lcol = nullptr; A->d_lval = nullptr; A->d_it_start = nullptr; A->d_it_len = nullptr; A->d_it_slot = nullptr;
@@ -309,21 +309,27 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
             DevBuf<uint32_t> idx(nnz_long), idx2(nnz_long);
             // (a matrix in its popularity order carries its own column ranges: about equal reference counts, at most ~2 MiB of operand)
             const bool own_ranges = kind == 4 && A->hot_identity && A->d_cold_bounds && A->ct_ncr > 0;
+            // ... and deals its hub rows to 64 classes (GB_Matrix_opaque::hub_ncls): only there are the LDS heads lines of the operand
+            // itself -- with a per-call hot table four times the codes would cost four times the image
+            const int hub_ncls = (own_ranges && ctx().hub_min_len > 0 && ncls < 64) ? 64 : 0;
+            const int64_t hub_lim = hub_ncls ? std::min<int64_t>((int64_t)A->ncols, long_lds_codes((int)A->type->size, A->type->code == TC_BOOL, LONG_LDS_WORDS) / 8 * hub_ncls) : 0;
+            const int64_t hub_len = hub_ncls ? (int64_t)ctx().hub_min_len : 0;
             if (kind == 4)
                 hipLaunchKernelGGL(k_long_keys, dim3((unsigned)nl), dim3(256), 0, ctx().stream, (const int64_t *)A->d_ptr,
                                    (const int64_t *)S->d_ptr, (const int32_t *)A->d_long_rows, col_src, nl, keys.p, idx.p,
                                    (unsigned)lds_lim4, (unsigned)std::max<int64_t>(1, ceil_div(codes_total - std::max<int64_t>(lds_lim4, hot ? A->hot_k : 0), (int64_t)COLD_CLS * (int64_t)sub)),
                                    sub, sub_min_len, (unsigned)ncls, 2, (unsigned)(hot ? A->hot_k : 0),
-                                   own_ranges ? (const int32_t *)A->d_cold_bounds : (const int32_t *)nullptr, own_ranges ? A->ct_ncr + 1 : 0);
+                                   own_ranges ? (const int32_t *)A->d_cold_bounds : (const int32_t *)nullptr, own_ranges ? A->ct_ncr + 1 : 0,
+                                   hub_len, (unsigned)hub_lim, (unsigned)hub_ncls);
             else
             hipLaunchKernelGGL(k_long_keys, dim3((unsigned)nl), dim3(256), 0, ctx().stream, (const int64_t *)A->d_ptr,
                                (const int64_t *)S->d_ptr, (const int32_t *)A->d_long_rows, col_src, nl, keys.p, idx.p,
                                (unsigned)(hot ? A->hot_k : 0), (unsigned)std::max<int64_t>(1, ceil_div((int64_t)A->ncols, (int64_t)ncls * (int64_t)sub)),
-                               sub, sub_min_len, (unsigned)ncls, kind == 2 ? 1 : 0, 0u, (const int32_t *)nullptr, 0);
+                               sub, sub_min_len, (unsigned)ncls, kind == 2 ? 1 : 0, 0u, (const int32_t *)nullptr, 0, (int64_t)0, 0u, 0u);
             // (virtual classes: kind 2 ncls * sub; kind 4 ncls hot classes + COLD_CLS cold ranges, with `sub` = 1 in the segment tables)
-            const int nvc = ncls;                                                       // classes of the strips (chunk ranges)
+            const int nvc = ncls + hub_ncls;                                            // classes of the strips (chunk ranges)
             const int n_cr = own_ranges ? A->ct_ncr : COLD_CLS * (int)sub;             // kind 4: column ranges of the cold tiles
-            const int nvirt = kind == 4 ? ncls + n_cr : ncls * (int)sub;                // virtual classes (sort keys)
+            const int nvirt = kind == 4 ? nvc + n_cr : ncls * (int)sub;                 // virtual classes (sort keys)
             const int hot_cls = 0;
             const unsigned strip_sub = kind == 4 ? 1u : sub;                            // virtual classes per strip class
             if (strips) {
@@ -343,16 +349,18 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
             int64_t n_strip = nnz_long;
             if (kind == 4) {
                 hipLaunchKernelGGL(k_ctile_first, dim3((unsigned)ceil_div(n_tiles + 1, 256)), dim3(256), 0, ctx().stream, (const uint64_t *)keys2.p, nnz_long,
-                                   n_tiles, n_sb, (unsigned)ncls, tile_first.p, ct_slots);
+                                   n_tiles, n_sb, (unsigned)nvc, tile_first.p, ct_slots);
                 d2h(h_first.data(), tile_first.p, sizeof(int64_t) * (size_t)(n_tiles + 1));
                 n_strip = h_first[0];
             }
             if (kind == 4) {
                 A->long_nnz = nnz_long;
                 A->strip_ncls = ncls;
+                A->hub_ncls = hub_ncls;
+                A->hub_lds_lim = (int)hub_lim;
                 A->strip_nseg = 0;
                 A->cls_lds_lim = (int)lds_lim4;
-                for (int c = 0; c <= ncls; c++) A->strip_cb[c] = 0;
+                for (int c = 0; c <= nvc; c++) A->strip_cb[c] = 0;
             }
             if (strips && n_strip > 0) {
                 // flat class strips (grb_mxv_strip.inc): segments = runs of equal keys; every segment padded to a multiple of 8
@@ -370,7 +378,7 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
                 hipLaunchKernelGGL(k_strip_plen, dim3((unsigned)ceil_div(nseg + 1, 256)), dim3(256), 0, ctx().stream, (const int64_t *)seg_first.p,
                                    nseg, off.p);
                 prim_exclusive_sum_i64(off.p, off.p, nseg + 1);
-                constexpr int MAXC = 64 + 8;
+                constexpr int MAXC = 160;
                 DevBuf<int64_t> sc(MAXC + 1), raw(MAXC + 1), cshift(MAXC);
                 hipLaunchKernelGGL(k_strip_class_bounds, dim3(1), dim3(128), 0, ctx().stream, (const uint64_t *)keys2.p, (const int64_t *)seg_first.p,
                                    nseg, nl, strip_sub, (const int64_t *)off.p, sc.p, raw.p, nvc, hot_cls);
@@ -386,7 +394,7 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
                 const int64_t padded = base, nch = padded / STRIP_CH;
                 h2d(cshift.p, h_shift, sizeof(int64_t) * (size_t)nvc);
                 A->cls_lds_lim = (int)lds_lim4;
-                const int64_t hot_chunks = kind == 4 ? h_cb[ncls] : 0;   // chunks of the hot strips (kind 4: all of them)
+                const int64_t hot_chunks = kind == 4 ? h_cb[nvc] : 0;    // chunks of the hot strips (kind 4: all of them)
                 const int64_t flat_entries = kind == 4 ? 0 : padded;     // entries held by d_lcol / d_lval
                 const int code_bytes = A->type->code == TC_BOOL ? 32 : 16;
                 const bool use_dict = A->vdict_n > 0;
@@ -421,7 +429,7 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
                                            A->iso ? 1 : 0, A->cls_lds_lim, ncls, A->d_lcol, (T *)A->d_lval, A->d_sstart, A->d_sslot,
                                            A->d_hrec, A->hrec_bytes, hot_chunks * STRIP_CH, hot_cls,
                                            use_dict ? (const unsigned long long *)A->d_vd_table : (const unsigned long long *)nullptr,
-                                           use_dict ? (const unsigned char *)A->d_vd_codes : (const unsigned char *)nullptr);
+                                           use_dict ? (const unsigned char *)A->d_vd_codes : (const unsigned char *)nullptr, hub_ncls, (int)hub_lim);
                     })
                     {
                         int64_t h_end[MAXC];
@@ -432,9 +440,61 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
                                            (const int64_t *)cshift.p, (const int64_t *)cend.p, nvc, A->d_sstart);
                         sync_stream();
                     }
-                    for (int c = 0; c <= ncls; c++) A->strip_cb[c] = h_cb[c];
+                    for (int c = 0; c <= nvc; c++) A->strip_cb[c] = h_cb[c];
+                    dev_free(A->d_wg_tab); dev_free(A->d_strip_cb);
+                    A->d_wg_tab = nullptr; A->d_strip_cb = nullptr; A->wg_tab_g = 0;
+                    if (hub_ncls > 0) {
+                        // one launch of the fast strip kernel over both levels: the persistent workgroups (one per CU) are dealt to the nvc
+                        // classes by chunk count -- every class with chunks gets one, the rest go to whichever class has the most chunks
+                        // per workgroup left
+                        const int G = std::max(nvc, ctx().num_cus);
+                        std::vector<int> wgs((size_t)nvc, 0);
+                        int used = 0;
+                        for (int c = 0; c < nvc; c++)
+                            if (h_cb[c + 1] > h_cb[c]) { wgs[(size_t)c] = 1; used++; }
+                        while (used < G) {
+                            int best = -1;
+                            double best_load = -1.0;
+                            for (int c = 0; c < nvc; c++) {
+                                if (!wgs[(size_t)c]) continue;
+                                const double load = (double)(h_cb[c + 1] - h_cb[c]) / wgs[(size_t)c];
+                                if (load > best_load) { best_load = load; best = c; }
+                            }
+                            if (best < 0) break;
+                            wgs[(size_t)best]++;
+                            used++;
+                        }
+                        std::vector<int32_t> tab((size_t)G * 5, 0);
+                        int b = 0;
+                        // (workgroups of one class are spread over the launch order, not adjacent: consecutive ones land on different XCDs)
+                        std::vector<int> next((size_t)nvc, 0);
+                        for (int round = 0; b < G; round++) {
+                            bool any = false;
+                            for (int c = 0; c < nvc && b < G; c++) {
+                                if (next[(size_t)c] >= wgs[(size_t)c]) continue;
+                                any = true;
+                                int32_t *t = &tab[(size_t)b * 5];
+                                t[0] = c;
+                                t[1] = c < ncls ? c : c - ncls;
+                                t[2] = c < ncls ? ncls : hub_ncls;
+                                t[3] = next[(size_t)c]++;
+                                t[4] = wgs[(size_t)c];
+                                b++;
+                            }
+                            if (!any) break;
+                        }
+                        for (; b < G; b++) {  // (no class left: an idle workgroup of class 0 behind its last chunk)
+                            int32_t *t = &tab[(size_t)b * 5];
+                            t[0] = 0; t[1] = 0; t[2] = ncls; t[3] = 1 << 28; t[4] = 1;
+                        }
+                        A->d_wg_tab = (int32_t *)dev_alloc(sizeof(int32_t) * tab.size());
+                        h2d(A->d_wg_tab, tab.data(), sizeof(int32_t) * tab.size());
+                        A->d_strip_cb = (int64_t *)dev_alloc(sizeof(int64_t) * (size_t)(nvc + 1));
+                        h2d(A->d_strip_cb, h_cb, sizeof(int64_t) * (size_t)(nvc + 1));
+                        A->wg_tab_g = G;
+                    }
                     if (getenv("GRB_PRINT_STRIPS")) {  // (diagnostic: chunks per class -- a persistent class with more chunks than the others sets the kernel's time)
-                        fprintf(stderr, "[strips kind %d] %d classes, chunks per class:", kind, nvc);
+                        fprintf(stderr, "[strips kind %d] %d classes (%d of them the hub level's), chunks per class:", kind, nvc, hub_ncls);
                         for (int c = 0; c < nvc; c++) fprintf(stderr, " %lld", (long long)(h_cb[c + 1] - h_cb[c]));
                         fprintf(stderr, "  segments %lld\n", (long long)nseg);
                     }
@@ -640,7 +700,7 @@ static uint64_t order_signature()
     const Context &c = ctx();
     uint64_t h = 1469598103934665603ull;
     const int64_t v[] = {c.long_kernel, c.short_kernel, c.long_classes, c.split_min_len, c.long_sub, c.long_sub_min_len, c.lean_min_nnz,
-                         c.split_min_nnz, c.hot_k, c.drop_hot_cols};
+                         c.split_min_nnz, c.hot_k, c.drop_hot_cols, c.hub_min_len, c.value_dict};
     for (int64_t x : v) h = (h ^ (uint64_t)x) * 1099511628211ull;
     return h;
 }
@@ -910,31 +970,61 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
                 a.hrec_bytes = A->hrec_bytes;
                 a.vdict = A->vdict_n > 0 ? A->d_vdict : nullptr;
                 ctx().stats.value_dict = A->vdict_n;
-                if (A->strip_cb[A->strip_ncls] > 0) {
+                // the fast kernel takes both levels of an ordered matrix in ONE launch (workgroups dealt to the classes by chunk count)
+                bool merged = false;
+                if constexpr (MON >= 0) {
+                    if constexpr (hstrip_fast_semiring<T>(MON, MUL)) {
+                        if (hot_fast && A->hub_ncls > 0 && A->d_wg_tab && A->wg_tab_g > 0 && A->strip_cb[A->strip_ncls + A->hub_ncls] > 0) {
+                            PullArgs al = a;
+                            al.wg_tab = A->d_wg_tab;
+                            al.strip_cb_dev = A->d_strip_cb;
+                            al.strip_chunks = A->strip_cb[A->strip_ncls + A->hub_ncls];
+                            bool dict_launched = false;
+                            if constexpr (sizeof(T) == 4) {
+                                if (al.vdict) {
+                                    hipLaunchKernelGGL((k_mxv_hstrip<T, MON, MUL, LONG_LDS_WORDS, true>), dim3((unsigned)A->wg_tab_g), dim3(LONG_BLOCK), 0, ctx().stream, al);
+                                    dict_launched = true;
+                                }
+                            }
+                            if (!dict_launched)
+                                hipLaunchKernelGGL((k_mxv_hstrip<T, MON, MUL, LONG_LDS_WORDS>), dim3((unsigned)A->wg_tab_g), dim3(LONG_BLOCK), 0, ctx().stream, al);
+                            merged = true;
+                        }
+                    }
+                }
+                // otherwise level 0: the classes of all long rows; level 1 (an ordered matrix): the 64 classes of its hub rows, strip_cb[strip_ncls ..]
+                for (int level = 0; !merged && level < (A->hub_ncls > 0 ? 2 : 1); level++) {
+                    const int c0 = level ? A->strip_ncls : 0, nc = level ? A->hub_ncls : A->strip_ncls;
+                    if (A->strip_cb[c0 + nc] == A->strip_cb[c0]) continue;  // (no chunk at this level)
+                    PullArgs al = a;
+                    al.strip_ncls = nc;
+                    for (int c = 0; c <= nc; c++) al.strip_cb[c] = A->strip_cb[c0 + c];
+                    al.cls_lds_lim = level ? A->hub_lds_lim : A->cls_lds_lim;
+                    const int64_t Gl = std::max<int64_t>(nc, (int64_t)(ctx().num_cus / nc) * nc);
                     bool launched = false;
                     if constexpr (MON >= 0) {
                         if constexpr (hstrip_fast_semiring<T>(MON, MUL)) {
                             if (hot_fast) {
                                 bool dict_launched = false;
                                 if constexpr (sizeof(T) == 4) {
-                                    if (a.vdict) {
-                                        hipLaunchKernelGGL((k_mxv_hstrip<T, MON, MUL, LONG_LDS_WORDS, true>), dim3((unsigned)G), dim3(LONG_BLOCK), 0, ctx().stream, a);
+                                    if (al.vdict) {
+                                        hipLaunchKernelGGL((k_mxv_hstrip<T, MON, MUL, LONG_LDS_WORDS, true>), dim3((unsigned)Gl), dim3(LONG_BLOCK), 0, ctx().stream, al);
                                         dict_launched = true;
                                     }
                                 }
                                 if (!dict_launched)
-                                    hipLaunchKernelGGL((k_mxv_hstrip<T, MON, MUL, LONG_LDS_WORDS>), dim3((unsigned)G), dim3(LONG_BLOCK), 0, ctx().stream, a);
+                                    hipLaunchKernelGGL((k_mxv_hstrip<T, MON, MUL, LONG_LDS_WORDS>), dim3((unsigned)Gl), dim3(LONG_BLOCK), 0, ctx().stream, al);
                                 launched = true;
                             }
                         }
                     }
                     if (!launched)
-                        hipLaunchKernelGGL((k_mxv_strip<T, MON, MUL, LONG_LDS_WORDS, 1>), dim3((unsigned)G), dim3(LONG_BLOCK), 0, ctx().stream, a);
+                        hipLaunchKernelGGL((k_mxv_strip<T, MON, MUL, LONG_LDS_WORDS, 1>), dim3((unsigned)Gl), dim3(LONG_BLOCK), 0, ctx().stream, al);
+                    if (level) ctx().stats.kernel_launches += 1;
                 }
                 if (A->ct_units > 0) {  // the cold entries: tagged tiles, column range by column range per XCD
                     a.ct_col = A->d_ct_col;
                     a.ct_val = A->d_ct_val;
-                    a.ct_dict = 0;  // (set with use_dict_all in ensure_split: the tiles keep full values)
                     a.ct_loc = A->d_ct_loc;
                     a.ct_tiles = (const CTile *)A->d_ct_tiles;
                     a.ct_order = A->d_ct_order;
@@ -1763,7 +1853,7 @@ extern "C" GrB_Info GrX_Matrix_cache_bytes(const GrB_Matrix A, uint64_t *bytes)
         b += bits_words64(A->nrows) * 8 + 4ull * (uint64_t)A->n_long + 4ull * bits_words64(A->nrows) + 16ull * (uint64_t)A->n_chunks;
         if (A->tg_state == 1) b += (uint64_t)A->tg_units * TAG_EPL * (5 + (A->d_tg_val ? (A->vdict_n > 0 ? 1 : vs) : 0)) + 12ull * ((A->nrows + 63) / 64);
         if (A->split_kind == 4 && (A->strip_nseg > 0 || A->ct_units > 0)) {
-            const uint64_t hot_lanes = (uint64_t)A->strip_cb[A->strip_ncls] * 64;
+            const uint64_t hot_lanes = (uint64_t)A->strip_cb[A->strip_ncls + A->hub_ncls] * 64;
             const uint64_t cold = (uint64_t)A->ct_units * CT_EPL;
             b += hot_lanes * (uint64_t)A->hrec_bytes + hot_lanes * 4 + hot_lanes / 8 + cold * (6 + (A->d_ct_val ? vs : 0)) + 20ull * (uint64_t)A->ct_ntiles;
         } else if (A->split_kind == 2 && A->strip_nseg > 0) {

@@ -725,6 +725,9 @@ void matrix_invalidate_caches(GB_Matrix_opaque *A)
     A->d_sslot = nullptr;
     A->d_hrec = nullptr;
     A->strip_nseg = 0;
+    A->hub_ncls = 0;
+    dev_free(A->d_wg_tab); dev_free(A->d_strip_cb);
+    A->d_wg_tab = nullptr; A->d_strip_cb = nullptr; A->wg_tab_g = 0;
     A->pull_calls = 0;
     dev_free(A->d_tg_off); dev_free(A->d_tg_col); dev_free(A->d_tg_val); dev_free(A->d_tg_tag); dev_free(A->d_tg_nonempty);
     A->d_tg_off = nullptr; A->d_tg_col = nullptr; A->d_tg_val = nullptr; A->d_tg_tag = nullptr; A->d_tg_nonempty = nullptr;

@@ -19,7 +19,7 @@ from tests.test_random_parity import rand_vals, rand_vec, same_vec
 ORDER_OPTS = ((b"order_min_nnz", 1), (b"lean_min_nnz", 1), (b"split_min_nnz", 1), (b"split_min_len", 8), (b"push_mode", 0), (b"hot_min_cols", 8),
               (b"lazy_layout", 0), (b"vec_pad_min_bytes", 0))
 RESTORE = ((b"order_min_nnz", 48 << 20), (b"lean_min_nnz", 48 << 20), (b"split_min_nnz", 1 << 22), (b"split_min_len", 0), (b"push_mode", 1),
-           (b"hot_min_cols", 1 << 20), (b"hot_k", 0), (b"lazy_layout", 1), (b"vec_pad_min_bytes", 1 << 20), (b"long_classes", 16), (b"order_mode", 1))
+           (b"hot_min_cols", 1 << 20), (b"hot_k", 0), (b"lazy_layout", 1), (b"vec_pad_min_bytes", 1 << 20), (b"long_classes", 16), (b"order_mode", 1), (b"hub_min_len", 1024))
 
 
 @pytest.fixture(params=DEVICES)
@@ -69,7 +69,8 @@ def test_ordered_product_matches_the_oracle(gb, seed):
     ou, ow, om = O.OVec(n, ui, uv, tname), O.OVec(n, wi, wv, tname), O.OVec(n, mi, mv, "BOOL")
     exp = O.mxv(oa, ou, sr, w=ow, mask=om, mask_comp=comp, mask_struct=struct, accum=accum, replace=repl)
     try:
-        set_opts(ORDER_OPTS + ((b"hot_k", [64, 256, 1 << 20][seed % 3]), (b"long_classes", [16, 8, 32][seed % 3])))
+        # (hub_min_len: rows from this many entries are dealt to 64 classes -- a second level of hot strips; 0 switches it off)
+        set_opts(ORDER_OPTS + ((b"hot_k", [64, 256, 1 << 20][seed % 3]), (b"long_classes", [16, 8, 32][seed % 3]), (b"hub_min_len", [100, 0, 300, 1024][seed % 4])))
         A = gb.Matrix.from_coo(rows, cols, vals, dtype=tname, nrows=n, ncols=n)
         u = gb.Vector.from_coo(ui, uv, dtype=tname, size=n)
         w = gb.Vector.from_coo(wi, wv, dtype=tname, size=n)
@@ -278,7 +279,7 @@ def test_value_dictionary_boundaries(gb, case):
     vals[:k] = pool  # (every value of the pool occurs)
     oa = O.OMat.from_coo(rows, cols, vals, n, n, "FP32")
     try:
-        set_opts(ORDER_OPTS + ((b"hot_k", 1 << 20), (b"value_dict", 0 if case == "dict_off" else 1)))
+        set_opts(ORDER_OPTS + ((b"hot_k", 1 << 20), (b"value_dict", 0 if case == "dict_off" else 1), (b"hub_min_len", 200)))
         A = gb.Matrix.from_coo(rows, cols, vals, dtype="FP32", nrows=n, ncols=n)
         for dens in (1.0, 0.4):
             ui, uv = rand_vec(rng, n, dens, "FP32")
