@@ -25,6 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+PROFILE_ROUND = 4  # PMC traffic profiles of kernels from earlier rounds do not describe this library: only profiles/r04 (and later) count
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); 6290 GB/s measured copy
 
 
@@ -39,7 +40,7 @@ def measured_traffic(workload, scale):
             rec = json.load(open(path))
         except (OSError, ValueError):
             continue
-        if rec.get("workload") == workload and rec.get("scale") == scale:
+        if rec.get("workload") == workload and rec.get("scale") == scale and int(rec.get("round", 0)) >= PROFILE_ROUND:
             best = rec  # (directories sort by round: the newest matching profile wins)
     return best["traffic_bytes_per_launch"] if best else None
 
@@ -55,7 +56,7 @@ def measured_traffic_band(workload, scale):
             rec = json.load(open(path))
         except (OSError, ValueError):
             continue
-        if rec.get("workload") == workload and rec.get("scale") == scale:
+        if rec.get("workload") == workload and rec.get("scale") == scale and int(rec.get("round", 0)) >= PROFILE_ROUND:
             best = rec
     if not best:
         return None
@@ -915,6 +916,19 @@ def emit(line):
         os.write(_REAL_STDOUT, data)
 
 
+def library_build_state():
+    """Is the shared library the kernels were launched from up to date with the sources next to it?  (`make -q`: 0 = nothing to rebuild --
+    the prebuilt .so that travelled with the tree is what ran; 1 = sources are newer than the library.)"""
+    import subprocess
+
+    csrc = os.path.join(ROOT, "python-graphblas_amd", "csrc")
+    try:
+        rc = subprocess.run(["make", "-q", "-C", csrc, "libgrb_mi355x.so"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=60).returncode
+    except Exception as e:
+        return {"make_q": f"not run: {e!r}"}
+    return {"make_q": rc, "up_to_date": rc == 0, "library": os.environ.get("GRB_MI355X_LIB") or os.path.join(csrc, "libgrb_mi355x.so")}
+
+
 def respawn_under_launcher(args):
     """`python bench.py --gpus N` started without a launcher (no WORLD_SIZE in the environment): start N ranks of this very
     command under torch.distributed.run on this node -- or fail cleanly when the node has fewer than N GPUs."""
@@ -1158,6 +1172,7 @@ def main():
             "roofline": res["roofline"],
             "cpu_baseline": cpu,
             "stats": res["stats"],
+            "build": library_build_state(),
         }
         if "exchange" in res:
             out["exchange"] = res["exchange"]

@@ -737,7 +737,7 @@ static GB_Perm *ensure_perm(GB_Matrix_opaque *S, int64_t k_hot, DevBuf<unsigned 
         P->d_rank = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)n);
         P->d_inv = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)n);
         DevBuf<unsigned long long> live(2, true);
-        hipLaunchKernelGGL(k_order_place, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx().stream, (const uint32_t *)ids2.p, (const uint64_t *)keys2.p, n, k_hot,
+        hipLaunchKernelGGL(k_order_place, dim3((unsigned)ceil_div(n, 1024)), dim3(1024), 0, ctx().stream, (const uint32_t *)ids2.p, (const uint64_t *)keys2.p, n, k_hot,
                            P->d_rank, P->d_inv, poscnt.p, live.p);
         unsigned long long h_live[2] = {0, 0};
         d2h(h_live, live.p, sizeof(h_live));
@@ -802,7 +802,7 @@ static void ensure_ordered(GB_Matrix_opaque *S)
         })
         {
             DevBuf<unsigned long long> last(1, true);
-            hipLaunchKernelGGL(k_twin_live_rows, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx().stream, (const int64_t *)R->d_ptr, n, last.p);
+            hipLaunchKernelGGL(k_twin_live_rows, dim3((unsigned)ceil_div(n, 1024)), dim3(1024), 0, ctx().stream, (const int64_t *)R->d_ptr, n, last.p);
             unsigned long long h_last = 0;
             d2h(&h_last, last.p, sizeof(h_last));
             R->ord_live_rows = (int64_t)h_last;
