@@ -30,6 +30,7 @@ struct dim3 {
 struct uint3 { unsigned x, y, z; };
 struct uint4 { unsigned x, y, z, w; };
 struct uint2 { unsigned x, y; };
+struct ulonglong2 { unsigned long long x, y; };
 inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
 
 extern uint3 threadIdx, blockIdx;
