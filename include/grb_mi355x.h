@@ -242,7 +242,7 @@ GrB_Info GrX_Vector_import_dense_device(GrB_Vector *v, GrB_Type type, GrB_Index 
                                         const uint32_t *d_present);
 /* Borrow the device image of v (the pointers stay valid until v is resized, cleared or freed). *d_present has ceil(n/64)*2 words.
  * The image is in natural index order when the call returns; a later product with a large square matrix may leave v in that
- * matrix's vertex order (section "vertex order" below): export again after such a call, or pin the vector. */
+XX
 GrB_Info GrX_Vector_export_dense_device(const void **d_val, const uint32_t **d_present, const GrB_Vector v);
 /* pinned != 0: v is never left in another than the natural index order (its image is aliased outside the library for longer than
  * one call: RCCL buffers, torch views); products that involve it run on the natural-order layouts. */
