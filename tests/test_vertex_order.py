@@ -294,3 +294,88 @@ def test_value_dictionary_boundaries(gb, case):
                 np.testing.assert_array_equal(gv, exp.vals)
     finally:
         set_opts(RESTORE + ((b"value_dict", 1),))
+
+
+def test_ordered_vectors_in_unusual_flows(gb):
+    """Vectors kept in a matrix's order through the entry points that are NOT order-aware, and through the life cycle of the matrix: build
+    into / resize / clear / indexed assign and extract on an ordered vector, a mask that aliases the output, an operand that aliases the
+    output, two matrices with different orders sharing vectors, the matrix freed or rebuilt while vectors still carry its order, a pinned
+    vector.  Everything against the oracle."""
+    from graphblas_amd import device
+
+    rng = np.random.default_rng(911)
+    n = 2600
+    tname = "INT64"
+    rows, cols, vals = skewed_square(rng, n, tname)
+    rows2, cols2, vals2 = skewed_square(np.random.default_rng(912), n, tname)
+    oa, ob = O.OMat.from_coo(rows, cols, vals, n, n, tname), O.OMat.from_coo(rows2, cols2, vals2, n, n, tname)
+    ui, uv = rand_vec(rng, n, 0.6, tname)
+    ou = O.OVec(n, ui, uv, tname)
+    try:
+        set_opts(ORDER_OPTS + ((b"hot_k", 256), (b"hub_min_len", 200)))
+        A = gb.Matrix.from_coo(rows, cols, vals, dtype=tname, nrows=n, ncols=n)
+        B = gb.Matrix.from_coo(rows2, cols2, vals2, dtype=tname, nrows=n, ncols=n)
+        u = gb.Vector.from_coo(ui, uv, dtype=tname, size=n)
+        # ---- an operand that is also the output, a mask that is also the output
+        w = u.dup()
+        w << A.mxv(w, gb.semiring.plus_times)
+        assert device.last_stats()["ordered"] == 1
+        e1 = O.mxv(oa, ou, "plus_times")
+        same_vec(w, e1)
+        w2 = A.mxv(u, gb.semiring.min_plus).new()
+        w2(w2.S, accum=gb.binary.plus) << A.mxv(u, gb.semiring.min_plus)
+        e2 = O.mxv(oa, ou, "min_plus")
+        e2b = O.mxv(oa, ou, "min_plus", w=e2, mask=e2, mask_struct=True, accum="plus")
+        same_vec(w2, e2b)
+        # ---- two matrices, two orders: the vector goes from one to the other and back
+        x = A.mxv(u, gb.semiring.min_plus).new()          # in A's order
+        y = B.mxv(x, gb.semiring.min_plus).new()          # x converted to B's
+        z = A.mxv(y, gb.semiring.min_plus).new()
+        ey = O.mxv(ob, e2, "min_plus")
+        same_vec(z, O.mxv(oa, ey, "min_plus"))
+        same_vec(y, ey)
+        # ---- build into, indexed assign / extract, resize, clear on ordered vectors
+        t = A.mxv(u, gb.semiring.min_plus).new()          # ordered
+        idx = np.array([3, 77, 1500, 2599])
+        got = t[idx].new()
+        dense = {int(i): int(v) for i, v in zip(e2.idx, e2.vals)}
+        gi, gv = got.to_coo()
+        assert gi.tolist() == [k for k, i in enumerate(idx) if int(i) in dense] and gv.tolist() == [dense[int(i)] for i in idx if int(i) in dense]
+        t2 = A.mxv(u, gb.semiring.min_plus).new()
+        t2[idx] << 5
+        d2 = dict(dense)
+        for i in idx:
+            d2[int(i)] = 5
+        gi, gv = t2.to_coo()
+        assert gi.tolist() == sorted(d2) and gv.tolist() == [d2[i] for i in sorted(d2)]
+        t3 = A.mxv(u, gb.semiring.min_plus).new()
+        t3.resize(n - 100)
+        gi, gv = t3.to_coo()
+        keep = [i for i in sorted(dense) if i < n - 100]
+        assert gi.tolist() == keep and gv.tolist() == [dense[i] for i in keep]
+        t4 = A.mxv(u, gb.semiring.min_plus).new()
+        t4.clear()
+        assert t4.nvals == 0
+        t4.build([1, 2], [10, 20])
+        gi, gv = t4.to_coo()
+        assert gi.tolist() == [1, 2] and gv.tolist() == [10, 20]
+        # ---- the matrix goes away (or is modified) while a vector still carries its order
+        keepv = A.mxv(u, gb.semiring.min_plus).new()
+        del A
+        import gc
+
+        gc.collect()
+        same_vec(keepv, e2)
+        k2 = B.mxv(u, gb.semiring.min_plus).new()
+        B.resize(n, n)                                     # (drops B's cached layouts and its order; k2 still carries it)
+        k3 = B.mxv(k2, gb.semiring.min_plus).new()
+        same_vec(k3, O.mxv(ob, O.mxv(ob, ou, "min_plus"), "min_plus"))
+        # ---- a pinned vector keeps the products it takes part in on the natural layouts
+        A2 = gb.Matrix.from_coo(rows, cols, vals, dtype=tname, nrows=n, ncols=n)
+        p = gb.Vector.from_coo(ui, uv, dtype=tname, size=n)
+        device.vector_pin_natural(p)
+        r = A2.mxv(p, gb.semiring.min_plus).new()
+        assert device.last_stats()["ordered"] == 0
+        same_vec(r, e2)
+    finally:
+        set_opts(RESTORE)
