@@ -1,9 +1,10 @@
-"""The reference's own known-answer tests for the mxm / mxv / vxm path, replayed through this
-package's python-graphblas-shaped host API and the C-ABI library (HIP kernels on the GPU tier,
-the same kernel sources under the CPU SIMT emulator on the CPU tier).
+"""Behaviour of the python-graphblas-shaped host API around the mxm / mxv / vxm path -- updater spellings, accumulators, descriptors,
+recorder text, error classes, element access, the traversal loops, aggregators, `power`, indexed assign / extract, `dup` -- through the
+C-ABI library (HIP kernels on the GPU tier, the same kernel sources under the CPU SIMT emulator on the CPU tier).  Each test cites the
+reference code it follows (paths relative to /root/reference).
 
-Each test cites the reference test it mirrors (paths relative to /root/reference); the expected
-values are the reference's literals (also stored in tests/golden/reference_literals.json)."""
+The reference's VALUE-LEVEL literals for mxm / mxv / vxm (plain, masks, transposes, accum, the docs' tables, the primer's SSSP) are not
+restated here any more: tests/test_library_golden.py runs them through the library from tests/golden/reference_literals.json."""
 import numpy as np
 import pytest
 
@@ -44,68 +45,6 @@ def v(gb):
     return gb.Vector.from_coo([1, 3, 4, 6], [1, 1, 2, 0])
 
 
-def test_mxv(gb, A, v):
-    # graphblas/tests/test_matrix.py:389-392
-    w = A.mxv(v, gb.semiring.plus_times).new()
-    result = gb.Vector.from_coo([0, 1, 6], [5, 16, 13])
-    assert heq(w, result)
-
-
-def test_vxm(gb, A, v):
-    # graphblas/tests/test_vector.py:299-302  (explicit zero at index 3 is kept)
-    w = v.vxm(A, gb.semiring.plus_times).new()
-    result = gb.Vector.from_coo([0, 2, 3, 4, 5, 6], [3, 3, 0, 8, 14, 4])
-    assert heq(w, result)
-
-
-def test_vxm_transpose(gb, A, v):
-    # graphblas/tests/test_vector.py:305-308
-    w = v.vxm(A.T, gb.semiring.plus_times).new()
-    result = gb.Vector.from_coo([0, 1, 6], [5, 16, 13])
-    assert heq(w, result)
-
-
-def test_vxm_nonsquare(gb, v):
-    # graphblas/tests/test_vector.py:311-322
-    A = gb.Matrix.from_coo([0, 3], [0, 1], [10, 20], nrows=7, ncols=2)
-    u = gb.Vector(v.dtype, size=2)
-    u().update(v.vxm(A, gb.semiring.min_plus))
-    result = gb.Vector.from_coo([1], [21])
-    assert heq(u, result)
-    w1 = v.vxm(A, gb.semiring.min_plus).new()
-    assert heq(w1, u)
-    v2 = gb.Vector.from_coo([0, 1], [1, 2])
-    w2 = v2.vxm(A.T, gb.semiring.min_plus).new()
-    assert w2.size == 7
-
-
-def test_vxm_mask(gb, A, v):
-    # graphblas/tests/test_vector.py:325-347
-    Vector, semiring = gb.Vector, gb.semiring
-    val_mask = Vector.from_coo([0, 1, 2, 3, 4], [True, False, False, True, True], size=7)
-    struct_mask = Vector.from_coo([0, 3, 4], [False, False, False], size=7)
-    u = v.dup()
-    u(struct_mask.S) << v.vxm(A, semiring.plus_times)
-    result = Vector.from_coo([0, 1, 3, 4, 6], [3, 1, 0, 8, 0], size=7)
-    assert heq(u, result)
-    u = v.dup()
-    u(~~struct_mask.S) << v.vxm(A, semiring.plus_times)
-    assert heq(u, result)
-    u = v.dup()
-    u(~struct_mask.S) << v.vxm(A, semiring.plus_times)
-    result2 = Vector.from_coo([2, 3, 4, 5, 6], [3, 1, 2, 14, 4], size=7)
-    assert heq(u, result2)
-    u = v.dup()
-    u(replace=True, mask=val_mask.V) << v.vxm(A, semiring.plus_times)
-    result3 = Vector.from_coo([0, 3, 4], [3, 0, 8], size=7)
-    assert heq(u, result3)
-    u = v.dup()
-    u(replace=True, mask=~~val_mask.V) << v.vxm(A, semiring.plus_times)
-    assert heq(u, result3)
-    w = v.vxm(A, semiring.plus_times).new(mask=val_mask.V)
-    assert heq(w, result3)
-
-
 def test_vxm_accum(gb, A, v):
     # graphblas/tests/test_vector.py:350-368 -- five spellings of the accumulator
     Vector, semiring, binary, monoid = gb.Vector, gb.semiring, gb.binary, gb.monoid
@@ -125,43 +64,6 @@ def test_vxm_accum(gb, A, v):
     w5 = v.dup()
     w5(accum="plus") << v.vxm(A, semiring.plus_times)
     assert heq(w5, result)
-
-
-def test_parameterized_plus_plus(gb):
-    # graphblas/tests/test_op.py:445-451
-    A = gb.Matrix.from_coo([0, 0, 1, 1], [0, 1, 0, 1], [1, 2, 3, 4])
-    x = gb.Vector.from_coo([0, 1], [10, 20])
-    y = A.mxv(x, gb.semiring.plus_plus).new()
-    assert heq(y, x.vxm(A.T, gb.semiring.plus_plus).new())
-    assert heq(y, gb.Vector.from_coo([0, 1], [33, 37]))
-
-
-def test_docs_mxv_vxm(gb):
-    # docs/user_guide/operations.rst:77-153
-    A = gb.Matrix.from_coo([0, 0, 1, 1, 2], [1, 2, 2, 3, 3], [2.0, 5.0, 1.5, 4.25, 0.5], nrows=4, ncols=4)
-    v = gb.Vector.from_coo([0, 1, 3], [10.0, 20.0, 40.0])
-    w = gb.Vector(float, A.nrows)
-    w << A.mxv(v, op="plus_times")
-    assert heq(w, gb.Vector.from_coo([0, 1, 2], [40.0, 170.0, 20.0], size=4))
-    w2 = gb.Vector(float, A.nrows)
-    w2 << gb.semiring.plus_times(A @ v)
-    assert heq(w2, w)
-    B = gb.Matrix.from_coo([0, 0, 1, 1, 2, 2, 3, 3], [1, 2, 0, 1, 1, 2, 0, 1], [3.0, 2.0, 9.0, 6.0, 3.0, 1.0, 0.0, 5.0])
-    u = gb.Vector(float, B.ncols)
-    u << v.vxm(B, op="plus_plus")
-    assert heq(u, gb.Vector.from_coo([0, 1, 2], [69.0, 84.0, 12.0]))
-
-
-def test_primer_sssp(gb):
-    # docs/getting_started/primer.rst:221-251
-    G = gb.Matrix.from_coo([0, 0, 1, 1, 2], [1, 2, 2, 3, 3], [2.0, 5.0, 1.5, 4.25, 0.5], nrows=4, ncols=4)
-    v = gb.Vector.from_coo([0], [0.0], size=4)
-    for _ in range(10):
-        w = v.dup()
-        v(gb.op.min) << gb.semiring.min_plus(v @ G)
-        if v.isequal(w):
-            break
-    assert heq(v, gb.Vector.from_coo([0, 1, 2, 3], [0.0, 2.0, 3.5, 4.0]))
 
 
 def test_semiring_handles(gb):
@@ -293,112 +195,6 @@ def test_resize_random(gb):
     assert big.to_coo()[0].tolist() == [0, 5]
     big.resize(0)
     assert big.nvals == 0 and big.size == 0
-
-
-# ---- mxm ------------------------------------------------------------------------------------------------
-def test_mxm(gb, A):
-    # graphblas/tests/test_matrix.py:307-314
-    C = A.mxm(A, gb.semiring.plus_times).new()
-    result = gb.Matrix.from_coo(
-        [0, 0, 0, 0, 1, 1, 1, 1, 2, 3, 3, 3, 4, 5, 6, 6, 6],
-        [0, 2, 4, 6, 2, 3, 4, 5, 2, 1, 3, 5, 2, 5, 0, 2, 5],
-        [9, 9, 16, 8, 20, 28, 12, 56, 1, 6, 9, 3, 7, 1, 21, 21, 26],
-    )
-    assert heq(C, result)
-
-
-def test_mxm_transpose(gb, A):
-    # graphblas/tests/test_matrix.py:317-332
-    C = A.dup()
-    C << A.mxm(A.T, gb.semiring.plus_times)
-    result = gb.Matrix.from_coo(
-        [0, 0, 1, 1, 2, 2, 3, 3, 3, 4, 4, 5, 5, 5, 6, 6, 6, 6, 6],
-        [0, 6, 1, 6, 2, 4, 3, 5, 6, 2, 4, 3, 5, 6, 0, 1, 3, 5, 6],
-        [13, 21, 80, 24, 1, 7, 18, 3, 15, 7, 49, 3, 1, 5, 21, 24, 15, 5, 83],
-    )
-    assert heq(C, result)
-    C << A.T.mxm(A, gb.semiring.plus_times)
-    result2 = gb.Matrix.from_coo(
-        [0, 0, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 6, 6],
-        [0, 2, 1, 3, 0, 2, 3, 4, 1, 2, 3, 4, 2, 3, 4, 6, 5, 4, 6],
-        [9, 9, 4, 6, 9, 35, 35, 15, 6, 35, 58, 21, 15, 21, 73, 32, 50, 32, 16],
-    )
-    assert heq(C, result2)
-
-
-def test_mxm_nonsquare(gb):
-    # graphblas/tests/test_matrix.py:335-345
-    A = gb.Matrix.from_coo([0, 0, 0], [0, 2, 4], [1, 2, 3], nrows=1, ncols=5)
-    B = gb.Matrix.from_coo([0, 2, 4], [0, 0, 0], [10, 20, 30], nrows=5, ncols=1)
-    C = gb.Matrix(A.dtype, nrows=1, ncols=1)
-    C << A.mxm(B, gb.semiring.max_plus)
-    assert C.to_coo()[2].tolist() == [33]
-    C1 = A.mxm(B, gb.semiring.max_plus).new()
-    assert heq(C1, C)
-    C2 = A.T.mxm(B.T, gb.semiring.max_plus).new()
-    assert C2.nrows == 5
-    assert C2.ncols == 5
-
-
-def test_mxm_mask(gb, A):
-    # graphblas/tests/test_matrix.py:348-374
-    Matrix, semiring = gb.Matrix, gb.semiring
-    val_mask = Matrix.from_coo([0, 3, 4], [2, 3, 2], [True, True, True], nrows=7, ncols=7)
-    struct_mask = Matrix.from_coo([0, 3, 4], [2, 3, 2], [1, 0, 0], nrows=7, ncols=7)
-    C = A.dup()
-    C(val_mask.V) << A.mxm(A, semiring.plus_times)
-    result = Matrix.from_coo(
-        [0, 0, 0, 1, 1, 2, 3, 3, 3, 4, 4, 5, 6, 6, 6],
-        [1, 2, 3, 4, 6, 5, 0, 2, 3, 2, 5, 2, 2, 3, 4],
-        [2, 9, 3, 8, 4, 1, 3, 3, 9, 7, 7, 1, 5, 7, 3],
-    )
-    assert heq(C, result)
-    C = A.dup()
-    C(~val_mask.V) << A.mxm(A, semiring.plus_times)
-    result2 = Matrix.from_coo(
-        [0, 0, 0, 1, 1, 1, 1, 2, 3, 3, 5, 6, 6, 6],
-        [0, 4, 6, 2, 3, 4, 5, 2, 1, 5, 5, 0, 2, 5],
-        [9, 16, 8, 20, 28, 12, 56, 1, 6, 3, 1, 21, 21, 26],
-    )
-    assert heq(C, result2)
-    C = A.dup()
-    C(struct_mask.S, replace=True).update(A.mxm(A, semiring.plus_times))
-    result3 = Matrix.from_coo([0, 3, 4], [2, 3, 2], [9, 9, 7], nrows=7, ncols=7)
-    assert heq(C, result3)
-    C2 = A.mxm(A, semiring.plus_times).new(mask=struct_mask.S)
-    assert heq(C2, result3)
-    with pytest.raises(TypeError, match="Mask must be"):
-        A.mxm(A).new(mask=struct_mask)  # would be okay if bool mask, but it's not
-
-
-def test_mxm_accum(gb, A):
-    # graphblas/tests/test_matrix.py:377-386 -- C aliased with A
-    A(gb.binary.plus) << A.mxm(A, gb.semiring.plus_times)
-    # fmt: off
-    result = gb.Matrix.from_coo(
-        [0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 3, 3, 3, 3, 3, 4, 4, 5, 5, 6, 6, 6, 6, 6],
-        [0, 1, 2, 3, 4, 6, 2, 3, 4, 5, 6, 2, 5, 0, 1, 2, 3, 5, 2, 5, 2, 5, 0, 2, 3, 4, 5],
-        [9, 2, 9, 3, 16, 8, 20, 28, 20, 56, 4, 1, 1, 3, 6, 3, 9, 3, 7, 7, 1, 1, 21, 26, 7, 3, 26],
-    )
-    # fmt: on
-    assert heq(A, result)
-
-
-def test_docs_mxm_and_plus_plus(gb):
-    # docs/user_guide/operations.rst:26-75 (cell [2,1] is 5.5 by arithmetic; the doc table prints 5.0 -- see
-    # tests/golden/make_reference_literals.py) and graphblas/tests/test_op.py:462-464
-    A = gb.Matrix.from_coo([0, 0, 1, 1, 2], [1, 2, 2, 3, 3], [2.0, 5.0, 1.5, 4.25, 0.5], nrows=4, ncols=4)
-    B = gb.Matrix.from_coo([0, 0, 1, 1, 2, 2, 3, 3], [1, 2, 0, 1, 1, 2, 0, 1], [3.0, 2.0, 9.0, 6.0, 3.0, 1.0, 0.0, 5.0])
-    C = gb.Matrix(float, A.nrows, B.ncols)
-    C << A.mxm(B, op="min_plus")
-    exp = gb.Matrix.from_coo([0, 0, 0, 1, 1, 1, 2, 2], [0, 1, 2, 0, 1, 2, 0, 1], [11.0, 8.0, 6.0, 4.25, 4.5, 2.5, 0.5, 5.5],
-                             nrows=4, ncols=3)
-    assert heq(C, exp)
-    C2 = gb.Matrix(float, A.nrows, B.ncols)
-    C2 << gb.semiring.min_plus(A @ B)
-    assert heq(C2, exp)
-    A2 = gb.Matrix.from_coo([0, 0, 1, 1], [0, 1, 0, 1], [1, 2, 3, 4])
-    assert heq(A2.mxm(A2, gb.semiring.plus_plus).new(), gb.Matrix.from_coo([0, 0, 1, 1], [0, 1, 0, 1], [7, 9, 11, 13]))
 
 
 # ---- the vector operations around the path -----------------------------------------------------
