@@ -278,6 +278,7 @@ typedef struct {
     int32_t reorders;         /* vectors this call converted between vertex orders (0 in the steady state of a loop) */
     int64_t ordered;          /* 1: the product ran on the matrix's popularity-ordered layouts with operands kept in that order */
     int64_t value_dict;       /* distinct values of the matrix when its hot-strip records carry one-byte value codes (0: full values) */
+    int64_t fill_absent;      /* 1: a sparse operand was run as a full one with the multiply's absorbing value under its absent entries */
 } GrX_Stats;
 GrB_Info GrX_last_stats(GrX_Stats *stats);
 /* T = A (+.x) B in row batches of A whose products fit `budget_bytes` of device memory; every batch runs the full two-pass
@@ -309,6 +310,10 @@ GrB_Info GrX_Matrix_cache_bytes(const GrB_Matrix A, uint64_t *bytes);
  *   "pull_ipt"      merge items per thread of the pull SpMV (0 = default)
  *   "hot_min_cols"  matrices with at least this many columns get a hot-column table for the pull SpMV
  *   "hot_k"         entries of that table (0 = sized to ~2 MiB of x values)
+ *   "fill_absent"   1 (default): floating-point min_plus / max_plus products with a sparse operand on an ordered matrix whose values are all
+ *                   finite run the full-operand kernels on an image with +-inf under the absent entries (exact: an operand that holds an
+ *                   infinity takes the general path); 0: never
+ *   "hub_min_len"   rows of an ordered matrix from this many entries (default 1024) are dealt to 64 column classes instead of 16; 0: no hub level
  *   "value_dict"    1 (default): a matrix of a 4-byte type with at most 256 distinct finite values keeps one-byte value codes in the
  *                   lane records of its hot strips (half the bytes of the stream that bounds them; exact: codes stand for bit patterns); 0: never
  *   "order_mode"    1 (default): square matrices with at least "order_min_nnz" (48 Mi) entries get their pull layouts in a vertex

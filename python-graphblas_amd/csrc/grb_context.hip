@@ -206,7 +206,7 @@ extern "C" GrB_Info GrB_init(GrB_Mode mode)
         {"GRB_LONG_KERNEL", "long_kernel"}, {"GRB_LONG_CLASSES", "long_classes"}, {"GRB_SPLIT_MIN_LEN", "split_min_len"},
         {"GRB_LONG_SUB", "long_sub"}, {"GRB_LONG_SUB_MIN_LEN", "long_sub_min_len"}, {"GRB_LEAN_MIN_NNZ", "lean_min_nnz"},
         {"GRB_MXM_MASK_MODE", "mxm_mask_mode"}, {"GRB_MAT_WRITE_KERNEL", "mat_write_kernel"}, {"GRB_MXM_SYM_WINDOWS", "mxm_sym_windows"},
-        {"GRB_ORDER_MODE", "order_mode"}, {"GRB_ORDER_MIN_NNZ", "order_min_nnz"}, {"GRB_VALUE_DICT", "value_dict"}, {"GRB_HUB_MIN_LEN", "hub_min_len"},
+        {"GRB_ORDER_MODE", "order_mode"}, {"GRB_ORDER_MIN_NNZ", "order_min_nnz"}, {"GRB_VALUE_DICT", "value_dict"}, {"GRB_HUB_MIN_LEN", "hub_min_len"}, {"GRB_FILL_ABSENT", "fill_absent"},
     };
     c.initialized = true;  // (alloc_cache = 0 releases the block cache: only once the context is complete)
     for (const auto &k : knobs)
@@ -354,6 +354,10 @@ extern "C" GrB_Info GrX_option_set(const char *name, int64_t value)
     else if (n == "mxm_bitmap_pool_cap") c.mxm_bitmap_pool_cap = value;
     else if (n == "vec_pad_min_bytes") c.vec_pad_min_bytes = value;
     else if (n == "hub_min_len") c.hub_min_len = (int)std::max<int64_t>(0, std::min<int64_t>(value, 1 << 30));
+    else if (n == "fill_absent") {
+        if (value != 0 && value != 1) return GrB_INVALID_VALUE;
+        c.fill_absent = (int)value;
+    }
     else if (n == "value_dict") {
         if (value != 0 && value != 1) return GrB_INVALID_VALUE;
         c.value_dict = (int)value;

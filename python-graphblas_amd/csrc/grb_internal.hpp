@@ -106,6 +106,8 @@ struct Context {
     int lazy_layout = 1;             // 1: the SpMV layouts of a large matrix are built at its SECOND pull product, not its first
     int64_t lazy_min_nnz = 1 << 22;  // ... for matrices with at least this many entries (smaller ones build at once)
     int push_mode = 1;               // 0 never push, 1 push when u has < n/64 entries, 2 always push (tests)
+    int fill_absent = 1;             // 1: min_plus / max_plus over floating point with a sparse operand run the full-operand kernels on an image with the
+                                     // absorbing value under the absent entries (ordered layouts, finite values; exact: section 4.1.10)
     int hub_min_len = 1024;          // rows of an ordered matrix from this many entries are dealt to 64 column classes (0: no hub level)
     int value_dict = 1;              // 1: hot-strip records carry 1-byte value codes when the matrix has at most 256 distinct values
     int order_mode = 1;              // 1: large square matrices get popularity-ordered pull layouts and keep their operands in that order
@@ -305,6 +307,8 @@ struct GB_Matrix_opaque {
     // values are, and half the bytes of the stream the hot strips are bound by
     void *d_vdict = nullptr;           // 256 values of the matrix type (unused codes: 0)
     int vdict_n = 0;                   // distinct values found (0: no dictionary)
+    bool vals_finite = false;          // every stored value is finite (known from the dictionary's scan): lets a sparse operand of a min_plus /
+                                       // max_plus product be run as a full one with +-inf under its absent entries (mxv_core)
     unsigned long long *d_vd_table = nullptr;  // the hash table value -> slot the codes were assigned from (build time: placement kernels)
     unsigned char *d_vd_codes = nullptr;       // code of every slot
     // (the cold tiles and the tagged row groups of such a matrix carry the one-byte codes too: d_ct_val / d_tg_val are then byte arrays)

@@ -159,6 +159,7 @@ static void ensure_vdict(GB_Matrix_opaque *A, bool wanted)
     dev_free(A->d_vdict); dev_free(A->d_vd_table); dev_free(A->d_vd_codes);
     A->d_vdict = nullptr; A->d_vd_table = nullptr; A->d_vd_codes = nullptr;
     A->vdict_n = 0;
+    A->vals_finite = false;
     const int64_t nnz = A->nvals;
     if (!wanted || !ctx().value_dict || A->iso || A->type->size != 4 || A->type->code == TC_BOOL || nnz == 0) return;
     DevBuf<unsigned long long> vd_table(VDICT_SLOTS, true);
@@ -191,6 +192,7 @@ static void ensure_vdict(GB_Matrix_opaque *A, bool wanted)
     A->d_vd_codes = (unsigned char *)dev_alloc(VDICT_SLOTS);
     h2d(A->d_vd_codes, h_codes.data(), VDICT_SLOTS);
     A->vdict_n = next;
+    A->vals_finite = true;  // (every distinct value was looked at above)
 }
 
 // Analyse (once) whether the rows split usefully into long and short ones and build the two parts.
@@ -1401,6 +1403,34 @@ static void mxv_core(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_Binar
             a.chunk_len = S->d_chunk_len;
             a.n_chunks = S->n_chunks;
             a.n_long = S->n_long;
+        }
+    }
+    // A sparse operand of a floating-point min_plus / max_plus product on an ordered matrix: run it as a FULL operand whose absent entries
+    // hold the multiply's absorbing value (+inf: a + inf = inf = the identity of min; -inf for max).  With every matrix value finite (known
+    // from the dictionary's scan) and every present operand value finite (checked by the pass that builds the image: one host read) a row's
+    // accumulator leaves the identity iff the row meets a present entry -- the product's pattern is exact -- and the kernels skip the
+    // presence gathers and take the fast hot-strip path: the sweeps of an SSSP loop, whose distance vector never becomes full, went from
+    // 1.53 to ~0.8 ms (section 4.1.10)
+    DevBuf<char> fill_img(0);
+    if (S->hot_identity && !a.u_full && a.need_uval && ctx().fill_absent && S->vals_finite && !S->iso && (st == TC_FP32 || st == TC_FP64) &&
+        mult == OP_PLUS && (monoid == OP_MIN || monoid == OP_MAX) && S->split_state == 1 && S->split_kind == 4) {
+        dev_free(fill_img.p);
+        fill_img.p = (char *)dev_alloc(type_size(st) * (size_t)u->n);
+        DevBuf<int> flag(1, true);
+        if (st == TC_FP32)
+            hipLaunchKernelGGL((k_fill_image<float>), dim3((unsigned)ceil_div((int64_t)u->n, 256)), dim3(256), 0, ctx().stream, (const float *)a.u_val,
+                               (const uint64_t *)a.u_bits, (int64_t)u->n, monoid == OP_MIN ? __builtin_huge_valf() : -__builtin_huge_valf(), (float *)fill_img.p, flag.p);
+        else
+            hipLaunchKernelGGL((k_fill_image<double>), dim3((unsigned)ceil_div((int64_t)u->n, 256)), dim3(256), 0, ctx().stream, (const double *)a.u_val,
+                               (const uint64_t *)a.u_bits, (int64_t)u->n, monoid == OP_MIN ? __builtin_huge_val() : -__builtin_huge_val(), (double *)fill_img.p, flag.p);
+        int h_flag = 0;
+        d2h(&h_flag, flag.p, sizeof(h_flag));
+        ctx().stats.kernel_launches += 1;
+        if (!h_flag) {
+            a.u_val = fill_img.p;
+            a.u_full = 1;
+            a.has_by_value = 1;
+            ctx().stats.fill_absent = 1;
         }
     }
     // BOOL: pack the values of the image the kernel indexes ([hot | u] or u) into bits

@@ -379,3 +379,37 @@ def test_ordered_vectors_in_unusual_flows(gb):
         same_vec(r, e2)
     finally:
         set_opts(RESTORE)
+
+
+@pytest.mark.parametrize("sr", ["min_plus", "max_plus"])
+def test_sparse_operand_run_as_full_with_absorbing_fill(gb, sr):
+    """A sparse operand of a floating-point min_plus / max_plus product on an ordered matrix runs the full-operand kernels on an image with
+    +-inf under its absent entries (the pattern of the product = the rows whose accumulator left the identity).  Exact only while every
+    present value is finite: an operand that HOLDS an infinity must take the general path -- a row whose only partner is that entry has a
+    product (value inf), which the fill would lose.  Both against the oracle, with the option on and off."""
+    from graphblas_amd import device
+
+    rng = np.random.default_rng(31)
+    n = 2400
+    rows, cols, vals = skewed_square(rng, n, "FP32")
+    oa = O.OMat.from_coo(rows, cols, vals, n, n, "FP32")
+    ui, uv = rand_vec(rng, n, 0.3, "FP32")
+    wi, wv = rand_vec(rng, n, 0.4, "FP32")
+    bad = float("inf") if sr == "min_plus" else -float("inf")
+    uv_inf = uv.copy()
+    uv_inf[: max(1, ui.size // 50)] = bad
+    try:
+        for fill in (1, 0):
+            set_opts(ORDER_OPTS + ((b"hot_k", 256), (b"hub_min_len", 200), (b"fill_absent", fill)))
+            A = gb.Matrix.from_coo(rows, cols, vals, dtype="FP32", nrows=n, ncols=n)
+            for values in (uv, uv_inf):
+                u = gb.Vector.from_coo(ui, values, dtype="FP32", size=n)
+                ou = O.OVec(n, ui, values, "FP32")
+                same_vec(A.mxv(u, getattr(gb.semiring, sr)).new(), O.mxv(oa, ou, sr))
+                assert device.last_stats()["fill_absent"] == (1 if (fill and values is uv) else 0), device.last_stats()
+                w = gb.Vector.from_coo(wi, wv, dtype="FP32", size=n)
+                acc = "min" if sr == "min_plus" else "max"
+                w(accum=getattr(gb.binary, acc)) << A.mxv(u, getattr(gb.semiring, sr))
+                same_vec(w, O.mxv(oa, ou, sr, w=O.OVec(n, wi, wv, "FP32"), accum=acc))
+    finally:
+        set_opts(RESTORE + ((b"fill_absent", 1),))
