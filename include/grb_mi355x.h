@@ -242,7 +242,8 @@ GrB_Info GrX_Vector_import_dense_device(GrB_Vector *v, GrB_Type type, GrB_Index 
                                         const uint32_t *d_present);
 /* Borrow the device image of v (the pointers stay valid until v is resized, cleared or freed). *d_present has ceil(n/64)*2 words.
  * The image is in natural index order when the call returns; a later product with a large square matrix may leave v in that
-XX
+ * matrix's vertex order -- in THE SAME buffers (an exported vector is converted in place): re-export, or pin (below), before reading
+ * the image again after such a call. */
 GrB_Info GrX_Vector_export_dense_device(const void **d_val, const uint32_t **d_present, const GrB_Vector v);
 /* pinned != 0: v is never left in another than the natural index order (its image is aliased outside the library for longer than
  * one call: RCCL buffers, torch views); products that involve it run on the natural-order layouts. */
@@ -310,6 +311,8 @@ GrB_Info GrX_Matrix_cache_bytes(const GrB_Matrix A, uint64_t *bytes);
  *   "pull_ipt"      merge items per thread of the pull SpMV (0 = default)
  *   "hot_min_cols"  matrices with at least this many columns get a hot-column table for the pull SpMV
  *   "hot_k"         entries of that table (0 = sized to ~2 MiB of x values)
+ *   "push_small"    1 (default): a pushed frontier whose rows hold at most 64 work items of 1024 entries runs the three push passes in ONE
+ *                   workgroup (frontier kernel, one host read, one kernel); 0: always the pass-per-kernel form
  *   "fill_absent"   1 (default): floating-point min_plus / max_plus products with a sparse operand on an ordered matrix whose values are all
  *                   finite run the full-operand kernels on an image with +-inf under the absent entries (exact: an operand that holds an
  *                   infinity takes the general path); 0: never

@@ -144,8 +144,23 @@ void h2d(void *dst, const void *src, size_t bytes)
 }
 void d2h(void *dst, const void *src, size_t bytes)
 {
-    if (bytes) GRB_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx().stream));
-    GRB_HIP(hipStreamSynchronize(ctx().stream));
+    // (entry counts, reduced scalars, the push path's counters: a copy into pageable memory is staged by the runtime -- the page-locked
+    //  block takes them directly)
+    Context &c = ctx();
+    if (bytes && bytes <= 4096) {
+        if (!c.host_pinned && hipHostMalloc(&c.host_pinned, 4096, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            c.host_pinned = nullptr;
+        }
+        if (c.host_pinned) {
+            GRB_HIP(hipMemcpyAsync(c.host_pinned, src, bytes, hipMemcpyDeviceToHost, c.stream));
+            GRB_HIP(hipStreamSynchronize(c.stream));
+            memcpy(dst, c.host_pinned, bytes);
+            return;
+        }
+    }
+    if (bytes) GRB_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c.stream));
+    GRB_HIP(hipStreamSynchronize(c.stream));
 }
 void d2d(void *dst, const void *src, size_t bytes)
 {
@@ -207,6 +222,7 @@ extern "C" GrB_Info GrB_init(GrB_Mode mode)
         {"GRB_LONG_SUB", "long_sub"}, {"GRB_LONG_SUB_MIN_LEN", "long_sub_min_len"}, {"GRB_LEAN_MIN_NNZ", "lean_min_nnz"},
         {"GRB_MXM_MASK_MODE", "mxm_mask_mode"}, {"GRB_MAT_WRITE_KERNEL", "mat_write_kernel"}, {"GRB_MXM_SYM_WINDOWS", "mxm_sym_windows"},
         {"GRB_ORDER_MODE", "order_mode"}, {"GRB_ORDER_MIN_NNZ", "order_min_nnz"}, {"GRB_VALUE_DICT", "value_dict"}, {"GRB_HUB_MIN_LEN", "hub_min_len"}, {"GRB_FILL_ABSENT", "fill_absent"},
+        {"GRB_PUSH_SMALL", "push_small"},
     };
     c.initialized = true;  // (alloc_cache = 0 releases the block cache: only once the context is complete)
     for (const auto &k : knobs)
@@ -220,8 +236,13 @@ extern "C" GrB_Info GrB_finalize(void)
 {
     Context &c = ctx();
     if (!c.initialized) return GrB_SUCCESS;
+    if (c.push_counters) dev_free(c.push_counters);
+    c.push_counters = nullptr;
+    c.push_counters_dirty = true;
     dev_cache_release();
     (void)hipStreamSynchronize(c.stream);
+    if (c.host_pinned) (void)hipHostFree(c.host_pinned);
+    c.host_pinned = nullptr;
     if (c.ev0) (void)hipEventDestroy(c.ev0);
     if (c.ev1) (void)hipEventDestroy(c.ev1);
     c.ev0 = c.ev1 = nullptr;
@@ -357,6 +378,10 @@ extern "C" GrB_Info GrX_option_set(const char *name, int64_t value)
     else if (n == "fill_absent") {
         if (value != 0 && value != 1) return GrB_INVALID_VALUE;
         c.fill_absent = (int)value;
+    }
+    else if (n == "push_small") {
+        if (value != 0 && value != 1) return GrB_INVALID_VALUE;
+        c.push_small = (int)value;
     }
     else if (n == "value_dict") {
         if (value != 0 && value != 1) return GrB_INVALID_VALUE;

@@ -106,6 +106,7 @@ struct Context {
     int lazy_layout = 1;             // 1: the SpMV layouts of a large matrix are built at its SECOND pull product, not its first
     int64_t lazy_min_nnz = 1 << 22;  // ... for matrices with at least this many entries (smaller ones build at once)
     int push_mode = 1;               // 0 never push, 1 push when u has < n/64 entries, 2 always push (tests)
+    int push_small = 1;              // 1: a pushed frontier of at most 64 work items runs its three passes in one workgroup (k_push_small)
     int fill_absent = 1;             // 1: min_plus / max_plus over floating point with a sparse operand run the full-operand kernels on an image with the
                                      // absorbing value under the absent entries (ordered layouts, finite values; exact: section 4.1.10)
     int hub_min_len = 1024;          // rows of an ordered matrix from this many entries are dealt to 64 column classes (0: no hub level)
@@ -114,6 +115,9 @@ struct Context {
                                      // (grb_mxv_order.inc); 0: never
     int64_t order_min_nnz = 48ll << 20;  // ... from this many entries (the layouts that profit are the ones of lean_min_nnz)
     int64_t reorder_count = 0;       // vectors converted between vertex orders so far (cumulative)
+    void *host_pinned = nullptr;     // 4 KiB of page-locked host memory: small device-to-host reads land here (no staging copy in the runtime)
+    unsigned long long *push_counters = nullptr;  // the thin push path's three counters (grb_mxv_push.inc), kept between calls ...
+    bool push_counters_dirty = true;              // ... and zeroed by the kernel that consumes them, or at the next call when this says so
 };
 Context &ctx();
 void require_init();

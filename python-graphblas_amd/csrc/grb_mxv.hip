@@ -1686,13 +1686,19 @@ static int push_thin(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_Binar
     a.c_cap = a.f_cap + P->nvals / PUSH_Q + 64;
     DevBuf<uint32_t> f_list(a.f_cap);
     DevBuf<uint64_t> chunks(a.c_cap);
-    DevBuf<unsigned long long> counters(4, true);
+    // (the counters live with the context: the kernel that consumes them leaves them zeroed, every other exit marks them dirty)
+    if (!ctx().push_counters) {
+        ctx().push_counters = (unsigned long long *)dev_alloc(4 * sizeof(unsigned long long));
+        ctx().push_counters_dirty = true;
+    }
+    if (ctx().push_counters_dirty) GRB_HIP(hipMemsetAsync(ctx().push_counters, 0, 4 * sizeof(unsigned long long), ctx().stream));
+    ctx().push_counters_dirty = true;
     a.f_list = f_list.p;
     a.chunks = chunks.p;
-    a.counters = counters.p;
+    a.counters = ctx().push_counters;
     hipLaunchKernelGGL(k_push_frontier, dim3((unsigned)ceil_div((int64_t)bits_words64(u->n), 256)), dim3(256), 0, ctx().stream, a);
     unsigned long long h[3] = {0, 0, 0};
-    d2h(h, counters.p, sizeof(h));
+    d2h(h, a.counters, sizeof(h));
     const int64_t fcount = (int64_t)h[0], work = (int64_t)h[1], n_chunks = (int64_t)h[2];
     u->nvals = fcount;
     ctx().stats.flops = work;
@@ -1719,12 +1725,29 @@ static int push_thin(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_Binar
     vector_ensure_storage(w);
     const size_t wbytes = type_size(widened_type_code(st));
     DevBuf<char> t_val((size_t)n_out * wbytes);  // (never filled: only positions a product marks are read)
-    DevBuf<unsigned long long> done(bits_words64((uint64_t)n_out), true);
+    const bool rule_deletes = !(accum && !f.replace);
+    // a handful of vertices: one workgroup runs the three passes (k_push_small) -- when what the rule deletes from w is nothing (w empty)
+    // or sits on the frontier list (w IS the frontier)
+    const bool small = n_chunks > 0 && n_chunks <= PUSH_SMALL_CHUNKS && fcount <= 4096 && ctx().push_small &&
+                       (!rule_deletes || w == u || w->nvals == 0);
+    DevBuf<unsigned long long> done(bits_words64((uint64_t)n_out), !small);
     a.t_val = t_val.p;
     a.done_bits = done.p;
     a.w_val = w->d_val;
     a.w_bits = (unsigned long long *)w->d_bits;
     a.accum = accum ? canonical_op(st, accum->op) : -1;
+    if (small) {
+        GRB_DISPATCH_TYPE(st, T, {
+            hipLaunchKernelGGL((k_push_small<T>), dim3(1), dim3(PUSH_SMALL_BLOCK), 0, ctx().stream, a, n_chunks, fcount,
+                               (rule_deletes && w == u) ? 1 : 0, f.replace ? 1 : 0);
+        })
+        ctx().push_counters_dirty = false;
+        ctx().stats.kernel_launches += 1;
+        ctx().stats.long_kernel = -2;  // (bookkeeping: the one-workgroup form ran)
+        w->nvals = -1;
+        if (ctx().blocking) sync_stream();
+        return 1;
+    }
     const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(n_chunks, 4), (int64_t)ctx().num_cus * 8));
     GRB_DISPATCH_TYPE(st, T, {
         if (n_chunks > 0) {
@@ -1732,7 +1755,7 @@ static int push_thin(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_Binar
             hipLaunchKernelGGL((k_push_pass<T, 1>), dim3(grid), dim3(256), 0, ctx().stream, a, n_chunks);
         }
         // what the rule deletes from w goes first (u was read above: w may alias it) ...
-        if (!(accum && !f.replace))
+        if (rule_deletes)
             hipLaunchKernelGGL(k_push_words, dim3((unsigned)ceil_div((int64_t)bits_words64(w->n), 256)), dim3(256), 0, ctx().stream,
                                (unsigned long long *)w->d_bits, a.m_bits, a.has_mask, a.m_comp, a.accum, f.replace ? 1 : 0, (int64_t)bits_words64(w->n));
         // ... then the products are applied

@@ -362,7 +362,8 @@ void vector_set_order(GB_Vector_opaque *v, GB_Perm *order)
         const bool sparse = v->nvals >= 0 && v->nvals * 16 < n;
         void *nval = nullptr;
         uint64_t *nbits = nullptr;
-        vector_alloc_pair(v, v->padded, false, &nval, &nbits);  // (presence zeroed)
+        vector_alloc_pair(v, v->padded, sparse, &nval, &nbits);  // (presence zeroed; the scatter form also zeroes the values: positions it does
+                                                                  //  not write must not show the block's previous content through an export)
         try {
             if (sparse) {
                 // forward maps: into an order, element i goes to position d_rank[i]; back, position p goes to element d_inv[p]

@@ -54,6 +54,8 @@ enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount };
 inline hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t, int) { *v = 3; return hipSuccess; }  // few CUs: persistent loops iterate
 inline hipError_t hipMallocAsync(void **p, size_t bytes, hipStream_t) { *p = malloc(bytes ? bytes : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 inline hipError_t hipFreeAsync(void *p, hipStream_t) { free(p); return hipSuccess; }
+inline hipError_t hipHostMalloc(void **p, size_t bytes, unsigned) { *p = malloc(bytes ? bytes : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
 inline hipError_t hipMemsetAsync(void *p, int v, size_t bytes, hipStream_t) { memset(p, v, bytes); return hipSuccess; }
 struct hipFuncAttributes { int numRegs; };
 inline hipError_t hipFuncGetAttributes(hipFuncAttributes *, const void *) { return hipSuccess; }
@@ -89,6 +91,7 @@ inline void emu_launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, Args &&.
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) emu_launch(kernel, grid, block, __VA_ARGS__)
 
 inline void __syncthreads() { emu::block_barrier(); }
+inline void __threadfence() {}
 
 template <typename T>
 inline T __shfl(T v, int src)

@@ -1564,3 +1564,84 @@ def test_vector_assign_extract_random(gb, seed):
 
 def cast_to(vals, tname):
     return O.cast(np.asarray(vals), tname)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_push_small_frontiers_in_one_workgroup(gb, seed):
+    """A pushed frontier of a few vertices (at most 64 work items of 1024 entries) runs the three push passes as phases of ONE
+    workgroup (k_push_small: grb_mxv_push.inc) when what the write rule deletes from w is nothing -- w empty, or an accumulator
+    without replace -- or sits on the frontier list (w IS the frontier: the level step of a BFS).  Every flavour against the oracle,
+    and against the pass-per-kernel form (option "push_small" 0); an output with content of its own under a deleting rule takes
+    that form by itself.  Rows of 0, 1, 1023, 1024, 1025 and 3000 entries in the frontier: the cuts of the work items."""
+    from graphblas_amd import _lib, device
+
+    rng = np.random.default_rng(7700 + seed)
+    tname = TYPES[seed % 7]
+    sr = semirings_for(tname)[(seed // 2) % 4]
+    n = int(rng.integers(3100, 5000))
+    deg = rng.integers(0, 5, n)
+    special = rng.permutation(n)[:6]
+    for v, ln in zip(special, (0, 1, 1023, 1024, 1025, 3000)):
+        deg[v] = ln
+    rows = np.repeat(np.arange(n), deg)
+    cols = np.concatenate([rng.choice(n, d, replace=False) for d in deg if d] or [np.zeros(0, np.int64)])
+    vals = rand_vals(rng, rows.size, tname)
+    oa = O.OMat.from_coo(rows, cols, vals, n, n, tname)
+    # the frontier: the special rows (some seeds) plus a few others
+    fi = np.unique(np.concatenate([special[: 1 + seed % 6], rng.integers(0, n, 1 + seed % 4)]))
+    fv = rand_vals(rng, fi.size, tname)
+    of = O.OVec(n, fi, fv, tname)
+    mi, mv = rand_vec(rng, n, 0.5, "BOOL")
+    om = O.OVec(n, mi, mv, "BOOL")
+    wi, wv = rand_vec(rng, n, 0.3, tname)
+    accum = [None, "plus", "min", "second"][seed % 4]
+    try:
+        _lib.lib.GrX_option_set(b"push_mode", 2)
+        A = gb.Matrix.from_coo(rows, cols, vals, dtype=tname, nrows=n, ncols=n)
+        mk = gb.Vector.from_coo(mi, mv, dtype="BOOL", size=n)
+        semi = getattr(gb.semiring, sr)
+        for small in (1, 0):
+            assert _lib.lib.GrX_option_set(b"push_small", small) == 0
+            ran_small = -2 if small else -1
+            # (1) w empty, complemented structural mask + replace: one level step into a fresh vector
+            f = gb.Vector.from_coo(fi, fv, dtype=tname, size=n)
+            w = gb.Vector(tname, n)
+            w(~mk.S, replace=True) << f.vxm(A, semi)
+            st = device.last_stats()
+            assert st["method"] == 2 and st["long_kernel"] == ran_small, st
+            same_vec(w, O.vxm(of, oa, sr, mask=om, mask_comp=True, mask_struct=True, replace=True))
+            # (2) w IS the frontier: q<!m.S, replace> = q A, then once more without a mask
+            q = gb.Vector.from_coo(fi, fv, dtype=tname, size=n)
+            q(~mk.S, replace=True) << q.vxm(A, semi)
+            assert device.last_stats()["long_kernel"] == ran_small
+            same_vec(q, O.vxm(of, oa, sr, w=of, mask=om, mask_comp=True, mask_struct=True, replace=True))
+            q2 = gb.Vector.from_coo(fi, fv, dtype=tname, size=n)
+            if accum:
+                q2(mk.V, accum=accum) << q2.vxm(A, semi)
+                exp2 = O.vxm(of, oa, sr, w=of, mask=om, accum=accum)
+            else:
+                q2 << q2.vxm(A, semi)
+                exp2 = O.vxm(of, oa, sr, w=of)
+            assert device.last_stats()["long_kernel"] == ran_small
+            same_vec(q2, exp2)
+            # (3) w with content of its own: an accumulator without replace deletes nothing (one workgroup); any other rule walks w's words
+            w3 = gb.Vector.from_coo(wi, wv, dtype=tname, size=n)
+            w3(mk.S, accum=accum or "plus") << f.vxm(A, semi)
+            assert device.last_stats()["long_kernel"] == ran_small
+            same_vec(w3, O.vxm(of, oa, sr, w=O.OVec(n, wi, wv, tname), mask=om, mask_struct=True, accum=accum or "plus"))
+            w4 = gb.Vector.from_coo(wi, wv, dtype=tname, size=n)
+            w4(mk.S, accum=accum, replace=True) << f.vxm(A, semi)
+            st = device.last_stats()
+            assert st["method"] == 2 and st["long_kernel"] == -1, st
+            same_vec(w4, O.vxm(of, oa, sr, w=O.OVec(n, wi, wv, tname), mask=om, mask_struct=True, accum=accum, replace=True))
+            # (4) the counters are left clean: a second small call right after a large one, and after a pulled one
+            big_i = np.unique(rng.integers(0, n, n // 3))
+            big = gb.Vector.from_coo(big_i, rand_vals(rng, big_i.size, tname), dtype=tname, size=n)
+            _ = big.vxm(A, semi).new()
+            w5 = gb.Vector(tname, n)
+            w5 << f.vxm(A, semi)
+            assert device.last_stats()["long_kernel"] == ran_small
+            same_vec(w5, O.vxm(of, oa, sr))
+    finally:
+        _lib.lib.GrX_option_set(b"push_mode", 1)
+        _lib.lib.GrX_option_set(b"push_small", 1)
