@@ -238,7 +238,6 @@ extern "C" GrB_Info GrB_finalize(void)
     if (!c.initialized) return GrB_SUCCESS;
     if (c.push_counters) dev_free(c.push_counters);
     c.push_counters = nullptr;
-    c.push_counters_dirty = true;
     dev_cache_release();
     (void)hipStreamSynchronize(c.stream);
     if (c.host_pinned) (void)hipHostFree(c.host_pinned);

@@ -116,8 +116,8 @@ struct Context {
     int64_t order_min_nnz = 48ll << 20;  // ... from this many entries (the layouts that profit are the ones of lean_min_nnz)
     int64_t reorder_count = 0;       // vectors converted between vertex orders so far (cumulative)
     void *host_pinned = nullptr;     // 4 KiB of page-locked host memory: small device-to-host reads land here (no staging copy in the runtime)
-    unsigned long long *push_counters = nullptr;  // the thin push path's three counters (grb_mxv_push.inc), kept between calls ...
-    bool push_counters_dirty = true;              // ... and zeroed by the kernel that consumes them, or at the next call when this says so
+    unsigned long long *push_counters = nullptr;  // the thin push path's counters (grb_mxv_push.inc): two sets of four words, used in turn --
+    int push_parity = 0;                          // a call's frontier kernel zeroes the set of the next call
 };
 Context &ctx();
 void require_init();

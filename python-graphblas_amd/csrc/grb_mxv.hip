@@ -1686,17 +1686,19 @@ static int push_thin(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_Binar
     a.c_cap = a.f_cap + P->nvals / PUSH_Q + 64;
     DevBuf<uint32_t> f_list(a.f_cap);
     DevBuf<uint64_t> chunks(a.c_cap);
-    // (the counters live with the context: the kernel that consumes them leaves them zeroed, every other exit marks them dirty)
+    // (two sets of counters live with the context: a call counts in one and its frontier kernel zeroes the other for the next call -- the
+    //  host read its own set before that call was launched; no memset in front of a call)
     if (!ctx().push_counters) {
-        ctx().push_counters = (unsigned long long *)dev_alloc(4 * sizeof(unsigned long long));
-        ctx().push_counters_dirty = true;
+        ctx().push_counters = (unsigned long long *)dev_alloc(8 * sizeof(unsigned long long));
+        GRB_HIP(hipMemsetAsync(ctx().push_counters, 0, 8 * sizeof(unsigned long long), ctx().stream));
+        ctx().push_parity = 0;
     }
-    if (ctx().push_counters_dirty) GRB_HIP(hipMemsetAsync(ctx().push_counters, 0, 4 * sizeof(unsigned long long), ctx().stream));
-    ctx().push_counters_dirty = true;
     a.f_list = f_list.p;
     a.chunks = chunks.p;
-    a.counters = ctx().push_counters;
+    a.counters = ctx().push_counters + 4 * ctx().push_parity;
+    a.counters_next = ctx().push_counters + 4 * (ctx().push_parity ^ 1);
     hipLaunchKernelGGL(k_push_frontier, dim3((unsigned)ceil_div((int64_t)bits_words64(u->n), 256)), dim3(256), 0, ctx().stream, a);
+    ctx().push_parity ^= 1;
     unsigned long long h[3] = {0, 0, 0};
     d2h(h, a.counters, sizeof(h));
     const int64_t fcount = (int64_t)h[0], work = (int64_t)h[1], n_chunks = (int64_t)h[2];
@@ -1722,13 +1724,17 @@ static int push_thin(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_Binar
     }
     a.has_mask = mask ? 1 : 0;
     a.m_comp = f.comp ? 1 : 0;
+    if (n_chunks == 0 && !w->d_val && w != u) {  // (a frontier of isolated vertices into a vector without storage: w stays as empty as it is)
+        ctx().stats.long_kernel = ctx().push_small ? -2 : -1;
+        return 1;
+    }
     vector_ensure_storage(w);
     const size_t wbytes = type_size(widened_type_code(st));
     DevBuf<char> t_val((size_t)n_out * wbytes);  // (never filled: only positions a product marks are read)
     const bool rule_deletes = !(accum && !f.replace);
     // a handful of vertices: one workgroup runs the three passes (k_push_small) -- when what the rule deletes from w is nothing (w empty)
     // or sits on the frontier list (w IS the frontier)
-    const bool small = n_chunks > 0 && n_chunks <= PUSH_SMALL_CHUNKS && fcount <= 4096 && ctx().push_small &&
+    const bool small = n_chunks <= PUSH_SMALL_CHUNKS && fcount <= 4096 && ctx().push_small &&
                        (!rule_deletes || w == u || w->nvals == 0);
     DevBuf<unsigned long long> done(bits_words64((uint64_t)n_out), !small);
     a.t_val = t_val.p;
@@ -1737,14 +1743,16 @@ static int push_thin(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_Binar
     a.w_bits = (unsigned long long *)w->d_bits;
     a.accum = accum ? canonical_op(st, accum->op) : -1;
     if (small) {
-        GRB_DISPATCH_TYPE(st, T, {
-            hipLaunchKernelGGL((k_push_small<T>), dim3(1), dim3(PUSH_SMALL_BLOCK), 0, ctx().stream, a, n_chunks, fcount,
-                               (rule_deletes && w == u) ? 1 : 0, f.replace ? 1 : 0);
-        })
-        ctx().push_counters_dirty = false;
-        ctx().stats.kernel_launches += 1;
-        ctx().stats.long_kernel = -2;  // (bookkeeping: the one-workgroup form ran)
-        w->nvals = -1;
+        const bool clear_frontier = rule_deletes && w == u;
+        ctx().stats.long_kernel = -2;  // (bookkeeping: the one-workgroup form)
+        if (n_chunks > 0 || clear_frontier) {  // (no work item and nothing to delete: w is what it was, nothing is launched)
+            GRB_DISPATCH_TYPE(st, T, {
+                hipLaunchKernelGGL((k_push_small<T>), dim3(1), dim3(PUSH_SMALL_BLOCK), 0, ctx().stream, a, n_chunks, fcount, clear_frontier ? 1 : 0,
+                                   f.replace ? 1 : 0);
+            })
+            ctx().stats.kernel_launches += 1;
+            w->nvals = -1;
+        }
         if (ctx().blocking) sync_stream();
         return 1;
     }

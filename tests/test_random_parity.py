@@ -1642,6 +1642,18 @@ def test_push_small_frontiers_in_one_workgroup(gb, seed):
             w5 << f.vxm(A, semi)
             assert device.last_stats()["long_kernel"] == ran_small
             same_vec(w5, O.vxm(of, oa, sr))
+            # (5) a frontier whose rows are all empty: no work item at all -- w stays empty, a frontier that is its own output is emptied
+            z = gb.Vector.from_coo(special[:1], rand_vals(rng, 1, tname), dtype=tname, size=n)
+            w6 = gb.Vector(tname, n)
+            w6(~mk.S, replace=True) << z.vxm(A, semi)
+            st = device.last_stats()
+            assert st["method"] == 2 and st["flops"] == 0 and st["long_kernel"] == ran_small, st
+            assert w6.nvals == 0
+            z(~mk.S, replace=True) << z.vxm(A, semi)
+            assert z.nvals == 0
+            w7 = gb.Vector(tname, n)
+            w7 << f.vxm(A, semi)  # (and the counters were left clean)
+            same_vec(w7, O.vxm(of, oa, sr))
     finally:
         _lib.lib.GrX_option_set(b"push_mode", 1)
         _lib.lib.GrX_option_set(b"push_small", 1)
