@@ -941,6 +941,14 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
         // (not for iso matrices: their padding entries would carry the one stored value instead of 0, and value (+) padding word must
         //  be the identity -- INT64_MAX + v wraps)
         if constexpr (MON >= 0) hot_fast = hstrip_fast_semiring<T>(MON, MUL) && A->split_kind == 4 && by_strip && a.u_full && a.need_uval && a.need_aval && !a.a_iso;
+        if (hot_fast) {
+            // (the fast kernel reads a class's records through a buffer descriptor with 32-bit offsets: every class below 2 GiB, records of
+            //  the layout it is compiled for)
+            const int rec_ct = A->vdict_n > 0 ? 24 : 16 + 8 * (int)sizeof(T);
+            int64_t widest = 0;
+            for (int c = 0; c < A->strip_ncls + A->hub_ncls; c++) widest = std::max<int64_t>(widest, A->strip_cb[c + 1] - A->strip_cb[c]);
+            if (A->hrec_bytes != rec_ct || widest * 64 * (int64_t)A->hrec_bytes >= (1ll << 31)) hot_fast = false;
+        }
         DevBuf<unsigned char> long_act8(hot_fast && a.has_mask ? (size_t)a.n_long : 1);
         a.long_act8 = long_act8.p;
         hipLaunchKernelGGL((k_long_init<W>), dim3((unsigned)ceil_div(a.n_long, 256)), dim3(256), 0, ctx().stream, tl_val.p, tl_has.p,
