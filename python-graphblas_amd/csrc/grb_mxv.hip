@@ -1099,10 +1099,10 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
             int64_t groups = ceil_div(b.m, 64);
             b.tg_groups = 0;
             b.tg_stride = 0;
-            if (A->hot_identity && !b.fresh) {
+            if (A->hot_identity) {
                 // a matrix in its popularity order: rows sorted by falling weight, the empty ones at the end
                 const int64_t live_groups = std::max<int64_t>(1, ceil_div(A->ord_live_rows, 64));
-                if (live_groups < groups) {
+                if (live_groups < groups && !b.fresh) {  // (an output written into fresh buffers keeps its tail in the kernel: the values move too)
                     if (!(b.accum >= 0 && !b.replace)) {
                         const int64_t tail = groups - live_groups;
                         hipLaunchKernelGGL(k_rows_tail, dim3((unsigned)ceil_div(tail, 256)), dim3(256), 0, ctx().stream, b, live_groups);
