@@ -271,7 +271,7 @@ typedef struct {
     int64_t flops;            /* mxm: sum_k nnz(A(:,k)) nnz(B(k,:)) from the symbolic pass; mxv: nnz(A) */
     int64_t out_nvals;        /* mxm: nnz(T); mxv: -1 (not counted) */
     int32_t method;           /* 1 pull SpMV, 2 push (SpMSpV), 3 hash SpGEMM, 4 mask-driven SpGEMM, 5 mxv by row length (PAIR, full operand), 6 empty operand: write rule only, 7 SpGEMM with the complemented mask fused into the product */
-    int32_t fused_epilogue;   /* 1 if mask/accum/replace were applied inside the product kernel */
+    int32_t fused_epilogue;   /* 1 if mask/accum/replace were applied inside the product kernel (2: by the short-row kernel with the LDS head) */
     int64_t hot_k;            /* mxv/vxm: entries of the hot-column table used by the call (0 = none) */
     int64_t long_entries;     /* mxv/vxm over a split matrix: entries held by the long rows (0 = no split) */
     int64_t long_segments;    /* ... as class strips: (class, sub-range, row) segments = atomics of an unmasked call */
@@ -311,6 +311,9 @@ GrB_Info GrX_Matrix_cache_bytes(const GrB_Matrix A, uint64_t *bytes);
  *   "pull_ipt"      merge items per thread of the pull SpMV (0 = default)
  *   "hot_min_cols"  matrices with at least this many columns get a hot-column table for the pull SpMV
  *   "hot_k"         entries of that table (0 = sized to ~2 MiB of x values)
+ *   "rows_head"     1 (default): the short rows of an ordered BOOL matrix multiplied with a BOOL operand that is not full run in persistent
+ *                   workgroups that keep the presence / value pairs of the hottest columns in LDS; 0: never.
+ *                   "rows_head_min_groups" (16384): ... for matrices with at least this many groups of 64 rows
  *   "push_small"    1 (default): a pushed frontier whose rows hold at most 64 work items of 1024 entries runs the three push passes in ONE
  *                   workgroup (frontier kernel, one host read, one kernel); 0: always the pass-per-kernel form
  *   "fill_absent"   1 (default): floating-point min_plus / max_plus products with a sparse operand on an ordered matrix whose values are all

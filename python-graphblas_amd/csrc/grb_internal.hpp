@@ -106,6 +106,8 @@ struct Context {
     int lazy_layout = 1;             // 1: the SpMV layouts of a large matrix are built at its SECOND pull product, not its first
     int64_t lazy_min_nnz = 1 << 22;  // ... for matrices with at least this many entries (smaller ones build at once)
     int push_mode = 1;               // 0 never push, 1 push when u has < n/64 entries, 2 always push (tests)
+    int rows_head = 1;               // 1: the short rows of an ordered matrix run with the hottest columns of the operand in LDS (k_mxv_rows_tag<.., HEAD>)
+    int64_t rows_head_min_groups = 16384;  // ... from this many row groups of 64 (below, filling 512 heads costs more than they save)
     int push_small = 1;              // 1: a pushed frontier of at most 64 work items runs its three passes in one workgroup (k_push_small)
     int fill_absent = 1;             // 1: min_plus / max_plus over floating point with a sparse operand run the full-operand kernels on an image with the
                                      // absorbing value under the absent entries (ordered layouts, finite values; exact: section 4.1.10)

@@ -17,9 +17,9 @@ from tests.backend import DEVICES, bind
 from tests.test_random_parity import rand_vals, rand_vec, same_vec
 
 ORDER_OPTS = ((b"order_min_nnz", 1), (b"lean_min_nnz", 1), (b"split_min_nnz", 1), (b"split_min_len", 8), (b"push_mode", 0), (b"hot_min_cols", 8),
-              (b"lazy_layout", 0), (b"vec_pad_min_bytes", 0))
+              (b"lazy_layout", 0), (b"vec_pad_min_bytes", 0), (b"rows_head_min_groups", 1))
 RESTORE = ((b"order_min_nnz", 48 << 20), (b"lean_min_nnz", 48 << 20), (b"split_min_nnz", 1 << 22), (b"split_min_len", 0), (b"push_mode", 1),
-           (b"hot_min_cols", 1 << 20), (b"hot_k", 0), (b"lazy_layout", 1), (b"vec_pad_min_bytes", 1 << 20), (b"long_classes", 16), (b"order_mode", 1), (b"hub_min_len", 1024))
+           (b"hot_min_cols", 1 << 20), (b"hot_k", 0), (b"lazy_layout", 1), (b"vec_pad_min_bytes", 1 << 20), (b"long_classes", 16), (b"order_mode", 1), (b"hub_min_len", 1024), (b"rows_head_min_groups", 16384), (b"rows_head", 1))
 
 
 @pytest.fixture(params=DEVICES)
@@ -70,7 +70,8 @@ def test_ordered_product_matches_the_oracle(gb, seed):
     exp = O.mxv(oa, ou, sr, w=ow, mask=om, mask_comp=comp, mask_struct=struct, accum=accum, replace=repl)
     try:
         # (hub_min_len: rows from this many entries are dealt to 64 classes -- a second level of hot strips; 0 switches it off)
-        set_opts(ORDER_OPTS + ((b"hot_k", [64, 256, 1 << 20][seed % 3]), (b"long_classes", [16, 8, 32][seed % 3]), (b"hub_min_len", [100, 0, 300, 1024][seed % 4])))
+        set_opts(ORDER_OPTS + ((b"hot_k", [64, 256, 1 << 20][seed % 3]), (b"long_classes", [16, 8, 32][seed % 3]), (b"hub_min_len", [100, 0, 300, 1024][seed % 4]),
+                             (b"rows_head", 0 if seed == 13 else 1)))  # (BOOL: the short rows with the LDS head of the hottest columns -- seeds 6, 20 -- and without)
         A = gb.Matrix.from_coo(rows, cols, vals, dtype=tname, nrows=n, ncols=n)
         u = gb.Vector.from_coo(ui, uv, dtype=tname, size=n)
         w = gb.Vector.from_coo(wi, wv, dtype=tname, size=n)
@@ -80,6 +81,8 @@ def test_ordered_product_matches_the_oracle(gb, seed):
         st = device.last_stats()
         by_rowlen = sr in ("any_pair",) and len(ui) == n
         assert by_rowlen or (st["ordered"] == 1 and st["long_kernel"] == (1 if tname == "BOOL" else 4) and st["reorders"] >= 1), st
+        if tname != "BOOL" or seed == 13:  # (the LDS head of the short-row kernel serves BOOL operands given as presence / value pairs)
+            assert by_rowlen or st["fused_epilogue"] == 1, st
         same_vec(w, exp)  # (to_coo brings w back to the natural order)
         # the same call again: the operands that stayed in the library are still in the matrix's order
         w2 = gb.Vector.from_coo(wi, wv, dtype=tname, size=n)
@@ -249,13 +252,16 @@ def test_sssp_and_bfs_loops_stay_ordered(gb, seed):
             olev_i += oq.idx.tolist()
             olev_v += [level] * oq.idx.size
             q(~levels.S, replace=True) << q.vxm(Gb, gb.semiring.lor_land)
-            conv.append((device.last_stats()["method"], device.last_stats()["reorders"]))
+            conv.append((device.last_stats()["method"], device.last_stats()["reorders"], device.last_stats()["fused_epilogue"]))
             seen = O.OVec(n, np.array(sorted(olev_i)), np.ones(len(olev_i), bool), "BOOL")
             oq = O.vxm(oq, ob, "lor_land", w=oq, mask=seen, mask_comp=True, mask_struct=True, replace=True)
         li, lv = levels.to_coo()
         order = np.argsort(olev_i)
         assert li.tolist() == np.asarray(olev_i)[order].tolist() and lv.tolist() == np.asarray(olev_v)[order].tolist()
         assert level >= 2, conv
+        # (the pulled levels of the BOOL graph: the frontier's presence / value pairs in the LDS head of the short-row kernel -- also
+        #  though q is its own output)
+        assert any(m == 1 and fe == 2 for m, _, fe in conv), conv
     finally:
         set_opts(RESTORE)
 
