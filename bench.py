@@ -230,7 +230,7 @@ class MxvWorkload:
 
         torch = self.torch
         if self.ov is None:
-            wv, wb = device.vector_device_views(self.w)
+            wv, wb = device.vector_device_views(self.w, pin=False)  # (transient views: fetched again after every call)
             if self.semiring == "min_plus":
                 # (after the warm-up w is at the fixed point of the relaxation: a call that computed nothing would leave it right.
                 #  Reset w to its initial values and run the call once more, on the layouts the timed calls ran on.)
@@ -238,7 +238,7 @@ class MxvWorkload:
                 self.step()
                 torch.cuda.synchronize()
                 # (the call may keep w in the matrix's vertex order between calls: the views are fetched again -- that brings it back)
-                wv, wb = device.vector_device_views(self.w)
+                wv, wb = device.vector_device_views(self.w, pin=False)
             got_has = self._bits(wb, self.m)
             if self.semiring == "min_plus":
                 d0 = self._dist[self.lo:self.hi]
@@ -332,7 +332,7 @@ def cpu_baseline_suitesparse(lib, wl, torch, reps=3):
     A, u, w, mk = vp(), vp(), vp(), vp()
     ok = lib.GrB_Matrix_new(ctypes.byref(A), h("GrB_FP32"), c_u64(m), c_u64(n)) == 0
     ok &= lib.GrB_Matrix_build_FP32(A, rows.ctypes.data_as(vp), cols.ctypes.data_as(vp), vals.ctypes.data_as(vp), c_u64(rows.size), h("GrB_PLUS_FP32")) == 0
-    uvals, _ = device.vector_device_views(wl.u)
+    uvals, _ = device.vector_device_views(wl.u, pin=False)
     uv = uvals.cpu().numpy()
     idx = np.arange(n, dtype=np.uint64)
     ok &= lib.GrB_Vector_new(ctypes.byref(u), h("GrB_FP32"), c_u64(n)) == 0
@@ -377,7 +377,7 @@ def cpu_baseline_mxv(wl, torch, reps_budget_s=20.0):
         from graphblas_amd import synthetic
 
         vals = synthetic.edge_weights(cj, int(round(np.log2(n)))).cpu().numpy()
-        uvals, _ = device.vector_device_views(wl.u)
+        uvals, _ = device.vector_device_views(wl.u, pin=False)
         u_val = uvals.cpu().numpy()
         u_has = np.ones(n, np.uint8)
         tcode, mon, mul, acc = O.TYPE_CODES["FP32"], O.OP_CODES["min"], O.OP_CODES["plus"], O.OP_CODES["min"]
@@ -385,7 +385,7 @@ def cpu_baseline_mxv(wl, torch, reps_budget_s=20.0):
         a_iso, replace = 0, 0
     else:
         vals = np.ones(1, np.uint8)
-        uvals, uwords = device.vector_device_views(wl.u)
+        uvals, uwords = device.vector_device_views(wl.u, pin=False)
         u_val = uvals.cpu().numpy().astype(np.uint8)
         u_has = np.unpackbits(uwords.cpu().numpy().view(np.uint8), bitorder="little")[:n].astype(np.uint8)
         tcode, mon, mul, acc = O.TYPE_CODES["BOOL"], O.OP_CODES["lor"], O.OP_CODES["land"], -1

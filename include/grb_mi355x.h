@@ -18,7 +18,7 @@
  *   - GrB_*_error <- exceptions.py:171-189
  *
  * GrX_* functions are this library's own extensions (device-resident import/export, stream and
- * timing hooks); the reference has no counterpart (its GxB zero-copy import is core/ss/matrix.py:1279-1349).
+ * timing hooks); the reference's own zero-copy import (core/ss/matrix.py:1279-1349) is offered under its GxB names below, over host arrays.
  */
 #ifndef GRB_MI355X_H
 #define GRB_MI355X_H
@@ -233,6 +233,22 @@ extern GrB_Semiring GxB_LOR_LOR_BOOL, GxB_LAND_LAND_BOOL, GxB_LOR_FIRST_BOOL, Gx
 GrB_Info GrX_Matrix_import_CSR_device(GrB_Matrix *A, GrB_Type type, GrB_Index nrows, GrB_Index ncols,
                                       const int64_t *d_Ap, const int32_t *d_Aj, const void *d_Ax, GrB_Index nvals,
                                       int iso, int copy);
+/* ---- the reference's zero-copy ingress, under the names it binds (SuiteSparse GxB layer) -------------------------------------
+ * graphblas/core/ss/matrix.py:1279-1349 (`Matrix.ss.import_csr` / `ss.pack_csr` -> `GxB_Matrix_{import,pack}_CSR`, arguments
+ * marshalled at :1316-1333) and graphblas/__init__.py:170-173 (GxB_init through suitesparse_graphblas.initialize).
+ * Ap / Aj / Ax are HOST arrays from the allocator given to GxB_init (default malloc); sizes in BYTES; iso: *Ax holds one value;
+ * jumbled: columns inside a row unsorted (sorted here either way).  On success the library OWNS the arrays: they are copied to HBM
+ * once (the matrices of this library live there), released with the registered deallocator, and *Ap = *Aj = *Ax = NULL -- the
+ * protocol the reference's wrapper relies on (it unclaims its numpy buffers after the call).  On failure the arrays stay the
+ * caller's.  pack replaces the content of an existing matrix of the same type and shape.  The form without any copy, for a CSR
+ * that is already in HBM, is GrX_Matrix_import_CSR_device above. */
+GrB_Info GxB_init(GrB_Mode mode, void *(*user_malloc)(size_t), void *(*user_calloc)(size_t, size_t),
+                  void *(*user_realloc)(void *, size_t), void (*user_free)(void *));
+GrB_Info GxB_Matrix_import_CSR(GrB_Matrix *A, GrB_Type type, GrB_Index nrows, GrB_Index ncols, GrB_Index **Ap, GrB_Index **Aj,
+                               void **Ax, GrB_Index Ap_size, GrB_Index Aj_size, GrB_Index Ax_size, bool iso, bool jumbled,
+                               const GrB_Descriptor desc);
+GrB_Info GxB_Matrix_pack_CSR(GrB_Matrix A, GrB_Index **Ap, GrB_Index **Aj, void **Ax, GrB_Index Ap_size, GrB_Index Aj_size,
+                             GrB_Index Ax_size, bool iso, bool jumbled, const GrB_Descriptor desc);
 /* Borrow the device CSR of A (valid until A is modified or freed). */
 GrB_Info GrX_Matrix_export_CSR_device(const int64_t **d_Ap, const int32_t **d_Aj, const void **d_Ax, GrB_Index *nvals,
                                       int *iso, const GrB_Matrix A);
@@ -241,12 +257,14 @@ GrB_Info GrX_Matrix_export_CSR_device(const int64_t **d_Ap, const int32_t **d_Aj
 GrB_Info GrX_Vector_import_dense_device(GrB_Vector *v, GrB_Type type, GrB_Index n, const void *d_val,
                                         const uint32_t *d_present);
 /* Borrow the device image of v (the pointers stay valid until v is resized, cleared or freed). *d_present has ceil(n/64)*2 words.
- * The image is in natural index order when the call returns; a later product with a large square matrix may leave v in that
- * matrix's vertex order -- in THE SAME buffers (an exported vector is converted in place): re-export, or pin (below), before reading
- * the image again after such a call. */
+ * The image is in natural index order when the call returns AND STAYS SO: an export pins the vector (round 5; before, a later product
+ * with a large square matrix could leave v in that matrix's vertex order inside the very buffers the caller still aliased).  Products
+ * that involve a pinned vector run on the natural-order layouts of their matrix.  A caller that is done with the pointers -- or that
+ * re-exports after every library call anyway -- hands the vector back with GrX_Vector_pin_natural(v, 0). */
 GrB_Info GrX_Vector_export_dense_device(const void **d_val, const uint32_t **d_present, const GrB_Vector v);
 /* pinned != 0: v is never left in another than the natural index order (its image is aliased outside the library for longer than
- * one call: RCCL buffers, torch views); products that involve it run on the natural-order layouts. */
+ * one call: RCCL buffers, torch views); products that involve it run on the natural-order layouts.  pinned == 0: the caller holds no
+ * pointer into v any more (or will not use one across a library call): v may live in a matrix's vertex order again. */
 GrB_Info GrX_Vector_pin_natural(GrB_Vector v, int pinned);
 /* Tell the library that the caller wrote into the image returned by GrX_Vector_export_dense_device
  * (e.g. an RCCL all-gather landed there): the cached entry count is dropped. */

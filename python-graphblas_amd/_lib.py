@@ -96,6 +96,10 @@ def _declare(L):
     L.GrB_Matrix_error.argtypes = [P(ctypes.c_char_p), c_void_p]
     L.GrB_Vector_error.argtypes = [P(ctypes.c_char_p), c_void_p]
     L.GrB_Matrix_exportSize.argtypes = [P(c_u64), P(c_u64), P(c_u64), c_int, c_void_p]
+    # (the reference's zero-copy ingress names, core/ss/matrix.py:1316-1333: array cells by address, sizes in bytes, iso, jumbled, desc)
+    L.GxB_Matrix_import_CSR.argtypes = [P(c_void_p), c_void_p, c_u64, c_u64, P(c_void_p), P(c_void_p), P(c_void_p), c_u64, c_u64, c_u64,
+                                        ctypes.c_bool, ctypes.c_bool, c_void_p]
+    L.GxB_Matrix_pack_CSR.argtypes = [c_void_p, P(c_void_p), P(c_void_p), P(c_void_p), c_u64, c_u64, c_u64, ctypes.c_bool, ctypes.c_bool, c_void_p]
     L.GrB_transpose.argtypes = [c_void_p] * 5
     L.GrB_Vector_new.argtypes = [P(c_void_p), c_void_p, c_u64]
     L.GrB_Vector_dup.argtypes = [P(c_void_p), c_void_p]

@@ -232,6 +232,20 @@ extern "C" GrB_Info GrB_init(GrB_Mode mode)
     return GrB_SUCCESS;
 }
 
+// SuiteSparse's initialiser with the caller's allocator (python-graphblas: graphblas/__init__.py:170-173 via
+// suitesparse_graphblas.initialize(memory_manager="numpy")): this library allocates nothing on the host for the caller, but the GxB
+// import / pack entries take OWNERSHIP of host arrays and release them with `user_free`.
+extern "C" GrB_Info GxB_init(GrB_Mode mode, void *(*user_malloc)(size_t), void *(*user_calloc)(size_t, size_t),
+                             void *(*user_realloc)(void *, size_t), void (*user_free)(void *))
+{
+    (void)user_malloc;
+    (void)user_calloc;
+    (void)user_realloc;
+    const GrB_Info info = GrB_init(mode);
+    if (info == GrB_SUCCESS) ctx().host_free = user_free;
+    return info;
+}
+
 extern "C" GrB_Info GrB_finalize(void)
 {
     Context &c = ctx();

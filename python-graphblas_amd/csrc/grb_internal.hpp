@@ -64,6 +64,7 @@ struct Context {
     int device = 0;
     int num_cus = 256;
     hipStream_t stream = nullptr;  // null stream: ordered with torch's default stream
+    void (*host_free)(void *) = nullptr;  // GxB_init: the deallocator of host arrays whose ownership an import / pack takes (nullptr: free)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int64_t vec_pad_min_bytes = 1 << 20;  // vectors with at least this many bytes of values are allocated with the front pad
     int alloc_cache = 1;    // 1: freed device blocks are kept per size class and reused without calling the HIP allocator

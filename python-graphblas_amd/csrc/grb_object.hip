@@ -968,35 +968,50 @@ GB_Matrix_opaque *matrix_cast_copy(GB_Matrix_opaque *A, int type)
 
 static GB_Matrix_opaque *matrix_dup(GB_Matrix_opaque *A) { return matrix_cast_copy(A, A->type->code); }
 
-// import host CSR/CSC (uint64 pointers and indices).  Entries inside a row need not be sorted.
+// import host CSR/CSC (uint64 pointers and indices) into the (empty) matrix A.  Entries inside a row need not be sorted.
+// iso: Ax holds ONE value that every entry takes (the GxB import / pack forms; GrB_Matrix_import has no such flag).
+template <typename T>
+static void matrix_import_into(GB_Matrix_opaque *A, const uint64_t *Ap, const uint64_t *Ai, const void *Ax, int x_type, uint64_t Ap_len,
+                               uint64_t Ai_len, uint64_t Ax_len, GrB_Format format, bool iso, const char *who)
+{
+    if (format != GrB_CSR_FORMAT && format != GrB_CSC_FORMAT) fail(GrB_NOT_IMPLEMENTED, std::string(who) + ": only CSR and CSC formats");
+    const bool csr = (format == GrB_CSR_FORMAT);
+    const uint64_t nvec = csr ? A->nrows : A->ncols;
+    if (!Ap) fail(GrB_NULL_POINTER, std::string(who) + ": Ap is NULL");
+    if (Ap_len < nvec + 1) fail(GrB_INVALID_VALUE, std::string(who) + ": Ap_len too small");
+    const uint64_t nnz = Ap[nvec];
+    if (Ai_len < nnz || Ax_len < (iso ? (nnz ? 1 : 0) : nnz)) fail(GrB_INVALID_VALUE, std::string(who) + ": Ai_len/Ax_len smaller than Ap[n]");
+    if (nnz == 0) return;
+    if (!Ai || !Ax) fail(GrB_NULL_POINTER, std::string(who) + ": NULL array");
+    // expand the pointer array into major indices on the device
+    DevBuf<int64_t> dp(nvec + 1);
+    DevBuf<uint64_t> dmaj(nnz), dmin(nnz);
+    h2d(dp.p, Ap, sizeof(uint64_t) * (nvec + 1));  // same bits (values < 2^63)
+    LAUNCH(k_expand_rows_u64, (int64_t)nnz, dp.p, (int64_t)nvec, (int64_t)nnz, dmaj.p);
+    h2d(dmin.p, Ai, sizeof(uint64_t) * nnz);
+    const uint64_t nx = iso ? 1 : nnz;
+    DevBuf<char> raw((size_t)nx * type_size(x_type));
+    h2d(raw.p, Ax, (size_t)nx * type_size(x_type));
+    DevBuf<T> dX(nnz);
+    if (iso) {
+        DevBuf<T> one(1);
+        cast_array(A->type->code, one.p, x_type, raw.p, 1);
+        LAUNCH((k_fill<T>), (int64_t)nnz, dX.p, (int64_t)nnz, (const T *)one.p);
+    } else {
+        cast_array(A->type->code, dX.p, x_type, raw.p, (int64_t)nnz);
+    }
+    matrix_build_device<T>(A, csr ? dmaj.p : dmin.p, csr ? dmin.p : dmaj.p, dX.p, (int64_t)nnz, nullptr, who);
+}
+
 template <typename T>
 static GB_Matrix_opaque *matrix_import_typed(GrB_Type type, uint64_t nrows, uint64_t ncols, const uint64_t *Ap,
                                              const uint64_t *Ai, const void *Ax, int x_type, uint64_t Ap_len,
                                              uint64_t Ai_len, uint64_t Ax_len, GrB_Format format)
 {
     if (format != GrB_CSR_FORMAT && format != GrB_CSC_FORMAT) fail(GrB_NOT_IMPLEMENTED, "GrB_Matrix_import: only CSR and CSC formats");
-    const bool csr = (format == GrB_CSR_FORMAT);
-    const uint64_t nvec = csr ? nrows : ncols;
-    if (!Ap) fail(GrB_NULL_POINTER, "GrB_Matrix_import: Ap is NULL");
-    if (Ap_len < nvec + 1) fail(GrB_INVALID_VALUE, "GrB_Matrix_import: Ap_len too small");
-    const uint64_t nnz = Ap[nvec];
-    if (Ai_len < nnz || Ax_len < nnz) fail(GrB_INVALID_VALUE, "GrB_Matrix_import: Ai_len/Ax_len smaller than Ap[n]");
     GB_Matrix_opaque *A = matrix_new(type, nrows, ncols);
-    if (nnz == 0) return A;
     try {
-        if (!Ai || !Ax) fail(GrB_NULL_POINTER, "GrB_Matrix_import: NULL array");
-        // expand the pointer array into major indices on the device
-        DevBuf<int64_t> dp(nvec + 1);
-        DevBuf<uint64_t> dmaj(nnz), dmin(nnz);
-        h2d(dp.p, Ap, sizeof(uint64_t) * (nvec + 1));  // same bits (values < 2^63)
-        LAUNCH(k_expand_rows_u64, (int64_t)nnz, dp.p, (int64_t)nvec, (int64_t)nnz, dmaj.p);
-        h2d(dmin.p, Ai, sizeof(uint64_t) * nnz);
-        DevBuf<char> raw((size_t)nnz * type_size(x_type));
-        h2d(raw.p, Ax, (size_t)nnz * type_size(x_type));
-        DevBuf<T> dX(nnz);
-        cast_array(type->code, dX.p, x_type, raw.p, (int64_t)nnz);
-        matrix_build_device<T>(A, csr ? dmaj.p : dmin.p, csr ? dmin.p : dmaj.p, dX.p, (int64_t)nnz, nullptr,
-                               "GrB_Matrix_import");
+        matrix_import_into<T>(A, Ap, Ai, Ax, x_type, Ap_len, Ai_len, Ax_len, format, false, "GrB_Matrix_import");
     } catch (...) {
         matrix_free(A);
         throw;
@@ -1432,6 +1447,70 @@ extern "C" GrB_Info GrX_Matrix_import_CSR_device(GrB_Matrix *A, GrB_Type type, G
     GRB_CATCH(nullptr)
 }
 
+// ---- the reference's zero-copy ingress names (SuiteSparse GxB layer; reference graphblas/core/ss/matrix.py:1279-1349) ------------
+// python-graphblas's ``Matrix.ss.import_csr`` / ``ss.pack_csr`` bind GxB_Matrix_import_CSR / GxB_Matrix_pack_CSR: host arrays the
+// caller allocated with the library's allocator (GxB_init; default malloc) whose OWNERSHIP passes to the library -- SuiteSparse
+// keeps them as the matrix, this library keeps its matrices in HBM: ONE host-to-device copy, then the host arrays are released with
+// the registered deallocator and the caller's pointers are set to NULL, exactly what the reference's wrapper expects
+// (it ``unclaim_buffer``s the numpy arrays after the call: nobody else would free them).  Sizes are in BYTES.  jumbled = the
+// column indices inside a row are not sorted (sorted here either way).  The device-resident form without any copy is
+// GrX_Matrix_import_CSR_device.
+static void gxb_take_csr(GB_Matrix_opaque *M, GrB_Index **Ap, GrB_Index **Aj, void **Ax, GrB_Index Ap_size, GrB_Index Aj_size,
+                         GrB_Index Ax_size, bool iso, const char *who)
+{
+    if (!Ap || !Aj || !Ax) fail(GrB_NULL_POINTER, std::string(who) + ": NULL argument");
+    if (!*Ap) fail(GrB_NULL_POINTER, std::string(who) + ": *Ap is NULL");
+    if (Ap_size < (M->nrows + 1) * sizeof(GrB_Index)) fail(GrB_INVALID_VALUE, std::string(who) + ": Ap_size too small");
+    const uint64_t nnz = (*Ap)[M->nrows];
+    if (nnz) check_index_width(M->nrows, M->ncols);
+    GRB_DISPATCH_TYPE(M->type->code, T, {
+        matrix_import_into<T>(M, *Ap, *Aj, *Ax, M->type->code, Ap_size / sizeof(GrB_Index), Aj_size / sizeof(GrB_Index),
+                              Ax_size / M->type->size, GrB_CSR_FORMAT, iso, who);
+    })
+    sync_stream();  // (the copies have left the host arrays)
+    void (*release)(void *) = ctx().host_free ? ctx().host_free : free;
+    release(*Ap);
+    if (*Aj) release(*Aj);
+    if (*Ax) release(*Ax);
+    *Ap = nullptr;
+    *Aj = nullptr;
+    *Ax = nullptr;
+}
+
+extern "C" GrB_Info GxB_Matrix_import_CSR(GrB_Matrix *A, GrB_Type type, GrB_Index nrows, GrB_Index ncols, GrB_Index **Ap,
+                                          GrB_Index **Aj, void **Ax, GrB_Index Ap_size, GrB_Index Aj_size, GrB_Index Ax_size,
+                                          bool iso, bool jumbled, const GrB_Descriptor desc)
+{
+    GRB_TRY
+    require_init();
+    (void)jumbled;
+    (void)desc;  // (secure_import: the indices are range-checked on every import)
+    if (!A || !type) fail(GrB_NULL_POINTER, "GxB_Matrix_import_CSR: NULL argument");
+    *A = nullptr;
+    GB_Matrix_opaque *M = matrix_new(type, nrows, ncols);
+    try {
+        gxb_take_csr(M, Ap, Aj, Ax, Ap_size, Aj_size, Ax_size, iso, "GxB_Matrix_import_CSR");
+    } catch (...) {
+        matrix_free(M);
+        throw;
+    }
+    *A = M;
+    GRB_CATCH(nullptr)
+}
+
+extern "C" GrB_Info GxB_Matrix_pack_CSR(GrB_Matrix A, GrB_Index **Ap, GrB_Index **Aj, void **Ax, GrB_Index Ap_size,
+                                        GrB_Index Aj_size, GrB_Index Ax_size, bool iso, bool jumbled, const GrB_Descriptor desc)
+{
+    GRB_TRY
+    require_init();
+    (void)jumbled;
+    (void)desc;
+    check_matrix(A, "A");
+    matrix_release_storage(A);  // (pack replaces the content of an existing matrix; type and shape stay)
+    gxb_take_csr(A, Ap, Aj, Ax, Ap_size, Aj_size, Ax_size, iso, "GxB_Matrix_pack_CSR");
+    GRB_CATCH(errp(A))
+}
+
 extern "C" GrB_Info GrX_Matrix_export_CSR_device(const int64_t **d_Ap, const int32_t **d_Aj, const void **d_Ax,
                                                  GrB_Index *nvals, int *iso, const GrB_Matrix A)
 {
@@ -1498,6 +1577,9 @@ extern "C" GrB_Info GrX_Vector_export_dense_device(const void **d_val, const uin
     check_vector(v, "v");
     vector_ensure_storage(v);
     v->exported = true;  // (from now on conversions between vertex orders keep these pointers)
+    // An export pins: the caller aliases the image for as long as it likes, and a product with an ordered matrix would otherwise permute
+    // the very buffers it reads.  GrX_Vector_pin_natural(v, 0) hands the vector back.
+    v->pinned = true;
     if (d_val) *d_val = v->d_val;
     if (d_present) *d_present = (const uint32_t *)v->d_bits;
     GRB_CATCH(errp(v))

@@ -77,17 +77,26 @@ def vector_pin_natural(v, pinned=True):
     call_on(v, "GrX_Vector_pin_natural", [v._handle, 1 if pinned else 0])
 
 
-def vector_device_views(v, device="cuda", *, pin=False):
+def vector_release_views(v):
+    """The caller no longer uses the tensors :func:`vector_device_views` returned for ``v``: the vector may live in a matrix's
+    vertex order again (GrX_Vector_pin_natural(v, 0))."""
+    vector_pin_natural(v, False)
+
+
+def vector_device_views(v, device="cuda", *, pin=True):
     """(values, presence_words) torch tensors ALIASING the vector's HBM image (valid until the vector is resized, cleared or
-    freed).  The image is in natural index order when this returns; a later product with a large square matrix may leave the
-    vector in that matrix's vertex order -- fetch the views again after such a call, or pass ``pin=True`` to hold the vector in
-    natural order for good.  ``device="cpu"`` is for the CPU test tier, where the emulator build keeps the image in host memory."""
+    freed).  The image is in natural index order when this returns, and with ``pin=True`` (the default: the library pins a vector
+    whose pointers it hands out) it stays so -- products that involve the vector then run on their matrix's natural-order layouts.
+    ``pin=False`` is for TRANSIENT views: the caller uses them before its next library call on ``v`` and fetches them again
+    afterwards (a product with a large square matrix may leave ``v`` in that matrix's vertex order, inside the same buffers);
+    :func:`vector_release_views` does the same for views that were pinned.  ``device="cpu"`` is for the CPU test tier, where the
+    emulator build keeps the image in host memory."""
     import torch
 
-    if pin:
-        vector_pin_natural(v)
     dv, db = ctypes.c_void_p(), ctypes.c_void_p()
     call_on(v, "GrX_Vector_export_dense_device", [ctypes.byref(dv), ctypes.byref(db), v._handle])
+    if not pin:
+        vector_pin_natural(v, False)
     n = v._size
     if device == "cpu":
         nb = n * np.dtype(v.dtype.np_type).itemsize

@@ -18,10 +18,93 @@ from .vector import Vector, _name_counter, _ptr
 GrB_CSR_FORMAT, GrB_CSC_FORMAT = 0, 1
 
 
+def _owned_copy(arr):
+    """A malloc'd copy of a numpy array: the GxB import / pack entries take OWNERSHIP of their host arrays and release them with
+    the library's deallocator (the reference hands over numpy buffers it has unclaimed, core/ss/matrix.py:1300-1349)."""
+    libc = ctypes.CDLL(None)
+    libc.malloc.restype = ctypes.c_void_p
+    libc.malloc.argtypes = [ctypes.c_size_t]
+    nbytes = max(int(arr.nbytes), 1)
+    p = libc.malloc(nbytes)
+    if not p:
+        raise MemoryError
+    if arr.nbytes:
+        ctypes.memmove(p, arr.ctypes.data, arr.nbytes)
+    return ctypes.c_void_p(p), int(arr.nbytes)
+
+
+class _MatrixSS:
+    """``Matrix.ss`` / ``A.ss``: the reference's SuiteSparse namespace (graphblas/core/ss/matrix.py), reduced to the ingress the
+    hot path's callers use -- ``import_csr`` (:1139-1237) and ``pack_csr`` (:1239-1277), both through ``_import_csr``
+    (:1279-1349) -> ``GxB_Matrix_{import,pack}_CSR``.  Same keyword arguments; ``take_ownership`` is accepted and means nothing
+    here (the matrix lives in HBM: the host arrays are copied once either way, and the caller's numpy arrays are left alone)."""
+
+    def __init__(self, parent=None):
+        self._parent = parent
+
+    @staticmethod
+    def _csr_args(indptr, values, col_indices, dtype, is_iso, fmt):
+        if fmt is not None and fmt.lower() != "csr":
+            raise ValueError(f"Invalid format: {fmt!r}.  Must be None or 'csr'.")
+        indptr = np.ascontiguousarray(indptr, dtype=np.uint64)
+        col_indices = np.ascontiguousarray(col_indices, dtype=np.uint64)
+        values = np.asarray(values)
+        dtype = lookup_dtype(dtype if dtype is not None else values.dtype)
+        values = np.ascontiguousarray(np.atleast_1d(values).astype(dtype.np_type, copy=False))
+        if is_iso:
+            values = values[:1]
+        ptrs = [_owned_copy(a) for a in (indptr, col_indices, values)]
+        cells = [ctypes.c_void_p(p.value) for p, _ in ptrs]
+        return dtype, cells, [nb for _, nb in ptrs]
+
+    @staticmethod
+    def _release_leftovers(cells):
+        libc = ctypes.CDLL(None)
+        libc.free.argtypes = [ctypes.c_void_p]
+        for c in cells:  # (a failed call leaves the arrays with the caller: *Ap & co. are still set)
+            if c.value:
+                libc.free(c)
+
+    def import_csr(self, *, nrows, ncols, indptr, values, col_indices, is_iso=False, sorted_cols=False, take_ownership=False,
+                   dtype=None, format=None, name=None, **opts):
+        dtype, cells, sizes = self._csr_args(indptr, values, col_indices, dtype, is_iso, format)
+        A = Matrix.__new__(Matrix)
+        A.dtype, A._nrows, A._ncols, A.name = dtype, int(nrows), int(ncols), name or f"M_{next(_name_counter)}"
+        A._handle = ctypes.c_void_p()
+        _lib.load()
+        try:
+            call_on(None, "GxB_Matrix_import_CSR",
+                    [ctypes.byref(A._handle), dtype._carg, A._nrows, A._ncols, ctypes.byref(cells[0]), ctypes.byref(cells[1]),
+                     ctypes.byref(cells[2]), sizes[0], sizes[1], sizes[2], bool(is_iso), not sorted_cols, None])
+        finally:
+            self._release_leftovers(cells)
+        return A
+
+    def pack_csr(self, *, indptr, values, col_indices, is_iso=False, sorted_cols=False, take_ownership=False, format=None,
+                 nrows=None, ncols=None, dtype=None, name=None, **opts):
+        A = self._parent
+        if A is None:
+            raise TypeError("pack_csr packs into an existing Matrix: call it on an instance (A.ss.pack_csr(...))")
+        _dt, cells, sizes = self._csr_args(indptr, values, col_indices, A.dtype, is_iso, format)
+        try:
+            call_on(A, "GxB_Matrix_pack_CSR",
+                    [A._handle, ctypes.byref(cells[0]), ctypes.byref(cells[1]), ctypes.byref(cells[2]), sizes[0], sizes[1], sizes[2],
+                     bool(is_iso), not sorted_cols, None])
+        finally:
+            self._release_leftovers(cells)
+        return A
+
+
+class _SSAccessor:
+    def __get__(self, obj, objtype=None):
+        return _MatrixSS(obj)
+
+
 class Matrix(BaseType):
     _grb_kind = "Matrix"
     ndim = 2
     _is_transposed = False
+    ss = _SSAccessor()  # Matrix.ss.import_csr(...), A.ss.pack_csr(...): reference core/ss/matrix.py:1139-1349
 
     def __init__(self, dtype=float, nrows=0, ncols=0, *, name=None):
         self.dtype = lookup_dtype(dtype)

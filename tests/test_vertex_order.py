@@ -419,3 +419,46 @@ def test_sparse_operand_run_as_full_with_absorbing_fill(gb, sr):
                 same_vec(w, O.mxv(oa, ou, sr, w=O.OVec(n, wi, wv, "FP32"), accum=acc))
     finally:
         set_opts(RESTORE + ((b"fill_absent", 1),))
+
+
+def test_view_held_across_an_ordered_product_stays_natural(gb):
+    """GrX_Vector_export_dense_device pins -- a torch view obtained BEFORE a product with an ordered matrix must still
+    read natural-order data after it (before, the product converted the vector to vertex order inside the aliased buffers), data
+    written through it and announced with GrX_Vector_modified must arrive, and a released vector may be ordered again."""
+    from graphblas_amd import device
+
+    rng = np.random.default_rng(9090)
+    tname, n = "FP32", 3000
+    rows, cols, vals = skewed_square(rng, n, tname)
+    ui, uv = rand_vec(rng, n, 1.0, tname)
+    oa, ou = O.OMat.from_coo(rows, cols, vals, n, n, tname), O.OVec(n, ui, uv, tname)
+    dev = "cuda" if _on_gpu() else "cpu"
+    try:
+        set_opts(ORDER_OPTS)
+        A = gb.Matrix.from_coo(rows, cols, vals, dtype=tname, nrows=n, ncols=n)
+        u = gb.Vector.from_coo(ui, uv, dtype=tname, size=n)
+        held_vals, held_words = device.vector_device_views(u, dev)  # (pins u)
+        before = np.asarray(held_vals.cpu()).copy()
+        assert before.tolist() == uv.tolist()
+        w = A.mxv(u, gb.semiring.min_plus).new()
+        st = device.last_stats()
+        assert st["ordered"] == 0, st  # (a pinned operand: natural-order layouts)
+        assert np.asarray(held_vals.cpu()).tolist() == before.tolist()  # the stale-view hazard: still natural, element for element
+        same_vec(w, O.mxv(oa, ou, "min_plus"))
+        # write through the held view, announce it, multiply again
+        uv2 = (uv + 1).astype(uv.dtype)
+        held_vals.copy_(held_vals.new_tensor(uv2))
+        device.vector_modified(u)
+        same_vec(A.mxv(u, gb.semiring.min_plus).new(), O.mxv(oa, O.OVec(n, ui, uv2, tname), "min_plus"))
+        # released: the next product may keep u in the matrix's order ...
+        device.vector_release_views(u)
+        w3 = A.mxv(u, gb.semiring.min_plus).new()
+        assert device.last_stats()["ordered"] == 1
+        same_vec(w3, O.mxv(oa, O.OVec(n, ui, uv2, tname), "min_plus"))
+        # ... and a TRANSIENT view fetched afterwards reads natural data again and leaves the vector free
+        tv, _tw = device.vector_device_views(u, dev, pin=False)
+        assert np.asarray(tv.cpu()).tolist() == uv2.tolist()
+        A.mxv(u, gb.semiring.min_plus).new()
+        assert device.last_stats()["ordered"] == 1
+    finally:
+        set_opts(RESTORE)
