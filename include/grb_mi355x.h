@@ -371,7 +371,13 @@ GrB_Info GrX_Matrix_cache_bytes(const GrB_Matrix A, uint64_t *bytes);
  *                   cut into column pieces; 0 a thread per row (rounds 1-2: 1.6 s on a 9.7 G-entry T)
  *   "mxm_heavy_kernel"  SpGEMM rows beyond the LDS hash tables: 1 (default) (row, column window) work units (k_spgemm_unit),
  *                   0 the 1024-thread row kernels of round 1
- *   "mxm_sym_windows"  consecutive column windows of a row one symbolic unit walks (rows of up to 128 entries of A; default 8,
+ *   "mxm_window_groups"  (round 5) the (row, window) units of a product walk GROUPS of this many 16 Ki-column windows (1 / 2 / 4 / 8;
+ *                   0 = default: from the width of B -- 1 up to 64 windows, 2 up to 128, 4 up to 256, 8 beyond -- so that a row of a
+ *                   scale-22 matrix is cut into as many units as a row of a scale-20 matrix); a group that holds more entries than
+ *                   the densest compact class is walked window by window as before
+ *   "mxm_checksum_pass"  GrX_mxm_streamed: 0 (default) the checksum of the product is folded into the numeric kernels' stores, 1 a pass
+ *                   of its own re-reads every batch's values (round 4)
+ *   "mxm_sym_windows"  consecutive column windows (groups of windows) of a row one symbolic unit walks (rows of up to 128 entries of A; default 8,
  *                   1 = one window per unit as in round 2, at most 64)
  *   "mxm_unit_min_flops" / "mxm_unit_min_per_window"  rows with more products than this (1024) and than this many per column window
  *                   (16), at most 4096, are walked as units

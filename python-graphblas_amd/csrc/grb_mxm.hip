@@ -52,6 +52,14 @@ struct MxmArgs {
     // (relative to Bp[k]) whose column is >= w * MM_WIN
     const int32_t *woff;
     int n_win;
+    // round 5: the (row, window) units of a product walk GROUPS of win_f consecutive windows (1, 2, 4 or 8: the unit kernels'
+    // template parameter F) -- the window is a function of n, so that a row of a scale-22 matrix is cut into as many units as a row
+    // of a scale-20 matrix.  The tables (woff, wcnt, wbm, cm_woff) stay per 16 Ki-column window: a group whose row holds more than
+    // the densest compact class takes (mxm_unit_dense entries) is split into its windows again, each a unit as before.
+    int win_f;
+    // streamed product (GrX_mxm_streamed): the wrapping sum of the values the numeric kernels store, folded into the store --
+    // 1024 counters a 128-byte line apart (one address would serialise millions of atomics); nullptr: not wanted
+    unsigned long long *csum;
     // (row, window) units (k_spgemm_unit): per row of the symbolic pass n_win + 1 numbers -- counts, then offsets inside the row;
     // wrow[row] = the row's slot in wcnt (-1: the symbolic pass counted the row with a hash kernel)
     int32_t *wcnt;
@@ -107,6 +115,22 @@ __device__ __forceinline__ int wave_inclusive_sum(int v)
 // a load through a pointer that went through LDS: the compiler no longer knows it points to global memory and emits FLAT loads
 // (counted on both memory counters, waited for together with the LDS operations) -- say so
 __device__ __forceinline__ int load_global_i32(const int32_t *p) { return *(const __attribute__((address_space(1))) int32_t *)p; }
+
+// streamed product: what a stored value adds to the wrapping checksum (floating-point values by their integer part, as the separate
+// pass over the product did), and the wavefront's share into one of 1024 counters (GrX_mxm_streamed adds them up)
+constexpr int MM_CSUM_SLOTS = 1024;
+template <typename T>
+__device__ __forceinline__ unsigned long long checksum_term(T v)
+{
+    if constexpr (std::is_floating_point<T>::value) return (unsigned long long)(long long)v;
+    else return (unsigned long long)v;
+}
+__device__ __forceinline__ void checksum_commit(const MxmArgs &a, unsigned long long mine)
+{
+    if (!a.csum) return;  // (uniform)
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&a.csum[(size_t)(blockIdx.x & (MM_CSUM_SLOTS - 1)) * 16], mine);
+}
 
 __device__ __forceinline__ unsigned hash_col(int c, int table_mask) { return ((unsigned)c * 2654435761u) & (unsigned)table_mask; }
 
@@ -283,13 +307,17 @@ __global__ __launch_bounds__(MM_BLOCK) void k_spgemm_hash(const MxmArgs a, const
     }
     const int64_t base = a.Tp[row];
     T *Tx = (T *)a.Tx;
+    unsigned long long csum_mine = 0;
     for (int k = tid; k < cnt; k += MM_BLOCK) {
         const int key = s_sorted[k];
         unsigned h = hash_col(key, TABLE - 1);
         while (s_key[h] != key) h = (h + 1) & (TABLE - 1);
         a.Tj[base + k] = key;
-        Tx[base + k] = from_acc<T, W>(s_val[h]);
+        const T v = from_acc<T, W>(s_val[h]);
+        Tx[base + k] = v;
+        csum_mine += checksum_term<T>(v);
     }
+    checksum_commit(a, csum_mine);
 }
 
 // ---- dense-accumulator (SPA) kernels for hub rows ------------------------------------------------------------------
@@ -306,6 +334,7 @@ __global__ __launch_bounds__(MM_BLOCK) void k_spgemm_spa(const MxmArgs a, const 
     const T *Ax = (const T *)a.Ax, *Bx = (const T *)a.Bx;
     unsigned long long *bits = (unsigned long long *)(a.spa_bits + (int64_t)blockIdx.x * a.spa_words);
     W *vals = NUMERIC ? ((W *)a.spa_vals + (int64_t)blockIdx.x * a.spa_words * 64) : nullptr;
+    unsigned long long csum_mine = 0;
     for (int64_t r = blockIdx.x; r < nrows_bin; r += gridDim.x) {
         const int64_t row = rows[r];
         if (tid == 0) { s_cnt = 0; s_base = 0; }
@@ -359,7 +388,9 @@ __global__ __launch_bounds__(MM_BLOCK) void k_spgemm_spa(const MxmArgs a, const 
                     b &= b - 1;
                     const int64_t j = w * 64 + t;
                     a.Tj[o] = (int32_t)j;
-                    Tx[o] = from_acc<T, W>(vals[j]);
+                    const T v = from_acc<T, W>(vals[j]);
+                    Tx[o] = v;
+                    csum_mine += checksum_term<T>(v);
                     vals[j] = ident;
                     o++;
                 }
@@ -369,6 +400,7 @@ __global__ __launch_bounds__(MM_BLOCK) void k_spgemm_spa(const MxmArgs a, const 
             __syncthreads();
         }
     }
+    if constexpr (NUMERIC) checksum_commit(a, csum_mine);
 }
 
 // ---- LDS dense-window numeric kernel for rows of T with more than 4096 entries --------------------------------
@@ -544,6 +576,7 @@ __global__ __launch_bounds__(MM_WIN_BLOCK) void k_spgemm_win(const MxmArgs a, co
     __syncthreads();
     int64_t out = a.Tp[row];
     T *Tx = (T *)a.Tx;
+    unsigned long long csum_mine = 0;
     walk_windows(a, row, [&](int w, auto &&visit) {
         const int c0 = w * MM_WIN;
         visit([&](int64_t p, int64_t q) {
@@ -586,7 +619,9 @@ __global__ __launch_bounds__(MM_WIN_BLOCK) void k_spgemm_win(const MxmArgs a, co
                 b &= b - 1;
                 const int j = tid * 64 + t;
                 a.Tj[o] = c0 + j;
-                Tx[o] = from_acc<T, W>(s_acc[j]);
+                const T v = from_acc<T, W>(s_acc[j]);
+                Tx[o] = v;
+                csum_mine += checksum_term<T>(v);
                 s_acc[j] = ident;
                 o++;
             }
@@ -594,6 +629,7 @@ __global__ __launch_bounds__(MM_WIN_BLOCK) void k_spgemm_win(const MxmArgs a, co
         out += total;
         __syncthreads();
     });
+    checksum_commit(a, csum_mine);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -655,13 +691,19 @@ __device__ __forceinline__ void mw_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <typename T, int MODE, int WPU, int CAP>
+// F (round 5) = windows per unit: the unit covers the columns [w F MM_WIN, (w + 1) F MM_WIN) -- `w` counts GROUPS of F windows --, its
+// bitmap holds F MM_WIN bits, its ranges of B run from window offset w F to (w + 1) F of the per-window table.  The symbolic unit
+// still reports one count per WINDOW (and keeps its bitmap as F consecutive window bitmaps of the pool): the classification sends
+// a group to one numeric unit of the same F, or -- beyond the densest compact class -- its windows to F = 1 units, as before.
+template <typename T, int MODE, int WPU, int CAP, int F = 1>
 __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const MxmArgs a, const uint32_t *rows, int64_t ridx0,
                                                                           int64_t nrows_here, const UnitRec *units, int64_t nunits)
 {
     using W = typename Widen<T>::type;
     constexpr bool NUMERIC = MODE != MU_SYMBOLIC, MASKED = MODE == MU_MASKED;
-    constexpr int WORDS = MM_WIN / 64, WPL = WORDS / 64;
+    static_assert(F == 1 || F == 2 || F == 4 || F == 8, "window groups of 1, 2, 4 or 8");
+    static_assert(F == 1 || !MASKED, "the mask-driven units walk single windows");
+    constexpr int WIN = MM_WIN * F, WORDS = WIN / 64, WPL = WORDS / 64, FWORDS = MM_WIN / 64;
     constexpr int WAVES = WPU > 4 ? WPU : 4;  // wavefronts per workgroup
     constexpr int UPB = WAVES / WPU;          // units per workgroup
     constexpr int NB = 2;  // batches of entries of A a wavefront keeps (range of B inside the window) from pass A for pass B
@@ -680,7 +722,8 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const 
     __shared__ unsigned long long s_hit[MASKED ? UPB : 1][MASKED ? (CAP + 63) / 64 : 1];  // (masked: which accumulators received a product)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int uib = WPU == 1 ? wave : 0, sub = WPU == 1 ? 0 : wave;  // unit inside the workgroup, wavefront inside the unit
-    const int nwin = a.n_win;
+    const int nwin = a.n_win;                   // (windows: the tables' unit)
+    const int ngroups_w = (nwin + F - 1) / F;   // (groups of F windows: the units' unit)
     const int64_t unit = (int64_t)blockIdx.x * UPB + uib;
     int64_t ridx = 0, row, out = 0, pbeg, pend;
     int w, w_end = 0, bslot = -1, mcnt = 0;
@@ -695,12 +738,12 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const 
         if constexpr (MASKED) mcnt = r.aux;  // (the unit's mask entries are Mj[out .. out + mcnt))
         else bslot = r.aux;
     } else {  // every (row, window) of the rows [ridx0, ridx0 + nrows_here) of the bin
-        const int wg = a.sym_wg, ngrp = (nwin + wg - 1) / wg;
+        const int wg = a.sym_wg, ngrp = (ngroups_w + wg - 1) / wg;
         if (unit >= nrows_here * ngrp) return;
         ridx = ridx0 + unit / ngrp;
         if (a.sym_list) ridx = a.sym_list[ridx];
         w = (int)(unit % ngrp) * wg;
-        w_end = w + wg < nwin ? w + wg : nwin;
+        w_end = w + wg < ngroups_w ? w + wg : ngroups_w;
         row = rows[ridx];
         pbeg = a.Ap[row];
         pend = a.Ap[row + 1];
@@ -729,8 +772,10 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const 
         if (a.need_b && a.b_iso) b_iso_val = Bx[0];
     }
     const int tiu = sub * 64 + lane;  // thread inside the unit
+    unsigned long long csum_mine = 0;  // (streamed product: the values this thread stores)
     for (;;) {  // (the windows of a symbolic unit; numeric and masked units: once)
-    const int c0 = w * MM_WIN;
+    const int c0 = w * WIN;
+    const int fspan = nwin - w * F < F ? nwin - w * F : F;  // windows of the group that exist (the last group of a row may be short)
     // the ranges of B inside the window for the first NB batches of the wavefront's entries of A: requested before anything
     // else (two dependent round trips that overlap the bitmap load / clear and the accumulator fill), kept for every pass
     int c_len[NB];
@@ -740,15 +785,15 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const 
     auto fetch = [&](int64_t p, int &len, int64_t &qb) {
         const bool ok = p < pend;
         const int k = a.Aj[ok ? p : pend - 1];
-        const int32_t *o = a.woff + (int64_t)k * (nwin + 1) + w;
-        const int o0 = o[0], o1 = o[1];
+        const int32_t *o = a.woff + (int64_t)k * (nwin + 1) + w * F;
+        const int o0 = o[0], o1 = o[fspan];
         qb = a.Bp[k] + o0;
         len = ok ? o1 - o0 : 0;
     };
 #pragma unroll
     for (int b = 0; b < NB; b++) fetch(pbeg + sub + (int64_t)b * 64 * WPU + (int64_t)lane * WPU, c_len[b], c_qb[b]);
     if (bslot >= 0) {  // (numeric pass: the symbolic pass kept the unit's bitmap)
-        for (int k = tiu; k < WORDS; k += 64 * WPU) bits[k] = a.bm_pool[(int64_t)bslot * WORDS + k];
+        for (int k = tiu; k < WORDS; k += 64 * WPU) bits[k] = a.bm_pool[(int64_t)bslot * FWORDS + k];  // (F consecutive window bitmaps)
     } else {
         for (int k = tiu; k < WORDS; k += 64 * WPU) bits[k] = 0ull;
     }
@@ -872,7 +917,7 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const 
     };
     // ---- pass A: which columns of the window does the row reach
     if (!MASKED && bslot < 0 && !(NUMERIC && MXM_ABL(a, 16)))
-        visit([&](const int32_t *from, unsigned t, int) { return MXM_ABL(a, 256) ? c0 + (int)((t * 37u) & (MM_WIN - 1)) : load_global_i32(from + t); },  // (256: no load of B)
+        visit([&](const int32_t *from, unsigned t, int) { return MXM_ABL(a, 256) ? c0 + (int)((t * 37u) & (WIN - 1)) : load_global_i32(from + t); },  // (256: no load of B)
               [&](int jraw) {
                   if (MXM_ABL(a, 64)) return;  // (64: no bitmap atomics)
                   const int j = jraw - c0;
@@ -887,8 +932,8 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const 
     // is already without them); pass B drops the products that find their column's bit clear
     const bool cmask = !MASKED && a.CMp != nullptr;
     if (cmask && bslot < 0) {
-        const int32_t *mo = a.cm_woff + (int64_t)row * (nwin + 1) + w;
-        const int m0 = mo[0], m1 = mo[1];
+        const int32_t *mo = a.cm_woff + (int64_t)row * (nwin + 1) + w * F;
+        const int m0 = mo[0], m1 = mo[fspan];
         if (m1 > m0) {
             const int64_t mb = a.CMp[row];
             for (int i = m0 + tiu; i < m1; i += 64 * WPU) {
@@ -909,22 +954,31 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const 
     const int incl = wave_inclusive_sum(c);
     const int cnt = __builtin_amdgcn_readlane(incl, 63);
     if constexpr (!NUMERIC) {
-        if (lane == 0) a.wcnt[ridx * (nwin + 1) + w] = cnt;
+        // one count per WINDOW of the group: window f's words belong to the lanes [f 64 / F, (f + 1) 64 / F)
+        constexpr int LPF = 64 / F;
+        int cf = 0;
+#pragma unroll
+        for (int f = 0; f < F; f++) {
+            const int upto = __builtin_amdgcn_readlane(incl, (f + 1) * LPF - 1);
+            const int before = f ? __builtin_amdgcn_readlane(incl, f ? f * LPF - 1 : 0) : 0;
+            if (lane == f) cf = upto - before;
+        }
+        if (lane < fspan) a.wcnt[ridx * (nwin + 1) + w * F + lane] = cf;
         if (a.wbm) {
             int slot = -1;
             if (cnt > a.bm_min_cnt) {
                 if (lane == 0) {  // (MU_POOLS sub-pools, a cursor each on its own 128-byte line: one cursor serialises millions of atomics)
                     const int sp = (int)(blockIdx.x & (a.bm_pools - 1));
-                    const unsigned long long got = atomicAdd(&a.bm_cursor[sp * 16], 1ull);
-                    slot = got < (unsigned long long)a.bm_cap ? (int)(sp * a.bm_cap + (int64_t)got) : -1;
+                    const unsigned long long got = atomicAdd(&a.bm_cursor[sp * 16], (unsigned long long)F);
+                    slot = got + F <= (unsigned long long)a.bm_cap ? (int)(sp * a.bm_cap + (int64_t)got) : -1;
                 }
                 slot = __shfl(slot, 0);
-                if (slot >= 0) {
+                if (slot >= 0) {  // (F window bitmaps, one after the other)
 #pragma unroll
-                    for (int x = 0; x < WPL; x++) a.bm_pool[(int64_t)slot * WORDS + lane * WPL + x] = mine[x];
+                    for (int x = 0; x < WPL; x++) a.bm_pool[(int64_t)slot * FWORDS + lane * WPL + x] = mine[x];
                 }
             }
-            if (lane == 0) a.wbm[ridx * nwin + w] = slot;
+            if (lane < fspan) a.wbm[ridx * nwin + w * F + lane] = slot >= 0 ? slot + lane : -1;
         }
     } else {
         if (sub == 0) {
@@ -997,7 +1051,11 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const 
                     if (hit) cv[out + r0 + i] = from_acc<T, W>(acc[i]);
                 }
             } else if (!MXM_ABL(a, 2)) {
-                for (int i = tiu; i < here; i += 64 * WPU) Tx[out + r0 + i] = from_acc<T, W>(acc[i]);
+                for (int i = tiu; i < here; i += 64 * WPU) {
+                    const T v = from_acc<T, W>(acc[i]);
+                    Tx[out + r0 + i] = v;
+                    csum_mine += checksum_term<T>(v);
+                }
             }
             usync();
         }
@@ -1046,6 +1104,7 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const 
         usync();  // (the next window clears the bitmap this one was counted from)
     }
     }  // for (;;)
+    if constexpr (NUMERIC && !MASKED) checksum_commit(a, csum_mine);
 }
 
 // a DENSE unit (more than MU_DENSE of the window's MM_WIN columns): compact accumulators would take several passes over the
@@ -1068,6 +1127,7 @@ __global__ __launch_bounds__(MM_WIN_BLOCK) void k_spgemm_unit_dense(const MxmArg
     const int monoid = a.monoid, mult = a.mult;
     const T *Ax = (const T *)a.Ax, *Bx = (const T *)a.Bx;
     const W ident = monoid_identity<T, W>(monoid);
+    unsigned long long csum_mine = 0;
     for (int k = tid; k < MM_WIN; k += MM_WIN_BLOCK) s_acc[k] = ident;
     if (tid < MM_WIN / 64) s_bits[tid] = bslot >= 0 ? a.bm_pool[(int64_t)bslot * (MM_WIN / 64) + tid] : 0ull;
     __syncthreads();
@@ -1154,19 +1214,40 @@ __global__ __launch_bounds__(MM_WIN_BLOCK) void k_spgemm_unit_dense(const MxmArg
         b16 &= b16 - 1;
         const int j = tid * 16 + t;
         if (!MXM_ABL(a, 1)) a.Tj[o] = c0 + j;
-        if (!MXM_ABL(a, 2)) Tx[o] = from_acc<T, W>(s_acc[j]);
+        const T v = from_acc<T, W>(s_acc[j]);
+        if (!MXM_ABL(a, 2)) Tx[o] = v;
+        csum_mine += checksum_term<T>(v);
         o++;
     }
+    checksum_commit(a, csum_mine);
 }
 
 // the units of the rows of the numeric bin, by class (the first class whose limit the entry count does not exceed, MU_NCLS - 1
 // = dense beyond the last limit; empty units are dropped): counts (FILL = false) or the lists themselves, (row << 16) |
 // window, class c from cursor[c] on.  One wavefront per row, lanes over the windows, one atomic per wavefront, class and batch
 // of 64 windows.
-constexpr int MU_NCLS = 4;
+// Round 5: classes 0 .. 2 = GROUP units (F > 1 consecutive windows of a row whose entries together fit the compact classes: up to
+// lim[0] / lim[1] / lim[2] entries), 3 .. 5 = single-window units of up to lim[0] / lim[1] / lim[2] entries, 6 = dense single-window units.
+// With F = 1 (and in the mask-driven product) every unit is a single window.
+constexpr int MU_NCLS = 7, MU_CLS_WINDOW = 3;
 struct UnitLimits {
-    int lim[MU_NCLS - 1];
+    int lim[3];
 };
+// the class of the unit lane `lane` LEADS (-1: none), cnt = the entries of the lane's window; the lanes of a wavefront hold consecutive
+// windows starting at a multiple of 64, so an aligned run of F lanes is a group.  All 64 lanes must call this.
+__device__ __forceinline__ int unit_class_of(int cnt, int F, const UnitLimits &L, int lane, bool *grouped_out = nullptr)
+{
+    int tot = cnt;
+    for (int d = 1; d < F; d <<= 1) tot += __shfl_xor(tot, d);
+    const bool grouped = F > 1 && tot <= L.lim[2];
+    if (grouped_out) *grouped_out = grouped;
+    if (grouped) {
+        if ((lane & (F - 1)) != 0 || tot == 0) return -1;
+        return tot <= L.lim[0] ? 0 : (tot <= L.lim[1] ? 1 : 2);
+    }
+    if (cnt <= 0) return -1;
+    return MU_CLS_WINDOW + (cnt <= L.lim[0] ? 0 : (cnt <= L.lim[1] ? 1 : (cnt <= L.lim[2] ? 2 : 3)));
+}
 // class counters and list cursors are kept per SLOT of the row ((row / 4) mod MU_CSLOTS): millions of atomics on one address
 // serialise (21 ms per pass over the 4 M rows of scale 22 with a single counter per class)
 constexpr int MU_CSLOTS = 256;
@@ -1175,7 +1256,7 @@ __device__ __forceinline__ int class_slot(int64_t row) { return (int)((row >> 2)
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_unit_classify(const int32_t *wcnt, const int32_t *wrow, int nwin, const uint32_t *rows, int64_t nrows_bin,
                                                        unsigned long long *cursor, UnitRec *lists, UnitLimits L, const int64_t *Ap,
-                                                       const int64_t *base_ptr, const int32_t *wbm, int masked)
+                                                       const int64_t *base_ptr, const int32_t *wbm, int masked, int F)
 {
     const int lane = threadIdx.x & 63;
     const int64_t ridx = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1189,12 +1270,7 @@ __global__ __launch_bounds__(256) void k_unit_classify(const int32_t *wcnt, cons
     for (int b = 0; b < nwin; b += 64) {
         const int w = b + lane;
         const int cnt = w < nwin ? wc[w + 1] - wc[w] : 0;
-        int cls = -1;
-        if (cnt > 0) {
-            cls = MU_NCLS - 1;
-            for (int c = MU_NCLS - 2; c >= 0; c--)
-                if (cnt <= L.lim[c]) cls = c;
-        }
+        const int cls = unit_class_of(cnt, F, L, lane);
         for (int c = 0; c < MU_NCLS; c++) {
             const unsigned long long mk = __ballot(cls == c);
             if (mk == 0) continue;
@@ -1206,12 +1282,12 @@ __global__ __launch_bounds__(256) void k_unit_classify(const int32_t *wcnt, cons
                 base = __shfl(base, 0);
                 if (cls == c) {
                     UnitRec r;
-                    r.out = base_ptr[row] + wc[w];  // (base_ptr: the row pointers of T, or of the mask)
+                    r.out = base_ptr[row] + wc[w];  // (base_ptr: the row pointers of T, or of the mask; a group starts where its first window starts)
                     r.pbeg = Ap[row];
                     r.plen = (int32_t)(Ap[row + 1] - r.pbeg);
                     r.row = (uint32_t)row;
-                    r.aux = masked ? cnt : (wbm ? wbm[(int64_t)slot * nwin + w] : -1);
-                    r.w = w;
+                    r.aux = masked ? cnt : (wbm ? wbm[(int64_t)slot * nwin + w] : -1);  // (a group's bitmap: F window bitmaps from its first window's slot on)
+                    r.w = c < MU_CLS_WINDOW ? w / F : w;  // (group units count groups)
                     lists[base + __popcll(mk & ((1ull << lane) - 1ull))] = r;
                 }
             }
@@ -1269,12 +1345,7 @@ __global__ __launch_bounds__(256) void k_window_offsets_wave(const int64_t *Bp, 
                 }
             }
             const int cnt = w < n_win ? next - first : 0;
-            int cls = -1;
-            if (cnt > 0) {
-                cls = MU_NCLS - 1;
-                for (int c = MU_NCLS - 2; c >= 0; c--)
-                    if (cnt <= L.lim[c]) cls = c;
-            }
+            const int cls = unit_class_of(cnt, 1, L, lane);  // (the mask-driven units walk single windows)
             for (int c = 0; c < MU_NCLS; c++) ccount[c] += (unsigned)__popcll(__ballot(cls == c));
         }
     }
@@ -1328,12 +1399,7 @@ __global__ __launch_bounds__(256) void k_window_offsets_hist(const int64_t *Bp, 
         if (w <= n_win) o[w] = carry + incl - cnt;  // entries of the row before window w
         carry += __builtin_amdgcn_readlane(incl, 63);
         if (classify) {
-            int cls = -1;
-            if (cnt > 0) {
-                cls = MU_NCLS - 1;
-                for (int c = MU_NCLS - 2; c >= 0; c--)
-                    if (cnt <= L.lim[c]) cls = c;
-            }
+            const int cls = unit_class_of(cnt, 1, L, lane);
             for (int c = 0; c < MU_NCLS; c++) ccount[c] += (unsigned)__popcll(__ballot(cls == c));
         }
     }
@@ -1367,7 +1433,7 @@ __global__ void k_sym_long_rows(const uint32_t *rows, int64_t nrows_bin, const i
 // One wavefront per row.
 // ... and, on the way, how many units each class of the numeric pass will hold (class_count[c]; k_unit_classify's counting pass)
 __global__ __launch_bounds__(256) void k_unit_prefix(int32_t *wcnt, int nwin, const uint32_t *rows, int64_t nrows_bin, int64_t *row_nnz,
-                                                     int32_t *wrow, unsigned long long *class_count, UnitLimits L)
+                                                     int32_t *wrow, unsigned long long *class_count, UnitLimits L, int F)
 {
     const int lane = threadIdx.x & 63;
     const int64_t ridx = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1377,12 +1443,7 @@ __global__ __launch_bounds__(256) void k_unit_prefix(int32_t *wcnt, int nwin, co
     unsigned ccount[MU_NCLS] = {0};
     for (int b = 0; b < nwin; b += 64) {
         const int v = b + lane < nwin ? wc[b + lane] : 0;
-        int cls = -1;
-        if (v > 0) {
-            cls = MU_NCLS - 1;
-            for (int c = MU_NCLS - 2; c >= 0; c--)
-                if (v <= L.lim[c]) cls = c;
-        }
+        const int cls = unit_class_of(v, F, L, lane);
         for (int c = 0; c < MU_NCLS; c++) ccount[c] += (unsigned)__popcll(__ballot(cls == c));
         int incl = wave_inclusive_sum(v);
         if (b + lane < nwin) wc[b + lane] = carry + incl - v;
@@ -1706,13 +1767,14 @@ static void launch_unit_classes(MxmArgs &a, const uint32_t *rows, int64_t nrows,
     constexpr int NC = MU_CSLOTS * MU_NCLS;
     DevBuf<unsigned long long> cur(NC, true);
     const UnitLimits L = unit_limits(MODE == MU_MASKED);
+    const int FG = MODE == MU_MASKED ? 1 : std::max(1, a.win_f);  // windows per group unit
     std::vector<unsigned long long> slot_cnt(NC);
     if (known) {
         std::copy(known, known + NC, slot_cnt.begin());
     } else {
         hipLaunchKernelGGL((k_unit_classify<false>), dim3((unsigned)ceil_div(nrows, 4)), dim3(256), 0, ctx().stream, (const int32_t *)a.wcnt,
                            (const int32_t *)a.wrow, a.n_win, rows, nrows, cur.p, (UnitRec *)nullptr, L, a.Ap, (const int64_t *)nullptr,
-                           (const int32_t *)nullptr, 0);
+                           (const int32_t *)nullptr, 0, FG);
         d2h(slot_cnt.data(), cur.p, sizeof(unsigned long long) * NC);
     }
     // class c's list = the slots' sub-lists one after the other: the fill pass's cursors start at the sub-lists' beginnings
@@ -1731,29 +1793,40 @@ static void launch_unit_classes(MxmArgs &a, const uint32_t *rows, int64_t nrows,
             }
     }
     if (getenv("GRB_MXM_TRACE"))
-        fprintf(stderr, "[mxm] %s units: %lld rows x %d windows; by class %llu %llu %llu %llu\n", MODE == MU_MASKED ? "masked" : "numeric",
-                (long long)nrows, a.n_win, cnt[0], cnt[1], cnt[2], cnt[3]);
+        fprintf(stderr, "[mxm] %s units: %lld rows x %d windows, groups of %d; group classes %llu %llu %llu, window classes %llu %llu %llu, dense %llu\n",
+                MODE == MU_MASKED ? "masked" : "numeric", (long long)nrows, a.n_win, FG, cnt[0], cnt[1], cnt[2], cnt[3], cnt[4], cnt[5], cnt[6]);
     DevBuf<UnitRec> lists((size_t)start[MU_NCLS]);
     h2d(cur.p, cursors.data(), sizeof(unsigned long long) * NC);
     hipLaunchKernelGGL((k_unit_classify<true>), dim3((unsigned)ceil_div(nrows, 4)), dim3(256), 0, ctx().stream, (const int32_t *)a.wcnt,
                        (const int32_t *)a.wrow, a.n_win, rows, nrows, cur.p, lists.p, L, a.Ap, MODE == MU_MASKED ? a.Mp : a.Tp,
-                       (const int32_t *)a.wbm, MODE == MU_MASKED ? 1 : 0);
+                       (const int32_t *)a.wbm, MODE == MU_MASKED ? 1 : 0, FG);
     constexpr int64_t PER = 1ll << 21;
     auto per_class = [&](int c, auto &&launch) {
         for (int64_t u0 = 0; u0 < (int64_t)cnt[c]; u0 += PER)
             launch(lists.p + start[c] + u0, std::min<int64_t>(PER, (int64_t)cnt[c] - u0));
     };
-    per_class(0, [&](const UnitRec *u, int64_t nu) {
-        hipLaunchKernelGGL((k_spgemm_unit<T, MODE, 1, MU_SMALL>), dim3((unsigned)ceil_div(nu, 4)), dim3(256), 0, ctx().stream, a, rows, 0, 0, u, nu);
-    });
-    per_class(1, [&](const UnitRec *u, int64_t nu) {
-        hipLaunchKernelGGL((k_spgemm_unit<T, MODE, 4, 1024>), dim3((unsigned)nu), dim3(256), 0, ctx().stream, a, rows, 0, 0, u, nu);
-    });
-    per_class(2, [&](const UnitRec *u, int64_t nu) {
-        hipLaunchKernelGGL((k_spgemm_unit<T, MODE, GRB_MU_M2_WPU, 4096>), dim3((unsigned)nu), dim3(64 * GRB_MU_M2_WPU), 0, ctx().stream, a, rows, 0, 0, u, nu);
-    });
+    // the three compact classes of units of F windows (F = 1: single windows)
+    auto compact_classes = [&](int c0, auto f_c) {
+        constexpr int F = decltype(f_c)::value;
+        per_class(c0, [&](const UnitRec *u, int64_t nu) {
+            hipLaunchKernelGGL((k_spgemm_unit<T, MODE, 1, MU_SMALL, F>), dim3((unsigned)ceil_div(nu, 4)), dim3(256), 0, ctx().stream, a, rows, 0, 0, u, nu);
+        });
+        per_class(c0 + 1, [&](const UnitRec *u, int64_t nu) {
+            hipLaunchKernelGGL((k_spgemm_unit<T, MODE, 4, 1024, F>), dim3((unsigned)nu), dim3(256), 0, ctx().stream, a, rows, 0, 0, u, nu);
+        });
+        per_class(c0 + 2, [&](const UnitRec *u, int64_t nu) {
+            hipLaunchKernelGGL((k_spgemm_unit<T, MODE, GRB_MU_M2_WPU, 4096, F>), dim3((unsigned)nu), dim3(64 * GRB_MU_M2_WPU), 0, ctx().stream, a, rows, 0, 0, u, nu);
+        });
+    };
+    if constexpr (MODE == MU_NUMERIC) {
+        using std::integral_constant;
+        if (FG == 2) compact_classes(0, integral_constant<int, 2>{});
+        else if (FG == 4) compact_classes(0, integral_constant<int, 4>{});
+        else if (FG == 8) compact_classes(0, integral_constant<int, 8>{});
+    }
+    compact_classes(MU_CLS_WINDOW, std::integral_constant<int, 1>{});
     if constexpr (MODE == MU_NUMERIC)
-        per_class(3, [&](const UnitRec *u, int64_t nu) {
+        per_class(MU_CLS_WINDOW + 3, [&](const UnitRec *u, int64_t nu) {
             hipLaunchKernelGGL((k_spgemm_unit_dense<T>), dim3((unsigned)nu), dim3(MM_WIN_BLOCK), 0, ctx().stream, a, u);
         });
     ctx().stats.kernel_launches += 6;
@@ -1779,7 +1852,9 @@ static void run_bins(MxmArgs &a, const RowBins &rb)
         } else {
             // rows with at most MU_SYM_PLEN entries of A (94 % of the unit rows of an R-MAT product): MU_SYM_WG windows per unit;
             // the others from a list, one window per unit
-            const int wg = (int)std::max<int64_t>(1, std::min<int64_t>(ctx().mxm_sym_windows, a.n_win));
+            const int FG = std::max(1, a.win_f);
+            const int64_t n_groups = ceil_div((int64_t)a.n_win, (int64_t)FG);  // (units walk groups of FG windows)
+            const int wg = (int)std::max<int64_t>(1, std::min<int64_t>(ctx().mxm_sym_windows, n_groups));
             DevBuf<int32_t> long_list(wg > 1 ? rb.count(4) : 0);
             int64_t n_long_rows = 0;
             if (wg > 1) {
@@ -1795,12 +1870,16 @@ static void run_bins(MxmArgs &a, const RowBins &rb)
                 as.sym_wg = wg_here;
                 as.sym_plen_max = plen_max;
                 as.sym_list = list;
-                const int64_t ngrp = ceil_div((int64_t)a.n_win, (int64_t)wg_here);
+                const int64_t ngrp = ceil_div(n_groups, (int64_t)wg_here);
                 const int64_t rows_per_launch = std::max<int64_t>(1, (1ll << 22) / ngrp);
                 for (int64_t r0 = 0; r0 < nrows_total; r0 += rows_per_launch) {
                     const int64_t nr = std::min(rows_per_launch, nrows_total - r0);
-                    hipLaunchKernelGGL((k_spgemm_unit<T, MU_SYMBOLIC, 1, 1>), dim3((unsigned)ceil_div(nr * ngrp, 4)), dim3(256), 0, ctx().stream, as, rb.ptr(4), r0,
-                                       nr, (const UnitRec *)nullptr, 0);
+                    const dim3 grid((unsigned)ceil_div(nr * ngrp, 4));
+                    const UnitRec *none = nullptr;
+                    if (FG == 2) hipLaunchKernelGGL((k_spgemm_unit<T, MU_SYMBOLIC, 1, 1, 2>), grid, dim3(256), 0, ctx().stream, as, rb.ptr(4), r0, nr, none, 0);
+                    else if (FG == 4) hipLaunchKernelGGL((k_spgemm_unit<T, MU_SYMBOLIC, 1, 1, 4>), grid, dim3(256), 0, ctx().stream, as, rb.ptr(4), r0, nr, none, 0);
+                    else if (FG == 8) hipLaunchKernelGGL((k_spgemm_unit<T, MU_SYMBOLIC, 1, 1, 8>), grid, dim3(256), 0, ctx().stream, as, rb.ptr(4), r0, nr, none, 0);
+                    else hipLaunchKernelGGL((k_spgemm_unit<T, MU_SYMBOLIC, 1, 1, 1>), grid, dim3(256), 0, ctx().stream, as, rb.ptr(4), r0, nr, none, 0);
                     ctx().stats.kernel_launches += 1;
                 }
             };
@@ -1812,7 +1891,7 @@ static void run_bins(MxmArgs &a, const RowBins &rb)
                 launch_sym(rb.count(4), 1, 0, nullptr);
             }
             hipLaunchKernelGGL(k_unit_prefix, dim3((unsigned)ceil_div(rb.count(4), 4)), dim3(256), 0, ctx().stream, a.wcnt, a.n_win, rb.ptr(4),
-                               rb.count(4), a.row_nnz, a.wrow, a.class_count, unit_limits(false));
+                               rb.count(4), a.row_nnz, a.wrow, a.class_count, unit_limits(false), FG);
             ctx().stats.kernel_launches += 1;
         }
     } else if (rb.count(4) && !NUMERIC && a.n <= (1 << 24) && !(ctx().debug_flags & 256)) {
@@ -1864,7 +1943,8 @@ struct ForbiddenPattern {
 };
 template <typename T>
 static GB_Matrix_opaque *spgemm(GB_Matrix_opaque *A, const void *Ax, GB_Matrix_opaque *B, const void *Bx, int st, int monoid,
-                                int mult, const ForbiddenPattern *forbidden = nullptr, bool *fused = nullptr)
+                                int mult, const ForbiddenPattern *forbidden = nullptr, bool *fused = nullptr,
+                                unsigned long long *csum_slots = nullptr)
 {
     if (fused) *fused = false;
     GB_Matrix_opaque *Tm = matrix_new(type_of_code(st), A->nrows, B->ncols);
@@ -1880,6 +1960,7 @@ static GB_Matrix_opaque *spgemm(GB_Matrix_opaque *A, const void *Ax, GB_Matrix_o
         a.mult = mult;
         a.need_a = !(mult == OP_PAIR || mult == OP_SECOND);
         a.need_b = !(mult == OP_PAIR || mult == OP_FIRST || mult == OP_ANY);
+        a.csum = csum_slots;  // (streamed product: the numeric kernels add the values they store)
 #ifdef GRB_ABLATE
         a.abl = (ctx().debug_flags >> 20) & 0x7FF;
 #endif
@@ -1929,7 +2010,17 @@ static GB_Matrix_opaque *spgemm(GB_Matrix_opaque *A, const void *Ax, GB_Matrix_o
                                   n_win < 65536;
             // (never above 4096: a row the hash kernels count must fit the numeric hash table, nnz <= flops <= 4096 -- or it falls to the
             //  1024-thread window walk, a quarter of the scale-22 run while the limit was 32 x 256 windows = 8192)
-            const int64_t sym_b3 = units_ok ? std::min<int64_t>(4096, std::max<int64_t>(ctx().mxm_unit_min_flops, ctx().mxm_unit_min_per_window * n_win)) : 16384;
+            // round 5: the units walk groups of win_f windows -- as many groups per row at scale 22 as windows at scale 20 (option
+            // mxm_window_groups: 0 = sized from the number of windows, at most 64 groups per row up to 512 windows; 1 / 2 / 4 / 8)
+            int win_f = 1;
+            if (units_ok) {
+                const int64_t want = ctx().mxm_window_groups;
+                if (want > 0) win_f = (int)want;
+                else win_f = n_win <= 64 ? 1 : (n_win <= 128 ? 2 : (n_win <= 256 ? 4 : 8));
+            }
+            a.win_f = win_f;
+            const int64_t n_groups = ceil_div(n_win, (int64_t)win_f);
+            const int64_t sym_b3 = units_ok ? std::min<int64_t>(4096, std::max<int64_t>(ctx().mxm_unit_min_flops, ctx().mxm_unit_min_per_window * n_groups)) : 16384;
             make_bins(rb, A->d_ptr, F.p, m, rownnz.p, 128, 1024, sym_b3, nullptr, fuse ? forbidden->p : nullptr);
             GRB_HIP(hipMemsetAsync(rownnz.p, 0, sizeof(int64_t) * (m + 1), ctx().stream));
             if (rb.count(4) && units_ok && rb.count(4) * (n_win + 1) * 4 <= (8ll << 30)) {
@@ -2460,7 +2551,10 @@ extern "C" GrB_Info GrX_mxm_streamed(const GrB_Semiring semiring, const GrB_Matr
     if (A->type->code != st || B->type->code != st) fail(GrB_DOMAIN_MISMATCH, "GrX_mxm_streamed: operands must have the semiring's type");
     const int monoid = canonical_op(st, semiring->monoid), mult = canonical_op(st, semiring->mult);
     uint64_t nv = 0, fl = 0, nb = 0;
-    DevBuf<unsigned long long> csum(1, true);
+    // the checksum of the product's values: folded into the numeric kernels' stores (round 5; MM_CSUM_SLOTS counters, a 128-byte line
+    // apart) -- or, with mxm_checksum_pass = 1, by a pass of its own over every batch's product (round 4: 7 % of the scale-22 run)
+    const bool sum_pass = ctx().mxm_checksum_pass != 0;
+    DevBuf<unsigned long long> csum((size_t)MM_CSUM_SLOTS * 16, true);
     const int64_t m = (int64_t)A->nrows;
     if (A->nvals && B->nvals) {
         DevBuf<int64_t> F(A->nvals + 1);
@@ -2501,8 +2595,8 @@ extern "C" GrB_Info GrX_mxm_streamed(const GrB_Semiring semiring, const GrB_Matr
                     V->nvals = e1 - e0;
                     V->owns = false;
                     GRB_DISPATCH_TYPE(st, T, {
-                        Tm = spgemm<T>(V, V->d_val, B, B->d_val, st, monoid, mult);
-                        if (Tm->nvals) {
+                        Tm = spgemm<T>(V, V->d_val, B, B->d_val, st, monoid, mult, nullptr, nullptr, sum_pass ? nullptr : csum.p);
+                        if (Tm->nvals && sum_pass) {
                             hipLaunchKernelGGL((k_value_checksum<T>), dim3((unsigned)(ctx().num_cus * 16)), dim3(256), 0, ctx().stream, (const T *)Tm->d_val, Tm->nvals,
                                                csum.p);
                         }
@@ -2527,7 +2621,11 @@ extern "C" GrB_Info GrX_mxm_streamed(const GrB_Semiring semiring, const GrB_Matr
         }
     }
     unsigned long long hsum = 0;
-    d2h(&hsum, csum.p, 8);
+    {
+        std::vector<unsigned long long> slots((size_t)MM_CSUM_SLOTS * 16);
+        d2h(slots.data(), csum.p, sizeof(unsigned long long) * slots.size());
+        for (size_t i = 0; i < slots.size(); i += (sum_pass ? slots.size() : 16)) hsum += slots[i];
+    }
     if (nvals_out) *nvals_out = nv;
     if (checksum_out) *checksum_out = hsum;
     if (flops_out) *flops_out = fl;

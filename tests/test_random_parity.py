@@ -1066,15 +1066,64 @@ def test_mxm_streamed_row_batches(gb, seed, request):
     ref = (Sa @ Sb).tocsr()
     want_sum = int(ref.data.astype(np.int64).sum()) & 0xFFFFFFFFFFFFFFFF
     sr = gb.semiring.plus_times[tname]
-    for budget in (1, 4096, 1 << 30):
-        nv, cs, fl, nb = (ctypes.c_uint64(0) for _ in range(4))
-        rc = _lib.lib.GrX_mxm_streamed(sr._carg, A._carg, B._carg, budget, ctypes.byref(nv), ctypes.byref(cs), ctypes.byref(fl), ctypes.byref(nb))
-        assert rc == 0
-        assert nv.value == pat.nnz
-        assert fl.value == int((np.diff(Sb.indptr)[ac]).sum())
-        if tname != "INT32":  # (INT32 entries are summed after sign extension: not comparable with the int64 product's sum)
-            assert cs.value == want_sum
-        assert nb.value >= 1 and (budget > 1 or nb.value > m // 4) and (budget < (1 << 30) or nb.value == 1)
+    sums = {}
+    try:
+        for sum_pass in (0, 1):  # (the checksum folded into the numeric kernels' stores -- round 5 -- and by a pass of its own over the product)
+            assert _lib.lib.GrX_option_set(b"mxm_checksum_pass", sum_pass) == 0
+            for budget in (1, 4096, 1 << 30):
+                nv, cs, fl, nb = (ctypes.c_uint64(0) for _ in range(4))
+                rc = _lib.lib.GrX_mxm_streamed(sr._carg, A._carg, B._carg, budget, ctypes.byref(nv), ctypes.byref(cs), ctypes.byref(fl), ctypes.byref(nb))
+                assert rc == 0
+                assert nv.value == pat.nnz
+                assert fl.value == int((np.diff(Sb.indptr)[ac]).sum())
+                if tname != "INT32":  # (INT32 entries are summed after sign extension: not comparable with the int64 product's sum)
+                    assert cs.value == want_sum
+                sums.setdefault(budget, []).append(cs.value)
+                assert nb.value >= 1 and (budget > 1 or nb.value > m // 4) and (budget < (1 << 30) or nb.value == 1)
+        assert all(a == b for a, b in sums.values())
+    finally:
+        _lib.lib.GrX_option_set(b"mxm_checksum_pass", 0)
+
+
+@pytest.mark.parametrize("groups", [0, 4])
+def test_mxm_streamed_checksum_through_the_unit_kernels(gb, groups, request):
+    """The folded checksum on the heavy-row kernels: rows of A with hundreds of entries times a B of nine column windows -- units of
+    every compact class, dense units, window groups -- in row batches; count and checksum against scipy."""
+    import ctypes
+
+    import scipy.sparse as sp
+
+    from graphblas_amd import _lib
+
+    rng = np.random.default_rng(515)
+    on_gpu = request.node.callspec.params["gb"] == "gpu"
+    k, n, m = 150, 9 * 16384 - 77, 6
+    br, bc = [], []
+    for r in range(k):
+        d = int(rng.integers(50, 400 if on_gpu else 150))
+        cols = np.unique(np.minimum((rng.random(d) ** 2 * n).astype(np.int64), n - 1))  # (the first windows are dense, the last ones thin)
+        br.append(np.full(cols.size, r))
+        bc.append(cols)
+    br, bc = np.concatenate(br), np.concatenate(bc)
+    deg = np.array([120, 3, 150, 0, 90, 40])
+    ar = np.repeat(np.arange(m), deg)
+    ac = np.concatenate([np.sort(rng.choice(k, d, replace=False)) for d in deg])
+    av = rng.integers(1, 4, ar.size).astype(np.int64)
+    bv = rng.integers(1, 4, br.size).astype(np.int64)
+    ref = (sp.csr_matrix((av, (ar, ac)), shape=(m, k)) @ sp.csr_matrix((bv, (br, bc)), shape=(k, n))).tocsr()
+    A = gb.Matrix.from_coo(ar, ac, av, dtype="INT64", nrows=m, ncols=k)
+    B = gb.Matrix.from_coo(br, bc, bv, dtype="INT64", nrows=k, ncols=n)
+    sr = gb.semiring.plus_times["INT64"]
+    try:
+        for name, val in dict(mxm_unit_min_flops=128, mxm_window_groups=groups, mxm_unit_dense=1500).items():
+            assert _lib.lib.GrX_option_set(name.encode(), val) == 0
+        for budget in (1 << 16, 1 << 30):
+            nv, cs, fl, nb = (ctypes.c_uint64(0) for _ in range(4))
+            assert _lib.lib.GrX_mxm_streamed(sr._carg, A._carg, B._carg, budget, ctypes.byref(nv), ctypes.byref(cs), ctypes.byref(fl), ctypes.byref(nb)) == 0
+            assert nv.value == ref.nnz and cs.value == int(ref.data.sum())
+    finally:
+        for name, val in dict(mxm_unit_min_flops=1024, mxm_window_groups=0, mxm_unit_dense=4096).items():
+            _lib.lib.GrX_option_set(name.encode(), val)
 
 
 def test_mxm_wide_heavy_rows(gb):
@@ -1206,6 +1255,20 @@ def test_mxm_very_wide(gb):
 
 @pytest.mark.parametrize("seed", range(20))
 def test_mxm_units_random(gb, seed, request=None):
+    on_gpu = request is None or request.node.callspec.params["gb"] == "gpu"  # (scripts/stress_parity.py calls without a request)
+    _mxm_units_case(gb, seed, on_gpu)
+
+
+@pytest.mark.parametrize("groups", [2, 4, 8])
+@pytest.mark.parametrize("seed", range(12))
+def test_mxm_units_window_groups(gb, seed, groups, request):
+    """Round 5: the units walk GROUPS of 2 / 4 / 8 column windows (option mxm_window_groups; by default a function of the width of B).
+    The same random cases as test_mxm_units_random on matrices of up to 12 windows: groups that fit the compact classes run as one
+    unit, denser ones fall back to their windows; the last group of a row is short; kept and recomputed bitmaps."""
+    _mxm_units_case(gb, 300 + seed, request.node.callspec.params["gb"] == "gpu", nwin_hi=13, groups=groups)
+
+
+def _mxm_units_case(gb, seed, on_gpu, nwin_hi=6, groups=0):
     """(row, column window) units on random shapes: the columns of B drawn from a skewed window distribution (units of every
     class: one wavefront / four wavefronts with 1024 and 4096 accumulators / an accumulator per column, several windows, empty
     windows), rows of A from a few to thousands of entries, every type and semiring of the random tests, iso and valued
@@ -1213,12 +1276,11 @@ def test_mxm_units_random(gb, seed, request=None):
     mask-driven with the units keyed by the mask row); random class limits and bitmap-pool sizes."""
     from graphblas_amd import _lib
 
-    on_gpu = request is None or request.node.callspec.params["gb"] == "gpu"  # (scripts/stress_parity.py calls without a request)
     rng = np.random.default_rng(9100 + seed)
     tname = TYPES[seed % 7]
     srs = semirings_for(tname)
     sr = srs[int(rng.integers(len(srs)))]
-    nwin = int(rng.integers(1, 6))
+    nwin = int(rng.integers(1, nwin_hi))
     n = int(rng.integers((nwin - 1) * 16384 + 1, nwin * 16384 + 1))
     k = int(rng.integers(40, 400 if on_gpu else 120))
     m = int(rng.integers(3, 40 if on_gpu else 10))
@@ -1268,10 +1330,10 @@ def test_mxm_units_random(gb, seed, request=None):
     opts = dict(mxm_unit_small=int(rng.choice([64, 512])), mxm_unit_mid=int(rng.choice([300, 1024])),
                 mxm_unit_dense=int(rng.choice([1500, 4096])), mxm_bitmap_pool_cap=int(rng.choice([0, 2, (1 << 31) - 1])),
                 mxm_unit_min_flops=int(rng.choice([128, 1024])), mxm_masked_units_min_flops=0, mxm_mask_mode=2 if mode == 2 else 0,
-                mxm_sym_windows=int(rng.choice([1, 2, 4, 64])))
+                mxm_sym_windows=int(rng.choice([1, 2, 4, 64])), mxm_window_groups=groups)
     try:
         for name, val in opts.items():
-            _lib.lib.GrX_option_set(name.encode(), val)
+            assert _lib.lib.GrX_option_set(name.encode(), val) == 0, name
         A = gb.Matrix.from_coo(ar, ac, av, dtype=tname, nrows=m, ncols=k)
         B = gb.Matrix.from_coo(br, bc, bv, dtype=tname, nrows=k, ncols=n)
         C = gb.Matrix.from_coo(cr, cc, cv, dtype=tname, nrows=m, ncols=n) if mode in (1, 3) else gb.Matrix(tname, m, n)
@@ -1296,7 +1358,8 @@ def test_mxm_units_random(gb, seed, request=None):
             same_mat(C, exp)
     finally:
         for name, val in dict(mxm_unit_small=512, mxm_unit_mid=1024, mxm_unit_dense=4096, mxm_bitmap_pool_cap=(1 << 31) - 1,
-                              mxm_unit_min_flops=1024, mxm_masked_units_min_flops=64 << 20, mxm_mask_mode=1, mxm_sym_windows=8).items():
+                              mxm_unit_min_flops=1024, mxm_masked_units_min_flops=64 << 20, mxm_mask_mode=1, mxm_sym_windows=8,
+                              mxm_window_groups=0).items():
             _lib.lib.GrX_option_set(name.encode(), val)
 
 
