@@ -372,9 +372,9 @@ GrB_Info GrX_Matrix_cache_bytes(const GrB_Matrix A, uint64_t *bytes);
  *   "mxm_heavy_kernel"  SpGEMM rows beyond the LDS hash tables: 1 (default) (row, column window) work units (k_spgemm_unit),
  *                   0 the 1024-thread row kernels of round 1
  *   "mxm_window_groups"  (round 5) the (row, window) units of a product walk GROUPS of this many 16 Ki-column windows (1 / 2 / 4 / 8;
- *                   0 = default: from the width of B -- 1 up to 64 windows, 2 up to 128, 4 up to 256, 8 beyond -- so that a row of a
- *                   scale-22 matrix is cut into as many units as a row of a scale-20 matrix); a group that holds more entries than
- *                   the densest compact class is walked window by window as before
+ *                   0 = default: 1 up to 64 windows per row, 2 beyond -- measured: wider groups lose more occupancy to their bitmaps
+ *                   than they save units); a group that holds more entries than the densest compact class is walked window by
+ *                   window as before
  *   "mxm_checksum_pass"  GrX_mxm_streamed: 0 (default) the checksum of the product is folded into the numeric kernels' stores, 1 a pass
  *                   of its own re-reads every batch's values (round 4)
  *   "mxm_sym_windows"  consecutive column windows (groups of windows) of a row one symbolic unit walks (rows of up to 128 entries of A; default 8,

@@ -2010,13 +2010,16 @@ static GB_Matrix_opaque *spgemm(GB_Matrix_opaque *A, const void *Ax, GB_Matrix_o
                                   n_win < 65536;
             // (never above 4096: a row the hash kernels count must fit the numeric hash table, nnz <= flops <= 4096 -- or it falls to the
             //  1024-thread window walk, a quarter of the scale-22 run while the limit was 32 x 256 windows = 8192)
-            // round 5: the units walk groups of win_f windows -- as many groups per row at scale 22 as windows at scale 20 (option
-            // mxm_window_groups: 0 = sized from the number of windows, at most 64 groups per row up to 512 windows; 1 / 2 / 4 / 8)
+            // round 5: the units walk groups of win_f windows (option mxm_window_groups: 1 / 2 / 4 / 8; 0 = 2 beyond 64 windows per row).
+            // Measured (profiles/r05/mxm_window_groups.txt; ms per product, groups 1 / 2 / 4 / 8): scale 20 (64 windows) 132.9 / 145.6 /
+            // 158.1 / 214.5, scale 22 (256 windows) 1565 / 1432 / 1505 / 2079, scale 21 456 / 447 -- the units of a wider matrix do gain from
+            // wider windows, but a group's bitmap and its per-lane words cost occupancy (symbolic unit: 8 / 8 / 4 / 2 wavefronts per SIMD,
+            // the one-wavefront numeric class 5 / 3 / 2 / 1) faster than they save units: pairs beyond 64 windows, single windows below.
             int win_f = 1;
             if (units_ok) {
                 const int64_t want = ctx().mxm_window_groups;
                 if (want > 0) win_f = (int)want;
-                else win_f = n_win <= 64 ? 1 : (n_win <= 128 ? 2 : (n_win <= 256 ? 4 : 8));
+                else win_f = n_win <= 64 ? 1 : 2;
             }
             a.win_f = win_f;
             const int64_t n_groups = ceil_div(n_win, (int64_t)win_f);
