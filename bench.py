@@ -109,7 +109,8 @@ class MxvWorkload:
     of every block, each followed by the asynchronous all-gather of its w slices into the replica the NEXT step reads
     (sharded.OverlappedMxv) -- the exchange of block c runs while block c + 1 is computed."""
 
-    def __init__(self, gb, torch, scale, rank, world, semiring, visited_frac, seed=0, block=None, chunks=1, force_dist=False):
+    def __init__(self, gb, torch, scale, rank, world, semiring, visited_frac, seed=0, block=None, chunks=1, force_dist=False, weights="int255",
+                 fresh_outputs=0):
         from graphblas_amd import _lib, device, sharded, synthetic
 
         self.gb, self.torch, self.rank, self.world = gb, torch, rank, world
@@ -159,7 +160,7 @@ class MxvWorkload:
             if semiring == "min_plus":
                 # (a sharded run never materialises the whole graph: every block draws its weights from the same stream, so the
                 #  N-rank runs relax other weights than the single-GPU run; each run is checked against ITS OWN operands)
-                vals = synthetic.edge_weights(col, scale)
+                vals = synthetic.edge_weights(col, scale) if weights == "int255" else synthetic.edge_weights_real(col, scale)
                 self.As.append(device.matrix_from_device_csr(indptr, col, vals, rows, n, "FP32"))
                 self.ws.append(device.vector_from_device(self._dist[lo:hi].contiguous()))
                 self._valss.append(vals)
@@ -180,6 +181,14 @@ class MxvWorkload:
         self._call = L.GrB_mxv
         self._args = (self.w._carg, self.mask._carg, self.accum._carg if self.accum else None, self.sr._carg,
                       self.A._carg, self.u._carg, ctypes.c_void_p(_lib.handle(desc_name)))
+        # "honest operands" variant: every timed step gets an output of its own holding the initial distances and the
+        # operand alternates between two vectors, so no step runs at the relaxation's fixed point and the write rule stores every time
+        self.fresh_ws, self.alt_us, self._dist2, self._k = [], [], None, 0
+        if fresh_outputs and not sharded_path and not block and semiring == "min_plus":
+            self._dist2 = torch.randint(0, 1000, (n,), generator=gen, device="cuda").to(torch.float32)
+            self.alt_us = [self.u, device.vector_from_device(self._dist2)]
+            self.fresh_ws = [device.vector_from_device(self._dist) for _ in range(fresh_outputs)]
+            self._none = device.vector_from_device(torch.ones(n, dtype=torch.bool, device="cuda"))  # (a full mask: its complement admits no row)
         self.ov = None
         if n_u == 2:
             # the BFS step's output is not full: its presence words travel with the values
@@ -188,9 +197,26 @@ class MxvWorkload:
             self.ov.probe_exchange()
             torch.cuda.synchronize()
 
+    def prepare_fresh(self):
+        """Bring every output / operand of the honest-operands variant into the matrix's vertex order WITHOUT changing it: a product under a
+        mask that admits no row converts the vectors it touches and stores nothing.  (Called after the layouts exist.)"""
+        for v in self.fresh_ws:
+            for uu in self.alt_us:
+                rc = self._call(v._carg, self._none._carg, self.accum._carg, self.sr._carg, self.A._carg, uu._carg, self._args[6])
+                assert rc == 0, rc
+        self._k = 0
+
     def step(self):
         if self.ov is not None:
             return self.ov.step()
+        if self.fresh_ws:
+            k = self._k
+            self._k += 1
+            rc = self._call(self.fresh_ws[k % len(self.fresh_ws)]._carg, self.mask._carg, self.accum._carg, self.sr._carg, self.A._carg,
+                            self.alt_us[k & 1]._carg, self._args[6])
+            if rc != 0:
+                raise RuntimeError(f"GrB_mxv failed with GrB_Info {rc}")
+            return
         rc = self._call(*self._args)
         if rc != 0:
             raise RuntimeError(f"GrB_mxv failed with GrB_Info {rc}")
@@ -229,6 +255,18 @@ class MxvWorkload:
         from graphblas_amd import device
 
         torch = self.torch
+        if self.fresh_ws:
+            # every timed step k relaxed ITS OWN copy of the initial distances with operand k & 1: check the last two (one per operand)
+            ok = self._k >= 2
+            for k in (self._k - 2, self._k - 1):
+                if k < 0:
+                    continue
+                wv, wb = device.vector_device_views(self.fresh_ws[k % len(self.fresh_ws)], pin=False)
+                uvals = self._dist if (k & 1) == 0 else self._dist2
+                d0 = self._dist[self.lo:self.hi]
+                _h, exp = self._expected_block(0, uvals, None, d0, torch.ones(self.m, dtype=torch.bool, device="cuda"))
+                ok = ok and bool(self._bits(wb, self.m).all().item()) and bool(torch.equal(wv, exp))
+            return ok
         if self.ov is None:
             wv, wb = device.vector_device_views(self.w, pin=False)  # (transient views: fetched again after every call)
             if self.semiring == "min_plus":
@@ -1012,10 +1050,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run(workload, scale, steps, warmup):
+    def run(workload, scale, steps, warmup, weights="int255", fresh_outputs=False):
         sr = {"mxv_min_plus_masked": "min_plus", "mxv_lor_land_masked": "lor_land", "mxv_min_plus": "min_plus"}[workload]
         visited = 0.0 if workload == "mxv_min_plus" else args.visited
-        wl = MxvWorkload(gb, torch, scale, rank, world, sr, visited, block=block, chunks=max(1, args.overlap_chunks), force_dist=args.force_dist)
+        wl = MxvWorkload(gb, torch, scale, rank, world, sr, visited, block=block, chunks=max(1, args.overlap_chunks), force_dist=args.force_dist,
+                         weights=weights, fresh_outputs=(steps if fresh_outputs else 0))
         # The first product of a matrix runs on its CSR arrays as they are; the second builds the cached layouts (hot-column coding,
         # long / short split, class strips).  Both are part of the warm-up and are timed apart (wall clock around a synchronised call).
         def timed_call():
@@ -1034,6 +1073,8 @@ def main():
             cache_bytes += int(cb.value)
         for _ in range(max(warmup - 2, 0)):
             wl.step()
+        if wl.fresh_ws:
+            wl.prepare_fresh()  # (every timed step works on an output of its own, already in the matrix's vertex order)
         barrier()
         t0 = time.perf_counter()
         device.timer_start()
@@ -1131,6 +1172,19 @@ def main():
                       **{k: r[k] for k in ("value", "ms_per_step", "dtype", "roofline", "verified")}, "unit": "GTEPS", "cpu_baseline": c2})
         del wl2
         freed()
+        # ---- the headline on inputs that lend it nothing: real-valued weights U[0,1) -- no value dictionary --,
+        #      and every step on an output of its own with the operand alternating -- no step at the fixed point, every admitted row stores
+        for label, kw in (("rmat24 mxv_min_plus_masked, FP32 weights U[0,1) instead of U{1..255}: the value dictionary cannot apply", dict(weights="real")),
+                          ("rmat24 mxv_min_plus_masked, every timed step on its own copy of the initial distances, operand alternating between two "
+                           "vectors: the write rule stores in every step (the default line repeats one call at its fixed point)", dict(fresh_outputs=True))):
+            try:
+                wl3, r = run("mxv_min_plus_masked", 24, args.steps, args.warmup, **kw)
+                extra.append({"workload": label, **{k: r[k] for k in ("value", "ms_per_step", "dtype", "roofline", "verified")}, "unit": "GTEPS",
+                              "stats": {k: r["stats"].get(k) for k in ("ordered", "value_dict", "fused_epilogue", "reorders")}})
+                del wl3
+            except Exception as e:  # an extra line must never take the headline down
+                extra.append({"workload": label, "error": repr(e)})
+            freed()
         for scale, steps, warmup, wk in ((20, 3, 1, "mxm_plus_times"), (20, 2, 1, "mxm_plus_times_cmask"), (22, 2, 1, "mxm_plus_times")):
             if scale == 20 and (world > 1 or args.force_dist):
                 continue  # (the sharded runs carry the scale-22 product, the size the north star quotes for 1 -> 8 GPUs)
@@ -1157,9 +1211,13 @@ def main():
             "vs_baseline": None,
             "dtype": res["dtype"],
             "data": "synthetic",
-            "config": {"workload": f"rmat{args.scale} {args.workload}: w<~visited.S> = min(w, A min.+ u), "
-                                   f"edge factor 16, visited density {args.visited}, dense u"
+            "config": {"workload": (f"rmat{args.scale} {args.workload}: w<~visited.S> = min(w, A min.+ u), "
+                                    f"edge factor 16, visited density {args.visited}, dense u, FP32 weights U{{1..255}} (BASELINE.md section 3); "
+                                    f"layouts: ordered={int(res['stats'].get('ordered', 0))} (popularity-ordered twin), "
+                                    f"value_dict={int(res['stats'].get('value_dict', 0))} (distinct values coded in one byte; the same call on U[0,1) "
+                                    "weights is under extra)")
                        if args.workload == "mxv_min_plus_masked" else f"rmat{args.scale} {args.workload}",
+                       "ordered": int(res["stats"].get("ordered", 0)), "value_dict": int(res["stats"].get("value_dict", 0)),
                        "edges_counted_per_step": res["edges_per_step"],
                        "parallelism": (f"rank {block[0]} of a {block[1]}-way row shard, compute only" if block else
                                        f"row-shard x{world}" + (f" ({res['exchange']['chunks_per_rank']} row blocks per rank) + RCCL all-gather of the w slices into "

@@ -109,6 +109,9 @@ struct Context {
     int lazy_layout = 1;             // 1: the SpMV layouts of a large matrix are built at its SECOND pull product, not its first
     int64_t lazy_min_nnz = 1 << 22;  // ... for matrices with at least this many entries (smaller ones build at once)
     int push_mode = 1;               // 0 never push, 1 push when u has < n/64 entries, 2 always push (tests)
+    int rows_tile = 1;               // 1: the short rows of an ordered matrix as sorted row tiles (k_mxv_rtile) where the call allows it (full operand, specialised semiring)
+    int rtile_rows = 8192;           // ... rows per tile (8192 or 16384; 8-byte accumulators: half)
+    int64_t rtile_entries = 32768;   // ... and about this many entries
     int rows_head = 1;               // 1: the short rows of an ordered matrix run with the hottest columns of the operand in LDS (k_mxv_rows_tag<.., HEAD>)
     int64_t rows_head_min_groups = 16384;  // ... from this many row groups of 64 (below, filling 512 heads costs more than they save)
     int push_small = 1;              // 1: a pushed frontier of at most 64 work items runs its three passes in one workgroup (k_push_small)
@@ -341,6 +344,19 @@ struct GB_Matrix_opaque {
     int64_t tg_units = 0;
     int tg_state = 0;
     bool short_tagged_only = false;    // the short part keeps its row pointers only: its entries live in the tagged row groups
+    // ... and, round 5, an ordered twin's short rows a second time as SORTED ROW TILES (k_mxv_rtile, grb_mxv_rtile.inc): tiles of up to
+    // rt_rows4 rows (8-byte accumulators: half) and ~rtile_entries entries, the entries of a tile sorted by column code in lane-transposed
+    // blocks of 256: column code, 16-bit row inside the tile, value (one-byte code with a dictionary)
+    int32_t *d_rt_col = nullptr;
+    uint16_t *d_rt_tag = nullptr;
+    void *d_rt_val = nullptr;
+    void *d_rt_tiles = nullptr;        // RTile[rt_ntiles]
+    int32_t *d_rt_order = nullptr;     // tile numbers, heaviest first (the order they are handed out in)
+    unsigned int *d_rt_counter = nullptr;  // the hand-out counter of a call (zeroed by k_long_init)
+    int64_t rt_units = 0;
+    int rt_ntiles = 0;
+    int rt_rows4 = 0;                  // the tile height the layout was built for (rows with 4-byte accumulators)
+    int rt_state = 0;                  // 0 = not built, 1 = built, -1 = not possible (sizes)
     // ---- vertex order (round 4; grb_mxv_order.inc): a large square matrix is laid out a second time as ord = P A P' for a permutation P
     //      by falling column count (perm); the pull kernels run on `ord` with operands kept in that order.  `ord` is a matrix object of its
     //      own whose column indices ARE the hot codes (hot_identity): the first hot_k positions are the hot table, no image is built

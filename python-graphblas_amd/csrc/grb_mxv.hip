@@ -39,6 +39,7 @@ namespace grb {
 #include "grb_mxv_rows.inc"
 #include "grb_mxv_rows_tag.inc"
 #include "grb_mxv_ctile.inc"
+#include "grb_mxv_rtile.inc"
 #include "grb_mxv_split_build.inc"
 #include "grb_mxv_write.inc"
 #include "grb_mxv_push.inc"
@@ -198,6 +199,7 @@ static void ensure_vdict(GB_Matrix_opaque *A, bool wanted)
 // Analyse (once) whether the rows split usefully into long and short ones and build the two parts.
 // `col_src` is the column array the kernels will index (hot-coded or original).
 static void ensure_tagged(GB_Matrix_opaque *A);
+static void ensure_rtile(GB_Matrix_opaque *A);
 // the short-row kernel of a matrix: option 6 (default) = tagged row groups for large matrices, the row-group kernel below
 static int short_kernel_for(const GB_Matrix_opaque *A)
 {
@@ -229,6 +231,9 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
         // (layouts derived from the short part go with it)
         dev_free(A->d_tg_off); dev_free(A->d_tg_col); dev_free(A->d_tg_val); dev_free(A->d_tg_tag); dev_free(A->d_tg_nonempty);
         A->d_tg_off = nullptr; A->d_tg_col = nullptr; A->d_tg_val = nullptr; A->d_tg_tag = nullptr; A->d_tg_nonempty = nullptr; A->tg_state = 0;
+        dev_free(A->d_rt_col); dev_free(A->d_rt_tag); dev_free(A->d_rt_val); dev_free(A->d_rt_tiles); dev_free(A->d_rt_order); dev_free(A->d_rt_counter);
+        A->d_rt_col = nullptr; A->d_rt_tag = nullptr; A->d_rt_val = nullptr; A->d_rt_tiles = nullptr; A->d_rt_order = nullptr; A->d_rt_counter = nullptr;
+        A->rt_state = 0; A->rt_units = 0; A->rt_ntiles = 0;
         dev_free(A->d_sstart); dev_free(A->d_sslot); dev_free(A->d_hrec);
         A->d_sstart = nullptr; A->d_sslot = nullptr; A->d_hrec = nullptr; A->strip_nseg = 0; A->hub_ncls = 0;
         dev_free(A->d_ct_col); dev_free(A->d_ct_val); dev_free(A->d_ct_loc); dev_free(A->d_ct_tiles); dev_free(A->d_ct_order);
@@ -675,6 +680,7 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
         // the tagged row groups are the only form of the short rows' entries the kernels read: the CSR copy they were built from is
         // released (0.42 GB of the cached layouts at scale 24); the row pointers stay (row lengths, accounting)
         ensure_tagged(A);
+        if (A->hot_identity && ctx().rows_tile) ensure_rtile(A);  // (an ordered twin: its short rows as sorted row tiles too, from the same CSR copy)
         dev_free(S->d_col);
         S->d_col = nullptr;
         if (!S->iso) {
@@ -702,7 +708,7 @@ static uint64_t order_signature()
     const Context &c = ctx();
     uint64_t h = 1469598103934665603ull;
     const int64_t v[] = {c.long_kernel, c.short_kernel, c.long_classes, c.split_min_len, c.long_sub, c.long_sub_min_len, c.lean_min_nnz,
-                         c.split_min_nnz, c.hot_k, c.drop_hot_cols, c.hub_min_len, c.value_dict};
+                         c.split_min_nnz, c.hot_k, c.drop_hot_cols, c.hub_min_len, c.value_dict, c.rows_tile, c.rtile_rows, c.rtile_entries};
     for (int64_t x : v) h = (h ^ (uint64_t)x) * 1099511628211ull;
     return h;
 }
@@ -916,6 +922,86 @@ static void ensure_tagged(GB_Matrix_opaque *A)
     A->tg_state = 1;
 }
 
+// sorted row tiles of the short part S of an ordered twin A (once per matrix; see grb_mxv_rtile.inc).  Needs the tagged row groups'
+// per-group "row has an entry" words (ensure_tagged) and S's CSR arrays.
+static void ensure_rtile(GB_Matrix_opaque *A)
+{
+    if (A->rt_state != 0) return;
+    A->rt_state = -1;
+    GB_Matrix_opaque *S = A->short_part;
+    const size_t vs = S->type->size;
+    if (!S->d_col || S->iso || S->nvals == 0 || S->nvals >= 0xf0000000ll || (vs != 4 && vs != 8) || S->type->code == TC_BOOL || A->tg_state != 1) return;
+    const int64_t m = (int64_t)S->nrows;
+    const int64_t live_rows = A->hot_identity ? std::min<int64_t>(m, std::max<int64_t>(A->ord_live_rows, 1)) : m;
+    const int64_t G = ceil_div(live_rows, 64);  // (the groups the row kernels cover; the rows behind them are empty)
+    const int64_t rows_end = std::min<int64_t>(G * 64, m);
+    const int rows4 = ctx().rtile_rows == 16384 ? 16384 : 8192;
+    const int rows_cap = vs > 4 ? rows4 / 2 : rows4;
+    const int64_t *sptr = matrix_rowptr(S);
+    const int64_t nnz = S->nvals;
+    DevBuf<int64_t> flag(G + 1), tidx(G + 1);
+    hipLaunchKernelGGL(k_rtile_heads, dim3((unsigned)ceil_div(G, 256)), dim3(256), 0, ctx().stream, sptr, G, std::max<int64_t>(256, ctx().rtile_entries),
+                       rows_cap / 64, flag.p);
+    GRB_HIP(hipMemsetAsync(flag.p + G, 0, sizeof(int64_t), ctx().stream));
+    prim_exclusive_sum_i64(flag.p, tidx.p, G + 1);
+    int64_t n_tiles = 0;
+    d2h(&n_tiles, tidx.p + G, sizeof(int64_t));
+    if (n_tiles <= 0 || n_tiles > (1 << 24)) return;
+    DevBuf<int32_t> g0(n_tiles);
+    DevBuf<int64_t> e0(n_tiles), units(n_tiles + 1);
+    hipLaunchKernelGGL(k_rtile_starts, dim3((unsigned)ceil_div(G, 256)), dim3(256), 0, ctx().stream, sptr, (const int64_t *)flag.p, (const int64_t *)tidx.p, G, g0.p, e0.p);
+    hipLaunchKernelGGL(k_rtile_units, dim3((unsigned)ceil_div(n_tiles + 1, 256)), dim3(256), 0, ctx().stream, (const int64_t *)e0.p, n_tiles, nnz, units.p);
+    prim_exclusive_sum_i64(units.p, units.p, n_tiles + 1);
+    int64_t total_units = 0;
+    d2h(&total_units, units.p + n_tiles, sizeof(int64_t));
+    if (total_units <= 0 || total_units >= 0x0ffffff0ll) return;  // (unit numbers are 28-bit offsets of the kernel's buffer loads)
+    RTile *tiles = (RTile *)dev_alloc(sizeof(RTile) * (size_t)n_tiles);
+    A->d_rt_tiles = tiles;
+    hipLaunchKernelGGL(k_rtile_table, dim3((unsigned)ceil_div(n_tiles, 256)), dim3(256), 0, ctx().stream, (const int32_t *)g0.p, (const int64_t *)units.p, n_tiles, G, tiles);
+    const size_t ents = (size_t)total_units * RT_EPL;
+    const bool dict = A->vdict_n > 0 && vs == 4;
+    const size_t vb = dict ? 1 : vs;
+    A->d_rt_col = (int32_t *)dev_alloc(sizeof(int32_t) * ents);
+    A->d_rt_tag = (uint16_t *)dev_alloc(sizeof(uint16_t) * ents);
+    A->d_rt_val = dev_alloc(vb * ents);
+    A->d_rt_counter = (unsigned int *)dev_alloc_zero(64);
+    GRB_HIP(hipMemsetAsync(A->d_rt_col, 0xff, sizeof(int32_t) * ents, ctx().stream));
+    GRB_HIP(hipMemsetAsync(A->d_rt_val, 0, vb * ents, ctx().stream));
+    hipLaunchKernelGGL(k_rtile_pad_tags, dim3((unsigned)ceil_div((int64_t)ents, 256)), dim3(256), 0, ctx().stream, A->d_rt_tag, (int64_t)ents, (uint16_t)rows_cap);
+    {
+        DevBuf<uint64_t> key(nnz), key2(nnz);
+        DevBuf<uint32_t> pay(nnz), pay2(nnz);
+        DevBuf<uint16_t> rtag(nnz);
+        hipLaunchKernelGGL(k_rtile_keys, dim3((unsigned)ceil_div(rows_end, 256)), dim3(256), 0, ctx().stream, sptr, (const int32_t *)S->d_col, rows_end,
+                           (const int64_t *)flag.p, (const int64_t *)tidx.p, (const int32_t *)g0.p, key.p, pay.p, rtag.p);
+        int tbits = 1;
+        while ((1ll << tbits) < n_tiles) tbits++;
+        prim_sort_pairs_u64_u32(key.p, key2.p, pay.p, pay2.p, nnz, 32 + tbits);
+        GRB_DISPATCH_TYPE(S->type->code, T, {
+            if constexpr (sizeof(T) == 4 || sizeof(T) == 8) {
+                hipLaunchKernelGGL((k_rtile_place<T>), dim3((unsigned)ceil_div(nnz, 256)), dim3(256), 0, ctx().stream, (const uint64_t *)key2.p, (const uint32_t *)pay2.p, nnz,
+                                   (const int64_t *)e0.p, (const RTile *)tiles, (const uint16_t *)rtag.p, (const T *)S->d_val, A->d_rt_col, A->d_rt_tag, (T *)A->d_rt_val,
+                                   dict ? (const unsigned long long *)A->d_vd_table : (const unsigned long long *)nullptr,
+                                   dict ? (const unsigned char *)A->d_vd_codes : (const unsigned char *)nullptr);
+            }
+        })
+        sync_stream();  // (the temporaries are released at the end of this scope)
+    }
+    // hand-out order: heaviest tiles first
+    std::vector<RTile> h_tiles((size_t)n_tiles);
+    d2h(h_tiles.data(), tiles, sizeof(RTile) * (size_t)n_tiles);
+    std::vector<int32_t> order((size_t)n_tiles);
+    for (int64_t t = 0; t < n_tiles; t++) order[(size_t)t] = (int32_t)t;
+    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return h_tiles[(size_t)x].n_units > h_tiles[(size_t)y].n_units; });
+    A->d_rt_order = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)n_tiles);
+    h2d(A->d_rt_order, order.data(), sizeof(int32_t) * (size_t)n_tiles);
+    sync_stream();
+    A->rt_units = total_units;
+    A->rt_ntiles = (int)n_tiles;
+    A->rt_rows4 = rows4;
+    A->rt_state = 1;
+}
+
 template <typename T, int MON, int MUL, int IPT>
 static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
 {
@@ -954,7 +1040,7 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
         hipLaunchKernelGGL((k_long_init<W>), dim3((unsigned)ceil_div(a.n_long, 256)), dim3(256), 0, ctx().stream, tl_val.p, tl_has.p,
                            a.n_long, monoid_identity<T, W>(a.monoid), a.long_rows, a.m_bits, a.has_mask, a.m_comp, long_act.p,
                            ((by_class || by_strip) && a.u_full) ? 1 : 0, (by_strip && acc_is_ordered<W>(a.monoid)) ? 1 : 0,
-                           (hot_fast && a.has_mask) ? long_act8.p : nullptr);
+                           (hot_fast && a.has_mask) ? long_act8.p : nullptr, A->rt_state == 1 ? A->d_rt_counter : nullptr);
         a.tl_ord = (by_strip && acc_is_ordered<W>(a.monoid)) ? 1 : 0;
         a.long_has_known = ((by_class || by_strip) && a.u_full) ? 1 : 0;
         a.tl_val = tl_val.p;
@@ -1117,6 +1203,41 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
             // an ordered BOOL matrix, a specialised semiring, the operand as presence / value pairs: two persistent workgroups per CU with the
             // pairs of the 276 Ki hottest columns in LDS (k_mxv_rows_tag<..., HEAD>; measured: 266 -> 238 us on the level step of scale 24.
             // For 4-byte values the head holds 17 Ki columns, a third of the references, and the kernel is 13 % SLOWER than without)
+            // the sorted row tiles of an ordered matrix (round 5, grb_mxv_rtile.inc): a specialised semiring over a full operand (or an image
+            // with the absorbing value under its absent entries) whose values are read, values of the matrix read, output in place
+            if constexpr (MON >= 0 && !std::is_same<T, bool>::value && (sizeof(T) == 4 || sizeof(T) == 8)) {
+                if (ctx().rows_tile && A->rt_state == 1 && A->hot_identity && !b.fresh && b.u_full && b.need_uval && b.need_aval && !b.a_iso &&
+                    b.tg_groups > 0 && b.tg_groups == ceil_div(std::min<int64_t>(b.m, std::max<int64_t>(A->ord_live_rows, 1)), 64)) {
+                    b.rt_col = A->d_rt_col;
+                    b.rt_tag = A->d_rt_tag;
+                    b.rt_val = A->d_rt_val;
+                    b.rt_tiles = (const RTile *)A->d_rt_tiles;
+                    b.rt_order = A->d_rt_order;
+                    b.rt_counter = A->d_rt_counter;
+                    b.rt_units = A->rt_units;
+                    b.rt_ntiles = A->rt_ntiles;
+                    const bool dict = b.vdict != nullptr && sizeof(T) == 4;
+                    const bool tall = A->rt_rows4 == 16384;
+                    const int64_t G = std::min<int64_t>(A->rt_ntiles, (int64_t)ctx().num_cus * (tall ? 2 : 4));
+                    bool launched = false;
+                    if constexpr (sizeof(T) == 4) {
+                        if (dict) {
+                            if (tall) hipLaunchKernelGGL((k_mxv_rtile<T, MON, MUL, 16384, true>), dim3((unsigned)G), dim3(RT_BLOCK), 0, ctx().stream, b);
+                            else hipLaunchKernelGGL((k_mxv_rtile<T, MON, MUL, 8192, true>), dim3((unsigned)G), dim3(RT_BLOCK), 0, ctx().stream, b);
+                            launched = true;
+                        }
+                    }
+                    if (!launched) {
+                        if (tall) hipLaunchKernelGGL((k_mxv_rtile<T, MON, MUL, 16384, false>), dim3((unsigned)G), dim3(RT_BLOCK), 0, ctx().stream, b);
+                        else hipLaunchKernelGGL((k_mxv_rtile<T, MON, MUL, 8192, false>), dim3((unsigned)G), dim3(RT_BLOCK), 0, ctx().stream, b);
+                    }
+                    GRB_HIP(hipGetLastError());
+                    ctx().stats.kernel_launches += 1;
+                    ctx().stats.fused_epilogue = 3;  // (bookkeeping: 3 = fused, by the sorted row tiles)
+                    ctx().stats.tiles = A->rt_ntiles;
+                    return;
+                }
+            }
             bool head = false;
             if constexpr (MON >= 0 && std::is_same<T, bool>::value) {
                 head = ctx().rows_head && A->hot_identity && b.tg_stride > 0 && b.u_pv != nullptr && groups >= ctx().rows_head_min_groups;
@@ -1508,7 +1629,7 @@ static void mxv_core(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_Binar
             w->d_val = new_val;
             w->d_bits = new_bits;
         }
-        if (ctx().stats.fused_epilogue != 2) ctx().stats.fused_epilogue = 1;
+        if (ctx().stats.fused_epilogue < 2) ctx().stats.fused_epilogue = 1;  // (2 / 3: which fused kernel took the short rows)
     } else {
         // product into a temporary of the semiring type, then the general write rule with a typecast
         GB_Vector_opaque *t = vector_new(type_of_code(st), w->n);
@@ -1933,6 +2054,7 @@ extern "C" GrB_Info GrX_Matrix_cache_bytes(const GrB_Matrix A, uint64_t *bytes)
         const GB_Matrix_opaque *S = A->short_part;
         b += 8ull * (A->nrows + 1) + (A->short_tagged_only ? 0 : 4ull * (uint64_t)S->nvals + (S->iso ? vs : vs * (uint64_t)S->nvals));
         b += bits_words64(A->nrows) * 8 + 4ull * (uint64_t)A->n_long + 4ull * bits_words64(A->nrows) + 16ull * (uint64_t)A->n_chunks;
+        if (A->rt_state == 1) b += (uint64_t)A->rt_units * RT_EPL * (6 + (A->vdict_n > 0 && vs == 4 ? 1 : vs)) + 36ull * (uint64_t)A->rt_ntiles;
         if (A->tg_state == 1) b += (uint64_t)A->tg_units * TAG_EPL * (5 + (A->d_tg_val ? (A->vdict_n > 0 ? 1 : vs) : 0)) + 12ull * ((A->nrows + 63) / 64);
         if (A->split_kind == 4 && (A->strip_nseg > 0 || A->ct_units > 0)) {
             const uint64_t hot_lanes = (uint64_t)A->strip_cb[A->strip_ncls + A->hub_ncls] * 64;

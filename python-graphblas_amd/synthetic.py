@@ -75,6 +75,16 @@ def edge_weights(col, seed, dtype=None, device=None):
     return w.to(dtype or torch.float32)
 
 
+def edge_weights_real(col, seed, dtype=None):
+    """Real-valued weights U[0,1) (FP32): more distinct values than any dictionary holds; min_plus stays bit-exact against a reference
+    that forms the same single-rounding sums a + x and takes their minimum."""
+    import torch
+
+    gen = torch.Generator(device=col.device)
+    gen.manual_seed(9000 + seed)
+    return torch.rand(col.numel(), generator=gen, device=col.device, dtype=dtype or torch.float32)
+
+
 def uniform_coo(nrows, ncols, density, seed, np_dtype=np.float64):
     """configs[0]: each entry present with probability ``density``; values U[0,1) (numpy, host)."""
     rng = np.random.default_rng(seed)

@@ -19,7 +19,8 @@ from tests.test_random_parity import rand_vals, rand_vec, same_vec
 ORDER_OPTS = ((b"order_min_nnz", 1), (b"lean_min_nnz", 1), (b"split_min_nnz", 1), (b"split_min_len", 8), (b"push_mode", 0), (b"hot_min_cols", 8),
               (b"lazy_layout", 0), (b"vec_pad_min_bytes", 0), (b"rows_head_min_groups", 1))
 RESTORE = ((b"order_min_nnz", 48 << 20), (b"lean_min_nnz", 48 << 20), (b"split_min_nnz", 1 << 22), (b"split_min_len", 0), (b"push_mode", 1),
-           (b"hot_min_cols", 1 << 20), (b"hot_k", 0), (b"lazy_layout", 1), (b"vec_pad_min_bytes", 1 << 20), (b"long_classes", 16), (b"order_mode", 1), (b"hub_min_len", 1024), (b"rows_head_min_groups", 16384), (b"rows_head", 1))
+           (b"hot_min_cols", 1 << 20), (b"hot_k", 0), (b"lazy_layout", 1), (b"vec_pad_min_bytes", 1 << 20), (b"long_classes", 16), (b"order_mode", 1), (b"hub_min_len", 1024), (b"rows_head_min_groups", 16384), (b"rows_head", 1),
+           (b"rows_tile", 1), (b"rtile_rows", 8192), (b"rtile_entries", 32768))
 
 
 @pytest.fixture(params=DEVICES)
@@ -82,7 +83,7 @@ def test_ordered_product_matches_the_oracle(gb, seed):
         by_rowlen = sr in ("any_pair",) and len(ui) == n
         assert by_rowlen or (st["ordered"] == 1 and st["long_kernel"] == (1 if tname == "BOOL" else 4) and st["reorders"] >= 1), st
         if tname != "BOOL" or seed == 13:  # (the LDS head of the short-row kernel serves BOOL operands given as presence / value pairs)
-            assert by_rowlen or st["fused_epilogue"] == 1, st
+            assert by_rowlen or st["fused_epilogue"] in (1, 3), st  # (3: the short rows ran as sorted row tiles -- full operand, specialised semiring)
         same_vec(w, exp)  # (to_coo brings w back to the natural order)
         # the same call again: the operands that stayed in the library are still in the matrix's order
         w2 = gb.Vector.from_coo(wi, wv, dtype=tname, size=n)
@@ -460,5 +461,60 @@ def test_view_held_across_an_ordered_product_stays_natural(gb):
         assert np.asarray(tv.cpu()).tolist() == uv2.tolist()
         A.mxv(u, gb.semiring.min_plus).new()
         assert device.last_stats()["ordered"] == 1
+    finally:
+        set_opts(RESTORE)
+
+
+@pytest.mark.parametrize("seed", range(18))
+def test_sorted_row_tiles_match_the_oracle(gb, seed):
+    """Round 5 (grb_mxv_rtile.inc): the short rows of an ordered matrix as sorted row tiles -- tiles cut by rows and by entries (small
+    limits: many tiles, dense and thin ones, tiles of one group), entries sorted by column code in lane-transposed blocks, dictionary-coded
+    and full values, 4- and 8-byte types, every mask / accumulator / replace combination the kernel takes, long rows inside the tiles,
+    a sparse operand run as a full one (absorbing fill), and the calls it must NOT take (sparse operand of plus_times, another semiring),
+    which fall back to the tagged row groups.  Against the oracle, element for element."""
+    from graphblas_amd import device
+
+    rng = np.random.default_rng(7700 + seed)
+    tname = ["FP32", "INT64", "FP64", "FP32", "INT32", "FP32"][seed % 6]
+    sr = ["min_plus", "plus_times", "min_plus", "plus_times", "min_plus", "max_plus"][seed % 6]
+    n = int(rng.integers(2500, 6000))
+    rows, cols, vals = skewed_square(rng, n, tname)
+    if seed % 4 == 1:  # (more than 256 distinct values: no dictionary)
+        vals = (rng.integers(1, 4000, rows.size)).astype(vals.dtype)
+    full = seed % 5 != 4
+    ui, uv = rand_vec(rng, n, 1.0 if full else 0.4, tname)
+    if tname in ("FP32", "FP64"):
+        vals, uv = np.abs(vals) + 1, np.abs(uv)
+    wi, wv = rand_vec(rng, n, [1.0, 0.6, 0.0][seed % 3], tname)
+    mi, mv = rand_vec(rng, n, 0.5, "BOOL")
+    accum = [None, "min", "plus"][(seed // 2) % 3]
+    use_mask, comp, repl, struct = seed % 7 != 6, bool(seed & 1), bool(seed & 2) and seed % 7 != 6, bool(seed & 4)
+    oa = O.OMat.from_coo(rows, cols, vals, n, n, tname)
+    ou, ow, om = O.OVec(n, ui, uv, tname), O.OVec(n, wi, wv, tname), O.OVec(n, mi, mv, "BOOL")
+    exp = O.mxv(oa, ou, sr, w=ow, mask=om if use_mask else None, mask_comp=comp and use_mask, mask_struct=struct, accum=accum, replace=repl)
+    try:
+        set_opts(ORDER_OPTS + ((b"rtile_rows", [8192, 16384][seed % 2]), (b"rtile_entries", [256, 700, 5000][seed % 3]), (b"hub_min_len", [100, 0][seed % 2])))
+        A = gb.Matrix.from_coo(rows, cols, vals, dtype=tname, nrows=n, ncols=n)
+        u = gb.Vector.from_coo(ui, uv, dtype=tname, size=n)
+        w = gb.Vector.from_coo(wi, wv, dtype=tname, size=n)
+        mk = gb.Vector.from_coo(mi, mv, dtype="BOOL", size=n)
+        m_arg = (mk.S if struct else mk.V)
+        kw = dict(accum=accum, replace=repl) if use_mask else dict(accum=accum)
+        target = w(~m_arg if comp else m_arg, **kw) if use_mask else w(**kw)
+        target << A.mxv(u, getattr(gb.semiring, sr))
+        st = device.last_stats()
+        specialised = (tname, sr) in (("FP32", "min_plus"), ("FP64", "min_plus"), ("INT64", "min_plus"), ("FP32", "plus_times"), ("FP64", "plus_times"), ("INT64", "plus_times"))
+        takes = specialised and (full or (st["fill_absent"] == 1))
+        assert st["ordered"] == 1 and st["fused_epilogue"] == (3 if takes else 1), (st, takes)
+        same_vec(w, exp)
+        # once more on the converted operands (nothing is reordered any more), and without the tiles: the same result
+        w2 = gb.Vector.from_coo(wi, wv, dtype=tname, size=n)
+        (w2(~m_arg if comp else m_arg, **kw) if use_mask else w2(**kw)) << A.mxv(u, getattr(gb.semiring, sr))
+        same_vec(w2, exp)
+        set_opts(((b"rows_tile", 0),))
+        w3 = gb.Vector.from_coo(wi, wv, dtype=tname, size=n)
+        (w3(~m_arg if comp else m_arg, **kw) if use_mask else w3(**kw)) << A.mxv(u, getattr(gb.semiring, sr))
+        assert device.last_stats()["fused_epilogue"] == 1
+        same_vec(w3, exp)
     finally:
         set_opts(RESTORE)
