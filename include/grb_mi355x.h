@@ -375,6 +375,8 @@ GrB_Info GrX_Matrix_cache_bytes(const GrB_Matrix A, uint64_t *bytes);
  *                   0 = default: 1 up to 64 windows per row, 2 beyond -- measured: wider groups lose more occupancy to their bitmaps
  *                   than they save units); a group that holds more entries than the densest compact class is walked window by
  *                   window as before
+ *   "mxm_xcd_map"   (round 5) 1 (default): the SpGEMM unit kernels give every XCD a contiguous eighth of the unit order, so that the windows
+ *                   of a row -- which read the same rows of B -- share one L2; 0: workgroups take the units round-robin
  *   "mxm_checksum_pass"  GrX_mxm_streamed: 0 (default) the checksum of the product is folded into the numeric kernels' stores, 1 a pass
  *                   of its own re-reads every batch's values (round 4)
  *   "mxm_sym_windows"  consecutive column windows (groups of windows) of a row one symbolic unit walks (rows of up to 128 entries of A; default 8,

@@ -78,6 +78,7 @@ struct Context {
     int64_t mxm_masked_units_min_flops = 64ll << 20;  // mask-driven products below this many multiplies keep the row kernels
     int64_t mxm_bitmap_pool_cap = INT32_MAX;  // ... and at most this many bitmaps (tests: a pool that runs out)
     int64_t mxm_window_groups = 0;  // SpGEMM units walk groups of this many 16 Ki-column windows (1 / 2 / 4 / 8); 0 = from the width of B: at most 64 groups per row
+    int mxm_xcd_map = 1;  // SpGEMM unit kernels: 1 = every XCD takes a contiguous eighth of the unit order (the windows of a row share one L2), 0 = round-robin
     int mxm_checksum_pass = 0;  // GrX_mxm_streamed: 0 = the checksum is folded into the numeric kernels' stores, 1 = a pass of its own over the product (round 4)
     int64_t mxm_sym_windows = 8;  // consecutive windows of a row a symbolic unit walks (rows of up to 128 entries of A; 1: one window per unit)
     int mxm_bitmap_min_cnt = 512;  // units with more entries than this keep their bitmap

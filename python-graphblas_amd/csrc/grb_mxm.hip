@@ -57,6 +57,10 @@ struct MxmArgs {
     // of a scale-20 matrix.  The tables (woff, wcnt, wbm, cm_woff) stay per 16 Ki-column window: a group whose row holds more than
     // the densest compact class takes (mxm_unit_dense entries) is split into its windows again, each a unit as before.
     int win_f;
+    // XCD-aware unit order (round 5): workgroups are dispatched round-robin over the 8 XCDs, each with an L2 of its own; the units of a
+    // row -- its windows -- follow each other in the unit order and read the SAME rows of B.  With xcd_map every XCD takes a contiguous
+    // eighth of the order (workgroup b works on position (b mod 8) grid / 8 + b / 8), so a row of B is fetched into one L2, not eight.
+    int xcd_map;
     // streamed product (GrX_mxm_streamed): the wrapping sum of the values the numeric kernels store, folded into the store --
     // 1024 counters a 128-byte line apart (one address would serialise millions of atomics); nullptr: not wanted
     unsigned long long *csum;
@@ -130,6 +134,14 @@ __device__ __forceinline__ void checksum_commit(const MxmArgs &a, unsigned long 
     if (!a.csum) return;  // (uniform)
     for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);
     if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&a.csum[(size_t)(blockIdx.x & (MM_CSUM_SLOTS - 1)) * 16], mine);
+}
+
+// (grids of the unit kernels are multiples of 8 when xcd_map is set: every position is covered)
+__device__ __forceinline__ int64_t xcd_block(const MxmArgs &a)
+{
+    if (!a.xcd_map) return (int64_t)blockIdx.x;
+    const int64_t per = ((int64_t)gridDim.x + 7) >> 3;
+    return (int64_t)(blockIdx.x & 7u) * per + (int64_t)(blockIdx.x >> 3);
 }
 
 __device__ __forceinline__ unsigned hash_col(int c, int table_mask) { return ((unsigned)c * 2654435761u) & (unsigned)table_mask; }
@@ -724,7 +736,7 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const 
     const int uib = WPU == 1 ? wave : 0, sub = WPU == 1 ? 0 : wave;  // unit inside the workgroup, wavefront inside the unit
     const int nwin = a.n_win;                   // (windows: the tables' unit)
     const int ngroups_w = (nwin + F - 1) / F;   // (groups of F windows: the units' unit)
-    const int64_t unit = (int64_t)blockIdx.x * UPB + uib;
+    const int64_t unit = xcd_block(a) * UPB + uib;
     int64_t ridx = 0, row, out = 0, pbeg, pend;
     int w, w_end = 0, bslot = -1, mcnt = 0;
     if constexpr (NUMERIC) {  // a unit of the class list
@@ -1113,15 +1125,17 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const 
 constexpr int MU_DENSE = 4096;
 
 template <typename T>
-__global__ __launch_bounds__(MM_WIN_BLOCK) void k_spgemm_unit_dense(const MxmArgs a, const UnitRec *units)
+__global__ __launch_bounds__(MM_WIN_BLOCK) void k_spgemm_unit_dense(const MxmArgs a, const UnitRec *units, int64_t nunits)
 {
+    const int64_t upos = xcd_block(a);
+    if (upos >= nunits) return;  // (uniform over the workgroup)
     using W = typename Widen<T>::type;
     __shared__ W s_acc[MM_WIN];
     __shared__ unsigned long long s_bits[MM_WIN / 64];
     __shared__ int s_wave[MM_WIN_BLOCK / 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nwin = a.n_win;
-    const UnitRec r = units[blockIdx.x];
+    const UnitRec r = units[upos];
     const int w = r.w;
     const int bslot = r.aux;  // (the symbolic pass kept the bitmap: no atomics on it here)
     const int monoid = a.monoid, mult = a.mult;
@@ -1806,16 +1820,17 @@ static void launch_unit_classes(MxmArgs &a, const uint32_t *rows, int64_t nrows,
             launch(lists.p + start[c] + u0, std::min<int64_t>(PER, (int64_t)cnt[c] - u0));
     };
     // the three compact classes of units of F windows (F = 1: single windows)
+    auto grid8 = [&](int64_t g) { return (unsigned)(a.xcd_map ? ceil_div(g, (int64_t)8) * 8 : g); };  // (xcd_block covers a multiple of 8)
     auto compact_classes = [&](int c0, auto f_c) {
         constexpr int F = decltype(f_c)::value;
         per_class(c0, [&](const UnitRec *u, int64_t nu) {
-            hipLaunchKernelGGL((k_spgemm_unit<T, MODE, 1, MU_SMALL, F>), dim3((unsigned)ceil_div(nu, 4)), dim3(256), 0, ctx().stream, a, rows, 0, 0, u, nu);
+            hipLaunchKernelGGL((k_spgemm_unit<T, MODE, 1, MU_SMALL, F>), dim3(grid8(ceil_div(nu, 4))), dim3(256), 0, ctx().stream, a, rows, 0, 0, u, nu);
         });
         per_class(c0 + 1, [&](const UnitRec *u, int64_t nu) {
-            hipLaunchKernelGGL((k_spgemm_unit<T, MODE, 4, 1024, F>), dim3((unsigned)nu), dim3(256), 0, ctx().stream, a, rows, 0, 0, u, nu);
+            hipLaunchKernelGGL((k_spgemm_unit<T, MODE, 4, 1024, F>), dim3(grid8(nu)), dim3(256), 0, ctx().stream, a, rows, 0, 0, u, nu);
         });
         per_class(c0 + 2, [&](const UnitRec *u, int64_t nu) {
-            hipLaunchKernelGGL((k_spgemm_unit<T, MODE, GRB_MU_M2_WPU, 4096, F>), dim3((unsigned)nu), dim3(64 * GRB_MU_M2_WPU), 0, ctx().stream, a, rows, 0, 0, u, nu);
+            hipLaunchKernelGGL((k_spgemm_unit<T, MODE, GRB_MU_M2_WPU, 4096, F>), dim3(grid8(nu)), dim3(64 * GRB_MU_M2_WPU), 0, ctx().stream, a, rows, 0, 0, u, nu);
         });
     };
     if constexpr (MODE == MU_NUMERIC) {
@@ -1827,7 +1842,7 @@ static void launch_unit_classes(MxmArgs &a, const uint32_t *rows, int64_t nrows,
     compact_classes(MU_CLS_WINDOW, std::integral_constant<int, 1>{});
     if constexpr (MODE == MU_NUMERIC)
         per_class(MU_CLS_WINDOW + 3, [&](const UnitRec *u, int64_t nu) {
-            hipLaunchKernelGGL((k_spgemm_unit_dense<T>), dim3((unsigned)nu), dim3(MM_WIN_BLOCK), 0, ctx().stream, a, u);
+            hipLaunchKernelGGL((k_spgemm_unit_dense<T>), dim3(grid8(nu)), dim3(MM_WIN_BLOCK), 0, ctx().stream, a, u, nu);
         });
     ctx().stats.kernel_launches += 6;
     sync_stream();  // (the lists are freed at the end of this scope)
@@ -1874,7 +1889,7 @@ static void run_bins(MxmArgs &a, const RowBins &rb)
                 const int64_t rows_per_launch = std::max<int64_t>(1, (1ll << 22) / ngrp);
                 for (int64_t r0 = 0; r0 < nrows_total; r0 += rows_per_launch) {
                     const int64_t nr = std::min(rows_per_launch, nrows_total - r0);
-                    const dim3 grid((unsigned)ceil_div(nr * ngrp, 4));
+                    const dim3 grid((unsigned)(as.xcd_map ? ceil_div(ceil_div(nr * ngrp, 4), (int64_t)8) * 8 : ceil_div(nr * ngrp, 4)));
                     const UnitRec *none = nullptr;
                     if (FG == 2) hipLaunchKernelGGL((k_spgemm_unit<T, MU_SYMBOLIC, 1, 1, 2>), grid, dim3(256), 0, ctx().stream, as, rb.ptr(4), r0, nr, none, 0);
                     else if (FG == 4) hipLaunchKernelGGL((k_spgemm_unit<T, MU_SYMBOLIC, 1, 1, 4>), grid, dim3(256), 0, ctx().stream, as, rb.ptr(4), r0, nr, none, 0);
@@ -1961,6 +1976,7 @@ static GB_Matrix_opaque *spgemm(GB_Matrix_opaque *A, const void *Ax, GB_Matrix_o
         a.need_a = !(mult == OP_PAIR || mult == OP_SECOND);
         a.need_b = !(mult == OP_PAIR || mult == OP_FIRST || mult == OP_ANY);
         a.csum = csum_slots;  // (streamed product: the numeric kernels add the values they store)
+        a.xcd_map = ctx().mxm_xcd_map;
 #ifdef GRB_ABLATE
         a.abl = (ctx().debug_flags >> 20) & 0x7FF;
 #endif
@@ -2133,6 +2149,7 @@ static GB_Matrix_opaque *spgemm_masked(GB_Matrix_opaque *A, const void *Ax, GB_M
         a.need_b = !(mult == OP_PAIR || mult == OP_FIRST || mult == OP_ANY);
         a.Mp = matrix_rowptr(Mask);
         a.Mj = Mask->d_col;
+        a.xcd_map = ctx().mxm_xcd_map;
         DevBuf<T> cap_val(nnzM);
         DevBuf<unsigned char> cap_hit(nnzM, true);
         a.cap_val = cap_val.p;

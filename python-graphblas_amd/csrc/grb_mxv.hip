@@ -1207,7 +1207,8 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
             // with the absorbing value under its absent entries) whose values are read, values of the matrix read, output in place
             if constexpr (MON >= 0 && !std::is_same<T, bool>::value && (sizeof(T) == 4 || sizeof(T) == 8)) {
                 if (ctx().rows_tile && A->rt_state == 1 && A->hot_identity && !b.fresh && b.u_full && b.need_uval && b.need_aval && !b.a_iso &&
-                    b.tg_groups > 0 && b.tg_groups == ceil_div(std::min<int64_t>(b.m, std::max<int64_t>(A->ord_live_rows, 1)), 64)) {
+                    b.tg_groups > 0 && b.tg_groups == ceil_div(std::min<int64_t>(b.m, std::max<int64_t>(A->ord_live_rows, 1)), 64) &&
+                    b.m * (int64_t)sizeof(T) < 0xfffffff0ll) {  // (the old values of a tile's rows are read through a buffer descriptor)
                     b.rt_col = A->d_rt_col;
                     b.rt_tag = A->d_rt_tag;
                     b.rt_val = A->d_rt_val;
