@@ -320,6 +320,7 @@ struct GB_Matrix_opaque {
     // values are, and half the bytes of the stream the hot strips are bound by
     void *d_vdict = nullptr;           // 256 values of the matrix type (unused codes: 0)
     int vdict_n = 0;                   // distinct values found (0: no dictionary)
+    double vals_absmax = 0.0;          // ... and the largest magnitude among them (from the dictionary)
     bool vals_finite = false;          // every stored value is finite (known from the dictionary's scan): lets a sparse operand of a min_plus /
                                        // max_plus product be run as a full one with +-inf under its absent entries (mxv_core)
     unsigned long long *d_vd_table = nullptr;  // the hash table value -> slot the codes were assigned from (build time: placement kernels)

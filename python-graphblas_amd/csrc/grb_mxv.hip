@@ -23,6 +23,7 @@
 //     against the old w, writes values coalesced and the presence word with one __ballot.
 //   * Few entries in u: push direction (SpMSpV, k_push) over the rows selected by u.
 #include <algorithm>
+#include <cstring>
 #include <vector>
 
 #include "grb_internal.hpp"
@@ -194,6 +195,13 @@ static void ensure_vdict(GB_Matrix_opaque *A, bool wanted)
     h2d(A->d_vd_codes, h_codes.data(), VDICT_SLOTS);
     A->vdict_n = next;
     A->vals_finite = true;  // (every distinct value was looked at above)
+    A->vals_absmax = 0.0;
+    if (A->type->code == TC_FP32)
+        for (int i = 0; i < next; i++) {
+            float f;
+            memcpy(&f, &dict[(size_t)i], 4);
+            A->vals_absmax = std::max(A->vals_absmax, (double)(f < 0 ? -f : f));
+        }
 }
 
 // Analyse (once) whether the rows split usefully into long and short ones and build the two parts.
@@ -1555,17 +1563,19 @@ static void mxv_core(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_Binar
     // presence gathers and take the fast hot-strip path: the sweeps of an SSSP loop, whose distance vector never becomes full, went from
     // 1.53 to ~0.8 ms (section 4.1.10)
     DevBuf<char> fill_img(0);
-    if (S->hot_identity && !a.u_full && a.need_uval && ctx().fill_absent && S->vals_finite && !S->iso && (st == TC_FP32 || st == TC_FP64) &&
+    // (vals_finite comes with the dictionary, i.e. with FP32 today; the bound on the operand keeps every product finite)
+    const double fill_limit = (st == TC_FP32 ? 3.4028234663852886e38 : 1.7976931348623157e308) - S->vals_absmax;
+    if (S->hot_identity && !a.u_full && a.need_uval && ctx().fill_absent && S->vals_finite && fill_limit > 0 && !S->iso && (st == TC_FP32 || st == TC_FP64) &&
         mult == OP_PLUS && (monoid == OP_MIN || monoid == OP_MAX) && S->split_state == 1 && S->split_kind == 4) {
         dev_free(fill_img.p);
         fill_img.p = (char *)dev_alloc(type_size(st) * (size_t)u->n);
         DevBuf<int> flag(1, true);
         if (st == TC_FP32)
             hipLaunchKernelGGL((k_fill_image<float>), dim3((unsigned)ceil_div((int64_t)u->n, 256)), dim3(256), 0, ctx().stream, (const float *)a.u_val,
-                               (const uint64_t *)a.u_bits, (int64_t)u->n, monoid == OP_MIN ? __builtin_huge_valf() : -__builtin_huge_valf(), (float *)fill_img.p, flag.p);
+                               (const uint64_t *)a.u_bits, (int64_t)u->n, monoid == OP_MIN ? __builtin_huge_valf() : -__builtin_huge_valf(), (float *)fill_img.p, flag.p, (float)(fill_limit * (1.0 - 1e-6)));
         else
             hipLaunchKernelGGL((k_fill_image<double>), dim3((unsigned)ceil_div((int64_t)u->n, 256)), dim3(256), 0, ctx().stream, (const double *)a.u_val,
-                               (const uint64_t *)a.u_bits, (int64_t)u->n, monoid == OP_MIN ? __builtin_huge_val() : -__builtin_huge_val(), (double *)fill_img.p, flag.p);
+                               (const uint64_t *)a.u_bits, (int64_t)u->n, monoid == OP_MIN ? __builtin_huge_val() : -__builtin_huge_val(), (double *)fill_img.p, flag.p, fill_limit * (1.0 - 1e-12));
         int h_flag = 0;
         d2h(&h_flag, flag.p, sizeof(h_flag));
         ctx().stats.kernel_launches += 1;

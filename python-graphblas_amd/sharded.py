@@ -71,7 +71,13 @@ def flops_prefix(indptr_a, col_a, rowlen_b):
 
 
 def allgather_into(u_full, w_local, *, device="cuda", values=True, presence=True):
-    """u_full[lo_r:hi_r] = w_local of rank r, for every r -- equal blocks, one collective per array."""
+    """u_full[lo_r:hi_r] = w_local of rank r, for every r -- equal blocks, one collective per array.
+
+    Side effect, here and in every function of this module that hands a vector's HBM image to a collective (``allgatherv_into``,
+    ``allgather_delta_into``, ``allreduce_monoid``, ``OverlappedMxv``): the vectors are PINNED to natural index order for good
+    (``GrX_Vector_pin_natural``) -- the collective's buffers alias them, and a row-sharded run works on non-square blocks that never take
+    a vertex order anyway.  A caller that goes on to use such a vector with a large square matrix on one GPU and wants its ordered
+    layouts back releases it with ``device.vector_release_views(v)``."""
     import torch.distributed as dist
 
     from . import device as dev
@@ -310,7 +316,20 @@ class OverlappedMxv:
             self.staged = True
             self._exchange(0, self.k & 1 ^ 1)
 
+    def _check_stream(self):
+        """The exchange is ordered behind the products through torch's current stream (see __init__): checked at every step, not only at
+        construction -- a caller may have entered torch.cuda.stream(...) or called GrX_set_stream in between.  One ctypes
+        call and one attribute read."""
+        if self.device == "cpu":
+            return
+        lib_stream = ctypes.c_void_p()
+        _lib.lib.GrX_get_stream(ctypes.byref(lib_stream))
+        if (lib_stream.value or 0) != (self._torch().cuda.current_stream().cuda_stream or 0):
+            raise RuntimeError("OverlappedMxv.step: the library's launch stream is not torch's current stream: the exchange would not be "
+                               "ordered behind the products")
+
     def step(self):
+        self._check_stream()
         src, dst = self.k & 1, (self.k + 1) & 1
         works = []
         for c in range(self.chunks):

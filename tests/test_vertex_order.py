@@ -405,11 +405,18 @@ def test_sparse_operand_run_as_full_with_absorbing_fill(gb, sr):
     bad = float("inf") if sr == "min_plus" else -float("inf")
     uv_inf = uv.copy()
     uv_inf[: max(1, ui.size // 50)] = bad
+    #  finite values whose sum with a matrix value overflows: a product of value +-inf that EXISTS -- the fill would take it for
+    # "no product"; the bound on the operand's magnitude sends such a call down the general path
+    uv_big = uv.copy()
+    uv_big[: max(1, ui.size // 50)] = np.float32(3.4e38 if sr == "min_plus" else -3.4e38)
+    vals = vals.copy()
+    vals[:: 7] = np.float32(1e37 if sr == "min_plus" else -1e37)
+    oa = O.OMat.from_coo(rows, cols, vals, n, n, "FP32")
     try:
         for fill in (1, 0):
             set_opts(ORDER_OPTS + ((b"hot_k", 256), (b"hub_min_len", 200), (b"fill_absent", fill)))
             A = gb.Matrix.from_coo(rows, cols, vals, dtype="FP32", nrows=n, ncols=n)
-            for values in (uv, uv_inf):
+            for values in (uv, uv_inf, uv_big):
                 u = gb.Vector.from_coo(ui, values, dtype="FP32", size=n)
                 ou = O.OVec(n, ui, values, "FP32")
                 same_vec(A.mxv(u, getattr(gb.semiring, sr)).new(), O.mxv(oa, ou, sr))
