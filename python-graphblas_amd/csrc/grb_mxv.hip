@@ -938,13 +938,16 @@ static void ensure_rtile(GB_Matrix_opaque *A)
     A->rt_state = -1;
     GB_Matrix_opaque *S = A->short_part;
     const size_t vs = S->type->size;
-    if (!S->d_col || S->iso || S->nvals == 0 || S->nvals >= 0xf0000000ll || (vs != 4 && vs != 8) || S->type->code == TC_BOOL || A->tg_state != 1) return;
+    // (4- and 8-byte types with their values; BOOL matrices when they are iso -- the adjacency matrices of the BFS step: k_mxv_rtile_bool)
+    const bool is_bool = S->type->code == TC_BOOL;
+    if (!S->d_col || S->nvals == 0 || S->nvals >= 0xf0000000ll || A->tg_state != 1) return;
+    if (is_bool ? !S->iso : (S->iso || (vs != 4 && vs != 8))) return;
     const int64_t m = (int64_t)S->nrows;
     const int64_t live_rows = A->hot_identity ? std::min<int64_t>(m, std::max<int64_t>(A->ord_live_rows, 1)) : m;
     const int64_t G = ceil_div(live_rows, 64);  // (the groups the row kernels cover; the rows behind them are empty)
     const int64_t rows_end = std::min<int64_t>(G * 64, m);
     const int rows4 = ctx().rtile_rows == 16384 ? 16384 : 8192;
-    const int rows_cap = vs > 4 ? rows4 / 2 : rows4;
+    const int rows_cap = (vs > 4 && !is_bool) ? rows4 / 2 : rows4;
     const int64_t *sptr = matrix_rowptr(S);
     const int64_t nnz = S->nvals;
     DevBuf<int64_t> flag(G + 1), tidx(G + 1);
@@ -971,10 +974,10 @@ static void ensure_rtile(GB_Matrix_opaque *A)
     const size_t vb = dict ? 1 : vs;
     A->d_rt_col = (int32_t *)dev_alloc(sizeof(int32_t) * ents);
     A->d_rt_tag = (uint16_t *)dev_alloc(sizeof(uint16_t) * ents);
-    A->d_rt_val = dev_alloc(vb * ents);
+    A->d_rt_val = is_bool ? nullptr : dev_alloc(vb * ents);
     A->d_rt_counter = (unsigned int *)dev_alloc_zero(64);
     GRB_HIP(hipMemsetAsync(A->d_rt_col, 0xff, sizeof(int32_t) * ents, ctx().stream));
-    GRB_HIP(hipMemsetAsync(A->d_rt_val, 0, vb * ents, ctx().stream));
+    if (A->d_rt_val) GRB_HIP(hipMemsetAsync(A->d_rt_val, 0, vb * ents, ctx().stream));
     hipLaunchKernelGGL(k_rtile_pad_tags, dim3((unsigned)ceil_div((int64_t)ents, 256)), dim3(256), 0, ctx().stream, A->d_rt_tag, (int64_t)ents, (uint16_t)rows_cap);
     {
         DevBuf<uint64_t> key(nnz), key2(nnz);
@@ -986,11 +989,11 @@ static void ensure_rtile(GB_Matrix_opaque *A)
         while ((1ll << tbits) < n_tiles) tbits++;
         prim_sort_pairs_u64_u32(key.p, key2.p, pay.p, pay2.p, nnz, 32 + tbits);
         GRB_DISPATCH_TYPE(S->type->code, T, {
-            if constexpr (sizeof(T) == 4 || sizeof(T) == 8) {
+            if constexpr (sizeof(T) == 4 || sizeof(T) == 8 || std::is_same<T, bool>::value) {
                 hipLaunchKernelGGL((k_rtile_place<T>), dim3((unsigned)ceil_div(nnz, 256)), dim3(256), 0, ctx().stream, (const uint64_t *)key2.p, (const uint32_t *)pay2.p, nnz,
                                    (const int64_t *)e0.p, (const RTile *)tiles, (const uint16_t *)rtag.p, (const T *)S->d_val, A->d_rt_col, A->d_rt_tag, (T *)A->d_rt_val,
                                    dict ? (const unsigned long long *)A->d_vd_table : (const unsigned long long *)nullptr,
-                                   dict ? (const unsigned char *)A->d_vd_codes : (const unsigned char *)nullptr);
+                                   dict ? (const unsigned char *)A->d_vd_codes : (const unsigned char *)nullptr, is_bool ? 1 : 0);
             }
         })
         sync_stream();  // (the temporaries are released at the end of this scope)
@@ -1196,7 +1199,10 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
             if (A->hot_identity) {
                 // a matrix in its popularity order: rows sorted by falling weight, the empty ones at the end
                 const int64_t live_groups = std::max<int64_t>(1, ceil_div(A->ord_live_rows, 64));
-                if (live_groups < groups && !b.fresh) {  // (an output written into fresh buffers keeps its tail in the kernel: the values move too)
+                // (an output written into fresh buffers keeps its tail in the kernel: the values move too -- unless nothing of the tail survives
+                //  the call: replace without an accumulator, the level step of a BFS whose frontier is its own output)
+                const bool tail_dies = b.replace && b.accum < 0;
+                if (live_groups < groups && (!b.fresh || tail_dies)) {
                     if (!(b.accum >= 0 && !b.replace)) {
                         const int64_t tail = groups - live_groups;
                         hipLaunchKernelGGL(k_rows_tail, dim3((unsigned)ceil_div(tail, 256)), dim3(256), 0, ctx().stream, b, live_groups);
@@ -1214,7 +1220,7 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
             // the sorted row tiles of an ordered matrix (round 5, grb_mxv_rtile.inc): a specialised semiring over a full operand (or an image
             // with the absorbing value under its absent entries) whose values are read, values of the matrix read, output in place
             if constexpr (MON >= 0 && !std::is_same<T, bool>::value && (sizeof(T) == 4 || sizeof(T) == 8)) {
-                if (ctx().rows_tile && A->rt_state == 1 && A->hot_identity && !b.fresh && b.u_full && b.need_uval && b.need_aval && !b.a_iso &&
+                if (ctx().rows_tile && A->rt_state == 1 && A->hot_identity && b.u_full && b.need_uval && b.need_aval && !b.a_iso &&
                     b.tg_groups > 0 && b.tg_groups == ceil_div(std::min<int64_t>(b.m, std::max<int64_t>(A->ord_live_rows, 1)), 64) &&
                     b.m * (int64_t)sizeof(T) < 0xfffffff0ll) {  // (the old values of a tile's rows are read through a buffer descriptor)
                     b.rt_col = A->d_rt_col;
@@ -1243,6 +1249,28 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
                     GRB_HIP(hipGetLastError());
                     ctx().stats.kernel_launches += 1;
                     ctx().stats.fused_epilogue = 3;  // (bookkeeping: 3 = fused, by the sorted row tiles)
+                    ctx().stats.tiles = A->rt_ntiles;
+                    return;
+                }
+            }
+            // ... and BOOL products over an operand given as presence / value pairs (the BFS level step): k_mxv_rtile_bool
+            if constexpr (std::is_same<T, bool>::value && ((MON == OP_LOR && MUL == OP_LAND) || (MON == OP_ANY && MUL == OP_PAIR))) {
+                if (ctx().rows_tile && A->rt_state == 1 && A->hot_identity && !b.u_full && (b.u_pv != nullptr || !b.need_uval) && (b.a_iso || !b.need_aval) &&
+                    b.tg_groups > 0 && b.tg_groups == ceil_div(std::min<int64_t>(b.m, std::max<int64_t>(A->ord_live_rows, 1)), 64) && b.m < 0xfffffff0ll) {
+                    b.rt_col = A->d_rt_col;
+                    b.rt_tag = A->d_rt_tag;
+                    b.rt_val = nullptr;
+                    b.rt_tiles = (const RTile *)A->d_rt_tiles;
+                    b.rt_order = A->d_rt_order;
+                    b.rt_counter = A->d_rt_counter;
+                    b.rt_units = A->rt_units;
+                    b.rt_ntiles = A->rt_ntiles;
+                    const int64_t G = std::min<int64_t>(A->rt_ntiles, (int64_t)ctx().num_cus * 4);
+                    if (A->rt_rows4 == 16384) hipLaunchKernelGGL((k_mxv_rtile_bool<MON, MUL, 16384>), dim3((unsigned)G), dim3(RT_BLOCK), 0, ctx().stream, b);
+                    else hipLaunchKernelGGL((k_mxv_rtile_bool<MON, MUL, 8192>), dim3((unsigned)G), dim3(RT_BLOCK), 0, ctx().stream, b);
+                    GRB_HIP(hipGetLastError());
+                    ctx().stats.kernel_launches += 1;
+                    ctx().stats.fused_epilogue = 3;
                     ctx().stats.tiles = A->rt_ntiles;
                     return;
                 }
@@ -2065,7 +2093,7 @@ extern "C" GrB_Info GrX_Matrix_cache_bytes(const GrB_Matrix A, uint64_t *bytes)
         const GB_Matrix_opaque *S = A->short_part;
         b += 8ull * (A->nrows + 1) + (A->short_tagged_only ? 0 : 4ull * (uint64_t)S->nvals + (S->iso ? vs : vs * (uint64_t)S->nvals));
         b += bits_words64(A->nrows) * 8 + 4ull * (uint64_t)A->n_long + 4ull * bits_words64(A->nrows) + 16ull * (uint64_t)A->n_chunks;
-        if (A->rt_state == 1) b += (uint64_t)A->rt_units * RT_EPL * (6 + (A->vdict_n > 0 && vs == 4 ? 1 : vs)) + 36ull * (uint64_t)A->rt_ntiles;
+        if (A->rt_state == 1) b += (uint64_t)A->rt_units * RT_EPL * (6 + (A->d_rt_val ? (A->vdict_n > 0 && vs == 4 ? 1 : vs) : 0)) + 36ull * (uint64_t)A->rt_ntiles;
         if (A->tg_state == 1) b += (uint64_t)A->tg_units * TAG_EPL * (5 + (A->d_tg_val ? (A->vdict_n > 0 ? 1 : vs) : 0)) + 12ull * ((A->nrows + 63) / 64);
         if (A->split_kind == 4 && (A->strip_nseg > 0 || A->ct_units > 0)) {
             const uint64_t hot_lanes = (uint64_t)A->strip_cb[A->strip_ncls + A->hub_ncls] * 64;

@@ -322,6 +322,10 @@ class OverlappedMxv:
         call and one attribute read."""
         if self.device == "cpu":
             return
+        import ctypes
+
+        from . import _lib
+
         lib_stream = ctypes.c_void_p()
         _lib.lib.GrX_get_stream(ctypes.byref(lib_stream))
         if (lib_stream.value or 0) != (self._torch().cuda.current_stream().cuda_stream or 0):

@@ -262,7 +262,7 @@ def test_sssp_and_bfs_loops_stay_ordered(gb, seed):
         assert level >= 2, conv
         # (the pulled levels of the BOOL graph: the frontier's presence / value pairs in the LDS head of the short-row kernel -- also
         #  though q is its own output)
-        assert any(m == 1 and fe == 2 for m, _, fe in conv), conv
+        assert any(m == 1 and fe in (2, 3) for m, _, fe in conv), conv  # (2: the LDS head of the row groups; 3: the sorted row tiles, round 5)
     finally:
         set_opts(RESTORE)
 
@@ -522,6 +522,51 @@ def test_sorted_row_tiles_match_the_oracle(gb, seed):
         w3 = gb.Vector.from_coo(wi, wv, dtype=tname, size=n)
         (w3(~m_arg if comp else m_arg, **kw) if use_mask else w3(**kw)) << A.mxv(u, getattr(gb.semiring, sr))
         assert device.last_stats()["fused_epilogue"] == 1
+        same_vec(w3, exp)
+    finally:
+        set_opts(RESTORE)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_sorted_row_tiles_bool_step(gb, seed):
+    """k_mxv_rtile_bool: the BFS level step on an iso BOOL matrix -- q<!visited.S, replace> = A lor.land q, and any.pair -- with the operand
+    as presence / value pairs, accumulators of two bits per row; false operand values (present but false: no true product), masks of every
+    kind, accumulators, outputs that are their own operand (fresh buffers: NOT taken by the tiles).  Against the oracle."""
+    from graphblas_amd import device
+
+    rng = np.random.default_rng(8800 + seed)
+    n = int(rng.integers(2500, 6000))
+    rows, cols, _ = skewed_square(rng, n, "BOOL")
+    vals = np.ones(rows.size, bool)
+    sr = ["lor_land", "any_pair"][seed % 2]
+    ui = np.flatnonzero(rng.random(n) < [0.3, 0.05, 0.7][seed % 3])
+    uv = rng.random(ui.size) < (0.6 if seed % 4 == 1 else 1.1)  # (seed 1, 5, 9: some present entries are false)
+    wi, wv = rand_vec(rng, n, 0.5, "BOOL")
+    mi, mv = rand_vec(rng, n, 0.5, "BOOL")
+    accum = [None, "lor", None][seed % 3]
+    comp, repl, struct = bool(seed & 1) or seed % 4 == 0, bool(seed & 2), bool(seed & 4)
+    oa = O.OMat.from_coo(rows, cols, vals, n, n, "BOOL")
+    ou, ow, om = O.OVec(n, ui, uv, "BOOL"), O.OVec(n, wi, wv, "BOOL"), O.OVec(n, mi, mv, "BOOL")
+    exp = O.mxv(oa, ou, sr, w=ow, mask=om, mask_comp=comp, mask_struct=struct, accum=accum, replace=repl)
+    try:
+        set_opts(ORDER_OPTS + ((b"rtile_rows", [8192, 16384][seed % 2]), (b"rtile_entries", [256, 900, 6000][seed % 3])))
+        A = gb.Matrix.from_coo(rows, cols, vals, dtype="BOOL", nrows=n, ncols=n)
+        u = gb.Vector.from_coo(ui, uv, dtype="BOOL", size=n)
+        w = gb.Vector.from_coo(wi, wv, dtype="BOOL", size=n)
+        mk = gb.Vector.from_coo(mi, mv, dtype="BOOL", size=n)
+        m_arg = (mk.S if struct else mk.V)
+        w(~m_arg if comp else m_arg, accum=accum, replace=repl) << A.mxv(u, getattr(gb.semiring, sr))
+        st = device.last_stats()
+        assert st["ordered"] == 1 and st["fused_epilogue"] == 3, st
+        same_vec(w, exp)
+        # the frontier as its own output (the notebook's q(~v.S, replace=True) << q.vxm(A, lor_land) shape, here with mxv): fresh buffers
+        q = gb.Vector.from_coo(ui, uv, dtype="BOOL", size=n)
+        q(~m_arg, replace=True) << A.mxv(q, getattr(gb.semiring, sr))
+        same_vec(q, O.mxv(oa, ou, sr, w=ou, mask=om, mask_comp=True, mask_struct=struct, replace=True))
+        set_opts(((b"rows_tile", 0),))
+        w3 = gb.Vector.from_coo(wi, wv, dtype="BOOL", size=n)
+        w3(~m_arg if comp else m_arg, accum=accum, replace=repl) << A.mxv(u, getattr(gb.semiring, sr))
+        assert device.last_stats()["fused_epilogue"] in (1, 2)
         same_vec(w3, exp)
     finally:
         set_opts(RESTORE)
