@@ -25,7 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PROFILE_ROUND = 4  # PMC traffic profiles of kernels from earlier rounds do not describe this library: only profiles/r04 (and later) count
+PROFILE_ROUND = 5  # PMC traffic profiles of kernels from earlier rounds do not describe this library: only profiles/r05 (and later) count
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); 6290 GB/s measured copy
 
 
@@ -1260,7 +1260,8 @@ def main():
         dist.destroy_process_group()
 
 
-MXV_KERNELS_NOTE = ("one GrB_mxv call: k_long_init + k_mxv_hstrip + k_mxv_ctile (k_long_compact_* + k_mxv_long_grp for BOOL matrices) + k_mxv_rows_tag (<.., HEAD> for BOOL operands: their hottest columns in LDS) "
+MXV_KERNELS_NOTE = ("one GrB_mxv call: k_long_init + k_mxv_hstrip + k_mxv_ctile (k_long_compact_* + k_mxv_long_grp for BOOL matrices) + k_mxv_rtile (round 5: the short rows as "
+                    "sorted row tiles; k_mxv_rtile_bool for BOOL operands given as presence / value pairs; k_mxv_rows_tag for the calls the tiles do not take) "
                     "(+ k_rows_tail when the write rule touches the empty tail) on the matrix's popularity-ordered layouts -- no per-call operand image; "
                     "k_x_image in front of them on the natural-order layouts (order_mode 0, row blocks of a sharded run); k_mxv_pull + k_mxv_seams below the split threshold")
 
