@@ -688,7 +688,9 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
         // the tagged row groups are the only form of the short rows' entries the kernels read: the CSR copy they were built from is
         // released (0.42 GB of the cached layouts at scale 24); the row pointers stay (row lengths, accounting)
         ensure_tagged(A);
-        if (A->hot_identity && ctx().rows_tile) ensure_rtile(A);  // (an ordered twin: its short rows as sorted row tiles too, from the same CSR copy)
+        // (the short rows as sorted row tiles too, from the same CSR copy: an ordered twin, or -- row blocks of a sharded run, order_mode 0 -- a
+        //  matrix whose columns are re-coded through the hot table: codes below hot_k are popularity ranks there as well)
+        if ((A->hot_identity || hot) && ctx().rows_tile) ensure_rtile(A);
         dev_free(S->d_col);
         S->d_col = nullptr;
         if (!S->iso) {
@@ -1220,8 +1222,8 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
             // the sorted row tiles of an ordered matrix (round 5, grb_mxv_rtile.inc): a specialised semiring over a full operand (or an image
             // with the absorbing value under its absent entries) whose values are read, values of the matrix read, output in place
             if constexpr (MON >= 0 && !std::is_same<T, bool>::value && (sizeof(T) == 4 || sizeof(T) == 8)) {
-                if (ctx().rows_tile && A->rt_state == 1 && A->hot_identity && b.u_full && b.need_uval && b.need_aval && !b.a_iso &&
-                    b.tg_groups > 0 && b.tg_groups == ceil_div(std::min<int64_t>(b.m, std::max<int64_t>(A->ord_live_rows, 1)), 64) &&
+                if (ctx().rows_tile && A->rt_state == 1 && b.u_full && b.need_uval && b.need_aval && !b.a_iso &&
+                    (A->hot_identity ? (b.tg_groups > 0 && b.tg_groups == ceil_div(std::min<int64_t>(b.m, std::max<int64_t>(A->ord_live_rows, 1)), 64)) : b.tg_groups == 0) &&
                     b.m * (int64_t)sizeof(T) < 0xfffffff0ll) {  // (the old values of a tile's rows are read through a buffer descriptor)
                     b.rt_col = A->d_rt_col;
                     b.rt_tag = A->d_rt_tag;
@@ -1255,8 +1257,9 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
             }
             // ... and BOOL products over an operand given as presence / value pairs (the BFS level step): k_mxv_rtile_bool
             if constexpr (std::is_same<T, bool>::value && ((MON == OP_LOR && MUL == OP_LAND) || (MON == OP_ANY && MUL == OP_PAIR))) {
-                if (ctx().rows_tile && A->rt_state == 1 && A->hot_identity && !b.u_full && (b.u_pv != nullptr || !b.need_uval) && (b.a_iso || !b.need_aval) &&
-                    b.tg_groups > 0 && b.tg_groups == ceil_div(std::min<int64_t>(b.m, std::max<int64_t>(A->ord_live_rows, 1)), 64) && b.m < 0xfffffff0ll) {
+                if (ctx().rows_tile && A->rt_state == 1 && !b.u_full && (b.u_pv != nullptr || !b.need_uval) && (b.a_iso || !b.need_aval) &&
+                    (A->hot_identity ? (b.tg_groups > 0 && b.tg_groups == ceil_div(std::min<int64_t>(b.m, std::max<int64_t>(A->ord_live_rows, 1)), 64)) : b.tg_groups == 0) &&
+                    b.m < 0xfffffff0ll) {
                     b.rt_col = A->d_rt_col;
                     b.rt_tag = A->d_rt_tag;
                     b.rt_val = nullptr;
