@@ -329,6 +329,11 @@ GrB_Info GrX_Matrix_cache_bytes(const GrB_Matrix A, uint64_t *bytes);
  *   "pull_ipt"      merge items per thread of the pull SpMV (0 = default)
  *   "hot_min_cols"  matrices with at least this many columns get a hot-column table for the pull SpMV
  *   "hot_k"         entries of that table (0 = sized to ~2 MiB of x values)
+ *   "rows_tile"     (round 5) 1 (default): the short rows of a matrix in its popularity order are kept a second time as SORTED ROW TILES
+ *                   (tiles of up to "rtile_rows" = 8192 | 16384 rows and about "rtile_entries" = 32768 entries, the entries of a tile sorted
+ *                   by column code) and run by k_mxv_rtile / k_mxv_rtile_bool where the call allows it: a compiled semiring over a full
+ *                   operand (or lor.land / any.pair over presence / value pairs); 0: the tagged row groups everywhere; 2: the tiles on the
+ *                   natural-order layouts of hot-coded matrices too (measured slower there)
  *   "rows_head"     1 (default): the short rows of an ordered BOOL matrix multiplied with a BOOL operand that is not full run in persistent
  *                   workgroups that keep the presence / value pairs of the hottest columns in LDS; 0: never.
  *                   "rows_head_min_groups" (16384): ... for matrices with at least this many groups of 64 rows

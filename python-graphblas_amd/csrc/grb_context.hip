@@ -405,7 +405,7 @@ extern "C" GrB_Info GrX_option_set(const char *name, int64_t value)
         c.fill_absent = (int)value;
     }
     else if (n == "rows_tile") {
-        if (value != 0 && value != 1) return GrB_INVALID_VALUE;
+        if (value != 0 && value != 1 && value != 2) return GrB_INVALID_VALUE;
         c.rows_tile = (int)value;
     }
     else if (n == "rtile_rows") {

@@ -688,9 +688,12 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
         // the tagged row groups are the only form of the short rows' entries the kernels read: the CSR copy they were built from is
         // released (0.42 GB of the cached layouts at scale 24); the row pointers stay (row lengths, accounting)
         ensure_tagged(A);
-        // (the short rows as sorted row tiles too, from the same CSR copy: an ordered twin, or -- row blocks of a sharded run, order_mode 0 -- a
-        //  matrix whose columns are re-coded through the hot table: codes below hot_k are popularity ranks there as well)
-        if ((A->hot_identity || hot) && ctx().rows_tile) ensure_rtile(A);
+        // (an ordered twin: its short rows as sorted row tiles too, from the same CSR copy.  rows_tile = 2 builds them for the natural-order
+        //  layouts of a hot-coded matrix as well -- row blocks of a sharded run, order_mode 0; the kernels take them there too, tested, but
+        //  MEASURED SLOWER than the tagged row groups: blocks 0/2, 0/4 of the scale-24 graph 0.335 -> 0.352, 0.197 -> 0.214 ms, the
+        //  Kronecker-26 block 0.636 -> 0.652 (profiles/r05/final_run_summary_tiles_on_natural_layouts.txt) -- behind a 2 MiB hot table the
+        //  codes of the other columns are original labels: sorting by them gathers nothing together)
+        if (ctx().rows_tile && (A->hot_identity || (hot && ctx().rows_tile == 2))) ensure_rtile(A);
         dev_free(S->d_col);
         S->d_col = nullptr;
         if (!S->iso) {

@@ -504,7 +504,7 @@ def test_sorted_row_tiles_match_the_oracle(gb, seed):
         #  hot table, the operand image [table | u] built per call -- carry the tiles too)
         natural = seed >= 12
         set_opts(ORDER_OPTS + ((b"rtile_rows", [8192, 16384][seed % 2]), (b"rtile_entries", [256, 700, 5000][seed % 3]), (b"hub_min_len", [100, 0][seed % 2]),
-                               (b"order_mode", 0 if natural else 1), (b"hot_k", 256 if natural else 0)))
+                               (b"order_mode", 0 if natural else 1), (b"hot_k", 256 if natural else 0), (b"rows_tile", 2 if natural else 1)))
         A = gb.Matrix.from_coo(rows, cols, vals, dtype=tname, nrows=n, ncols=n)
         u = gb.Vector.from_coo(ui, uv, dtype=tname, size=n)
         w = gb.Vector.from_coo(wi, wv, dtype=tname, size=n)
