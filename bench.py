@@ -535,7 +535,12 @@ def run_mxm(args, gb, torch, device, rank, world, dist, barrier, *, scale, workl
     # rows of A cut so that every rank carries the same number of multiplies (not the same number of rows): no collective
     # constrains the block sizes here
     sharded_path = world > 1 or getattr(args, "force_dist", False)  # (--force-dist: the flop-balanced cuts and the row view of A with one rank)
-    if sharded_path:
+    blk = tuple(int(x) for x in args.block.split("/")) if (getattr(args, "block", None) and world == 1) else None
+    if blk:  # (--block r/w: rank r's flop-balanced share of a w-way run, alone on this GPU: what one rank of the sharded product computes)
+        sharded_path = True
+        cuts = sharded.balanced_cuts(sharded.flops_prefix(ip_b, col_b, ip_b[1:] - ip_b[:-1]), blk[1])
+        lo, hi = cuts[blk[0]], cuts[blk[0] + 1]
+    elif sharded_path:
         cuts = sharded.balanced_cuts(sharded.flops_prefix(ip_b, col_b, ip_b[1:] - ip_b[:-1]), world)
         lo, hi = cuts[rank], cuts[rank + 1]
     else:
@@ -621,7 +626,8 @@ def run_mxm(args, gb, torch, device, rank, world, dist, barrier, *, scale, workl
         "config": {"workload": f"rmat{scale} {workload}: " + ("C<!A.S> = A (+.x) A (complemented mask fused into the product)" if masked == "comp"
                                                             else "C<A.S> = A (+.x) A (mask-driven)" if masked else "C = A (+.x) A")
                    + ", INT64 ones" + (f"; row batches under {args.stream_budget_gb:g} GiB, output streamed (count + checksum)" if streamed else ""),
-                   "nnz_A": nnz_a, "flops": flops, "nnz_C": nnz_c, "parallelism": f"row-shard x{world} (flop-balanced cuts), B replicated", **stream_out},
+                   "nnz_A": nnz_a, "flops": flops, "nnz_C": nnz_c, "parallelism": (f"rank {blk[0]} of a {blk[1]}-way row shard (flop-balanced cuts), B replicated, compute only" if blk else
+                                   f"row-shard x{world} (flop-balanced cuts), B replicated"), **stream_out},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None if streamed else measured_traffic(workload, scale),
                      "kernel": "k_spgemm_mhash / k_spgemm_mwin" if masked is True else "k_spgemm_unit (symbolic + numeric classes) / k_spgemm_unit_dense / k_spgemm_hash",
