@@ -956,7 +956,9 @@ static void ensure_rtile(GB_Matrix_opaque *A)
     const int64_t *sptr = matrix_rowptr(S);
     const int64_t nnz = S->nvals;
     DevBuf<int64_t> flag(G + 1), tidx(G + 1);
-    hipLaunchKernelGGL(k_rtile_heads, dim3((unsigned)ceil_div(G, 256)), dim3(256), 0, ctx().stream, sptr, G, std::max<int64_t>(256, ctx().rtile_entries),
+    // (BOOL tiles: two bits of accumulator per row and 6-byte entries -- twice the entries per tile measured best on the BFS step: 0.399 -> 0.383 ms)
+    const int64_t ents_per_tile = std::max<int64_t>(256, ctx().rtile_entries) * (is_bool ? 2 : 1);
+    hipLaunchKernelGGL(k_rtile_heads, dim3((unsigned)ceil_div(G, 256)), dim3(256), 0, ctx().stream, sptr, G, ents_per_tile,
                        rows_cap / 64, flag.p);
     GRB_HIP(hipMemsetAsync(flag.p + G, 0, sizeof(int64_t), ctx().stream));
     prim_exclusive_sum_i64(flag.p, tidx.p, G + 1);
