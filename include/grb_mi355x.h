@@ -345,7 +345,7 @@ GrB_Info GrX_Matrix_cache_bytes(const GrB_Matrix A, uint64_t *bytes);
  *   "hub_min_len"   rows of an ordered matrix from this many entries (default 1024) are dealt to 64 column classes instead of 16; 0: no hub level
  *   "value_dict"    1 (default): a matrix of a 4-byte type with at most 256 distinct finite values keeps one-byte value codes in the
  *                   lane records of its hot strips (half the bytes of the stream that bounds them; exact: codes stand for bit patterns); 0: never
- *   "order_mode"    1 (default): square matrices with at least "order_min_nnz" (48 Mi) entries get their pull layouts in a vertex
+ *   "order_mode"    1 (default): square matrices with at least "order_min_nnz" (24 Mi; 48 Mi before round 5) entries get their pull layouts in a vertex
  *                   order of their own -- vertices by falling column count -- and the vectors they are multiplied with are KEPT in
  *                   that order between calls (converted on first use, converted back by every entry point that is not element-wise:
  *                   build / extractTuples / export / indexed assign and extract / a product with another matrix); results are the

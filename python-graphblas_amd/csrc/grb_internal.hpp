@@ -122,7 +122,9 @@ struct Context {
     int value_dict = 1;              // 1: hot-strip records carry 1-byte value codes when the matrix has at most 256 distinct values
     int order_mode = 1;              // 1: large square matrices get popularity-ordered pull layouts and keep their operands in that order
                                      // (grb_mxv_order.inc); 0: never
-    int64_t order_min_nnz = 48ll << 20;  // ... from this many entries (the layouts that profit are the ones of lean_min_nnz)
+    int64_t order_min_nnz = 24ll << 20;  // ... from this many entries.  Round 5 (profiles/r05/small_scales.txt): scale 21 (33.5 M entries) 0.130 -> 0.087 ms unmasked,
+                                         // 0.102 -> 0.080 masked on the ordered layouts; scale 20 (16.8 M) 0.067 -> 0.072: the crossover lies between.  The twin
+                                         // always takes the lean layouts (hot strips + cold tiles + row tiles), whatever lean_min_nnz says
     int64_t reorder_count = 0;       // vectors converted between vertex orders so far (cumulative)
     void *host_pinned = nullptr;     // 4 KiB of page-locked host memory: small device-to-host reads land here (no staging copy in the runtime)
     unsigned long long *push_counters = nullptr;  // the thin push path's counters (grb_mxv_push.inc): two sets of four words, used in turn --

@@ -212,7 +212,7 @@ static void ensure_rtile(GB_Matrix_opaque *A);
 static int short_kernel_for(const GB_Matrix_opaque *A)
 {
     const int sk = ctx().short_kernel;
-    return sk == 6 ? (A->nvals >= ctx().lean_min_nnz ? 5 : 1) : sk;
+    return sk == 6 ? ((A->hot_identity || A->nvals >= ctx().lean_min_nnz) ? 5 : 1) : sk;  // (an ordered twin: always the lean layouts)
 }
 static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
 {
@@ -221,7 +221,7 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
     // products are terminal monoids (the BFS step), where the item kernel's per-row early exit wins
     // (5: the same by type with the hot / cold strips -- 4 -- for non-BOOL matrices)
     const int lk = ctx().long_kernel;
-    const bool big = A->nvals >= ctx().lean_min_nnz;  // (the hot / cold strips and the tagged row groups pay from ~50 M entries)
+    const bool big = A->hot_identity || A->nvals >= ctx().lean_min_nnz;  // (the hot / cold strips and the tagged row groups pay from ~50 M entries in natural order; an ordered twin always takes them)
     const int kind = lk == 3 ? (A->type->code == TC_BOOL ? 1 : 2) : (lk == 5 ? (A->type->code == TC_BOOL ? 1 : (big ? 4 : 2)) : lk);
     // (the short part holds its entries either as CSR arrays or, for the tagged row groups, in that layout alone: another short-row
     //  kernel than the one the split was built for rebuilds it)

@@ -18,7 +18,7 @@ from tests.test_random_parity import rand_vals, rand_vec, same_vec
 
 ORDER_OPTS = ((b"order_min_nnz", 1), (b"lean_min_nnz", 1), (b"split_min_nnz", 1), (b"split_min_len", 8), (b"push_mode", 0), (b"hot_min_cols", 8),
               (b"lazy_layout", 0), (b"vec_pad_min_bytes", 0), (b"rows_head_min_groups", 1))
-RESTORE = ((b"order_min_nnz", 48 << 20), (b"lean_min_nnz", 48 << 20), (b"split_min_nnz", 1 << 22), (b"split_min_len", 0), (b"push_mode", 1),
+RESTORE = ((b"order_min_nnz", 24 << 20), (b"lean_min_nnz", 48 << 20), (b"split_min_nnz", 1 << 22), (b"split_min_len", 0), (b"push_mode", 1),
            (b"hot_min_cols", 1 << 20), (b"hot_k", 0), (b"lazy_layout", 1), (b"vec_pad_min_bytes", 1 << 20), (b"long_classes", 16), (b"order_mode", 1), (b"hub_min_len", 1024), (b"rows_head_min_groups", 16384), (b"rows_head", 1),
            (b"rows_tile", 1), (b"rtile_rows", 8192), (b"rtile_entries", 32768))
 
