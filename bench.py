@@ -76,6 +76,10 @@ def parse():
                             "uniform_fp64", "kron26"])
     p.add_argument("--block", default=None, metavar="R/W",
                    help="single GPU: run rank R's row block of a W-way sharded run (the compute part of one rank's step; no exchange)")
+    p.add_argument("--ranked", action="store_true",
+                   help="one GPU: the graph's vertices numbered by falling in-degree up front, rows dealt block-cyclically (--stripe rows at a time) with --block r/w, "
+                        "GrX_Matrix_hint_ranked on every matrix: what a rank of a sharded run over a relabelled graph computes (round 5)")
+    p.add_argument("--stripe", type=int, default=64, help="--ranked --block r/w: rows per stripe of the block-cyclic row dealing")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--streamed", action="store_true", help="mxm: run the unmasked product in row batches with the output streamed")
     p.add_argument("--stream-budget-gb", type=float, default=64.0, help="mxm --streamed: device bytes one batch's product may take")
@@ -110,7 +114,7 @@ class MxvWorkload:
     (sharded.OverlappedMxv) -- the exchange of block c runs while block c + 1 is computed."""
 
     def __init__(self, gb, torch, scale, rank, world, semiring, visited_frac, seed=0, block=None, chunks=1, force_dist=False, weights="int255",
-                 fresh_outputs=0):
+                 fresh_outputs=0, ranked=False, stripe=64):
         from graphblas_amd import _lib, device, sharded, synthetic
 
         self.gb, self.torch, self.rank, self.world = gb, torch, rank, world
@@ -125,10 +129,22 @@ class MxvWorkload:
             ranges = sharded.chunk_blocks(n, rank, world, chunks)
         else:
             ranges = [(0, n)]
+        # --ranked (round 5): the graph's vertices numbered by falling in-degree ONCE, up front (synthetic.rmat_csr(relabel="popularity")), its
+        # rows dealt to the ranks block-cyclically in stripes of --stripe rows (a contiguous block of a ranked graph would hold all the hubs), every
+        # matrix carrying GrX_Matrix_hint_ranked: the library then builds its popularity-ordered layouts in these labels -- for row blocks too
+        self.ranked, self._gid = bool(ranked), None
+        if ranked and sharded_path:
+            raise SystemExit("bench.py: --ranked is wired for one GPU (the whole graph, or --block r/w: what one rank of the block-cyclic run computes)")
+        if ranked and block:
+            self._gid = synthetic.stripe_rows(n, stripe, block[1], block[0])
+            ranges = [(0, n // block[1])]
         self.ranges, self.n, self.block = ranges, n, block
         self.lo, self.hi = ranges[0]
         self.m = sum(hi - lo for lo, hi in ranges)
-        graphs = synthetic.rmat_csr(scale, device="cuda", row_ranges=ranges) if (block or sharded_path) else [synthetic.rmat_csr(scale, device="cuda")]
+        if ranked:
+            graphs = [synthetic.rmat_csr(scale, device="cuda", relabel="popularity", stripes=(stripe, block[1], block[0]) if block else None)]
+        else:
+            graphs = synthetic.rmat_csr(scale, device="cuda", row_ranges=ranges) if (block or sharded_path) else [synthetic.rmat_csr(scale, device="cuda")]
         gen = torch.Generator(device="cuda")
         gen.manual_seed(4242 + seed)
         visited = torch.rand(n, generator=gen, device="cuda") < visited_frac
@@ -151,9 +167,10 @@ class MxvWorkload:
         self.u = self.us[0]
         self.As, self.ws, self.masks, self.visited_c, self._keeps, self._valss = [], [], [], [], [], []
         self.nnz_local = self.nnz_active_local = 0
+        self._rows_of = lambda X, lo, hi: (X[self._gid] if self._gid is not None else X[lo:hi])  # (this rank's rows of a vector over all vertices)
         for (lo, hi), (indptr, col) in zip(ranges, graphs):
             rows = hi - lo
-            vis_c = visited[lo:hi].contiguous()
+            vis_c = self._rows_of(visited, lo, hi).contiguous()
             rowlen = indptr[1:] - indptr[:-1]
             self.nnz_local += int(col.numel())
             self.nnz_active_local += int(rowlen[~vis_c].sum().item())
@@ -162,14 +179,16 @@ class MxvWorkload:
                 #  N-rank runs relax other weights than the single-GPU run; each run is checked against ITS OWN operands)
                 vals = synthetic.edge_weights(col, scale) if weights == "int255" else synthetic.edge_weights_real(col, scale)
                 self.As.append(device.matrix_from_device_csr(indptr, col, vals, rows, n, "FP32"))
-                self.ws.append(device.vector_from_device(self._dist[lo:hi].contiguous()))
+                self.ws.append(device.vector_from_device(self._rows_of(self._dist, lo, hi).contiguous()))
                 self._valss.append(vals)
             else:
                 one = torch.ones(1, dtype=torch.bool, device="cuda")
                 self.As.append(device.matrix_from_device_csr(indptr, col, one, rows, n, "BOOL", iso=True))
                 self.ws.append(device.vector_from_device(torch.ones(rows, dtype=torch.bool, device="cuda"),
-                                                         present=self._frontier[lo:hi].contiguous()))
+                                                         present=self._rows_of(self._frontier, lo, hi).contiguous()))
                 self._valss.append(None)
+            if ranked:
+                device.matrix_hint_ranked(self.As[-1])
             self.masks.append(device.vector_from_device(torch.ones(rows, dtype=torch.bool, device="cuda"), present=vis_c))
             self.visited_c.append(vis_c)
             self._keeps.append((indptr, col))
@@ -263,7 +282,7 @@ class MxvWorkload:
                     continue
                 wv, wb = device.vector_device_views(self.fresh_ws[k % len(self.fresh_ws)], pin=False)
                 uvals = self._dist if (k & 1) == 0 else self._dist2
-                d0 = self._dist[self.lo:self.hi]
+                d0 = self._rows_of(self._dist, self.lo, self.hi)
                 _h, exp = self._expected_block(0, uvals, None, d0, torch.ones(self.m, dtype=torch.bool, device="cuda"))
                 ok = ok and bool(self._bits(wb, self.m).all().item()) and bool(torch.equal(wv, exp))
             return ok
@@ -272,14 +291,14 @@ class MxvWorkload:
             if self.semiring == "min_plus":
                 # (after the warm-up w is at the fixed point of the relaxation: a call that computed nothing would leave it right.
                 #  Reset w to its initial values and run the call once more, on the layouts the timed calls ran on.)
-                wv.copy_(self._dist[self.lo:self.hi])
+                wv.copy_(self._rows_of(self._dist, self.lo, self.hi))
                 self.step()
                 torch.cuda.synchronize()
                 # (the call may keep w in the matrix's vertex order between calls: the views are fetched again -- that brings it back)
                 wv, wb = device.vector_device_views(self.w, pin=False)
             got_has = self._bits(wb, self.m)
             if self.semiring == "min_plus":
-                d0 = self._dist[self.lo:self.hi]
+                d0 = self._rows_of(self._dist, self.lo, self.hi)
                 exp_has, exp = self._expected_block(0, self._dist, None, d0, torch.ones(self.m, dtype=torch.bool, device="cuda"))
                 return bool(got_has.all().item()) and bool(torch.equal(wv, exp))
             exp_has, _ = self._expected_block(0, torch.ones(self.n, dtype=torch.bool, device="cuda"), self._frontier, None, None)
@@ -1074,7 +1093,7 @@ def main():
         sr = {"mxv_min_plus_masked": "min_plus", "mxv_lor_land_masked": "lor_land", "mxv_min_plus": "min_plus"}[workload]
         visited = 0.0 if workload == "mxv_min_plus" else args.visited
         wl = MxvWorkload(gb, torch, scale, rank, world, sr, visited, block=block, chunks=max(1, args.overlap_chunks), force_dist=args.force_dist,
-                         weights=weights, fresh_outputs=(steps if fresh_outputs else 0))
+                         weights=weights, fresh_outputs=(steps if fresh_outputs else 0), ranked=args.ranked, stripe=args.stripe)
         # The first product of a matrix runs on its CSR arrays as they are; the second builds the cached layouts (hot-column coding,
         # long / short split, class strips).  Both are part of the warm-up and are timed apart (wall clock around a synchronised call).
         def timed_call():
@@ -1239,7 +1258,7 @@ def main():
                        if args.workload == "mxv_min_plus_masked" else f"rmat{args.scale} {args.workload}",
                        "ordered": int(res["stats"].get("ordered", 0)), "value_dict": int(res["stats"].get("value_dict", 0)),
                        "edges_counted_per_step": res["edges_per_step"],
-                       "parallelism": (f"rank {block[0]} of a {block[1]}-way row shard, compute only" if block else
+                       "parallelism": ((f"rank {block[0]} of a {block[1]}-way row shard, compute only" + (f" (ranked labels, stripes of {args.stripe} rows dealt block-cyclically)" if args.ranked else "")) if block else
                                        f"row-shard x{world}" + (f" ({res['exchange']['chunks_per_rank']} row blocks per rank) + RCCL all-gather of the w slices into "
                                                                 "the other replica of u, overlapped with the next block's product" if "exchange" in res else ""))},
             "verified": res["verified"],

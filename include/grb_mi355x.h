@@ -249,6 +249,12 @@ GrB_Info GxB_Matrix_import_CSR(GrB_Matrix *A, GrB_Type type, GrB_Index nrows, Gr
                                const GrB_Descriptor desc);
 GrB_Info GxB_Matrix_pack_CSR(GrB_Matrix A, GrB_Index **Ap, GrB_Index **Aj, void **Ax, GrB_Index Ap_size, GrB_Index Aj_size,
                              GrB_Index Ax_size, bool iso, bool jumbled, const GrB_Descriptor desc);
+/* (round 5) A performance hint, never a semantic one: the caller's labels are POPULARITY RANKS -- column 0 is the most referred-to column,
+ * heavy rows come first -- e.g. because the application relabelled its graph once (rows and columns by the same ranking) before sharding it
+ * by rows.  The library then builds the popularity-ordered layouts (hub level, hot strips whose LDS heads are lines of the operand, no
+ * per-call operand image, empty-tail skip, sorted row tiles) in the caller's own index order: no permutation, no vector is ever converted,
+ * square and non-square matrices alike -- what GrB_mxv does by itself for a large square matrix, for the row blocks of a sharded run. */
+GrB_Info GrX_Matrix_hint_ranked(GrB_Matrix A, int ranked);
 /* Borrow the device CSR of A (valid until A is modified or freed). */
 GrB_Info GrX_Matrix_export_CSR_device(const int64_t **d_Ap, const int32_t **d_Aj, const void **d_Ax, GrB_Index *nvals,
                                       int *iso, const GrB_Matrix A);

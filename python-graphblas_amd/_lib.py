@@ -129,6 +129,7 @@ def _declare(L):
                                                 c_u64, c_int, c_int]
     L.GrX_Matrix_export_CSR_device.argtypes = [P(c_void_p), P(c_void_p), P(c_void_p), P(c_u64), P(c_int), c_void_p]
     L.GrX_Matrix_cache_transpose.argtypes = [c_void_p]
+    L.GrX_Matrix_hint_ranked.argtypes = [c_void_p, c_int]
     L.GrX_Vector_import_dense_device.argtypes = [P(c_void_p), c_void_p, c_u64, c_void_p, c_void_p]
     L.GrX_Vector_export_dense_device.argtypes = [P(c_void_p), P(c_void_p), c_void_p]
     L.GrX_Vector_modified.argtypes = [c_void_p]

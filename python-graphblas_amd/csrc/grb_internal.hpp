@@ -364,6 +364,10 @@ struct GB_Matrix_opaque {
     // ---- vertex order (round 4; grb_mxv_order.inc): a large square matrix is laid out a second time as ord = P A P' for a permutation P
     //      by falling column count (perm); the pull kernels run on `ord` with operands kept in that order.  `ord` is a matrix object of its
     //      own whose column indices ARE the hot codes (hot_identity): the first hot_k positions are the hot table, no image is built
+    bool ranked = false;               // (GrX_Matrix_hint_ranked, round 5) the caller's labels ARE popularity ranks: column j is referred to about as often as
+                                       // or more often than column j + 1, heavy rows first.  The ordered layouts are then built in the caller's own order --
+                                       // no permutation, vectors stay natural -- for square and non-square matrices alike (the row blocks of a sharded run
+                                       // whose graph was relabelled once, up front).  A performance hint: no result depends on it.
     GB_Perm *perm = nullptr;           // the order of this matrix's vertex space (shared with its transpose and with vectors)
     GB_Matrix_opaque *ord = nullptr;   // the matrix in that order (owned): layouts only -- its CSR arrays are released once they are built
     GB_Matrix_opaque *tr_of = nullptr; // this matrix is the cached transpose of tr_of (not owned)

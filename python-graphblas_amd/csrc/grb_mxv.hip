@@ -794,9 +794,27 @@ static void ensure_ordered(GB_Matrix_opaque *S)
     const int64_t k_hot = hot_table_size(n, vb);
     if (k_hot < 64 || n < ctx().hot_min_cols) return;
     DevBuf<unsigned int> poscnt(n);
-    GB_Perm *P = ensure_perm(S, k_hot, poscnt);
+    // A matrix whose labels the caller has ranked already (GrX_Matrix_hint_ranked): the twin is the matrix itself, copied -- its layouts are
+    // built from the copy, which is released afterwards like any twin's arrays --, positions are the caller's indices, no vector is ever
+    // converted, and nothing has to be square: m rows, n columns.
+    const bool ranked = S->ranked;
+    const int64_t m_rows = (int64_t)S->nrows;
+    GB_Perm *P = ranked ? nullptr : ensure_perm(S, k_hot, poscnt);
     GB_Matrix_opaque *R = matrix_new(S->type, S->nrows, S->ncols);
     try {
+      if (ranked) {
+        GRB_HIP(hipMemsetAsync(poscnt.p, 0, sizeof(unsigned int) * (size_t)n, ctx().stream));
+        const int hstride = nnz >= ((int64_t)1 << 26) ? 8 : 1;
+        hipLaunchKernelGGL(k_hot_hist, dim3((unsigned)ceil_div(nnz, 256 * hstride)), dim3(256), 0, ctx().stream, S->d_col, nnz, poscnt.p, hstride);
+        R->d_ptr = (int64_t *)dev_alloc(sizeof(int64_t) * (size_t)(m_rows + 1));
+        d2d(R->d_ptr, matrix_rowptr(S), sizeof(int64_t) * (size_t)(m_rows + 1));
+        R->d_col = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)nnz);
+        d2d(R->d_col, S->d_col, sizeof(int32_t) * (size_t)nnz);
+        R->d_val = dev_alloc(vb * (size_t)(S->iso ? 1 : nnz));
+        d2d(R->d_val, S->d_val, vb * (size_t)(S->iso ? 1 : nnz));
+        R->iso = S->iso;
+        R->nvals = nnz;
+      } else {
         // ---- the matrix in the new order: row p = row d_inv[p] of S with its columns renamed by d_rank (unsorted inside a row: no
         //      layout below needs them sorted)
         DevBuf<int64_t> len(n + 1);
@@ -821,9 +839,10 @@ static void ensure_ordered(GB_Matrix_opaque *S)
                                    (const T *)S->d_val, S->iso ? 1 : 0, (const int32_t *)P->d_inv, (const int32_t *)P->d_rank, (const int64_t *)R->d_ptr,
                                    R->d_col, (T *)R->d_val);
         })
+      }
         {
             DevBuf<unsigned long long> last(1, true);
-            hipLaunchKernelGGL(k_twin_live_rows, dim3((unsigned)ceil_div(n, 1024)), dim3(1024), 0, ctx().stream, (const int64_t *)R->d_ptr, n, last.p);
+            hipLaunchKernelGGL(k_twin_live_rows, dim3((unsigned)ceil_div(m_rows, 1024)), dim3(1024), 0, ctx().stream, (const int64_t *)R->d_ptr, m_rows, last.p);
             unsigned long long h_last = 0;
             d2h(&h_last, last.p, sizeof(h_last));
             R->ord_live_rows = (int64_t)h_last;
@@ -855,7 +874,7 @@ static void ensure_ordered(GB_Matrix_opaque *S)
                 acc += h_blk[(size_t)b];
                 width += g;
                 const int64_t end = std::min<int64_t>(lim + (b + 1) * g, n);
-                const bool last_ref = (lim + (b + 1) * g >= P->n_live_cols);  // (behind it: columns nobody counted a reference to)
+                const bool last_ref = (lim + (b + 1) * g >= (P ? P->n_live_cols : n));  // (behind it: columns nobody counted a reference to)
                 if ((int)bounds.size() < R_MAX && end < n && (acc >= target || width >= cap_codes || (last_ref && acc > 0))) {
                     bounds.push_back((int32_t)end);
                     acc = 0;
@@ -2003,8 +2022,9 @@ static void mxv_any_order(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_
         ctx().stats.reorders = (int32_t)(ctx().reorder_count - reorders0);
         return;
     }
-    if (shapes_ok && ctx().order_mode && S->nrows == S->ncols && S->nvals >= ctx().order_min_nnz &&
-        sr->type == S->type->code && !w->pinned && !u->pinned && !(mask && mask->pinned) && S->d_col) {
+    // (a matrix with ranked labels, GrX_Matrix_hint_ranked: the ordered layouts without an order -- any shape, pinned vectors welcome)
+    if (shapes_ok && ctx().order_mode && S->nvals >= ctx().order_min_nnz && sr->type == S->type->code && S->d_col &&
+        (S->ranked || (S->nrows == S->ncols && !w->pinned && !u->pinned && !(mask && mask->pinned)))) {
         int mult = canonical_op(sr->type, sr->mult);
         if (flip) mult = flip_op(mult);
         const bool by_rowlen = mult == OP_PAIR && u->nvals == (int64_t)u->n && !(ctx().debug_flags & 65536);
@@ -2016,7 +2036,7 @@ static void mxv_any_order(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_
         }
     }
     if (ordered) {
-        GB_Perm *P = S->perm;
+        GB_Perm *P = S->ranked ? nullptr : S->perm;  // (ranked labels: the twin is in the caller's own order -- the vectors stay natural)
         // an output that keeps nothing of its old content needs no conversion: it is emptied and takes the order
         const bool w_dead = !accum && (!mask || f.replace) && w != u && w != mask;
         if (w_dead && w->order != P && w->d_val) {
@@ -2086,6 +2106,31 @@ extern "C" GrB_Info GrB_vxm(GrB_Vector w, const GrB_Vector mask, const GrB_Binar
 
 // Device bytes of the layouts the pull SpMV caches with a matrix (hot-coded columns, short part, long-row strips / items,
 // tile table, transpose not included), for the bench line's bookkeeping.
+// The caller's labels are popularity ranks (round 5): see GB_Matrix_opaque::ranked.  Setting or clearing the hint drops the ordered twin.
+extern "C" GrB_Info GrX_Matrix_hint_ranked(GrB_Matrix A, int ranked)
+{
+    GRB_TRY
+    require_init();
+    check_matrix(A, "A");
+    if (A->ranked != (ranked != 0)) {
+        if (A->ord) {
+            matrix_free(A->ord);
+            A->ord = nullptr;
+        }
+        A->ord_state = 0;
+        A->ranked = ranked != 0;
+        if (A->tr) {  // (the cached transpose shares the labels)
+            if (A->tr->ord) {
+                matrix_free(A->tr->ord);
+                A->tr->ord = nullptr;
+            }
+            A->tr->ord_state = 0;
+            A->tr->ranked = A->ranked;
+        }
+    }
+    GRB_CATCH(errp(A))
+}
+
 extern "C" GrB_Info GrX_Matrix_cache_bytes(const GrB_Matrix A, uint64_t *bytes)
 {
     GRB_TRY

@@ -949,6 +949,7 @@ GB_Matrix_opaque *matrix_transpose_cached(GB_Matrix_opaque *A)
     if (!A->tr) {
         GRB_DISPATCH_TYPE(A->type->code, T, { A->tr = matrix_transpose_new<T>(A); })
         A->tr->tr_of = A;
+        A->tr->ranked = A->ranked;  // (labels ranked for rows and columns alike: GrX_Matrix_hint_ranked)
     }
     return A->tr;
 }

@@ -152,6 +152,13 @@ def last_stats():
     return {k: getattr(s, k) for k, _ in s._fields_}
 
 
+def matrix_hint_ranked(A, ranked=True):
+    """The labels of ``A`` are popularity ranks already (column 0 the most referred-to, heavy rows first): the library builds its
+    popularity-ordered layouts in the caller's own index order -- no permutation, no vector conversion, any shape (GrX_Matrix_hint_ranked).
+    A performance hint only."""
+    call_on(A, "GrX_Matrix_hint_ranked", [A._handle, 1 if ranked else 0])
+
+
 def cache_transpose(A):
     call_on(A, "GrX_Matrix_cache_transpose", [A._handle])
 

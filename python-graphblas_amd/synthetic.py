@@ -10,47 +10,91 @@ import numpy as np
 
 
 def rmat_csr(scale, edge_factor=16, *, seed=None, device="cuda", abcd=(0.57, 0.19, 0.19, 0.05), row_range=None,
-             row_ranges=None, chunk_edges=1 << 27):
+             row_ranges=None, chunk_edges=1 << 27, relabel=None, stripes=None):
     """Returns (indptr int64[n_rows+1], col int32[nnz]) torch tensors on ``device``; sorted, deduped.
 
     ``row_range=(lo, hi)`` keeps only rows lo..hi-1 (1-D row sharding: every rank draws the same
     edge stream from the same seed and keeps its block), re-based so that row lo becomes row 0.
     ``row_ranges=[(lo, hi), ...]`` does the same for several blocks from ONE pass over the edge stream
     and returns a list of (indptr, col) pairs (a rank that owns several row blocks: sharded.OverlappedMxv).
+
+    ``relabel="popularity"`` (round 5): instead of the scrambled labels the vertices are numbered by falling in-degree (ties: falling
+    out-degree) of the whole edge stream -- what an application does ONCE before it shards a graph whose matrix it will multiply with many
+    times; every rank derives the same numbering from the same stream.  ``stripes=(B, w, r)``: keep the rows of the stripes of ``B``
+    consecutive rows numbered r, r + w, r + 2 w, ... (block-cyclic 1-D sharding: with ranked labels a contiguous block would give rank 0
+    all the hubs), re-based so that local row = (stripe // w) * B + row % B.
     """
     import torch
 
     n = 1 << scale
     n_edges = edge_factor * n
     seed = scale if seed is None else seed
-    gen = torch.Generator(device=device)
-    gen.manual_seed(1000 + seed)
-    perm = torch.randperm(n, generator=gen, device=device)
     a, b, c, _ = abcd
-    ranges = list(row_ranges) if row_ranges is not None else [row_range if row_range is not None else (0, n)]
-    whole = row_ranges is None and row_range is None
+
+    def stream():
+        """(perm, generator of (src, dst) chunks before the labels are applied) -- the same sequence at every call."""
+        gen = torch.Generator(device=device)
+        gen.manual_seed(1000 + seed)
+        perm = torch.randperm(n, generator=gen, device=device)
+
+        def chunks():
+            done = 0
+            while done < n_edges:
+                m = min(chunk_edges, n_edges - done)
+                src = torch.zeros(m, dtype=torch.int64, device=device)
+                dst = torch.zeros(m, dtype=torch.int64, device=device)
+                for _ in range(scale):
+                    r = torch.rand(m, generator=gen, device=device)
+                    src_bit = r >= (a + b)
+                    dst_bit = ((r >= a) & (r < a + b)) | (r >= (a + b + c))
+                    src = (src << 1) | src_bit
+                    dst = (dst << 1) | dst_bit
+                yield src, dst
+                done += m
+
+        return perm, chunks()
+
+    perm, chunks = stream()
+    if relabel == "popularity":
+        indeg = torch.zeros(n, dtype=torch.int64, device=device)
+        outdeg = torch.zeros(n, dtype=torch.int64, device=device)
+        for src, dst in chunks:
+            indeg += torch.bincount(perm[dst], minlength=n)
+            outdeg += torch.bincount(perm[src], minlength=n)
+        order = torch.argsort(indeg * (n_edges + 1) + outdeg, descending=True, stable=True)
+        rank = torch.empty(n, dtype=torch.int64, device=device)
+        rank[order] = torch.arange(n, device=device)
+        del indeg, outdeg, order
+        perm0, chunks = stream()
+        perm = rank[perm0]
+        del rank, perm0
+    elif relabel is not None:
+        raise ValueError(f"relabel={relabel!r}")
+    if stripes is not None:
+        B, sw, sr = stripes
+        assert row_range is None and row_ranges is None and n % (B * sw) == 0
+        ranges = [(0, n // sw)]
+    else:
+        ranges = list(row_ranges) if row_ranges is not None else [row_range if row_range is not None else (0, n)]
+    whole = row_ranges is None and row_range is None and stripes is None
     keys = [[] for _ in ranges]
-    done = 0
-    while done < n_edges:
-        m = min(chunk_edges, n_edges - done)
-        src = torch.zeros(m, dtype=torch.int64, device=device)
-        dst = torch.zeros(m, dtype=torch.int64, device=device)
-        for _ in range(scale):
-            r = torch.rand(m, generator=gen, device=device)
-            src_bit = r >= (a + b)
-            dst_bit = ((r >= a) & (r < a + b)) | (r >= (a + b + c))
-            src = (src << 1) | src_bit
-            dst = (dst << 1) | dst_bit
+    for src, dst in chunks:
         src = perm[src]
         dst = perm[dst]
-        for k, (lo, hi) in enumerate(ranges):
-            if whole:
-                keys[k].append(torch.unique(src * n + dst))
-            else:
-                keep = (src >= lo) & (src < hi)
-                keys[k].append(torch.unique((src[keep] - lo) * n + dst[keep]))
+        if stripes is not None:
+            stripe = torch.div(src, B, rounding_mode="floor")
+            keep = (stripe % sw) == sr
+            local = torch.div(stripe[keep], sw, rounding_mode="floor") * B + src[keep] % B
+            keys[0].append(torch.unique(local * n + dst[keep]))
+            del stripe, keep, local
+        else:
+            for k, (lo, hi) in enumerate(ranges):
+                if whole:
+                    keys[k].append(torch.unique(src * n + dst))
+                else:
+                    keep = (src >= lo) & (src < hi)
+                    keys[k].append(torch.unique((src[keep] - lo) * n + dst[keep]))
         del src, dst
-        done += m
     out = []
     for k, (lo, hi) in enumerate(ranges):
         key = torch.unique(torch.cat(keys[k])) if len(keys[k]) > 1 else keys[k][0]
@@ -63,6 +107,14 @@ def rmat_csr(scale, edge_factor=16, *, seed=None, device="cuda", abcd=(0.57, 0.1
         indptr[1:] = torch.cumsum(counts, 0)
         out.append((indptr, col))
     return out if row_ranges is not None else out[0]
+
+
+def stripe_rows(n, B, w, r, device="cuda"):
+    """Global row numbers of the local rows of rank r in the block-cyclic sharding ``stripes=(B, w, r)`` of :func:`rmat_csr`."""
+    import torch
+
+    local = torch.arange(n // w, device=device)
+    return (torch.div(local, B, rounding_mode="floor") * w + r) * B + local % B
 
 
 def edge_weights(col, seed, dtype=None, device=None):
