@@ -77,9 +77,9 @@ def parse():
     p.add_argument("--block", default=None, metavar="R/W",
                    help="single GPU: run rank R's row block of a W-way sharded run (the compute part of one rank's step; no exchange)")
     p.add_argument("--ranked", action="store_true",
-                   help="one GPU: the graph's vertices numbered by falling in-degree up front, rows dealt block-cyclically (--stripe rows at a time) with --block r/w, "
-                        "GrX_Matrix_hint_ranked on every matrix: what a rank of a sharded run over a relabelled graph computes (round 5)")
-    p.add_argument("--stripe", type=int, default=64, help="--ranked --block r/w: rows per stripe of the block-cyclic row dealing")
+                   help="the graph's vertices numbered by falling in-degree up front (the application relabels once), GrX_Matrix_hint_ranked on every "
+                        "matrix; with --gpus N (or --block r/w: one rank's share, alone) the rows are dealt block-cyclically, --stripe rows at a time (round 5)")
+    p.add_argument("--stripe", type=int, default=8, help="--ranked: rows per stripe of the block-cyclic row dealing (a multiple of 8)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--streamed", action="store_true", help="mxm: run the unmasked product in row batches with the output streamed")
     p.add_argument("--stream-budget-gb", type=float, default=64.0, help="mxm --streamed: device bytes one batch's product may take")
@@ -114,7 +114,7 @@ class MxvWorkload:
     (sharded.OverlappedMxv) -- the exchange of block c runs while block c + 1 is computed."""
 
     def __init__(self, gb, torch, scale, rank, world, semiring, visited_frac, seed=0, block=None, chunks=1, force_dist=False, weights="int255",
-                 fresh_outputs=0, ranked=False, stripe=64):
+                 fresh_outputs=0, ranked=False, stripe=8):
         from graphblas_amd import _lib, device, sharded, synthetic
 
         self.gb, self.torch, self.rank, self.world = gb, torch, rank, world
@@ -134,7 +134,13 @@ class MxvWorkload:
         # matrix carrying GrX_Matrix_hint_ranked: the library then builds its popularity-ordered layouts in these labels -- for row blocks too
         self.ranked, self._gid = bool(ranked), None
         if ranked and sharded_path:
-            raise SystemExit("bench.py: --ranked is wired for one GPU (the whole graph, or --block r/w: what one rank of the block-cyclic run computes)")
+            # N ranks: rank r holds the stripes r, r + world, ... (n / world local rows) in `chunks` blocks of consecutive LOCAL rows; the
+            # exchange deals the gathered slices back stripe by stripe (sharded.OverlappedMxv(cyclic=stripe))
+            h = n // (world * chunks)
+            if stripe % 8 or h % stripe or n % (64 * world * chunks):
+                raise SystemExit("bench.py --ranked: --stripe must be a multiple of 8 rows and divide n / (ranks * chunks)")
+            self._gid = synthetic.stripe_rows(n, stripe, world, rank)
+            ranges = [(c * h, (c + 1) * h) for c in range(chunks)]
         if ranked and block:
             self._gid = synthetic.stripe_rows(n, stripe, block[1], block[0])
             ranges = [(0, n // block[1])]
@@ -142,7 +148,15 @@ class MxvWorkload:
         self.lo, self.hi = ranges[0]
         self.m = sum(hi - lo for lo, hi in ranges)
         if ranked:
-            graphs = [synthetic.rmat_csr(scale, device="cuda", relabel="popularity", stripes=(stripe, block[1], block[0]) if block else None)]
+            deal = (stripe, block[1], block[0]) if block else ((stripe, world, rank) if sharded_path else None)
+            ip_l, col_l = synthetic.rmat_csr(scale, device="cuda", relabel="popularity", stripes=deal)
+            graphs = []
+            for lo, hi in ranges:  # (the rank's local rows cut into its blocks)
+                e0, e1 = int(ip_l[lo].item()), int(ip_l[hi].item())
+                graphs.append(((ip_l[lo: hi + 1] - e0).contiguous(), col_l[e0:e1].contiguous()))
+            if len(ranges) == 1:
+                graphs = [(ip_l, col_l)]
+            del ip_l, col_l
         else:
             graphs = synthetic.rmat_csr(scale, device="cuda", row_ranges=ranges) if (block or sharded_path) else [synthetic.rmat_csr(scale, device="cuda")]
         gen = torch.Generator(device="cuda")
@@ -167,7 +181,7 @@ class MxvWorkload:
         self.u = self.us[0]
         self.As, self.ws, self.masks, self.visited_c, self._keeps, self._valss = [], [], [], [], [], []
         self.nnz_local = self.nnz_active_local = 0
-        self._rows_of = lambda X, lo, hi: (X[self._gid] if self._gid is not None else X[lo:hi])  # (this rank's rows of a vector over all vertices)
+        self._rows_of = lambda X, lo, hi: (X[self._gid[lo:hi]] if self._gid is not None else X[lo:hi])  # (this rank's rows lo..hi-1 of a vector over all vertices)
         for (lo, hi), (indptr, col) in zip(ranges, graphs):
             rows = hi - lo
             vis_c = self._rows_of(visited, lo, hi).contiguous()
@@ -212,7 +226,7 @@ class MxvWorkload:
         if n_u == 2:
             # the BFS step's output is not full: its presence words travel with the values
             self.ov = sharded.OverlappedMxv(self.As, self.ws, self.masks, self.us, self.sr, accum=self.accum, desc_name=desc_name,
-                                            presence=(semiring != "min_plus"))
+                                            presence=(semiring != "min_plus"), cyclic=stripe if ranked else 0)
             self.ov.probe_exchange()
             torch.cuda.synchronize()
 
@@ -313,7 +327,7 @@ class MxvWorkload:
             uv.copy_(self._dist)
             for c in range(ov.chunks):
                 lo, hi = self.ranges[c]
-                device.vector_device_views(self.ws[c])[0].copy_(self._dist[lo:hi])
+                device.vector_device_views(self.ws[c])[0].copy_(self._rows_of(self._dist, lo, hi))
         u_vals, u_has = uv.clone(), self._bits(ub, self.n)
         before = []
         for c in range(ov.chunks):
@@ -330,10 +344,10 @@ class MxvWorkload:
             got_has = self._bits(wb, hi - lo)
             exp_has, exp = self._expected_block(c, u_vals, u_has, *before[c])
             if self.semiring == "min_plus":
-                ok = ok and bool(got_has.all().item()) and bool(torch.equal(wv, exp)) and bool(torch.equal(nv[lo:hi], wv))
+                ok = ok and bool(got_has.all().item()) and bool(torch.equal(wv, exp)) and bool(torch.equal(self._rows_of(nv, lo, hi), wv))
             else:
                 ok = ok and bool(torch.equal(got_has, exp_has)) and bool(wv[exp_has].all().item())
-                ok = ok and bool(torch.equal(n_has[lo:hi], got_has)) and bool(nv[lo:hi][got_has].all().item())
+                ok = ok and bool(torch.equal(self._rows_of(n_has, lo, hi), got_has)) and bool(self._rows_of(nv, lo, hi)[got_has].all().item())
         # the replica every rank will read next must be the same everywhere: two order-independent checksums
         img = nv.view(torch.int32).to(torch.int64) if self.semiring == "min_plus" else (nv.to(torch.int64) & n_has.to(torch.int64))
         idx = torch.arange(1, self.n + 1, device="cuda", dtype=torch.int64)
@@ -1089,11 +1103,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run(workload, scale, steps, warmup, weights="int255", fresh_outputs=False):
+    def run(workload, scale, steps, warmup, weights="int255", fresh_outputs=False, ranked=None):
         sr = {"mxv_min_plus_masked": "min_plus", "mxv_lor_land_masked": "lor_land", "mxv_min_plus": "min_plus"}[workload]
         visited = 0.0 if workload == "mxv_min_plus" else args.visited
         wl = MxvWorkload(gb, torch, scale, rank, world, sr, visited, block=block, chunks=max(1, args.overlap_chunks), force_dist=args.force_dist,
-                         weights=weights, fresh_outputs=(steps if fresh_outputs else 0), ranked=args.ranked, stripe=args.stripe)
+                         weights=weights, fresh_outputs=(steps if fresh_outputs else 0), ranked=(args.ranked if ranked is None else ranked),
+                         stripe=args.stripe)
         # The first product of a matrix runs on its CSR arrays as they are; the second builds the cached layouts (hot-column coding,
         # long / short split, class strips).  Both are part of the warm-up and are timed apart (wall clock around a synchronised call).
         def timed_call():
@@ -1215,7 +1230,15 @@ def main():
         #      and every step on an output of its own with the operand alternating -- no step at the fixed point, every admitted row stores
         for label, kw in (("rmat24 mxv_min_plus_masked, FP32 weights U[0,1) instead of U{1..255}: the value dictionary cannot apply", dict(weights="real")),
                           ("rmat24 mxv_min_plus_masked, every timed step on its own copy of the initial distances, operand alternating between two "
-                           "vectors: the write rule stores in every step (the default line repeats one call at its fixed point)", dict(fresh_outputs=True))):
+                           "vectors: the write rule stores in every step (the default line repeats one call at its fixed point)", dict(fresh_outputs=True)),
+                          ("rmat24 mxv_min_plus_masked on a graph whose vertices the APPLICATION numbered by falling in-degree once, up front (not the "
+                           "scrambled labels of the headline), every matrix carrying GrX_Matrix_hint_ranked" +
+                           (f"; rows dealt to the {world} ranks block-cyclically in stripes of {args.stripe}, the gathered slices dealt back the same way"
+                            if (world > 1 or args.force_dist) else ""), dict(ranked=True))):
+            if kw.get("fresh_outputs") and (world > 1 or args.force_dist):
+                continue  # (the N-rank step feeds every output back as the next operand already)
+            if kw.get("ranked") and args.ranked:
+                continue
             try:
                 wl3, r = run("mxv_min_plus_masked", 24, args.steps, args.warmup, **kw)
                 extra.append({"workload": label, **{k: r[k] for k in ("value", "ms_per_step", "dtype", "roofline", "verified")}, "unit": "GTEPS",
@@ -1251,7 +1274,9 @@ def main():
             "dtype": res["dtype"],
             "data": "synthetic",
             "config": {"workload": (f"rmat{args.scale} {args.workload}: w<~visited.S> = min(w, A min.+ u), "
-                                    f"edge factor 16, visited density {args.visited}, dense u, FP32 weights U{{1..255}} (BASELINE.md section 3); "
+                                    f"edge factor 16, visited density {args.visited}, dense u, FP32 weights U{{1..255}} (BASELINE.md section 3)"
+                                    + (" -- NOT the headline input: --ranked numbers the vertices by falling in-degree instead of scrambling them; "
+                                       if args.ranked else "; ") +
                                     f"layouts: ordered={int(res['stats'].get('ordered', 0))} (popularity-ordered twin), "
                                     f"value_dict={int(res['stats'].get('value_dict', 0))} (distinct values coded in one byte; the same call on U[0,1) "
                                     "weights is under extra)")
@@ -1259,7 +1284,8 @@ def main():
                        "ordered": int(res["stats"].get("ordered", 0)), "value_dict": int(res["stats"].get("value_dict", 0)),
                        "edges_counted_per_step": res["edges_per_step"],
                        "parallelism": ((f"rank {block[0]} of a {block[1]}-way row shard, compute only" + (f" (ranked labels, stripes of {args.stripe} rows dealt block-cyclically)" if args.ranked else "")) if block else
-                                       f"row-shard x{world}" + (f" ({res['exchange']['chunks_per_rank']} row blocks per rank) + RCCL all-gather of the w slices into "
+                                       f"row-shard x{world}" + (f", ranked labels, stripes of {args.stripe} rows dealt block-cyclically" if args.ranked else "") +
+                                       (f" ({res['exchange']['chunks_per_rank']} row blocks per rank) + RCCL all-gather of the w slices into "
                                                                 "the other replica of u, overlapped with the next block's product" if "exchange" in res else ""))},
             "verified": res["verified"],
             "first_call_ms": res["first_call_ms"],

@@ -203,11 +203,18 @@ class OverlappedMxv:
     is the plain step (product, then all-gather).  Values always travel; presence words only when ``presence`` (an output that
     is not full: the BFS step -- min_plus relaxations with a full u keep u and w full).
 
+    ``cyclic=B`` (round 5): the rows are dealt to the ranks BLOCK-CYCLICALLY in stripes of B rows (global row (k * world + r) * B + i is
+    local row k * B + i of rank r; B a multiple of 8) -- the sharding of a graph whose vertices are numbered by popularity
+    (``GrX_Matrix_hint_ranked``: every rank's rows then carry the same mix of hubs and leaves, and the library builds its ordered layouts in
+    those labels).  Chunk c of a rank is its local rows c * h .. (c + 1) * h - 1.  The all-gather of a chunk lands in a staging buffer
+    (rank-major) and one strided copy per chunk deals the stripes into the replica the next step reads, after the collective: 2 x 4 bytes
+    per row more HBM traffic than the contiguous sharding, on rows / (world * chunks) * world elements.
+
     The products go straight to the C ABI (``GrB_mxv`` with pre-resolved handles).  ``device="cpu"``: the gloo tests over the
     emulator build, where the vectors' images live in host memory."""
 
     def __init__(self, A_blocks, w_blocks, mask_blocks, u_pair, semiring, *, accum=None, desc_name=None, presence=False,
-                 device="cuda"):
+                 device="cuda", cyclic=0):
         import ctypes
 
         import torch.distributed as dist
@@ -229,6 +236,10 @@ class OverlappedMxv:
         if n % (64 * world * self.chunks):
             raise ValueError("n must be a multiple of 64 * world_size * chunks")
         self.n, self.world, self.h = n, world, n // (world * self.chunks)
+        self.cyclic = int(cyclic)
+        if self.cyclic and (self.cyclic % 8 or self.h % self.cyclic):
+            raise ValueError("cyclic: the stripe must be a multiple of 8 rows and divide n / (world_size * chunks)")
+        self._stage, self._deal = {}, []
         if device != "cpu":
             # The asynchronous collective is ordered behind the product (and the next product behind the collective) through torch's
             # CURRENT stream: ProcessGroupNCCL records its events there.  That orders against the library only if the library launches on
@@ -269,7 +280,33 @@ class OverlappedMxv:
         """The replica the NEXT step reads."""
         return self.u[self.k & 1]
 
+    def _exchange_cyclic(self, c, dst):
+        """all-gather of chunk c into its staging buffer; the strided copies that deal the stripes into replica ``dst`` are queued in
+        self._deal and run once the collective has completed (step)."""
+        torch = self._torch()
+        B, h, world = self.cyclic, self.h, self.world
+        k_c = h // B
+        pairs = [("v", self.u_vals[dst], self.w_vals[c][:h], B)]
+        if self.presence:
+            pairs.append(("b", self.u_words[dst].view(torch.uint8), self.w_words[c][: h // 32].view(torch.uint8), B // 8))
+        works = []
+        for tag, out_full, part, b in pairs:
+            host = self.host_staged
+            send = part.cpu() if host else (part.clone() if self.staged else part)
+            G = self._stage.get((tag, c))
+            if G is None:
+                G = self._stage[(tag, c)] = torch.empty(world * part.numel(), dtype=send.dtype, device=send.device)
+            if host:
+                _gather(self.dist, G, send)
+            else:
+                works.append(_gather_async(self.dist, G, send))
+            # u[(k * world + r) * b + i]  <-  G[r][k * b + i]   for the stripes k of this chunk
+            self._deal.append((out_full.view(-1, world, b)[c * k_c: (c + 1) * k_c], G.view(world, k_c, b).permute(1, 0, 2)))
+        return works
+
     def _exchange(self, c, dst):
+        if self.cyclic:
+            return self._exchange_cyclic(c, dst)
         n_c, h = self.n // self.chunks, self.h
         out_v = self.u_vals[dst][c * n_c: (c + 1) * n_c]
         part_v = self.w_vals[c][:h]
@@ -314,7 +351,9 @@ class OverlappedMxv:
                 wk.wait()
         except RuntimeError:
             self.staged = True
-            self._exchange(0, self.k & 1 ^ 1)
+            for wk in self._exchange(0, self.k & 1 ^ 1):
+                wk.wait()
+        self._deal = []  # (a probe: nothing is dealt into the replica)
 
     def _check_stream(self):
         """The exchange is ordered behind the products through torch's current stream (see __init__): checked at every step, not only at
@@ -343,6 +382,9 @@ class OverlappedMxv:
             works += self._exchange(c, dst)
         for wk in works:
             wk.wait()
+        for out_t, src_t in self._deal:
+            out_t.copy_(src_t)
+        self._deal = []
         if self.presence:
             self.dev.vector_modified(self.u[dst])
         self.k += 1

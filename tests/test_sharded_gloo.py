@@ -514,6 +514,114 @@ def test_overlapped_sharded_step(kind, chunks, world):
         assert res[r][3] is False
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# the block-cyclic step of `bench.py --gpus N --ranked` (round 5): labels ranked by popularity up front, rows dealt in stripes of B rows,
+# every block matrix carrying GrX_Matrix_hint_ranked (ordered layouts, no permutation), the gathered slices dealt back into u
+# ---------------------------------------------------------------------------------------------------------------------
+_CYCLIC_OPTS = ((b"order_min_nnz", 1), (b"lean_min_nnz", 1), (b"split_min_nnz", 1), (b"split_min_len", 8), (b"hot_min_cols", 8), (b"lazy_layout", 0),
+                (b"vec_pad_min_bytes", 0), (b"rows_head_min_groups", 1), (b"rtile_entries", 700), (b"hub_min_len", 100))
+
+
+def _cyclic_worker(rank, world, port, q, scale, iters, chunks, kind, B):
+    gb, dist = _init(rank, world, port)
+    import scipy.sparse as sp
+    import torch
+
+    from graphblas_amd import _lib, device, sharded, synthetic
+
+    for name, val in _CYCLIC_OPTS:
+        assert _lib.lib.GrX_option_set(name, val) == 0
+    n = 1 << scale
+    ip, col = synthetic.rmat_csr(scale, device="cpu", relabel="popularity", stripes=(B, world, rank))
+    gid = synthetic.stripe_rows(n, B, world, rank, device="cpu").numpy()
+    full_ip, full_col = synthetic.rmat_csr(scale, device="cpu", relabel="popularity")
+    wts_full = synthetic.edge_weights(full_col, scale).numpy()
+    M = sp.csr_matrix((wts_full, full_col.numpy(), full_ip.numpy()), shape=(n, n))[gid]
+    assert np.array_equal(M.indptr, ip.numpy()) and np.array_equal(M.indices, col.numpy())  # the generator's stripes = those rows of the whole graph
+    g = torch.Generator().manual_seed(11)
+    dist0 = torch.randint(0, 1000, (n,), generator=g).to(torch.float32).numpy()
+    frontier = (torch.rand(n, generator=g) < 0.3).numpy()
+    visited = (torch.rand(n, generator=g) < 0.5).numpy()
+    h = n // (world * chunks)
+    As, ws, masks, ordered = [], [], [], []
+    for c in range(chunks):
+        blk = M[c * h: (c + 1) * h]
+        rows_g = gid[c * h: (c + 1) * h]
+        vloc = np.flatnonzero(visited[rows_g])
+        masks.append(gb.Vector.from_coo(vloc, np.ones(vloc.size, bool), dtype="BOOL", size=h))
+        bip, bcol = torch.from_numpy(blk.indptr.astype(np.int64)), torch.from_numpy(blk.indices.astype(np.int32))
+        if kind == "min_plus":
+            As.append(device.matrix_from_device_csr(bip, bcol, torch.from_numpy(blk.data.astype(np.float32)), h, n, "FP32", copy=True))
+            ws.append(gb.Vector.from_coo(np.arange(h), dist0[rows_g], dtype="FP32", size=h))
+        else:
+            As.append(device.matrix_from_device_csr(bip, bcol, torch.ones(1, dtype=torch.bool), h, n, "BOOL", copy=True, iso=True))
+            floc = np.flatnonzero(frontier[rows_g])
+            ws.append(gb.Vector.from_coo(floc, np.ones(floc.size, bool), dtype="BOOL", size=h))
+        device.matrix_hint_ranked(As[-1])
+    if kind == "min_plus":
+        us = [gb.Vector.from_coo(np.arange(n), dist0, dtype="FP32", size=n) for _ in range(2)]
+        ov = sharded.OverlappedMxv(As, ws, masks, us, gb.semiring.min_plus["FP32"], accum=gb.binary.min["FP32"], desc_name="GrB_DESC_SC",
+                                   presence=False, device="cpu", cyclic=B)
+    else:
+        fi = np.flatnonzero(frontier)
+        us = [gb.Vector.from_coo(fi, np.ones(fi.size, bool), dtype="BOOL", size=n) for _ in range(2)]
+        ov = sharded.OverlappedMxv(As, ws, masks, us, gb.semiring.lor_land["BOOL"], desc_name="GrB_DESC_RSC", presence=True, device="cpu", cyclic=B)
+    ov.probe_exchange()
+    for _ in range(iters):
+        ov.step()
+    ui, uv = ov.current_u().to_coo()
+    # which layouts the blocks ran on: one more product of every block into a scratch output (the hub-heavy first block takes the ordered
+    # layouts; a block of leaf rows may decline them -- no skew left)
+    for c in range(chunks):
+        t = gb.Vector(ws[c].dtype, size=h)
+        t << As[c].mxv(ov.current_u(), gb.semiring.min_plus if kind == "min_plus" else gb.semiring.lor_land)
+        st = device.last_stats()
+        ordered.append((int(st["ordered"]), int(st["reorders"])))
+    q.put((rank, (ui.tolist(), uv.tolist(), ordered, ov.staged)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind,chunks,world,B", [("min_plus", 2, 2, 8), ("lor_land", 2, 2, 8), ("min_plus", 1, 2, 64), ("lor_land", 1, 2, 16)])
+def test_block_cyclic_ranked_step(kind, chunks, world, B):
+    """The step of `bench.py --gpus N --ranked`: the graph relabelled by popularity, every rank holding the stripes r, r + world, ... of B rows
+    (in `chunks` blocks of local rows), the matrices hinted as ranked (ordered layouts in the caller's labels, nothing permuted), the slices
+    gathered rank-major and dealt back stripe by stripe.  Three steps equal the single-process oracle on the whole relabelled graph."""
+    import torch
+
+    from graphblas_amd import synthetic
+    from oracle import grb_oracle as O
+
+    scale, iters = 10, 3
+    res = _spawn(_cyclic_worker, world, (scale, iters, chunks, kind, B))
+    n = 1 << scale
+    ip, col = synthetic.rmat_csr(scale, device="cpu", relabel="popularity")
+    indeg = np.bincount(col.numpy(), minlength=n)
+    # the labels are popularity ranks of the edge stream (duplicates counted): near-monotone column counts after the dedupe
+    assert indeg[: n // 8].sum() > 0.6 * indeg.sum() and indeg[: n // 64].min() >= indeg[n // 2:].max()
+    g = torch.Generator().manual_seed(11)
+    dist0 = torch.randint(0, 1000, (n,), generator=g).to(torch.float32).numpy()
+    frontier = (torch.rand(n, generator=g) < 0.3).numpy()
+    visited = (torch.rand(n, generator=g) < 0.5).numpy()
+    ovis = O.OVec(n, np.flatnonzero(visited), np.ones(int(visited.sum()), bool), "BOOL")
+    if kind == "min_plus":
+        oa = O.OMat(n, n, ip.numpy(), col.numpy().astype(np.int64), synthetic.edge_weights(col, scale).numpy(), "FP32")
+        ou = O.OVec(n, np.arange(n), dist0, "FP32")
+        for _ in range(iters):
+            ou = O.mxv(oa, ou, "min_plus", w=ou, mask=ovis, mask_comp=True, mask_struct=True, accum="min")
+    else:
+        oa = O.OMat(n, n, ip.numpy(), col.numpy().astype(np.int64), np.ones(col.numel(), bool), "BOOL")
+        fi = np.flatnonzero(frontier)
+        ou = O.OVec(n, fi, np.ones(fi.size, bool), "BOOL")
+        for _ in range(iters):
+            ou = O.mxv(oa, ou, "lor_land", w=ou, mask=ovis, mask_comp=True, mask_struct=True, replace=True)
+        assert ou.idx.size > 0
+    for r in range(world):
+        assert res[r][0] == ou.idx.tolist() and res[r][1] == ou.vals.tolist()
+        assert res[r][2][0] == (1, 0) and all(o[1] == 0 for o in res[r][2]), res[r][2]  # ordered layouts, no vector converted
+        assert res[r][3] is False
+
+
 def _any_worker(rank, world, port, q):
     gb, dist = _init(rank, world, port)
     from graphblas_amd import sharded
