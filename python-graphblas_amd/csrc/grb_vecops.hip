@@ -661,7 +661,13 @@ extern "C" GrB_Info GrB_Vector_removeElement(GrB_Vector w, GrB_Index i)
     {                                                                                                                                   \
         GRB_TRY                                                                                                                         \
         require_init();                                                                                                                 \
-        check_vector_any(u, "u");  /* (a reduction does not care where the elements are) */                                            \
+        /* (a reduction does not care where the elements are -- except a floating-point PLUS / TIMES, whose rounding depends on the  */ \
+        /*  order of the fold: those see the natural order, so the result does not depend on what an earlier product left behind)     */ \
+        check_vector_any(u, "u");                                                                                                       \
+        if (monoid && u->order && (monoid->type == TC_FP32 || monoid->type == TC_FP64)) {                                               \
+            const int mop = canonical_op(monoid->type, monoid->op);                                                                     \
+            if (mop == OP_PLUS || mop == OP_TIMES) check_vector(u, "u");                                                                \
+        }                                                                                                                               \
         (void)desc;                                                                                                                     \
         reduce_to<ctype>(val, accum, monoid, u);                                                                                        \
         GRB_CATCH(errp(u))                                                                                                              \

@@ -178,6 +178,33 @@ def test_ordered_vectors_through_every_exit(gb, seed):
         set_opts(RESTORE)
 
 
+@pytest.mark.parametrize("tname", ["FP32", "FP64"])
+def test_fp_plus_reduction_does_not_depend_on_the_stored_order(gb, tname):
+    """a floating-point PLUS / TIMES reduction rounds differently in another fold order, and whether an earlier product left the
+    vector in a matrix's vertex order is hidden state -- such reductions see the natural order.  The sum of a vector a product has just left
+    ordered equals, bit for bit, the sum of the same entries built as a fresh (natural) vector."""
+    from graphblas_amd import device
+
+    rng = np.random.default_rng(991)
+    n = 2900
+    rows, cols, _ = skewed_square(rng, n, tname)
+    vals = (rng.random(rows.size) * 10.0 ** rng.integers(-3, 4, rows.size)).astype(O.NP_OF[tname])
+    uv = (rng.random(n) * 10.0 ** rng.integers(-3, 4, n)).astype(O.NP_OF[tname])
+    try:
+        set_opts(ORDER_OPTS + ((b"hot_k", 256),))
+        A = gb.Matrix.from_coo(rows, cols, vals, dtype=tname, nrows=n, ncols=n, dup_op=gb.binary.min)
+        u = gb.Vector.from_coo(np.arange(n), uv, dtype=tname, size=n)
+        for mon in (gb.monoid.plus, gb.monoid.times):
+            w = A.mxv(u, gb.semiring.min_plus).new()
+            assert device.last_stats()["ordered"] == 1
+            got = w.reduce(mon).new().value  # (w is in the matrix's order when the reduction is called)
+            wi, wv = w.to_coo()
+            fresh = gb.Vector.from_coo(wi, wv, dtype=tname, size=n)
+            assert got == fresh.reduce(mon).new().value
+    finally:
+        set_opts(RESTORE)
+
+
 def _on_gpu():
     from tests import backend
 
