@@ -139,7 +139,10 @@ class MxvWorkload:
             h = n // (world * chunks)
             if stripe % 8 or h % stripe or n % (64 * world * chunks):
                 raise SystemExit("bench.py --ranked: --stripe must be a multiple of 8 rows and divide n / (ranks * chunks)")
-            self._gid = synthetic.stripe_rows(n, stripe, world, rank)
+            gid_all = synthetic.stripe_rows(n, stripe, world, rank)
+            # (the rank's stripes are dealt to its chunks cyclically too: chunk c = local stripes c, c + chunks, ...; _gid is chunk-major)
+            self._chunk_rows = [sharded.cyclic_chunk_rows(n // world, stripe, chunks, c) for c in range(chunks)]
+            self._gid = torch.cat([gid_all[sel] for sel in self._chunk_rows])
             ranges = [(c * h, (c + 1) * h) for c in range(chunks)]
         if ranked and block:
             self._gid = synthetic.stripe_rows(n, stripe, block[1], block[0])
@@ -150,12 +153,16 @@ class MxvWorkload:
         if ranked:
             deal = (stripe, block[1], block[0]) if block else ((stripe, world, rank) if sharded_path else None)
             ip_l, col_l = synthetic.rmat_csr(scale, device="cuda", relabel="popularity", stripes=deal)
-            graphs = []
-            for lo, hi in ranges:  # (the rank's local rows cut into its blocks)
-                e0, e1 = int(ip_l[lo].item()), int(ip_l[hi].item())
-                graphs.append(((ip_l[lo: hi + 1] - e0).contiguous(), col_l[e0:e1].contiguous()))
-            if len(ranges) == 1:
-                graphs = [(ip_l, col_l)]
+            graphs = [(ip_l, col_l)]
+            if len(ranges) > 1:  # (the rank's local rows dealt to its chunks: a row selection of the local CSR)
+                graphs = []
+                for sel in self._chunk_rows:
+                    lens = ip_l[sel + 1] - ip_l[sel]
+                    ip_c = torch.zeros(sel.numel() + 1, dtype=torch.int64, device="cuda")
+                    ip_c[1:] = torch.cumsum(lens, 0)
+                    src = torch.repeat_interleave(ip_l[sel] - ip_c[:-1], lens) + torch.arange(int(ip_c[-1].item()), device="cuda")
+                    graphs.append((ip_c, col_l[src].contiguous()))
+                    del lens, src
             del ip_l, col_l
         else:
             graphs = synthetic.rmat_csr(scale, device="cuda", row_ranges=ranges) if (block or sharded_path) else [synthetic.rmat_csr(scale, device="cuda")]

@@ -184,6 +184,15 @@ def allgather_delta_into(u_full, w_local, cuts, *, device="cuda", dense_above=0.
     return int(all_counts[:, 0].sum())
 
 
+def cyclic_chunk_rows(n_local, B, chunks, c, device="cuda"):
+    """LOCAL row numbers (in the rank's stripe order, ``synthetic.stripe_rows``) of chunk c of a block-cyclic rank: the stripes
+    c, c + chunks, c + 2 chunks, ... of B rows each."""
+    import torch
+
+    j = torch.arange(n_local // chunks, device=device)
+    return (torch.div(j, B, rounding_mode="floor") * chunks + c) * B + j % B
+
+
 def _gather_async(dist, out, part):
     """all-gather `part` of every rank into `out` (rank order), asynchronously; returns the work handle."""
     try:
@@ -206,9 +215,10 @@ class OverlappedMxv:
     ``cyclic=B`` (round 5): the rows are dealt to the ranks BLOCK-CYCLICALLY in stripes of B rows (global row (k * world + r) * B + i is
     local row k * B + i of rank r; B a multiple of 8) -- the sharding of a graph whose vertices are numbered by popularity
     (``GrX_Matrix_hint_ranked``: every rank's rows then carry the same mix of hubs and leaves, and the library builds its ordered layouts in
-    those labels).  Chunk c of a rank is its local rows c * h .. (c + 1) * h - 1.  The all-gather of a chunk lands in a staging buffer
-    (rank-major) and one strided copy per chunk deals the stripes into the replica the next step reads, after the collective: 2 x 4 bytes
-    per row more HBM traffic than the contiguous sharding, on rows / (world * chunks) * world elements.
+    those labels).  The chunks of a rank are interleaved the same way (its stripe k belongs to chunk k mod chunks: ``cyclic_chunk_rows``), so
+    that every chunk carries the same mix too and the exchange of one hides behind a product as long as its own.  The all-gather of a chunk
+    lands in a staging buffer (rank-major) and one strided copy per chunk deals the stripes into the replica the next step reads, after the
+    collective: 2 x 4 bytes per row more HBM traffic than the contiguous sharding.
 
     The products go straight to the C ABI (``GrB_mxv`` with pre-resolved handles).  ``device="cpu"``: the gloo tests over the
     emulator build, where the vectors' images live in host memory."""
@@ -300,8 +310,8 @@ class OverlappedMxv:
                 _gather(self.dist, G, send)
             else:
                 works.append(_gather_async(self.dist, G, send))
-            # u[(k * world + r) * b + i]  <-  G[r][k * b + i]   for the stripes k of this chunk
-            self._deal.append((out_full.view(-1, world, b)[c * k_c: (c + 1) * k_c], G.view(world, k_c, b).permute(1, 0, 2)))
+            # u[((j * chunks + c) * world + r) * b + i]  <-  G[r][j * b + i]   for the stripes j of this chunk
+            self._deal.append((out_full.view(k_c, self.chunks, world, b)[:, c], G.view(world, k_c, b).permute(1, 0, 2)))
         return works
 
     def _exchange(self, c, dst):

@@ -545,8 +545,9 @@ def _cyclic_worker(rank, world, port, q, scale, iters, chunks, kind, B):
     h = n // (world * chunks)
     As, ws, masks, ordered = [], [], [], []
     for c in range(chunks):
-        blk = M[c * h: (c + 1) * h]
-        rows_g = gid[c * h: (c + 1) * h]
+        sel = sharded.cyclic_chunk_rows(n // world, B, chunks, c, device="cpu").numpy()  # (local stripes c, c + chunks, ...)
+        blk = M[sel]
+        rows_g = gid[sel]
         vloc = np.flatnonzero(visited[rows_g])
         masks.append(gb.Vector.from_coo(vloc, np.ones(vloc.size, bool), dtype="BOOL", size=h))
         bip, bcol = torch.from_numpy(blk.indptr.astype(np.int64)), torch.from_numpy(blk.indices.astype(np.int32))
@@ -570,8 +571,7 @@ def _cyclic_worker(rank, world, port, q, scale, iters, chunks, kind, B):
     for _ in range(iters):
         ov.step()
     ui, uv = ov.current_u().to_coo()
-    # which layouts the blocks ran on: one more product of every block into a scratch output (the hub-heavy first block takes the ordered
-    # layouts; a block of leaf rows may decline them -- no skew left)
+    # which layouts the blocks ran on: one more product of every block into a scratch output (every chunk carries the same mix of rows)
     for c in range(chunks):
         t = gb.Vector(ws[c].dtype, size=h)
         t << As[c].mxv(ov.current_u(), gb.semiring.min_plus if kind == "min_plus" else gb.semiring.lor_land)
@@ -618,7 +618,7 @@ def test_block_cyclic_ranked_step(kind, chunks, world, B):
         assert ou.idx.size > 0
     for r in range(world):
         assert res[r][0] == ou.idx.tolist() and res[r][1] == ou.vals.tolist()
-        assert res[r][2][0] == (1, 0) and all(o[1] == 0 for o in res[r][2]), res[r][2]  # ordered layouts, no vector converted
+        assert all(o == (1, 0) for o in res[r][2]), res[r][2]  # ordered layouts on every chunk, no vector converted
         assert res[r][3] is False
 
 
