@@ -50,6 +50,11 @@ echo "== bench scale 20 (configs[1])"; timeout 600 python bench.py --scale 20 --
 echo "== config 0"; timeout 600 python bench.py --workload uniform_fp64 --steps 50 > "$OUT/bench_uniform_fp64.json" 2>/dev/null; line $OUT/bench_uniform_fp64.json
 echo "== kron26 rank 0 of 8 (configs[4] shape)"; timeout 900 python bench.py --workload kron26 --block 0/8 > "$OUT/kron26_block0of8.json" 2>/dev/null; line $OUT/kron26_block0of8.json
 echo "== row blocks of the scale-24 graph"; for w in 1 2 4 8; do timeout 600 python bench.py --block 0/$w --no-cpu-baseline --no-extra 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps({'block': '0/$w', 'ms_per_step': d['ms_per_step'], 'verified': d['verified']}))"; done > "$OUT/block_times_s24.jsonl"; cat "$OUT/block_times_s24.jsonl"
+echo "== ranked labels (GrX_Matrix_hint_ranked): whole graph, blocks of a block-cyclic dealing, Kronecker-26 block"
+for spec in "" "--block 0/2" "--block 0/4" "--block 0/8" "--block 7/8"; do
+  timeout 600 python bench.py --ranked $spec --no-cpu-baseline --no-extra 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps({'ranked': '$spec', 'ms_per_step': d['ms_per_step'], 'frac': d['roofline']['frac'], 'verified': d['verified'], 'ordered': d['stats'].get('ordered'), 'build_ms': d['layout_build_call_ms']}))"
+done > "$OUT/ranked_block_times_s24.jsonl"; cat "$OUT/ranked_block_times_s24.jsonl"
+timeout 900 python bench.py --workload kron26 --ranked --block 0/8 --no-cpu-baseline > "$OUT/kron26_ranked_block0of8.json" 2>/dev/null; line $OUT/kron26_ranked_block0of8.json
 echo "== BFS / SSSP loops"; timeout 600 python bench.py --workload bfs --steps 5 > "$OUT/bfs_s24.json" 2>/dev/null; line $OUT/bfs_s24.json; timeout 600 python bench.py --workload sssp --steps 3 > "$OUT/sssp_s24.json" 2>/dev/null; line $OUT/sssp_s24.json
 echo "== masked SpGEMM"; timeout 600 python bench.py --workload mxm_plus_times_masked --scale 20 --steps 5 --warmup 1 > "$OUT/mxm_masked_s20.json" 2>/dev/null; line $OUT/mxm_masked_s20.json; timeout 900 python bench.py --workload mxm_plus_times_masked --scale 22 --steps 3 --warmup 1 > "$OUT/mxm_masked_s22.json" 2>/dev/null; line $OUT/mxm_masked_s22.json
 echo "== SpGEMM scale 18"; timeout 600 python bench.py --workload mxm_plus_times --scale 18 --steps 5 --warmup 1 > "$OUT/mxm_s18.json" 2>/dev/null; line $OUT/mxm_s18.json
