@@ -304,6 +304,7 @@ typedef struct {
     int64_t ordered;          /* 1: the product ran on the matrix's popularity-ordered layouts with operands kept in that order */
     int64_t value_dict;       /* distinct values of the matrix when its hot-strip records carry one-byte value codes (0: full values) */
     int64_t fill_absent;      /* 1: a sparse operand was run as a full one with the multiply's absorbing value under its absent entries */
+    int64_t long_probe;       /* BOOL product under a terminal monoid (LOR.LAND, ANY.PAIR): entries of every admitted long row tested bottom-up before the item kernels (0 = not probed) */
 } GrX_Stats;
 GrB_Info GrX_last_stats(GrX_Stats *stats);
 /* T = A (+.x) B in row batches of A whose products fit `budget_bytes` of device memory; every batch runs the full two-pass
@@ -340,6 +341,9 @@ GrB_Info GrX_Matrix_cache_bytes(const GrB_Matrix A, uint64_t *bytes);
  *                   by column code) and run by k_mxv_rtile / k_mxv_rtile_bool where the call allows it: a compiled semiring over a full
  *                   operand (or lor.land / any.pair over presence / value pairs); 0: the tagged row groups everywhere; 2: the tiles on the
  *                   natural-order layouts of hot-coded matrices too (measured slower there)
+ *   "bool_probe"    (round 5) 8 (default; 0 .. 16): BOOL products under a terminal monoid (lor.land over an iso matrix, any.pair) with an operand
+ *                   that is not full test the first "bool_probe" entries of every admitted long row before the item kernels run -- the bottom-up
+ *                   step of a direction-optimising BFS: a row whose partner is found there is decided; 0: never
  *   "rows_head"     1 (default): the short rows of an ordered BOOL matrix multiplied with a BOOL operand that is not full run in persistent
  *                   workgroups that keep the presence / value pairs of the hottest columns in LDS; 0: never.
  *                   "rows_head_min_groups" (16384): ... for matrices with at least this many groups of 64 rows

@@ -111,6 +111,7 @@ struct Context {
     int64_t lazy_min_nnz = 1 << 22;  // ... for matrices with at least this many entries (smaller ones build at once)
     int push_mode = 1;               // 0 never push, 1 push when u has < n/64 entries, 2 always push (tests)
     int rows_tile = 1;               // 1: the short rows of an ordered matrix as sorted row tiles (k_mxv_rtile) where the call allows it (full operand, specialised semiring)
+    int bool_probe = 8;  // entries of a long row of a BOOL matrix tested by k_long_init before the item kernels (terminal monoids: LOR, ANY); 0 = off
     int rtile_rows = 8192;           // ... rows per tile (8192 or 16384; 8-byte accumulators: half)
     int64_t rtile_entries = 32768;   // ... and about this many entries
     int rows_head = 1;               // 1: the short rows of an ordered matrix run with the hottest columns of the operand in LDS (k_mxv_rows_tag<.., HEAD>)
@@ -357,6 +358,10 @@ struct GB_Matrix_opaque {
     void *d_rt_tiles = nullptr;        // RTile[rt_ntiles]
     int32_t *d_rt_order = nullptr;     // tile numbers, heaviest first (the order they are handed out in)
     unsigned int *d_rt_counter = nullptr;  // the hand-out counter of a call (zeroed by k_long_init)
+    // bottom-up probe (round 5, BOOL matrices with class items): the first probe_k column codes of every long row, k-major
+    // (d_probe[k * n_long + i]; -1 = the row has no k-th entry) -- k_long_init tests them before any item kernel runs
+    int32_t *d_probe = nullptr;
+    int probe_k = 0;
     int64_t rt_units = 0;
     int rt_ntiles = 0;
     int rt_rows4 = 0;                  // the tile height the layout was built for (rows with 4-byte accumulators)

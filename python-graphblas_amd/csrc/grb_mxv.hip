@@ -234,6 +234,7 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
         matrix_free(A->short_part);
         A->short_part = nullptr;
         dev_free(A->d_long_bits); dev_free(A->d_long_rows); dev_free(A->d_chunk_slot); dev_free(A->d_chunk_start); dev_free(A->d_chunk_len); dev_free(A->d_long_prefix);
+        dev_free(A->d_probe); A->d_probe = nullptr; A->probe_k = 0;
         dev_free(A->d_lcol); dev_free(A->d_lval); dev_free(A->d_it_start); dev_free(A->d_it_len); dev_free(A->d_it_slot);
         dev_free(A->d_item_begin);
         // (layouts derived from the short part go with it)
@@ -292,6 +293,16 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
                                (const int64_t *)S->d_ptr, (const int64_t *)lflag.p, (const int64_t *)nchunk.p, S->d_col,
                                (T *)S->d_val, A->d_long_rows, A->d_chunk_slot, A->d_chunk_start, A->d_chunk_len, A->d_long_prefix);
         })
+        // the bottom-up probe of a BOOL matrix (k_long_init): the first 16 column codes of every long row
+        dev_free(A->d_probe);
+        A->d_probe = nullptr;
+        A->probe_k = 0;
+        if (A->type->code == TC_BOOL && kind == 1 && nl * 16 < 0x7fffffffll) {
+            A->d_probe = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)(nl * 16));
+            hipLaunchKernelGGL(k_probe_fill, dim3((unsigned)ceil_div(nl * 16, 256)), dim3(256), 0, ctx().stream, (const int64_t *)A->d_ptr, col_src,
+                               (const int32_t *)A->d_long_rows, nl, 16, A->d_probe);
+            A->probe_k = 16;
+        }
         // class-partitioned copy of the long rows: sort the entries by (class, slot), cut the runs into items, sort the
         // items by (class, falling length), lay them out with 4-entry aligned starts
         const int64_t nnz_long = nnz - nnz_short;
@@ -1074,10 +1085,24 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
         }
         DevBuf<unsigned char> long_act8(hot_fast && a.has_mask ? (size_t)a.n_long : 1);
         a.long_act8 = long_act8.p;
+        // BOOL, a terminal monoid, the operand as pairs or presence bits: the first entries of every admitted long row are tested here
+        LongProbe pb{nullptr, 0, nullptr, nullptr, nullptr, 0u};
+        if constexpr (std::is_same<T, bool>::value && ((MON == OP_LOR && MUL == OP_LAND) || (MON == OP_ANY && MUL == OP_PAIR))) {
+            if (by_class && A->d_probe && ctx().bool_probe > 0 && !a.u_full && (a.u_pv != nullptr || !a.need_uval) && (a.a_iso || !a.need_aval) &&
+                a.col == (A->split_hot ? A->d_col_hot : A->d_col)) {
+                pb.probe = A->d_probe;
+                pb.k = std::min(ctx().bool_probe, A->probe_k);
+                pb.pv = a.u_pv;
+                pb.pbits = a.u_pv ? nullptr : (const uint32_t *)a.u_bits;
+                pb.iso_val = a.need_aval ? (const bool *)a.aval : nullptr;
+                pb.want = MON == OP_LOR ? 2u : 1u;
+                ctx().stats.long_probe = pb.k;
+            }
+        }
         hipLaunchKernelGGL((k_long_init<W>), dim3((unsigned)ceil_div(a.n_long, 256)), dim3(256), 0, ctx().stream, tl_val.p, tl_has.p,
                            a.n_long, monoid_identity<T, W>(a.monoid), a.long_rows, a.m_bits, a.has_mask, a.m_comp, long_act.p,
                            ((by_class || by_strip) && a.u_full) ? 1 : 0, (by_strip && acc_is_ordered<W>(a.monoid)) ? 1 : 0,
-                           (hot_fast && a.has_mask) ? long_act8.p : nullptr, A->rt_state == 1 ? A->d_rt_counter : nullptr);
+                           (hot_fast && a.has_mask) ? long_act8.p : nullptr, A->rt_state == 1 ? A->d_rt_counter : nullptr, pb);
         a.tl_ord = (by_strip && acc_is_ordered<W>(a.monoid)) ? 1 : 0;
         a.long_has_known = ((by_class || by_strip) && a.u_full) ? 1 : 0;
         a.tl_val = tl_val.p;
@@ -2146,6 +2171,7 @@ extern "C" GrB_Info GrX_Matrix_cache_bytes(const GrB_Matrix A, uint64_t *bytes)
         const GB_Matrix_opaque *S = A->short_part;
         b += 8ull * (A->nrows + 1) + (A->short_tagged_only ? 0 : 4ull * (uint64_t)S->nvals + (S->iso ? vs : vs * (uint64_t)S->nvals));
         b += bits_words64(A->nrows) * 8 + 4ull * (uint64_t)A->n_long + 4ull * bits_words64(A->nrows) + 16ull * (uint64_t)A->n_chunks;
+        if (A->d_probe) b += 4ull * (uint64_t)A->probe_k * (uint64_t)A->n_long;
         if (A->rt_state == 1) b += (uint64_t)A->rt_units * RT_EPL * (6 + (A->d_rt_val ? (A->vdict_n > 0 && vs == 4 ? 1 : vs) : 0)) + 36ull * (uint64_t)A->rt_ntiles;
         if (A->tg_state == 1) b += (uint64_t)A->tg_units * TAG_EPL * (5 + (A->d_tg_val ? (A->vdict_n > 0 ? 1 : vs) : 0)) + 12ull * ((A->nrows + 63) / 64);
         if (A->split_kind == 4 && (A->strip_nseg > 0 || A->ct_units > 0)) {

@@ -732,6 +732,7 @@ void matrix_invalidate_caches(GB_Matrix_opaque *A)
     A->pull_calls = 0;
     dev_free(A->d_tg_off); dev_free(A->d_tg_col); dev_free(A->d_tg_val); dev_free(A->d_tg_tag); dev_free(A->d_tg_nonempty);
     A->d_tg_off = nullptr; A->d_tg_col = nullptr; A->d_tg_val = nullptr; A->d_tg_tag = nullptr; A->d_tg_nonempty = nullptr;
+    dev_free(A->d_probe); A->d_probe = nullptr; A->probe_k = 0;
     dev_free(A->d_rt_col); dev_free(A->d_rt_tag); dev_free(A->d_rt_val); dev_free(A->d_rt_tiles); dev_free(A->d_rt_order); dev_free(A->d_rt_counter);
     A->d_rt_col = nullptr; A->d_rt_tag = nullptr; A->d_rt_val = nullptr; A->d_rt_tiles = nullptr; A->d_rt_order = nullptr; A->d_rt_counter = nullptr;
     A->rt_state = 0; A->rt_units = 0; A->rt_ntiles = 0;

@@ -20,7 +20,7 @@ ORDER_OPTS = ((b"order_min_nnz", 1), (b"lean_min_nnz", 1), (b"split_min_nnz", 1)
               (b"lazy_layout", 0), (b"vec_pad_min_bytes", 0), (b"rows_head_min_groups", 1))
 RESTORE = ((b"order_min_nnz", 24 << 20), (b"lean_min_nnz", 48 << 20), (b"split_min_nnz", 1 << 22), (b"split_min_len", 0), (b"push_mode", 1),
            (b"hot_min_cols", 1 << 20), (b"hot_k", 0), (b"lazy_layout", 1), (b"vec_pad_min_bytes", 1 << 20), (b"long_classes", 16), (b"order_mode", 1), (b"hub_min_len", 1024), (b"rows_head_min_groups", 16384), (b"rows_head", 1),
-           (b"rows_tile", 1), (b"rtile_rows", 8192), (b"rtile_entries", 32768))
+           (b"rows_tile", 1), (b"rtile_rows", 8192), (b"rtile_entries", 32768), (b"bool_probe", 8))
 
 
 @pytest.fixture(params=DEVICES)
@@ -599,6 +599,44 @@ def test_sorted_row_tiles_bool_step(gb, seed):
         w3(~m_arg if comp else m_arg, accum=accum, replace=repl) << A.mxv(u, getattr(gb.semiring, sr))
         assert device.last_stats()["fused_epilogue"] in (1, 2)
         same_vec(w3, exp)
+    finally:
+        set_opts(RESTORE)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_bottom_up_probe_of_long_bool_rows(gb, seed):
+    """The bottom-up probe (k_long_init, round 5): a BOOL product under a terminal monoid tests the first entries of every admitted long row
+    before the item kernels run; a row that finds a present (and, for lor.land, true) partner there is decided.  Frontiers from 0.1 % to
+    90 %, present-but-false entries, an iso matrix value of FALSE (no row may be decided), ordered and natural-order layouts, every probe
+    depth -- against the oracle, and the same with the probe switched off."""
+    from graphblas_amd import device
+
+    rng = np.random.default_rng(9900 + seed)
+    n = int(rng.integers(2500, 5000))
+    rows, cols, _ = skewed_square(rng, n, "BOOL")
+    iso_false = seed == 7
+    vals = np.zeros(rows.size, bool) if iso_false else np.ones(rows.size, bool)
+    sr = "lor_land" if iso_false else ["lor_land", "any_pair"][seed % 2]
+    ui = np.flatnonzero(rng.random(n) < [0.3, 0.02, 0.9, 0.001][seed % 4])
+    uv = rng.random(ui.size) < (0.5 if seed % 3 == 2 else 1.1)  # (seed 2, 5, 8, 11: half of the present entries are false)
+    mi, mv = rand_vec(rng, n, 0.5, "BOOL")
+    oa = O.OMat.from_coo(rows, cols, vals, n, n, "BOOL")
+    ou, om = O.OVec(n, ui, uv, "BOOL"), O.OVec(n, mi, mv, "BOOL")
+    exp = O.mxv(oa, ou, sr, mask=om, mask_comp=True, mask_struct=True, replace=True)
+    exp_nomask = O.mxv(oa, ou, sr)
+    try:
+        set_opts(ORDER_OPTS + ((b"order_mode", 0 if seed % 5 == 4 else 1),))
+        A = gb.Matrix.from_coo(rows, cols, vals, dtype="BOOL", nrows=n, ncols=n)
+        u = gb.Vector.from_coo(ui, uv, dtype="BOOL", size=n)
+        mk = gb.Vector.from_coo(mi, mv, dtype="BOOL", size=n)
+        for depth in (8, 0, 16, 1):
+            set_opts(((b"bool_probe", depth),))
+            w = gb.Vector("BOOL", size=n)
+            w(~mk.S, replace=True) << A.mxv(u, getattr(gb.semiring, sr))
+            st = device.last_stats()
+            assert st["long_kernel"] == 1 and st["long_probe"] == depth, st
+            same_vec(w, exp)
+            same_vec(A.mxv(u, getattr(gb.semiring, sr)).new(), exp_nomask)
     finally:
         set_opts(RESTORE)
 
