@@ -32,6 +32,7 @@ struct uint4 { unsigned x, y, z, w; };
 struct uint2 { unsigned x, y; };
 struct ulonglong2 { unsigned long long x, y; };
 inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
+inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
 
 extern uint3 threadIdx, blockIdx;
 extern dim3 blockDim, gridDim;
