@@ -1318,7 +1318,8 @@ def main():
         dist.destroy_process_group()
 
 
-MXV_KERNELS_NOTE = ("one GrB_mxv call: k_long_init + k_mxv_hstrip + k_mxv_ctile (k_long_compact_* + k_mxv_long_grp for BOOL matrices) + k_mxv_rtile (round 5: the short rows as "
+MXV_KERNELS_NOTE = ("one GrB_mxv call: k_long_init (BOOL under a terminal monoid: with the bottom-up probe of the long rows) + k_mxv_hstrip + k_mxv_ctile (k_long_compact_* + k_mxv_long_grp "
+                    "for BOOL matrices) + k_mxv_rtile (round 5: the short rows as "
                     "sorted row tiles; k_mxv_rtile_bool for BOOL operands given as presence / value pairs; k_mxv_rows_tag for the calls the tiles do not take) "
                     "(+ k_rows_tail when the write rule touches the empty tail) on the matrix's popularity-ordered layouts -- no per-call operand image; "
                     "k_x_image in front of them on the natural-order layouts (order_mode 0, row blocks of a sharded run); k_mxv_pull + k_mxv_seams below the split threshold")

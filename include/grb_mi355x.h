@@ -341,6 +341,9 @@ GrB_Info GrX_Matrix_cache_bytes(const GrB_Matrix A, uint64_t *bytes);
  *                   by column code) and run by k_mxv_rtile / k_mxv_rtile_bool where the call allows it: a compiled semiring over a full
  *                   operand (or lor.land / any.pair over presence / value pairs); 0: the tagged row groups everywhere; 2: the tiles on the
  *                   natural-order layouts of hot-coded matrices too (measured slower there)
+ *   "stream_nt_min_nnz" (round 5) 48 Mi: matrices with at least this many entries read the streams of their row tiles and cold tiles non-temporal
+ *                   (the streams no longer displace the operand's lines from L2); smaller ones -- whose layouts the 256 MB infinity cache keeps
+ *                   from call to call -- keep plain loads
  *   "bool_probe"    (round 5) 8 (default; 0 .. 16): BOOL products under a terminal monoid (lor.land over an iso matrix, any.pair) with an operand
  *                   that is not full test the first "bool_probe" entries of every admitted long row before the item kernels run -- the bottom-up
  *                   step of a direction-optimising BFS: a row whose partner is found there is decided; 0: never

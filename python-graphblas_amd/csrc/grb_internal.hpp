@@ -111,6 +111,7 @@ struct Context {
     int64_t lazy_min_nnz = 1 << 22;  // ... for matrices with at least this many entries (smaller ones build at once)
     int push_mode = 1;               // 0 never push, 1 push when u has < n/64 entries, 2 always push (tests)
     int rows_tile = 1;               // 1: the short rows of an ordered matrix as sorted row tiles (k_mxv_rtile) where the call allows it (full operand, specialised semiring)
+    int64_t stream_nt_min_nnz = 48ll << 20;  // matrices with at least this many entries stream their layouts non-temporal (k_mxv_rtile / _bool / k_mxv_ctile)
     int bool_probe = 8;  // entries of a long row of a BOOL matrix tested by k_long_init before the item kernels (terminal monoids: LOR, ANY); 0 = off
     int rtile_rows = 8192;           // ... rows per tile (8192 or 16384; 8-byte accumulators: half)
     int64_t rtile_entries = 32768;   // ... and about this many entries

@@ -1525,6 +1525,7 @@ static void mxv_core(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_Binar
     PullArgs a{};
     a.m = m;
     a.nnz = S->nvals;
+    a.stream_nt = S->nvals >= ctx().stream_nt_min_nnz ? 1 : 0;  // (a matrix much larger than the 256 MB infinity cache: its streams bypass the caches)
     a.rowptr = matrix_rowptr(S);
     a.col = S->d_col;
     a.aval = aval;

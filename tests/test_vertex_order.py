@@ -20,7 +20,7 @@ ORDER_OPTS = ((b"order_min_nnz", 1), (b"lean_min_nnz", 1), (b"split_min_nnz", 1)
               (b"lazy_layout", 0), (b"vec_pad_min_bytes", 0), (b"rows_head_min_groups", 1))
 RESTORE = ((b"order_min_nnz", 24 << 20), (b"lean_min_nnz", 48 << 20), (b"split_min_nnz", 1 << 22), (b"split_min_len", 0), (b"push_mode", 1),
            (b"hot_min_cols", 1 << 20), (b"hot_k", 0), (b"lazy_layout", 1), (b"vec_pad_min_bytes", 1 << 20), (b"long_classes", 16), (b"order_mode", 1), (b"hub_min_len", 1024), (b"rows_head_min_groups", 16384), (b"rows_head", 1),
-           (b"rows_tile", 1), (b"rtile_rows", 8192), (b"rtile_entries", 32768), (b"bool_probe", 8))
+           (b"rows_tile", 1), (b"rtile_rows", 8192), (b"rtile_entries", 32768), (b"bool_probe", 8), (b"stream_nt_min_nnz", 48 << 20))
 
 
 @pytest.fixture(params=DEVICES)
@@ -531,7 +531,8 @@ def test_sorted_row_tiles_match_the_oracle(gb, seed):
         #  hot table, the operand image [table | u] built per call -- carry the tiles too)
         natural = seed >= 12
         set_opts(ORDER_OPTS + ((b"rtile_rows", [8192, 16384][seed % 2]), (b"rtile_entries", [256, 700, 5000][seed % 3]), (b"hub_min_len", [100, 0][seed % 2]),
-                               (b"order_mode", 0 if natural else 1), (b"hot_k", 256 if natural else 0), (b"rows_tile", 2 if natural else 1)))
+                               (b"order_mode", 0 if natural else 1), (b"hot_k", 256 if natural else 0), (b"rows_tile", 2 if natural else 1),
+                               (b"stream_nt_min_nnz", [1, 48 << 20][(seed >> 1) & 1])))  # (1: the streams of the row tiles and cold tiles are read non-temporal)
         A = gb.Matrix.from_coo(rows, cols, vals, dtype=tname, nrows=n, ncols=n)
         u = gb.Vector.from_coo(ui, uv, dtype=tname, size=n)
         w = gb.Vector.from_coo(wi, wv, dtype=tname, size=n)
@@ -580,7 +581,8 @@ def test_sorted_row_tiles_bool_step(gb, seed):
     ou, ow, om = O.OVec(n, ui, uv, "BOOL"), O.OVec(n, wi, wv, "BOOL"), O.OVec(n, mi, mv, "BOOL")
     exp = O.mxv(oa, ou, sr, w=ow, mask=om, mask_comp=comp, mask_struct=struct, accum=accum, replace=repl)
     try:
-        set_opts(ORDER_OPTS + ((b"rtile_rows", [8192, 16384][seed % 2]), (b"rtile_entries", [256, 900, 6000][seed % 3])))
+        set_opts(ORDER_OPTS + ((b"rtile_rows", [8192, 16384][seed % 2]), (b"rtile_entries", [256, 900, 6000][seed % 3]),
+                             (b"stream_nt_min_nnz", [1, 48 << 20][(seed >> 1) & 1])))  # (1: the tiles' streams are read non-temporal)
         A = gb.Matrix.from_coo(rows, cols, vals, dtype="BOOL", nrows=n, ncols=n)
         u = gb.Vector.from_coo(ui, uv, dtype="BOOL", size=n)
         w = gb.Vector.from_coo(wi, wv, dtype="BOOL", size=n)
