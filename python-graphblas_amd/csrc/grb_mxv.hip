@@ -1109,7 +1109,8 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
         a.tl_has = tl_has.p;
         a.dbg = ctx().debug_flags;
         const int64_t ncb = ceil_div(A->n_items, (int64_t)COMPACT_BLOCK);
-        const bool compact = by_class && a.has_mask;
+        // (the items of the rows that are switched off -- by the mask, or decided by the bottom-up probe -- are compacted away per call)
+        const bool compact = by_class && (a.has_mask || pb.probe != nullptr);
         DevBuf<int64_t> act_start(compact ? (size_t)A->n_items : 1), block_cnt(compact ? (size_t)ncb + 1 : 1), class_off(9);
         DevBuf<int32_t> act_len(compact ? (size_t)A->n_items : 1), act_slot(compact ? (size_t)A->n_items : 1);
         if (by_strip) {

@@ -599,6 +599,22 @@ __global__ void k_pack_pv(const uint64_t *present, const bool *val, int64_t n, u
     if (w >= ((n + 15) >> 4)) return;
     const uint32_t p16 = (uint32_t)(present[w >> 2] >> ((w & 3) * 16)) & 0xffffu;
     uint32_t o = 0;
+    if (p16 == 0u) {  // (nothing present in these 16: the values are not read)
+        out[w] = 0u;
+        return;
+    }
+    if ((w << 4) + 16 <= n && (((uintptr_t)val) & 15) == 0) {
+        // the 16 one-byte values in one load (a byte load per element was 14 us per call at scale 24: a twentieth of the BFS level step)
+        const uint4 v = *(const uint4 *)(val + (w << 4));
+        const uint32_t vw[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const uint32_t b = (vw[k >> 2] >> ((k & 3) * 8)) & 0xffu;
+            if ((p16 >> k) & 1u) o |= (1u | (b ? 2u : 0u)) << (2 * k);
+        }
+        out[w] = o;
+        return;
+    }
     for (int k = 0; k < 16; k++) {
         const int64_t i = (w << 4) + k;
         if (i < n && ((p16 >> k) & 1u)) o |= (1u | (val[i] ? 2u : 0u)) << (2 * k);
