@@ -2,6 +2,7 @@
 // Counterpart of the reference's `initialize(blocking=..., memory_manager="numpy")` call at
 // graphblas/__init__.py:170-173 (there: SuiteSparse GrB_init on the host; here: a gfx950 device is
 // mandatory -- there is no CPU fallback).
+#include <chrono>
 #include <algorithm>
 #include <cstdlib>
 #include <mutex>
@@ -135,31 +136,85 @@ void dev_free(void *p)
     (void)hipFreeAsync(p, ctx().stream);
 }
 
-void h2d(void *dst, const void *src, size_t bytes)
+// Host <-> device copies of the library's own small tables (tile descriptors, class bounds, counts): through page-locked memory of the
+// context -- 4 KiB for the scalars, STAGE_BYTES for the tables -- instead of the runtime's staging of pageable memory.  Measured on the
+// layout-building call of the headline matrix (profiles/r05/layout_build_timeline.txt): host time inside its 26 hipMemcpyAsync calls
+// 13.0 -> 6.6 ms; the call's wall time does not move (44 ms: 39 ms of kernels, the waits reappear in the synchronisations).
+// Larger copies (the caller's tuples at ingress / egress) keep the runtime's path.
+static constexpr size_t STAGE_BYTES = 8u << 20;
+static void *stage_block(size_t bytes)
 {
-    if (bytes) {
-        GRB_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx().stream));
-        GRB_HIP(hipStreamSynchronize(ctx().stream));  // the caller's host buffer is only borrowed for the call
-    }
-}
-void d2h(void *dst, const void *src, size_t bytes)
-{
-    // (entry counts, reduced scalars, the push path's counters: a copy into pageable memory is staged by the runtime -- the page-locked
-    //  block takes them directly)
     Context &c = ctx();
-    if (bytes && bytes <= 4096) {
+    if (bytes <= 4096) {
         if (!c.host_pinned && hipHostMalloc(&c.host_pinned, 4096, 0) != hipSuccess) {
             (void)hipGetLastError();
             c.host_pinned = nullptr;
         }
-        if (c.host_pinned) {
-            GRB_HIP(hipMemcpyAsync(c.host_pinned, src, bytes, hipMemcpyDeviceToHost, c.stream));
+        if (c.host_pinned) return c.host_pinned;
+    }
+    if (bytes <= STAGE_BYTES) {
+        if (!c.host_stage && !c.host_stage_failed && hipHostMalloc(&c.host_stage, STAGE_BYTES, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            c.host_stage = nullptr;
+            c.host_stage_failed = true;
+        }
+        return c.host_stage;
+    }
+    return nullptr;
+}
+void preload_stage() { (void)stage_block(4096); (void)stage_block(STAGE_BYTES); }
+// (GRB_TRACE_COPIES=1: every host <-> device copy of the library that holds the host for more than 0.5 ms, on stderr)
+static bool trace_copies()
+{
+    static const bool on = [] { const char *e = getenv("GRB_TRACE_COPIES"); return e && atoi(e) != 0; }();
+    return on;
+}
+struct CopyTrace {
+    const char *what;
+    size_t bytes;
+    bool staged;
+    std::chrono::steady_clock::time_point t0;
+    CopyTrace(const char *w, size_t b, bool s) : what(w), bytes(b), staged(s), t0(std::chrono::steady_clock::now()) {}
+    ~CopyTrace()
+    {
+        if (!trace_copies()) return;
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (ms > 0.5) fprintf(stderr, "[grb copy] %s %zu bytes %s: %.2f ms\n", what, bytes, staged ? "staged" : "direct", ms);
+    }
+};
+void h2d(void *dst, const void *src, size_t bytes)
+{
+    if (!bytes) return;
+    Context &c = ctx();
+    if (void *st = stage_block(bytes)) {
+        CopyTrace tr("h2d", bytes, true);
+        memcpy(st, src, bytes);
+        GRB_HIP(hipMemcpyAsync(dst, st, bytes, hipMemcpyHostToDevice, c.stream));
+        GRB_HIP(hipStreamSynchronize(c.stream));  // (the block is free for the next copy)
+        return;
+    }
+    CopyTrace tr("h2d", bytes, false);
+    GRB_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c.stream));
+    GRB_HIP(hipStreamSynchronize(c.stream));  // the caller's host buffer is only borrowed for the call
+}
+void d2h(void *dst, const void *src, size_t bytes)
+{
+    // (entry counts, reduced scalars, the push path's counters, tile tables: a copy into pageable memory is staged by the runtime -- the
+    //  page-locked blocks take them directly)
+    Context &c = ctx();
+    if (bytes) {
+        if (void *st = stage_block(bytes)) {
+            CopyTrace tr("d2h", bytes, true);
+            GRB_HIP(hipMemcpyAsync(st, src, bytes, hipMemcpyDeviceToHost, c.stream));
             GRB_HIP(hipStreamSynchronize(c.stream));
-            memcpy(dst, c.host_pinned, bytes);
+            memcpy(dst, st, bytes);
             return;
         }
+        CopyTrace tr("d2h", bytes, false);
+        GRB_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c.stream));
+        GRB_HIP(hipStreamSynchronize(c.stream));
+        return;
     }
-    if (bytes) GRB_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c.stream));
     GRB_HIP(hipStreamSynchronize(c.stream));
 }
 void d2d(void *dst, const void *src, size_t bytes)
@@ -208,6 +263,7 @@ extern "C" GrB_Info GrB_init(GrB_Mode mode)
         preload_vecops();
         preload_object();
         preload_prim();
+        preload_stage();  // (the page-locked blocks of h2d / d2h: not inside the first matrix's layout build)
     }
     if (const char *e = getenv("GRB_DEBUG_FLAGS")) c.debug_flags = atoi(e) & DEBUG_FLAGS_MASK;
     // tuning knobs from the environment go through the same validation as GrX_option_set (an invalid value is ignored)
@@ -256,6 +312,9 @@ extern "C" GrB_Info GrB_finalize(void)
     (void)hipStreamSynchronize(c.stream);
     if (c.host_pinned) (void)hipHostFree(c.host_pinned);
     c.host_pinned = nullptr;
+    if (c.host_stage) (void)hipHostFree(c.host_stage);
+    c.host_stage = nullptr;
+    c.host_stage_failed = false;
     if (c.ev0) (void)hipEventDestroy(c.ev0);
     if (c.ev1) (void)hipEventDestroy(c.ev1);
     c.ev0 = c.ev1 = nullptr;

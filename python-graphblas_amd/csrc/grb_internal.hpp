@@ -128,6 +128,8 @@ struct Context {
                                          // 0.102 -> 0.080 masked on the ordered layouts; scale 20 (16.8 M) 0.067 -> 0.072: the crossover lies between.  The twin
                                          // always takes the lean layouts (hot strips + cold tiles + row tiles), whatever lean_min_nnz says
     int64_t reorder_count = 0;       // vectors converted between vertex orders so far (cumulative)
+    void *host_stage = nullptr;      // 8 MiB of page-locked host memory: the library's own tables travel through it in both directions (grb_context.hip)
+    bool host_stage_failed = false;
     void *host_pinned = nullptr;     // 4 KiB of page-locked host memory: small device-to-host reads land here (no staging copy in the runtime)
     unsigned long long *push_counters = nullptr;  // the thin push path's counters (grb_mxv_push.inc): two sets of four words, used in turn --
     int push_parity = 0;                          // a call's frontier kernel zeroes the set of the next call
@@ -165,6 +167,7 @@ struct DevBuf {  // RAII temporary
 
 // one per translation unit with kernels: touches a kernel so that the HIP runtime loads the unit's code object (GrB_init)
 void preload_mxv();
+void preload_stage();
 void preload_mxm();
 void preload_vecops();
 void preload_object();
