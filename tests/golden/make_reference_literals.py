@@ -185,6 +185,34 @@ vector_ops = [
      "semiring": "plus_pair", "expect_scalar": 12},
     {"name": "resize_vector", "cite": "graphblas/tests/test_vector.py:182-191", "op": "resize", "w": "v7", "to": [4],
      "expect": V([1, 3], [1, 1], 4)},
+    # (round 5, last session) the literals of the element / index-list / transpose / aggregator tests that tests/test_reference_parity.py
+    # used to restate in its bodies
+    {"name": "extract_element_v", "cite": "graphblas/tests/test_vector.py:267-269,282,293", "op": "extract_element", "u": "v7",
+     "probes": [[1, 1], [6, 0], [4, 2], [0, None]]},
+    {"name": "set_element_v", "cite": "graphblas/tests/test_vector.py:281-287", "op": "set_element", "w": "v7",
+     "sets": [[0, 12], [1, 9]], "expect": V([0, 1, 3, 4, 6], [12, 9, 1, 2, 0])},
+    {"name": "remove_element_v", "cite": "graphblas/tests/test_vector.py:290-293", "op": "remove_element", "w": "v7", "index": 1,
+     "expect": V([3, 4, 6], [1, 2, 0])},
+    {"name": "extract_index_list", "cite": "graphblas/tests/test_vector.py:426-434", "op": "extract", "u": "v7", "indices": [1, 3, 5],
+     "expect": V([0, 1], [1, 1], 3)},
+    {"name": "assign_vector_index_list", "cite": "graphblas/tests/test_vector.py:505-510", "op": "assign_vector", "w": "v7",
+     "indices": [0, 2, 4], "u": V([0, 2], [9, 8], 3), "expect": V([0, 1, 3, 4, 6], [9, 1, 1, 8, 0])},
+    {"name": "assign_scalar_index_list", "cite": "graphblas/tests/test_vector.py:520-524", "op": "assign_scalar_at", "w": "v7",
+     "indices": [1, 3, 5], "value": 9, "expect": V([1, 3, 4, 5, 6], [9, 9, 2, 9, 0])},
+    {"name": "transpose", "cite": "graphblas/tests/test_matrix.py:1700-1707", "op": "transpose", "A": "A7",
+     "expect": M([0, 1, 2, 2, 2, 3, 3, 4, 4, 5, 5, 6], [3, 0, 3, 5, 6, 0, 6, 1, 6, 2, 4, 1], [3, 2, 3, 1, 5, 3, 7, 8, 3, 1, 7, 4])},
+    {"name": "resize_matrix_grow", "cite": "graphblas/tests/test_matrix.py:197-201", "op": "resize", "A": "A7", "to": [10, 11],
+     "expect": M([3, 0, 3, 5, 6, 0, 6, 1, 6, 2, 4, 1], [0, 1, 2, 2, 2, 3, 3, 4, 4, 5, 5, 6], [3, 2, 3, 1, 5, 3, 7, 8, 3, 1, 7, 4], 10, 11)},
+    {"name": "resize_vector_grow", "cite": "graphblas/tests/test_vector.py:185-188", "op": "resize", "w": "v7", "to": [20],
+     "expect": V([1, 3, 4, 6], [1, 1, 2, 0], 20)},
+    {"name": "reduce_scalar_exists", "cite": "graphblas/tests/test_matrix.py:1429", "op": "agg_exists_scalar", "A": "A7", "expect_scalar": 1},
+    {"name": "vector_reduce_exists", "cite": "graphblas/tests/test_vector.py:935", "op": "agg_exists_scalar", "u": "v7", "expect_scalar": 1},
+    {"name": "vector_reduce_max", "cite": "graphblas/tests/test_vector.py:1050-1052", "op": "reduce", "u": "v7", "monoid": "max",
+     "expect_scalar": 2},
+    {"name": "agg_sum_rowwise", "cite": "graphblas/tests/test_matrix.py:1364-1368", "op": "reduce_rowwise", "A": "A7", "monoid": "plus",
+     "agg": "sum", "expect": V([0, 1, 2, 3, 4, 5, 6], [5, 12, 1, 6, 7, 1, 15])},
+    {"name": "agg_sum_columnwise", "cite": "graphblas/tests/test_matrix.py:1394-1398", "op": "reduce_columnwise", "A": "A7", "monoid": "plus",
+     "agg": "sum", "expect": V([0, 1, 2, 3, 4, 5, 6], [3, 2, 9, 10, 11, 8, 4])},
 ]
 
 if __name__ == "__main__":

@@ -1,5 +1,5 @@
 """Every known-answer literal the reference's own tests and docs hold for the path (tests/golden/reference_literals.json: 25 mxm / mxv /
-vxm cases, the primer's SSSP loop, 16 cases of the operations around the path), run THROUGH THE LIBRARY from the data file -- the HIP
+vxm cases, the primer's SSSP loop, 30 cases of the operations around the path), run THROUGH THE LIBRARY from the data file -- the HIP
 kernels on the GPU tier, the same sources under the wave64 emulator on the CPU tier.  The fixtures are data (inputs and expected outputs
 with the reference line each comes from); this file holds no transcription of the reference's test bodies: one generic runner turns a
 case record into calls of the host API.  (tests/test_oracle_golden.py pins the ORACLE on the same records.)"""
@@ -98,9 +98,7 @@ def test_primer_sssp_through_the_library(gb):
     check(v, s["expect"])
 
 
-@pytest.mark.parametrize("case", [c for c in _G["vector_ops"] if c["op"] in ("reduce", "ewise_mult", "ewise_add", "reduce_rowwise", "reduce_columnwise",
-                                                                              "reduce_scalar", "assign_scalar")],
-                         ids=lambda c: c["name"])
+@pytest.mark.parametrize("case", _G["vector_ops"], ids=lambda c: c["name"])
 def test_operations_around_the_path_through_the_library(gb, case):
     op = case["op"]
     if op == "reduce":
@@ -111,11 +109,63 @@ def test_operations_around_the_path_through_the_library(gb, case):
         check(got, case["expect"])
     elif op in ("reduce_rowwise", "reduce_columnwise"):
         A = obj(gb, case["A"])
-        got = (A.reduce_columnwise if op == "reduce_columnwise" else A.reduce_rowwise)(getattr(gb.monoid, case["monoid"])).new()
+        how = getattr(gb.agg, case["agg"]) if "agg" in case else getattr(gb.monoid, case["monoid"])  # (an aggregator or the monoid behind it)
+        got = (A.reduce_columnwise if op == "reduce_columnwise" else A.reduce_rowwise)(how).new()
         check(got, case["expect"])
     elif op == "reduce_scalar":
         assert obj(gb, case["A"]).reduce_scalar(getattr(gb.monoid, case["monoid"])).new().value == case["expect_scalar"]
-    else:  # assign_scalar
+    elif op == "resize":
+        x = obj(gb, case["A"] if "A" in case else case["w"])
+        x.resize(*case["to"])
+        check(x, case["expect"])
+    elif op == "agg_matvec":  # the exists / count aggregators: one semiring mat-vec inside the host (agg.py)
+        A = obj(gb, case["A"])
+        ag = {"any_pair": gb.agg.exists, "plus_pair": gb.agg.count}[case["semiring"]]
+        check((A.reduce_columnwise if case.get("columns") else A.reduce_rowwise)(ag).new(), case["expect"])
+    elif op == "agg_matvec_scalar":
+        ag = {"any_pair": gb.agg.exists, "plus_pair": gb.agg.count}[case["semiring"]]
+        assert obj(gb, case["A"]).reduce_scalar(ag).new().value == case["expect_scalar"]
+    elif op == "agg_exists_scalar":
+        got = obj(gb, case["A"]).reduce_scalar(gb.agg.exists).new() if "A" in case else obj(gb, case["u"]).reduce(gb.agg.exists).new()
+        assert got.value == case["expect_scalar"]
+    elif op == "extract_element":
+        u = obj(gb, case["u"])
+        for i, want in case["probes"]:
+            assert u[i].new().value == want
+    elif op == "set_element":
+        w = obj(gb, case["w"])
+        for k, (i, x) in enumerate(case["sets"]):
+            if k % 2:
+                w[i] << x  # (both spellings of the reference's test)
+            else:
+                w[i] = x
+        check(w, case["expect"])
+    elif op == "remove_element":
+        w = obj(gb, case["w"])
+        del w[case["index"]]
+        check(w, case["expect"])
+    elif op == "extract":
+        u = obj(gb, case["u"])
+        w = gb.Vector(u.dtype, len(case["indices"]))
+        w << u[case["indices"]]
+        check(w, case["expect"])
+        check(u[np.array(case["indices"])].new(), case["expect"])
+    elif op == "assign_vector":
+        w = obj(gb, case["w"])
+        w[case["indices"]] = obj(gb, case["u"])
+        check(w, case["expect"])
+    elif op == "assign_scalar_at":
+        w = obj(gb, case["w"])
+        w[case["indices"]] = case["value"]
+        check(w, case["expect"])
+    elif op == "transpose":
+        A = obj(gb, case["A"])
+        check(A.T.new(), case["expect"])
+        C = gb.Matrix(A.dtype, A.ncols, A.nrows)
+        C << A.T
+        check(C, case["expect"])
+    else:
+        assert op == "assign_scalar", op
         w = obj(gb, case["w"])
         if "mask" in case:
             m = obj(gb, case["mask"]).V

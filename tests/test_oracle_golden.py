@@ -63,6 +63,32 @@ def test_reference_literal_vector_ops(case):
             keep = src.idx < case["to"][0]
             got = O.OVec(case["to"][0], src.idx[keep], src.vals[keep], src.tname)
         same(got, case["expect"])
+    elif op == "extract_element":  # (element access is the vector's own content: the oracle's dense view)
+        has, val = get(case["u"]).dense()
+        for i, want in case["probes"]:
+            assert (int(val[i]) if has[i] else None) == want
+    elif op == "set_element":  # GrB_Vector_setElement = assign of a scalar at one index
+        w = get(case["w"])
+        for i, x in case["sets"]:
+            w = O.vec_assign(w, x, [i])
+        same(w, case["expect"])
+    elif op == "remove_element":  # GrB_Vector_removeElement: the entry leaves the pattern
+        w = get(case["w"])
+        keep = w.idx != case["index"]
+        same(O.OVec(w.size, w.idx[keep], w.vals[keep], w.tname), case["expect"])
+    elif op == "extract":
+        u = get(case["u"])
+        same(O.vec_extract(O.OVec.empty(len(case["indices"]), u.tname), u, case["indices"]), case["expect"])
+    elif op == "assign_vector":
+        same(O.vec_assign(get(case["w"]), get(case["u"]), case["indices"]), case["expect"])
+    elif op == "assign_scalar_at":
+        same(O.vec_assign(get(case["w"]), case["value"], case["indices"]), case["expect"])
+    elif op == "transpose":
+        same(get(case["A"]).transpose(), case["expect"])
+    elif op == "agg_exists_scalar":  # exists = any_pair over the whole object (reference core/operator/agg.py:264-283): 1 iff it holds an entry
+        x = get(case["A"] if "A" in case else case["u"])
+        nvals = x.nvals if "A" in case else len(x.idx)
+        assert (1 if nvals else None) == case["expect_scalar"]
     else:
         raise AssertionError(op)
 
