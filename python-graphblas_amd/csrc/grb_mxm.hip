@@ -720,7 +720,11 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const 
     constexpr int UPB = WAVES / WPU;          // units per workgroup
     constexpr int NB = 2;  // batches of entries of A a wavefront keeps (range of B inside the window) from pass A for pass B
     __shared__ unsigned long long s_bits[UPB][WORDS];
-    __shared__ int s_wpre[NUMERIC ? UPB : 1][NUMERIC ? WORDS : 1];
+    // (the words' prefix counts as 16-bit numbers where the unit's bitmap holds at most 65536 bits: what decides how many workgroups a CU holds
+    //  is LDS -- with groups of two windows the one-wavefront class took 44032 bytes, three workgroups per CU; 39936 are four.  Last session
+    //  of round 5, profiles/r05/mxm_lds_occupancy.txt)
+    using WPre = typename std::conditional<(WIN <= 65536), unsigned short, int>::type;
+    __shared__ WPre s_wpre[NUMERIC ? UPB : 1][NUMERIC ? WORDS : 1];
     // how a wavefront finds the entry of A a product belongs to: by rank in a bitmap of first product numbers, or -- the numeric
     // one-wavefront class, measured 3 ms faster with it -- by binary search in the scan of the range lengths (round 2)
     constexpr bool SEARCH_DEAL = NUMERIC && WPU == 1;
@@ -766,7 +770,7 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const 
         else __syncthreads();
     };
     unsigned long long *bits = s_bits[uib];
-    int *wpre = s_wpre[NUMERIC ? uib : 0];
+    WPre *wpre = s_wpre[NUMERIC ? uib : 0];
     unsigned long long *recm = s_recm[wave];
     short *recb = s_recb[wave];
     int *scan = s_scan[wave];
@@ -997,7 +1001,7 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const 
             int pre = incl - c;
 #pragma unroll
             for (int x = 0; x < WPL; x++) {
-                wpre[lane * WPL + x] = pre;
+                wpre[lane * WPL + x] = (WPre)pre;
                 pre += __popcll(mine[x]);
             }
         }
@@ -1035,7 +1039,7 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const 
                     const int j = d.j - c0;
                     const unsigned long long word = bits[j >> 6];
                     if ((MASKED || cmask) && !((word >> (j & 63)) & 1ull)) return;
-                    const int rank = wpre[j >> 6] + __popcll(word & ((1ull << (j & 63)) - 1ull)) - r0;
+                    const int rank = (int)wpre[j >> 6] + __popcll(word & ((1ull << (j & 63)) - 1ull)) - r0;
                     if ((unsigned)rank < (unsigned)CAP && !MXM_ABL(a, 4)) {
                         const W v = (W)apply_binop<T>(mult_, d.av, d.bv);
                         if (monoid_ == OP_ANY) acc[rank] = v;
@@ -1830,7 +1834,9 @@ static void launch_unit_classes(MxmArgs &a, const uint32_t *rows, int64_t nrows,
             hipLaunchKernelGGL((k_spgemm_unit<T, MODE, 4, 1024, F>), dim3(grid8(nu)), dim3(256), 0, ctx().stream, a, rows, 0, 0, u, nu);
         });
         per_class(c0 + 2, [&](const UnitRec *u, int64_t nu) {
-            hipLaunchKernelGGL((k_spgemm_unit<T, MODE, GRB_MU_M2_WPU, 4096, F>), dim3(grid8(nu)), dim3(64 * GRB_MU_M2_WPU), 0, ctx().stream, a, rows, 0, 0, u, nu);
+            // (group units: 128 accumulators fewer -- 40448 bytes of LDS, four workgroups per CU instead of three; a unit of more than
+            //  3968 entries takes a second pass over its products)
+            hipLaunchKernelGGL((k_spgemm_unit<T, MODE, GRB_MU_M2_WPU, (F == 1 ? 4096 : 3968), F>), dim3(grid8(nu)), dim3(64 * GRB_MU_M2_WPU), 0, ctx().stream, a, rows, 0, 0, u, nu);
         });
     };
     if constexpr (MODE == MU_NUMERIC) {
