@@ -112,3 +112,19 @@ def test_raw_entry_takes_ownership_and_nulls_the_cells(gb):
     assert rc != 0 and not h.value and ap.value and aj.value and ax.value
     for cell in (ap, aj, ax):
         libc.free(cell)
+
+
+@pytest.mark.parametrize("count", [300, 600, 150_000, 1_200_000])
+def test_host_copies_staged_and_direct(gb, count):
+    """The caller's tuples cross the boundary through the context's page-locked blocks (up to 4 KiB / 8 MiB per array: csrc/grb_context.hip
+    h2d / d2h) or straight from / to the caller's memory (larger): 2.4 KB, 4.8 KB, 1.2 MB and 9.6 MB per array, in and out, values intact."""
+    rng = np.random.default_rng(count)
+    n = 4 * count
+    idx = np.sort(rng.choice(n, size=count, replace=False)).astype(np.uint64)
+    vals = rng.integers(-(1 << 40), 1 << 40, size=count)
+    v = gb.Vector.from_coo(idx, vals, dtype="INT64", size=n)
+    assert v.nvals == count
+    gi, gv = v.to_coo()
+    assert np.array_equal(gi, idx) and np.array_equal(gv, vals)
+    w = gb.Vector.from_coo(idx[::-1].copy(), vals[::-1].copy(), dtype="INT64", size=n)  # (unsorted input: the device sort sees the same bytes)
+    assert w.isequal(v)
