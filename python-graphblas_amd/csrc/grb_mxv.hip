@@ -967,6 +967,14 @@ static void ensure_tagged(GB_Matrix_opaque *A)
 
 // sorted row tiles of the short part S of an ordered twin A (once per matrix; see grb_mxv_rtile.inc).  Needs the tagged row groups'
 // per-group "row has an entry" words (ensure_tagged) and S's CSR arrays.
+// can k_mxv_rtile address every stream of `units` lane units with its 32-bit byte offsets?  (columns 4 B, tags 2 B, values vb B per entry, RT_EPL entries
+// per unit; the sentinel unit 0x0fffffff must stay OUT of range of every descriptor, so the largest stream must end below it as well)
+static bool rtile_units_addressable(int64_t units, size_t vb)
+{
+    const uint64_t per_unit = (uint64_t)RT_EPL * (uint64_t)std::max<size_t>(4, vb);
+    return units > 0 && (uint64_t)units * per_unit < 0xffffff00ull && (uint64_t)units < 0x0ffffff0ull;
+}
+
 static void ensure_rtile(GB_Matrix_opaque *A)
 {
     if (A->rt_state != 0) return;
@@ -1002,7 +1010,14 @@ static void ensure_rtile(GB_Matrix_opaque *A)
     prim_exclusive_sum_i64(units.p, units.p, n_tiles + 1);
     int64_t total_units = 0;
     d2h(&total_units, units.p + n_tiles, sizeof(int64_t));
-    if (total_units <= 0 || total_units >= 0x0ffffff0ll) return;  // (unit numbers are 28-bit offsets of the kernel's buffer loads)
+    // (unit numbers are 28-bit offsets of the kernel's buffer loads -- and the kernel addresses a unit's values at byte u * RT_EPL * sizeof(value)
+    //  with 32-bit arithmetic: 8-byte values wrap from 2^27 units on, inside a descriptor clamped to 0xfffffff0 bytes.  The
+    //  tagged row groups run when the layout is not built.)
+    if (total_units <= 0 || total_units >= 0x0ffffff0ll) return;
+    {
+        const size_t vb_chk = (A->vdict_n > 0 && vs == 4) ? 1 : (is_bool ? 1 : vs);
+        if (!rtile_units_addressable(total_units, vb_chk)) return;
+    }
     RTile *tiles = (RTile *)dev_alloc(sizeof(RTile) * (size_t)n_tiles);
     A->d_rt_tiles = tiles;
     hipLaunchKernelGGL(k_rtile_table, dim3((unsigned)ceil_div(n_tiles, 256)), dim3(256), 0, ctx().stream, (const int32_t *)g0.p, (const int64_t *)units.p, n_tiles, G, tiles);

@@ -1527,8 +1527,21 @@ extern "C" GrB_Info GxB_Matrix_pack_CSR(GrB_Matrix A, GrB_Index **Ap, GrB_Index 
     (void)jumbled;
     (void)desc;
     check_matrix(A, "A");
-    matrix_release_storage(A);  // (pack replaces the content of an existing matrix; type and shape stay)
-    gxb_take_csr(A, Ap, Aj, Ax, Ap_size, Aj_size, Ax_size, iso, "GxB_Matrix_pack_CSR");
+    // pack replaces the content of an existing matrix; type and shape stay.  The arrays are validated and copied into a fresh object
+    // first: a call that fails (a NULL cell, a size that is too small, an index out of range) leaves A as it was and the caller's
+    // arrays with the caller (SuiteSparse validates before it frees the old content).
+    GB_Matrix_opaque *M = matrix_new(A->type, A->nrows, A->ncols);
+    try {
+        gxb_take_csr(M, Ap, Aj, Ax, Ap_size, Aj_size, Ax_size, iso, "GxB_Matrix_pack_CSR");
+    } catch (...) {
+        matrix_free(M);
+        throw;
+    }
+    matrix_release_storage(A);
+    A->d_ptr = M->d_ptr; A->d_col = M->d_col; A->d_val = M->d_val;
+    A->nvals = M->nvals; A->iso = M->iso; A->owns = M->owns;
+    M->d_ptr = nullptr; M->d_col = nullptr; M->d_val = nullptr; M->nvals = 0;
+    matrix_free(M);
     GRB_CATCH(errp(A))
 }
 
