@@ -17,6 +17,7 @@ reported CPU baseline, never the product.
 import argparse
 import ctypes
 import json
+import math
 import os
 import sys
 import time
@@ -659,7 +660,10 @@ def run_mxm(args, gb, torch, device, rank, world, dist, barrier, *, scale, workl
             cpu = cpu_baseline_mxm(ip_b, col_b, n, flops, masked)
         except Exception as e:  # the baseline must never take the bench line down
             cpu = {"value": None, "unit": "nnz(C)/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
-    return {
+    # (streamed products: the PMC pass of round 6 ran the streamed command itself, so its traffic describes this line too)
+    traffic = measured_traffic(workload + ("_streamed" if streamed else ""), scale)
+    kernel_s = ev_ms / steps * 1e-3
+    line = {
         "metric": "SpGEMM nnz-out/s on R-MAT scale-%d" % scale, "value": nnz_c / (ms * 1e-3), "unit": "nnz(C)/s",
         "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": ms, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "int64", "data": "synthetic", "verified": verified,
@@ -669,10 +673,12 @@ def run_mxm(args, gb, torch, device, rank, world, dist, barrier, *, scale, workl
                    "nnz_A": nnz_a, "flops": flops, "nnz_C": nnz_c, "parallelism": (f"rank {blk[0]} of a {blk[1]}-way row shard (flop-balanced cuts), B replicated, compute only" if blk else
                                    f"row-shard x{world} (flop-balanced cuts), B replicated"), **stream_out},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None if streamed else measured_traffic(workload, scale),
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "frac_moved": (traffic / kernel_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
                      "kernel": "k_spgemm_mhash / k_spgemm_mwin" if masked is True else "k_spgemm_unit (symbolic + numeric classes) / k_spgemm_unit_dense / k_spgemm_hash",
                      "kernel_ms_hip_events": ev_ms / steps, "algorithmic_bytes_per_launch": alg_bytes / world},
         "cpu_baseline": cpu, "stats": st}
+    return line
 
 
 def main_mxm(args, gb, torch, device, rank, world, dist, barrier):
@@ -994,6 +1000,68 @@ def main_sssp(args, gb, torch, device, rank, world):
 _REAL_STDOUT = None
 
 
+def sssp_sharded_line(wl, gb, torch, device, dist, steps_cap=64):
+    """The N-rank SSSP LOOP: Bellman-Ford relaxations  d = min(d, A min.+ d)  from one source over this run's row blocks,
+    operands CHANGING from step to step, with the exchange chosen per step (sharded.OverlappedMxv(exchange="auto")): dense all-gathers while
+    many distances move, (row, value) pairs once few do.  Unreached vertices hold a large finite distance (the library's full-operand
+    kernels; 2^30 + w rounds the same way on both sides of the check).  Run twice -- "auto" and "dense" -- from the same start: the final
+    replicas must agree bit for bit on every rank, and a checksum of the replica must be the same on every rank."""
+    from graphblas_amd import sharded
+
+    n, BIG = wl.n, float(1 << 30)
+    src_vertex = 1
+    out = {}
+    finals = {}
+    for mode in ("auto", "dense"):
+        d0 = torch.full((n,), BIG, dtype=torch.float32, device="cuda")
+        d0[src_vertex] = 0.0
+        us = [device.vector_from_device(d0.clone()) for _ in range(2)]
+        ws = [device.vector_from_device(wl._rows_of(d0, lo, hi).contiguous()) for lo, hi in wl.ranges]
+        ov = sharded.OverlappedMxv(wl.As, ws, [None] * len(ws), us, wl.sr, accum=wl.accum, desc_name=None, presence=False,
+                                   cyclic=wl.ov.cyclic, exchange=mode)
+        ov.staged = wl.ov.staged
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        it = 0
+        prev = None
+        while it < steps_cap:
+            ov.step()
+            it += 1
+            if mode == "auto":
+                if ov.last_changed == 0 and it > 2:
+                    break
+            elif it >= out["auto"]["iterations"]:
+                break
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        uv, _ub = device.vector_device_views(ov.current_u())
+        finals[mode] = uv.clone()
+        out[mode] = {"iterations": it, "ms": dt * 1e3, "bytes_sent_per_rank": int(sum(x[1] for x in ov.log)),
+                     "methods": "".join("D" if x[0] == "dense" else "d" for x in ov.log),
+                     "rows_changed_per_step": [x[2] for x in ov.log]}
+        del ov, us, ws
+    same = bool(torch.equal(finals["auto"], finals["dense"]))
+    reached = int((finals["auto"] < BIG).sum().item())
+    if dist is not None:
+        img = finals["auto"].view(torch.int32).to(torch.int64)
+        sums = torch.stack([img.sum(), (img * torch.arange(1, n + 1, device="cuda", dtype=torch.int64)).sum()])
+        hi_, lo_ = sums.clone(), sums.clone()
+        dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
+        same = same and bool(torch.equal(hi_, lo_))
+        flag = torch.tensor([1 if same else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        same = bool(flag.item())
+    return {"workload": f"rmat{int(math.log2(n))} sssp_sharded: Bellman-Ford loop d = min(d, A min.+ d) from one source over this run's row blocks, "
+                        "the exchange chosen per step from what the last step changed (auto) against the dense all-gather every step (dense)",
+            "verified": same, "reached_vertices": reached, "auto": out["auto"], "dense": out["dense"],
+            "exchange_bytes_ratio_dense_over_auto": out["dense"]["bytes_sent_per_rank"] / max(out["auto"]["bytes_sent_per_rank"], 1),
+            "note": "methods: one letter per step, D = dense all-gather, d = (row, value) pairs; verified = both runs end on the same distances, "
+                    "bit for bit, on every rank"}
+
+
 def claim_stdout():
     """The driver reads ONE JSON line from stdout.  Libraries loaded later write there too (RCCL prints its version banner to the C
     stdout when a communicator comes up): file descriptor 1 is pointed at stderr for the rest of the run and the line goes out through a
@@ -1178,12 +1246,22 @@ def main():
         if wl.ov is not None:
             res["roofline"]["note"] = ("per rank: this rank's algorithmic bytes over the HIP-event time of its step on the library's stream "
                                        "(products + waits for the exchanges), max over ranks")
+            timed = wl.ov.log[-steps:] if steps else []
             res["exchange"] = {"chunks_per_rank": wl.ov.chunks, "replicas_of_u": 2, "staged_through_torch_buffers": wl.ov.staged,
-                               "presence_words_travel": wl.ov.presence, "collective": "all_gather_into_tensor per chunk, async_op"}
+                               "presence_words_travel": wl.ov.presence, "collective": "all_gather_into_tensor per chunk, async_op",
+                               # what travelled in the timed steps: the dense all-gather SURVEY 8e prescribes is the headline's
+                               # method; the sparse (row, value) exchange of a loop whose operand changes is the `sssp_sharded` line under extra
+                               "method": wl.ov.exchange, "methods_of_timed_steps": {m: sum(1 for x in timed if x[0] == m) for m in ("dense", "delta")},
+                               "bytes_per_step": (sum(x[1] for x in timed) / max(len(timed), 1)) if timed else None,
+                               "bytes_per_step_note": "bytes THIS rank contributes per step; every rank receives (world - 1) times that"}
         if res["roofline"]["traffic"]:
             res["roofline"]["traffic_band"] = measured_traffic_band(workload, scale)
             # the PMC traffic (L2 misses x 128 B, measured in separate profiled runs of this workload) over this run's kernel time
             res["roofline"]["traffic_GBps"] = res["roofline"]["traffic"] / (kernel_ms * 1e-3) / 1e9
+            # the second fraction: what the call MOVED (counter traffic) over its time and the peak, next to `frac`
+            # (what the algorithm NEEDS over the same time).  frac_moved > frac: wasted re-reads; frac_moved < frac: the kernels read
+            # fewer bytes than the formula counts (early exits of terminal monoids, dictionary-coded values)
+            res["roofline"]["frac_moved"] = res["roofline"]["traffic_GBps"] / HBM_PEAK_GBS
         return wl, res
 
     def cpu_line(wl):
@@ -1217,6 +1295,12 @@ def main():
     extra = []
     default_line = args.workload == "mxv_min_plus_masked" and args.scale == 24 and not block
     if default_line and not args.no_extra:
+        if wl.ov is not None and args.workload == "mxv_min_plus_masked":
+            # the N-rank SSSP loop on this run's blocks (operands that change; the exchange chosen per step)
+            try:
+                extra.append(sssp_sharded_line(wl, gb, torch, device, dist))
+            except Exception as e:  # an extra line must never take the headline down
+                extra.append({"workload": "sssp_sharded", "error": repr(e)})
         del wl
 
         def freed():

@@ -22,6 +22,9 @@
  * Build: see oracle/Makefile  (gcc -O3 -fopenmp -shared -fPIC).
  * ==========================================================================*/
 #include <stdint.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <stdlib.h>
 #include <string.h>
 

@@ -254,6 +254,8 @@ extern "C" GrB_Info GrB_init(GrB_Mode mode)
     }
     (void)hipGetLastError();
     if (hipEventCreate(&c.ev0) != hipSuccess || hipEventCreate(&c.ev1) != hipSuccess) return GrB_PANIC;
+    if (hipStreamCreateWithFlags(&c.aux_stream, hipStreamNonBlocking) != hipSuccess) c.aux_stream = nullptr;  // (no second stream: the kernels run one after another)
+    if (hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c.ev_join, hipEventDisableTiming) != hipSuccess) return GrB_PANIC;
     // The HIP runtime loads a translation unit's code object at the first launch of one of its kernels: several ms for the
     // SpMV unit with its template instantiations -- paid by whichever product came first (it showed up as 8 of the 12.7 ms of
     // the first GrB_mxv of the scale-24 bench).  Load them here, once per process (GRB_PRELOAD=0: on demand, as before).
@@ -268,7 +270,7 @@ extern "C" GrB_Info GrB_init(GrB_Mode mode)
     if (const char *e = getenv("GRB_DEBUG_FLAGS")) c.debug_flags = atoi(e) & DEBUG_FLAGS_MASK;
     // tuning knobs from the environment go through the same validation as GrX_option_set (an invalid value is ignored)
     static const struct { const char *env, *opt; } knobs[] = {
-        {"GRB_PULL_IPT", "pull_ipt"}, {"GRB_HOT_MIN_COLS", "hot_min_cols"}, {"GRB_HOT_K", "hot_k"}, {"GRB_PUSH_MODE", "push_mode"},
+        {"GRB_PULL_IPT", "pull_ipt"}, {"GRB_MXV_OVERLAP", "mxv_overlap"}, {"GRB_STRIP_WGS", "strip_wgs"}, {"GRB_HOT_MIN_COLS", "hot_min_cols"}, {"GRB_HOT_K", "hot_k"}, {"GRB_PUSH_MODE", "push_mode"},
         {"GRB_ALLOC_CACHE", "alloc_cache"}, {"GRB_SHORT_KERNEL", "short_kernel"},
         {"GRB_LAZY_LAYOUT", "lazy_layout"}, {"GRB_MXM_HEAVY_KERNEL", "mxm_heavy_kernel"}, {"GRB_DROP_HOT_COLS", "drop_hot_cols"},
         {"GRB_MXM_UNIT_MIN_FLOPS", "mxm_unit_min_flops"}, {"GRB_MXM_UNIT_MIN_PER_WINDOW", "mxm_unit_min_per_window"},
@@ -318,6 +320,11 @@ extern "C" GrB_Info GrB_finalize(void)
     if (c.ev0) (void)hipEventDestroy(c.ev0);
     if (c.ev1) (void)hipEventDestroy(c.ev1);
     c.ev0 = c.ev1 = nullptr;
+    if (c.ev_fork) (void)hipEventDestroy(c.ev_fork);
+    if (c.ev_join) (void)hipEventDestroy(c.ev_join);
+    c.ev_fork = c.ev_join = nullptr;
+    if (c.aux_stream) { (void)hipStreamSynchronize(c.aux_stream); (void)hipStreamDestroy(c.aux_stream); }
+    c.aux_stream = nullptr;
     c.initialized = false;
     return GrB_SUCCESS;
 }
@@ -407,6 +414,8 @@ extern "C" GrB_Info GrX_option_set(const char *name, int64_t value)
         c.debug_flags = (int)value;
     }
     else if (n == "pull_ipt") c.tune_pull_ipt = (int)value;
+    else if (n == "mxv_overlap") c.mxv_overlap = value ? 1 : 0;
+    else if (n == "strip_wgs") c.strip_wgs = (int)std::max<int64_t>(0, std::min<int64_t>(value, 4096));
     else if (n == "hot_min_cols") c.hot_min_cols = value;
     else if (n == "hot_k") c.hot_k = value;
     else if (n == "push_mode") c.push_mode = (int)value;

@@ -66,6 +66,12 @@ struct Context {
     hipStream_t stream = nullptr;  // null stream: ordered with torch's default stream
     void (*host_free)(void *) = nullptr;  // GxB_init: the deallocator of host arrays whose ownership an import / pack takes (nullptr: free)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // round 6: the kernels of one pull product that do not depend on each other run on two streams (mxv_overlap): the cold tiles gather
+    // (TA-bound) on `aux_stream` while the hot strips stream (HBM-bound) on `stream`; ev_fork / ev_join order them with the rest of the call
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int mxv_overlap = 0;             // 1: k_mxv_ctile on the auxiliary stream next to k_mxv_hstrip; 0: one stream.  Measured (profiles/r06/overlap.txt): 0.477 vs 0.479 ms -- the two kernels stretch to the same total, the call is bound by the lines it moves; off
+    int strip_wgs = 0;               // persistent workgroups of the merged k_mxv_hstrip launch (0 = one per CU); read when the layouts are built
     int64_t vec_pad_min_bytes = 1 << 20;  // vectors with at least this many bytes of values are allocated with the front pad
     int alloc_cache = 1;    // 1: freed device blocks are kept per size class and reused without calling the HIP allocator
     int drop_hot_cols = 1;     // release the re-coded copy of the whole column array once the long / short split is built from it

@@ -695,6 +695,16 @@ constexpr int MU_POOLS = 1024;  // sub-pools of the bitmap pool
 #define GRB_MU_SMALL 512
 #endif
 constexpr int MU_SMALL = GRB_MU_SMALL;  // entries of a unit a single wavefront accumulates
+// Units per wavefront of the numeric one-wavefront class (round 6, VERDICT r03-r05 "two independent units interleaved per wavefront").
+// A unit is a chain of dependent round trips -- its record, the entries of A, their window offsets and row pointers of B, the
+// bitmap, then the products -- and LDS holds the workgroups per CU at four, i.e. four chains per SIMD.  With GRB_MU_UPW = 2 a
+// wavefront owns two consecutive units of the class list (neighbouring windows of one row, as a rule): both records and both
+// offset chains are requested BEFORE the first unit's bitmap and products are touched, so the second unit's chain travels
+// under the first unit's work; the units then run one after the other in the same LDS (no more LDS, +14 registers).
+#ifndef GRB_MU_UPW
+#define GRB_MU_UPW 2
+#endif
+constexpr int mu_units_per_wave(int mode, int wpu) { return (mode == 1 && wpu == 1) ? GRB_MU_UPW : 1; }
 
 __device__ __forceinline__ void mw_sync()
 {
@@ -707,8 +717,12 @@ __device__ __forceinline__ void mw_sync()
 // bitmap holds F MM_WIN bits, its ranges of B run from window offset w F to (w + 1) F of the per-window table.  The symbolic unit
 // still reports one count per WINDOW (and keeps its bitmap as F consecutive window bitmaps of the pool): the classification sends
 // a group to one numeric unit of the same F, or -- beyond the densest compact class -- its windows to F = 1 units, as before.
+// (wavefronts per SIMD the register allocation must leave room for: the 1024 class of GROUP units (F = 2) stood at 99 registers = four
+//  waves per SIMD; asked for five it compiles to 95 without spills: scale 22 1317 -> 1290 ms, profiles/r05/mxm_lds_occupancy.txt -- shipped
+//  in round 6 after the whole GPU tier ran on it.  F = 4 spills 23 registers under the same hint: not hinted.)
+constexpr int mu_min_waves(int mode, int wpu, int cap, int f) { return (mode == 1 && wpu == 4 && cap == 1024 && f == 2) ? 5 : 1; }
 template <typename T, int MODE, int WPU, int CAP, int F = 1>
-__global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const MxmArgs a, const uint32_t *rows, int64_t ridx0,
+__global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4), mu_min_waves(MODE, WPU, CAP, F)) void k_spgemm_unit(const MxmArgs a, const uint32_t *rows, int64_t ridx0,
                                                                           int64_t nrows_here, const UnitRec *units, int64_t nunits)
 {
     using W = typename Widen<T>::type;
@@ -718,7 +732,6 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const 
     constexpr int WIN = MM_WIN * F, WORDS = WIN / 64, WPL = WORDS / 64, FWORDS = MM_WIN / 64;
     constexpr int WAVES = WPU > 4 ? WPU : 4;  // wavefronts per workgroup
     constexpr int UPB = WAVES / WPU;          // units per workgroup
-    constexpr int NB = 2;  // batches of entries of A a wavefront keeps (range of B inside the window) from pass A for pass B
     __shared__ unsigned long long s_bits[UPB][WORDS];
     // (the words' prefix counts as 16-bit numbers where the unit's bitmap holds at most 65536 bits: what decides how many workgroups a CU holds
     //  is LDS -- with groups of two windows the one-wavefront class took 44032 bytes, three workgroups per CU; 39936 are four.  Last session
@@ -740,12 +753,44 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const 
     const int uib = WPU == 1 ? wave : 0, sub = WPU == 1 ? 0 : wave;  // unit inside the workgroup, wavefront inside the unit
     const int nwin = a.n_win;                   // (windows: the tables' unit)
     const int ngroups_w = (nwin + F - 1) / F;   // (groups of F windows: the units' unit)
-    const int64_t unit = xcd_block(a) * UPB + uib;
+    constexpr int UPW = mu_units_per_wave(MODE, WPU);  // units this wavefront owns (numeric one-wavefront class: GRB_MU_UPW)
+    const int64_t unit = (xcd_block(a) * UPB + uib) * UPW;
     int64_t ridx = 0, row, out = 0, pbeg, pend;
     int w, w_end = 0, bslot = -1, mcnt = 0;
+    constexpr int NB = 2;  // batches of entries of A a wavefront keeps (range of B inside the window) from pass A for pass B
+    UnitRec urec[UPW];
+    int pf_len[UPW][NB];     // (UPW > 1: the ranges of B of every owned unit's first NB batches, requested up front)
+    int64_t pf_qb[UPW][NB];
     if constexpr (NUMERIC) {  // a unit of the class list
         if (unit >= nunits) return;  // (uniform over the unit's threads)
-        const UnitRec r = units[unit];
+#pragma unroll
+        for (int k = 0; k < UPW; k++) urec[k] = units[unit + k < nunits ? unit + k : nunits - 1];  // (past the list: the last unit again, never run)
+        if constexpr (UPW > 1) {
+            // both offset chains, stage by stage: all entries of A first, then everything that depends on them -- the loads of the
+            // second unit leave with the first unit's instead of behind its products
+            int pk[UPW][NB];
+            bool pok[UPW][NB];
+#pragma unroll
+            for (int k = 0; k < UPW; k++)
+#pragma unroll
+                for (int b = 0; b < NB; b++) {
+                    const int64_t pe = urec[k].pbeg + urec[k].plen, pp = urec[k].pbeg + (int64_t)b * 64 + (int64_t)lane;
+                    pok[k][b] = pp < pe;
+                    pk[k][b] = a.Aj[pok[k][b] ? pp : pe - 1];
+                }
+#pragma unroll
+            for (int k = 0; k < UPW; k++)
+#pragma unroll
+                for (int b = 0; b < NB; b++) {
+                    const int wk = urec[k].w;
+                    const int fs = a.n_win - wk * F < F ? a.n_win - wk * F : F;
+                    const int32_t *o = a.woff + (int64_t)pk[k][b] * (a.n_win + 1) + wk * F;
+                    const int o0 = o[0], o1 = o[fs];
+                    pf_qb[k][b] = a.Bp[pk[k][b]] + o0;
+                    pf_len[k][b] = pok[k][b] ? o1 - o0 : 0;
+                }
+        }
+        const UnitRec &r = urec[0];
         row = r.row;
         w = r.w;
         out = r.out;
@@ -789,6 +834,24 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const 
     }
     const int tiu = sub * 64 + lane;  // thread inside the unit
     unsigned long long csum_mine = 0;  // (streamed product: the values this thread stores)
+    // (the units this wavefront owns, one instance of the body per unit -- `uk` is a compile-time constant: a run-time loop over them was
+    //  left un-unrolled by the compiler, and the prefetched ranges, indexed by `uk`, went to scratch memory; UPW = 1 everywhere but in
+    //  the numeric one-wavefront class)
+    auto run_unit = [&](auto uk_c) {
+    constexpr int uk = decltype(uk_c)::value;
+    if constexpr (UPW > 1) {
+        if (uk > 0) {
+            if (unit + uk >= nunits) return;  // (uniform over the wavefront)
+            usync();  // (the next unit clears / loads the bitmap and the accumulators the last one wrote its columns from)
+            const UnitRec &r = urec[uk];
+            row = r.row;
+            w = r.w;
+            out = r.out;
+            pbeg = r.pbeg;
+            pend = pbeg + r.plen;
+            bslot = r.aux;
+        }
+    }
     for (;;) {  // (the windows of a symbolic unit; numeric and masked units: once)
     const int c0 = w * WIN;
     const int fspan = nwin - w * F < F ? nwin - w * F : F;  // windows of the group that exist (the last group of a row may be short)
@@ -806,8 +869,16 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const 
         qb = a.Bp[k] + o0;
         len = ok ? o1 - o0 : 0;
     };
+    if constexpr (UPW > 1) {
 #pragma unroll
-    for (int b = 0; b < NB; b++) fetch(pbeg + sub + (int64_t)b * 64 * WPU + (int64_t)lane * WPU, c_len[b], c_qb[b]);
+        for (int b = 0; b < NB; b++) {
+            c_len[b] = pf_len[uk][b];
+            c_qb[b] = pf_qb[uk][b];
+        }
+    } else {
+#pragma unroll
+        for (int b = 0; b < NB; b++) fetch(pbeg + sub + (int64_t)b * 64 * WPU + (int64_t)lane * WPU, c_len[b], c_qb[b]);
+    }
     if (bslot >= 0) {  // (numeric pass: the symbolic pass kept the unit's bitmap)
         for (int k = tiu; k < WORDS; k += 64 * WPU) bits[k] = a.bm_pool[(int64_t)bslot * FWORDS + k];  // (F consecutive window bitmaps)
     } else {
@@ -1120,6 +1191,12 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4)) void k_spgemm_unit(const 
         usync();  // (the next window clears the bitmap this one was counted from)
     }
     }  // for (;;)
+    };  // run_unit
+    run_unit(std::integral_constant<int, 0>{});
+    if constexpr (UPW > 1) run_unit(std::integral_constant<int, 1>{});
+    if constexpr (UPW > 2) run_unit(std::integral_constant<int, 2>{});
+    if constexpr (UPW > 3) run_unit(std::integral_constant<int, 3>{});
+    static_assert(UPW >= 1 && UPW <= 4, "one to four units per wavefront");
     if constexpr (NUMERIC && !MASKED) checksum_commit(a, csum_mine);
 }
 
@@ -1828,7 +1905,7 @@ static void launch_unit_classes(MxmArgs &a, const uint32_t *rows, int64_t nrows,
     auto compact_classes = [&](int c0, auto f_c) {
         constexpr int F = decltype(f_c)::value;
         per_class(c0, [&](const UnitRec *u, int64_t nu) {
-            hipLaunchKernelGGL((k_spgemm_unit<T, MODE, 1, MU_SMALL, F>), dim3(grid8(ceil_div(nu, 4))), dim3(256), 0, ctx().stream, a, rows, 0, 0, u, nu);
+            hipLaunchKernelGGL((k_spgemm_unit<T, MODE, 1, MU_SMALL, F>), dim3(grid8(ceil_div(nu, (int64_t)4 * mu_units_per_wave(MODE, 1)))), dim3(256), 0, ctx().stream, a, rows, 0, 0, u, nu);
         });
         per_class(c0 + 1, [&](const UnitRec *u, int64_t nu) {
             hipLaunchKernelGGL((k_spgemm_unit<T, MODE, 4, 1024, F>), dim3(grid8(nu)), dim3(256), 0, ctx().stream, a, rows, 0, 0, u, nu);

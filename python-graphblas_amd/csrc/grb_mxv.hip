@@ -473,7 +473,7 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
                         // one launch of the fast strip kernel over both levels: the persistent workgroups (one per CU) are dealt to the nvc
                         // classes by chunk count -- every class with chunks gets one, the rest go to whichever class has the most chunks
                         // per workgroup left
-                        const int G = std::max(nvc, ctx().num_cus);
+                        const int G = std::max(nvc, ctx().strip_wgs > 0 ? ctx().strip_wgs : ctx().num_cus);
                         std::vector<int> wgs((size_t)nvc, 0);
                         int used = 0;
                         for (int c = 0; c < nvc; c++)
@@ -1144,6 +1144,29 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
                 a.hrec_bytes = A->hrec_bytes;
                 a.vdict = A->vdict_n > 0 ? A->d_vdict : nullptr;
                 ctx().stats.value_dict = A->vdict_n;
+                // the cold entries (tagged tiles, column range by column range per XCD) gather through the texture path and leave HBM idle; the hot
+                // strips stream from HBM and leave the texture path idle; both only ADD to the long rows' accumulators (atomics), so their order
+                // does not matter: round 6 runs the tiles on the auxiliary stream next to the strips (mxv_overlap).  The short-row kernel that
+                // follows reads the accumulators: the main stream waits for the tiles (ev_join) before it.
+                auto launch_ctile = [&](hipStream_t on) {
+                    if (A->ct_units <= 0) return;
+                    a.ct_col = A->d_ct_col;
+                    a.ct_val = A->d_ct_val;
+                    a.ct_loc = A->d_ct_loc;
+                    a.ct_tiles = (const CTile *)A->d_ct_tiles;
+                    a.ct_order = A->d_ct_order;
+                    for (int x = 0; x <= 8; x++) a.ct_xoff[x] = A->ct_xoff[x];
+                    const int64_t Gt = std::max<int64_t>(8, (int64_t)(ctx().num_cus * CT_WGS_PER_CU / 8) * 8);
+                    hipLaunchKernelGGL((k_mxv_ctile<T, MON, MUL>), dim3((unsigned)Gt), dim3(CT_BLOCK), 0, on, a);
+                    ctx().stats.kernel_launches += 1;
+                };
+                const bool forked = ctx().mxv_overlap && ctx().aux_stream && A->ct_units > 0;
+                if (forked) {
+                    GRB_HIP(hipEventRecord(ctx().ev_fork, ctx().stream));
+                    GRB_HIP(hipStreamWaitEvent(ctx().aux_stream, ctx().ev_fork, 0));
+                    launch_ctile(ctx().aux_stream);
+                    GRB_HIP(hipEventRecord(ctx().ev_join, ctx().aux_stream));
+                }
                 // the fast kernel takes both levels of an ordered matrix in ONE launch (workgroups dealt to the classes by chunk count)
                 bool merged = false;
                 if constexpr (MON >= 0) {
@@ -1196,17 +1219,8 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
                         hipLaunchKernelGGL((k_mxv_strip<T, MON, MUL, LONG_LDS_WORDS, 1>), dim3((unsigned)Gl), dim3(LONG_BLOCK), 0, ctx().stream, al);
                     if (level) ctx().stats.kernel_launches += 1;
                 }
-                if (A->ct_units > 0) {  // the cold entries: tagged tiles, column range by column range per XCD
-                    a.ct_col = A->d_ct_col;
-                    a.ct_val = A->d_ct_val;
-                    a.ct_loc = A->d_ct_loc;
-                    a.ct_tiles = (const CTile *)A->d_ct_tiles;
-                    a.ct_order = A->d_ct_order;
-                    for (int x = 0; x <= 8; x++) a.ct_xoff[x] = A->ct_xoff[x];
-                    const int64_t Gt = std::max<int64_t>(8, (int64_t)(ctx().num_cus * CT_WGS_PER_CU / 8) * 8);
-                    hipLaunchKernelGGL((k_mxv_ctile<T, MON, MUL>), dim3((unsigned)Gt), dim3(CT_BLOCK), 0, ctx().stream, a);
-                    ctx().stats.kernel_launches += 1;
-                }
+                if (forked) GRB_HIP(hipStreamWaitEvent(ctx().stream, ctx().ev_join, 0));
+                else launch_ctile(ctx().stream);
             } else
             hipLaunchKernelGGL((k_mxv_strip<T, MON, MUL, LONG_LDS_WORDS>), dim3((unsigned)G), dim3(LONG_BLOCK), 0, ctx().stream, a);
         } else if (by_class) {

@@ -157,6 +157,15 @@ GRB_HD D cast_value(S s)
     } else return (D)s;
 }
 
+// (experiment builds only -- scripts/build_variant_mxm.sh: -DGRB_DISPATCH_ONLY_INT64 compiles the INT64 instantiations alone, a tenth of
+//  the compile time of grb_mxm.hip; every other type then fails with GrB_NOT_IMPLEMENTED.  Never defined for the shipped library.)
+#ifdef GRB_DISPATCH_ONLY_INT64
+#define GRB_DISPATCH_TYPE(code, T, ...)                                               \
+    switch (code) {                                                                   \
+    case ::grb::TC_INT64: { using T = int64_t; __VA_ARGS__; } break;                  \
+    default: ::grb::fail(GrB_NOT_IMPLEMENTED, "experiment build: INT64 only");        \
+    }
+#else
 #define GRB_DISPATCH_TYPE(code, T, ...)                                               \
     switch (code) {                                                                   \
     case ::grb::TC_BOOL: { using T = bool; __VA_ARGS__; } break;                      \
@@ -172,6 +181,7 @@ GRB_HD D cast_value(S s)
     case ::grb::TC_FP64: { using T = double; __VA_ARGS__; } break;                    \
     default: ::grb::fail(GrB_INVALID_OBJECT, "unknown type code");                    \
     }
+#endif
 
 // ---- accumulator helpers (device only) ----------------------------------------------------------------
 template <typename T, typename W>

@@ -224,7 +224,7 @@ class OverlappedMxv:
     emulator build, where the vectors' images live in host memory."""
 
     def __init__(self, A_blocks, w_blocks, mask_blocks, u_pair, semiring, *, accum=None, desc_name=None, presence=False,
-                 device="cuda", cyclic=0):
+                 device="cuda", cyclic=0, exchange="dense", delta_below=0.03):
         import ctypes
 
         import torch.distributed as dist
@@ -250,6 +250,17 @@ class OverlappedMxv:
         if self.cyclic and (self.cyclic % 8 or self.h % self.cyclic):
             raise ValueError("cyclic: the stripe must be a multiple of 8 rows and divide n / (world_size * chunks)")
         self._stage, self._deal = {}, []
+        # round 6: what travels.  "dense" = every chunk's slice, every step (the all-gather SURVEY 8e prescribes).  "auto": a step whose
+        # PREDECESSOR changed less than `delta_below` of the rows (the same number on every rank: it comes out of the exchange itself)
+        # sends (global row, value) pairs of the entries that differ from what the target replica holds, and the changed presence words --
+        # under `~visited.S` only unvisited rows can change, and the tail of an SSSP / BFS run changes a few thousand rows of millions.
+        # The first two steps are dense (both replicas must have been written once).
+        if exchange not in ("dense", "auto", "delta"):
+            raise ValueError("exchange: 'dense', 'auto' or 'delta'")
+        self.exchange, self.delta_below = exchange, float(delta_below)
+        self.last_changed = None       # rows changed by the last step over all ranks (None: unknown -- the dense exchange does not count)
+        self.log = []                  # per step: (method, bytes this rank sent, rows changed over all ranks or -1)
+        self._gidx = {}
         if device != "cpu":
             # The asynchronous collective is ordered behind the product (and the next product behind the collective) through torch's
             # CURRENT stream: ProcessGroupNCCL records its events there.  That orders against the library only if the library launches on
@@ -381,15 +392,104 @@ class OverlappedMxv:
             raise RuntimeError("OverlappedMxv.step: the library's launch stream is not torch's current stream: the exchange would not be "
                                "ordered behind the products")
 
+    def _global_rows(self, c):
+        """int64 tensor: the global row of every local row of chunk c (contiguous blocks: a range; cyclic: the stripes' rows)."""
+        g = self._gidx.get(c)
+        if g is None:
+            torch = self._torch()
+            rank = self.dist.get_rank()
+            dev_t = self.u_vals[0].device
+            j = torch.arange(self.h, device=dev_t, dtype=torch.int64)
+            if self.cyclic:
+                B = self.cyclic
+                g = ((torch.div(j, B, rounding_mode="floor") * self.chunks + c) * self.world + rank) * B + j % B
+            else:
+                g = c * (self.n // self.chunks) + rank * self.h + j
+            self._gidx[c] = g
+        return g
+
+    def _exchange_delta(self, c, dst):
+        """The entries of chunk c's slice that differ from what replica ``dst`` holds for those rows travel as (global row, bit pattern)
+        pairs, the presence words that differ as (word index, word) pairs: three small collectives.  Returns (rows changed over all
+        ranks, bytes this rank sent).  Synchronous (the sizes are read on the host); used where little changes, i.e. where the
+        products are short as well."""
+        torch = self._torch()
+        dist, world, h = self.dist, self.world, self.h
+        uv, wv = self.u_vals[dst], self.w_vals[c][:h]
+        as_bits = {1: torch.uint8, 2: torch.int16, 4: torch.int32, 8: torch.int64}[uv.element_size()]
+        g = self._global_rows(c)
+        old_bits, new_bits = uv.view(as_bits)[g], wv.view(as_bits)
+        vi = torch.nonzero(old_bits != new_bits).flatten()
+        wi = None
+        cnt = [int(vi.numel()), 0]
+        if self.presence:
+            # (64-row aligned slices: local presence word q covers local rows 32 q .. 32 q + 31; cyclic stripes are multiples of 8 rows, so
+            #  presence travels as BYTES there: byte b of the local image = local rows 8 b .. 8 b + 7 = global byte g[8 b] / 8)
+            ub = self.u_words[dst].view(torch.uint8)
+            wb = self.w_words[c][: h // 32].view(torch.uint8)
+            gb = torch.div(g[::8], 8, rounding_mode="floor")
+            wi = torch.nonzero(ub[gb] != wb).flatten()
+            cnt[1] = int(wi.numel())
+        counts = torch.tensor(cnt, dtype=torch.int64)
+        allc = [torch.empty_like(counts) for _ in range(world)]
+        host_counts = counts if (self.device == "cpu" or self.host_staged) else counts.to(uv.device)
+        allh = [torch.empty_like(host_counts) for _ in range(world)]
+        dist.all_gather(allh, host_counts)
+        allc = torch.stack([t.cpu() for t in allh])
+        mv, mw = int(allc[:, 0].max()), int(allc[:, 1].max())
+        sent = 16
+
+        def gather_pairs(idx, payload, m, scatter):
+            si = torch.zeros(m, dtype=torch.int64, device=idx.device)
+            sx = torch.zeros(m, dtype=payload.dtype, device=payload.device)
+            si[: idx.numel()] = idx
+            sx[: idx.numel()] = payload
+            if self.host_staged:
+                si, sx = si.cpu(), sx.cpu()
+            gi = [torch.empty_like(si) for _ in range(world)]
+            gx = [torch.empty_like(sx) for _ in range(world)]
+            dist.all_gather(gi, si)
+            dist.all_gather(gx, sx)
+            return gi, gx
+
+        if mv:
+            gi, gx = gather_pairs(g[vi], new_bits[vi], mv, None)
+            flat = uv.view(as_bits)
+            for r in range(world):
+                k = int(allc[r, 0])
+                if k:
+                    flat[gi[r][:k].to(flat.device)] = gx[r][:k].to(flat.device)
+            sent += cnt[0] * (8 + uv.element_size())
+        if self.presence and mw:
+            gi, gx = gather_pairs(gb[wi], wb[wi], mw, None)
+            for r in range(world):
+                k = int(allc[r, 1])
+                if k:
+                    ub[gi[r][:k].to(ub.device)] = gx[r][:k].to(ub.device)
+            sent += cnt[1] * 9
+        return int(allc[:, 0].sum()), sent
+
     def step(self):
         self._check_stream()
         src, dst = self.k & 1, (self.k + 1) & 1
+        rows_all = self.n
+        use_delta = self.exchange == "delta" or (self.exchange == "auto" and self.k >= 2 and self.last_changed is not None and
+                                                 self.last_changed <= self.delta_below * rows_all)
+        if self.k < 2 and self.exchange != "dense":
+            use_delta = False  # (a replica that was never written holds nothing to take a difference from)
         works = []
+        changed, sent = 0, 0
         for c in range(self.chunks):
             rc = self._call(*self._args[src][c])
             if rc != 0:
                 raise RuntimeError(f"GrB_mxv failed with GrB_Info {rc}")
-            works += self._exchange(c, dst)
+            if use_delta:
+                ch, by = self._exchange_delta(c, dst)
+                changed += ch
+                sent += by
+            else:
+                works += self._exchange(c, dst)
+                sent += self.h * self.u_vals[dst].element_size() + (self.h // 8 if self.presence else 0)
         for wk in works:
             wk.wait()
         for out_t, src_t in self._deal:
@@ -397,6 +497,24 @@ class OverlappedMxv:
         self._deal = []
         if self.presence:
             self.dev.vector_modified(self.u[dst])
+        if self.exchange != "dense" and not use_delta:
+            # a dense step of an "auto" run still has to know how much changed -- the next step chooses from it: one count per rank
+            # (the rows of this rank's slices that differ between the two replicas), summed by a tiny all-reduce
+            torch = self._torch()
+            diff = 0
+            for c in range(self.chunks):
+                g = self._global_rows(c)
+                a_bits = self.u_vals[dst].view(self.u_vals[dst].dtype)[g]
+                b_bits = self.u_vals[src].view(self.u_vals[src].dtype)[g]
+                diff += int((a_bits != b_bits).sum().item()) if a_bits.dtype != torch.float32 and a_bits.dtype != torch.float64 else \
+                    int((a_bits.view(torch.int32 if a_bits.element_size() == 4 else torch.int64) != b_bits.view(torch.int32 if b_bits.element_size() == 4 else torch.int64)).sum().item())
+            t = torch.tensor([diff], dtype=torch.int64)
+            if not (self.device == "cpu" or self.host_staged):
+                t = t.to(self.u_vals[dst].device)
+            self.dist.all_reduce(t)
+            changed = int(t.item())
+        self.last_changed = changed if self.exchange != "dense" else None
+        self.log.append(("delta" if use_delta else "dense", sent, changed if self.exchange != "dense" else -1))
         self.k += 1
 
 

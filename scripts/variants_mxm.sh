@@ -2,7 +2,7 @@
 # A/B of build-time variants of grb_mxm.hip on the SpGEMM bench lines.
 #   build host:  scripts/variants_mxm.sh build "GRB_MU_ILP=8" "GRB_MU_ILP_SYM=8" ...   (a variant may hold several defines: "A=1 -DB=2")
 #   GPU box:     gpurun -- 'bash scripts/variants_mxm.sh run'
-set -e
+set -e; set +e
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 SRC="$ROOT/python-graphblas_amd/csrc"
 case "$1" in

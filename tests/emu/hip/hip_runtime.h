@@ -68,6 +68,12 @@ inline hipError_t hipMemPoolSetAttribute(hipMemPool_t, hipMemPoolAttr, void *) {
 inline hipError_t hipMemPoolTrimTo(hipMemPool_t, size_t) { return hipSuccess; }
 inline hipError_t hipEventCreate(hipEvent_t *e) { *e = (hipEvent_t)malloc(8); return hipSuccess; }
 inline hipError_t hipEventDestroy(hipEvent_t e) { free(e); return hipSuccess; }
+// (round 6: a second stream -- the emulator runs every launch to completion at once, so streams and the events between them are no-ops)
+constexpr unsigned hipStreamNonBlocking = 1u, hipEventDisableTiming = 2u;
+inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = nullptr; return hipSuccess; }
+inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { return hipEventCreate(e); }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t);
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b);

@@ -5,6 +5,8 @@ oracle finishes in seconds and (b) size-independent properties at full scale:
   * idempotence of a min.+ relaxation with accum=min once converged (SSSP fixed point = Dijkstra via scipy);
   * BFS by lor_land level steps reaches exactly the vertices scipy's BFS reaches, level by level.
 All through the C ABI (the Python host is a thin ctypes layer)."""
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -415,12 +417,14 @@ def test_scale24_headline_calls(gb):
     import torch
 
     from graphblas_amd import device, synthetic
+    from oracle import grb_oracle as O
 
     scale = 24
     n = 1 << scale
     indptr, col = synthetic.rmat_csr(scale, device="cuda")
     rows = torch.repeat_interleave(torch.arange(n, device="cuda"), indptr[1:] - indptr[:-1])
     cl = col.long()
+    ip_np, cj_np = indptr.cpu().numpy(), col.cpu().numpy().astype(np.int64)
     gen = torch.Generator(device="cuda")
     gen.manual_seed(99)
     visited = torch.rand(n, generator=gen, device="cuda") < 0.5
@@ -440,16 +444,34 @@ def test_scale24_headline_calls(gb):
         u = device.vector_from_device(dist)
         ref = torch.full((n,), float("inf"), device="cuda").scatter_reduce(0, rows, vals + dist[cl], "amin")
         exp = torch.where(~visited, torch.minimum(dist, ref), dist)
-        for call in range(2):  # first product: plain CSR arrays; second: hot-column table + class strips
+        # the C oracle on the same operands (one full-size pass, a fraction of a second on the box's cores): the checker the small-size
+        # parity tests use, here at the size the headline is quoted on (the full-size call was only put against torch)
+        O.use_all_threads()
+        t_has = np.zeros(n, np.uint8)
+        t_val = np.zeros(n, np.float32)
+        act = (~visited).cpu().numpy().astype(np.uint8)
+        rc = O.lib().grbo_mxv(O.TYPE_CODES["FP32"], O.OP_CODES["min"], O.OP_CODES["plus"], ctypes.c_int64(n), O._p(ip_np), O._p(cj_np),
+                              O._p(np.ascontiguousarray(vals.cpu().numpy())), 0, O._p(np.ones(n, np.uint8)), O._p(np.ascontiguousarray(dist.cpu().numpy())),
+                              O._p(act), O._p(t_has), O._p(t_val))
+        assert rc == 0
+        d_np = dist.cpu().numpy()
+        exp_c = np.where((act != 0) & (t_has != 0), np.minimum(d_np, t_val), d_np)
+        assert np.array_equal(exp_c, exp.cpu().numpy()), "the C oracle and the torch reduction disagree"
+        for call in range(3):  # first product: plain CSR arrays; second and third: the cached layouts (the third is what bench.py times)
             w = device.vector_from_device(dist.clone())
             w(~vis.S, accum=gb.binary.min) << A.mxv(u, gb.semiring.min_plus)
             st = device.last_stats()
-            if call == 1:
+            if call >= 1:
                 assert st["long_kernel"] == 4 and st["long_entries"] > 100_000_000 and st["hot_k"] > 0
+                # ... on the popularity-ordered twin, the short rows as sorted row tiles with the write rule fused (k_mxv_rtile): the kernels
+                # of the bench line are the ones that produced the result checked below
+                assert st["ordered"] == 1 and st["fused_epilogue"] == 3, st
+                assert st["value_dict"] == (255 if weights == "integer" else 0), st
             else:
                 assert st["long_kernel"] == -1 and st["hot_k"] == 0
-            wv, wb = device.vector_device_views(w)
+            wv, wb = device.vector_device_views(w, pin=False)
             assert bool(bits(wb).all()) and torch.equal(wv, exp)
+            assert np.array_equal(wv.cpu().numpy(), exp_c)
         del A, u, w, ref, exp
     one = torch.ones(1, dtype=torch.bool, device="cuda")
     Ab = device.matrix_from_device_csr(indptr, col, one, n, n, "BOOL", iso=True)
@@ -464,6 +486,48 @@ def test_scale24_headline_calls(gb):
         nv, nb = device.vector_device_views(nxt)
         got = bits(nb)
         assert torch.equal(got, hit & ~visited) and bool(nv[got].all())
+
+
+@pytest.mark.gpu
+def test_scale24_ranked_hint_call(gb):
+    """The headline call on a graph whose application relabelled its vertices by popularity once (synthetic.rmat_csr(relabel="popularity"))
+    and says so (GrX_Matrix_hint_ranked, `bench.py --ranked`), at full size against the C oracle: the ordered layouts are built in the
+    caller's own labels -- no permutation, an operand whose pointers were handed out (pinned) is taken as it is."""
+    import torch
+
+    from graphblas_amd import device, synthetic
+    from oracle import grb_oracle as O
+
+    scale = 24
+    n = 1 << scale
+    indptr, col = synthetic.rmat_csr(scale, device="cuda", relabel="popularity")
+    vals = synthetic.edge_weights(col, scale)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(77)
+    visited = torch.rand(n, generator=gen, device="cuda") < 0.5
+    dist = torch.randint(0, 1000, (n,), generator=gen, device="cuda").to(torch.float32)
+    vis = device.vector_from_device(torch.ones(n, dtype=torch.bool, device="cuda"), present=visited)
+    A = device.matrix_from_device_csr(indptr, col, vals, n, n, "FP32")
+    device.matrix_hint_ranked(A)
+    u = device.vector_from_device(dist)
+    device.vector_device_views(u)  # (pinned natural: what a vector that RCCL gathers into looks like)
+    O.use_all_threads()
+    t_has, t_val = np.zeros(n, np.uint8), np.zeros(n, np.float32)
+    act = (~visited).cpu().numpy().astype(np.uint8)
+    d_np = dist.cpu().numpy()
+    rc = O.lib().grbo_mxv(O.TYPE_CODES["FP32"], O.OP_CODES["min"], O.OP_CODES["plus"], ctypes.c_int64(n), O._p(indptr.cpu().numpy()),
+                          O._p(col.cpu().numpy().astype(np.int64)), O._p(np.ascontiguousarray(vals.cpu().numpy())), 0, O._p(np.ones(n, np.uint8)),
+                          O._p(d_np), O._p(act), O._p(t_has), O._p(t_val))
+    assert rc == 0
+    exp = np.where((act != 0) & (t_has != 0), np.minimum(d_np, t_val), d_np)
+    for call in range(3):
+        w = device.vector_from_device(dist.clone())
+        w(~vis.S, accum=gb.binary.min) << A.mxv(u, gb.semiring.min_plus)
+        st = device.last_stats()
+        if call >= 1:
+            assert st["long_kernel"] == 4 and st["fused_epilogue"] == 3 and st["reorders"] == 0, st
+        wv, _wb = device.vector_device_views(w, pin=False)
+        assert np.array_equal(wv.cpu().numpy(), exp)
 
 
 @pytest.mark.gpu

@@ -222,3 +222,54 @@ def test_oracle_assign_extract_literals():
     assert w.idx.tolist() == [0, 1, 3, 4, 6] and w.vals.tolist() == [9, 1, 1, 8, 0]
     w = O.vec_assign(v, 9, [1, 3, 5])
     assert w.idx.tolist() == [1, 3, 4, 5, 6] and w.vals.tolist() == [9, 9, 2, 9, 0]
+
+
+@pytest.mark.parametrize("tname,sr", [("INT64", "plus_times"), ("INT64", "min_plus"), ("FP32", "min_plus"), ("FP64", "plus_times"),
+                                      ("BOOL", "lor_land"), ("INT32", "any_pair")])
+def test_oracle_mxv_balanced_partition_and_split_hub_rows(tname, sr):
+    """Round 6: the oracle's mxv cuts the rows into chunks of equal weight and folds a row heavier than a chunk in fixed blocks
+    (only for monoids that are exactly associative in the type).  Whatever the partition, the result must be the row-by-row
+    definition: checked against numpy on a matrix with one 300 000-entry hub row among 40 000 short ones, with several threads."""
+    from oracle import grb_oracle as O
+
+    rng = np.random.default_rng(11)
+    n, m = 400_000, 40_001
+    lens = rng.integers(0, 6, m)
+    lens[17] = 300_000
+    indptr = np.zeros(m + 1, np.int64)
+    indptr[1:] = np.cumsum(lens)
+    col = np.concatenate([np.sort(rng.choice(n, int(k), replace=False)) for k in lens]).astype(np.int64)
+    npt = O.NP_OF[tname]
+    vals = (rng.integers(1, 7, col.size) if tname != "BOOL" else rng.integers(0, 2, col.size)).astype(npt)
+    A = O.OMat(m, n, indptr, col, vals, tname)
+    ui = np.flatnonzero(rng.random(n) < 0.6)
+    uv = (rng.integers(1, 9, ui.size) if tname != "BOOL" else rng.integers(0, 2, ui.size)).astype(npt)
+    u = O.OVec(n, ui, uv, tname)
+    O.lib()  # (loads the library: _MAX_THREADS is known afterwards)
+    saved = O._MAX_THREADS
+    try:
+        O._MAX_THREADS = max(4, saved or 1)  # (several chunks and the block phase even on a small host)
+        got = O.mxv(A, u, sr)
+    finally:
+        O._MAX_THREADS = saved
+    u_has = np.zeros(n, bool); u_has[ui] = True
+    u_val = np.zeros(n, npt); u_val[ui] = uv
+    rows = np.repeat(np.arange(m), lens)
+    keep = u_has[col]
+    r, a, x = rows[keep], vals[keep], u_val[col[keep]]
+    mon, mul = sr.split("_")
+    prod = {"times": lambda: a * x, "plus": lambda: a + x, "land": lambda: a & x, "pair": lambda: np.ones_like(a)}[mul]()
+    exp_rows = np.unique(r)
+    assert got.idx.tolist() == exp_rows.tolist()
+    if mon == "plus":
+        exp = np.zeros(m, np.float64 if tname.startswith("FP") else npt); np.add.at(exp, r, prod)
+    elif mon == "min":
+        exp = np.full(m, np.inf if tname.startswith("FP") else np.iinfo(npt).max, npt); np.minimum.at(exp, r, prod)
+    elif mon == "lor":
+        exp = np.zeros(m, npt); np.logical_or.at(exp, r, prod)
+    else:  # any_pair: every product is 1
+        exp = np.ones(m, npt)
+    if tname == "FP64" and mon == "plus":
+        np.testing.assert_allclose(got.vals, exp[exp_rows], rtol=1e-12)
+    else:
+        assert got.vals.tolist() == exp[exp_rows].astype(npt).tolist()

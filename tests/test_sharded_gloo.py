@@ -432,7 +432,7 @@ def test_row_sharded_mxm_streamed_counts():
 # the overlapped step bench.py --gpus N runs (sharded.OverlappedMxv): every rank owns `chunks` row blocks, two replicas of u,
 # the all-gather of block c is issued asynchronously while block c + 1 is computed
 # ---------------------------------------------------------------------------------------------------------------------
-def _overlap_worker(rank, world, port, q, scale, iters, chunks, kind):
+def _overlap_worker(rank, world, port, q, scale, iters, chunks, kind, exchange="dense"):
     gb, dist = _init(rank, world, port)
     import torch
 
@@ -462,18 +462,62 @@ def _overlap_worker(rank, world, port, q, scale, iters, chunks, kind):
     if kind == "min_plus":
         us = [gb.Vector.from_coo(np.arange(n), dist0, dtype="FP32", size=n) for _ in range(2)]
         ov = sharded.OverlappedMxv(As, ws, masks, us, gb.semiring.min_plus["FP32"], accum=gb.binary.min["FP32"], desc_name="GrB_DESC_SC",
-                                   presence=False, device="cpu")
+                                   presence=False, device="cpu", exchange=exchange, delta_below=0.2)
     else:
         fi = np.flatnonzero(frontier)
         us = [gb.Vector.from_coo(fi, np.ones(fi.size, bool), dtype="BOOL", size=n) for _ in range(2)]
-        ov = sharded.OverlappedMxv(As, ws, masks, us, gb.semiring.lor_land["BOOL"], desc_name="GrB_DESC_RSC", presence=True, device="cpu")
+        ov = sharded.OverlappedMxv(As, ws, masks, us, gb.semiring.lor_land["BOOL"], desc_name="GrB_DESC_RSC", presence=True, device="cpu",
+                                   exchange=exchange)
     ov.probe_exchange()
     for _ in range(iters):
         ov.step()
     ui, uv = ov.current_u().to_coo()
-    q.put((rank, (ui.tolist(), uv.tolist(), ranges, ov.staged)))
+    q.put((rank, (ui.tolist(), uv.tolist(), ranges, ov.staged, ov.log)))
     dist.barrier()
     dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind,chunks,world,exchange", [("min_plus", 2, 2, "auto"), ("lor_land", 2, 2, "delta"), ("min_plus", 1, 2, "delta")])
+def test_sharded_step_exchanges_what_changed(kind, chunks, world, exchange):
+    """Round 6: the N-rank step sends what CHANGED when little does (sharded.OverlappedMxv(exchange="auto" | "delta")): (global row, value)
+    pairs of the entries that differ from the target replica, the changed presence bytes of a BFS step.  Six steps of the masked
+    relaxation -- it converges after a few, so an "auto" run starts dense and ends on deltas -- and of the BFS level step with the delta
+    exchange forced equal the single-process oracle on every rank; the log says which method every step took, identically on every rank."""
+    import torch
+
+    from graphblas_amd import synthetic
+    from oracle import grb_oracle as O
+
+    scale, iters = 10, 6
+    res = _spawn(_overlap_worker, world, (scale, iters, chunks, kind, exchange))
+    n = 1 << scale
+    ip, col = synthetic.rmat_csr(scale, device="cpu")
+    g = torch.Generator().manual_seed(11)
+    dist0 = torch.randint(0, 1000, (n,), generator=g).to(torch.float32).numpy()
+    frontier = (torch.rand(n, generator=g) < 0.3).numpy()
+    visited = (torch.rand(n, generator=g) < 0.5).numpy()
+    ovis = O.OVec(n, np.flatnonzero(visited), np.ones(int(visited.sum()), bool), "BOOL")
+    if kind == "min_plus":
+        oa = O.OMat(n, n, ip.numpy(), col.numpy().astype(np.int64), synthetic.edge_weights(col, scale).numpy(), "FP32")
+        ou = O.OVec(n, np.arange(n), dist0, "FP32")
+        for _ in range(iters):
+            ou = O.mxv(oa, ou, "min_plus", w=ou, mask=ovis, mask_comp=True, mask_struct=True, accum="min")
+    else:
+        oa = O.OMat(n, n, ip.numpy(), col.numpy().astype(np.int64), np.ones(col.numel(), bool), "BOOL")
+        fi = np.flatnonzero(frontier)
+        ou = O.OVec(n, fi, np.ones(fi.size, bool), "BOOL")
+        for _ in range(iters):
+            ou = O.mxv(oa, ou, "lor_land", w=ou, mask=ovis, mask_comp=True, mask_struct=True, replace=True)
+    for r in range(world):
+        assert res[r][0] == ou.idx.tolist() and res[r][1] == ou.vals.tolist(), (kind, r)
+        methods = [m for m, _b, _c in res[r][4]]
+        assert methods == [m for m, _b, _c in res[0][4]]  # (the same choice on every rank)
+        assert methods[:2] == ["dense", "dense"] and "delta" in methods, methods
+        if exchange == "delta":
+            assert methods[2:] == ["delta"] * (iters - 2)
+        # a delta step sends less than the dense one
+        dense_b = max(b for m, b, _c in res[r][4] if m == "dense")
+        assert all(b < dense_b for m, b, _c in res[r][4][-2:] if m == "delta") or kind == "lor_land"
 
 
 @pytest.mark.parametrize("kind,chunks,world", [("min_plus", 2, 2), ("lor_land", 2, 2), ("min_plus", 1, 2), ("lor_land", 4, 2)])
