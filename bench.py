@@ -82,6 +82,9 @@ def parse():
                         "matrix; with --gpus N (or --block r/w: one rank's share, alone) the rows are dealt block-cyclically, --stripe rows at a time (round 5)")
     p.add_argument("--stripe", type=int, default=8, help="--ranked: rows per stripe of the block-cyclic row dealing (a multiple of 8)")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-shard-setup", action="store_true",
+                   help="row blocks (--block / --gpus N) on scrambled labels: skip the set-up step that hands the library the global column "
+                        "counts (sharded.shard_setup); the blocks then run the natural-order layouts of rounds 1-5")
     p.add_argument("--streamed", action="store_true", help="mxm: run the unmasked product in row batches with the output streamed")
     p.add_argument("--stream-budget-gb", type=float, default=64.0, help="mxm --streamed: device bytes one batch's product may take")
     p.add_argument("--extra", action="store_true", help="(kept for old command lines: the secondary workloads now run by default)")
@@ -115,7 +118,7 @@ class MxvWorkload:
     (sharded.OverlappedMxv) -- the exchange of block c runs while block c + 1 is computed."""
 
     def __init__(self, gb, torch, scale, rank, world, semiring, visited_frac, seed=0, block=None, chunks=1, force_dist=False, weights="int255",
-                 fresh_outputs=0, ranked=False, stripe=8):
+                 fresh_outputs=0, ranked=False, stripe=8, shard_setup=True):
         from graphblas_amd import _lib, device, sharded, synthetic
 
         self.gb, self.torch, self.rank, self.world = gb, torch, rank, world
@@ -214,6 +217,21 @@ class MxvWorkload:
             self.masks.append(device.vector_from_device(torch.ones(rows, dtype=torch.bool, device="cuda"), present=vis_c))
             self.visited_c.append(vis_c)
             self._keeps.append((indptr, col))
+        # round 6: row blocks on labels the application did not rank -- the ranks all-reduce their column histograms ONCE and hand every block
+        # the global counts (sharded.shard_setup -> GrX_Matrix_shard_setup): the library ranks the columns, the same way on every rank, and
+        # lays the block out in that order.  A process that holds one block only (--block) draws the counts from the same edge stream.
+        self.shard_setup = False
+        if shard_setup and not ranked and (block or sharded_path):
+            if block:
+                counts = synthetic.rmat_col_counts(scale, device="cuda").clamp(max=(1 << 31) - 1).to(torch.int32)
+                for k, A in enumerate(self.As):
+                    device.matrix_shard_setup(A, counts) if k == 0 else device.matrix_shard_setup(A, like=self.As[0])
+                del counts
+            else:
+                import torch.distributed as tdist
+
+                sharded.shard_setup(self.As, [k[1] for k in self._keeps], n, dist=tdist if tdist.is_initialized() else None)
+            self.shard_setup = True
         # (single block: the names the CPU baseline and the single-GPU check use)
         self.A, self.w, self.mask, self.visited_local, self._keep, self._vals = (self.As[0], self.ws[0], self.masks[0], self.visited_c[0],
                                                                                  self._keeps[0], self._valss[0])
@@ -1183,7 +1201,7 @@ def main():
         visited = 0.0 if workload == "mxv_min_plus" else args.visited
         wl = MxvWorkload(gb, torch, scale, rank, world, sr, visited, block=block, chunks=max(1, args.overlap_chunks), force_dist=args.force_dist,
                          weights=weights, fresh_outputs=(steps if fresh_outputs else 0), ranked=(args.ranked if ranked is None else ranked),
-                         stripe=args.stripe)
+                         stripe=args.stripe, shard_setup=not args.no_shard_setup)
         # The first product of a matrix runs on its CSR arrays as they are; the second builds the cached layouts (hot-column coding,
         # long / short split, class strips).  Both are part of the warm-up and are timed apart (wall clock around a synchronised call).
         def timed_call():
@@ -1242,6 +1260,7 @@ def main():
                          "kernel": MXV_KERNELS_NOTE,
                          "kernel_ms_hip_events": kernel_ms, "algorithmic_bytes_per_launch": wl.bytes_per_step()},
             "stats": stats,
+            "shard_setup": bool(wl.shard_setup),
         }
         if wl.ov is not None:
             res["roofline"]["note"] = ("per rank: this rank's algorithmic bytes over the HIP-event time of its step on the library's stream "
@@ -1379,6 +1398,10 @@ def main():
                                        (f" ({res['exchange']['chunks_per_rank']} row blocks per rank) + RCCL all-gather of the w slices into "
                                                                 "the other replica of u, overlapped with the next block's product" if "exchange" in res else ""))},
             "verified": res["verified"],
+            "shard_setup": ("the blocks were handed the global column counts (sharded.shard_setup / GrX_Matrix_shard_setup): the library ranked the "
+                            "columns and laid the blocks out in that order" + ("; the replicas of u are RCCL buffers (pinned natural): the N-rank "
+                            "products run the natural-order layouts all the same, compute-only block runs (--block) the ordered ones"
+                            if "exchange" in res else "")) if res.get("shard_setup") else None,
             "first_call_ms": res["first_call_ms"],
             "layout_build_call_ms": res["layout_build_call_ms"],
             "preprocess_bytes": res["preprocess_bytes"],

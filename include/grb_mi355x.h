@@ -255,6 +255,11 @@ GrB_Info GxB_Matrix_pack_CSR(GrB_Matrix A, GrB_Index **Ap, GrB_Index **Aj, void 
  * per-call operand image, empty-tail skip, sorted row tiles) in the caller's own index order: no permutation, no vector is ever converted,
  * square and non-square matrices alike -- what GrB_mxv does by itself for a large square matrix, for the row blocks of a sharded run. */
 GrB_Info GrX_Matrix_hint_ranked(GrB_Matrix A, int ranked);
+/* Round 6: a row block of a sharded graph takes a column order derived from the GLOBAL column reference counts (identical on every rank:
+ * the host layer all-reduces the ranks' histograms once) -- the library ranks the columns itself and builds the block's ordered layouts in
+ * that order, whatever the application's labels are.  `like` != NULL: share the order object of another set-up block of the same width.
+ * Where the reference would carry this: graphblas/core/ss/context.py:71-85 (`ngpus` / per-object settings), SURVEY.md section 5. */
+GrB_Info GrX_Matrix_shard_setup(GrB_Matrix A, const uint32_t *col_counts, int on_device, const GrB_Matrix like);
 /* Borrow the device CSR of A (valid until A is modified or freed). */
 GrB_Info GrX_Matrix_export_CSR_device(const int64_t **d_Ap, const int32_t **d_Aj, const void **d_Ax, GrB_Index *nvals,
                                       int *iso, const GrB_Matrix A);
@@ -305,6 +310,7 @@ typedef struct {
     int64_t value_dict;       /* distinct values of the matrix when its hot-strip records carry one-byte value codes (0: full values) */
     int64_t fill_absent;      /* 1: a sparse operand was run as a full one with the multiply's absorbing value under its absent entries */
     int64_t long_probe;       /* BOOL product under a terminal monoid (LOR.LAND, ANY.PAIR): entries of every admitted long row tested bottom-up before the item kernels (0 = not probed) */
+    int64_t long_tails;       /* 1: the cold entries of the long rows below the hub level ran with the short rows (sorted row tiles / tagged row groups), merged with the strips' accumulators (option "cold_in_rows") */
 } GrX_Stats;
 GrB_Info GrX_last_stats(GrX_Stats *stats);
 /* T = A (+.x) B in row batches of A whose products fit `budget_bytes` of device memory; every batch runs the full two-pass
@@ -341,6 +347,11 @@ GrB_Info GrX_Matrix_cache_bytes(const GrB_Matrix A, uint64_t *bytes);
  *                   by column code) and run by k_mxv_rtile / k_mxv_rtile_bool where the call allows it: a compiled semiring over a full
  *                   operand (or lor.land / any.pair over presence / value pairs); 0: the tagged row groups everywhere; 2: the tiles on the
  *                   natural-order layouts of hot-coded matrices too (measured slower there)
+ *   "cold_in_rows"  (round 6) 0 (default; measured slower when on): > 0: on an ordered matrix the long rows with fewer entries than this (and than
+ *                   "hub_min_len") keep only their LDS-resident entries in the hot strips; their other, COLD entries are stored with the short rows
+ *                   (sorted row tiles, tagged row groups) and the short-row kernel merges the strips' accumulator into the row's result.
+ *                   0: every cold entry of a long row in the cold tiles (k_mxv_ctile), whose XCD-pinned column ranges fetch an operand line once
+ *                   per XCD instead of once per gather
  *   "stream_nt_min_nnz" (round 5) 48 Mi: matrices with at least this many entries read the streams of their row tiles and cold tiles non-temporal
  *                   (the streams no longer displace the operand's lines from L2); smaller ones -- whose layouts the 256 MB infinity cache keeps
  *                   from call to call -- keep plain loads

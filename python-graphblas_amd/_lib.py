@@ -33,7 +33,7 @@ class GrX_Stats(ctypes.Structure):
                 ("out_nvals", ctypes.c_int64), ("method", ctypes.c_int32), ("fused_epilogue", ctypes.c_int32),
                 ("hot_k", ctypes.c_int64), ("long_entries", ctypes.c_int64), ("long_segments", ctypes.c_int64),
                 ("long_kernel", ctypes.c_int32), ("reorders", ctypes.c_int32), ("ordered", ctypes.c_int64), ("value_dict", ctypes.c_int64), ("fill_absent", ctypes.c_int64),
-                ("long_probe", ctypes.c_int64)]
+                ("long_probe", ctypes.c_int64), ("long_tails", ctypes.c_int64)]
 
 
 def load(path: str | None = None):
@@ -131,6 +131,7 @@ def _declare(L):
     L.GrX_Matrix_export_CSR_device.argtypes = [P(c_void_p), P(c_void_p), P(c_void_p), P(c_u64), P(c_int), c_void_p]
     L.GrX_Matrix_cache_transpose.argtypes = [c_void_p]
     L.GrX_Matrix_hint_ranked.argtypes = [c_void_p, c_int]
+    L.GrX_Matrix_shard_setup.argtypes = [c_void_p, c_void_p, c_int, c_void_p]
     L.GrX_Vector_import_dense_device.argtypes = [P(c_void_p), c_void_p, c_u64, c_void_p, c_void_p]
     L.GrX_Vector_export_dense_device.argtypes = [P(c_void_p), P(c_void_p), c_void_p]
     L.GrX_Vector_modified.argtypes = [c_void_p]

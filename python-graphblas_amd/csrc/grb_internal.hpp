@@ -120,7 +120,7 @@ struct Context {
     int64_t stream_nt_min_nnz = 48ll << 20;  // matrices with at least this many entries stream their layouts non-temporal (k_mxv_rtile / _bool / k_mxv_ctile)
     int bool_probe = 8;  // entries of a long row of a BOOL matrix tested by k_long_init before the item kernels (terminal monoids: LOR, ANY); 0 = off
     int rtile_rows = 8192;           // ... rows per tile (8192 or 16384; 8-byte accumulators: half)
-    int64_t rtile_entries = 32768;   // ... and about this many entries
+    int64_t rtile_entries = 49152;   // ... and about this many entries (round 6, tiles handed out heaviest first: 32 Ki / 40 Ki / 48 Ki / 64 Ki / 96 Ki / 128 Ki = 0.469 / 0.460 / 0.464 / 0.465 / 0.471 / 0.483 ms masked, 0.589 / - / - / 0.573 / - / 0.603 unmasked; profiles/r06/option_sweeps.txt)
     int rows_head = 1;               // 1: the short rows of an ordered matrix run with the hottest columns of the operand in LDS (k_mxv_rows_tag<.., HEAD>)
     int64_t rows_head_min_groups = 16384;  // ... from this many row groups of 64 (below, filling 512 heads costs more than they save)
     int push_small = 1;              // 1: a pushed frontier of at most 64 work items runs its three passes in one workgroup (k_push_small)
@@ -139,6 +139,13 @@ struct Context {
     void *host_pinned = nullptr;     // 4 KiB of page-locked host memory: small device-to-host reads land here (no staging copy in the runtime)
     unsigned long long *push_counters = nullptr;  // the thin push path's counters (grb_mxv_push.inc): two sets of four words, used in turn --
     int push_parity = 0;                          // a call's frontier kernel zeroes the set of the next call
+    int cold_in_rows = 0;            // (round 6, MEASURED AND OFF) > 0: long rows of an ordered matrix with fewer entries than this (and than hub_min_len) keep
+                                     // only their LDS-resident (hot) entries in the strips; their COLD entries join the short rows' sorted row tiles (and
+                                     // tagged row groups), whose kernel merges the strips' accumulator into the row's result.  Headline, scale 24: 0.458 ->
+                                     // 0.487 ms with 1024 (k_mxv_ctile 124 -> 64 us, k_mxv_rtile 179 -> 270 us), unmasked 0.573 -> 0.665: an unpinned cold
+                                     // gather moves a 128-byte line over the fabric EVERY time (0.7 GB more for the 5.5 M admitted gathers that moved), the
+                                     // cold tiles' XCD-pinned column ranges fetch a line once per XCD (profiles/r06/cold_in_rows.txt).  0 = all cold
+                                     // entries of the long rows as cold tiles (rounds 3-5)
 };
 Context &ctx();
 void require_init();
@@ -384,6 +391,9 @@ struct GB_Matrix_opaque {
                                        // no permutation, vectors stay natural -- for square and non-square matrices alike (the row blocks of a sharded run
                                        // whose graph was relabelled once, up front).  A performance hint: no result depends on it.
     GB_Perm *perm = nullptr;           // the order of this matrix's vertex space (shared with its transpose and with vectors)
+    bool col_order_only = false;       // (GrX_Matrix_shard_setup, round 6) `perm` orders the COLUMN space only: the matrix is a row block of a sharded
+                                       // graph (m rows over n columns), its twin keeps the rows as they are and renames the columns; only the
+                                       // operand of a product carries the order, outputs and masks (m elements) stay natural
     GB_Matrix_opaque *ord = nullptr;   // the matrix in that order (owned): layouts only -- its CSR arrays are released once they are built
     GB_Matrix_opaque *tr_of = nullptr; // this matrix is the cached transpose of tr_of (not owned)
     int ord_state = 0;                 // 0 = not analysed, 1 = `ord` is built, -1 = not worth it / not possible
@@ -398,6 +408,8 @@ struct GB_Matrix_opaque {
     int split_state;          // 0 = not analysed, 1 = enabled, -1 = not worth it
     bool split_hot;           // short_part's columns are hot-coded
     std::string err;
+    int64_t tails_max_len = 0;         // > 0: long rows with fewer entries than this have their cold entries in `short_part` (Context::cold_in_rows): the
+                                       // short-row kernels add them up and MERGE the long-row accumulator into the row's result
 };
 
 namespace grb {

@@ -701,8 +701,16 @@ constexpr int MU_SMALL = GRB_MU_SMALL;  // entries of a unit a single wavefront 
 // wavefront owns two consecutive units of the class list (neighbouring windows of one row, as a rule): both records and both
 // offset chains are requested BEFORE the first unit's bitmap and products are touched, so the second unit's chain travels
 // under the first unit's work; the units then run one after the other in the same LDS (no more LDS, +14 registers).
+// MEASURED (profiles/r06/mxm_units_per_wavefront.txt, INT64 A (+.x) A, ms per product, UPW = 1 / 2 / 3): scale 20 (single windows)
+// 130.0 / 134.2 / 133.3; scale 22 (window pairs) 1292.8 / 1270.7 / 1265.4, run-to-run noise +-0.5 %.  The offset chain is not what a unit
+// waits for (round 3 found the same for the symbolic units); a unit's TRIPS are, and two units' trips in flight at once need two
+// bitmaps and two accumulator sets -- the LDS that already holds the class at four workgroups per CU.  Default: 1 (2 from window
+// groups on would buy 1.7 % at scale 22 and cost 3 % wherever single windows run).
 #ifndef GRB_MU_UPW
-#define GRB_MU_UPW 2
+#define GRB_MU_UPW 1
+#endif
+#ifndef GRB_MU_PIPE
+#define GRB_MU_PIPE 1  // 1: the trips of a batch / segment are software-pipelined (round 6); 0: load, wait, apply per trip (rounds 2-5)
 #endif
 constexpr int mu_units_per_wave(int mode, int wpu) { return (mode == 1 && wpu == 1) ? GRB_MU_UPW : 1; }
 
@@ -914,22 +922,57 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4), mu_min_waves(MODE, WPU, C
                 scan[lane] = start;
                 sqb[lane] = qb - start;  // (product t of the batch is entry sqb[e] + t of B, e = the lane that brought it)
                 mw_sync();
-                for (int t0 = lane; t0 < total; t0 += 64 * ILP) {
-                    // ILP products per lane: their searches interleave and their loads are issued back to back -- every product number
-                    // is clamped into the batch instead of being guarded by a branch (a guarded load is waited for inside its branch)
-                    decltype(load((const int32_t *)nullptr, 0u, 0)) d[ILP];
+                // ILP products per lane and TRIP: their searches interleave and their loads are issued back to back -- every product number
+                // is clamped into the batch instead of being guarded by a branch (a guarded load is waited for inside its branch).
+                // Round 6 (GRB_MU_PIPE): the trips of a batch are SOFTWARE-PIPELINED -- the loads of trip k + 1 are issued before the
+                // products of trip k go to LDS, through two register sets with static roles (no copies: a copied register waits for its
+                // load), and only trips that exist are ever requested (the loop runs while two more trips follow; the last one or two
+                // are peeled).  A unit's wavefront used to wait one global round trip per trip with nothing else of its own in flight.
+                using D = decltype(load((const int32_t *)nullptr, 0u, 0));
+                constexpr int TRIP = 64 * ILP;
+                auto fetch_trip = [&](int base, D (&d)[ILP]) {
 #pragma unroll
                     for (int u = 0; u < ILP; u++) {
-                        const int t = t0 + 64 * u < total ? t0 + 64 * u : total - 1;
+                        const int tt = base + lane + 64 * u;
+                        const int t = tt < total ? tt : total - 1;
                         int lo = 0;  // the last entry whose first product number is <= t (scan[0] = 0 <= t): six steps, three VALU each
 #pragma unroll
                         for (int st = 32; st > 0; st >>= 1)
                             if (scan[lo + st] <= t) lo += st;
                         d[u] = load(a.Bj + sqb[lo], (unsigned)t, lo);
                     }
+                };
+                auto apply_trip = [&](int base, const D (&d)[ILP]) {
 #pragma unroll
                     for (int u = 0; u < ILP; u++)
-                        if (t0 + 64 * u < total) apply(d[u]);
+                        if (base + lane + 64 * u < total) apply(d[u]);
+                };
+                D da[ILP];
+                int base = 0;
+                fetch_trip(0, da);
+                if constexpr (GRB_MU_PIPE != 0) {
+                    D db[ILP];
+                    while (base + 2 * TRIP < total) {  // (uniform: two more trips follow the one in `da`)
+                        fetch_trip(base + TRIP, db);
+                        apply_trip(base, da);
+                        fetch_trip(base + 2 * TRIP, da);
+                        apply_trip(base + TRIP, db);
+                        base += 2 * TRIP;
+                    }
+                    if (base + TRIP < total) {
+                        fetch_trip(base + TRIP, db);
+                        apply_trip(base, da);
+                        apply_trip(base + TRIP, db);
+                    } else {
+                        apply_trip(base, da);
+                    }
+                } else {
+                    for (;;) {
+                        apply_trip(base, da);
+                        base += TRIP;
+                        if (base >= total) break;
+                        fetch_trip(base, da);
+                    }
                 }
                 mw_sync();
                 return;
@@ -972,17 +1015,49 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4), mu_min_waves(MODE, WPU, C
                 const short *rpb = recb;
                 unsigned t = (unsigned)(seg0 + lane);
                 const unsigned t_last = (unsigned)(total - 1);
-                for (int g0 = 0; g0 < g_n; g0 += ILP, rpm += ILP, rpb += ILP, t += 64 * ILP) {
-                    decltype(load((const int32_t *)nullptr, 0u, 0)) d[ILP];
+                // (round 6, GRB_MU_PIPE: the trips of a segment software-pipelined as in the search dealing above -- the loads of trip k + 1
+                //  leave before the products of trip k go to LDS; two register sets with static roles; only trips that exist are requested)
+                using D = decltype(load((const int32_t *)nullptr, 0u, 0));
+                auto fetch_grp = [&](int g0, D (&d)[ILP]) {
 #pragma unroll
                     for (int u = 0; u < ILP; u++) {
-                        const int rank = (int)rpb[u] + __popcll(rpm[u] & lane_le);
-                        const unsigned tu = t + 64u * u < t_last ? t + 64u * u : t_last;
+                        const int rank = (int)rpb[g0 + u] + __popcll(rpm[g0 + u] & lane_le);
+                        const unsigned tt = t + 64u * (unsigned)(g0 + u);
+                        const unsigned tu = tt < t_last ? tt : t_last;
                         d[u] = load(cptr[rank], tu, rank);
                     }
+                };
+                auto apply_grp = [&](int g0, const D (&d)[ILP]) {
 #pragma unroll
                     for (int u = 0; u < ILP; u++)
-                        if (t + 64u * u <= t_last) apply(d[u]);
+                        if (t + 64u * (unsigned)(g0 + u) <= t_last) apply(d[u]);
+                };
+                D da[ILP];
+                int g0 = 0;
+                fetch_grp(0, da);
+                if constexpr (GRB_MU_PIPE != 0) {
+                    D db[ILP];
+                    while (g0 + 2 * ILP < g_n) {  // (uniform: two more trips follow the one in `da`)
+                        fetch_grp(g0 + ILP, db);
+                        apply_grp(g0, da);
+                        fetch_grp(g0 + 2 * ILP, da);
+                        apply_grp(g0 + ILP, db);
+                        g0 += 2 * ILP;
+                    }
+                    if (g0 + ILP < g_n) {
+                        fetch_grp(g0 + ILP, db);
+                        apply_grp(g0, da);
+                        apply_grp(g0 + ILP, db);
+                    } else {
+                        apply_grp(g0, da);
+                    }
+                } else {
+                    for (;;) {
+                        apply_grp(g0, da);
+                        g0 += ILP;
+                        if (g0 >= g_n) break;
+                        fetch_grp(g0, da);
+                    }
                 }
                 mw_sync();
             }

@@ -243,6 +243,7 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
         dev_free(A->d_rt_col); dev_free(A->d_rt_tag); dev_free(A->d_rt_val); dev_free(A->d_rt_tiles); dev_free(A->d_rt_order); dev_free(A->d_rt_counter);
         A->d_rt_col = nullptr; A->d_rt_tag = nullptr; A->d_rt_val = nullptr; A->d_rt_tiles = nullptr; A->d_rt_order = nullptr; A->d_rt_counter = nullptr;
         A->rt_state = 0; A->rt_units = 0; A->rt_ntiles = 0;
+        A->tails_max_len = 0;
         dev_free(A->d_sstart); dev_free(A->d_sslot); dev_free(A->d_hrec);
         A->d_sstart = nullptr; A->d_sslot = nullptr; A->d_hrec = nullptr; A->strip_nseg = 0; A->hub_ncls = 0;
         dev_free(A->d_ct_col); dev_free(A->d_ct_val); dev_free(A->d_ct_loc); dev_free(A->d_ct_tiles); dev_free(A->d_ct_order);
@@ -261,10 +262,27 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
     const int64_t m = (int64_t)A->nrows, nnz = A->nvals;
     if (nnz < ctx().split_min_nnz || m == 0 || (ctx().debug_flags & 128)) return;
     const int min_len = ctx().split_min_len > 0 ? ctx().split_min_len : ((kind == 2 || kind == 4) ? 64 : 256);  // (measured optima, scripts/gpu_r02_nc.sh)
+    // Round 6: the COLD entries of the long rows below `tail_max` entries -- column codes that are not LDS-resident in their class: codes from
+    // `tail_lim` on -- join the short part (Context::cold_in_rows): on an ordered twin the short rows' sorted row tiles stream them at 7 bytes
+    // an entry into accumulators they hold in LDS anyway, where the cold tiles (10 bytes, a flush by global atomics, a launch of their own)
+    // cost twice as much per entry.  Hub rows keep their cold entries as cold tiles (64 of them would fill a row tile a hundred times).
+    // (the limits below are the ones the class keys use further down: strip_classes / lds_lim4 / hub_ncls -- checked there)
+    int64_t tail_max = 0;
+    unsigned tail_lim = 0u;
+    if (kind == 4 && A->hot_identity && hot && want_tagged_only && ctx().rows_tile && ctx().cold_in_rows > min_len && nnz < 0xf0000000ll &&
+        A->d_cold_bounds && A->ct_ncr > 0 && !A->iso && (A->type->size == 4 || A->type->size == 8)) {
+        const int ncls_t = (ctx().long_classes == 16 || ctx().long_classes == 32 || ctx().long_classes == 64) ? ctx().long_classes : 8;
+        const int64_t lim_t = std::min<int64_t>(A->hot_k, long_lds_codes((int)A->type->size, false, LONG_LDS_WORDS) / 8 * ncls_t);
+        const bool hub_t = ctx().hub_min_len > 0 && ncls_t < 64;
+        tail_max = hub_t ? std::min<int64_t>(ctx().cold_in_rows, ctx().hub_min_len) : (int64_t)ctx().cold_in_rows;
+        tail_lim = (unsigned)lim_t;
+        if (tail_max <= min_len) tail_max = 0;
+    }
     DevBuf<uint64_t> lbits(bits_words64((uint64_t)m));
     DevBuf<int64_t> slen(m + 1), lflag(m + 1), nchunk(m + 1);
+    DevBuf<unsigned long long> tails_total(1, true);
     hipLaunchKernelGGL(k_split_classify, dim3((unsigned)ceil_div((int64_t)bits_words64((uint64_t)m) * 64 + 1, 256)), dim3(256), 0,
-                       ctx().stream, (const int64_t *)A->d_ptr, m, min_len, lbits.p, slen.p, lflag.p, nchunk.p);
+                       ctx().stream, (const int64_t *)A->d_ptr, m, min_len, lbits.p, slen.p, lflag.p, nchunk.p, col_src, tail_max, tail_lim, tails_total.p);
     prim_exclusive_sum_i64(slen.p, slen.p, m + 1);
     prim_exclusive_sum_i64(lflag.p, lflag.p, m + 1);
     prim_exclusive_sum_i64(nchunk.p, nchunk.p, m + 1);
@@ -272,7 +290,9 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
     d2h(&nnz_short, slen.p + m, 8);
     d2h(&nl, lflag.p + m, 8);
     d2h(&nc, nchunk.p + m, 8);
-    if (nl == 0 || (double)(nnz - nnz_short) < 0.3 * (double)nnz) return;  // too few entries in long rows to pay off
+    unsigned long long n_tails = 0;
+    if (tail_max > 0) d2h(&n_tails, tails_total.p, 8);
+    if (nl == 0 || (double)(nnz - nnz_short + (int64_t)n_tails) < 0.3 * (double)nnz) return;  // too few entries in long rows to pay off
     ensure_vdict(A, kind == 4);
     GB_Matrix_opaque *S = matrix_new(A->type, A->nrows, A->ncols);
     try {
@@ -292,6 +312,10 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
                                (const int64_t *)A->d_ptr, col_src, (const T *)A->d_val, A->iso ? 1 : 0, m, min_len,
                                (const int64_t *)S->d_ptr, (const int64_t *)lflag.p, (const int64_t *)nchunk.p, S->d_col,
                                (T *)S->d_val, A->d_long_rows, A->d_chunk_slot, A->d_chunk_start, A->d_chunk_len, A->d_long_prefix);
+            if (tail_max > 0)
+                hipLaunchKernelGGL((k_split_fill_tails<T>), dim3((unsigned)ceil_div(nl, 4)), dim3(256), 0, ctx().stream, (const int64_t *)A->d_ptr, col_src,
+                                   (const T *)A->d_val, A->iso ? 1 : 0, (const int32_t *)A->d_long_rows, nl, (const int64_t *)S->d_ptr, S->d_col, (T *)S->d_val,
+                                   tail_max, tail_lim);
         })
         // the bottom-up probe of a BOOL matrix (k_long_init): the first 16 column codes of every long row
         dev_free(A->d_probe);
@@ -305,10 +329,19 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
         }
         // class-partitioned copy of the long rows: sort the entries by (class, slot), cut the runs into items, sort the
         // items by (class, falling length), lay them out with 4-entry aligned starts
+        // (tail_max > 0: the keys cover ALL entries of the long rows -- those that moved to the short part get the discard class and sort behind
+        //  everything; nnz_long counts the entries the long-row kernels keep)
         const int64_t nnz_long = nnz - nnz_short;
+        DevBuf<int64_t> lpre(tail_max > 0 ? nl + 1 : 0);
+        int64_t nnz_keyed = nnz_long;
+        if (tail_max > 0) {
+            hipLaunchKernelGGL(k_long_lens, dim3((unsigned)ceil_div(nl + 1, 256)), dim3(256), 0, ctx().stream, (const int64_t *)A->d_ptr, (const int32_t *)A->d_long_rows, nl, lpre.p);
+            prim_exclusive_sum_i64(lpre.p, lpre.p, nl + 1);
+            d2h(&nnz_keyed, lpre.p + nl, 8);
+        }
         A->long_nnz = 0;
         A->n_items = 0;
-        if (nnz_long < 0xf0000000ll && nnz < 0xffffffffll) {
+        if (nnz_keyed < 0xf0000000ll && nnz < 0xffffffffll) {
             // sub-ranges per class: sized so that one sub-range of the operand image is ~2 MiB (half an XCD's L2; BOOL images are
             // bit-packed and fit as they are); measured on R-MAT scale 24 fp32: 4 sub-ranges -3 % per call, and rows need ~512
             // entries per sub-range or their items get too small (sub 8 from 2048 entries: +3 %)
@@ -331,8 +364,8 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
             const int64_t nv = (int64_t)ncls * (int64_t)sub * nl;
             int bits = 1;
             while (((int64_t)1 << bits) < nv) bits++;
-            DevBuf<uint64_t> keys(nnz_long), keys2(nnz_long);
-            DevBuf<uint32_t> idx(nnz_long), idx2(nnz_long);
+            DevBuf<uint64_t> keys(nnz_keyed), keys2(nnz_keyed);
+            DevBuf<uint32_t> idx(nnz_keyed), idx2(nnz_keyed);
             // (a matrix in its popularity order carries its own column ranges: about equal reference counts, at most ~2 MiB of operand)
             const bool own_ranges = kind == 4 && A->hot_identity && A->d_cold_bounds && A->ct_ncr > 0;
             // ... and deals its hub rows to 64 classes (GB_Matrix_opaque::hub_ncls): only there are the LDS heads lines of the operand
@@ -340,30 +373,33 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
             const int hub_ncls = (own_ranges && ctx().hub_min_len > 0 && ncls < 64) ? 64 : 0;
             const int64_t hub_lim = hub_ncls ? std::min<int64_t>((int64_t)A->ncols, long_lds_codes((int)A->type->size, A->type->code == TC_BOOL, LONG_LDS_WORDS) / 8 * hub_ncls) : 0;
             const int64_t hub_len = hub_ncls ? (int64_t)ctx().hub_min_len : 0;
+            if (tail_max > 0 && (!own_ranges || (int64_t)tail_lim != lds_lim4 || (hub_ncls && tail_max > hub_len)))
+                fail(GrB_PANIC, "long / short split: the cold entries of the long rows were cut at another limit than the class keys use (internal error)");
+            const unsigned discard_cls = (unsigned)(ncls + hub_ncls + (own_ranges ? A->ct_ncr : COLD_CLS * (int)sub));  // (behind the last cold range)
             if (kind == 4)
                 hipLaunchKernelGGL(k_long_keys, dim3((unsigned)nl), dim3(256), 0, ctx().stream, (const int64_t *)A->d_ptr,
                                    (const int64_t *)S->d_ptr, (const int32_t *)A->d_long_rows, col_src, nl, keys.p, idx.p,
                                    (unsigned)lds_lim4, (unsigned)std::max<int64_t>(1, ceil_div(codes_total - std::max<int64_t>(lds_lim4, hot ? A->hot_k : 0), (int64_t)COLD_CLS * (int64_t)sub)),
                                    sub, sub_min_len, (unsigned)ncls, 2, (unsigned)(hot ? A->hot_k : 0),
                                    own_ranges ? (const int32_t *)A->d_cold_bounds : (const int32_t *)nullptr, own_ranges ? A->ct_ncr + 1 : 0,
-                                   hub_len, (unsigned)hub_lim, (unsigned)hub_ncls);
+                                   hub_len, (unsigned)hub_lim, (unsigned)hub_ncls, tail_max, discard_cls, tail_max > 0 ? (const int64_t *)lpre.p : (const int64_t *)nullptr);
             else
             hipLaunchKernelGGL(k_long_keys, dim3((unsigned)nl), dim3(256), 0, ctx().stream, (const int64_t *)A->d_ptr,
                                (const int64_t *)S->d_ptr, (const int32_t *)A->d_long_rows, col_src, nl, keys.p, idx.p,
                                (unsigned)(hot ? A->hot_k : 0), (unsigned)std::max<int64_t>(1, ceil_div((int64_t)A->ncols, (int64_t)ncls * (int64_t)sub)),
-                               sub, sub_min_len, (unsigned)ncls, kind == 2 ? 1 : 0, 0u, (const int32_t *)nullptr, 0, (int64_t)0, 0u, 0u);
+                               sub, sub_min_len, (unsigned)ncls, kind == 2 ? 1 : 0, 0u, (const int32_t *)nullptr, 0, (int64_t)0, 0u, 0u, (int64_t)0, 0u, (const int64_t *)nullptr);
             // (virtual classes: kind 2 ncls * sub; kind 4 ncls hot classes + COLD_CLS cold ranges, with `sub` = 1 in the segment tables)
             const int nvc = ncls + hub_ncls;                                            // classes of the strips (chunk ranges)
             const int n_cr = own_ranges ? A->ct_ncr : COLD_CLS * (int)sub;             // kind 4: column ranges of the cold tiles
-            const int nvirt = kind == 4 ? nvc + n_cr : ncls * (int)sub;                 // virtual classes (sort keys)
+            const int nvirt = kind == 4 ? nvc + n_cr + (tail_max > 0 ? 1 : 0) : ncls * (int)sub;  // virtual classes (sort keys; + the discard class)
             const int hot_cls = 0;
             const unsigned strip_sub = kind == 4 ? 1u : sub;                            // virtual classes per strip class
             if (strips) {
                 int vbits = 1;
                 while ((1 << vbits) < nvirt) vbits++;
-                prim_sort_pairs_u64_u32_bits(keys.p, keys2.p, idx.p, idx2.p, nnz_long, 32, 32 + vbits);
+                prim_sort_pairs_u64_u32_bits(keys.p, keys2.p, idx.p, idx2.p, nnz_keyed, 32, 32 + vbits);
             } else {
-                prim_sort_pairs_u64_u32(keys.p, keys2.p, idx.p, idx2.p, nnz_long, bits);
+                prim_sort_pairs_u64_u32(keys.p, keys2.p, idx.p, idx2.p, nnz_keyed, bits);
             }
             // kind 4: the sorted entries are [hot: virtual classes 0 .. ncls - 1 | cold: column ranges ncls .. ncls + n_cr - 1]; the hot
             // part becomes strips (lane records), the cold part tagged tiles (grb_mxv_ctile.inc)
@@ -374,10 +410,13 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
             DevBuf<int64_t> tile_first(n_tiles + 1);
             int64_t n_strip = nnz_long;
             if (kind == 4) {
-                hipLaunchKernelGGL(k_ctile_first, dim3((unsigned)ceil_div(n_tiles + 1, 256)), dim3(256), 0, ctx().stream, (const uint64_t *)keys2.p, nnz_long,
+                hipLaunchKernelGGL(k_ctile_first, dim3((unsigned)ceil_div(n_tiles + 1, 256)), dim3(256), 0, ctx().stream, (const uint64_t *)keys2.p, nnz_keyed,
                                    n_tiles, n_sb, (unsigned)nvc, tile_first.p, ct_slots);
                 d2h(h_first.data(), tile_first.p, sizeof(int64_t) * (size_t)(n_tiles + 1));
                 n_strip = h_first[0];
+                // (h_first[n_tiles] = the first key of the discard class: everything in front of it is what the long-row kernels keep)
+                if (h_first[(size_t)n_tiles] != nnz_long)
+                    fail(GrB_PANIC, "long / short split: the short part and the class keys disagree about the cold entries that moved (internal error)");
             }
             if (kind == 4) {
                 A->long_nnz = nnz_long;
@@ -694,6 +733,7 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
     A->split_hot = hot;
     A->split_kind = kind;
     A->split_state = 1;
+    A->tails_max_len = tail_max;
     A->short_tagged_only = false;
     if (want_tagged_only && S->nrows == A->nrows && S->nvals < 0x1ffffffffll) {
         // the tagged row groups are the only form of the short rows' entries the kernels read: the CSR copy they were built from is
@@ -732,7 +772,7 @@ static uint64_t order_signature()
     const Context &c = ctx();
     uint64_t h = 1469598103934665603ull;
     const int64_t v[] = {c.long_kernel, c.short_kernel, c.long_classes, c.split_min_len, c.long_sub, c.long_sub_min_len, c.lean_min_nnz,
-                         c.split_min_nnz, c.hot_k, c.drop_hot_cols, c.hub_min_len, c.value_dict, c.rows_tile, c.rtile_rows, c.rtile_entries};
+                         c.split_min_nnz, c.hot_k, c.drop_hot_cols, c.hub_min_len, c.value_dict, c.rows_tile, c.rtile_rows, c.rtile_entries, c.cold_in_rows};
     for (int64_t x : v) h = (h ^ (uint64_t)x) * 1099511628211ull;
     return h;
 }
@@ -810,10 +850,31 @@ static void ensure_ordered(GB_Matrix_opaque *S)
     // converted, and nothing has to be square: m rows, n columns.
     const bool ranked = S->ranked;
     const int64_t m_rows = (int64_t)S->nrows;
-    GB_Perm *P = ranked ? nullptr : ensure_perm(S, k_hot, poscnt);
+    // A row block set up for a sharded run (GrX_Matrix_shard_setup, round 6): the column order came from the GLOBAL reference counts -- the
+    // same on every rank --, the rows stay as they are: the twin is the block with its columns renamed, any shape.
+    if (S->col_order_only && !S->perm) S->col_order_only = false;
+    const bool col_only = !ranked && S->col_order_only;
+    if (!ranked && !col_only && S->nrows != S->ncols) return;  // (an order of the library's own needs one vertex space)
+    GB_Perm *P = ranked ? nullptr : (col_only ? S->perm : ensure_perm(S, k_hot, poscnt));
     GB_Matrix_opaque *R = matrix_new(S->type, S->nrows, S->ncols);
     try {
-      if (ranked) {
+      if (col_only) {
+        // reference counts of THIS block by position (they steer the column ranges of its cold tiles)
+        DevBuf<unsigned int> cnt(n, true);
+        const int hstride = nnz >= ((int64_t)1 << 26) ? 8 : 1;
+        hipLaunchKernelGGL(k_hot_hist, dim3((unsigned)ceil_div(nnz, 256 * hstride)), dim3(256), 0, ctx().stream, S->d_col, nnz, cnt.p, hstride);
+        hipLaunchKernelGGL(k_order_poscnt, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx().stream, (const unsigned int *)cnt.p,
+                           (const int32_t *)P->d_inv, n, poscnt.p);
+        R->d_ptr = (int64_t *)dev_alloc(sizeof(int64_t) * (size_t)(m_rows + 1));
+        d2d(R->d_ptr, matrix_rowptr(S), sizeof(int64_t) * (size_t)(m_rows + 1));
+        R->d_col = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)nnz);
+        hipLaunchKernelGGL(k_cols_rename, dim3((unsigned)ceil_div(nnz, 256)), dim3(256), 0, ctx().stream, (const int32_t *)S->d_col, (const int32_t *)P->d_rank, nnz, R->d_col);
+        R->d_val = dev_alloc(vb * (size_t)(S->iso ? 1 : nnz));
+        d2d(R->d_val, S->d_val, vb * (size_t)(S->iso ? 1 : nnz));
+        R->iso = S->iso;
+        R->nvals = nnz;
+        sync_stream();  // (cnt is released at the end of this scope)
+      } else if (ranked) {
         GRB_HIP(hipMemsetAsync(poscnt.p, 0, sizeof(unsigned int) * (size_t)n, ctx().stream));
         const int hstride = nnz >= ((int64_t)1 << 26) ? 8 : 1;
         hipLaunchKernelGGL(k_hot_hist, dim3((unsigned)ceil_div(nnz, 256 * hstride)), dim3(256), 0, ctx().stream, S->d_col, nnz, poscnt.p, hstride);
@@ -1083,6 +1144,9 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
         ctx().stats.long_segments = by_strip ? A->strip_nseg : 0;
         const bool by_class = A->split_kind == 1 && A->long_nnz > 0 && A->n_items > 0;
         ctx().stats.long_kernel = by_strip ? A->split_kind : (by_class ? 1 : 0);
+        // (round 6: the short part holds the cold entries of the long rows below tails_max_len entries -- the short-row kernels merge)
+        a.long_tails = A->tails_max_len > 0 ? 1 : 0;
+        ctx().stats.long_tails = a.long_tails;
         DevBuf<uint32_t> long_act((size_t)ceil_div(a.n_long, 64) * 2);
         a.long_act = long_act.p;
         // the fast kernel of the hot strips (k_mxv_hstrip): a specialised semiring over a full operand whose values are read
@@ -1249,6 +1313,10 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
             // one persistent 1024-thread workgroup per CU; block b works on column class b % 8 (= the XCD it runs on)
             const int64_t G = std::max<int64_t>(8, (int64_t)(ctx().num_cus / 8) * 8);
             hipLaunchKernelGGL((k_mxv_long_grp<T, MON, MUL, LONG_LDS_WORDS>), dim3((unsigned)G), dim3(LONG_BLOCK), 0, ctx().stream, a);
+        } else if (a.long_tails) {
+            // (neither strips nor cold tiles were built.  With cold entries of long rows in the short part that means EVERY entry of every long row
+            //  is there -- hub rows, which keep theirs, always produce strips or tiles -- and the chunk kernel, which walks whole rows of A, must not run)
+            if (A->long_nnz > 0) fail(GrB_PANIC, "pull SpMV: long rows with entries in the short part but no strips (internal error)");
         } else {
             const int64_t want = ceil_div(a.n_chunks, LONG_BLOCK / 64);
             const int64_t G = std::min<int64_t>(want, (int64_t)ctx().num_cus);  // persistent: one 1024-thread workgroup per CU
@@ -1374,6 +1442,7 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
             ctx().stats.tiles = ceil_div(b.m, 64);
             return;
         }
+        if (a.long_tails) fail(GrB_PANIC, "pull SpMV: the short part holds entries of long rows, which only the tagged row groups and the row tiles merge (internal error)");
         if (sk != 0 && S->nrows == A->nrows) {
             // short rows: one wavefront per 64 consecutive rows, which also applies the write rule of the long rows
             b.long_prefix = A->d_long_prefix;
@@ -2079,8 +2148,10 @@ static void mxv_any_order(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_
         return;
     }
     // (a matrix with ranked labels, GrX_Matrix_hint_ranked: the ordered layouts without an order -- any shape, pinned vectors welcome)
+    // (a row block with a column order, GrX_Matrix_shard_setup: only the operand is converted -- it must be free to: not pinned, not the output)
+    const bool col_only = S->col_order_only && S->perm && !S->ranked;
     if (shapes_ok && ctx().order_mode && S->nvals >= ctx().order_min_nnz && sr->type == S->type->code && S->d_col &&
-        (S->ranked || (S->nrows == S->ncols && !w->pinned && !u->pinned && !(mask && mask->pinned)))) {
+        (S->ranked || (col_only ? (!u->pinned && u != w && u != mask && !u_token) : (S->nrows == S->ncols && !w->pinned && !u->pinned && !(mask && mask->pinned))))) {
         int mult = canonical_op(sr->type, sr->mult);
         if (flip) mult = flip_op(mult);
         const bool by_rowlen = mult == OP_PAIR && u->nvals == (int64_t)u->n && !(ctx().debug_flags & 65536);
@@ -2091,7 +2162,14 @@ static void mxv_any_order(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_
             ordered = S->ord_state == 1;
         }
     }
-    if (ordered) {
+    if (ordered && col_only) {
+        // the operand in the column order, the output and the mask (the block's ROW space) natural
+        vector_set_order(w, nullptr);
+        if (mask) vector_set_order(mask, nullptr);
+        vector_set_order(u, S->perm);
+        mxv_core(w, mask, accum, sr, S->ord, u, flip, f);
+        ctx().stats.ordered = 1;
+    } else if (ordered) {
         GB_Perm *P = S->ranked ? nullptr : S->perm;  // (ranked labels: the twin is in the caller's own order -- the vectors stay natural)
         // an output that keeps nothing of its old content needs no conversion: it is emptied and takes the order
         const bool w_dead = !accum && (!mask || f.replace) && w != u && w != mask;
@@ -2184,6 +2262,65 @@ extern "C" GrB_Info GrX_Matrix_hint_ranked(GrB_Matrix A, int ranked)
             A->tr->ranked = A->ranked;
         }
     }
+    GRB_CATCH(errp(A))
+}
+
+// A row block of a sharded graph (round 6): every rank passes the SAME reference counts of the n columns
+// (its host layer all-reduced the ranks' column histograms once, at set-up), the library ranks the columns by them -- falling count, ties
+// by index: the same permutation on every rank -- and builds the popularity-ordered layouts of THIS block in that column order, rows as
+// they are, any shape.  `like`: take the order of another block that was set up (the chunks of one rank share one order object, so an
+// operand is converted once for all of them); `col_counts` is then ignored.  A performance hint only: results are those of the natural
+// order.  An operand whose image is pinned (RCCL buffers) cannot be converted in place: such a product runs the natural-order layouts.
+extern "C" GrB_Info GrX_Matrix_shard_setup(GrB_Matrix A, const uint32_t *col_counts, int on_device, const GrB_Matrix like)
+{
+    GRB_TRY
+    require_init();
+    check_matrix(A, "A");
+    GB_Perm *P = nullptr;
+    const int64_t n = (int64_t)A->ncols;
+    if (like) {
+        check_matrix(like, "like");
+        if (!like->perm || !like->col_order_only || like->ncols != A->ncols) fail(GrB_INVALID_VALUE, "GrX_Matrix_shard_setup: `like` carries no column order of this width");
+        P = like->perm;
+        perm_retain(P);
+    } else {
+        if (!col_counts) fail(GrB_NULL_POINTER, "GrX_Matrix_shard_setup: col_counts is NULL");
+        if (n <= 0 || n + (int64_t)(1 << 22) > 0x7fffffff) fail(GrB_NOT_IMPLEMENTED, "GrX_Matrix_shard_setup: column count out of range");
+        DevBuf<unsigned int> cnt(n);
+        if (on_device) d2d(cnt.p, col_counts, sizeof(unsigned int) * (size_t)n);
+        else h2d(cnt.p, col_counts, sizeof(unsigned int) * (size_t)n);
+        DevBuf<uint64_t> keys(n), keys2(n);
+        DevBuf<uint32_t> ids(n), ids2(n);
+        DevBuf<unsigned int> poscnt(n);
+        hipLaunchKernelGGL(k_order_keys, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx().stream, (const unsigned int *)cnt.p, (const int64_t *)nullptr, n, keys.p, ids.p);
+        prim_sort_pairs_u64_u32(keys.p, keys2.p, ids.p, ids2.p, n, 40);
+        P = new GB_Perm();
+        P->n = (uint64_t)n;
+        try {
+            P->d_rank = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)n);
+            P->d_inv = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)n);
+            DevBuf<unsigned long long> live(2, true);
+            const int64_t k_hot = hot_table_size(n, A->type->size);
+            hipLaunchKernelGGL(k_order_place, dim3((unsigned)ceil_div(n, 1024)), dim3(1024), 0, ctx().stream, (const uint32_t *)ids2.p, (const uint64_t *)keys2.p, n, k_hot,
+                               P->d_rank, P->d_inv, poscnt.p, live.p);
+            unsigned long long h_live[2] = {0, 0};
+            d2h(h_live, live.p, sizeof(h_live));
+            P->n_live_rows = 0;
+            P->n_live_cols = (int64_t)h_live[1];
+        } catch (...) {
+            perm_release(P);
+            throw;
+        }
+        sync_stream();
+    }
+    if (A->ord) {
+        matrix_free(A->ord);
+        A->ord = nullptr;
+    }
+    A->ord_state = 0;
+    perm_release(A->perm);
+    A->perm = P;
+    A->col_order_only = true;
     GRB_CATCH(errp(A))
 }
 

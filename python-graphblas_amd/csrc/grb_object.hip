@@ -701,6 +701,7 @@ void matrix_invalidate_caches(GB_Matrix_opaque *A)
     }
     perm_release(A->perm);  // (vectors in this order keep it alive until they are converted)
     A->perm = nullptr;
+    A->col_order_only = false;  // (a shard set-up describes the content that is going away)
     A->ord_state = 0;
     dev_free(A->d_cold_bounds); dev_free(A->d_ct_order);
     A->d_cold_bounds = nullptr; A->d_ct_order = nullptr; A->ct_ntiles = 0;

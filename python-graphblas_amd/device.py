@@ -159,6 +159,35 @@ def matrix_hint_ranked(A, ranked=True):
     call_on(A, "GrX_Matrix_hint_ranked", [A._handle, 1 if ranked else 0])
 
 
+def matrix_shard_setup(A, col_counts=None, *, like=None):
+    """``A`` is a row block of a sharded graph: hand the library the GLOBAL reference counts of its columns (a uint32 / int32 torch tensor of
+    ``ncols`` elements on the library's device, a CPU tensor or a numpy array -- identical on every rank: the host layer all-reduces the ranks'
+    column histograms once) and it ranks the columns itself and builds the block's popularity-ordered layouts in that column order, rows as
+    they are (GrX_Matrix_shard_setup).  ``like``: another set-up block of the same width whose order object ``A`` shares (the chunks of one
+    rank: an operand is then converted once for all of them).  A performance hint only."""
+    if like is not None:
+        call_on(A, "GrX_Matrix_shard_setup", [A._handle, None, 0, like._handle])
+        return
+    import numpy as np
+
+    on_device = 0
+    keep = None
+    if hasattr(col_counts, "data_ptr"):  # a torch tensor
+        import torch
+
+        keep = col_counts.to(torch.int32).contiguous() if col_counts.dtype != torch.int32 else col_counts.contiguous()
+        if keep.numel() != A.ncols:
+            raise ValueError("matrix_shard_setup: one count per column")
+        on_device = 1 if keep.is_cuda else 0
+        ptr = ctypes.c_void_p(keep.data_ptr())
+    else:
+        keep = np.ascontiguousarray(col_counts, dtype=np.uint32)
+        if keep.size != A.ncols:
+            raise ValueError("matrix_shard_setup: one count per column")
+        ptr = keep.ctypes.data_as(ctypes.c_void_p)
+    call_on(A, "GrX_Matrix_shard_setup", [A._handle, ptr, on_device, None])
+
+
 def cache_transpose(A):
     call_on(A, "GrX_Matrix_cache_transpose", [A._handle])
 

@@ -184,6 +184,35 @@ def allgather_delta_into(u_full, w_local, cuts, *, device="cuda", dense_above=0.
     return int(all_counts[:, 0].sum())
 
 
+def shard_setup(A_blocks, col_of_blocks, ncols, *, device="cuda", dist=None):
+    """The set-up step of a row-sharded run on labels the application did NOT rank (round 6): every rank histograms the
+    column indices of its blocks (``col_of_blocks``: their int32 column arrays as torch tensors), the histograms are summed over the ranks
+    by ONE all-reduce, and every block matrix is handed the global counts (``GrX_Matrix_shard_setup``): the library ranks the columns --
+    the same permutation on every rank -- and lays the block out in that order.  The blocks of one rank share one order object.
+    ``dist`` = torch.distributed (None: a single process, e.g. one rank's block run alone).  Returns the counts."""
+    import torch
+
+    from . import device as dev
+
+    dev_t = "cpu" if device == "cpu" else "cuda"
+    counts = torch.zeros(ncols, dtype=torch.int64, device=dev_t)
+    for col in col_of_blocks:
+        counts += torch.bincount(col.to(dev_t).long(), minlength=ncols)
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        t = counts.cpu() if (dev_t == "cuda" and dist.get_backend() == "gloo") else counts
+        dist.all_reduce(t)
+        counts = t.to(dev_t)
+    c32 = counts.clamp(max=(1 << 31) - 1).to(torch.int32)
+    first = None
+    for A in A_blocks:
+        if first is None:
+            dev.matrix_shard_setup(A, c32)
+            first = A
+        else:
+            dev.matrix_shard_setup(A, like=first)
+    return counts
+
+
 def cyclic_chunk_rows(n_local, B, chunks, c, device="cuda"):
     """LOCAL row numbers (in the rank's stripe order, ``synthetic.stripe_rows``) of chunk c of a block-cyclic rank: the stripes
     c, c + chunks, c + 2 chunks, ... of B rows each."""

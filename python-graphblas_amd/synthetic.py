@@ -10,7 +10,7 @@ import numpy as np
 
 
 def rmat_csr(scale, edge_factor=16, *, seed=None, device="cuda", abcd=(0.57, 0.19, 0.19, 0.05), row_range=None,
-             row_ranges=None, chunk_edges=1 << 27, relabel=None, stripes=None):
+             row_ranges=None, chunk_edges=1 << 27, relabel=None, stripes=None, col_counts_only=False):
     """Returns (indptr int64[n_rows+1], col int32[nnz]) torch tensors on ``device``; sorted, deduped.
 
     ``row_range=(lo, hi)`` keeps only rows lo..hi-1 (1-D row sharding: every rank draws the same
@@ -70,6 +70,12 @@ def rmat_csr(scale, edge_factor=16, *, seed=None, device="cuda", abcd=(0.57, 0.1
         del rank, perm0
     elif relabel is not None:
         raise ValueError(f"relabel={relabel!r}")
+    if col_counts_only:
+        # (the column histogram of the raw edge stream -- duplicates counted: a ranking signal, one pass, no keys kept)
+        counts = torch.zeros(n, dtype=torch.int64, device=device)
+        for _src, dst in chunks:
+            counts += torch.bincount(perm[dst], minlength=n)
+        return counts
     if stripes is not None:
         B, sw, sr = stripes
         assert row_range is None and row_ranges is None and n % (B * sw) == 0
@@ -107,6 +113,13 @@ def rmat_csr(scale, edge_factor=16, *, seed=None, device="cuda", abcd=(0.57, 0.1
         indptr[1:] = torch.cumsum(counts, 0)
         out.append((indptr, col))
     return out if row_ranges is not None else out[0]
+
+
+def rmat_col_counts(scale, edge_factor=16, *, seed=None, device="cuda", abcd=(0.57, 0.19, 0.19, 0.05), chunk_edges=1 << 27):
+    """Reference counts of the columns of the WHOLE edge stream :func:`rmat_csr` draws (duplicates counted), int64[n] on ``device`` -- the
+    ranking signal the ranks of a sharded run obtain by all-reducing the histograms of their blocks; a process that holds one block only
+    (``bench.py --block``) draws it from the same stream instead."""
+    return rmat_csr(scale, edge_factor, seed=seed, device=device, abcd=abcd, chunk_edges=chunk_edges, col_counts_only=True)
 
 
 def stripe_rows(n, B, w, r, device="cuda"):

@@ -1,8 +1,8 @@
 #!/bin/bash
-# Round-4 measurement set: rocprofv3 kernel stats of the default command, PMC traffic (separate passes) for the two roofline workloads,
+# Round-6 measurement set (round 5's script with the round number changed, the SpGEMM PMC pass at scale 22 and the block / shard set-up lines added): rocprofv3 kernel stats of the default command, PMC traffic (separate passes) for the two roofline workloads,
 # the bench lines of every BASELINE config (default + extras, scale 20, config 0, kron26 block, row blocks, BFS / SSSP loops, masked SpGEMM).
 cd "$(dirname "$0")/.."
-TAG=${1:-r04}; OUT=gpurun_out/$TAG; mkdir -p "$OUT"; export TMPDIR=/tmp
+TAG=${1:-r06}; OUT=gpurun_out/$TAG; mkdir -p "$OUT"; export TMPDIR=/tmp
 pmc() {  # pmc <workload> : three PMC passes -> $OUT/pmc_traffic_<workload>.json
   wl=$1
   for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
@@ -26,13 +26,13 @@ fetch = sum(d.get("FETCH_SIZE", 0.0) for d in per_kernel.values())
 write = sum(d.get("WRITE_SIZE", 0.0) for d in per_kernel.values())
 hit = sum(d.get("TCC_HIT_sum", 0.0) for d in per_kernel.values())
 miss = sum(d.get("TCC_MISS_sum", 0.0) for d in per_kernel.values())
-rec = {"workload": wl, "scale": 24, "round": 4, "kernels": sorted(per_kernel),
+rec = {"workload": wl, "scale": 24, "round": 6, "kernels": sorted(per_kernel),
        "FETCH_SIZE_KiB_raw": fetch, "WRITE_SIZE_KiB_raw": write,
        "traffic_bytes_per_launch": (2 * fetch + write) * 1024, "traffic_bytes_per_launch_uncorrected": (fetch + write) * 1024,
        "traffic_band_bytes": [(fetch + write) * 1024, (2 * fetch + write) * 1024],
        "tcc_hit_rate": hit / (hit + miss) if hit + miss else None, "tcc_miss_x_128_bytes": miss * 128, "per_kernel": per_kernel,
        "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc TCC_HIT_sum TCC_MISS_sum in three separate passes with --kernel-trace "
-                 "(scripts/gpu_final_r04.sh); per-launch averages summed over the steady-state kernels of one GrB_mxv call; KiB units; FETCH_SIZE "
+                 "(scripts/gpu_final_r06.sh); per-launch averages summed over the steady-state kernels of one GrB_mxv call; KiB units; FETCH_SIZE "
                  "doubled per MI355X_MICROARCH.md section HBM (gfx950 reports half the bytes of 16-B/lane streaming reads); the doubling is "
                  "calibrated for the streamed arrays only: quote the BAND between the uncorrected and the corrected value (traffic_band_bytes), "
                  "not the corrected figure alone; tcc_miss_x_128_bytes = L2 misses x one 128-byte line, an independent estimate."}
@@ -50,6 +50,13 @@ echo "== bench scale 20 (configs[1])"; timeout 600 python bench.py --scale 20 --
 echo "== config 0"; timeout 600 python bench.py --workload uniform_fp64 --steps 50 > "$OUT/bench_uniform_fp64.json" 2>/dev/null; line $OUT/bench_uniform_fp64.json
 echo "== kron26 rank 0 of 8 (configs[4] shape)"; timeout 900 python bench.py --workload kron26 --block 0/8 > "$OUT/kron26_block0of8.json" 2>/dev/null; line $OUT/kron26_block0of8.json
 echo "== row blocks of the scale-24 graph"; for w in 1 2 4 8; do timeout 600 python bench.py --block 0/$w --no-cpu-baseline --no-extra 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps({'block': '0/$w', 'ms_per_step': d['ms_per_step'], 'verified': d['verified']}))"; done > "$OUT/block_times_s24.jsonl"; cat "$OUT/block_times_s24.jsonl"
+echo "== the same blocks without the set-up step (natural-order layouts, rounds 1-5)"; for w in 2 4 8; do timeout 600 python bench.py --block 0/$w --no-shard-setup --no-cpu-baseline --no-extra 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps({'block': '0/$w', 'shard_setup': False, 'ms_per_step': d['ms_per_step'], 'verified': d['verified'], 'ordered': d['stats'].get('ordered')}))"; done > "$OUT/block_times_s24_no_setup.jsonl"; cat "$OUT/block_times_s24_no_setup.jsonl"
+timeout 900 python bench.py --workload kron26 --block 0/8 --no-shard-setup --no-cpu-baseline > "$OUT/kron26_block0of8_no_setup.json" 2>/dev/null; line $OUT/kron26_block0of8_no_setup.json
+echo "== ranked labels (GrX_Matrix_hint_ranked): whole graph, blocks of a block-cyclic dealing, Kronecker-26 block"
+for spec in "" "--block 0/2" "--block 0/4" "--block 0/8" "--block 7/8"; do
+  timeout 600 python bench.py --ranked $spec --no-cpu-baseline --no-extra 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps({'ranked': '$spec', 'ms_per_step': d['ms_per_step'], 'frac': d['roofline']['frac'], 'verified': d['verified'], 'ordered': d['stats'].get('ordered'), 'build_ms': d['layout_build_call_ms']}))"
+done > "$OUT/ranked_block_times_s24.jsonl"; cat "$OUT/ranked_block_times_s24.jsonl"
+timeout 900 python bench.py --workload kron26 --ranked --block 0/8 --no-cpu-baseline > "$OUT/kron26_ranked_block0of8.json" 2>/dev/null; line $OUT/kron26_ranked_block0of8.json
 echo "== BFS / SSSP loops"; timeout 600 python bench.py --workload bfs --steps 5 > "$OUT/bfs_s24.json" 2>/dev/null; line $OUT/bfs_s24.json; timeout 600 python bench.py --workload sssp --steps 3 > "$OUT/sssp_s24.json" 2>/dev/null; line $OUT/sssp_s24.json
 echo "== masked SpGEMM"; timeout 600 python bench.py --workload mxm_plus_times_masked --scale 20 --steps 5 --warmup 1 > "$OUT/mxm_masked_s20.json" 2>/dev/null; line $OUT/mxm_masked_s20.json; timeout 900 python bench.py --workload mxm_plus_times_masked --scale 22 --steps 3 --warmup 1 > "$OUT/mxm_masked_s22.json" 2>/dev/null; line $OUT/mxm_masked_s22.json
 echo "== SpGEMM scale 18"; timeout 600 python bench.py --workload mxm_plus_times --scale 18 --steps 5 --warmup 1 > "$OUT/mxm_s18.json" 2>/dev/null; line $OUT/mxm_s18.json
@@ -71,7 +78,7 @@ for f in glob.glob(os.path.join(out, "pmc_mxm_*", "**", "*counter_collection.csv
             tot[r["Counter_Name"]] += float(r["Counter_Value"])
 # (2 products per run: warm-up + the timed one)
 fetch, write = tot.get("FETCH_SIZE", 0.0) / 2, tot.get("WRITE_SIZE", 0.0) / 2
-rec = {"workload": "mxm_plus_times", "scale": 20, "round": 4, "FETCH_SIZE_KiB_raw": fetch, "WRITE_SIZE_KiB_raw": write,
+rec = {"workload": "mxm_plus_times", "scale": 20, "round": 6, "FETCH_SIZE_KiB_raw": fetch, "WRITE_SIZE_KiB_raw": write,
        "traffic_bytes_per_launch": (2 * fetch + write) * 1024, "traffic_bytes_per_launch_uncorrected": (fetch + write) * 1024,
        "traffic_band_bytes": [(fetch + write) * 1024, (2 * fetch + write) * 1024],
        "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in two separate passes with --kernel-trace; summed over every grb:: kernel of one product "
@@ -80,11 +87,37 @@ json.dump(rec, open(os.path.join(out, "pmc_traffic_mxm.json"), "w"), indent=1)
 print("mxm traffic band per product (GB):", [round(x / 1e9, 1) for x in rec["traffic_band_bytes"]])
 PY
 find "$OUT" -name '*counter_collection.csv' -size +4M -delete; find "$OUT" -name '*kernel_trace.csv' -size +1M -delete
-echo "== the headline on the natural-order layouts / without the value dictionary / without the hub level (same library, options)"
-for kv in "GRB_ORDER_MODE=0" "GRB_VALUE_DICT=0" "GRB_HUB_MIN_LEN=0" "GRB_ORDER_MODE=0 GRB_VALUE_DICT=0"; do
+echo "== PMC of the SpGEMM product at scale 22 (streamed: the line the 1 -> 8 GPU target is quoted on)"
+for c in "FETCH_SIZE" "WRITE_SIZE"; do
+  d="$OUT/pmc_mxm22_$(echo $c | tr ' ' '_')"
+  timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$d" -o p -- python bench.py --workload mxm_plus_times --scale 22 --steps 1 --warmup 1 --no-cpu-baseline > "$d.json" 2> "$d.err"; echo "pmc mxm22 [$c] rc=$?"
+done
+python - "$OUT" <<'PY'
+import csv, sys, glob, json, os, collections
+out = sys.argv[1]
+tot = collections.defaultdict(float)
+for f in glob.glob(os.path.join(out, "pmc_mxm22_*", "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "grb::" in r.get("Kernel_Name", ""):
+            tot[r["Counter_Name"]] += float(r["Counter_Value"])
+fetch, write = tot.get("FETCH_SIZE", 0.0) / 2, tot.get("WRITE_SIZE", 0.0) / 2  # (2 products per run: warm-up + the timed one)
+rec = {"workload": "mxm_plus_times_streamed", "scale": 22, "round": 6, "FETCH_SIZE_KiB_raw": fetch, "WRITE_SIZE_KiB_raw": write,
+       "traffic_bytes_per_launch": (2 * fetch + write) * 1024, "traffic_bytes_per_launch_uncorrected": (fetch + write) * 1024,
+       "traffic_band_bytes": [(fetch + write) * 1024, (2 * fetch + write) * 1024],
+       "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in two separate passes with --kernel-trace over `bench.py --workload mxm_plus_times --scale 22` "
+                 "(row batches, output streamed); summed over every grb:: kernel of one product (two products per run, halved); KiB units; FETCH_SIZE "
+                 "doubled per MI355X_MICROARCH.md: quote the band"}
+json.dump(rec, open(os.path.join(out, "pmc_traffic_mxm_s22.json"), "w"), indent=1)
+print("mxm scale 22 traffic band per product (GB):", [round(x / 1e9, 1) for x in rec["traffic_band_bytes"]])
+PY
+find "$OUT" -name '*counter_collection.csv' -size +4M -delete; find "$OUT" -name '*kernel_trace.csv' -size +1M -delete
+echo "== the headline with round-5 / round-4 features off one at a time (same library, options)"
+for kv in "GRB_ROWS_TILE=0" "GRB_ORDER_MODE=0" "GRB_VALUE_DICT=0" "GRB_HUB_MIN_LEN=0"; do
   env $kv timeout 600 python bench.py --no-cpu-baseline --no-extra > "$OUT/bench_headline_$(echo $kv | tr ' =' '__').json" 2>/dev/null; echo -n "$kv: "; line "$OUT/bench_headline_$(echo $kv | tr ' =' '__').json"
 done
-echo "== push / pull grid"; timeout 1200 python scripts/push_vs_pull.py 24 > "$OUT/push_pull_grid.jsonl" 2>/dev/null; wc -l "$OUT/push_pull_grid.jsonl"
-echo "== SpGEMM kernel stats (whole CSVs)"; bash scripts/gpu_r04_mxm_prof.sh > "$OUT/mxm_kernel_stats_summary.txt" 2>&1; cp gpurun_out/r04_mxm/*kernel_stats.csv "$OUT/" 2>/dev/null; tail -3 "$OUT/mxm_kernel_stats_summary.txt"
-echo "== RCCL one rank"; bash scripts/gpu_r04_rccl.sh > "$OUT/rccl_one_rank_summary.txt" 2>&1; grep -c True "$OUT/rccl_one_rank_summary.txt"
-echo "== layout build"; bash scripts/gpu_r04_build_profile.sh > "$OUT/layout_build_summary.txt" 2>&1; tail -3 "$OUT/layout_build_summary.txt"
+echo "== SpGEMM kernel stats (scale 20 / 22, default options)"
+for s in 20 22; do ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_mxm$s -o mxm -- python $OLDPWD/bench.py --workload mxm_plus_times --scale $s --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1 ); cp $(find /tmp/prof_mxm$s -name '*kernel_stats.csv' | head -1) "$OUT/mxm_s${s}_kernel_stats.csv"; head -7 "$OUT/mxm_s${s}_kernel_stats.csv" | cut -c1-150; done
+echo "== RCCL one rank"; export HSA_ENABLE_IPC_MODE_LEGACY=0; timeout 600 python tests/nccl_one_rank.py > "$OUT/rccl_one_rank.json" 2> "$OUT/rccl_one_rank.err"; tail -c 400 "$OUT/rccl_one_rank.json"; timeout 600 python bench.py --force-dist --backend nccl --no-cpu-baseline > "$OUT/bench_force_dist_nccl_one_rank.json" 2>/dev/null; line "$OUT/bench_force_dist_nccl_one_rank.json"
+echo "== layout build kernels"; ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_build -o b -- python $OLDPWD/bench.py --steps 1 --warmup 2 --no-cpu-baseline --no-extra > /dev/null 2>&1 ); cp $(find /tmp/prof_build -name '*kernel_stats.csv' | head -1) "$OUT/layout_build_kernel_stats.csv"; head -25 "$OUT/layout_build_kernel_stats.csv" | cut -c1-120
+echo "== pytest -m gpu (everything)"; ( time timeout 1200 python -m pytest tests -m gpu -q ) > "$OUT/tests_gpu_full.log" 2>&1; tail -4 "$OUT/tests_gpu_full.log"
+

@@ -20,7 +20,7 @@ ORDER_OPTS = ((b"order_min_nnz", 1), (b"lean_min_nnz", 1), (b"split_min_nnz", 1)
               (b"lazy_layout", 0), (b"vec_pad_min_bytes", 0), (b"rows_head_min_groups", 1))
 RESTORE = ((b"order_min_nnz", 24 << 20), (b"lean_min_nnz", 48 << 20), (b"split_min_nnz", 1 << 22), (b"split_min_len", 0), (b"push_mode", 1),
            (b"hot_min_cols", 1 << 20), (b"hot_k", 0), (b"lazy_layout", 1), (b"vec_pad_min_bytes", 1 << 20), (b"long_classes", 16), (b"order_mode", 1), (b"hub_min_len", 1024), (b"rows_head_min_groups", 16384), (b"rows_head", 1),
-           (b"rows_tile", 1), (b"rtile_rows", 8192), (b"rtile_entries", 32768), (b"bool_probe", 8), (b"stream_nt_min_nnz", 48 << 20))
+           (b"rows_tile", 1), (b"rtile_rows", 8192), (b"rtile_entries", 49152), (b"bool_probe", 8), (b"stream_nt_min_nnz", 48 << 20), (b"cold_in_rows", 0))
 
 
 @pytest.fixture(params=DEVICES)
@@ -72,7 +72,8 @@ def test_ordered_product_matches_the_oracle(gb, seed):
     try:
         # (hub_min_len: rows from this many entries are dealt to 64 classes -- a second level of hot strips; 0 switches it off)
         set_opts(ORDER_OPTS + ((b"hot_k", [64, 256, 1 << 20][seed % 3]), (b"long_classes", [16, 8, 32][seed % 3]), (b"hub_min_len", [100, 0, 300, 1024][seed % 4]),
-                             (b"rows_head", 0 if seed == 13 else 1)))  # (BOOL: the short rows with the LDS head of the hottest columns -- seeds 6, 20 -- and without)
+                             (b"rows_head", 0 if seed == 13 else 1),  # (BOOL: the short rows with the LDS head of the hottest columns -- seeds 6, 20 -- and without)
+                             (b"cold_in_rows", [0, 1024][(seed // 3) % 2])))  # (round 6: the cold entries of the long rows below the hub level with the short rows)
         A = gb.Matrix.from_coo(rows, cols, vals, dtype=tname, nrows=n, ncols=n)
         u = gb.Vector.from_coo(ui, uv, dtype=tname, size=n)
         w = gb.Vector.from_coo(wi, wv, dtype=tname, size=n)
@@ -532,7 +533,11 @@ def test_sorted_row_tiles_match_the_oracle(gb, seed):
         natural = seed >= 12
         set_opts(ORDER_OPTS + ((b"rtile_rows", [8192, 16384][seed % 2]), (b"rtile_entries", [256, 700, 5000][seed % 3]), (b"hub_min_len", [100, 0][seed % 2]),
                                (b"order_mode", 0 if natural else 1), (b"hot_k", 256 if natural else 0), (b"rows_tile", 2 if natural else 1),
-                               (b"stream_nt_min_nnz", [1, 48 << 20][(seed >> 1) & 1])))  # (1: the streams of the row tiles and cold tiles are read non-temporal)
+                               (b"stream_nt_min_nnz", [1, 48 << 20][(seed >> 1) & 1]),  # (1: the streams of the row tiles and cold tiles are read non-temporal)
+                               # (round 6: the cold entries of the long rows below the hub level with the short rows -- 1024: all of them, 40: of the
+                               #  rows below 40 entries, 0: none, i.e. the cold tiles of rounds 3-5)
+                               (b"cold_in_rows", [1024, 0, 40][(seed // 2) % 3])))
+        cold_in_rows = [1024, 0, 40][(seed // 2) % 3]
         A = gb.Matrix.from_coo(rows, cols, vals, dtype=tname, nrows=n, ncols=n)
         u = gb.Vector.from_coo(ui, uv, dtype=tname, size=n)
         w = gb.Vector.from_coo(wi, wv, dtype=tname, size=n)
@@ -545,6 +550,9 @@ def test_sorted_row_tiles_match_the_oracle(gb, seed):
         specialised = (tname, sr) in (("FP32", "min_plus"), ("FP64", "min_plus"), ("INT64", "min_plus"), ("FP32", "plus_times"), ("FP64", "plus_times"), ("INT64", "plus_times"))
         takes = specialised and (full or (st["fill_absent"] == 1))
         assert st["ordered"] == (0 if natural else 1) and st["fused_epilogue"] == (3 if takes else 1), (st, takes)
+        # (the short-row kernel -- row tiles or, for the calls they do not take, tagged row groups -- merged the strips' accumulators into rows
+        #  whose cold entries it folded itself: split_min_len 8 < cold_in_rows)
+        assert st["long_tails"] == (1 if (not natural and cold_in_rows > 8) else 0), st
         same_vec(w, exp)
         # once more on the converted operands (nothing is reordered any more), and without the tiles: the same result
         w2 = gb.Vector.from_coo(wi, wv, dtype=tname, size=n)
@@ -704,5 +712,74 @@ def test_ranked_hint_orders_without_a_permutation(gb, seed):
         w2 = gb.Vector.from_coo(wi, wv, dtype=tname, size=m)
         w2(~mk.S, accum=accum, replace=repl) << A.mxv(u, getattr(gb.semiring, sr))
         same_vec(w2, exp)
+    finally:
+        set_opts(RESTORE)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_shard_setup_orders_a_row_block_by_global_column_counts(gb, seed):
+    """GrX_Matrix_shard_setup (round 6): a NON-square row block on labels nobody ranked is handed the global reference counts of its columns;
+    the library ranks the columns itself and runs the block on its popularity-ordered layouts, the operand kept in that column order, the
+    output and the mask (the block's rows) natural.  Two blocks of one rank share one order object (`like`): the operand is converted once
+    for both.  A pinned operand (an RCCL buffer) cannot be converted: the product runs the natural-order layouts and gives the same result.
+    Everything against the oracle."""
+    from graphblas_amd import device
+
+    rng = np.random.default_rng(9900 + seed)
+    tname = ["FP32", "INT64", "BOOL", "FP64"][seed % 4]
+    sr = {"FP32": "min_plus", "INT64": "plus_times", "BOOL": "lor_land", "FP64": "min_plus"}[tname]
+    n = int(rng.integers(3000, 6000))
+    rows, cols, vals = skewed_square(rng, n, tname)
+    if tname == "BOOL":
+        vals = np.ones(rows.size, bool)
+    counts = np.bincount(cols, minlength=n)  # (what the ranks' all-reduce of their histograms yields)
+    cut = [0, n // 3 // 64 * 64, n]  # two row blocks of the square graph
+    accum = {"FP32": "min", "INT64": "plus", "BOOL": None, "FP64": "min"}[tname]
+    repl = tname == "BOOL"
+    ui, uv = rand_vec(rng, n, [1.0, 0.4][seed % 2] if tname != "BOOL" else 0.3, tname)
+    ou = O.OVec(n, ui, uv, tname)
+    try:
+        set_opts(ORDER_OPTS + ((b"hub_min_len", [100, 0][seed % 2]), (b"rtile_entries", 700), (b"hot_k", 256)))
+        u = gb.Vector.from_coo(ui, uv, dtype=tname, size=n)
+        blocks, expected = [], []
+        for b in range(2):
+            lo, hi = cut[b], cut[b + 1]
+            keep = (rows >= lo) & (rows < hi)
+            r, c, v = rows[keep] - lo, cols[keep], vals[keep]
+            m = hi - lo
+            A = gb.Matrix.from_coo(r, c, v, dtype=tname, nrows=m, ncols=n)
+            if b == 0:
+                device.matrix_shard_setup(A, counts if seed % 2 else counts.astype(np.uint32))
+            else:
+                device.matrix_shard_setup(A, like=blocks[0][0])
+            wi, wv = rand_vec(rng, m, 0.7, tname)
+            mi, mv = rand_vec(rng, m, 0.5, "BOOL")
+            oa = O.OMat.from_coo(r, c, v, m, n, tname)
+            exp = O.mxv(oa, ou, sr, w=O.OVec(m, wi, wv, tname), mask=O.OVec(m, mi, mv, "BOOL"), mask_comp=True, mask_struct=True, accum=accum, replace=repl)
+            blocks.append((A, oa, (wi, wv), (mi, mv), m))
+            expected.append(exp)
+        total_reorders = 0
+        for rep in range(2):
+            for (A, oa, (wi, wv), (mi, mv), m), exp in zip(blocks, expected):
+                w = gb.Vector.from_coo(wi, wv, dtype=tname, size=m)
+                mk = gb.Vector.from_coo(mi, mv, dtype="BOOL", size=m)
+                w(~mk.S, accum=accum, replace=repl) << A.mxv(u, getattr(gb.semiring, sr))
+                st = device.last_stats()
+                assert st["ordered"] == 1 and st["long_kernel"] == (1 if tname == "BOOL" else 4), st
+                total_reorders += st["reorders"]
+                same_vec(w, exp)
+        assert total_reorders == 1  # (the operand was converted once, for both blocks and both rounds)
+        # the operand read back is the natural one; a plain product too
+        gi, gv = u.to_coo()
+        assert gi.tolist() == ui.tolist() and gv.tolist() == uv.tolist()
+        same_vec(blocks[1][0].mxv(u, getattr(gb.semiring, sr)).new(), O.mxv(blocks[1][1], ou, sr))
+        # a pinned operand: natural-order layouts, same result
+        device.vector_device_views(u, "cuda" if _on_gpu() else "cpu")
+        A, oa, (wi, wv), (mi, mv), m = blocks[0]
+        w = gb.Vector.from_coo(wi, wv, dtype=tname, size=m)
+        mk = gb.Vector.from_coo(mi, mv, dtype="BOOL", size=m)
+        w(~mk.S, accum=accum, replace=repl) << A.mxv(u, getattr(gb.semiring, sr))
+        assert device.last_stats()["ordered"] == 0
+        same_vec(w, expected[0])
     finally:
         set_opts(RESTORE)
