@@ -710,7 +710,8 @@ constexpr int MU_SMALL = GRB_MU_SMALL;  // entries of a unit a single wavefront 
 #define GRB_MU_UPW 1
 #endif
 #ifndef GRB_MU_PIPE
-#define GRB_MU_PIPE 1  // 1: the trips of a batch / segment are software-pipelined (round 6); 0: load, wait, apply per trip (rounds 2-5)
+#define GRB_MU_PIPE 0  // bit 0: the trips of a batch of the SEARCH dealing (one-wavefront numeric class) are software-pipelined (round 6), bit 1: the trips
+                       // of a segment of the RANKED dealing (every other class); 0: load, wait, apply per trip (rounds 2-5).  See the measurement at the loops.
 #endif
 constexpr int mu_units_per_wave(int mode, int wpu) { return (mode == 1 && wpu == 1) ? GRB_MU_UPW : 1; }
 
@@ -928,6 +929,7 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4), mu_min_waves(MODE, WPU, C
                 // products of trip k go to LDS, through two register sets with static roles (no copies: a copied register waits for its
                 // load), and only trips that exist are ever requested (the loop runs while two more trips follow; the last one or two
                 // are peeled).  A unit's wavefront used to wait one global round trip per trip with nothing else of its own in flight.
+                if constexpr ((GRB_MU_PIPE & 1) != 0) {
                 using D = decltype(load((const int32_t *)nullptr, 0u, 0));
                 constexpr int TRIP = 64 * ILP;
                 auto fetch_trip = [&](int base, D (&d)[ILP]) {
@@ -947,32 +949,39 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4), mu_min_waves(MODE, WPU, C
                     for (int u = 0; u < ILP; u++)
                         if (base + lane + 64 * u < total) apply(d[u]);
                 };
-                D da[ILP];
+                D da[ILP], db[ILP];
                 int base = 0;
                 fetch_trip(0, da);
-                if constexpr (GRB_MU_PIPE != 0) {
-                    D db[ILP];
-                    while (base + 2 * TRIP < total) {  // (uniform: two more trips follow the one in `da`)
-                        fetch_trip(base + TRIP, db);
-                        apply_trip(base, da);
-                        fetch_trip(base + 2 * TRIP, da);
-                        apply_trip(base + TRIP, db);
-                        base += 2 * TRIP;
-                    }
-                    if (base + TRIP < total) {
-                        fetch_trip(base + TRIP, db);
-                        apply_trip(base, da);
-                        apply_trip(base + TRIP, db);
-                    } else {
-                        apply_trip(base, da);
-                    }
+                while (base + 2 * TRIP < total) {  // (uniform: two more trips follow the one in `da`)
+                    fetch_trip(base + TRIP, db);
+                    apply_trip(base, da);
+                    fetch_trip(base + 2 * TRIP, da);
+                    apply_trip(base + TRIP, db);
+                    base += 2 * TRIP;
+                }
+                if (base + TRIP < total) {
+                    fetch_trip(base + TRIP, db);
+                    apply_trip(base, da);
+                    apply_trip(base + TRIP, db);
                 } else {
-                    for (;;) {
-                        apply_trip(base, da);
-                        base += TRIP;
-                        if (base >= total) break;
-                        fetch_trip(base, da);
+                    apply_trip(base, da);
+                }
+                } else {
+                for (int t0 = lane; t0 < total; t0 += 64 * ILP) {  // (rounds 2-5: load, wait, apply per trip)
+                    decltype(load((const int32_t *)nullptr, 0u, 0)) d[ILP];
+#pragma unroll
+                    for (int u = 0; u < ILP; u++) {
+                        const int t = t0 + 64 * u < total ? t0 + 64 * u : total - 1;
+                        int lo = 0;  // the last entry whose first product number is <= t (scan[0] = 0 <= t): six steps, three VALU each
+#pragma unroll
+                        for (int st = 32; st > 0; st >>= 1)
+                            if (scan[lo + st] <= t) lo += st;
+                        d[u] = load(a.Bj + sqb[lo], (unsigned)t, lo);
                     }
+#pragma unroll
+                    for (int u = 0; u < ILP; u++)
+                        if (t0 + 64 * u < total) apply(d[u]);
+                }
                 }
                 mw_sync();
                 return;
@@ -1017,6 +1026,7 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4), mu_min_waves(MODE, WPU, C
                 const unsigned t_last = (unsigned)(total - 1);
                 // (round 6, GRB_MU_PIPE: the trips of a segment software-pipelined as in the search dealing above -- the loads of trip k + 1
                 //  leave before the products of trip k go to LDS; two register sets with static roles; only trips that exist are requested)
+                if constexpr ((GRB_MU_PIPE & 2) != 0) {
                 using D = decltype(load((const int32_t *)nullptr, 0u, 0));
                 auto fetch_grp = [&](int g0, D (&d)[ILP]) {
 #pragma unroll
@@ -1032,32 +1042,36 @@ __global__ __launch_bounds__(64 * (WPU > 4 ? WPU : 4), mu_min_waves(MODE, WPU, C
                     for (int u = 0; u < ILP; u++)
                         if (t + 64u * (unsigned)(g0 + u) <= t_last) apply(d[u]);
                 };
-                D da[ILP];
+                D da[ILP], db[ILP];
                 int g0 = 0;
                 fetch_grp(0, da);
-                if constexpr (GRB_MU_PIPE != 0) {
-                    D db[ILP];
-                    while (g0 + 2 * ILP < g_n) {  // (uniform: two more trips follow the one in `da`)
-                        fetch_grp(g0 + ILP, db);
-                        apply_grp(g0, da);
-                        fetch_grp(g0 + 2 * ILP, da);
-                        apply_grp(g0 + ILP, db);
-                        g0 += 2 * ILP;
-                    }
-                    if (g0 + ILP < g_n) {
-                        fetch_grp(g0 + ILP, db);
-                        apply_grp(g0, da);
-                        apply_grp(g0 + ILP, db);
-                    } else {
-                        apply_grp(g0, da);
-                    }
+                while (g0 + 2 * ILP < g_n) {  // (uniform: two more trips follow the one in `da`)
+                    fetch_grp(g0 + ILP, db);
+                    apply_grp(g0, da);
+                    fetch_grp(g0 + 2 * ILP, da);
+                    apply_grp(g0 + ILP, db);
+                    g0 += 2 * ILP;
+                }
+                if (g0 + ILP < g_n) {
+                    fetch_grp(g0 + ILP, db);
+                    apply_grp(g0, da);
+                    apply_grp(g0 + ILP, db);
                 } else {
-                    for (;;) {
-                        apply_grp(g0, da);
-                        g0 += ILP;
-                        if (g0 >= g_n) break;
-                        fetch_grp(g0, da);
+                    apply_grp(g0, da);
+                }
+                } else {
+                for (int g0 = 0; g0 < g_n; g0 += ILP, rpm += ILP, rpb += ILP, t += 64 * ILP) {  // (rounds 3-5: load, wait, apply per trip)
+                    decltype(load((const int32_t *)nullptr, 0u, 0)) d[ILP];
+#pragma unroll
+                    for (int u = 0; u < ILP; u++) {
+                        const int rank = (int)rpb[u] + __popcll(rpm[u] & lane_le);
+                        const unsigned tu = t + 64u * u < t_last ? t + 64u * u : t_last;
+                        d[u] = load(cptr[rank], tu, rank);
                     }
+#pragma unroll
+                    for (int u = 0; u < ILP; u++)
+                        if (t + 64u * u <= t_last) apply(d[u]);
+                }
                 }
                 mw_sync();
             }
