@@ -311,6 +311,7 @@ typedef struct {
     int64_t fill_absent;      /* 1: a sparse operand was run as a full one with the multiply's absorbing value under its absent entries */
     int64_t long_probe;       /* BOOL product under a terminal monoid (LOR.LAND, ANY.PAIR): entries of every admitted long row tested bottom-up before the item kernels (0 = not probed) */
     int64_t long_tails;       /* 1: the cold entries of the long rows below the hub level ran with the short rows (sorted row tiles / tagged row groups), merged with the strips' accumulators (option "cold_in_rows") */
+    int64_t pinned_natural;   /* 1: the product would have taken the matrix's popularity-ordered layouts but one of its vectors is pinned to the natural order (an exported device view, GrX_Vector_pin_natural): it ran the natural-order layouts */
 } GrX_Stats;
 GrB_Info GrX_last_stats(GrX_Stats *stats);
 /* T = A (+.x) B in row batches of A whose products fit `budget_bytes` of device memory; every batch runs the full two-pass

@@ -33,7 +33,7 @@ class GrX_Stats(ctypes.Structure):
                 ("out_nvals", ctypes.c_int64), ("method", ctypes.c_int32), ("fused_epilogue", ctypes.c_int32),
                 ("hot_k", ctypes.c_int64), ("long_entries", ctypes.c_int64), ("long_segments", ctypes.c_int64),
                 ("long_kernel", ctypes.c_int32), ("reorders", ctypes.c_int32), ("ordered", ctypes.c_int64), ("value_dict", ctypes.c_int64), ("fill_absent", ctypes.c_int64),
-                ("long_probe", ctypes.c_int64), ("long_tails", ctypes.c_int64)]
+                ("long_probe", ctypes.c_int64), ("long_tails", ctypes.c_int64), ("pinned_natural", ctypes.c_int64)]
 
 
 def load(path: str | None = None):

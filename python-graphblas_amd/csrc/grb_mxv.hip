@@ -2187,6 +2187,12 @@ static void mxv_any_order(GB_Vector_opaque *w, GB_Vector_opaque *mask, const GB_
         mxv_core(w, mask, accum, sr, S, u, flip, f);
     }
     ctx().stats.reorders = (int32_t)(ctx().reorder_count - reorders0);
+    // (a caller can see WHY a product that would have taken the ordered layouts did not -- one of its vectors is pinned to the natural
+    //  order: a device view was exported from it, GrX_Vector_export_dense_device / pin_natural, e.g. the RCCL buffers of a sharded run)
+    if (!ordered && shapes_ok && ctx().order_mode && S->nvals >= ctx().order_min_nnz && sr->type == S->type->code && S->d_col && !S->ranked) {
+        const bool pinned = col_only ? u->pinned : (S->nrows == S->ncols && (w->pinned || u->pinned || (mask && mask->pinned)));
+        if (pinned) ctx().stats.pinned_natural = 1;
+    }
 }
 
 }  // namespace grb

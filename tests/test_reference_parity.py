@@ -294,11 +294,13 @@ def test_ewise_mult_and_add(gb, v):
     w2 = gb.Vector(w.dtype, w.size)
     w2 << v.ewise_mult(v2, gb.monoid.times)
     assert heq(w, w2)
+    assert [x.tolist() for x in w.to_coo()] == [[3, 6], [3, 0]]  # (by hand: the indices both hold -- 1 * 3 and 0 * 1, the explicit zero kept)
     with pytest.raises(TypeError, match="Expected type: BinaryOp, Monoid"):
         v.ewise_mult(v2, gb.semiring.plus_times)
     w = v.ewise_add(v2, gb.binary.max).new()
     w2.update(v.ewise_add(v2, gb.monoid.max))
     assert heq(w, w2)
+    assert [x.tolist() for x in w.to_coo()] == [[0, 1, 3, 4, 5, 6], [2, 1, 3, 2, 2, 1]]  # (by hand: the union, max where both hold an entry)
     with pytest.raises(TypeError, match="Expected type: BinaryOp, Monoid"):
         v.ewise_add(v2, gb.semiring.max_times)
     assert heq(v.ewise_add(v2).new(), v.ewise_add(v2, gb.monoid.plus).new())  # default is plus
@@ -344,10 +346,14 @@ def test_operator_strings_match_objects(gb):
 def test_reduce_rowwise_columnwise(gb, A):
     # graphblas/tests/test_matrix.py:1355-1360, 1648-1653 -- operator spellings and the transposed forms against each other (the literal
     # vectors: reference_literals.json reduce_rowwise_plus / reduce_columnwise_plus)
+    I0, J0, X0 = (np.asarray(a) for a in A.to_coo())
     result = A.reduce_rowwise(gb.monoid.plus).new()
+    assert [x.tolist() for x in result.to_coo()] == [list(range(7)), np.bincount(I0.astype(int), weights=X0).astype(int).tolist()]  # (numpy on the same tuples)
+    assert result.to_coo()[1].tolist() == [5, 12, 1, 6, 7, 1, 15]  # (by hand from the fixture)
     assert heq(A.reduce_rowwise(gb.binary.plus).new(), result)
     assert heq(A.T.reduce_columnwise(gb.monoid.plus).new(), result)
     result = A.reduce_columnwise(gb.monoid.plus).new()
+    assert [x.tolist() for x in result.to_coo()] == [list(range(7)), np.bincount(J0.astype(int), weights=X0).astype(int).tolist()]
     assert heq(A.T.reduce_rowwise(gb.binary.plus).new(), result)
     with pytest.raises(TypeError, match="Expected type: Monoid"):
         A.reduce_rowwise(gb.binary.minus)
@@ -401,11 +407,11 @@ def test_vector_reduce_agg(gb, v):
     # graphblas/tests/test_vector.py:919-935, 1047-1052 (the same subset; literals: reference_literals.json reduce_plus / vector_reduce_*)
     s = gb.Scalar(int)
     s << v.reduce(gb.agg.sum)
-    assert s == v.reduce(gb.monoid.plus).new()
+    assert s == v.reduce(gb.monoid.plus).new() and s.value == 4  # (1 + 1 + 2 + 0)
     s << v.reduce(gb.agg.count)
-    assert s == v.nvals
+    assert s == v.nvals and s.value == 4
     s << v.reduce(gb.agg.max)
-    assert s == v.reduce(gb.monoid.max).new()
+    assert s == v.reduce(gb.monoid.max).new() and s.value == 2
     empty = gb.Vector(int, size=3)
     s << empty.reduce(gb.agg.count)
     assert s.is_empty
@@ -530,6 +536,7 @@ def test_extract_and_assign_with_index_lists(gb, v):
     w = gb.Vector(v.dtype, 3)
     w() << v[1::2]
     assert heq(w, result)
+    assert [x.tolist() for x in result.to_coo()] == [[0, 1], [1, 1]]  # (by hand: v[1], v[3]; v[5] is absent)
     assert heq(v[1::2].new(), w)
     u = gb.Vector.from_coo([0, 2], [9, 8])
     result = v.dup()
@@ -537,6 +544,7 @@ def test_extract_and_assign_with_index_lists(gb, v):
     w = v.dup()
     w[:5:2] << u
     assert heq(w, result)
+    assert [x.tolist() for x in result.to_coo()] == [[0, 1, 3, 4, 6], [9, 1, 1, 8, 0]]  # (by hand: w[0] = u[0], w[2] takes u's absent entry, w[4] = u[2])
     with pytest.raises(TypeError, match="Invalid type for index"):
         w[w] = 1
     result = v.dup()
@@ -544,6 +552,7 @@ def test_extract_and_assign_with_index_lists(gb, v):
     w = v.dup()
     w[1::2] = 9
     assert heq(w, result)
+    assert [x.tolist() for x in result.to_coo()] == [[1, 3, 4, 5, 6], [9, 9, 2, 9, 0]]
     with pytest.raises(IndexError):
         v[[-v.size - 1]]
     # accumulate into a sub-vector, and a mask of the output's size with replace (C API 2.0 GrB_assign)

@@ -410,8 +410,9 @@ def test_ordered_vectors_in_unusual_flows(gb):
         p = gb.Vector.from_coo(ui, uv, dtype=tname, size=n)
         device.vector_pin_natural(p)
         r = A2.mxv(p, gb.semiring.min_plus).new()
-        assert device.last_stats()["ordered"] == 0
+        assert device.last_stats()["ordered"] == 0 and device.last_stats()["pinned_natural"] == 1  # (the statistics say why: ADVICE r05)
         same_vec(r, e2)
+        assert A2.mxv(u, gb.semiring.min_plus).new().isequal(r) and device.last_stats()["pinned_natural"] == 0
     finally:
         set_opts(RESTORE)
 
@@ -779,7 +780,7 @@ def test_shard_setup_orders_a_row_block_by_global_column_counts(gb, seed):
         w = gb.Vector.from_coo(wi, wv, dtype=tname, size=m)
         mk = gb.Vector.from_coo(mi, mv, dtype="BOOL", size=m)
         w(~mk.S, accum=accum, replace=repl) << A.mxv(u, getattr(gb.semiring, sr))
-        assert device.last_stats()["ordered"] == 0
+        assert device.last_stats()["ordered"] == 0 and device.last_stats()["pinned_natural"] == 1
         same_vec(w, expected[0])
     finally:
         set_opts(RESTORE)
