@@ -501,9 +501,12 @@ def cpu_baseline_mxv(wl, torch, reps_budget_s=20.0):
         L.grbo_vec_write(tcode, ctypes.c_int64(m), p(w_has), p(w_val), p(t_has), p(t_val), p(mask_true), 1, acc, replace)
         times.append(time.perf_counter() - t0)
     best = float(np.median(times))
+    logical, quota = O.cpu_budget()
     return {"value": wl.nnz_active_local / best / 1e9, "unit": "GTEPS", "cores": O.num_threads(), "kind": "port",
             "sample": f"same graph and operands, full pass, median of {len(times)} reps ({best * 1e3:.1f} ms each); "
-                      "C oracle (oracle/grb_oracle.c, OpenMP) -- a CPU restatement, not SuiteSparse"}
+                      "C oracle (oracle/grb_oracle.c, OpenMP) -- a CPU restatement, not SuiteSparse; "
+                      f"host: {logical} logical CPUs visible, " + (f"cgroup quota {quota:.0f} CPUs of time -- the team is 2 threads per granted CPU "
+                      "(more are throttled, not faster: profiles/r06/cpu_host.txt)" if quota else "no CPU quota")}
 
 
 def _desc_s():
