@@ -476,7 +476,7 @@ def cpu_baseline_mxv(wl, torch, reps_budget_s=20.0):
         vals = synthetic.edge_weights(cj, int(round(np.log2(n)))).cpu().numpy()
         uvals, _ = device.vector_device_views(wl.u, pin=False)
         u_val = uvals.cpu().numpy()
-        u_has = np.ones(n, np.uint8)
+        u_has = None  # (the operand is full: the oracle skips the presence lookups, as the GPU kernels do)
         tcode, mon, mul, acc = O.TYPE_CODES["FP32"], O.OP_CODES["min"], O.OP_CODES["plus"], O.OP_CODES["min"]
         w_val = u_val[:m].copy()
         a_iso, replace = 0, 0

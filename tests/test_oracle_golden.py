@@ -273,3 +273,32 @@ def test_oracle_mxv_balanced_partition_and_split_hub_rows(tname, sr):
         np.testing.assert_allclose(got.vals, exp[exp_rows], rtol=1e-12)
     else:
         assert got.vals.tolist() == exp[exp_rows].astype(npt).tolist()
+
+
+def test_oracle_mxv_full_operand_without_presence_bytes():
+    """A full operand may be handed to the C oracle without presence bytes (u_has = NULL; bench.py's CPU baseline does): the result
+    must be the one with an explicit all-ones presence array, for the specialised loops and the generic one."""
+    import ctypes
+
+    from oracle import grb_oracle as O
+
+    rng = np.random.default_rng(5)
+    m, n = 3000, 2500
+    lens = rng.integers(0, 12, m)
+    indptr = np.zeros(m + 1, np.int64)
+    indptr[1:] = np.cumsum(lens)
+    col = np.concatenate([np.sort(rng.choice(n, int(k), replace=False)) for k in lens]).astype(np.int64)
+    L = O.lib()
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+    for tname, mon, mul in (("FP32", "min", "plus"), ("INT64", "plus", "times"), ("FP64", "max", "plus"), ("INT32", "min", "second"), ("BOOL", "lor", "land")):
+        npt = O.NP_OF[tname]
+        vals = (rng.integers(1, 50, col.size) if tname != "BOOL" else rng.integers(0, 2, col.size)).astype(npt)
+        u_val = (rng.integers(1, 50, n) if tname != "BOOL" else rng.integers(0, 2, n)).astype(npt)
+        out = []
+        for u_has in (np.ones(n, np.uint8), None):
+            t_has, t_val = np.zeros(m, np.uint8), np.zeros(m, npt)
+            assert L.grbo_mxv(O.TYPE_CODES[tname], O.OP_CODES[mon], O.OP_CODES[mul], ctypes.c_int64(m), p(indptr), p(col), p(vals), 0, p(u_has), p(u_val),
+                              None, p(t_has), p(t_val)) == 0
+            out.append((t_has.copy(), np.where(t_has != 0, t_val, 0)))
+        assert out[0][0].tolist() == out[1][0].tolist() and out[0][1].tolist() == out[1][1].tolist(), tname
+        assert out[1][0].tolist() == (lens > 0).astype(np.uint8).tolist()
