@@ -139,6 +139,8 @@ struct Context {
     void *host_pinned = nullptr;     // 4 KiB of page-locked host memory: small device-to-host reads land here (no staging copy in the runtime)
     unsigned long long *push_counters = nullptr;  // the thin push path's counters (grb_mxv_push.inc): two sets of four words, used in turn --
     int push_parity = 0;                          // a call's frontier kernel zeroes the set of the next call
+    int rtile_pack = 1;              // (round 6) 1: the sorted row tiles of a dictionary-coded matrix with at most 2^24 columns keep column code and value
+                                     // code in ONE 32-bit word per entry (code << 24 | column): 6 instead of 7 bytes per entry, one stream less per block
     int cold_in_rows = 0;            // (round 6, MEASURED AND OFF) > 0: long rows of an ordered matrix with fewer entries than this (and than hub_min_len) keep
                                      // only their LDS-resident (hot) entries in the strips; their COLD entries join the short rows' sorted row tiles (and
                                      // tagged row groups), whose kernel merges the strips' accumulator into the row's result.  Headline, scale 24: 0.458 ->

@@ -772,7 +772,7 @@ static uint64_t order_signature()
     const Context &c = ctx();
     uint64_t h = 1469598103934665603ull;
     const int64_t v[] = {c.long_kernel, c.short_kernel, c.long_classes, c.split_min_len, c.long_sub, c.long_sub_min_len, c.lean_min_nnz,
-                         c.split_min_nnz, c.hot_k, c.drop_hot_cols, c.hub_min_len, c.value_dict, c.rows_tile, c.rtile_rows, c.rtile_entries, c.cold_in_rows};
+                         c.split_min_nnz, c.hot_k, c.drop_hot_cols, c.hub_min_len, c.value_dict, c.rows_tile, c.rtile_rows, c.rtile_entries, c.cold_in_rows, c.rtile_pack};
     for (int64_t x : v) h = (h ^ (uint64_t)x) * 1099511628211ull;
     return h;
 }
@@ -1085,9 +1085,11 @@ static void ensure_rtile(GB_Matrix_opaque *A)
     const size_t ents = (size_t)total_units * RT_EPL;
     const bool dict = A->vdict_n > 0 && vs == 4;
     const size_t vb = dict ? 1 : vs;
+    // (round 6: a dictionary-coded matrix with at most 2^24 columns keeps the value code in the top byte of the column word -- no value stream)
+    const bool pack = dict && !is_bool && ctx().rtile_pack && (int64_t)S->ncols <= ((int64_t)1 << 24);
     A->d_rt_col = (int32_t *)dev_alloc(sizeof(int32_t) * ents);
     A->d_rt_tag = (uint16_t *)dev_alloc(sizeof(uint16_t) * ents);
-    A->d_rt_val = is_bool ? nullptr : dev_alloc(vb * ents);
+    A->d_rt_val = (is_bool || pack) ? nullptr : dev_alloc(vb * ents);
     A->d_rt_counter = (unsigned int *)dev_alloc_zero(64);
     GRB_HIP(hipMemsetAsync(A->d_rt_col, 0xff, sizeof(int32_t) * ents, ctx().stream));
     if (A->d_rt_val) GRB_HIP(hipMemsetAsync(A->d_rt_val, 0, vb * ents, ctx().stream));
@@ -1106,7 +1108,7 @@ static void ensure_rtile(GB_Matrix_opaque *A)
                 hipLaunchKernelGGL((k_rtile_place<T>), dim3((unsigned)ceil_div(nnz, 256)), dim3(256), 0, ctx().stream, (const uint64_t *)key2.p, (const uint32_t *)pay2.p, nnz,
                                    (const int64_t *)e0.p, (const RTile *)tiles, (const uint16_t *)rtag.p, (const T *)S->d_val, A->d_rt_col, A->d_rt_tag, (T *)A->d_rt_val,
                                    dict ? (const unsigned long long *)A->d_vd_table : (const unsigned long long *)nullptr,
-                                   dict ? (const unsigned char *)A->d_vd_codes : (const unsigned char *)nullptr, is_bool ? 1 : 0);
+                                   dict ? (const unsigned char *)A->d_vd_codes : (const unsigned char *)nullptr, is_bool ? 1 : 0, pack ? 1 : 0);
             }
         })
         sync_stream();  // (the temporaries are released at the end of this scope)
@@ -1381,11 +1383,16 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
                     b.rt_units = A->rt_units;
                     b.rt_ntiles = A->rt_ntiles;
                     const bool dict = b.vdict != nullptr && sizeof(T) == 4;
+                    const bool pack = dict && A->d_rt_val == nullptr;  // (value codes in the top byte of the column words: ensure_rtile)
                     const bool tall = A->rt_rows4 == 16384;
                     const int64_t G = std::min<int64_t>(A->rt_ntiles, (int64_t)ctx().num_cus * (tall ? 2 : 4));
                     bool launched = false;
                     if constexpr (sizeof(T) == 4) {
-                        if (dict) {
+                        if (dict && pack) {
+                            if (tall) hipLaunchKernelGGL((k_mxv_rtile<T, MON, MUL, 16384, true, true>), dim3((unsigned)G), dim3(RT_BLOCK), 0, ctx().stream, b);
+                            else hipLaunchKernelGGL((k_mxv_rtile<T, MON, MUL, 8192, true, true>), dim3((unsigned)G), dim3(RT_BLOCK), 0, ctx().stream, b);
+                            launched = true;
+                        } else if (dict) {
                             if (tall) hipLaunchKernelGGL((k_mxv_rtile<T, MON, MUL, 16384, true>), dim3((unsigned)G), dim3(RT_BLOCK), 0, ctx().stream, b);
                             else hipLaunchKernelGGL((k_mxv_rtile<T, MON, MUL, 8192, true>), dim3((unsigned)G), dim3(RT_BLOCK), 0, ctx().stream, b);
                             launched = true;
