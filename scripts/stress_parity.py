@@ -30,7 +30,8 @@ names = seeded(T)
 # (test_ordered_vectors_through_every_exit indexes a list by its seed: pytest's four seeds only)
 vnames = ["test_ordered_product_matches_the_oracle", "test_sssp_and_bfs_loops_stay_ordered",
           "test_sorted_row_tiles_match_the_oracle", "test_sorted_row_tiles_bool_step", "test_bottom_up_probe_of_long_bool_rows",
-          "test_ranked_hint_orders_without_a_permutation"]
+          "test_ranked_hint_orders_without_a_permutation",
+          "test_shard_setup_orders_a_row_block_by_global_column_counts"]  # (round 6; the row-tile test now also draws cold_in_rows and rtile_pack)
 which = os.environ.get("STRESS_SET", "all")  # random | order | all
 todo = ([(T, n) for n in names] if which in ("random", "all") else []) + ([(V, n) for n in vnames] if which in ("order", "all") else [])
 fails = 0
