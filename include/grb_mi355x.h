@@ -348,6 +348,8 @@ GrB_Info GrX_Matrix_cache_bytes(const GrB_Matrix A, uint64_t *bytes);
  *                   by column code) and run by k_mxv_rtile / k_mxv_rtile_bool where the call allows it: a compiled semiring over a full
  *                   operand (or lor.land / any.pair over presence / value pairs); 0: the tagged row groups everywhere; 2: the tiles on the
  *                   natural-order layouts of hot-coded matrices too (measured slower there)
+ *   "strip_slot16"  (round 6) 1 (default): the class strips keep a lane's accumulator slot as a 16-bit offset from the smallest slot of its chunk of
+ *                   64 lanes (one 32-bit base per chunk) when every chunk's slots span fewer than 65535 rows: half the slot stream; 0: 32-bit slots
  *   "rtile_pack"    (round 6) 1 (default): the sorted row tiles of a dictionary-coded matrix with at most 2^24 columns keep an entry's column code and
  *                   value code in one 32-bit word (6 instead of 7 bytes per entry, no separate value stream); 0: separate streams
  *   "cold_in_rows"  (round 6) 0 (default; measured slower when on): > 0: on an ordered matrix the long rows with fewer entries than this (and than

@@ -139,6 +139,8 @@ struct Context {
     void *host_pinned = nullptr;     // 4 KiB of page-locked host memory: small device-to-host reads land here (no staging copy in the runtime)
     unsigned long long *push_counters = nullptr;  // the thin push path's counters (grb_mxv_push.inc): two sets of four words, used in turn --
     int push_parity = 0;                          // a call's frontier kernel zeroes the set of the next call
+    int strip_slot16 = 1;            // (round 6) 1: the strips keep a lane's accumulator slot as a 16-bit offset from its chunk's smallest slot (+ one base per chunk)
+                                     // where every chunk's slots span less than 65535 rows: 2 instead of 4 bytes per lane record of the slot stream
     int rtile_pack = 1;              // (round 6) 1: the sorted row tiles of a dictionary-coded matrix with at most 2^24 columns keep column code and value
                                      // code in ONE 32-bit word per entry (code << 24 | column): 6 instead of 7 bytes per entry, one stream less per block
     int cold_in_rows = 0;            // (round 6, MEASURED AND OFF) > 0: long rows of an ordered matrix with fewer entries than this (and than hub_min_len) keep
@@ -410,6 +412,8 @@ struct GB_Matrix_opaque {
     int split_state;          // 0 = not analysed, 1 = enabled, -1 = not worth it
     bool split_hot;           // short_part's columns are hot-coded
     std::string err;
+    uint16_t *d_sslot16 = nullptr;     // (round 6, Context::strip_slot16) per lane: slot - d_sslot_base[chunk], 0xffff = padding; then d_sslot is released
+    int32_t *d_sslot_base = nullptr;   // ... per chunk of 64 lanes: its smallest slot
     int64_t tails_max_len = 0;         // > 0: long rows with fewer entries than this have their cold entries in `short_part` (Context::cold_in_rows): the
                                        // short-row kernels add them up and MERGE the long-row accumulator into the row's result
 };

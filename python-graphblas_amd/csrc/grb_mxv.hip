@@ -244,8 +244,9 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
         A->d_rt_col = nullptr; A->d_rt_tag = nullptr; A->d_rt_val = nullptr; A->d_rt_tiles = nullptr; A->d_rt_order = nullptr; A->d_rt_counter = nullptr;
         A->rt_state = 0; A->rt_units = 0; A->rt_ntiles = 0;
         A->tails_max_len = 0;
-        dev_free(A->d_sstart); dev_free(A->d_sslot); dev_free(A->d_hrec);
+        dev_free(A->d_sstart); dev_free(A->d_sslot); dev_free(A->d_hrec); dev_free(A->d_sslot16); dev_free(A->d_sslot_base);
         A->d_sstart = nullptr; A->d_sslot = nullptr; A->d_hrec = nullptr; A->strip_nseg = 0; A->hub_ncls = 0;
+        A->d_sslot16 = nullptr; A->d_sslot_base = nullptr;
         dev_free(A->d_ct_col); dev_free(A->d_ct_val); dev_free(A->d_ct_loc); dev_free(A->d_ct_tiles); dev_free(A->d_ct_order);
         A->d_ct_col = nullptr; A->d_ct_val = nullptr; A->d_ct_loc = nullptr; A->d_ct_tiles = nullptr; A->d_ct_order = nullptr; A->ct_units = 0; A->ct_ntiles = 0;
         A->d_lcol = nullptr; A->d_lval = nullptr; A->d_it_start = nullptr; A->d_it_len = nullptr; A->d_it_slot = nullptr;
@@ -504,6 +505,26 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
                         hipLaunchKernelGGL(k_strip_pad_starts, dim3(1), dim3(128), 0, ctx().stream, (const int64_t *)sc.p, (const int64_t *)off.p,
                                            (const int64_t *)cshift.p, (const int64_t *)cend.p, nvc, A->d_sstart);
                         sync_stream();
+                    }
+                    // round 6: the slots as 16-bit offsets from each chunk's smallest slot (half the slot stream of the strip kernels)
+                    dev_free(A->d_sslot16); dev_free(A->d_sslot_base);
+                    A->d_sslot16 = nullptr; A->d_sslot_base = nullptr;
+                    if (ctx().strip_slot16 && nch > 0) {
+                        DevBuf<unsigned int> too_wide(1, true);
+                        uint16_t *s16 = (uint16_t *)dev_alloc(sizeof(uint16_t) * (size_t)(padded / 8));
+                        int32_t *sb = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)nch);
+                        hipLaunchKernelGGL(k_strip_slot16, dim3((unsigned)ceil_div(nch, 4)), dim3(256), 0, ctx().stream, (const int32_t *)A->d_sslot, nch, s16, sb, too_wide.p);
+                        unsigned int wide = 0;
+                        d2h(&wide, too_wide.p, sizeof(wide));
+                        if (wide) {  // (a chunk whose rows lie 65535 slots apart: the 32-bit slots stay)
+                            dev_free(s16);
+                            dev_free(sb);
+                        } else {
+                            A->d_sslot16 = s16;
+                            A->d_sslot_base = sb;
+                            dev_free(A->d_sslot);
+                            A->d_sslot = nullptr;
+                        }
                     }
                     for (int c = 0; c <= nvc; c++) A->strip_cb[c] = h_cb[c];
                     dev_free(A->d_wg_tab); dev_free(A->d_strip_cb);
@@ -772,7 +793,7 @@ static uint64_t order_signature()
     const Context &c = ctx();
     uint64_t h = 1469598103934665603ull;
     const int64_t v[] = {c.long_kernel, c.short_kernel, c.long_classes, c.split_min_len, c.long_sub, c.long_sub_min_len, c.lean_min_nnz,
-                         c.split_min_nnz, c.hot_k, c.drop_hot_cols, c.hub_min_len, c.value_dict, c.rows_tile, c.rtile_rows, c.rtile_entries, c.cold_in_rows, c.rtile_pack};
+                         c.split_min_nnz, c.hot_k, c.drop_hot_cols, c.hub_min_len, c.value_dict, c.rows_tile, c.rtile_rows, c.rtile_entries, c.cold_in_rows, c.rtile_pack, c.strip_slot16};
     for (int64_t x : v) h = (h ^ (uint64_t)x) * 1099511628211ull;
     return h;
 }
@@ -1086,7 +1107,9 @@ static void ensure_rtile(GB_Matrix_opaque *A)
     const bool dict = A->vdict_n > 0 && vs == 4;
     const size_t vb = dict ? 1 : vs;
     // (round 6: a dictionary-coded matrix with at most 2^24 columns keeps the value code in the top byte of the column word -- no value stream)
-    const bool pack = dict && !is_bool && ctx().rtile_pack && (int64_t)S->ncols <= ((int64_t)1 << 24);
+    // (the codes of a hot-coded matrix in natural order -- rows_tile = 2 -- index the image [table | u]: ncols + hot_k of them)
+    const int64_t n_codes = (int64_t)S->ncols + (A->hot_identity ? 0 : std::max<int64_t>(A->hot_k, 0));
+    const bool pack = dict && !is_bool && ctx().rtile_pack && n_codes <= ((int64_t)1 << 24);
     A->d_rt_col = (int32_t *)dev_alloc(sizeof(int32_t) * ents);
     A->d_rt_tag = (uint16_t *)dev_alloc(sizeof(uint16_t) * ents);
     A->d_rt_val = (is_bool || pack) ? nullptr : dev_alloc(vb * ents);
@@ -1200,6 +1223,8 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
             a.cls_lds_lim = A->cls_lds_lim;
             a.strip_start = A->d_sstart;
             a.strip_slot = A->d_sslot;
+            a.strip_slot16 = A->d_sslot16;  // (round 6: 16-bit offsets + a base per chunk; d_sslot is then gone)
+            a.strip_slot_base = A->d_sslot_base;
             a.strip_nseg = A->strip_nseg;
             for (int c = 0; c <= A->strip_ncls; c++) a.strip_cb[c] = A->strip_cb[c];
             a.strip_ncls = A->strip_ncls;
@@ -1243,14 +1268,18 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
                             al.strip_cb_dev = A->d_strip_cb;
                             al.strip_chunks = A->strip_cb[A->strip_ncls + A->hub_ncls];
                             bool dict_launched = false;
+                            const bool s16 = al.strip_slot16 != nullptr;
                             if constexpr (sizeof(T) == 4) {
                                 if (al.vdict) {
-                                    hipLaunchKernelGGL((k_mxv_hstrip<T, MON, MUL, LONG_LDS_WORDS, true>), dim3((unsigned)A->wg_tab_g), dim3(LONG_BLOCK), 0, ctx().stream, al);
+                                    if (s16) hipLaunchKernelGGL((k_mxv_hstrip<T, MON, MUL, LONG_LDS_WORDS, true, true>), dim3((unsigned)A->wg_tab_g), dim3(LONG_BLOCK), 0, ctx().stream, al);
+                                    else hipLaunchKernelGGL((k_mxv_hstrip<T, MON, MUL, LONG_LDS_WORDS, true>), dim3((unsigned)A->wg_tab_g), dim3(LONG_BLOCK), 0, ctx().stream, al);
                                     dict_launched = true;
                                 }
                             }
-                            if (!dict_launched)
-                                hipLaunchKernelGGL((k_mxv_hstrip<T, MON, MUL, LONG_LDS_WORDS>), dim3((unsigned)A->wg_tab_g), dim3(LONG_BLOCK), 0, ctx().stream, al);
+                            if (!dict_launched) {
+                                if (s16) hipLaunchKernelGGL((k_mxv_hstrip<T, MON, MUL, LONG_LDS_WORDS, false, true>), dim3((unsigned)A->wg_tab_g), dim3(LONG_BLOCK), 0, ctx().stream, al);
+                                else hipLaunchKernelGGL((k_mxv_hstrip<T, MON, MUL, LONG_LDS_WORDS>), dim3((unsigned)A->wg_tab_g), dim3(LONG_BLOCK), 0, ctx().stream, al);
+                            }
                             merged = true;
                         }
                     }
@@ -1269,14 +1298,18 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
                         if constexpr (hstrip_fast_semiring<T>(MON, MUL)) {
                             if (hot_fast) {
                                 bool dict_launched = false;
+                                const bool s16 = al.strip_slot16 != nullptr;
                                 if constexpr (sizeof(T) == 4) {
                                     if (al.vdict) {
-                                        hipLaunchKernelGGL((k_mxv_hstrip<T, MON, MUL, LONG_LDS_WORDS, true>), dim3((unsigned)Gl), dim3(LONG_BLOCK), 0, ctx().stream, al);
+                                        if (s16) hipLaunchKernelGGL((k_mxv_hstrip<T, MON, MUL, LONG_LDS_WORDS, true, true>), dim3((unsigned)Gl), dim3(LONG_BLOCK), 0, ctx().stream, al);
+                                        else hipLaunchKernelGGL((k_mxv_hstrip<T, MON, MUL, LONG_LDS_WORDS, true>), dim3((unsigned)Gl), dim3(LONG_BLOCK), 0, ctx().stream, al);
                                         dict_launched = true;
                                     }
                                 }
-                                if (!dict_launched)
-                                    hipLaunchKernelGGL((k_mxv_hstrip<T, MON, MUL, LONG_LDS_WORDS>), dim3((unsigned)Gl), dim3(LONG_BLOCK), 0, ctx().stream, al);
+                                if (!dict_launched) {
+                                    if (s16) hipLaunchKernelGGL((k_mxv_hstrip<T, MON, MUL, LONG_LDS_WORDS, false, true>), dim3((unsigned)Gl), dim3(LONG_BLOCK), 0, ctx().stream, al);
+                                    else hipLaunchKernelGGL((k_mxv_hstrip<T, MON, MUL, LONG_LDS_WORDS>), dim3((unsigned)Gl), dim3(LONG_BLOCK), 0, ctx().stream, al);
+                                }
                                 launched = true;
                             }
                         }
@@ -2358,7 +2391,7 @@ extern "C" GrB_Info GrX_Matrix_cache_bytes(const GrB_Matrix A, uint64_t *bytes)
         if (A->split_kind == 4 && (A->strip_nseg > 0 || A->ct_units > 0)) {
             const uint64_t hot_lanes = (uint64_t)A->strip_cb[A->strip_ncls + A->hub_ncls] * 64;
             const uint64_t cold = (uint64_t)A->ct_units * CT_EPL;
-            b += hot_lanes * (uint64_t)A->hrec_bytes + hot_lanes * 4 + hot_lanes / 8 + cold * (6 + (A->d_ct_val ? vs : 0)) + 20ull * (uint64_t)A->ct_ntiles;
+            b += hot_lanes * (uint64_t)A->hrec_bytes + (A->d_sslot16 ? hot_lanes * 2 + hot_lanes / 16 : hot_lanes * 4) + hot_lanes / 8 + cold * (6 + (A->d_ct_val ? vs : 0)) + 20ull * (uint64_t)A->ct_ntiles;
         } else if (A->split_kind == 2 && A->strip_nseg > 0) {
             const uint64_t padded = (uint64_t)A->strip_cb[A->strip_ncls] * STRIP_CH;
             b += padded * 4 + (A->d_lval ? padded * vs : 0) + padded / 2 + padded / STRIP_CH * 8;

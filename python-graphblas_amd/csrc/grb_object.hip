@@ -733,6 +733,8 @@ void matrix_invalidate_caches(GB_Matrix_opaque *A)
     dev_free(A->d_item_begin);
     dev_free(A->d_sstart);
     dev_free(A->d_sslot);
+    dev_free(A->d_sslot16); dev_free(A->d_sslot_base);
+    A->d_sslot16 = nullptr; A->d_sslot_base = nullptr;
     dev_free(A->d_hrec);
     dev_free(A->d_vdict); dev_free(A->d_vd_table); dev_free(A->d_vd_codes);
     A->d_vdict = nullptr; A->d_vd_table = nullptr; A->d_vd_codes = nullptr;
