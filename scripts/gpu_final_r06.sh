@@ -7,7 +7,7 @@ pmc() {  # pmc <workload> : three PMC passes -> $OUT/pmc_traffic_<workload>.json
   wl=$1
   for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
     d="$OUT/pmc_${wl}_$(echo $c | tr ' ' '_')"
-    timeout 420 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$d" -o p -- python bench.py --workload $wl --steps 2 --warmup 3 --no-cpu-baseline --no-extra > "$d.json" 2> "$d.err"; echo "pmc $wl [$c] rc=$?"
+    timeout 420 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$d" -o p -- python bench.py --workload $wl --steps 2 --warmup 3 --no-cpu-baseline --no-extra --no-warm-build > "$d.json" 2> "$d.err"; echo "pmc $wl [$c] rc=$?"
   done
   python - "$OUT" "$wl" <<'PY'
 import csv, sys, glob, json, collections, os
@@ -41,20 +41,20 @@ PY
   find "$OUT" -name '*counter_collection.csv' -size +4M -delete; find "$OUT" -name '*kernel_trace.csv' -size +1M -delete
 }
 line() { python -c "import sys,json; d=json.loads(open('$1').read().strip().splitlines()[-1]); print({k: d.get(k) for k in ('value','unit','ms_per_step','verified')}, (d.get('roofline') or {}).get('frac'))"; }
-echo "== rocprofv3 stats of the default command (headline workload only)"; ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "/tmp/prof_$TAG" -o bench -- python $OLDPWD/bench.py --no-cpu-baseline --no-extra > $OLDPWD/$OUT/bench_default_under_rocprof.json 2> $OLDPWD/$OUT/prof.err ); cp $(find /tmp/prof_$TAG -name '*kernel_stats.csv' | head -1) $OUT/bench_default_kernel_stats.csv; grep -E "grb::k_mxv|grb::k_x_image|grb::k_long_init" "$OUT/bench_default_kernel_stats.csv" | cut -c1-150 | head -8
-echo "== rocprofv3 stats of the BFS level step"; ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "/tmp/prof_${TAG}_bfs" -o bench -- python $OLDPWD/bench.py --workload mxv_lor_land_masked --no-cpu-baseline --no-extra > $OLDPWD/$OUT/bench_lor_land_under_rocprof.json 2>/dev/null ); cp $(find /tmp/prof_${TAG}_bfs -name '*kernel_stats.csv' | head -1) $OUT/bench_lor_land_kernel_stats.csv
+echo "== rocprofv3 stats of the default command (headline workload only)"; ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "/tmp/prof_$TAG" -o bench -- python $OLDPWD/bench.py --no-cpu-baseline --no-extra --no-warm-build > $OLDPWD/$OUT/bench_default_under_rocprof.json 2> $OLDPWD/$OUT/prof.err ); cp $(find /tmp/prof_$TAG -name '*kernel_stats.csv' | head -1) $OUT/bench_default_kernel_stats.csv; grep -E "grb::k_mxv|grb::k_x_image|grb::k_long_init" "$OUT/bench_default_kernel_stats.csv" | cut -c1-150 | head -8
+echo "== rocprofv3 stats of the BFS level step"; ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "/tmp/prof_${TAG}_bfs" -o bench -- python $OLDPWD/bench.py --workload mxv_lor_land_masked --no-cpu-baseline --no-extra --no-warm-build > $OLDPWD/$OUT/bench_lor_land_under_rocprof.json 2>/dev/null ); cp $(find /tmp/prof_${TAG}_bfs -name '*kernel_stats.csv' | head -1) $OUT/bench_lor_land_kernel_stats.csv
 echo "== PMC"; pmc mxv_min_plus_masked; pmc mxv_lor_land_masked
 echo "== bench default (headline + extras)"; ( time timeout 900 python bench.py ) > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"; line $OUT/bench_default.json
 echo "== unmasked min_plus scale 24"; timeout 600 python bench.py --workload mxv_min_plus --no-extra > "$OUT/bench_s24_unmasked.json" 2>/dev/null; line $OUT/bench_s24_unmasked.json
 echo "== bench scale 20 (configs[1])"; timeout 600 python bench.py --scale 20 --workload mxv_min_plus > "$OUT/bench_s20_minplus.json" 2>/dev/null; line $OUT/bench_s20_minplus.json
 echo "== config 0"; timeout 600 python bench.py --workload uniform_fp64 --steps 50 > "$OUT/bench_uniform_fp64.json" 2>/dev/null; line $OUT/bench_uniform_fp64.json
 echo "== kron26 rank 0 of 8 (configs[4] shape)"; timeout 900 python bench.py --workload kron26 --block 0/8 > "$OUT/kron26_block0of8.json" 2>/dev/null; line $OUT/kron26_block0of8.json
-echo "== row blocks of the scale-24 graph"; for w in 1 2 4 8; do timeout 600 python bench.py --block 0/$w --no-cpu-baseline --no-extra 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps({'block': '0/$w', 'ms_per_step': d['ms_per_step'], 'verified': d['verified']}))"; done > "$OUT/block_times_s24.jsonl"; cat "$OUT/block_times_s24.jsonl"
-echo "== the same blocks without the set-up step (natural-order layouts, rounds 1-5)"; for w in 2 4 8; do timeout 600 python bench.py --block 0/$w --no-shard-setup --no-cpu-baseline --no-extra 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps({'block': '0/$w', 'shard_setup': False, 'ms_per_step': d['ms_per_step'], 'verified': d['verified'], 'ordered': d['stats'].get('ordered')}))"; done > "$OUT/block_times_s24_no_setup.jsonl"; cat "$OUT/block_times_s24_no_setup.jsonl"
+echo "== row blocks of the scale-24 graph"; for w in 1 2 4 8; do timeout 600 python bench.py --block 0/$w --no-cpu-baseline --no-extra --no-warm-build 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps({'block': '0/$w', 'ms_per_step': d['ms_per_step'], 'verified': d['verified']}))"; done > "$OUT/block_times_s24.jsonl"; cat "$OUT/block_times_s24.jsonl"
+echo "== the same blocks without the set-up step (natural-order layouts, rounds 1-5)"; for w in 2 4 8; do timeout 600 python bench.py --block 0/$w --no-shard-setup --no-cpu-baseline --no-extra --no-warm-build 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps({'block': '0/$w', 'shard_setup': False, 'ms_per_step': d['ms_per_step'], 'verified': d['verified'], 'ordered': d['stats'].get('ordered')}))"; done > "$OUT/block_times_s24_no_setup.jsonl"; cat "$OUT/block_times_s24_no_setup.jsonl"
 timeout 900 python bench.py --workload kron26 --block 0/8 --no-shard-setup --no-cpu-baseline > "$OUT/kron26_block0of8_no_setup.json" 2>/dev/null; line $OUT/kron26_block0of8_no_setup.json
 echo "== ranked labels (GrX_Matrix_hint_ranked): whole graph, blocks of a block-cyclic dealing, Kronecker-26 block"
 for spec in "" "--block 0/2" "--block 0/4" "--block 0/8" "--block 7/8"; do
-  timeout 600 python bench.py --ranked $spec --no-cpu-baseline --no-extra 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps({'ranked': '$spec', 'ms_per_step': d['ms_per_step'], 'frac': d['roofline']['frac'], 'verified': d['verified'], 'ordered': d['stats'].get('ordered'), 'build_ms': d['layout_build_call_ms']}))"
+  timeout 600 python bench.py --ranked $spec --no-cpu-baseline --no-extra --no-warm-build 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps({'ranked': '$spec', 'ms_per_step': d['ms_per_step'], 'frac': d['roofline']['frac'], 'verified': d['verified'], 'ordered': d['stats'].get('ordered'), 'build_ms': d['layout_build_call_ms']}))"
 done > "$OUT/ranked_block_times_s24.jsonl"; cat "$OUT/ranked_block_times_s24.jsonl"
 timeout 900 python bench.py --workload kron26 --ranked --block 0/8 --no-cpu-baseline > "$OUT/kron26_ranked_block0of8.json" 2>/dev/null; line $OUT/kron26_ranked_block0of8.json
 echo "== BFS / SSSP loops"; timeout 600 python bench.py --workload bfs --steps 5 > "$OUT/bfs_s24.json" 2>/dev/null; line $OUT/bfs_s24.json; timeout 600 python bench.py --workload sssp --steps 3 > "$OUT/sssp_s24.json" 2>/dev/null; line $OUT/sssp_s24.json
@@ -113,11 +113,11 @@ PY
 find "$OUT" -name '*counter_collection.csv' -size +4M -delete; find "$OUT" -name '*kernel_trace.csv' -size +1M -delete
 echo "== the headline with round-5 / round-4 features off one at a time (same library, options)"
 for kv in "GRB_ROWS_TILE=0" "GRB_ORDER_MODE=0" "GRB_VALUE_DICT=0" "GRB_HUB_MIN_LEN=0"; do
-  env $kv timeout 600 python bench.py --no-cpu-baseline --no-extra > "$OUT/bench_headline_$(echo $kv | tr ' =' '__').json" 2>/dev/null; echo -n "$kv: "; line "$OUT/bench_headline_$(echo $kv | tr ' =' '__').json"
+  env $kv timeout 600 python bench.py --no-cpu-baseline --no-extra --no-warm-build > "$OUT/bench_headline_$(echo $kv | tr ' =' '__').json" 2>/dev/null; echo -n "$kv: "; line "$OUT/bench_headline_$(echo $kv | tr ' =' '__').json"
 done
 echo "== SpGEMM kernel stats (scale 20 / 22, default options)"
 for s in 20 22; do ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_mxm$s -o mxm -- python $OLDPWD/bench.py --workload mxm_plus_times --scale $s --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1 ); cp $(find /tmp/prof_mxm$s -name '*kernel_stats.csv' | head -1) "$OUT/mxm_s${s}_kernel_stats.csv"; head -7 "$OUT/mxm_s${s}_kernel_stats.csv" | cut -c1-150; done
 echo "== RCCL one rank"; export HSA_ENABLE_IPC_MODE_LEGACY=0; timeout 600 python tests/nccl_one_rank.py > "$OUT/rccl_one_rank.json" 2> "$OUT/rccl_one_rank.err"; tail -c 400 "$OUT/rccl_one_rank.json"; timeout 600 python bench.py --force-dist --backend nccl --no-cpu-baseline > "$OUT/bench_force_dist_nccl_one_rank.json" 2>/dev/null; line "$OUT/bench_force_dist_nccl_one_rank.json"
-echo "== layout build kernels"; ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_build -o b -- python $OLDPWD/bench.py --steps 1 --warmup 2 --no-cpu-baseline --no-extra > /dev/null 2>&1 ); cp $(find /tmp/prof_build -name '*kernel_stats.csv' | head -1) "$OUT/layout_build_kernel_stats.csv"; head -25 "$OUT/layout_build_kernel_stats.csv" | cut -c1-120
+echo "== layout build kernels"; ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_build -o b -- python $OLDPWD/bench.py --steps 1 --warmup 2 --no-cpu-baseline --no-extra --no-warm-build > /dev/null 2>&1 ); cp $(find /tmp/prof_build -name '*kernel_stats.csv' | head -1) "$OUT/layout_build_kernel_stats.csv"; head -25 "$OUT/layout_build_kernel_stats.csv" | cut -c1-120
 echo "== pytest -m gpu (everything)"; ( time timeout 1200 python -m pytest tests -m gpu -q ) > "$OUT/tests_gpu_full.log" 2>&1; tail -4 "$OUT/tests_gpu_full.log"
 

@@ -3,12 +3,12 @@
 OUT=gpurun_out/r06s; mkdir -p $OUT; export TMPDIR=/tmp
 [ -n "$VARIANT" ] && export GRB_MI355X_LIB=$PWD/build/variants/$VARIANT/libgrb_mi355x.so
 python -m pytest tests/test_vertex_order.py tests/test_gpu_scale.py -m gpu -x -q -k "sorted_row_tiles or ordered_product or scale24_headline or rmat_vs_oracle" 2>&1 | tail -3
-one() { tag=$1; shift; env "$@" python bench.py --steps 30 --no-cpu-baseline --no-extra --no-page-in 2>$OUT/$tag.err | tee $OUT/$tag.json | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$tag', round(d['ms_per_step'],4), 'frac', round(d['roofline']['frac'],4), 'verified', d['verified'], 'cache_GB', round(d['preprocess_bytes']/1e9,3))"; }
-oneu() { tag=$1; shift; env "$@" python bench.py --workload mxv_min_plus --steps 30 --no-cpu-baseline --no-extra --no-page-in 2>$OUT/$tag.err | tee $OUT/$tag.json | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$tag', round(d['ms_per_step'],4), 'verified', d['verified'])"; }
+one() { tag=$1; shift; env "$@" python bench.py --steps 30 --no-cpu-baseline --no-extra --no-warm-build 2>$OUT/$tag.err | tee $OUT/$tag.json | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$tag', round(d['ms_per_step'],4), 'frac', round(d['roofline']['frac'],4), 'verified', d['verified'], 'cache_GB', round(d['preprocess_bytes']/1e9,3))"; }
+oneu() { tag=$1; shift; env "$@" python bench.py --workload mxv_min_plus --steps 30 --no-cpu-baseline --no-extra --no-warm-build 2>$OUT/$tag.err | tee $OUT/$tag.json | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$tag', round(d['ms_per_step'],4), 'verified', d['verified'])"; }
 one pack1 GRB_RTILE_PACK=1; one pack0 GRB_RTILE_PACK=0; one pack1_b GRB_RTILE_PACK=1; one pack0_b GRB_RTILE_PACK=0
 oneu unmasked_pack1 GRB_RTILE_PACK=1; oneu unmasked_pack0 GRB_RTILE_PACK=0
 for c in 1 0; do
-  GRB_RTILE_PACK=$c timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_pack$c -o b -- python bench.py --steps 10 --no-cpu-baseline --no-extra --no-page-in > /dev/null 2>&1
+  GRB_RTILE_PACK=$c timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_pack$c -o b -- python bench.py --steps 10 --no-cpu-baseline --no-extra --no-warm-build > /dev/null 2>&1
   echo "kernels, rtile_pack=$c"
   python - $OUT/prof_pack$c/b_kernel_stats.csv <<'PY'
 import csv, sys

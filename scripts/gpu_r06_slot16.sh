@@ -3,12 +3,12 @@
 OUT=gpurun_out/r06u; mkdir -p $OUT; export TMPDIR=/tmp
 [ -n "$VARIANT" ] && export GRB_MI355X_LIB=$PWD/build/variants/$VARIANT/libgrb_mi355x.so
 python -m pytest tests/test_vertex_order.py tests/test_gpu_scale.py -m gpu -x -q -k "sorted_row_tiles or ordered_product or scale24_headline or rmat_vs_oracle" 2>&1 | tail -3
-one() { tag=$1; shift; env "$@" python bench.py --steps 30 --no-cpu-baseline --no-extra --no-page-in 2>$OUT/$tag.err | tee $OUT/$tag.json | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$tag', round(d['ms_per_step'],4), 'frac', round(d['roofline']['frac'],4), 'verified', d['verified'], 'cache_GB', round(d['preprocess_bytes']/1e9,3))"; }
-oneu() { tag=$1; shift; env "$@" python bench.py --workload mxv_min_plus --steps 30 --no-cpu-baseline --no-extra --no-page-in 2>$OUT/$tag.err | tee $OUT/$tag.json | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$tag', round(d['ms_per_step'],4), 'verified', d['verified'])"; }
+one() { tag=$1; shift; env "$@" python bench.py --steps 30 --no-cpu-baseline --no-extra --no-warm-build 2>$OUT/$tag.err | tee $OUT/$tag.json | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$tag', round(d['ms_per_step'],4), 'frac', round(d['roofline']['frac'],4), 'verified', d['verified'], 'cache_GB', round(d['preprocess_bytes']/1e9,3))"; }
+oneu() { tag=$1; shift; env "$@" python bench.py --workload mxv_min_plus --steps 30 --no-cpu-baseline --no-extra --no-warm-build 2>$OUT/$tag.err | tee $OUT/$tag.json | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$tag', round(d['ms_per_step'],4), 'verified', d['verified'])"; }
 one s16_1 GRB_STRIP_SLOT16=1; one s16_0 GRB_STRIP_SLOT16=0; one s16_1_b GRB_STRIP_SLOT16=1; one s16_0_b GRB_STRIP_SLOT16=0
 oneu unmasked_s16_1 GRB_STRIP_SLOT16=1; oneu unmasked_s16_0 GRB_STRIP_SLOT16=0
 for c in 1 0; do
-  GRB_STRIP_SLOT16=$c timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_s16_$c -o b -- python bench.py --steps 10 --no-cpu-baseline --no-extra --no-page-in > /dev/null 2>&1
+  GRB_STRIP_SLOT16=$c timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_s16_$c -o b -- python bench.py --steps 10 --no-cpu-baseline --no-extra --no-warm-build > /dev/null 2>&1
   echo "kernels, strip_slot16=$c"
   python - $OUT/prof_s16_$c/b_kernel_stats.csv <<'PY'
 import csv, sys
