@@ -46,3 +46,38 @@ for it in range(15):
                             ctypes.byref(fl), ctypes.byref(nb))
     assert rc == 0
 print(f"mxm streamed ({nb.value} batches): delta {before - free_mb():.1f} MiB")
+
+# round 6: the cached layouts of a large matrix (popularity-ordered twin, strips with 16-bit slots, packed row tiles, cold tiles; a row block with
+# the library's column ranking) are released with the matrix: free memory after five build / drop cycles = free memory after the first
+import gc  # noqa: E402
+
+
+def cycle(block):
+    s = 22
+    nn = 1 << s
+    if block:
+        ipb, colb = synthetic.rmat_csr(s, device="cuda", row_range=(0, nn // 4))
+        M = device.matrix_from_device_csr(ipb, colb, synthetic.edge_weights(colb, s), nn // 4, nn, "FP32")
+        device.matrix_shard_setup(M, torch.bincount(colb.long(), minlength=nn).to(torch.int32))
+        w = device.vector_from_device(torch.rand(nn // 4, device="cuda"))
+    else:
+        ipb, colb = synthetic.rmat_csr(s, device="cuda")
+        M = device.matrix_from_device_csr(ipb, colb, synthetic.edge_weights(colb, s), nn, nn, "FP32")
+        w = device.vector_from_device(torch.rand(nn, device="cuda"))
+    x = device.vector_from_device(torch.rand(nn, device="cuda"))
+    for _ in range(3):
+        w(accum=gb.binary.min) << M.mxv(x, gb.semiring.min_plus)
+    st = device.last_stats()
+    del M, w, x, ipb, colb
+    gc.collect()
+    device.trim_memory()
+    torch.cuda.empty_cache()
+    return st["ordered"]
+
+
+for block in (False, True):
+    ordered = cycle(block)
+    base = free_mb()
+    for _ in range(4):
+        cycle(block)
+    print(f"layouts of a scale-22 {'row block (shard set-up)' if block else 'matrix'}: ordered {ordered}, free after cycle 1 {base:.0f} MiB, after cycle 5 {free_mb():.0f} MiB, delta {base - free_mb():.1f} MiB")
