@@ -348,6 +348,9 @@ GrB_Info GrX_Matrix_cache_bytes(const GrB_Matrix A, uint64_t *bytes);
  *                   by column code) and run by k_mxv_rtile / k_mxv_rtile_bool where the call allows it: a compiled semiring over a full
  *                   operand (or lor.land / any.pair over presence / value pairs); 0: the tagged row groups everywhere; 2: the tiles on the
  *                   natural-order layouts of hot-coded matrices too (measured slower there)
+ *   "ctile_pack"    (round 6) 0 (default; 0 .. 2; measured: no gain): 1: the cold tiles of an ordered matrix keep an entry's column (as an offset in its
+ *                   column range, every range below 2^19 codes) and its row slot in one 32-bit word -- tiles of 8192 rows, 8 instead of 10 bytes per
+ *                   entry; 2: and one-byte dictionary codes for the values (5 bytes per entry); 0: three streams
  *   "strip_slot16"  (round 6) 1 (default): the class strips keep a lane's accumulator slot as a 16-bit offset from the smallest slot of its chunk of
  *                   64 lanes (one 32-bit base per chunk) when every chunk's slots span fewer than 65535 rows: half the slot stream; 0: 32-bit slots
  *   "rtile_pack"    (round 6) 1 (default): the sorted row tiles of a dictionary-coded matrix with at most 2^24 columns keep an entry's column code and

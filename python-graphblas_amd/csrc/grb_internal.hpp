@@ -139,6 +139,10 @@ struct Context {
     void *host_pinned = nullptr;     // 4 KiB of page-locked host memory: small device-to-host reads land here (no staging copy in the runtime)
     unsigned long long *push_counters = nullptr;  // the thin push path's counters (grb_mxv_push.inc): two sets of four words, used in turn --
     int push_parity = 0;                          // a call's frontier kernel zeroes the set of the next call
+    int ctile_pack = 0;              // (round 6, MEASURED AND OFF) cold tiles of an ordered matrix with every column range below 2^19 codes: 1 = an entry's column (offset in
+                                     // its range) and row slot in ONE word (slot << 19 | column; tiles of 8192 slots, up to 128 ranges): 8 instead of 10 bytes per
+                                     // entry; 2 = ... and one-byte dictionary codes for its value (5 bytes).  Headline 0.461-0.471 ms with three streams, 0.471-0.479
+                                     // packed, 0.468-0.480 packed + codes: 4204 tiles instead of 2333 cost what 46 / 115 MB of stream save (profiles/r06/ctile_pack.txt)
     int strip_slot16 = 1;            // (round 6) 1: the strips keep a lane's accumulator slot as a 16-bit offset from its chunk's smallest slot (+ one base per chunk)
                                      // where every chunk's slots span less than 65535 rows: 2 instead of 4 bytes per lane record of the slot stream
     int rtile_pack = 1;              // (round 6) 1: the sorted row tiles of a dictionary-coded matrix with at most 2^24 columns keep column code and value
@@ -412,6 +416,8 @@ struct GB_Matrix_opaque {
     int split_state;          // 0 = not analysed, 1 = enabled, -1 = not worth it
     bool split_hot;           // short_part's columns are hot-coded
     std::string err;
+    int ct_mode = 0;                   // (round 6, Context::ctile_pack) 0: d_ct_col / d_ct_val / d_ct_loc as three streams; 1: d_ct_col holds slot << 19 | (column - base of
+                                       // the tile's column range), no d_ct_loc, the tiles' range bases behind the CTile array; 2: ... and d_ct_val holds one-byte codes
     uint16_t *d_sslot16 = nullptr;     // (round 6, Context::strip_slot16) per lane: slot - d_sslot_base[chunk], 0xffff = padding; then d_sslot is released
     int32_t *d_sslot_base = nullptr;   // ... per chunk of 64 lanes: its smallest slot
     int64_t tails_max_len = 0;         // > 0: long rows with fewer entries than this have their cold entries in `short_part` (Context::cold_in_rows): the

@@ -404,7 +404,18 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
             }
             // kind 4: the sorted entries are [hot: virtual classes 0 .. ncls - 1 | cold: column ranges ncls .. ncls + n_cr - 1]; the hot
             // part becomes strips (lane records), the cold part tagged tiles (grb_mxv_ctile.inc)
-            const int ct_slots = A->type->size > 4 ? CT_SLOTS / 2 : CT_SLOTS;  // (CtSlots<W>: 8-byte accumulators take half the slots)
+            // Round 6 (Context::ctile_pack): the cold tiles of an ordered matrix whose column ranges are at most 2^19 codes wide keep column (offset in the
+            // range) and row slot of an entry in one word -- slot << 19 | column: tiles of 8192 slots --, mode 2 also one-byte value codes
+            int ct_mode = 0;
+            std::vector<int32_t> h_bounds;
+            if (kind == 4 && own_ranges && ctx().ctile_pack > 0) {
+                h_bounds.resize((size_t)A->ct_ncr + 1);
+                d2h(h_bounds.data(), A->d_cold_bounds, sizeof(int32_t) * h_bounds.size());
+                int64_t widest = 0;
+                for (int r = 0; r < A->ct_ncr; r++) widest = std::max<int64_t>(widest, (int64_t)h_bounds[(size_t)r + 1] - (int64_t)h_bounds[(size_t)r]);
+                if (widest < ((int64_t)1 << 19) - 1) ct_mode = (ctx().ctile_pack == 2 && A->vdict_n > 0 && A->type->size == 4 && !A->iso) ? 2 : 1;
+            }
+            const int ct_slots = ct_mode ? CT_PACK_SLOTS : (A->type->size > 4 ? CT_SLOTS / 2 : CT_SLOTS);  // (CtSlots<W>: 8-byte accumulators take half the slots)
             const int n_sb = (int)ceil_div(nl, (int64_t)ct_slots);
             const int64_t n_tiles = kind == 4 ? (int64_t)n_cr * n_sb : 0;
             std::vector<int64_t> h_first((size_t)n_tiles + 1, 0);
@@ -593,7 +604,8 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
             // (measured, profiles/r04/value_dict.txt: one-byte codes make the tagged row groups 5 % faster -- 9 -> 6 bytes per entry of a
             //  kernel that streams them all -- and the cold tiles 7 % SLOWER: their stream is a third of their time, the code load + LDS
             //  lookup per entry costs more than the bytes it saves.  The tiles keep full values.)
-            const bool use_dict_all = false;
+            const bool use_dict_all = ct_mode == 2;  // (round 6: behind the packed words the codes were measured again -- profiles/r06/ctile_pack.txt)
+            A->ct_mode = 0;
             if (kind == 4 && nnz_long > n_strip) {
                 // the cold entries as tagged tiles: a (column range, slot block) pair is one tile, or several when it holds more than
                 // CT_MAX_ENTRIES entries (the hub rows: the sorted run is cut into equal pieces -- a piece still lies inside the
@@ -650,8 +662,14 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
                 }
                 A->ct_xoff[8] = (int64_t)h_order.size();
                 const size_t ents = (size_t)std::max<int64_t>(units, 1) * CT_EPL;
-                A->d_ct_tiles = dev_alloc(sizeof(CTile) * (size_t)std::max<int64_t>(nt, 1));
+                // (packed: behind the nt tile records, the first column code of every tile's range -- int32[nt])
+                A->d_ct_tiles = dev_alloc((sizeof(CTile) + sizeof(int32_t)) * (size_t)std::max<int64_t>(nt, 1));
                 h2d(A->d_ct_tiles, h_tiles.data(), sizeof(CTile) * (size_t)nt);
+                if (ct_mode) {
+                    std::vector<int32_t> h_cbase((size_t)nt);
+                    for (int64_t t = 0; t < nt; t++) h_cbase[(size_t)t] = h_bounds[(size_t)tile_range[(size_t)t]];
+                    h2d((char *)A->d_ct_tiles + sizeof(CTile) * (size_t)std::max<int64_t>(nt, 1), h_cbase.data(), sizeof(int32_t) * (size_t)nt);
+                }
                 dev_free(A->d_ct_order);
                 A->d_ct_order = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)std::max<int64_t>(nt, 1));
                 h2d(A->d_ct_order, h_order.data(), sizeof(int32_t) * (size_t)nt);
@@ -660,10 +678,10 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
                 A->d_ct_col = (int32_t *)dev_alloc(sizeof(int32_t) * ents);
                 const size_t ct_vb = use_dict_all ? 1 : A->type->size;  // (dictionary-coded matrices: one byte per value)
                 A->d_ct_val = A->iso ? nullptr : dev_alloc(ct_vb * ents);
-                A->d_ct_loc = (uint16_t *)dev_alloc(sizeof(uint16_t) * ents);
-                GRB_HIP(hipMemsetAsync(A->d_ct_col, 0xff, sizeof(int32_t) * ents, ctx().stream));
+                A->d_ct_loc = ct_mode ? nullptr : (uint16_t *)dev_alloc(sizeof(uint16_t) * ents);
+                GRB_HIP(hipMemsetAsync(A->d_ct_col, 0xff, sizeof(int32_t) * ents, ctx().stream));  // (padding: column -1 / the packed word 0xffffffff)
                 if (A->d_ct_val) GRB_HIP(hipMemsetAsync(A->d_ct_val, 0, ct_vb * ents, ctx().stream));
-                GRB_HIP(hipMemsetAsync(A->d_ct_loc, 0, sizeof(uint16_t) * ents, ctx().stream));
+                if (A->d_ct_loc) GRB_HIP(hipMemsetAsync(A->d_ct_loc, 0, sizeof(uint16_t) * ents, ctx().stream));
                 const int64_t n_cold = nnz_long - n_strip;
                 {
                     // inside a tile the entries go by column code: neighbouring lanes gather from the same lines (grb_mxv_ctile.inc)
@@ -679,16 +697,18 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
                                            (const uint32_t *)idx2.p, n_strip, n_cold, (const uint64_t *)key2s.p, (const uint32_t *)pays.p, (const int64_t *)efirst.p,
                                            (const CTile *)A->d_ct_tiles, (const T *)A->d_val, A->iso ? 1 : 0, A->d_ct_col, (T *)A->d_ct_val, A->d_ct_loc,
                                            use_dict_all ? (const unsigned long long *)A->d_vd_table : (const unsigned long long *)nullptr,
-                                           use_dict_all ? (const unsigned char *)A->d_vd_codes : (const unsigned char *)nullptr);
+                                           use_dict_all ? (const unsigned char *)A->d_vd_codes : (const unsigned char *)nullptr,
+                                           ct_mode ? (const int32_t *)((const char *)A->d_ct_tiles + sizeof(CTile) * (size_t)std::max<int64_t>(nt, 1)) : (const int32_t *)nullptr);
                     })
                     sync_stream();
                 }
+                A->ct_mode = ct_mode;
                 A->ct_nsb = n_sb;
                 A->ct_ncr = n_cr;
                 A->ct_ntiles = nt;
                 A->ct_units = units;
                 if (getenv("GRB_PRINT_STRIPS")) {
-                    fprintf(stderr, "[cold tiles] %d column ranges, %lld tiles, entries per range:", n_cr, (long long)nt);
+                    fprintf(stderr, "[cold tiles] mode %d (slots %d), %d column ranges, %lld tiles, entries per range:", ct_mode, ct_slots, n_cr, (long long)nt);
                     for (int r = 0; r < n_cr; r++) fprintf(stderr, " %lld(x%d)", (long long)range_cnt[(size_t)r], range_xcd[(size_t)r]);
                     fprintf(stderr, "\n");
                 }
@@ -793,7 +813,7 @@ static uint64_t order_signature()
     const Context &c = ctx();
     uint64_t h = 1469598103934665603ull;
     const int64_t v[] = {c.long_kernel, c.short_kernel, c.long_classes, c.split_min_len, c.long_sub, c.long_sub_min_len, c.lean_min_nnz,
-                         c.split_min_nnz, c.hot_k, c.drop_hot_cols, c.hub_min_len, c.value_dict, c.rows_tile, c.rtile_rows, c.rtile_entries, c.cold_in_rows, c.rtile_pack, c.strip_slot16};
+                         c.split_min_nnz, c.hot_k, c.drop_hot_cols, c.hub_min_len, c.value_dict, c.rows_tile, c.rtile_rows, c.rtile_entries, c.cold_in_rows, c.rtile_pack, c.strip_slot16, c.ctile_pack};
     for (int64_t x : v) h = (h ^ (uint64_t)x) * 1099511628211ull;
     return h;
 }
@@ -957,9 +977,13 @@ static void ensure_ordered(GB_Matrix_opaque *S)
             d2h(h_blk.data(), blk.p, sizeof(int64_t) * (size_t)nblk);
             int64_t total = 0;
             for (int64_t b = 0; b < nblk; b++) total += h_blk[(size_t)b];
-            const int R_TARGET = getenv("GRB_ORD_RANGES") ? std::max(1, std::min(48, atoi(getenv("GRB_ORD_RANGES")))) : 32, R_MAX = 48;
+            // (packed cold tiles need EVERY range below 2^19 codes: no last range that takes whatever is left)
+            const int R_TARGET = getenv("GRB_ORD_RANGES") ? std::max(1, std::min(48, atoi(getenv("GRB_ORD_RANGES")))) : 32, R_MAX = ctx().ctile_pack ? 128 : 48;
             const int64_t cap_bytes = getenv("GRB_ORD_RANGE_KB") ? (int64_t)atoi(getenv("GRB_ORD_RANGE_KB")) << 10 : (int64_t)2 << 20;
-            const int64_t cap_codes = std::max<int64_t>(g, cap_bytes / (int64_t)std::max<size_t>(vb, 1)), target = std::max<int64_t>(1, total / R_TARGET);
+            int64_t cap_codes = std::max<int64_t>(g, cap_bytes / (int64_t)std::max<size_t>(vb, 1));
+            // (round 6, packed cold tiles: a column's offset in its range takes 19 bits and the all-ones word is the padding -- ranges stay below 2^19 codes)
+            if (ctx().ctile_pack) cap_codes = std::min<int64_t>(cap_codes, ((int64_t)1 << 19) - g);
+            const int64_t target = std::max<int64_t>(1, total / R_TARGET);
             std::vector<int32_t> bounds;
             bounds.push_back((int32_t)lim);
             int64_t acc = 0, width = 0;
@@ -1245,6 +1269,9 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
                     a.ct_val = A->d_ct_val;
                     a.ct_loc = A->d_ct_loc;
                     a.ct_tiles = (const CTile *)A->d_ct_tiles;
+                    a.ct_mode = A->ct_mode;
+                    a.ct_cbase = A->ct_mode ? (const int32_t *)((const char *)A->d_ct_tiles + sizeof(CTile) * (size_t)std::max<int64_t>(A->ct_ntiles, 1)) : nullptr;
+                    if (A->ct_mode == 2) a.vdict = A->d_vdict;  // (the cold tiles' values are dictionary codes)
                     a.ct_order = A->d_ct_order;
                     for (int x = 0; x <= 8; x++) a.ct_xoff[x] = A->ct_xoff[x];
                     const int64_t Gt = std::max<int64_t>(8, (int64_t)(ctx().num_cus * CT_WGS_PER_CU / 8) * 8);
@@ -2391,7 +2418,7 @@ extern "C" GrB_Info GrX_Matrix_cache_bytes(const GrB_Matrix A, uint64_t *bytes)
         if (A->split_kind == 4 && (A->strip_nseg > 0 || A->ct_units > 0)) {
             const uint64_t hot_lanes = (uint64_t)A->strip_cb[A->strip_ncls + A->hub_ncls] * 64;
             const uint64_t cold = (uint64_t)A->ct_units * CT_EPL;
-            b += hot_lanes * (uint64_t)A->hrec_bytes + (A->d_sslot16 ? hot_lanes * 2 + hot_lanes / 16 : hot_lanes * 4) + hot_lanes / 8 + cold * (6 + (A->d_ct_val ? vs : 0)) + 20ull * (uint64_t)A->ct_ntiles;
+            b += hot_lanes * (uint64_t)A->hrec_bytes + (A->d_sslot16 ? hot_lanes * 2 + hot_lanes / 16 : hot_lanes * 4) + hot_lanes / 8 + cold * ((A->d_ct_loc ? 6 : 4) + (A->d_ct_val ? (A->ct_mode == 2 ? 1 : vs) : 0)) + 20ull * (uint64_t)A->ct_ntiles;
         } else if (A->split_kind == 2 && A->strip_nseg > 0) {
             const uint64_t padded = (uint64_t)A->strip_cb[A->strip_ncls] * STRIP_CH;
             b += padded * 4 + (A->d_lval ? padded * vs : 0) + padded / 2 + padded / STRIP_CH * 8;

@@ -20,7 +20,7 @@ ORDER_OPTS = ((b"order_min_nnz", 1), (b"lean_min_nnz", 1), (b"split_min_nnz", 1)
               (b"lazy_layout", 0), (b"vec_pad_min_bytes", 0), (b"rows_head_min_groups", 1))
 RESTORE = ((b"order_min_nnz", 24 << 20), (b"lean_min_nnz", 48 << 20), (b"split_min_nnz", 1 << 22), (b"split_min_len", 0), (b"push_mode", 1),
            (b"hot_min_cols", 1 << 20), (b"hot_k", 0), (b"lazy_layout", 1), (b"vec_pad_min_bytes", 1 << 20), (b"long_classes", 16), (b"order_mode", 1), (b"hub_min_len", 1024), (b"rows_head_min_groups", 16384), (b"rows_head", 1),
-           (b"rows_tile", 1), (b"rtile_rows", 8192), (b"rtile_entries", 49152), (b"bool_probe", 8), (b"stream_nt_min_nnz", 48 << 20), (b"cold_in_rows", 0), (b"rtile_pack", 1), (b"strip_slot16", 1))
+           (b"rows_tile", 1), (b"rtile_rows", 8192), (b"rtile_entries", 49152), (b"bool_probe", 8), (b"stream_nt_min_nnz", 48 << 20), (b"cold_in_rows", 0), (b"rtile_pack", 1), (b"strip_slot16", 1), (b"ctile_pack", 0))
 
 
 @pytest.fixture(params=DEVICES)
@@ -74,7 +74,8 @@ def test_ordered_product_matches_the_oracle(gb, seed):
         set_opts(ORDER_OPTS + ((b"hot_k", [64, 256, 1 << 20][seed % 3]), (b"long_classes", [16, 8, 32][seed % 3]), (b"hub_min_len", [100, 0, 300, 1024][seed % 4]),
                              (b"rows_head", 0 if seed == 13 else 1),  # (BOOL: the short rows with the LDS head of the hottest columns -- seeds 6, 20 -- and without)
                              (b"cold_in_rows", [0, 1024][(seed // 3) % 2]),  # (round 6: the cold entries of the long rows below the hub level with the short rows)
-                             (b"strip_slot16", [1, 0][(seed // 2) % 2])))  # (the strips' lane slots as 16-bit offsets from the chunk's base / as 32-bit numbers)
+                             (b"strip_slot16", [1, 0][(seed // 2) % 2]),  # (the strips' lane slots as 16-bit offsets from the chunk's base / as 32-bit numbers)
+                             (b"ctile_pack", [1, 2, 0][seed % 3])))  # (cold tiles: slot and column in one word / + one-byte value codes / three streams)
         A = gb.Matrix.from_coo(rows, cols, vals, dtype=tname, nrows=n, ncols=n)
         u = gb.Vector.from_coo(ui, uv, dtype=tname, size=n)
         w = gb.Vector.from_coo(wi, wv, dtype=tname, size=n)
@@ -539,7 +540,8 @@ def test_sorted_row_tiles_match_the_oracle(gb, seed):
                                # (round 6: the cold entries of the long rows below the hub level with the short rows -- 1024: all of them, 40: of the
                                #  rows below 40 entries, 0: none, i.e. the cold tiles of rounds 3-5)
                                (b"cold_in_rows", [1024, 0, 40][(seed // 2) % 3]),
-                               (b"rtile_pack", [1, 0][(seed // 3) % 2])))  # (column and value code of a dictionary-coded entry in one word / in two streams)
+                               (b"rtile_pack", [1, 0][(seed // 3) % 2]),  # (column and value code of a dictionary-coded entry in one word / in two streams)
+                               (b"ctile_pack", [2, 1, 0][(seed // 2) % 3])))
         cold_in_rows = [1024, 0, 40][(seed // 2) % 3]
         A = gb.Matrix.from_coo(rows, cols, vals, dtype=tname, nrows=n, ncols=n)
         u = gb.Vector.from_coo(ui, uv, dtype=tname, size=n)
