@@ -348,6 +348,8 @@ GrB_Info GrX_Matrix_cache_bytes(const GrB_Matrix A, uint64_t *bytes);
  *                   by column code) and run by k_mxv_rtile / k_mxv_rtile_bool where the call allows it: a compiled semiring over a full
  *                   operand (or lor.land / any.pair over presence / value pairs); 0: the tagged row groups everywhere; 2: the tiles on the
  *                   natural-order layouts of hot-coded matrices too (measured slower there)
+ *   "lazy_tagged"   (round 6) 1 (default): a matrix whose short rows have sorted row tiles lays the entries of its tagged row groups out only when a call
+ *                   arrives that the tiles do not take (another semiring, a sparse operand that cannot be filled) -- from the tiles; 0: at layout build
  *   "ctile_pack"    (round 6) 0 (default; 0 .. 2; measured: no gain): 1: the cold tiles of an ordered matrix keep an entry's column (as an offset in its
  *                   column range, every range below 2^19 codes) and its row slot in one 32-bit word -- tiles of 8192 rows, 8 instead of 10 bytes per
  *                   entry; 2: and one-byte dictionary codes for the values (5 bytes per entry); 0: three streams

@@ -280,7 +280,7 @@ extern "C" GrB_Info GrB_init(GrB_Mode mode)
         {"GRB_LONG_SUB", "long_sub"}, {"GRB_LONG_SUB_MIN_LEN", "long_sub_min_len"}, {"GRB_LEAN_MIN_NNZ", "lean_min_nnz"},
         {"GRB_MXM_MASK_MODE", "mxm_mask_mode"}, {"GRB_MAT_WRITE_KERNEL", "mat_write_kernel"}, {"GRB_MXM_SYM_WINDOWS", "mxm_sym_windows"}, {"GRB_MXM_WINDOW_GROUPS", "mxm_window_groups"}, {"GRB_MXM_CHECKSUM_PASS", "mxm_checksum_pass"}, {"GRB_MXM_XCD_MAP", "mxm_xcd_map"},
         {"GRB_ORDER_MODE", "order_mode"}, {"GRB_ORDER_MIN_NNZ", "order_min_nnz"}, {"GRB_VALUE_DICT", "value_dict"}, {"GRB_HUB_MIN_LEN", "hub_min_len"}, {"GRB_FILL_ABSENT", "fill_absent"},
-        {"GRB_PUSH_SMALL", "push_small"}, {"GRB_ROWS_HEAD", "rows_head"}, {"GRB_ROWS_TILE", "rows_tile"}, {"GRB_COLD_IN_ROWS", "cold_in_rows"}, {"GRB_RTILE_PACK", "rtile_pack"}, {"GRB_STRIP_SLOT16", "strip_slot16"}, {"GRB_CTILE_PACK", "ctile_pack"}, {"GRB_BOOL_PROBE", "bool_probe"}, {"GRB_STREAM_NT_MIN_NNZ", "stream_nt_min_nnz"}, {"GRB_RTILE_ROWS", "rtile_rows"}, {"GRB_RTILE_ENTRIES", "rtile_entries"}, {"GRB_ROWS_HEAD_MIN_GROUPS", "rows_head_min_groups"},
+        {"GRB_PUSH_SMALL", "push_small"}, {"GRB_ROWS_HEAD", "rows_head"}, {"GRB_ROWS_TILE", "rows_tile"}, {"GRB_COLD_IN_ROWS", "cold_in_rows"}, {"GRB_RTILE_PACK", "rtile_pack"}, {"GRB_STRIP_SLOT16", "strip_slot16"}, {"GRB_CTILE_PACK", "ctile_pack"}, {"GRB_LAZY_TAGGED", "lazy_tagged"}, {"GRB_BOOL_PROBE", "bool_probe"}, {"GRB_STREAM_NT_MIN_NNZ", "stream_nt_min_nnz"}, {"GRB_RTILE_ROWS", "rtile_rows"}, {"GRB_RTILE_ENTRIES", "rtile_entries"}, {"GRB_ROWS_HEAD_MIN_GROUPS", "rows_head_min_groups"},
     };
     c.initialized = true;  // (alloc_cache = 0 releases the block cache: only once the context is complete)
     for (const auto &k : knobs)
@@ -475,6 +475,10 @@ extern "C" GrB_Info GrX_option_set(const char *name, int64_t value)
     else if (n == "rows_tile") {
         if (value != 0 && value != 1 && value != 2) return GrB_INVALID_VALUE;
         c.rows_tile = (int)value;
+    }
+    else if (n == "lazy_tagged") {
+        if (value != 0 && value != 1) return GrB_INVALID_VALUE;
+        c.lazy_tagged = (int)value;
     }
     else if (n == "ctile_pack") {
         if (value < 0 || value > 2) return GrB_INVALID_VALUE;

@@ -139,6 +139,9 @@ struct Context {
     void *host_pinned = nullptr;     // 4 KiB of page-locked host memory: small device-to-host reads land here (no staging copy in the runtime)
     unsigned long long *push_counters = nullptr;  // the thin push path's counters (grb_mxv_push.inc): two sets of four words, used in turn --
     int push_parity = 0;                          // a call's frontier kernel zeroes the set of the next call
+    int lazy_tagged = 1;             // (round 6) 1: a matrix whose short rows have sorted row tiles builds the tagged row groups' ENTRIES (the layout of the calls the
+                                     // tiles do not take) only when such a call arrives -- from the tiles; their offsets and "row has an entry" words are always built.
+                                     // Scale 24: 0.32 GB less cached layouts and 2.3 ms less layout build when every call takes the tiles
     int ctile_pack = 0;              // (round 6, MEASURED AND OFF) cold tiles of an ordered matrix with every column range below 2^19 codes: 1 = an entry's column (offset in
                                      // its range) and row slot in ONE word (slot << 19 | column; tiles of 8192 slots, up to 128 ranges): 8 instead of 10 bytes per
                                      // entry; 2 = ... and one-byte dictionary codes for its value (5 bytes).  Headline 0.461-0.471 ms with three streams, 0.471-0.479
@@ -372,7 +375,7 @@ struct GB_Matrix_opaque {
     unsigned char *d_tg_tag = nullptr;
     uint64_t *d_tg_nonempty = nullptr; // per group: bit l = short row 64 g + l has an entry
     int64_t tg_units = 0;
-    int tg_state = 0;
+    int tg_state = 0;  // 0 nothing, 2 offsets + non-empty words (ensure_tagged_index), 1 + the entries (ensure_tagged)
     bool short_tagged_only = false;    // the short part keeps its row pointers only: its entries live in the tagged row groups
     // ... and, round 5, an ordered twin's short rows a second time as SORTED ROW TILES (k_mxv_rtile, grb_mxv_rtile.inc): tiles of up to
     // rt_rows4 rows (8-byte accumulators: half) and ~rtile_entries entries, the entries of a tile sorted by column code in lane-transposed

@@ -206,6 +206,7 @@ static void ensure_vdict(GB_Matrix_opaque *A, bool wanted)
 
 // Analyse (once) whether the rows split usefully into long and short ones and build the two parts.
 // `col_src` is the column array the kernels will index (hot-coded or original).
+static void ensure_tagged_index(GB_Matrix_opaque *A);
 static void ensure_tagged(GB_Matrix_opaque *A);
 static void ensure_rtile(GB_Matrix_opaque *A);
 // the short-row kernel of a matrix: option 6 (default) = tagged row groups for large matrices, the row-group kernel below
@@ -779,13 +780,15 @@ static void ensure_split(GB_Matrix_opaque *A, const int32_t *col_src, bool hot)
     if (want_tagged_only && S->nrows == A->nrows && S->nvals < 0x1ffffffffll) {
         // the tagged row groups are the only form of the short rows' entries the kernels read: the CSR copy they were built from is
         // released (0.42 GB of the cached layouts at scale 24); the row pointers stay (row lengths, accounting)
-        ensure_tagged(A);
+        // (round 6, lazy_tagged: with row tiles the groups' ENTRIES wait for the first call that needs them -- ensure_tagged then builds them from the tiles)
+        ensure_tagged_index(A);
         // (an ordered twin: its short rows as sorted row tiles too, from the same CSR copy.  rows_tile = 2 builds them for the natural-order
         //  layouts of a hot-coded matrix as well -- row blocks of a sharded run, order_mode 0; the kernels take them there too, tested, but
         //  MEASURED SLOWER than the tagged row groups: blocks 0/2, 0/4 of the scale-24 graph 0.335 -> 0.352, 0.197 -> 0.214 ms, the
         //  Kronecker-26 block 0.636 -> 0.652 (profiles/r05/final_run_summary_tiles_on_natural_layouts.txt) -- behind a 2 MiB hot table the
         //  codes of the other columns are original labels: sorting by them gathers nothing together)
         if (ctx().rows_tile && (A->hot_identity || (hot && ctx().rows_tile == 2))) ensure_rtile(A);
+        if (A->rt_state != 1 || !ctx().lazy_tagged) ensure_tagged(A);
         dev_free(S->d_col);
         S->d_col = nullptr;
         if (!S->iso) {
@@ -813,7 +816,7 @@ static uint64_t order_signature()
     const Context &c = ctx();
     uint64_t h = 1469598103934665603ull;
     const int64_t v[] = {c.long_kernel, c.short_kernel, c.long_classes, c.split_min_len, c.long_sub, c.long_sub_min_len, c.lean_min_nnz,
-                         c.split_min_nnz, c.hot_k, c.drop_hot_cols, c.hub_min_len, c.value_dict, c.rows_tile, c.rtile_rows, c.rtile_entries, c.cold_in_rows, c.rtile_pack, c.strip_slot16, c.ctile_pack};
+                         c.split_min_nnz, c.hot_k, c.drop_hot_cols, c.hub_min_len, c.value_dict, c.rows_tile, c.rtile_rows, c.rtile_entries, c.cold_in_rows, c.rtile_pack, c.strip_slot16, c.ctile_pack, c.lazy_tagged};
     for (int64_t x : v) h = (h ^ (uint64_t)x) * 1099511628211ull;
     return h;
 }
@@ -1033,10 +1036,10 @@ static void ensure_ordered(GB_Matrix_opaque *S)
 }
 
 // tagged row groups of the short part S of A (once per matrix; see grb_mxv_rows_tag.inc)
-static void ensure_tagged(GB_Matrix_opaque *A)
+// offsets of the row groups (units of TAG_EPL entries) and their "row has an entry" words: from the short part's row pointers alone
+static void ensure_tagged_index(GB_Matrix_opaque *A)
 {
-    if (A->tg_state == 1) return;
-    if (!A->short_part->d_col && A->short_part->nvals > 0) fail(GrB_PANIC, "tagged row groups: the short part's CSR arrays were released (internal error)");
+    if (A->tg_state != 0) return;
     GB_Matrix_opaque *S = A->short_part;
     const int64_t m = (int64_t)S->nrows, ngroups = ceil_div(m, 64);
     const int64_t *sptr = matrix_rowptr(S);
@@ -1051,6 +1054,22 @@ static void ensure_tagged(GB_Matrix_opaque *A)
     A->d_tg_off = (int32_t *)dev_alloc(sizeof(int32_t) * (size_t)(ngroups + 1));
     hipLaunchKernelGGL(k_tag_off32, dim3((unsigned)ceil_div(ngroups + 1, 256)), dim3(256), 0, ctx().stream, (const int64_t *)cnt.p, ngroups + 1,
                        A->d_tg_off);
+    sync_stream();  // (cnt is released at the end of this scope)
+    A->tg_units = units;
+    A->tg_state = 2;
+}
+// ... and their entries: from the short part's CSR arrays (layout build), or -- those are gone and the short rows have sorted row tiles: round 6,
+// Context::lazy_tagged -- from the tiles, at the first call the tiles do not take
+static void ensure_tagged(GB_Matrix_opaque *A)
+{
+    if (A->tg_state == 1) return;
+    ensure_tagged_index(A);
+    GB_Matrix_opaque *S = A->short_part;
+    const bool from_csr = S->d_col != nullptr || S->nvals == 0;
+    if (!from_csr && A->rt_state != 1) fail(GrB_PANIC, "tagged row groups: the short part's CSR arrays were released and it has no row tiles (internal error)");
+    const int64_t m = (int64_t)S->nrows, ngroups = ceil_div(m, 64);
+    const int64_t *sptr = matrix_rowptr(S);
+    const int64_t units = A->tg_units;
     const size_t ents = (size_t)std::max<int64_t>(units, 1) * TAG_EPL;
     A->d_tg_col = (int32_t *)dev_alloc(sizeof(int32_t) * ents);
     const bool dict = A->vdict_n > 0;  // (dictionary-coded matrices: one byte per value)
@@ -1060,14 +1079,28 @@ static void ensure_tagged(GB_Matrix_opaque *A)
     GRB_HIP(hipMemsetAsync(A->d_tg_col, 0xff, sizeof(int32_t) * ents, ctx().stream));
     if (A->d_tg_val) GRB_HIP(hipMemsetAsync(A->d_tg_val, 0, tg_vb * ents, ctx().stream));
     GRB_HIP(hipMemsetAsync(A->d_tg_tag, 0x40, ents, ctx().stream));
-    GRB_DISPATCH_TYPE(S->type->code, T, {
-        hipLaunchKernelGGL((k_tag_fill<T>), dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, ctx().stream, sptr, (const int32_t *)S->d_col,
-                           (const T *)S->d_val, S->iso ? 1 : 0, m, (const int64_t *)cnt.p, A->d_tg_col, (T *)A->d_tg_val, A->d_tg_tag,
-                           dict ? (const unsigned long long *)A->d_vd_table : (const unsigned long long *)nullptr,
-                           dict ? (const unsigned char *)A->d_vd_codes : (const unsigned char *)nullptr);
-    })
-    sync_stream();  // (cnt is released at the end of this scope)
-    A->tg_units = units;
+    if (from_csr) {
+        GRB_DISPATCH_TYPE(S->type->code, T, {
+            hipLaunchKernelGGL((k_tag_fill<T>), dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, ctx().stream, sptr, (const int32_t *)S->d_col,
+                               (const T *)S->d_val, S->iso ? 1 : 0, m, (const int32_t *)A->d_tg_off, A->d_tg_col, (T *)A->d_tg_val, A->d_tg_tag,
+                               dict ? (const unsigned long long *)A->d_vd_table : (const unsigned long long *)nullptr,
+                               dict ? (const unsigned char *)A->d_vd_codes : (const unsigned char *)nullptr);
+        })
+    } else {
+        // (the tiles hold every entry of the short part: column code, row inside the tile, value or value code)
+        const bool is_bool = S->type->code == TC_BOOL;
+        const int rows4 = A->rt_rows4 == 16384 ? 16384 : 8192;
+        const int rows_cap = (S->type->size > 4 && !is_bool) ? rows4 / 2 : rows4;
+        const int vmode = S->iso ? 0 : (dict ? (A->d_rt_val ? 1 : -1) : (int)S->type->size);
+        DevBuf<int32_t> gcnt(ngroups + 1, true);
+        GRB_DISPATCH_TYPE(S->type->code, T, {
+            hipLaunchKernelGGL((k_tag_from_tiles<T>), dim3((unsigned)A->rt_ntiles), dim3(1024), 0, ctx().stream, (const RTile *)A->d_rt_tiles, (const int32_t *)A->d_rt_col,
+                               (const uint16_t *)A->d_rt_tag, (const void *)A->d_rt_val, vmode, rows_cap, (const int32_t *)A->d_tg_off, gcnt.p, A->d_tg_col, A->d_tg_val,
+                               A->d_tg_tag);
+        })
+        sync_stream();  // (gcnt is released at the end of this scope)
+    }
+    sync_stream();
     A->tg_state = 1;
 }
 
@@ -1089,7 +1122,7 @@ static void ensure_rtile(GB_Matrix_opaque *A)
     const size_t vs = S->type->size;
     // (4- and 8-byte types with their values; BOOL matrices when they are iso -- the adjacency matrices of the BFS step: k_mxv_rtile_bool)
     const bool is_bool = S->type->code == TC_BOOL;
-    if (!S->d_col || S->nvals == 0 || S->nvals >= 0xf0000000ll || A->tg_state != 1) return;
+    if (!S->d_col || S->nvals == 0 || S->nvals >= 0xf0000000ll || A->tg_state == 0) return;
     if (is_bool ? !S->iso : (S->iso || (vs != 4 && vs != 8))) return;
     const int64_t m = (int64_t)S->nrows;
     const int64_t live_rows = A->hot_identity ? std::min<int64_t>(m, std::max<int64_t>(A->ord_live_rows, 1)) : m;
@@ -1396,13 +1429,11 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
         const int sk = short_kernel_for(A);
         if ((sk == 5 || A->short_tagged_only) && S->nrows == A->nrows && S->nvals < 0x1ffffffffll) {
             // short rows as tagged row groups: the row of every entry is stored with it (no marks, no scan, no segmented fold)
-            ensure_tagged(A);
+            // (round 6: the groups' offsets and non-empty words now, their entries only if the call ends up with k_mxv_rows_tag -- lazy_tagged)
+            ensure_tagged_index(A);
             b.long_prefix = A->d_long_prefix;
             b.tg_off = A->d_tg_off;
-            b.tg_col = A->d_tg_col;
-            b.tg_val = A->d_tg_val;
             b.vdict = A->vdict_n > 0 ? A->d_vdict : nullptr;
-            b.tg_tag = A->d_tg_tag;
             b.tg_nonempty = A->d_tg_nonempty;
             int64_t groups = ceil_div(b.m, 64);
             b.tg_groups = 0;
@@ -1492,6 +1523,11 @@ static void launch_pull_ipt(GB_Matrix_opaque *A, PullArgs &a)
                     return;
                 }
             }
+            // (neither kind of row tiles took the call: the tagged row groups -- their entries laid out now if they were not yet)
+            ensure_tagged(A);
+            b.tg_col = A->d_tg_col;
+            b.tg_val = A->d_tg_val;
+            b.tg_tag = A->d_tg_tag;
             bool head = false;
             if constexpr (MON >= 0 && std::is_same<T, bool>::value) {
                 head = ctx().rows_head && A->hot_identity && b.tg_stride > 0 && b.u_pv != nullptr && groups >= ctx().rows_head_min_groups;
@@ -2415,6 +2451,7 @@ extern "C" GrB_Info GrX_Matrix_cache_bytes(const GrB_Matrix A, uint64_t *bytes)
         if (A->d_probe) b += 4ull * (uint64_t)A->probe_k * (uint64_t)A->n_long;
         if (A->rt_state == 1) b += (uint64_t)A->rt_units * RT_EPL * (6 + (A->d_rt_val ? (A->vdict_n > 0 && vs == 4 ? 1 : vs) : 0)) + 36ull * (uint64_t)A->rt_ntiles;
         if (A->tg_state == 1) b += (uint64_t)A->tg_units * TAG_EPL * (5 + (A->d_tg_val ? (A->vdict_n > 0 ? 1 : vs) : 0)) + 12ull * ((A->nrows + 63) / 64);
+        else if (A->tg_state == 2) b += 12ull * ((A->nrows + 63) / 64);  // (offsets and non-empty words only: the entries are built when a call needs them)
         if (A->split_kind == 4 && (A->strip_nseg > 0 || A->ct_units > 0)) {
             const uint64_t hot_lanes = (uint64_t)A->strip_cb[A->strip_ncls + A->hub_ncls] * 64;
             const uint64_t cold = (uint64_t)A->ct_units * CT_EPL;

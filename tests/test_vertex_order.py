@@ -20,7 +20,7 @@ ORDER_OPTS = ((b"order_min_nnz", 1), (b"lean_min_nnz", 1), (b"split_min_nnz", 1)
               (b"lazy_layout", 0), (b"vec_pad_min_bytes", 0), (b"rows_head_min_groups", 1))
 RESTORE = ((b"order_min_nnz", 24 << 20), (b"lean_min_nnz", 48 << 20), (b"split_min_nnz", 1 << 22), (b"split_min_len", 0), (b"push_mode", 1),
            (b"hot_min_cols", 1 << 20), (b"hot_k", 0), (b"lazy_layout", 1), (b"vec_pad_min_bytes", 1 << 20), (b"long_classes", 16), (b"order_mode", 1), (b"hub_min_len", 1024), (b"rows_head_min_groups", 16384), (b"rows_head", 1),
-           (b"rows_tile", 1), (b"rtile_rows", 8192), (b"rtile_entries", 49152), (b"bool_probe", 8), (b"stream_nt_min_nnz", 48 << 20), (b"cold_in_rows", 0), (b"rtile_pack", 1), (b"strip_slot16", 1), (b"ctile_pack", 0))
+           (b"rows_tile", 1), (b"rtile_rows", 8192), (b"rtile_entries", 49152), (b"bool_probe", 8), (b"stream_nt_min_nnz", 48 << 20), (b"cold_in_rows", 0), (b"rtile_pack", 1), (b"strip_slot16", 1), (b"ctile_pack", 0), (b"lazy_tagged", 1))
 
 
 @pytest.fixture(params=DEVICES)
@@ -541,7 +541,9 @@ def test_sorted_row_tiles_match_the_oracle(gb, seed):
                                #  rows below 40 entries, 0: none, i.e. the cold tiles of rounds 3-5)
                                (b"cold_in_rows", [1024, 0, 40][(seed // 2) % 3]),
                                (b"rtile_pack", [1, 0][(seed // 3) % 2]),  # (column and value code of a dictionary-coded entry in one word / in two streams)
-                               (b"ctile_pack", [2, 1, 0][(seed // 2) % 3])))
+                               (b"ctile_pack", [2, 1, 0][(seed // 2) % 3]),
+                               # (the tagged row groups' entries at layout build / from the tiles at the first call the tiles do not take)
+                               (b"lazy_tagged", [1, 1, 0][seed % 3])))
         cold_in_rows = [1024, 0, 40][(seed // 2) % 3]
         A = gb.Matrix.from_coo(rows, cols, vals, dtype=tname, nrows=n, ncols=n)
         u = gb.Vector.from_coo(ui, uv, dtype=tname, size=n)
@@ -559,6 +561,13 @@ def test_sorted_row_tiles_match_the_oracle(gb, seed):
         #  whose cold entries it folded itself: split_min_len 8 < cold_in_rows)
         assert st["long_tails"] == (1 if (not natural and cold_in_rows > 8) else 0), st
         same_vec(w, exp)
+        # a call the tiles do NOT take on the same matrix (a semiring without a compiled tile kernel): the tagged row groups, whose entries are
+        # laid out from the tiles now when lazy_tagged is on -- against the oracle
+        if tname in ("FP32", "FP64", "INT64", "INT32"):
+            w9 = gb.Vector.from_coo(wi, wv, dtype=tname, size=n)
+            (w9(~m_arg if comp else m_arg, **kw) if use_mask else w9(**kw)) << A.mxv(u, gb.semiring.max_second)
+            assert device.last_stats()["fused_epilogue"] == 1, device.last_stats()
+            same_vec(w9, O.mxv(oa, ou, "max_second", w=ow, mask=om if use_mask else None, mask_comp=comp and use_mask, mask_struct=struct, accum=accum, replace=repl))
         # once more on the converted operands (nothing is reordered any more), and without the tiles: the same result
         w2 = gb.Vector.from_coo(wi, wv, dtype=tname, size=n)
         (w2(~m_arg if comp else m_arg, **kw) if use_mask else w2(**kw)) << A.mxv(u, getattr(gb.semiring, sr))
