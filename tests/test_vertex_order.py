@@ -797,3 +797,34 @@ def test_shard_setup_orders_a_row_block_by_global_column_counts(gb, seed):
         same_vec(w, expected[0])
     finally:
         set_opts(RESTORE)
+
+
+def test_shard_setup_argument_errors(gb):
+    """GrX_Matrix_shard_setup rejects what it cannot use and leaves the matrix as it was: no counts and no `like`, counts of the wrong length
+    (host layer), a `like` that carries no column order or another width; a matrix that was set up and is then modified forgets the order."""
+    import ctypes
+
+    from graphblas_amd import _lib, device, exceptions
+
+    rng = np.random.default_rng(77)
+    n = 2000
+    rows, cols, vals = skewed_square(rng, n, "FP32")
+    A = gb.Matrix.from_coo(rows, cols, vals, dtype="FP32", nrows=n, ncols=n)
+    B = gb.Matrix.from_coo(rows, cols, vals, dtype="FP32", nrows=n, ncols=n)
+    C = gb.Matrix.from_coo([0, 1], [1, 0], [1.0, 2.0], dtype="FP32", nrows=100, ncols=100)
+    assert _lib.lib.GrX_Matrix_shard_setup(A._carg, None, 0, None) != 0  # (GrB_NULL_POINTER: neither counts nor `like`)
+    with pytest.raises(ValueError, match="one count per column"):
+        device.matrix_shard_setup(A, np.ones(n - 1, np.uint32))
+    with pytest.raises(exceptions.InvalidValue):  # (B was never set up: it carries no column order)
+        device.matrix_shard_setup(A, like=B)
+    device.matrix_shard_setup(B, np.bincount(cols, minlength=n).astype(np.uint32))
+    with pytest.raises(exceptions.InvalidValue):  # (another width)
+        device.matrix_shard_setup(C, like=B)
+    device.matrix_shard_setup(A, like=B)  # (and this one is fine)
+    ui, uv = rand_vec(rng, n, 1.0, "FP32")
+    u = gb.Vector.from_coo(ui, uv, dtype="FP32", size=n)
+    exp = O.mxv(O.OMat.from_coo(rows, cols, vals, n, n, "FP32"), O.OVec(n, ui, uv, "FP32"), "min_plus")
+    same_vec(A.mxv(u, gb.semiring.min_plus).new(), exp)
+    A.resize(n, n)  # (a modification drops A's cached layouts and its share of the order; B keeps its own)
+    same_vec(A.mxv(u, gb.semiring.min_plus).new(), exp)
+    same_vec(B.mxv(u, gb.semiring.min_plus).new(), exp)
